@@ -1,0 +1,79 @@
+"""Build recipes: the gfx950 shared library (product) and the CPU oracle (test infrastructure).
+
+`hipcc --offload-arch=gfx950` cross-compiles without a GPU; outputs stay in-tree so they
+travel to the GPU box with the repo snapshot (they are git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bundlefusion_amd", "csrc")
+LIB_DIR = os.path.join(ROOT, "bundlefusion_amd", "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libbf_hip.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off",          # op-by-op IEEE arithmetic, bit-comparable with the oracle
+    "-fvisibility=hidden", "-Wno-unused-value", "-Wno-unused-result",
+]
+
+
+def _sources(d, exts):
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build_lib(force=False, verbose=False):
+    """Compile every HIP/C++ source under csrc/ into bundlefusion_amd/lib/libbf_hip.so."""
+    srcs = _sources(CSRC, (".hip", ".cpp"))
+    deps = srcs + _sources(CSRC, (".h",)) + _sources(os.path.join(ROOT, "include"), (".h",))
+    if not force and not _stale(LIB_PATH, deps):
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    objdir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + [d for d in deps if d.endswith(".h")]):
+            cmd = [hipcc] + [f for f in HIP_FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    return LIB_PATH
+
+
+def build_oracle(force=False):
+    """Compile the CPU oracle (oracle/*.cpp) into oracle/_build/liboracle.so via its Makefile."""
+    args = ["make", "-s", "-C", ORACLE_DIR]
+    if force:
+        args.append("-B")
+    r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout.decode())
+    return ORACLE_LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="-f" in sys.argv, verbose=True))
+    print(build_oracle(force="-f" in sys.argv))

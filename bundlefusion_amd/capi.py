@@ -1,0 +1,246 @@
+"""ctypes bindings of include/bf_hip.h (the C ABI of libbf_hip.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbf_hip.so")
+
+
+class BFError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "bundlefusion_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(there is no CPU fallback)" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+SDF_BLOCK_SIZE = 8
+HASH_BUCKET_SIZE = 4
+FREE_ENTRY = -2
+VOX_PER_BLOCK = 512
+
+
+class HashParams(C.Structure):
+    _fields_ = [
+        ("m_rigidTransform", C.c_float * 16),
+        ("m_rigidTransformInverse", C.c_float * 16),
+        ("m_hashNumBuckets", C.c_uint32),
+        ("m_hashBucketSize", C.c_uint32),
+        ("m_hashMaxCollisionLinkedListSize", C.c_uint32),
+        ("m_numSDFBlocks", C.c_uint32),
+        ("m_SDFBlockSize", C.c_int32),
+        ("m_virtualVoxelSize", C.c_float),
+        ("m_numOccupiedBlocks", C.c_uint32),
+        ("m_maxIntegrationDistance", C.c_float),
+        ("m_truncScale", C.c_float),
+        ("m_truncation", C.c_float),
+        ("m_integrationWeightSample", C.c_uint32),
+        ("m_integrationWeightMax", C.c_uint32),
+        ("m_streamingVoxelExtents", C.c_float * 3),
+        ("m_streamingGridDimensions", C.c_int32 * 3),
+        ("m_streamingMinGridPos", C.c_int32 * 3),
+        ("m_streamingInitialChunkListSize", C.c_uint32),
+        ("m_dummy", C.c_uint32 * 2),
+    ]
+
+
+class DepthCameraParams(C.Structure):
+    _fields_ = [
+        ("fx", C.c_float), ("fy", C.c_float), ("mx", C.c_float), ("my", C.c_float),
+        ("m_imageWidth", C.c_uint32), ("m_imageHeight", C.c_uint32),
+        ("m_sensorDepthWorldMin", C.c_float), ("m_sensorDepthWorldMax", C.c_float),
+    ]
+
+
+class DepthCameraData(C.Structure):
+    _fields_ = [("d_depthData", C.c_void_p), ("d_colorData", C.c_void_p)]
+
+
+class HashData(C.Structure):
+    _fields_ = [
+        ("d_heap", C.c_void_p), ("d_heapCounter", C.c_void_p), ("d_hashDecision", C.c_void_p),
+        ("d_hashDecisionPrefix", C.c_void_p), ("d_hash", C.c_void_p), ("d_hashCompactified", C.c_void_p),
+        ("d_hashCompactifiedCounter", C.c_void_p), ("d_SDFBlocks", C.c_void_p), ("d_hashBucketMutex", C.c_void_p),
+    ]
+
+
+HASH_ENTRY_DTYPE = np.dtype([("pos", "<i4", 3), ("ptr", "<i4"), ("offset", "<u4"), ("_pad", "<u4", 3)])
+VOXEL_DTYPE = np.dtype([("sdf", "<f4"), ("weight", "<f4"), ("color", "u1", 4)])
+assert HASH_ENTRY_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 12
+
+lib.bf_last_error.restype = C.c_char_p
+lib.bf_version.restype = C.c_char_p
+
+
+def check(rc):
+    if rc != 0:
+        raise BFError("libbf_hip status %d: %s" % (rc, lib.bf_last_error().decode()))
+
+
+def mat16(m):
+    a = np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(16))
+    return (C.c_float * 16)(*a.tolist())
+
+
+def default_hash_params(num_buckets=800000, num_sdf_blocks=200000, voxel_size=0.010, max_integration_distance=3.0,
+                        truncation=0.06, trunc_scale=0.02, weight_sample=1, weight_max=99999999, max_chain=7):
+    """CUDASceneRepHashSDF::parametersFromGlobalAppState with zParametersDefault.txt values."""
+    p = HashParams()
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    p.m_rigidTransform[:] = eye.tolist()
+    p.m_rigidTransformInverse[:] = eye.tolist()
+    p.m_hashNumBuckets = num_buckets
+    p.m_hashBucketSize = HASH_BUCKET_SIZE
+    p.m_hashMaxCollisionLinkedListSize = max_chain
+    p.m_numSDFBlocks = num_sdf_blocks
+    p.m_SDFBlockSize = SDF_BLOCK_SIZE
+    p.m_virtualVoxelSize = voxel_size
+    p.m_numOccupiedBlocks = 0
+    p.m_maxIntegrationDistance = max_integration_distance
+    p.m_truncScale = trunc_scale
+    p.m_truncation = truncation
+    p.m_integrationWeightSample = weight_sample
+    p.m_integrationWeightMax = weight_max
+    p.m_streamingVoxelExtents[:] = [1.0, 1.0, 1.0]
+    p.m_streamingGridDimensions[:] = [257, 257, 257]
+    p.m_streamingMinGridPos[:] = [-128, -128, -128]
+    p.m_streamingInitialChunkListSize = 2000
+    return p
+
+
+def camera_params(width, height, fx, fy, mx, my, dmin=0.1, dmax=4.0):
+    c = DepthCameraParams()
+    c.fx, c.fy, c.mx, c.my = fx, fy, mx, my
+    c.m_imageWidth, c.m_imageHeight = width, height
+    c.m_sensorDepthWorldMin, c.m_sensorDepthWorldMax = dmin, dmax
+    return c
+
+
+class SceneRepHashSDF:
+    """Python view of `bf_scene` (== the reference's CUDASceneRepHashSDF)."""
+
+    def __init__(self, params, stream=None):
+        self._h = C.c_void_p()
+        self.params = params
+        check(lib.bf_scene_create(C.byref(params), C.byref(self._h)))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self._h:
+            lib.bf_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        check(lib.bf_scene_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def reset(self):
+        check(lib.bf_scene_reset(self._h))
+
+    @staticmethod
+    def _data(depth, color):
+        d = DepthCameraData()
+        d.d_depthData = depth.data_ptr()
+        d.d_colorData = color.data_ptr() if color is not None else None
+        return d
+
+    def integrate(self, cam_to_world, depth, color, cam):
+        d = self._data(depth, color)
+        check(lib.bf_scene_integrate(self._h, mat16(cam_to_world), C.byref(d), C.byref(cam), None))
+
+    def deintegrate(self, cam_to_world, depth, color, cam):
+        d = self._data(depth, color)
+        check(lib.bf_scene_deintegrate(self._h, mat16(cam_to_world), C.byref(d), C.byref(cam), None))
+
+    def garbage_collect(self):
+        check(lib.bf_scene_garbage_collect(self._h))
+
+    def compactify(self, cam_to_world, cam):
+        check(lib.bf_scene_set_last_rigid_transform_and_compactify(self._h, mat16(cam_to_world), C.byref(cam)))
+
+    def hash_data(self):
+        hd = HashData()
+        check(lib.bf_scene_get_hash_data(self._h, C.byref(hd)))
+        return hd
+
+    def hash_params(self):
+        p = HashParams()
+        check(lib.bf_scene_get_hash_params(self._h, C.byref(p)))
+        return p
+
+    def heap_free_count(self):
+        v = C.c_uint32()
+        check(lib.bf_scene_get_heap_free_count(self._h, C.byref(v)))
+        return v.value
+
+    def num_allocated_blocks(self):
+        v = C.c_uint32()
+        check(lib.bf_scene_get_num_allocated_blocks(self._h, C.byref(v)))
+        return v.value
+
+    def num_integrated_frames(self):
+        v = C.c_uint32()
+        check(lib.bf_scene_get_num_integrated_frames(self._h, C.byref(v)))
+        return v.value
+
+    def debug_hash(self):
+        out = (C.c_uint32 * 6)()
+        check(lib.bf_scene_debug_hash(self._h, out))
+        return dict(occupied=out[0], heap_free=out[1], duplicate_keys=out[2], free_and_allocated=out[3], leaked=out[4],
+                    dropped=out[5])
+
+    def kernel_timing(self, enable):
+        check(lib.bf_scene_kernel_timing(self._h, int(enable)))
+
+    def kernel_timing_read(self):
+        n, ms = C.c_uint32(), C.c_float()
+        check(lib.bf_scene_kernel_timing_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # ---- test helpers: copy raw arrays back (hipMemcpy through torch) ----
+    def download(self):
+        """Returns (hash[numBuckets*4], heap[numSDFBlocks], heapCounter, voxels[numSDFBlocks*512]) as numpy."""
+        import torch
+        torch.cuda.synchronize()
+        hd = self.hash_data()
+        nE = self.params.m_hashNumBuckets * HASH_BUCKET_SIZE
+        nB = self.params.m_numSDFBlocks
+        hash_np = _d2h(hd.d_hash, nE * 32).view(HASH_ENTRY_DTYPE)
+        heap_np = _d2h(hd.d_heap, nB * 4).view("<u4")
+        heap_counter = int(_d2h(hd.d_heapCounter, 4).view("<u4")[0])
+        vox_np = _d2h(hd.d_SDFBlocks, nB * VOX_PER_BLOCK * 12).view(VOXEL_DTYPE)
+        return hash_np, heap_np, heap_counter, vox_np
+
+    def download_compactified(self):
+        import torch
+        torch.cuda.synchronize()
+        hd = self.hash_data()
+        n = int(_d2h(hd.d_hashCompactifiedCounter, 4).view("<i4")[0])
+        return _d2h(hd.d_hashCompactified, n * 32).view(HASH_ENTRY_DTYPE)
+
+
+_hip = None
+
+
+def _d2h(ptr, nbytes):
+    """hipMemcpy D2H of a raw device pointer into a fresh numpy byte array."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+    out = np.empty(nbytes, dtype=np.uint8)
+    if nbytes:
+        rc = _hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(2))
+        if rc != 0:
+            raise BFError("hipMemcpy D2H failed: %d" % rc)
+    return out

@@ -1,0 +1,1069 @@
+// Voxel-hashed TSDF for gfx950: reset / alloc / compactify / integrate / de-integrate / GC.
+// Replaces DepthSensing/CUDASceneRepHashSDF.{h,cu} + VoxelUtilHashSDF.h of the reference
+// (paths relative to /root/reference/FriedLiver/Source) behind the bf_scene_* C ABI.
+//
+// Design:
+//  * memory layout of d_hash / d_SDFBlocks / d_heap / d_hashCompactified is the reference's
+//    (32-B HashEntry stride, 12-B AoS voxels, ptr = block*512) so downstream consumers of
+//    HashDataStruct (ray cast, marching cubes) keep working;
+//  * allocation is lock-free and run-to-run deterministic: one pass over the depth pixels
+//    collects the missing block keys into a 64-bit CAS de-dup set and scatters them into 256
+//    bins by home-bucket range; each bin is sorted in LDS by (home bucket, key) and inserted
+//    with rank-based slot / heap assignment; bucket-full keys are chained by one serial tail
+//    kernel.  No bucket mutex, no host fixed-point loop, no D2H read-back;
+//  * the frustum list is built from an incremental list of allocated blocks (16 B each)
+//    instead of scanning all numBuckets*4 hash slots; its length never leaves the device —
+//    the voxel-update kernel is a persistent grid-stride loop over a device-side count.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "bf_device.h"
+#include "bf_internal.h"
+
+using namespace bf;
+
+namespace {
+
+constexpr int BS = BF_SDF_BLOCK_SIZE;
+constexpr int VOX = BS * BS * BS;
+constexpr uint32_t NBINS = 256;        // one LDS sort workgroup per bin (~1 per CU)
+constexpr uint32_t BINCAP = 4096;      // records per bin (64 KB of LDS when sorting)
+constexpr uint32_t OVCAP = 4096;       // bucket-full keys per alloc handled by the tail
+constexpr uint32_t TILE = 1024;        // entries per ordered-compaction tile
+constexpr uint64_t EMPTY64 = ~0ull;
+constexpr int KEYLIM = 1 << 20;
+
+struct AllocRec { uint64_t key; int32_t ptr; uint32_t pad; };          // 16 B
+struct BinRec { uint64_t key; uint32_t bucket; uint32_t aux; };        // 16 B
+
+enum Stat { ST_DROPPED = 0, ST_ERROR = 1, ST_COUNT = 4 };
+enum ErrBits { ERR_BIN_OVERFLOW = 1, ERR_DEDUPE_FULL = 2, ERR_OV_OVERFLOW = 4, ERR_GC_MISSING = 8 };
+
+struct Dev {
+    bf_hash_entry* hash;
+    uint32_t* heap;
+    uint32_t* heapCounter;
+    bf_voxel* vox;
+    bf_hash_entry* compact;
+    uint32_t* compactSrc;
+    int32_t* compactCount;
+    AllocRec* allocList;
+    AllocRec* allocListAlt;
+    uint32_t* allocCount;
+    uint64_t* dedupe;
+    uint32_t dedupeMask;
+    BinRec* bins;
+    uint32_t* binCount;
+    BinRec* overflow;
+    uint32_t* overflowCount;
+    uint32_t* tileCounts;
+    uint32_t* stats;
+};
+
+struct Frame {          // per-call constants (kernarg => scalar loads)
+    m44 T, Tinv;
+    bf_depth_camera_params cam;
+    uint32_t numBuckets;
+    uint32_t maxChain;
+    uint32_t numSDFBlocks;
+    float voxelSize;
+    float maxIntegrationDistance;
+    float truncScale;
+    float truncation;
+    float weightMax;
+};
+
+// ---------------------------------------------------------------------------------------
+// integer maps (bit-exact parity targets)
+// ---------------------------------------------------------------------------------------
+// VoxelUtilHashSDF.h:226-234; m_hashNumBuckets is unsigned so `%` is an unsigned modulo.
+BF_HD uint32_t hashPos(uint32_t numBuckets, i3 v) {
+    uint32_t h = ((uint32_t)v.x * 73856093u) ^ ((uint32_t)v.y * 19349669u) ^ ((uint32_t)v.z * 83492791u);
+    return h % numBuckets;
+}
+BF_HD bool keyable(i3 b) {
+    return b.x >= -KEYLIM && b.x < KEYLIM && b.y >= -KEYLIM && b.y < KEYLIM && b.z >= -KEYLIM && b.z < KEYLIM;
+}
+BF_HD uint64_t packKey(i3 b) {
+    return ((uint64_t)(uint32_t)(b.z + KEYLIM) << 42) | ((uint64_t)(uint32_t)(b.y + KEYLIM) << 21) |
+           (uint64_t)(uint32_t)(b.x + KEYLIM);
+}
+BF_HD i3 unpackKey(uint64_t k) {
+    i3 r;
+    r.x = (int)(k & 0x1FFFFF) - KEYLIM;
+    r.y = (int)((k >> 21) & 0x1FFFFF) - KEYLIM;
+    r.z = (int)((k >> 42) & 0x1FFFFF) - KEYLIM;
+    return r;
+}
+BF_HD i3 worldToVirtualVoxelPos(float voxelSize, f3 pos) {     // :283-287
+    f3 p = pos / voxelSize;
+    i3 r;
+    r.x = f2i(p.x + (float)sgn(p.x) * 0.5f);
+    r.y = f2i(p.y + (float)sgn(p.y) * 0.5f);
+    r.z = f2i(p.z + (float)sgn(p.z) * 0.5f);
+    return r;
+}
+BF_HD i3 virtualVoxelPosToSDFBlock(i3 v) {                     // :290-299
+    if (v.x < 0) v.x -= BS - 1;
+    if (v.y < 0) v.y -= BS - 1;
+    if (v.z < 0) v.z -= BS - 1;
+    i3 r; r.x = v.x / BS; r.y = v.y / BS; r.z = v.z / BS;
+    return r;
+}
+BF_HD f3 SDFBlockToWorld(float voxelSize, i3 b) {
+    return mk3((float)(b.x * BS), (float)(b.y * BS), (float)(b.z * BS)) * voxelSize;
+}
+BF_HD bool blockInFrustum(const Frame& f, i3 b) {              // :322-326, DepthCameraUtil.h:97-142
+    f3 w = SDFBlockToWorld(f.voxelSize, b);
+    const float off = f.voxelSize * 0.5f * ((float)BS - 1.0f);
+    w = w + mk3(off, off, off);
+    f3 pc = xform(f.Tinv, w);
+    const float sx = pc.x * f.cam.fx / pc.z + f.cam.mx;
+    const float sy = pc.y * f.cam.fy / pc.z + f.cam.my;
+    const float wm1 = (float)f.cam.m_imageWidth - 1.0f, hm1 = (float)f.cam.m_imageHeight - 1.0f;
+    float px = (2.0f * sx - wm1) / wm1;
+    float py = (hm1 - 2.0f * sy) / hm1;
+    float pz = (pc.z - f.cam.m_sensorDepthWorldMin) / (f.cam.m_sensorDepthWorldMax - f.cam.m_sensorDepthWorldMin);
+    px *= 0.95f; py *= 0.95f; pz *= 0.95f;
+    return !(px < -1.0f || px > 1.0f || py < -1.0f || py > 1.0f || pz < 0.0f || pz > 1.0f);
+}
+
+// read-only lookup, VoxelUtilHashSDF.h:441-485
+BF_DEV bool blockPresent(const Dev& d, const Frame& f, i3 b, uint32_t h) {
+    const uint32_t hp = h * BF_HASH_BUCKET_SIZE;
+    const int4* e4 = reinterpret_cast<const int4*>(d.hash);
+    uint32_t lastOffset = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) {
+        const int4 a = e4[(size_t)(hp + j) * 2];                 // pos.xyz, ptr
+        if (a.x == b.x && a.y == b.y && a.z == b.z && a.w != BF_FREE_ENTRY) return true;
+        if (j == BF_HASH_BUCKET_SIZE - 1) lastOffset = d.hash[hp + j].offset;
+    }
+    if (lastOffset == 0) return false;
+    const uint32_t last = hp + BF_HASH_BUCKET_SIZE - 1;
+    const uint32_t total = BF_HASH_BUCKET_SIZE * f.numBuckets;
+    uint32_t i = (last + lastOffset) % total;
+    for (uint32_t it = 1; it < f.maxChain; ++it) {
+        const int4 a = e4[(size_t)i * 2];
+        if (a.x == b.x && a.y == b.y && a.z == b.z && a.w != BF_FREE_ENTRY) return true;
+        const uint32_t off = d.hash[i].offset;
+        if (off == 0) break;
+        i = (last + off) % total;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// reset
+// ---------------------------------------------------------------------------------------
+__global__ void k_reset(Dev d, uint32_t numSDFBlocks, uint32_t numEntries, uint32_t dedupeSize) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t i = gid; i < numSDFBlocks; i += stride) d.heap[i] = numSDFBlocks - i - 1;   // .cu:38
+    uint4* h4 = reinterpret_cast<uint4*>(d.hash);
+    for (uint32_t i = gid; i < numEntries; i += stride) {                                       // .cu:47-55
+        h4[(size_t)i * 2] = make_uint4(0, 0, 0, (uint32_t)BF_FREE_ENTRY);
+        h4[(size_t)i * 2 + 1] = make_uint4(0, 0, 0, 0);
+    }
+    for (uint32_t i = gid; i < dedupeSize; i += stride) d.dedupe[i] = EMPTY64;
+    if (gid < NBINS) d.binCount[gid] = 0;
+    if (gid < ST_COUNT) d.stats[gid] = 0;
+    if (gid == 0) {
+        d.heapCounter[0] = numSDFBlocks - 1;                                                   // .cu:33
+        d.compactCount[0] = 0;
+        d.allocCount[0] = 0;
+        d.overflowCount[0] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// alloc, pass A: depth pixels -> missing block keys -> de-dup set -> bins
+//   (CUDASceneRepHashSDF.cu:165-251 DDA;  one wave = one 8x8 pixel tile)
+// ---------------------------------------------------------------------------------------
+BF_DEV void emitCandidate(const Dev& d, const Frame& f, i3 b) {
+    if (!keyable(b)) return;
+    const uint32_t h = hashPos(f.numBuckets, b);
+    if (blockPresent(d, f, b, h)) return;
+    const uint64_t key = packKey(b);
+    // 64-bit CAS claim in the open-addressing de-dup set (linear probing)
+    uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & d.dedupeMask;
+    for (uint32_t probe = 0; probe <= d.dedupeMask; ++probe) {
+        const unsigned long long old =
+            atomicCAS(reinterpret_cast<unsigned long long*>(&d.dedupe[slot]), (unsigned long long)EMPTY64, (unsigned long long)key);
+        if (old == key) return;                 // somebody already queued this block
+        if (old == EMPTY64) {
+            const uint32_t bin = (uint32_t)(((uint64_t)h * NBINS) / f.numBuckets);
+            const uint32_t pos = atomicAdd(&d.binCount[bin], 1u);
+            if (pos < BINCAP) {
+                BinRec r; r.key = key; r.bucket = h; r.aux = slot;
+                d.bins[(size_t)bin * BINCAP + pos] = r;
+            } else {
+                atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW);
+                d.dedupe[slot] = EMPTY64;
+            }
+            return;
+        }
+        slot = (slot + 1) & d.dedupeMask;
+    }
+    atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
+}
+
+__global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth) {
+    const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
+    const uint32_t tilesX = (W + 7) / 8;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t x = (tile % tilesX) * 8 + (lane & 7);
+    const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
+    if (x >= W || y >= H) return;
+    const float dd = depth[(size_t)y * W + x];
+    if (dd == BF_MINF || dd == 0.0f) return;
+    if (dd >= f.maxIntegrationDistance) return;
+    const float t = f.truncation + f.truncScale * dd;
+    const float minDepth = fminf(f.maxIntegrationDistance, dd - t);
+    const float maxDepth = fminf(f.maxIntegrationDistance, dd + t);
+    if (minDepth >= maxDepth) return;
+    const float kx = ((float)x - f.cam.mx) / f.cam.fx;
+    const float ky = ((float)y - f.cam.my) / f.cam.fy;
+    const f3 rayMin = xform(f.T, mk3(minDepth * kx, minDepth * ky, minDepth));
+    const f3 rayMax = xform(f.T, mk3(maxDepth * kx, maxDepth * ky, maxDepth));
+    const f3 dv = rayMax - rayMin;
+    const float invLen = 1.0f / sqrtf(dot3(dv, dv));
+    const f3 rayDir = dv * invLen;
+    i3 cur = virtualVoxelPosToSDFBlock(worldToVirtualVoxelPos(f.voxelSize, rayMin));
+    const i3 end = virtualVoxelPosToSDFBlock(worldToVirtualVoxelPos(f.voxelSize, rayMax));
+    const f3 step = mk3((float)sgn(rayDir.x), (float)sgn(rayDir.y), (float)sgn(rayDir.z));
+    i3 nb;
+    nb.x = cur.x + f2i(fminf(fmaxf(step.x, 0.0f), 1.0f));
+    nb.y = cur.y + f2i(fminf(fmaxf(step.y, 0.0f), 1.0f));
+    nb.z = cur.z + f2i(fminf(fmaxf(step.z, 0.0f), 1.0f));
+    const float hv = 0.5f * f.voxelSize;
+    const f3 boundary = SDFBlockToWorld(f.voxelSize, nb) - mk3(hv, hv, hv);
+    f3 tMax = mk3((boundary.x - rayMin.x) / rayDir.x, (boundary.y - rayMin.y) / rayDir.y, (boundary.z - rayMin.z) / rayDir.z);
+    f3 tDelta = mk3((step.x * (float)BS * f.voxelSize) / rayDir.x, (step.y * (float)BS * f.voxelSize) / rayDir.y,
+                    (step.z * (float)BS * f.voxelSize) / rayDir.z);
+    i3 bound;
+    bound.x = f2i((float)end.x + step.x);
+    bound.y = f2i((float)end.y + step.y);
+    bound.z = f2i((float)end.z + step.z);
+    if (rayDir.x == 0.0f) { tMax.x = BF_PINF; tDelta.x = BF_PINF; }
+    if (boundary.x - rayMin.x == 0.0f) { tMax.x = BF_PINF; tDelta.x = BF_PINF; }
+    if (rayDir.y == 0.0f) { tMax.y = BF_PINF; tDelta.y = BF_PINF; }
+    if (boundary.y - rayMin.y == 0.0f) { tMax.y = BF_PINF; tDelta.y = BF_PINF; }
+    if (rayDir.z == 0.0f) { tMax.z = BF_PINF; tDelta.z = BF_PINF; }
+    if (boundary.z - rayMin.z == 0.0f) { tMax.z = BF_PINF; tDelta.z = BF_PINF; }
+    for (unsigned iter = 0; iter < 1024; ++iter) {
+        if (blockInFrustum(f, cur)) emitCandidate(d, f, cur);
+        if (tMax.x < tMax.y && tMax.x < tMax.z) {
+            cur.x = f2i((float)cur.x + step.x);
+            if (cur.x == bound.x) return;
+            tMax.x += tDelta.x;
+        } else if (tMax.z < tMax.y) {
+            cur.z = f2i((float)cur.z + step.z);
+            if (cur.z == bound.z) return;
+            tMax.z += tDelta.z;
+        } else {
+            cur.y = f2i((float)cur.y + step.y);
+            if (cur.y == bound.y) return;
+            tMax.y += tDelta.y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS bitonic sort of (bucket, key, aux) records, ascending by (bucket, key)
+// ---------------------------------------------------------------------------------------
+struct SortLds {
+    uint64_t key[BINCAP];
+    uint32_t bucket[BINCAP];
+    uint32_t aux[BINCAP];
+};
+
+BF_DEV uint32_t nextPow2(uint32_t v) {
+    uint32_t p = 64;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+BF_DEV void ldsBitonicSort(SortLds& s, uint32_t npad) {
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t hi = lo | j;
+                const bool up = ((lo & k) == 0);
+                const uint32_t bl = s.bucket[lo], bh = s.bucket[hi];
+                const uint64_t kl = s.key[lo], kh = s.key[hi];
+                const bool gt = (bl != bh) ? (bl > bh) : (kl > kh);
+                if (gt == up) {
+                    s.bucket[lo] = bh; s.bucket[hi] = bl;
+                    s.key[lo] = kh; s.key[hi] = kl;
+                    const uint32_t a = s.aux[lo]; s.aux[lo] = s.aux[hi]; s.aux[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+BF_DEV uint32_t loadBinSorted(SortLds& s, const BinRec* recs, uint32_t n) {
+    const uint32_t npad = nextPow2(n);
+    for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x) {
+        if (i < n) { const BinRec r = recs[i]; s.key[i] = r.key; s.bucket[i] = r.bucket; s.aux[i] = r.aux; }
+        else { s.key[i] = EMPTY64; s.bucket[i] = 0xFFFFFFFFu; s.aux[i] = 0; }
+    }
+    __syncthreads();
+    ldsBitonicSort(s, npad);
+    return npad;
+}
+
+// sum over bins b < limit of min(binCount[b], BINCAP); result broadcast to the block
+BF_DEV uint32_t binPrefix(const uint32_t* binCount, uint32_t limit, uint32_t* scratch) {
+    uint32_t v = 0;
+    for (uint32_t b = threadIdx.x; b < limit; b += blockDim.x) v += min(binCount[b], BINCAP);
+    v = (uint32_t)wave_sum_i((int)v);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) total += scratch[w];
+    __syncthreads();
+    return total;
+}
+
+// ---------------------------------------------------------------------------------------
+// alloc, pass B: one workgroup per bin — sort, rank, place into home buckets
+//   (serial-equivalent of allocBlock's in-bucket branch, VoxelUtilHashSDF.h:553-612)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_alloc_insert(Dev d, Frame f) {
+    __shared__ SortLds s;
+    __shared__ uint32_t scratch[16];
+    __shared__ int8_t sel[BINCAP];
+    const uint32_t bin = blockIdx.x;
+    const uint32_t n = min(d.binCount[bin], BINCAP);
+    if (n == 0) return;
+    loadBinSorted(s, d.bins + (size_t)bin * BINCAP, n);
+    const uint32_t base = binPrefix(d.binCount, bin, scratch);
+    const uint32_t heapC = d.heapCounter[0];
+    const uint32_t heapFree = heapC + 1u;
+    const uint32_t allocBase = d.allocCount[0];
+    uint4* h4 = reinterpret_cast<uint4*>(d.hash);
+    // phase 1 (reads only): rank among the bin's new keys of the same home bucket -> free slot
+    for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const uint32_t h = s.bucket[idx];
+        uint32_t rank = 0;
+        while (rank < BF_HASH_BUCKET_SIZE && idx > rank && s.bucket[idx - rank - 1] == h) ++rank;
+        int slot = -1;
+        if (rank < BF_HASH_BUCKET_SIZE) {
+            uint32_t seen = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) {
+                const int32_t p = d.hash[h * BF_HASH_BUCKET_SIZE + j].ptr;
+                if (p == BF_FREE_ENTRY) { if (seen == rank && slot < 0) slot = (int)j; ++seen; }
+            }
+        }
+        sel[idx] = (int8_t)slot;
+    }
+    __syncthreads();
+    // phase 2 (writes): disjoint slots, rank-ordered heap consumption
+    for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const uint32_t gi = base + idx;
+        const uint64_t key = s.key[idx];
+        const uint32_t h = s.bucket[idx];
+        d.dedupe[s.aux[idx]] = EMPTY64;
+        if (gi >= heapFree) { atomicAdd(&d.stats[ST_DROPPED], 1u); continue; }     // heap exhausted
+        const int32_t ptr = (int32_t)(d.heap[heapC - gi] * (uint32_t)VOX);          // consumeHeap :536-540
+        AllocRec ar; ar.key = key; ar.ptr = ptr; ar.pad = 0;
+        d.allocList[allocBase + gi] = ar;
+        const int slot = sel[idx];
+        if (slot >= 0) {
+            const i3 b = unpackKey(key);
+            const size_t e = (size_t)h * BF_HASH_BUCKET_SIZE + (uint32_t)slot;
+            h4[e * 2] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)ptr);
+            h4[e * 2 + 1] = make_uint4(0u, 0u, 0u, 0u);                              // NO_OFFSET :608
+        } else {
+            const uint32_t ov = atomicAdd(d.overflowCount, 1u);
+            if (ov < OVCAP) { BinRec r; r.key = key; r.bucket = h; r.aux = gi; d.overflow[ov] = r; }
+            else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// alloc, pass C: single workgroup tail — bucket-full keys walk the collision window in
+// sorted order (VoxelUtilHashSDF.h:614-654), counters are committed, bins are recycled.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
+    __shared__ SortLds s;
+    __shared__ uint32_t scratch[16];
+    const uint32_t M = binPrefix(d.binCount, NBINS, scratch);
+    const uint32_t nov = min(d.overflowCount[0], OVCAP);
+    if (nov > 0) loadBinSorted(s, d.overflow, nov);
+    if (threadIdx.x == 0) {
+        const uint32_t heapC = d.heapCounter[0];
+        const uint32_t heapFree = heapC + 1u;
+        const uint32_t Mp = min(M, heapFree);
+        const uint32_t allocBase = d.allocCount[0];
+        const uint32_t total = BF_HASH_BUCKET_SIZE * f.numBuckets;
+        uint32_t newCounter = heapC - Mp;
+        uint32_t dropped = 0;
+        for (uint32_t k = 0; k < nov; ++k) {
+            const uint32_t h = s.bucket[k];
+            const uint32_t gi = s.aux[k];
+            const uint32_t last = (h + 1) * BF_HASH_BUCKET_SIZE - 1;
+            const int32_t ptr = d.allocList[allocBase + gi].ptr;
+            bool done = false;
+            uint32_t maxIter = 0;
+            int offset = 0;
+            while (maxIter < f.maxChain) {
+                offset++;
+                const uint32_t i = (last + (uint32_t)offset) % total;
+                if ((offset % BF_HASH_BUCKET_SIZE) == 0) continue;      // never a bucket's last slot :624
+                if (d.hash[i].ptr == BF_FREE_ENTRY) {
+                    const i3 b = unpackKey(s.key[k]);
+                    d.hash[i].pos[0] = b.x; d.hash[i].pos[1] = b.y; d.hash[i].pos[2] = b.z;
+                    d.hash[i].offset = d.hash[last].offset;
+                    d.hash[i].ptr = ptr;
+                    d.hash[last].offset = (uint32_t)offset;
+                    done = true;
+                    break;
+                }
+                maxIter++;
+            }
+            if (!done) {                                              // window exhausted: give the block back
+                d.allocList[allocBase + gi].ptr = BF_FREE_ENTRY;
+                newCounter++;
+                d.heap[newCounter] = (uint32_t)ptr / (uint32_t)VOX;  // appendHeap :542-546
+                dropped++;
+            }
+        }
+        d.heapCounter[0] = newCounter;
+        d.allocCount[0] = allocBase + Mp;
+        if (dropped) atomicAdd(&d.stats[ST_DROPPED], dropped);
+        d.overflowCount[0] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < NBINS) d.binCount[threadIdx.x] = 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// ordered stream compaction over the allocated-block list (two passes, deterministic)
+//   MODE 0: frustum list (replaces compactifyHashAllInOneKernel, .cu:324-366)
+//   MODE 1: drop holes from the allocated list (after GC)
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+BF_DEV bool keepRec(const Frame& f, const AllocRec& r) {
+    if (r.ptr == BF_FREE_ENTRY) return false;
+    if (MODE == 1) return true;
+    return blockInFrustum(f, unpackKey(r.key));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t n = d.allocCount[0];
+    const uint32_t numTiles = (n + TILE - 1) / TILE;
+    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
+            if (i < n) c += keepRec<MODE>(f, d.allocList[i]) ? 1u : 0u;
+        }
+        c = (uint32_t)wave_sum_i((int)c);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) d.tileCounts[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wscan[4];
+    const uint32_t n = d.allocCount[0];
+    const uint32_t numTiles = (n + TILE - 1) / TILE;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (numTiles == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { if (MODE == 0) d.compactCount[0] = 0; }
+        return;
+    }
+    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        // exclusive prefix of the preceding tiles
+        uint32_t v = 0;
+        for (uint32_t t = threadIdx.x; t < tile; t += blockDim.x) v += d.tileCounts[t];
+        v = (uint32_t)wave_sum_i((int)v);
+        if (lane == 0) wsum[wave] = v;
+        __syncthreads();
+        const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        AllocRec recs[4];
+        bool keep[4];
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
+            keep[k] = false;
+            if (i < n) { recs[k] = d.allocList[i]; keep[k] = keepRec<MODE>(f, recs[k]); }
+            c += keep[k] ? 1u : 0u;
+        }
+        // exclusive scan of c across the block: wave scan + wave totals
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+        if (lane == 63) wscan[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += wscan[w];
+        const uint32_t tileTotal = wscan[0] + wscan[1] + wscan[2] + wscan[3];
+        uint32_t pos = base + woff + incl - c;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (!keep[k]) continue;
+            if (MODE == 0) {
+                const i3 b = unpackKey(recs[k].key);
+                uint4* o4 = reinterpret_cast<uint4*>(d.compact + pos);
+                o4[0] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)recs[k].ptr);
+                o4[1] = make_uint4(0u, 0u, 0u, 0u);
+                d.compactSrc[pos] = tile * TILE + threadIdx.x * 4 + k;
+            } else {
+                d.allocListAlt[pos] = recs[k];
+            }
+            ++pos;
+        }
+        if (tile == numTiles - 1 && threadIdx.x == 0) {
+            if (MODE == 0) d.compactCount[0] = (int32_t)(base + tileTotal);
+            else d.tileCounts[numTiles] = base + tileTotal;      // new list length, committed by k_list_commit
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_list_commit(Dev d) {
+    const uint32_t n = d.allocCount[0];
+    const uint32_t numTiles = (n + TILE - 1) / TILE;
+    if (numTiles > 0) d.allocCount[0] = d.tileCounts[numTiles];
+}
+
+// ---------------------------------------------------------------------------------------
+// voxel update: integrate / de-integrate (CUDASceneRepHashSDF.cu:420-521)
+// one 512-thread workgroup per SDF block, persistent grid-stride over the frustum list
+// ---------------------------------------------------------------------------------------
+template <bool DEINT>
+__global__ __launch_bounds__(512) void k_update(Dev d, Frame f, const float* __restrict__ depth,
+                                                const uchar4* __restrict__ color) {
+    if (color == nullptr) return;   // .cu:441-448: without colour data `color.x != MINF` never holds
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t i = threadIdx.x;
+    const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
+    const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
+    for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
+        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];   // wave-uniform
+        f3 pf = mk3((float)(e.x * BS + lx), (float)(e.y * BS + ly), (float)(e.z * BS + lz)) * f.voxelSize;
+        pf = xform(f.Tinv, pf);
+        const float sx = pf.x * f.cam.fx / pf.z + f.cam.mx;
+        const float sy = pf.y * f.cam.fy / pf.z + f.cam.my;
+        const uint32_t px = (uint32_t)f2i(sx + 0.5f), py = (uint32_t)f2i(sy + 0.5f);
+        if (!(px < W && py < H)) continue;
+        const size_t pix = (size_t)py * W + px;
+        const float dep = depth[pix];
+        if (dep == BF_MINF) continue;
+        if (!(dep < f.maxIntegrationDistance)) continue;
+        float sdf = dep - pf.z;
+        const float trunc = f.truncation + f.truncScale * dep;
+        if (!(fabsf(sdf) < trunc)) continue;
+        if (sdf >= 0.0f) sdf = fminf(trunc, sdf); else sdf = fmaxf(-trunc, sdf);
+        const uchar4 cc = color[pix];
+        const float c0 = (float)cc.x, c1 = (float)cc.y, c2 = (float)cc.z;
+        uint32_t* vp = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + i));
+        const float oSdf = __uint_as_float(vp[0]);
+        const float oW = __uint_as_float(vp[1]);
+        const uint32_t oC = vp[2];
+        const float o0 = (float)(oC & 0xFF), o1 = (float)((oC >> 8) & 0xFF), o2 = (float)((oC >> 16) & 0xFF);
+        float nSdf, nW;
+        uint32_t nC;
+        if (!DEINT) {
+            float r0, r1, r2;
+            if (oW == 0.0f) { r0 = c0; r1 = c1; r2 = c2; }
+            else { r0 = 0.2f * c0 + 0.8f * o0; r1 = 0.2f * c1 + 0.8f * o1; r2 = 0.2f * c2 + 0.8f * o2; }
+            r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
+            r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
+            r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
+            nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
+            nSdf = (sdf * 1.0f + oSdf * oW) / (1.0f + oW);
+            nW = fminf(f.weightMax, 1.0f + oW);
+        } else {
+            float r0 = (o0 * oW - c0 * 1.0f) / (oW - 1.0f);
+            float r1 = (o1 * oW - c1 * 1.0f) / (oW - 1.0f);
+            float r2 = (o2 * oW - c2 * 1.0f) / (oW - 1.0f);
+            r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
+            r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
+            r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
+            nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
+            nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
+            nW = fmaxf(0.0f, oW - 1.0f);
+            if (nW <= 0.001f) { nSdf = 0.0f; nC = 0u; nW = 0.0f; }
+        }
+        vp[0] = __float_as_uint(nSdf);
+        vp[1] = __float_as_uint(nW);
+        vp[2] = nC;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// garbage collection (CUDASceneRepHashSDF.cu:584-668, VoxelUtilHashSDF.h:740-826)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gc_identify(Dev d, Frame f) {
+    __shared__ uint32_t wmax[4];
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
+        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];
+        const bf_voxel* v = d.vox + (size_t)(uint32_t)e.w;
+        const uint32_t w0 = (uint32_t)f2i(v[2 * threadIdx.x + 0].weight);      // uint shared_MaxWeight, .cu:581,606
+        const uint32_t w1 = (uint32_t)f2i(v[2 * threadIdx.x + 1].weight);
+        uint32_t m = wave_max_u(max(w0, w1));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+            if (m == 0) {
+                i3 b; b.x = e.x; b.y = e.y; b.z = e.z;
+                const uint32_t h = hashPos(f.numBuckets, b);
+                const uint32_t bin = (uint32_t)(((uint64_t)h * NBINS) / f.numBuckets);
+                const uint32_t pos = atomicAdd(&d.binCount[bin], 1u);
+                if (pos < BINCAP) {
+                    BinRec r; r.key = packKey(b); r.bucket = h; r.aux = d.compactSrc[blk];
+                    d.bins[(size_t)bin * BINCAP + pos] = r;
+                } else {
+                    atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// serial deleteHashEntryElement; returns the freed ptr or FREE_ENTRY if the key is absent
+BF_DEV int32_t deleteEntry(const Dev& d, const Frame& f, i3 b, uint32_t h) {
+    const uint32_t hp = h * BF_HASH_BUCKET_SIZE;
+    const uint32_t total = BF_HASH_BUCKET_SIZE * f.numBuckets;
+    uint4* h4 = reinterpret_cast<uint4*>(d.hash);
+    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) {
+        const uint32_t i = hp + j;
+        const bf_hash_entry c = d.hash[i];
+        if (c.pos[0] == b.x && c.pos[1] == b.y && c.pos[2] == b.z && c.ptr != BF_FREE_ENTRY) {
+            if (c.offset != 0) {
+                const uint32_t next = (i + c.offset) % total;
+                h4[(size_t)i * 2] = h4[(size_t)next * 2];
+                h4[(size_t)i * 2 + 1] = h4[(size_t)next * 2 + 1];
+                h4[(size_t)next * 2] = make_uint4(0, 0, 0, (uint32_t)BF_FREE_ENTRY);
+                h4[(size_t)next * 2 + 1] = make_uint4(0, 0, 0, 0);
+            } else {
+                h4[(size_t)i * 2] = make_uint4(0, 0, 0, (uint32_t)BF_FREE_ENTRY);
+                h4[(size_t)i * 2 + 1] = make_uint4(0, 0, 0, 0);
+            }
+            return c.ptr;
+        }
+    }
+    const uint32_t last = hp + BF_HASH_BUCKET_SIZE - 1;
+    bf_hash_entry c = d.hash[last];
+    uint32_t prev = last;
+    uint32_t i = (last + c.offset) % total;
+    for (uint32_t it = 0; it < f.maxChain; ++it) {
+        c = d.hash[i];
+        if (c.pos[0] == b.x && c.pos[1] == b.y && c.pos[2] == b.z && c.ptr != BF_FREE_ENTRY) {
+            h4[(size_t)i * 2] = make_uint4(0, 0, 0, (uint32_t)BF_FREE_ENTRY);
+            h4[(size_t)i * 2 + 1] = make_uint4(0, 0, 0, 0);
+            d.hash[prev].offset = c.offset;
+            return c.ptr;
+        }
+        if (c.offset == 0) return BF_FREE_ENTRY;
+        prev = i;
+        i = (last + c.offset) % total;
+    }
+    return BF_FREE_ENTRY;
+}
+
+__global__ __launch_bounds__(1024) void k_gc_delete(Dev d, Frame f) {
+    __shared__ SortLds s;
+    __shared__ uint32_t scratch[16];
+    const uint32_t bin = blockIdx.x;
+    const uint32_t n = min(d.binCount[bin], BINCAP);
+    if (n == 0) return;
+    loadBinSorted(s, d.bins + (size_t)bin * BINCAP, n);
+    const uint32_t base = binPrefix(d.binCount, bin, scratch);
+    const uint32_t heapC = d.heapCounter[0];
+    for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const uint32_t h = s.bucket[idx];
+        if (idx > 0 && s.bucket[idx - 1] == h) continue;            // one thread per home bucket
+        for (uint32_t k = idx; k < n && s.bucket[k] == h; ++k) {
+            const int32_t ptr = deleteEntry(d, f, unpackKey(s.key[k]), h);
+            d.allocList[s.aux[k]].ptr = BF_FREE_ENTRY;
+            if (ptr == BF_FREE_ENTRY) { atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_GC_MISSING); s.aux[k] = 0xFFFFFFFFu; continue; }
+            d.heap[heapC + 1u + base + k] = (uint32_t)ptr / (uint32_t)VOX;   // appendHeap, rank-ordered
+            s.aux[k] = (uint32_t)ptr;
+        }
+    }
+    __syncthreads();
+    // clear the freed voxel blocks (.cu:662-665): 6144 B = 384 x 16 B each
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t ptr = s.aux[k];
+        if (ptr == 0xFFFFFFFFu) continue;
+        uint4* v4 = reinterpret_cast<uint4*>(d.vox + (size_t)ptr);
+        for (uint32_t t = threadIdx.x; t < (uint32_t)(VOX * 12 / 16); t += blockDim.x) v4[t] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gc_finish(Dev d) {
+    __shared__ uint32_t scratch[16];
+    const uint32_t D = binPrefix(d.binCount, NBINS, scratch);
+    if (threadIdx.x == 0) d.heapCounter[0] += D;
+    __syncthreads();
+    if (threadIdx.x < NBINS) d.binCount[threadIdx.x] = 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+// host side: bf_scene == CUDASceneRepHashSDF
+// =========================================================================================
+struct bf_scene {
+    bf_hash_params params;
+    bf_depth_camera_params cam;
+    bool haveCam = false;
+    Dev d{};
+    hipStream_t stream = nullptr;
+    uint32_t numIntegrated = 0;
+    uint32_t dedupeSize = 0;
+    uint32_t gridCompact = 0, gridUpdate = 0;
+    int32_t* d_hashDecision = nullptr;
+    // optional HIP-event timing of the voxel-update kernel
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t eventsUsed = 0;
+    std::vector<void*> allocations;
+};
+
+namespace {
+
+template <class T>
+int devAlloc(bf_scene* s, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) { set_error("hipMalloc(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e)); return BF_ERR_HIP; }
+    s->allocations.push_back(q);
+    *p = (T*)q;
+    return BF_OK;
+}
+
+Frame makeFrame(const bf_scene* s) {
+    Frame f;
+    memcpy(f.T.e, s->params.m_rigidTransform, 64);
+    memcpy(f.Tinv.e, s->params.m_rigidTransformInverse, 64);
+    f.cam = s->cam;
+    f.numBuckets = s->params.m_hashNumBuckets;
+    f.maxChain = s->params.m_hashMaxCollisionLinkedListSize;
+    f.numSDFBlocks = s->params.m_numSDFBlocks;
+    f.voxelSize = s->params.m_virtualVoxelSize;
+    f.maxIntegrationDistance = s->params.m_maxIntegrationDistance;
+    f.truncScale = s->params.m_truncScale;
+    f.truncation = s->params.m_truncation;
+    f.weightMax = (float)s->params.m_integrationWeightMax;
+    return f;
+}
+
+void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepHashSDF.h:128-134
+    m44 m;
+    memcpy(m.e, T, 64);
+    const m44 inv = inverse44(m);
+    memcpy(s->params.m_rigidTransform, m.e, 64);
+    memcpy(s->params.m_rigidTransformInverse, inv.e, 64);
+}
+
+int launchCompactify(bf_scene* s) {                              // compactifyHashEntries :355-391
+    const Frame f = makeFrame(s);
+    hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+int launchAlloc(bf_scene* s, const float* d_depth) {             // alloc :328-352
+    const Frame f = makeFrame(s);
+    const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
+    hipLaunchKernelGGL(k_alloc_candidates, dim3(div_up(tiles, 4)), dim3(256), 0, s->stream, s->d, f, d_depth);
+    hipLaunchKernelGGL(k_alloc_insert, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_alloc_finish, dim3(1), dim3(1024), 0, s->stream, s->d, f);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+template <bool DEINT>
+int launchUpdate(bf_scene* s, const bf_depth_camera_data* data) {
+    const Frame f = makeFrame(s);
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (s->timing) {
+        if (s->eventsUsed == s->events.size()) {
+            hipEvent_t a, b;
+            BF_HIP_TRY(hipEventCreate(&a));
+            BF_HIP_TRY(hipEventCreate(&b));
+            s->events.push_back({a, b});
+        }
+        ev = &s->events[s->eventsUsed++];
+        BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
+    }
+    hipLaunchKernelGGL(k_update<DEINT>, dim3(s->gridUpdate), dim3(512), 0, s->stream, s->d, f, data->d_depthData,
+                       reinterpret_cast<const uchar4*>(data->d_colorData));
+    if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+int checkCall(bf_scene* s, const float* T, const bf_depth_camera_data* data, const bf_depth_camera_params* cam,
+              const uint32_t* d_bitMask) {
+    BF_REQUIRE(s && T && data && cam, "null argument");
+    BF_REQUIRE(data->d_depthData, "d_depthData is null");
+    BF_REQUIRE(d_bitMask == nullptr, "chunk streaming (d_bitMask) is not supported: it is disabled for BundleFusion");
+    BF_REQUIRE(cam->m_imageWidth > 0 && cam->m_imageHeight > 0, "empty image");
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
+    BF_REQUIRE(p && out, "null argument");
+    BF_REQUIRE(p->m_hashNumBuckets > 0 && p->m_numSDFBlocks > 0, "empty hash / heap");
+    BF_REQUIRE(p->m_hashBucketSize == BF_HASH_BUCKET_SIZE, "m_hashBucketSize must be 4 (HASH_BUCKET_SIZE)");
+    BF_REQUIRE(p->m_SDFBlockSize == BF_SDF_BLOCK_SIZE, "m_SDFBlockSize must be 8 (SDF_BLOCK_SIZE)");
+    BF_REQUIRE((uint64_t)p->m_hashNumBuckets * BF_HASH_BUCKET_SIZE < 0x7FFFFFFFull, "hash too large for 32-bit slot indices");
+    BF_REQUIRE((uint64_t)p->m_numSDFBlocks * VOX < 0x7FFFFFFFull, "too many SDF blocks for the reference's int ptr");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible"); return BF_ERR_NO_DEVICE; }
+    bf_scene* s = new bf_scene();
+    s->params = *p;
+    const size_t numEntries = (size_t)p->m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
+    const size_t N = p->m_numSDFBlocks;
+    uint32_t ds = 1u << 16;
+    while (ds < 2u * NBINS * BINCAP && ds < 4u * N) ds <<= 1;
+    s->dedupeSize = ds;
+    int rc = BF_OK;
+#define A(ptr, cnt) if (rc == BF_OK) rc = devAlloc(s, &(ptr), (cnt))
+    A(s->d.hash, numEntries);
+    A(s->d.heap, N);
+    A(s->d.heapCounter, 1);
+    A(s->d.vox, N * VOX);
+    A(s->d.compact, N);
+    A(s->d.compactSrc, N);
+    A(s->d.compactCount, 1);
+    A(s->d.allocList, N);
+    A(s->d.allocListAlt, N);
+    A(s->d.allocCount, 1);
+    A(s->d.dedupe, (size_t)ds);
+    A(s->d.bins, (size_t)NBINS * BINCAP);
+    A(s->d.binCount, NBINS);
+    A(s->d.overflow, OVCAP);
+    A(s->d.overflowCount, 1);
+    A(s->d.tileCounts, N / TILE + 4);
+    A(s->d.stats, ST_COUNT);
+    A(s->d_hashDecision, 4);
+#undef A
+    if (rc != BF_OK) { bf_scene_destroy(s); return rc; }
+    s->d.dedupeMask = ds - 1;
+    s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
+    s->gridUpdate = 256 * 8;     // 256 CUs x 8 resident 512-thread workgroups' worth of queue depth
+    *out = s;
+    return bf_scene_reset(s);
+}
+
+int bf_scene_destroy(bf_scene* s) {
+    if (!s) return BF_OK;
+    hipStreamSynchronize(s->stream);
+    for (void* q : s->allocations) hipFree(q);
+    for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete s;
+    return BF_OK;
+}
+
+int bf_scene_set_stream(bf_scene* s, void* hip_stream) {
+    BF_REQUIRE(s, "null scene");
+    s->stream = (hipStream_t)hip_stream;
+    return BF_OK;
+}
+
+int bf_scene_reset(bf_scene* s) {                                  // CUDASceneRepHashSDF.h:147-155
+    BF_REQUIRE(s, "null scene");
+    s->numIntegrated = 0;
+    const m44 I = identity44();
+    memcpy(s->params.m_rigidTransform, I.e, 64);
+    memcpy(s->params.m_rigidTransformInverse, I.e, 64);
+    s->params.m_numOccupiedBlocks = 0;
+    const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
+    BF_HIP_TRY(hipMemsetAsync(s->d.vox, 0, (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel), s->stream));
+    hipLaunchKernelGGL(k_reset, dim3(2048), dim3(256), 0, s->stream, s->d, s->params.m_numSDFBlocks, (uint32_t)numEntries,
+                       s->dedupeSize);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+int bf_scene_integrate(bf_scene* s, const float T[16], const bf_depth_camera_data* data,
+                       const bf_depth_camera_params* cam, const uint32_t* d_bitMask) {
+    int rc = checkCall(s, T, data, cam, d_bitMask);
+    if (rc) return rc;
+    s->cam = *cam; s->haveCam = true;
+    setLastRigidTransform(s, T);
+    if ((rc = launchAlloc(s, data->d_depthData))) return rc;
+    if ((rc = launchCompactify(s))) return rc;
+    if ((rc = launchUpdate<false>(s, data))) return rc;
+    s->numIntegrated++;
+    return BF_OK;
+}
+
+int bf_scene_deintegrate(bf_scene* s, const float T[16], const bf_depth_camera_data* data,
+                         const bf_depth_camera_params* cam, const uint32_t* d_bitMask) {
+    int rc = checkCall(s, T, data, cam, d_bitMask);
+    if (rc) return rc;
+    s->cam = *cam; s->haveCam = true;
+    setLastRigidTransform(s, T);
+    if ((rc = launchCompactify(s))) return rc;
+    if ((rc = launchUpdate<true>(s, data))) return rc;
+    s->numIntegrated--;
+    return BF_OK;
+}
+
+int bf_scene_set_last_rigid_transform_and_compactify(bf_scene* s, const float T[16], const bf_depth_camera_params* cam) {
+    BF_REQUIRE(s && T && cam, "null argument");
+    s->cam = *cam; s->haveCam = true;
+    setLastRigidTransform(s, T);
+    return launchCompactify(s);
+}
+
+int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
+    BF_REQUIRE(s, "null scene");
+    if (!s->haveCam) return BF_OK;                                  // nothing was ever compactified
+    const Frame f = makeFrame(s);
+    hipLaunchKernelGGL(k_gc_identify, dim3(s->gridUpdate), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_gc_delete, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_gc_finish, dim3(1), dim3(256), 0, s->stream, s->d);
+    hipLaunchKernelGGL(k_compact_count<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_compact_scatter<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_list_commit, dim3(1), dim3(1), 0, s->stream, s->d);
+    std::swap(s->d.allocList, s->d.allocListAlt);
+    BF_HIP_TRY(hipGetLastError());
+    return launchCompactify(s);
+}
+
+int bf_scene_get_hash_data(bf_scene* s, bf_hash_data* out) {
+    BF_REQUIRE(s && out, "null argument");
+    out->d_heap = s->d.heap;
+    out->d_heapCounter = s->d.heapCounter;
+    out->d_hashDecision = s->d_hashDecision;
+    out->d_hashDecisionPrefix = nullptr;
+    out->d_hash = s->d.hash;
+    out->d_hashCompactified = s->d.compact;
+    out->d_hashCompactifiedCounter = s->d.compactCount;
+    out->d_SDFBlocks = s->d.vox;
+    out->d_hashBucketMutex = nullptr;
+    return BF_OK;
+}
+
+int bf_scene_get_hash_params(bf_scene* s, bf_hash_params* out) {
+    BF_REQUIRE(s && out, "null argument");
+    int32_t n = 0;
+    BF_HIP_TRY(hipMemcpyAsync(&n, s->d.compactCount, 4, hipMemcpyDeviceToHost, s->stream));
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    s->params.m_numOccupiedBlocks = (uint32_t)n;
+    *out = s->params;
+    return BF_OK;
+}
+
+int bf_scene_get_heap_free_count(bf_scene* s, uint32_t* out) {       // :168-172
+    BF_REQUIRE(s && out, "null argument");
+    uint32_t c = 0;
+    BF_HIP_TRY(hipMemcpyAsync(&c, s->d.heapCounter, 4, hipMemcpyDeviceToHost, s->stream));
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    *out = c + 1u;
+    return BF_OK;
+}
+
+int bf_scene_get_num_integrated_frames(bf_scene* s, uint32_t* out) {
+    BF_REQUIRE(s && out, "null argument");
+    *out = s->numIntegrated;
+    return BF_OK;
+}
+
+int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out) {
+    BF_REQUIRE(s && out, "null argument");
+    uint32_t n = 0;
+    BF_HIP_TRY(hipMemcpyAsync(&n, s->d.allocCount, 4, hipMemcpyDeviceToHost, s->stream));
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<AllocRec> recs(n);
+    if (n) BF_HIP_TRY(hipMemcpy(recs.data(), s->d.allocList, (size_t)n * sizeof(AllocRec), hipMemcpyDeviceToHost));
+    uint32_t live = 0;
+    for (auto& r : recs) live += (r.ptr != BF_FREE_ENTRY);
+    *out = live;
+    return BF_OK;
+}
+
+int bf_scene_debug_hash(bf_scene* s, uint32_t out[6]) {              // debugHash :179-314
+    BF_REQUIRE(s && out, "null argument");
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
+    const uint32_t N = s->params.m_numSDFBlocks;
+    std::vector<bf_hash_entry> hash(numEntries);
+    std::vector<uint32_t> heap(N);
+    uint32_t heapCounter = 0, stats[ST_COUNT];
+    BF_HIP_TRY(hipMemcpy(hash.data(), s->d.hash, numEntries * sizeof(bf_hash_entry), hipMemcpyDeviceToHost));
+    BF_HIP_TRY(hipMemcpy(heap.data(), s->d.heap, (size_t)N * 4, hipMemcpyDeviceToHost));
+    BF_HIP_TRY(hipMemcpy(&heapCounter, s->d.heapCounter, 4, hipMemcpyDeviceToHost));
+    BF_HIP_TRY(hipMemcpy(stats, s->d.stats, sizeof stats, hipMemcpyDeviceToHost));
+    const uint32_t nFree = heapCounter + 1u;
+    std::vector<uint8_t> state(N, 0);   // 1 = free, 2 = allocated
+    uint32_t dupFree = 0;
+    for (uint32_t i = 0; i < nFree && i < N; ++i) { if (state[heap[i]] == 1) dupFree++; state[heap[i]] = 1; }
+    uint32_t occupied = 0, both = 0, dupKeys = 0;
+    std::unordered_set<uint64_t> keys;
+    for (size_t i = 0; i < numEntries; ++i) {
+        if (hash[i].ptr == BF_FREE_ENTRY) continue;
+        occupied++;
+        const uint32_t blk = (uint32_t)hash[i].ptr / VOX;
+        if (blk < N) { if (state[blk] == 1) both++; else state[blk] = 2; }
+        i3 b; b.x = hash[i].pos[0]; b.y = hash[i].pos[1]; b.z = hash[i].pos[2];
+        if (!keys.insert(packKey(b)).second) dupKeys++;
+    }
+    uint32_t leaked = dupFree;
+    for (uint32_t i = 0; i < N; ++i) leaked += (state[i] == 0);
+    out[0] = occupied; out[1] = nFree; out[2] = dupKeys; out[3] = both; out[4] = leaked; out[5] = stats[ST_DROPPED];
+    if (stats[ST_ERROR]) { set_error("TSDF scratch capacity exceeded (error bits 0x%x)", stats[ST_ERROR]); return BF_ERR_CAPACITY; }
+    return BF_OK;
+}
+
+int bf_scene_kernel_timing(bf_scene* s, int enable) {
+    BF_REQUIRE(s, "null scene");
+    s->timing = enable != 0;
+    s->eventsUsed = 0;
+    return BF_OK;
+}
+
+int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms) {
+    BF_REQUIRE(s && count && total_ms, "null argument");
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    float tot = 0.0f;
+    for (size_t i = 0; i < s->eventsUsed; ++i) {
+        float ms = 0.0f;
+        BF_HIP_TRY(hipEventElapsedTime(&ms, s->events[i].first, s->events[i].second));
+        tot += ms;
+    }
+    *count = (uint32_t)s->eventsUsed;
+    *total_ms = tot;
+    s->eventsUsed = 0;
+    return BF_OK;
+}
+
+}  // extern "C"

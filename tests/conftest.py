@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the product library and the oracle exist (cross-compiles without a GPU)."""
+    from bundlefusion_amd import build
+    build.build_lib()
+    build.build_oracle()
+    return build
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
+    from tests import oracle_api
+    return oracle_api
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("test is marked gpu but no GPU is visible (there is no CPU fallback)")
+    import bundlefusion_amd
+    return bundlefusion_amd

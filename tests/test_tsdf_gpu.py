@@ -1,0 +1,181 @@
+"""GPU parity tests (-m gpu): HIP voxel-hash TSDF through the C ABI vs the CPU oracle.
+
+Bar: bit-exact for the hash table image (keys, slots, chain offsets, heap, heap counter, frustum
+list) and — because both sides evaluate the same IEEE op sequence without FMA contraction —
+bit-exact voxel bytes (sdf, weight, colour) as well.  tol = 0.
+"""
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_hash_params, camera_params, FREE_ENTRY, VOX_PER_BLOCK
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_dev(depth, color):
+    import torch
+    d = torch.from_numpy(np.ascontiguousarray(depth)).cuda()
+    c = torch.from_numpy(np.ascontiguousarray(color)).cuda() if color is not None else None
+    return d, c
+
+
+def assert_same_state(gs, osc, what=""):
+    gh, gheap, gcnt, gvox = gs.download()
+    oh, oheap, ocnt, ovox = osc.hash(), osc.heap(), osc.heap_counter(), osc.voxels()
+    assert gcnt == ocnt, what + " heap counter"
+    for f in ("pos", "ptr", "offset"):
+        assert np.array_equal(gh[f], oh[f]), what + " hash." + f
+    assert np.array_equal(gheap, oheap), what + " heap"
+    assert np.array_equal(gvox.view(np.uint8), ovox.view(np.uint8)), what + " voxel bytes"
+    gc, oc = gs.download_compactified(), osc.compactified()
+    assert len(gc) == len(oc) == osc.num_occupied(), what + " numOccupiedBlocks"
+    assert np.array_equal(gc["pos"], oc["pos"]) and np.array_equal(gc["ptr"], oc["ptr"]), what + " frustum list"
+    dbg = gs.debug_hash()
+    assert dbg["duplicate_keys"] == 0 and dbg["free_and_allocated"] == 0 and dbg["leaked"] == 0
+    assert dbg["dropped"] == osc.num_dropped(), what + " dropped"
+    assert gs.num_allocated_blocks() == osc.num_allocated()
+
+
+def _setup(width, height, voxel, buckets, blocks, scene="wall", k=0):
+    if scene == "wall":
+        depth, color, T, K = synth.scene_wall(width, height)
+    else:
+        depth, color, T, K = synth.scene_room(k, width, height)
+    cam = camera_params(width, height, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=buckets, num_sdf_blocks=blocks, voxel_size=voxel)
+    return depth, color, T, cam, p
+
+
+def test_integrate_bit_exact_small(gpu, oracle):
+    depth, color, T, cam, p = _setup(160, 120, 0.01, 20000, 6000)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    osc = oracle.OracleScene(p)
+    d, c = _to_dev(depth, color)
+    gs.integrate(T, d, c, cam)
+    osc.integrate(T, depth, color, cam)
+    assert_same_state(gs, osc, "after integrate:")
+    assert gs.num_integrated_frames() == 1
+    assert gs.hash_params().m_numOccupiedBlocks == osc.num_occupied()
+    assert gs.heap_free_count() == osc.heap_counter() + 1
+
+
+def test_sequence_integrate_deintegrate_gc_bit_exact(gpu, oracle):
+    """Moving camera over S2: integrate 6 frames, re-integrate 2 at perturbed poses, de-integrate, GC."""
+    W, H = 160, 120
+    frames = [synth.scene_room(k * 15, W, H) for k in range(6)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=50000, num_sdf_blocks=40000, voxel_size=0.02)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    osc = oracle.OracleScene(p)
+    dev = [_to_dev(f[0], f[1]) for f in frames]
+    for i, (depth, color, T, _) in enumerate(frames):
+        gs.integrate(T, dev[i][0], dev[i][1], cam)
+        osc.integrate(T, depth, color, cam)
+    assert_same_state(gs, osc, "after 6 integrates:")
+    for i in (1, 4):      # reintegrate() of DepthSensing.cpp:882-889
+        depth, color, T, _ = frames[i]
+        T2 = T.copy()
+        T2[:3, 3] += np.float32(0.03)
+        gs.deintegrate(T, dev[i][0], dev[i][1], cam)
+        gs.integrate(T2, dev[i][0], dev[i][1], cam)
+        osc.deintegrate(T, depth, color, cam)
+        osc.integrate(T2, depth, color, cam)
+        frames[i] = (depth, color, T2, None)
+    gs.garbage_collect()
+    osc.garbage_collect()
+    assert_same_state(gs, osc, "after re-integration + GC:")
+    for i, (depth, color, T, _) in enumerate(frames):
+        gs.deintegrate(T, dev[i][0], dev[i][1], cam)
+        osc.deintegrate(T, depth, color, cam)
+        gs.garbage_collect()
+        osc.garbage_collect()
+    assert_same_state(gs, osc, "after de-integrating everything:")
+    gh, gheap, gcnt, gvox = gs.download()
+    assert gs.num_allocated_blocks() == 0 and gcnt + 1 == p.m_numSDFBlocks
+    assert np.all(gh["ptr"] == FREE_ENTRY)
+    assert not gvox.view(np.uint8).any()
+
+
+def test_collision_chains_and_drops_bit_exact(gpu, oracle):
+    depth, color, T, cam, p = _setup(160, 120, 0.01, 400, 6000)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    osc = oracle.OracleScene(p)
+    d, c = _to_dev(depth, color)
+    gs.integrate(T, d, c, cam)
+    osc.integrate(T, depth, color, cam)
+    assert (osc.hash()["offset"] != 0).sum() > 10 and osc.num_dropped() > 0
+    assert_same_state(gs, osc, "chains:")
+    gs.deintegrate(T, d, c, cam)
+    osc.deintegrate(T, depth, color, cam)
+    gs.garbage_collect()
+    osc.garbage_collect()
+    assert_same_state(gs, osc, "chains after GC:")
+
+
+def test_heap_exhaustion_bit_exact(gpu, oracle):
+    depth, color, T, cam, p = _setup(160, 120, 0.01, 20000, 300)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    osc = oracle.OracleScene(p)
+    d, c = _to_dev(depth, color)
+    gs.integrate(T, d, c, cam)
+    osc.integrate(T, depth, color, cam)
+    assert_same_state(gs, osc, "heap exhausted:")
+    assert gs.heap_free_count() == 0
+
+
+def test_empty_invalid_and_no_colour(gpu, oracle):
+    depth, color, T, cam, p = _setup(160, 120, 0.01, 20000, 6000)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    osc = oracle.OracleScene(p)
+    for dimg in (np.full_like(depth, -np.inf), np.zeros_like(depth)):
+        d, c = _to_dev(dimg, color)
+        gs.integrate(T, d, c, cam)
+        osc.integrate(T, dimg, color, cam)
+        assert gs.num_allocated_blocks() == 0
+    gs.garbage_collect()
+    osc.garbage_collect()
+    d, _ = _to_dev(depth, None)
+    gs.integrate(T, d, None, cam)
+    osc.integrate(T, depth, None, cam)
+    assert_same_state(gs, osc, "no colour:")
+    assert gs.num_allocated_blocks() > 0
+    gs.reset()
+    osc.reset()
+    assert_same_state(gs, osc, "after reset:")
+
+
+def test_bad_arguments_fail_loudly(gpu):
+    import ctypes as C
+    from bundlefusion_amd.capi import lib, BFError, HashParams
+    p = default_hash_params(num_buckets=1000, num_sdf_blocks=100)
+    p.m_hashBucketSize = 8
+    with pytest.raises(BFError):
+        gpu.capi.SceneRepHashSDF(p)
+    assert b"m_hashBucketSize" in lib.bf_last_error()
+    assert lib.bf_scene_integrate(None, None, None, None, None) != 0
+
+
+def test_config1_full_size_properties(gpu, oracle):
+    """BASELINE config 1: one 640x480 frame of S1 at 4 mm voxels.  Full-size check through
+    size-independent properties plus bit-exact comparison against the oracle (it takes ~2 s)."""
+    depth, color, T, cam, p = _setup(640, 480, 0.004, 100000, 60000)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    d, c = _to_dev(depth, color)
+    gs.integrate(T, d, c, cam)
+    dbg = gs.debug_hash()
+    assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["dropped"] == 0
+    n_alloc = gs.num_allocated_blocks()
+    assert 15000 < n_alloc < 40000          # ~22 k blocks for the wall at 4 mm
+    assert dbg["occupied"] == n_alloc and dbg["heap_free"] == p.m_numSDFBlocks - n_alloc
+    osc = oracle.OracleScene(p)
+    osc.integrate(T, depth, color, cam)
+    assert_same_state(gs, osc, "config 1:")
+    # integrate -> de-integrate -> GC round trip restores the empty volume exactly
+    gs.deintegrate(T, d, c, cam)
+    gs.garbage_collect()
+    gh, gheap, gcnt, gvox = gs.download()
+    assert gcnt + 1 == p.m_numSDFBlocks and np.all(gh["ptr"] == FREE_ENTRY)
+    assert not gvox.view(np.uint8).any()
+    assert sorted(gheap.tolist()) == list(range(p.m_numSDFBlocks))
