@@ -244,3 +244,191 @@ def _d2h(ptr, nbytes):
         if rc != 0:
             raise BFError("hipMemcpy D2H failed: %d" % rc)
     return out
+
+
+# --------------------------------------------------------------------------- cache + solver
+class CachedFrame(C.Structure):
+    _fields_ = [("d_depthDownsampled", C.c_void_p), ("d_cameraposDownsampled", C.c_void_p), ("d_intensityDownsampled", C.c_void_p),
+                ("d_intensityDerivsDownsampled", C.c_void_p), ("d_normalsDownsampledUCHAR4", C.c_void_p),
+                ("d_normalsDownsampled", C.c_void_p)]
+
+
+class SolverConfig(C.Structure):
+    _fields_ = [("optMaxResThresh", C.c_float), ("denseDistThresh", C.c_float), ("denseNormalThresh", C.c_float),
+                ("denseColorThresh", C.c_float), ("denseColorGradientMin", C.c_float), ("denseDepthMin", C.c_float),
+                ("denseDepthMax", C.c_float), ("denseOverlapCheckSubsampleFactor", C.c_uint32), ("verifyOptDistThresh", C.c_float),
+                ("verifyOptPercentThresh", C.c_float), ("recordConvergence", C.c_int32)]
+
+
+ENTRYJ_DTYPE = np.dtype([("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", 3), ("pos_j", "<f4", 3)])
+assert ENTRYJ_DTYPE.itemsize == 32
+
+
+def default_solver_config(record_convergence=False):
+    """zParametersBundlingDefault.txt values."""
+    c = SolverConfig()
+    c.optMaxResThresh = 0.08
+    c.denseDistThresh = 0.15
+    c.denseNormalThresh = 0.97
+    c.denseColorThresh = 0.1
+    c.denseColorGradientMin = 0.005
+    c.denseDepthMin = 0.5
+    c.denseDepthMax = 4.0
+    c.denseOverlapCheckSubsampleFactor = 4
+    c.verifyOptDistThresh = 0.02
+    c.verifyOptPercentThresh = 0.05
+    c.recordConvergence = int(record_convergence)
+    return c
+
+
+def intrinsics_matrix(fx, fy, mx, my):
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, mx, my
+    return K
+
+
+class Cache:
+    """Python view of `bf_cache` (== the reference's CUDACache)."""
+
+    def __init__(self, depth_w, depth_h, w, h, max_images, input_intrinsics, color_sigma=2.5, depth_sigma_d=1.0, depth_sigma_r=0.05,
+                 stream=None):
+        self._h = C.c_void_p()
+        self.w, self.h, self.max_images = w, h, max_images
+        check(lib.bf_cache_create(depth_w, depth_h, w, h, max_images, mat16(input_intrinsics), C.c_float(color_sigma),
+                                  C.c_float(depth_sigma_d), C.c_float(depth_sigma_r), C.byref(self._h)))
+        if stream is not None:
+            check(lib.bf_cache_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            lib.bf_cache_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def store_frame(self, depth, color):
+        dh, dw = depth.shape[:2]
+        ch, cw = color.shape[:2]
+        check(lib.bf_cache_store_frame(self._h, C.c_void_p(depth.data_ptr()), dw, dh, C.c_void_p(color.data_ptr()), cw, ch))
+
+    def reset(self):
+        check(lib.bf_cache_reset(self._h))
+
+    def num_frames(self):
+        v = C.c_uint32()
+        check(lib.bf_cache_get_num_frames(self._h, C.byref(v)))
+        return v.value
+
+    def frames_gpu(self):
+        p = C.c_void_p()
+        check(lib.bf_cache_get_frames_gpu(self._h, C.byref(p)))
+        return p.value
+
+    def geometry(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        k = (C.c_float * 4)()
+        check(lib.bf_cache_get_geometry(self._h, C.byref(w), C.byref(h), k))
+        return w.value, h.value, [k[0], k[1], k[2], k[3]]
+
+    def download_frame(self, i):
+        import torch
+        torch.cuda.synchronize()
+        f = CachedFrame()
+        check(lib.bf_cache_get_frame(self._h, i, C.byref(f)))
+        n = self.w * self.h
+        return dict(
+            depth=_d2h(f.d_depthDownsampled, n * 4).view("<f4").reshape(self.h, self.w),
+            campos=_d2h(f.d_cameraposDownsampled, n * 16).view("<f4").reshape(self.h, self.w, 4),
+            intensity=_d2h(f.d_intensityDownsampled, n * 4).view("<f4").reshape(self.h, self.w),
+            derivs=_d2h(f.d_intensityDerivsDownsampled, n * 8).view("<f4").reshape(self.h, self.w, 2),
+            normals_u=_d2h(f.d_normalsDownsampledUCHAR4, n * 4).reshape(self.h, self.w, 4),
+            normals=_d2h(f.d_normalsDownsampled, n * 16).view("<f4").reshape(self.h, self.w, 4),
+        )
+
+
+class Solver:
+    """Python view of `bf_solver` (== the reference's CUDASolverBundling)."""
+
+    def __init__(self, max_images, max_residuals, cfg=None, stream=None):
+        self._h = C.c_void_p()
+        self.cfg = cfg or default_solver_config()
+        check(lib.bf_solver_create(max_images, max_residuals, C.byref(self.cfg), C.byref(self._h)))
+        if stream is not None:
+            check(lib.bf_solver_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            lib.bf_solver_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, corr, num_corr, valid, num_images, n_nonlin, n_lin, cache, weights_sparse, weights_dense_depth, weights_dense_color,
+              rot, trans, use_pairwise=True, rebuild_jt=True, find_max_residual=False, revalidate_idx=0xFFFFFFFF):
+        nw = len(weights_sparse)
+        ws = (C.c_float * nw)(*weights_sparse)
+        wd = (C.c_float * nw)(*weights_dense_depth)
+        wc = (C.c_float * nw)(*weights_dense_color)
+        if cache is not None:
+            w, h, k = cache.geometry()
+            frames, k4 = C.c_void_p(cache.frames_gpu()), (C.c_float * 4)(*k)
+        else:
+            w = h = 0
+            frames, k4 = None, None
+        check(lib.bf_solver_solve(self._h, C.c_void_p(corr.data_ptr()) if corr is not None else None, num_corr,
+                                  C.c_void_p(valid.data_ptr()), num_images, n_nonlin, n_lin, frames, w, h, k4, ws, wd, wc, nw,
+                                  int(use_pairwise), C.c_void_p(rot.data_ptr()), C.c_void_p(trans.data_ptr()), int(rebuild_jt),
+                                  int(find_max_residual), C.c_uint32(revalidate_idx)))
+
+    def max_residual(self):
+        m, i = C.c_float(), C.c_int32()
+        check(lib.bf_solver_get_max_residual(self._h, C.byref(m), C.byref(i)))
+        return m.value, i.value
+
+    def max_residual_pair(self, cur_frame, corr):
+        idx = (C.c_uint32 * 2)()
+        m, rm = C.c_float(), C.c_int()
+        check(lib.bf_solver_get_max_residual_pair(self._h, cur_frame, C.c_void_p(corr.data_ptr()), idx, C.byref(m), C.byref(rm)))
+        return (idx[0], idx[1]), m.value, bool(rm.value)
+
+    def use_verification(self, corr, num_corr):
+        out = C.c_int()
+        check(lib.bf_solver_use_verification(self._h, C.c_void_p(corr.data_ptr()), num_corr, C.byref(out)))
+        return bool(out.value)
+
+    def convergence(self):
+        buf = (C.c_float * 40)()
+        n = C.c_uint32()
+        check(lib.bf_solver_get_convergence(self._h, buf, 40, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def iteration_counts(self):
+        buf = (C.c_int32 * 33)()
+        check(lib.bf_solver_get_iteration_counts(self._h, buf, 33))
+        return buf[0], [buf[1 + i] for i in range(buf[0])]
+
+    def debug_dense_system(self, n):
+        dim = 6 * n
+        JtJ = np.zeros((dim, dim), dtype=np.float32)
+        Jtr = np.zeros(dim, dtype=np.float32)
+        npairs = C.c_int32()
+        check(lib.bf_solver_debug_dense_system(self._h, JtJ.ctypes.data_as(C.c_void_p), Jtr.ctypes.data_as(C.c_void_p), n, C.byref(npairs)))
+        return JtJ, Jtr, npairs.value
+
+
+def convert_matrices_to_poses(T, rot, trans, valid, stream=0):
+    check(lib.bf_convert_matrices_to_poses(C.c_void_p(T.data_ptr()), T.shape[0], C.c_void_p(rot.data_ptr()), C.c_void_p(trans.data_ptr()),
+                                           C.c_void_p(valid.data_ptr()), C.c_void_p(stream)))
+
+
+def convert_poses_to_matrices(rot, trans, T, valid, stream=0):
+    check(lib.bf_convert_poses_to_matrices(C.c_void_p(rot.data_ptr()), C.c_void_p(trans.data_ptr()), T.shape[0], C.c_void_p(T.data_ptr()),
+                                           C.c_void_p(valid.data_ptr()), C.c_void_p(stream)))

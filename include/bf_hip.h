@@ -164,6 +164,112 @@ BF_API int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out);
 BF_API int bf_scene_kernel_timing(bf_scene* s, int enable);
 BF_API int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms);
 
+
+/* ------------------------------------------------------------------------- */
+/* Dense frame cache:  CUDACache.h / CUDACacheUtil.h                          */
+/* ------------------------------------------------------------------------- */
+
+/* CUDACachedFrame, CUDACacheUtil.h:10-53 (CUDACACHE_UCHAR_NORMALS and _FLOAT_NORMALS both on) */
+typedef struct bf_cached_frame {
+    float* d_depthDownsampled;            /* W*H                                  */
+    float* d_cameraposDownsampled;        /* float4 per pixel (x,y,z,1) or -inf   */
+    float* d_intensityDownsampled;        /* W*H                                  */
+    float* d_intensityDerivsDownsampled;  /* float2 per pixel                     */
+    uint8_t* d_normalsDownsampledUCHAR4;  /* uchar4 per pixel                     */
+    float* d_normalsDownsampled;          /* float4 per pixel (nx,ny,nz,0) or -inf */
+} bf_cached_frame;
+
+typedef struct bf_cache bf_cache; /* == class CUDACache */
+
+/* CUDACache(widthDepthInput, heightDepthInput, widthDownSampled, heightDownSampled, maxNumImages,
+ *           inputIntrinsics)  CUDACache.cpp:14-43; the three filter sigmas are
+ * GlobalBundlingState s_colorDownSigma / s_depthDownSigmaD / s_depthDownSigmaR.               */
+BF_API int bf_cache_create(uint32_t widthDepthInput, uint32_t heightDepthInput, uint32_t widthDownSampled,
+                           uint32_t heightDownSampled, uint32_t maxNumImages, const float inputIntrinsics[16],
+                           float colorDownSigma, float depthDownSigmaD, float depthDownSigmaR, bf_cache** out);
+BF_API int bf_cache_destroy(bf_cache* c);
+BF_API int bf_cache_set_stream(bf_cache* c, void* hip_stream);
+/* storeFrame(d_depth, w, h, d_color, cw, ch)                  CUDACache.cpp:45-86 */
+BF_API int bf_cache_store_frame(bf_cache* c, const float* d_depth, uint32_t inputDepthWidth, uint32_t inputDepthHeight,
+                                const uint8_t* d_color, uint32_t inputColorWidth, uint32_t inputColorHeight);
+BF_API int bf_cache_reset(bf_cache* c);                                   /* CUDACache.h:17 */
+BF_API int bf_cache_copy_cache_frame_from(bf_cache* c, bf_cache* other, uint32_t frameFrom); /* :24 */
+BF_API int bf_cache_increment(bf_cache* c);                               /* incrementCache :43 */
+BF_API int bf_cache_get_num_frames(bf_cache* c, uint32_t* out);
+BF_API int bf_cache_set_current_frame(bf_cache* c, uint32_t n);           /* setCurrentFrame (debug) */
+/* getCacheFramesGPU(): device array of maxNumImages bf_cached_frame   CUDACache.h:22 */
+BF_API int bf_cache_get_frames_gpu(bf_cache* c, const bf_cached_frame** d_frames);
+/* host copy of one frame's pointer struct (getCacheFrames()[i]) */
+BF_API int bf_cache_get_frame(bf_cache* c, uint32_t i, bf_cached_frame* out);
+/* getWidth/getHeight/getIntrinsics: out = {fx, fy, cx, cy} of the down-sampled camera */
+BF_API int bf_cache_get_geometry(bf_cache* c, uint32_t* width, uint32_t* height, float intrinsics4[4]);
+
+/* ------------------------------------------------------------------------- */
+/* Bundling solver:  Solver/CUDASolverBundling.h, SBA.cu                      */
+/* ------------------------------------------------------------------------- */
+
+/* EntryJ, SiftGPU/SIFTImageManager.h:45-60 (32 B) */
+typedef struct bf_entry_j {
+    uint32_t imgIdx_i, imgIdx_j;   /* 0xFFFFFFFF in imgIdx_i == invalid */
+    float pos_i[3];
+    float pos_j[3];
+} bf_entry_j;
+
+/* thresholds CUDASolverBundling reads from GlobalBundlingState (.cpp:35-36, :93-100) */
+typedef struct bf_solver_config {
+    float optMaxResThresh;          /* s_optMaxResThresh              */
+    float denseDistThresh;          /* s_denseDistThresh              */
+    float denseNormalThresh;        /* s_denseNormalThresh            */
+    float denseColorThresh;         /* s_denseColorThresh             */
+    float denseColorGradientMin;    /* s_denseColorGradientMin        */
+    float denseDepthMin;            /* s_denseDepthMin                */
+    float denseDepthMax;            /* s_denseDepthMax                */
+    uint32_t denseOverlapCheckSubsampleFactor;
+    float verifyOptDistThresh;      /* 0.02 (.cpp:35)                 */
+    float verifyOptPercentThresh;   /* 0.05 (.cpp:36)                 */
+    int32_t recordConvergence;      /* s_recordSolverConvergence      */
+} bf_solver_config;
+
+typedef struct bf_solver bf_solver; /* == class CUDASolverBundling */
+
+/* CUDASolverBundling(maxNumberOfImages, maxNumResiduals)      CUDASolverBundling.cpp:24 */
+BF_API int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const bf_solver_config* cfg,
+                            bf_solver** out);
+BF_API int bf_solver_destroy(bf_solver* s);
+BF_API int bf_solver_set_stream(bf_solver* s, void* hip_stream);
+/* solve(...)                                                   CUDASolverBundling.cpp:187-284
+ * d_rot / d_trans: float3 per image (se(3) unknowns), updated in place.  d_cacheFrames may be
+ * NULL (dense term off).  weights*: numWeights host floats, one per non-linear iteration.
+ * Asynchronous unless findMaxResidual/recordConvergence need host values (one sync at the end). */
+BF_API int bf_solver_solve(bf_solver* s, bf_entry_j* d_correspondences, uint32_t numberOfCorrespondences,
+                           const int32_t* d_validImages, uint32_t numberOfImages, uint32_t nNonLinearIterations,
+                           uint32_t nLinearIterations, const bf_cached_frame* d_cacheFrames, uint32_t cacheWidth,
+                           uint32_t cacheHeight, const float cacheIntrinsics4[4], const float* weightsSparse,
+                           const float* weightsDenseDepth, const float* weightsDenseColor, uint32_t numWeights,
+                           int usePairwiseDense, float* d_rot, float* d_trans, int rebuildJT, int findMaxResidual,
+                           uint32_t revalidateIdx);
+/* getMaxResidual(max, index)                                   CUDASolverBundling.h:37-40 */
+BF_API int bf_solver_get_max_residual(bf_solver* s, float* max, int32_t* index);
+/* getMaxResidual(curFrame, d_corr, imageIndices, maxRes) -> remove?   .cpp:429-452 */
+BF_API int bf_solver_get_max_residual_pair(bf_solver* s, uint32_t curFrame, const bf_entry_j* d_correspondences,
+                                           uint32_t imageIndices[2], float* maxRes, int* remove);
+/* useVerification(d_corr, n)                                   .cpp:454-476 (syncs) */
+BF_API int bf_solver_use_verification(bf_solver* s, const bf_entry_j* d_correspondences, uint32_t numberOfCorrespondences,
+                                      int* out);
+/* getConvergenceAnalysis(): energies per GN iteration of the last solve (needs recordConvergence) */
+BF_API int bf_solver_get_convergence(bf_solver* s, float* out, uint32_t capacity, uint32_t* count);
+/* diagnostics of the last solve (syncs): out[0]=#GN iterations run, out[1..]=#PCG iterations of each */
+BF_API int bf_solver_get_iteration_counts(bf_solver* s, int32_t* out, uint32_t capacity);
+/* dump of the last dense system in the reference's layout (6N x 6N row-major JtJ, 6N Jtr);
+ * test hook, syncs.  numPairs = #overlapping image pairs found.                              */
+BF_API int bf_solver_debug_dense_system(bf_solver* s, float* h_JtJ, float* h_Jtr, uint32_t numImages, int32_t* numPairs);
+
+/* convertMatricesToPosesCU / convertPosesToMatricesCU          SBA.cu:75-108 (Lie space) */
+BF_API int bf_convert_matrices_to_poses(const float* d_transforms, uint32_t numTransforms, float* d_rot, float* d_trans,
+                                        const int32_t* d_validImages, void* hip_stream);
+BF_API int bf_convert_poses_to_matrices(const float* d_rot, const float* d_trans, uint32_t numImages, float* d_transforms,
+                                        const int32_t* d_validImages, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

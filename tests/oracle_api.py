@@ -124,3 +124,128 @@ def mat4_inverse(m):
     out = (C.c_float * 16)()
     olib.or_mat4_inverse(mat16(m), out)
     return np.array(out[:], dtype=np.float32).reshape(4, 4)
+
+
+# --------------------------------------------------------------------------- image ops / cache / solver oracle
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cache_store_frame(depth, color, W, H, input_intrinsics, sigma_intensity=2.5, sigma_d=1.0, sigma_r=0.05):
+    """CUDACache::storeFrame on the CPU -> dict of the six cached arrays."""
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    color = np.ascontiguousarray(color, dtype=np.uint8)
+    dh, dw = depth.shape
+    ch, cw = color.shape[:2]
+    inv = np.ascontiguousarray(mat4_inverse(np.asarray(input_intrinsics, dtype=np.float32)).reshape(16))
+    out = dict(depth=np.full((H, W), np.nan, np.float32), campos=np.full((H, W, 4), np.nan, np.float32),
+               intensity=np.full((H, W), np.nan, np.float32), derivs=np.full((H, W, 2), np.nan, np.float32),
+               normals_u=np.zeros((H, W, 4), np.uint8), normals=np.full((H, W, 4), np.nan, np.float32))
+    olib.or_cache_store_frame(_fp(depth), dw, dh, _fp(color), cw, ch, W, H, _fp(inv), C.c_float(sigma_intensity), C.c_float(sigma_d),
+                              C.c_float(sigma_r), _fp(out["depth"]), _fp(out["campos"]), _fp(out["intensity"]), _fp(out["derivs"]),
+                              _fp(out["normals_u"]), _fp(out["normals"]))
+    return out
+
+
+def erode_depth(depth, structure_size=3, d_thresh=0.05, frac_req=0.3):
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    out = np.empty_like(depth)
+    h, w = depth.shape
+    olib.or_erode_depth(_fp(out), _fp(depth), structure_size, w, h, C.c_float(d_thresh), C.c_float(frac_req))
+    return out
+
+
+def gauss_filter_depth(depth, sigma_d, sigma_r):
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    out = np.empty_like(depth)
+    h, w = depth.shape
+    olib.or_gauss_filter_depth(_fp(out), _fp(depth), C.c_float(sigma_d), C.c_float(sigma_r), w, h)
+    return out
+
+
+class _CacheFrameHost(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("campos4", C.c_void_p), ("intensity", C.c_void_p), ("derivs2", C.c_void_p),
+                ("normalsU4", C.c_void_p), ("normals4", C.c_void_p)]
+
+
+class _SolverArgs(C.Structure):
+    _fields_ = [("corr", C.c_void_p), ("numCorr", C.c_uint32), ("validImages", C.c_void_p), ("numImages", C.c_uint32),
+                ("maxCorrPerImage", C.c_uint32), ("nNonLin", C.c_uint32), ("nLin", C.c_uint32), ("cacheFrames", C.c_void_p),
+                ("W", C.c_uint32), ("H", C.c_uint32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("weightsSparse", C.c_void_p), ("weightsDenseDepth", C.c_void_p), ("weightsDenseColor", C.c_void_p),
+                ("usePairwise", C.c_int), ("denseDistThresh", C.c_float), ("denseNormalThresh", C.c_float),
+                ("denseColorThresh", C.c_float), ("denseColorGradientMin", C.c_float), ("denseDepthMin", C.c_float),
+                ("denseDepthMax", C.c_float), ("denseOverlapCheckSubsampleFactor", C.c_uint32), ("rot3", C.c_void_p),
+                ("trans3", C.c_void_p), ("convergence", C.c_void_p), ("pcgIterations", C.c_void_p), ("gnIterations", C.c_void_p),
+                ("maxResidual", C.c_void_p), ("maxResidualIndex", C.c_void_p), ("denseJtJ", C.c_void_p), ("denseJtr", C.c_void_p),
+                ("numDensePairs", C.c_void_p)]
+
+
+def solver_solve(corr, valid, n_images, n_nonlin, n_lin, weights_sparse, weights_dense_depth, weights_dense_color, rot, trans,
+                 cache_frames=None, cache_geom=None, cfg=None, use_pairwise=True, max_corr_per_image=4000, dump_dense=False):
+    """CUDASolverBundling::solve on the CPU.  corr: ENTRYJ array (modified in place when a row overflows); rot/trans float32 [N,3]
+    (updated in place).  cache_frames: list of dicts from cache_store_frame.  Returns a dict of diagnostics."""
+    from bundlefusion_amd.capi import default_solver_config
+    cfg = cfg or default_solver_config()
+    a = _SolverArgs()
+    keep = []
+    a.corr = corr.ctypes.data if len(corr) else None
+    a.numCorr = len(corr)
+    valid = np.ascontiguousarray(valid, dtype=np.int32)
+    a.validImages = valid.ctypes.data
+    a.numImages = n_images
+    a.maxCorrPerImage = max_corr_per_image
+    a.nNonLin, a.nLin = n_nonlin, n_lin
+    if cache_frames is not None:
+        arr = (_CacheFrameHost * n_images)()
+        for i in range(n_images):
+            f = {k: np.ascontiguousarray(v) for k, v in cache_frames[i].items()}
+            keep.append(f)
+            arr[i].depth, arr[i].campos4, arr[i].intensity = f["depth"].ctypes.data, f["campos"].ctypes.data, f["intensity"].ctypes.data
+            arr[i].derivs2, arr[i].normalsU4, arr[i].normals4 = f["derivs"].ctypes.data, f["normals_u"].ctypes.data, f["normals"].ctypes.data
+        keep.append(arr)
+        a.cacheFrames = C.addressof(arr)
+        a.W, a.H, k = cache_geom
+        a.fx, a.fy, a.cx, a.cy = k
+    ws = np.asarray(weights_sparse, np.float32); wd = np.asarray(weights_dense_depth, np.float32); wc = np.asarray(weights_dense_color, np.float32)
+    a.weightsSparse, a.weightsDenseDepth, a.weightsDenseColor = ws.ctypes.data, wd.ctypes.data, wc.ctypes.data
+    a.usePairwise = int(use_pairwise)
+    for f in ("denseDistThresh", "denseNormalThresh", "denseColorThresh", "denseColorGradientMin", "denseDepthMin", "denseDepthMax",
+              "denseOverlapCheckSubsampleFactor"):
+        setattr(a, f, getattr(cfg, f))
+    a.rot3, a.trans3 = rot.ctypes.data, trans.ctypes.data
+    conv = np.full(n_nonlin + 1, -1.0, np.float32)
+    pcg = np.zeros(n_nonlin, np.int32)
+    gn = C.c_int(0); mx = C.c_float(0); mi = C.c_int(0); npairs = C.c_int(0)
+    a.convergence, a.pcgIterations = conv.ctypes.data, pcg.ctypes.data
+    a.gnIterations, a.maxResidual, a.maxResidualIndex = C.addressof(gn), C.addressof(mx), C.addressof(mi)
+    a.numDensePairs = C.addressof(npairs)
+    JtJ = Jtr = None
+    if dump_dense:
+        JtJ = np.zeros((6 * n_images, 6 * n_images), np.float32); Jtr = np.zeros(6 * n_images, np.float32)
+        a.denseJtJ, a.denseJtr = JtJ.ctypes.data, Jtr.ctypes.data
+    olib.or_solver_solve(C.byref(a))
+    return dict(convergence=conv, pcg_iterations=pcg[:gn.value].tolist(), gn_iterations=gn.value, max_residual=mx.value,
+                max_residual_index=mi.value, JtJ=JtJ, Jtr=Jtr, num_dense_pairs=npairs.value)
+
+
+def solver_use_verification(corr, rot, trans, n_images, dist_thresh=0.02, percent_thresh=0.05):
+    return bool(olib.or_solver_use_verification(C.c_void_p(corr.ctypes.data), len(corr), _fp(rot), _fp(trans), n_images,
+                                                C.c_float(dist_thresh), C.c_float(percent_thresh)))
+
+
+def matrices_to_poses(T, valid=None):
+    T = np.ascontiguousarray(T, np.float32)
+    n = T.shape[0]
+    valid = np.ones(n, np.int32) if valid is None else np.ascontiguousarray(valid, np.int32)
+    rot = np.zeros((n, 3), np.float32); trans = np.zeros((n, 3), np.float32)
+    olib.or_matrices_to_poses(_fp(T), n, _fp(rot), _fp(trans), _fp(valid))
+    return rot, trans
+
+
+def poses_to_matrices(rot, trans, valid=None):
+    n = rot.shape[0]
+    valid = np.ones(n, np.int32) if valid is None else np.ascontiguousarray(valid, np.int32)
+    T = np.zeros((n, 4, 4), np.float32)
+    olib.or_poses_to_matrices(_fp(np.ascontiguousarray(rot, np.float32)), _fp(np.ascontiguousarray(trans, np.float32)), n, _fp(T), _fp(valid))
+    return T

@@ -1,0 +1,175 @@
+"""GPU parity tests (-m gpu): dense frame cache and bundling solver through the C ABI vs the CPU oracle.
+
+Tolerances (stated per assertion):
+  * cache (image operators): bit-exact — same IEEE op sequence, Gaussian taps tabulated on the host.
+  * SE(3) conversions: 2e-6 absolute (sin/cos/asin/acos are libm on the CPU, device libm on the GPU).
+  * solver: the HIP path contracts the Jacobians into a block-sparse normal matrix once per Gauss-Newton
+    iteration, the oracle re-applies J / J^T per PCG iteration like the reference; both are exact
+    restatements of the same linear system, so results agree to float round-off amplified by the CG:
+    energies rel 1e-3, poses 1e-4 (north_star: ATE within 1 mm), dense JtJ/Jtr rel 2e-4 of the
+    matrix norm, identical iteration counts are NOT required (early-out thresholds sit on round-off).
+"""
+import numpy as np
+import pytest
+
+from bundlefusion_amd.capi import ENTRYJ_DTYPE, intrinsics_matrix, default_solver_config
+from tests import bundle_synth as bs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_se3_conversions(gpu, oracle):
+    import torch
+    rng = np.random.default_rng(1)
+    T = np.stack([bs.random_pose(rng, s, 1.0) for s in np.r_[np.linspace(0, 1.7, 150), np.full(50, 1e-4)]]).astype(np.float32)
+    valid = np.ones(len(T), np.int32); valid[3] = 0
+    dT, dv = _dev(T), _dev(valid)
+    rot = torch.zeros(len(T), 3, device="cuda"); tr = torch.zeros(len(T), 3, device="cuda")
+    gpu.capi.convert_matrices_to_poses(dT, rot, tr, dv)
+    orot, otr = oracle.matrices_to_poses(T, valid)
+    assert np.abs(rot.cpu().numpy() - orot).max() < 2e-6 and np.abs(tr.cpu().numpy() - otr).max() < 2e-6
+    T2 = torch.zeros_like(dT)
+    gpu.capi.convert_poses_to_matrices(rot, tr, T2, dv)
+    oT2 = oracle.poses_to_matrices(orot, otr, valid)
+    assert np.abs(T2.cpu().numpy() - oT2).max() < 2e-6
+    assert not T2.cpu().numpy()[3].any()          # invalid image left untouched (SBA.cu:80,105)
+
+
+def test_cache_store_frame_bit_exact(gpu, oracle):
+    from bundlefusion_amd import synth
+    for (w, h, k) in ((160, 120, 40), (640, 480, 300)):
+        depth, color, T, K = synth.scene_room(k, w, h)
+        depth = depth.copy(); depth[h // 3: h // 3 + 9, w // 2: w // 2 + 30] = -np.inf      # a hole: invalid-neighbour paths
+        Kin = intrinsics_matrix(K["fx"], K["fy"], K["mx"], K["my"])
+        cache = gpu.capi.Cache(w, h, 80, 60, 4, Kin)
+        cache.store_frame(_dev(depth), _dev(color))
+        cache.store_frame(_dev(depth), _dev(color))
+        assert cache.num_frames() == 2
+        g = cache.download_frame(1)
+        o = oracle.cache_store_frame(depth, color, 80, 60, Kin)
+        for key in ("depth", "campos", "normals", "normals_u", "intensity", "derivs"):
+            assert np.array_equal(g[key].view(np.uint8), np.ascontiguousarray(o[key]).view(np.uint8)), (w, key)
+        gw, gh, gk = cache.geometry()
+        assert (gw, gh) == (80, 60)
+        assert np.allclose(gk, [K["fx"] * 80 / w, K["fy"] * 60 / h, K["mx"] * 79 / (w - 1), K["my"] * 59 / (h - 1)], rtol=1e-6)
+
+
+def _solve_both(gpu, oracle, corr, T_init, n_nonlin, n_lin, ws, wd, wc, cache_pair=None, valid=None, find_max=True, record=True):
+    import torch
+    n = len(T_init)
+    valid = np.ones(n, np.int32) if valid is None else valid
+    orot, otr = oracle.matrices_to_poses(T_init)
+    grot, gtr = _dev(orot.copy()), _dev(otr.copy())
+    ocorr = corr.copy()
+    ocache = ogeom = gcache = None
+    if cache_pair is not None:
+        gcache, ocache, ogeom = cache_pair
+    ores = oracle.solver_solve(ocorr, valid, n, n_nonlin, n_lin, ws, wd, wc, orot, otr, cache_frames=ocache, cache_geom=ogeom, dump_dense=ocache is not None)
+    solver = gpu.capi.Solver(max(n, 2), max(len(corr), 1), default_solver_config(record_convergence=record))
+    gcorr = _dev(corr.view(np.uint8)) if len(corr) else None
+    solver.solve(gcorr, len(corr), _dev(valid), n, n_nonlin, n_lin, gcache, ws, wd, wc, grot, gtr, find_max_residual=find_max)
+    return solver, gcorr, ores, (orot, otr), (grot.cpu().numpy(), gtr.cpu().numpy())
+
+
+def test_sparse_solve_matches_oracle(gpu, oracle):
+    for n, seed in ((11, 0), (40, 1), (150, 2)):
+        corr, T_gt, T_init = bs.sparse_problem(n_images=n, pair_prob=min(0.5, 8.0 / n), seed=seed)
+        solver, gcorr, ores, (orot, otr), (grot, gtr) = _solve_both(gpu, oracle, corr, T_init, 3, 150, [1.0] * 3, [0.0] * 3, [0.0] * 3)
+        assert np.abs(grot - orot).max() < 1e-4 and np.abs(gtr - otr).max() < 1e-4, (n, np.abs(grot - orot).max(), np.abs(gtr - otr).max())
+        gn, pcg = solver.iteration_counts()
+        assert gn == ores["gn_iterations"]
+        gconv = np.array(solver.convergence()[: gn + 1]); oconv = ores["convergence"][: gn + 1]
+        assert np.allclose(gconv, oconv, rtol=1e-3, atol=1e-7), (gconv, oconv)
+        assert gconv[-1] < gconv[0]
+        dt, dR = bs.pose_errors(oracle.poses_to_matrices(grot, gtr), T_gt)
+        assert dt < 5e-3 and dR < 5e-3
+        mres, midx = solver.max_residual()
+        assert abs(mres - ores["max_residual"]) < 1e-4
+        assert midx == ores["max_residual_index"] or abs(mres - ores["max_residual"]) < 1e-6
+        assert solver.use_verification(gcorr, len(corr)) == oracle.solver_use_verification(corr, orot, otr, n)
+
+
+def test_outlier_pair_is_reported_for_removal(gpu, oracle):
+    corr, T_gt, T_init = bs.sparse_problem(n_images=14, seed=5, outlier_pair=(3, 12))
+    solver, gcorr, ores, _, _ = _solve_both(gpu, oracle, corr, T_init, 3, 100, [1.0] * 3, [0.0] * 3, [0.0] * 3)
+    pair, mres, remove = solver.max_residual_pair(13, gcorr)
+    assert pair == (3, 12) and remove and mres > 0.08
+    assert solver.use_verification(gcorr, len(corr))
+
+
+def test_invalid_entries_and_run_to_run_determinism(gpu, oracle):
+    corr, T_gt, T_init = bs.sparse_problem(n_images=30, seed=9)
+    corr["imgIdx_i"][::4] = 0xFFFFFFFF
+    corr["imgIdx_j"][::4] = 0xFFFFFFFF
+    corr = corr[np.random.default_rng(0).permutation(len(corr))]          # same pair scattered over many runs
+    a = _solve_both(gpu, oracle, corr, T_init, 3, 100, [1.0] * 3, [0.0] * 3, [0.0] * 3)
+    b = _solve_both(gpu, oracle, corr, T_init, 3, 100, [1.0] * 3, [0.0] * 3, [0.0] * 3)
+    assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1])     # bit-identical re-run (no float atomics)
+    assert np.abs(a[4][0] - a[3][0]).max() < 1e-4 and np.abs(a[4][1] - a[3][1]).max() < 1e-4
+
+
+def _dense_pair(gpu, oracle, n_frames, width=160, height=120, perturb=(0.004, 0.01)):
+    frames, K, T_gt, T_init = bs.dense_chunk(n_frames=n_frames, width=width, height=height, perturb=perturb)
+    Kin = intrinsics_matrix(K["fx"], K["fy"], K["mx"], K["my"])
+    gcache = gpu.capi.Cache(width, height, 80, 60, n_frames, Kin)
+    ocache = []
+    for d, c in frames:
+        gcache.store_frame(_dev(d), _dev(c))
+        ocache.append(oracle.cache_store_frame(d, c, 80, 60, Kin))
+    w, h, k = gcache.geometry()
+    return (gcache, ocache, (w, h, k)), T_gt, T_init
+
+
+def test_dense_system_matches_oracle(gpu, oracle):
+    """One GN iteration, zero PCG effect on the dump: compare the explicit 6N x 6N JtJ / Jtr (reference layout)."""
+    pair, T_gt, T_init = _dense_pair(gpu, oracle, 4)
+    for wd, wc in (([1.0], [0.0]), ([1.0], [0.1]), ([0.0], [0.1])):
+        corr = np.zeros(0, dtype=ENTRYJ_DTYPE)
+        solver, _, ores, _, _ = _solve_both(gpu, oracle, corr, T_init, 1, 1, [0.0], wd, wc, cache_pair=pair, find_max=False, record=False)
+        JtJ, Jtr, npairs = solver.debug_dense_system(4)
+        assert npairs == ores["num_dense_pairs"] == 6
+        scale = np.abs(ores["JtJ"]).max()
+        assert np.abs(JtJ - ores["JtJ"]).max() < 2e-4 * scale, (wd, wc, np.abs(JtJ - ores["JtJ"]).max() / scale)
+        assert np.abs(Jtr - ores["Jtr"]).max() < 2e-4 * np.abs(ores["Jtr"]).max()
+
+
+def test_local_chunk_solve_sparse_plus_dense(gpu, oracle):
+    """The local-chunk configuration: 2 GN x <=100 PCG, sparse weight 1, dense depth weight i+1 (SBA.cpp:28-33)."""
+    n = 5
+    pair, T_gt, T_init = _dense_pair(gpu, oracle, n, perturb=(0.006, 0.015))
+    rng = np.random.default_rng(4)
+    rows = []
+    for i in range(n):
+        for j in range(i + 1, n):
+            pw = rng.uniform(-0.8, 0.8, (15, 3)) + np.array([0, 0, 1.5])
+            for p in pw:
+                ph = np.r_[p, 1.0]
+                rows.append((i, j, (np.linalg.inv(T_gt[i].astype(np.float64)) @ ph)[:3] + rng.normal(0, 0.003, 3),
+                             (np.linalg.inv(T_gt[j].astype(np.float64)) @ ph)[:3] + rng.normal(0, 0.003, 3)))
+    corr = np.zeros(len(rows), dtype=ENTRYJ_DTYPE)
+    for k, (i, j, a, b) in enumerate(rows):
+        corr[k] = (i, j, a.astype(np.float32), b.astype(np.float32))
+    solver, gcorr, ores, (orot, otr), (grot, gtr) = _solve_both(gpu, oracle, corr, T_init, 2, 100, [1.0, 1.0], [1.0, 2.0], [0.0, 0.0], cache_pair=pair)
+    assert np.abs(grot - orot).max() < 1e-4 and np.abs(gtr - otr).max() < 1e-4, (np.abs(grot - orot).max(), np.abs(gtr - otr).max())
+    e0 = bs.pose_errors(T_init, T_gt)
+    e1 = bs.pose_errors(oracle.poses_to_matrices(grot, gtr), T_gt)
+    assert e1[0] < 0.3 * e0[0] and e1[1] < 0.3 * e0[1], (e0, e1)
+    gconv = solver.convergence(); oconv = ores["convergence"]
+    gn, _ = solver.iteration_counts()
+    assert np.allclose(gconv[: gn + 1], oconv[: gn + 1], rtol=1e-3)
+
+
+def test_solver_argument_errors(gpu):
+    from bundlefusion_amd.capi import BFError
+    import torch
+    solver = gpu.capi.Solver(4, 16)
+    z = torch.zeros(4, 3, device="cuda"); v = torch.ones(4, dtype=torch.int32, device="cuda")
+    with pytest.raises(BFError):
+        solver.solve(None, 0, v, 1, 2, 10, None, [1.0, 1.0], [0.0, 0.0], [0.0, 0.0], z, z)       # numberOfImages > 1 (MLIB_ASSERT .cpp:194)
+    with pytest.raises(BFError):
+        solver.solve(None, 0, v, 9, 2, 10, None, [1.0, 1.0], [0.0, 0.0], [0.0, 0.0], z, z)       # exceeds capacity
