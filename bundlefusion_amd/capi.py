@@ -432,3 +432,51 @@ def convert_matrices_to_poses(T, rot, trans, valid, stream=0):
 def convert_poses_to_matrices(rot, trans, T, valid, stream=0):
     check(lib.bf_convert_poses_to_matrices(C.c_void_p(rot.data_ptr()), C.c_void_p(trans.data_ptr()), T.shape[0], C.c_void_p(T.data_ptr()),
                                            C.c_void_p(valid.data_ptr()), C.c_void_p(stream)))
+
+
+# --------------------------------------------------------------------------- SIFT detection
+KEYPOINT_DTYPE = np.dtype([("pos", "<f4", 2), ("scale", "<f4"), ("depth", "<f4")])
+
+
+class Sift:
+    """Python view of `bf_sift` (== the reference's SiftGPU detection object)."""
+
+    def __init__(self, width, height, depth_w, depth_h, feature_count_threshold=150, depth_min=0.1, depth_max=4.0, min_key_scale=3.0,
+                 max_keys=1024, stream=None):
+        self._h = C.c_void_p()
+        self.w, self.h, self.max_keys = width, height, max_keys
+        check(lib.bf_sift_create(width, height, depth_w, depth_h, feature_count_threshold, C.c_float(depth_min), C.c_float(depth_max),
+                                 C.c_float(min_key_scale), max_keys, C.byref(self._h)))
+        if stream is not None:
+            check(lib.bf_sift_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            lib.bf_sift_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, intensity, depth, keys, descs, count):
+        check(lib.bf_sift_run(self._h, C.c_void_p(intensity.data_ptr()), C.c_void_p(depth.data_ptr()), C.c_void_p(keys.data_ptr()),
+                              C.c_void_p(descs.data_ptr()), C.c_void_p(count.data_ptr())))
+
+    def debug_level(self, octave, index):
+        out = np.empty(((self.h >> octave), (self.w >> octave)), dtype=np.float32)
+        check(lib.bf_sift_debug_level(self._h, octave, index, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def debug_counts(self):
+        out = (C.c_int32 * 26)()
+        check(lib.bf_sift_debug_counts(self._h, out))
+        return dict(num_raw=out[0], num_feat=out[1], level0=[out[2 + i] for i in range(12)], level1=[out[14 + i] for i in range(12)])
+
+
+def rgbx_to_intensity(color):
+    """CUDAImageUtil convertToIntensity (CUDAImageUtil.cu:204-207) in float32, same op order."""
+    c = color.astype(np.float32)
+    return ((np.float32(0.299) * c[..., 0] + np.float32(0.587) * c[..., 1]) + np.float32(0.114) * c[..., 2]) / np.float32(255.0)

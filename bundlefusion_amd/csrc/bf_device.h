@@ -32,6 +32,12 @@ BF_HD int f2i(float v) {
     if (v <= -2147483648.0f) return (-2147483647 - 1);
     return (int)v;
 }
+// float -> uint32 toward zero, saturating (negative and NaN -> 0), as v_cvt_u32_f32
+BF_HD uint32_t f2u(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
 BF_HD int sgn(float v) { return (0.0f < v) - (v < 0.0f); }
 
 // row-major 4x4 (reference float4x4 / mat4f memory layout)

@@ -270,6 +270,32 @@ BF_API int bf_convert_matrices_to_poses(const float* d_transforms, uint32_t numT
 BF_API int bf_convert_poses_to_matrices(const float* d_rot, const float* d_trans, uint32_t numImages, float* d_transforms,
                                         const int32_t* d_validImages, void* hip_stream);
 
+/* ------------------------------------------------------------------------- */
+/* SIFT detection:  SiftGPU/SiftGPU.h (detection half of the fork)            */
+/* ------------------------------------------------------------------------- */
+
+/* SIFTKeyPoint, SiftGPU/SIFTImageManager.h:20-24 (16 B); SIFTKeyPointDesc :26-28 (128 B) */
+typedef struct bf_sift_keypoint { float pos[2]; float scale; float depth; } bf_sift_keypoint;
+typedef struct bf_sift_keypoint_desc { uint8_t feature[128]; } bf_sift_keypoint_desc;
+
+typedef struct bf_sift bf_sift; /* == class SiftGPU (+ SiftPyramid) */
+
+/* SiftGPU::SetParams(siftWidth, siftHeight, enableTiming, featureCountThreshold, siftDepthMin, siftDepthMax)
+ * + InitSiftGPU  (SiftGPU.cpp:224-253; Bundler.cpp:57-62 passes threshold 150 and the sensor depth range);
+ * depthWidth/Height and minKeyScale are the SiftCameraParams fields the kernels read
+ * (SiftCameraParams.h, OnlineBundler.cpp:46-56).                                                      */
+BF_API int bf_sift_create(uint32_t siftWidth, uint32_t siftHeight, uint32_t depthWidth, uint32_t depthHeight,
+                          uint32_t featureCountThreshold, float siftDepthMin, float siftDepthMax, float minKeyScale,
+                          uint32_t maxNumKeysPerImage, bf_sift** out);
+BF_API int bf_sift_destroy(bf_sift* s);
+BF_API int bf_sift_set_stream(bf_sift* s, void* hip_stream);
+/* RunSIFT(d_intensity, d_depth) + GetKeyPointsAndDescriptorsCUDA(image, d_depth, max)  SiftGPU.cpp:72-101,267-272.
+ * Asynchronous; *d_numKeys (device int) receives the feature count, or -1 for "too many keypoints".  */
+BF_API int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_depth, float* d_keyPoints, uint8_t* d_descs,
+                       int32_t* d_numKeys);
+BF_API int bf_sift_debug_level(bf_sift* s, uint32_t octave, uint32_t index, float* h_out);
+BF_API int bf_sift_debug_counts(bf_sift* s, int32_t out[26]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,12 @@ inline int f2i(float v) {
     if (v <= -2147483648.0f) return (-2147483647 - 1);
     return (int)v;
 }
+// float -> uint32 toward zero: cvt.rzi.u32.f32 / v_cvt_u32_f32 saturate (negative and NaN -> 0)
+inline uint32_t f2u(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
 // cutil_math.h:31  sign(): (0<v)-(v<0)
 inline int sgn(float v) { return (0.0f < v) - (v < 0.0f); }
 

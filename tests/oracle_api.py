@@ -249,3 +249,27 @@ def poses_to_matrices(rot, trans, valid=None):
     T = np.zeros((n, 4, 4), np.float32)
     olib.or_poses_to_matrices(_fp(np.ascontiguousarray(rot, np.float32)), _fp(np.ascontiguousarray(trans, np.float32)), n, _fp(T), _fp(valid))
     return T
+
+
+# --------------------------------------------------------------------------- SIFT oracle
+def sift_run(intensity, depth, depth_min=0.1, depth_max=4.0, min_key_scale=3.0, feature_count_threshold=150, max_features=1024):
+    intensity = np.ascontiguousarray(intensity, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    H, W = intensity.shape
+    dH, dW = depth.shape
+    keys = np.zeros((max_features, 4), np.float32)
+    descs = np.zeros((max_features, 128), np.uint8)
+    levels = np.zeros(12, np.int32)
+    n = olib.or_sift_run(_fp(intensity), _fp(depth), W, H, dW, dH, C.c_float(depth_min), C.c_float(depth_max), C.c_float(min_key_scale),
+                         feature_count_threshold, max_features, _fp(keys), _fp(descs), _fp(levels))
+    if n < 0:
+        return n, None, None, levels
+    return n, keys[:n].copy(), descs[:n].copy(), levels
+
+
+def sift_pyramid_level(intensity, octave, index):
+    intensity = np.ascontiguousarray(intensity, np.float32)
+    H, W = intensity.shape
+    out = np.zeros((H >> octave, W >> octave), np.float32)
+    olib.or_sift_pyramid_level(_fp(intensity), W, H, octave, index, _fp(out))
+    return out

@@ -1,0 +1,71 @@
+"""GPU parity tests (-m gpu): HIP SIFT detection through the C ABI vs the CPU oracle — bit-exact
+(tol = 0): pyramid levels, feature count per level, keypoint records and all 128 descriptor bytes.
+Both sides evaluate the same IEEE op sequences incl. bf_detmath.h and the same 64-lane summation tree."""
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import rgbx_to_intensity, KEYPOINT_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(gpu, I, d, **kw):
+    import torch
+    H, W = I.shape
+    sift = gpu.capi.Sift(W, H, d.shape[1], d.shape[0], **kw)
+    mk = kw.get("max_keys", 1024)
+    keys = torch.zeros(mk, 4, device="cuda"); descs = torch.zeros(mk, 128, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sift.run(torch.from_numpy(I).cuda(), torch.from_numpy(d).cuda(), keys, descs, cnt)
+    n = int(cnt.item())
+    return sift, n, keys.cpu().numpy()[:max(n, 0)], descs.cpu().numpy()[:max(n, 0)]
+
+
+def test_pyramid_bit_exact(gpu, oracle):
+    d, c, T, K = synth.scene_room(200)
+    I = rgbx_to_intensity(c)
+    sift, n, _, _ = _run_gpu(gpu, I, d)
+    for o in range(4):
+        for a in (0, 1, 3, 5):
+            assert np.array_equal(sift.debug_level(o, a), oracle.sift_pyramid_level(I, o, a)), (o, a)
+
+
+@pytest.mark.parametrize("k", [0, 200, 450, 777])
+def test_features_bit_exact(gpu, oracle, k):
+    d, c, T, K = synth.scene_room(k)
+    I = rgbx_to_intensity(c)
+    sift, n, keys, descs = _run_gpu(gpu, I, d)
+    on, okeys, odescs, olevels = oracle.sift_run(I, d)
+    cnts = sift.debug_counts()
+    assert cnts["level1"] == olevels.tolist()
+    assert n == on > 20
+    assert np.array_equal(keys.view(np.uint32), okeys.view(np.uint32))
+    assert np.array_equal(descs, odescs)
+
+
+def test_no_limit_many_features_and_small_image(gpu, oracle):
+    d, c, T, K = synth.scene_room(300)
+    I = rgbx_to_intensity(c)
+    sift, n, keys, descs = _run_gpu(gpu, I, d, feature_count_threshold=0, max_keys=4096)
+    on, okeys, odescs, _ = oracle.sift_run(I, d, feature_count_threshold=0, max_features=4096)
+    assert n == on > 200
+    assert np.array_equal(keys, okeys) and np.array_equal(descs, odescs)
+    d2, c2, _, _ = synth.scene_room(300, 320, 240)
+    I2 = rgbx_to_intensity(c2)
+    sift2, n2, keys2, descs2 = _run_gpu(gpu, I2, d2)
+    on2, okeys2, odescs2, _ = oracle.sift_run(I2, d2)
+    assert n2 == on2 and np.array_equal(keys2, okeys2) and np.array_equal(descs2, odescs2)
+
+
+def test_invalid_depth_and_overflow(gpu, oracle):
+    d, c, T, K = synth.scene_room(200)
+    I = rgbx_to_intensity(c)
+    _, n0, _, _ = _run_gpu(gpu, I, np.full_like(d, -np.inf))
+    assert n0 == 0
+    d2 = d.copy(); d2[:, 320:] = -np.inf
+    _, n1, keys1, descs1 = _run_gpu(gpu, I, d2)
+    on1, okeys1, odescs1, _ = oracle.sift_run(I, d2)
+    assert n1 == on1 and np.array_equal(keys1, okeys1) and np.array_equal(descs1, odescs1)
+    _, nerr, _, _ = _run_gpu(gpu, I, d, feature_count_threshold=0, max_keys=16)
+    assert nerr == -1
