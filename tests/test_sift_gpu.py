@@ -45,13 +45,13 @@ def test_features_bit_exact(gpu, oracle, k):
 
 
 def test_no_limit_many_features_and_small_image(gpu, oracle):
-    d, c, T, K = synth.scene_room(300)
+    d, c, T, K = synth.scene_room(100)
     I = rgbx_to_intensity(c)
     sift, n, keys, descs = _run_gpu(gpu, I, d, feature_count_threshold=0, max_keys=4096)
     on, okeys, odescs, _ = oracle.sift_run(I, d, feature_count_threshold=0, max_features=4096)
     assert n == on > 200
     assert np.array_equal(keys, okeys) and np.array_equal(descs, odescs)
-    d2, c2, _, _ = synth.scene_room(300, 320, 240)
+    d2, c2, _, _ = synth.scene_room(100, 320, 240)
     I2 = rgbx_to_intensity(c2)
     sift2, n2, keys2, descs2 = _run_gpu(gpu, I2, d2)
     on2, okeys2, odescs2, _ = oracle.sift_run(I2, d2)
