@@ -273,3 +273,57 @@ def sift_pyramid_level(intensity, octave, index):
     out = np.zeros((H >> octave, W >> octave), np.float32)
     olib.or_sift_pyramid_level(_fp(intensity), W, H, octave, index, _fp(out))
     return out
+
+
+# --------------------------------------------------------------------------- match / filter oracle
+def sift_match(d1, d2, distmax=0.7, ratiomax=0.8, off1=0, off2=0, sort=True):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    idx = np.zeros((128, 2), np.uint32); dist = np.zeros(128, np.float32)
+    olib.or_sift_match.restype = C.c_int
+    n = olib.or_sift_match(_fp(d1), len(d1), _fp(d2), len(d2), C.c_float(distmax), C.c_float(ratiomax), off1, off2, _fp(idx), _fp(dist), int(sort))
+    m = min(n, 128)
+    return n, idx[:m].copy(), dist[:m].copy()
+
+
+def filter_matches(keys, idx, dist, n_raw, Kinv, min_matches=5, max_res2=0.0004):
+    keys = np.ascontiguousarray(keys, np.float32)
+    idx = np.ascontiguousarray(idx, np.uint32).copy(); dist = np.ascontiguousarray(dist, np.float32).copy()
+    T = np.zeros((4, 4), np.float32)
+    Kinv = np.ascontiguousarray(Kinv, np.float32)
+    olib.or_filter_keypoint_matches.restype = C.c_int
+    n = olib.or_filter_keypoint_matches(_fp(keys), _fp(idx), _fp(dist), int(n_raw), _fp(Kinv), int(min_matches), C.c_float(max_res2), _fp(T))
+    return n, idx[:n].copy(), dist[:n].copy(), T
+
+
+def filter_surface_area(keys, idx, Kinv, area_thresh=0.032):
+    keys = np.ascontiguousarray(keys, np.float32); idx = np.ascontiguousarray(idx, np.uint32)
+    areas = np.zeros(2, np.float32)
+    olib.or_filter_surface_area.restype = C.c_int
+    ok = olib.or_filter_surface_area(_fp(keys), _fp(idx), len(idx), _fp(np.ascontiguousarray(Kinv, np.float32)), C.c_float(area_thresh), _fp(areas))
+    return bool(ok), areas
+
+
+def dense_verify(fin, fmo, W, H, K, T, dist_thresh=0.15, normal_thresh=0.97, err_thresh=0.075, corr_thresh=0.02, dmin=0.1, dmax=3.0):
+    """fin/fmo: cache-frame dicts (depth, campos, normals) at W x H."""
+    a = [np.ascontiguousarray(fin[k], np.float32) for k in ("depth", "campos", "normals")]
+    b = [np.ascontiguousarray(fmo[k], np.float32) for k in ("depth", "campos", "normals")]
+    err = C.c_float(0); corr = C.c_float(0)
+    olib.or_dense_verify.restype = C.c_int
+    ok = olib.or_dense_verify(*[_fp(x) for x in a], *[_fp(x) for x in b], W, H, _fp(np.ascontiguousarray(K, np.float32)),
+                              _fp(np.ascontiguousarray(T, np.float32)), C.c_float(dist_thresh), C.c_float(normal_thresh), C.c_float(err_thresh),
+                              C.c_float(corr_thresh), C.c_float(dmin), C.c_float(dmax), C.byref(err), C.byref(corr))
+    return bool(ok), err.value, corr.value
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, np.float32)
+    U = np.zeros((3, 3), np.float32); S = np.zeros((3, 3), np.float32); V = np.zeros((3, 3), np.float32)
+    olib.or_svd3(_fp(A), _fp(U), _fp(S), _fp(V))
+    return U, S, V
+
+
+def kabsch(src, tgt):
+    src = np.ascontiguousarray(src, np.float32); tgt = np.ascontiguousarray(tgt, np.float32)
+    T = np.zeros((4, 4), np.float32); ev = np.zeros(3, np.float32)
+    olib.or_kabsch(_fp(src), _fp(tgt), len(src), _fp(T), _fp(ev))
+    return T, ev
