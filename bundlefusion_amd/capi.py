@@ -17,6 +17,12 @@ if not os.path.exists(LIB_PATH):
         "bundlefusion_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(there is no CPU fallback)" % LIB_PATH)
 
+try:
+    # PyTorch ships its own libamdhip64/libhsa-runtime64.  Load it FIRST so that libbf_hip.so binds to the same HIP
+    # runtime (same soname): two runtimes in one process have independent null streams and no mutual ordering.
+    import torch  # noqa: F401
+except ImportError:      # pure C-ABI use without torch is fine: the library then brings /opt/rocm's runtime
+    pass
 lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
 
 SDF_BLOCK_SIZE = 8
@@ -234,15 +240,9 @@ _hip = None
 
 
 def _d2h(ptr, nbytes):
-    """hipMemcpy D2H of a raw device pointer into a fresh numpy byte array."""
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
+    """D2H of a raw device pointer into a fresh numpy byte array (through the library's own runtime, fenced)."""
     out = np.empty(nbytes, dtype=np.uint8)
-    if nbytes:
-        rc = _hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(2))
-        if rc != 0:
-            raise BFError("hipMemcpy D2H failed: %d" % rc)
+    check(lib.bf_memcpy_d2h(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes)))
     return out
 
 
@@ -480,3 +480,192 @@ def rgbx_to_intensity(color):
     """CUDAImageUtil convertToIntensity (CUDAImageUtil.cu:204-207) in float32, same op order."""
     c = color.astype(np.float32)
     return ((np.float32(0.299) * c[..., 0] + np.float32(0.587) * c[..., 1]) + np.float32(0.114) * c[..., 2]) / np.float32(255.0)
+
+
+# --------------------------------------------------------------------------- keypoint / match store
+class SiftImageGPU(C.Structure):
+    _fields_ = [("d_keyPoints", C.c_void_p), ("d_keyPointDescs", C.c_void_p), ("d_numKeyPoints", C.c_void_p)]
+
+
+def _h2d(ptr, arr):
+    arr = np.ascontiguousarray(arr)
+    check(lib.bf_memcpy_h2d(C.c_void_p(ptr), C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)))
+
+
+def _f16(m):
+    return (C.c_float * 16)(*np.asarray(m, np.float32).reshape(16))
+
+
+class SiftManager:
+    """Python view of `bf_siftmgr` (== the reference's SIFTImageManager + the matcher it feeds)."""
+    MAX_RAW, MAX_FILT = 128, 25
+
+    def __init__(self, max_images, max_keys=1024, stream=None):
+        self._h = C.c_void_p()
+        self.max_images, self.max_keys = max_images, max_keys
+        check(lib.bf_siftmgr_create(max_images, max_keys, C.byref(self._h)))
+        if stream is not None:
+            check(lib.bf_siftmgr_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            lib.bf_siftmgr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(lib.bf_siftmgr_reset(self._h))
+
+    def create_image(self):
+        img = SiftImageGPU()
+        check(lib.bf_siftmgr_create_image(self._h, C.byref(img)))
+        return img
+
+    def finalize_image(self, num_keys=-1):
+        check(lib.bf_siftmgr_finalize_image(self._h, int(num_keys)))
+
+    def add_image_host(self, keys, descs):
+        """createSIFTImageGPU + H2D upload + finalize (the fuseToGlobal / loadFromFile way of filling an image)."""
+        img = self.create_image()
+        keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 4); descs = np.ascontiguousarray(descs, np.uint8).reshape(-1, 128)
+        _h2d(img.d_keyPoints, keys); _h2d(img.d_keyPointDescs, descs)
+        self.finalize_image(len(keys))
+
+    def add_image_sift(self, sift, intensity, depth):
+        """detectFeatures (Bundler.cpp:91-101): the detector writes keys, descriptors and the count straight into the store."""
+        img = self.create_image()
+        check(lib.bf_sift_run(sift._h, C.c_void_p(intensity.data_ptr()), C.c_void_p(depth.data_ptr()), C.c_void_p(img.d_keyPoints),
+                              C.c_void_p(img.d_keyPointDescs), C.c_void_p(img.d_numKeyPoints)))
+        self.finalize_image(-1)
+
+    def num_images(self):
+        n = C.c_uint32()
+        check(lib.bf_siftmgr_get_num_images(self._h, C.byref(n)))
+        return n.value
+
+    def num_keypoints(self, first=0, count=None):
+        count = self.num_images() - first if count is None else count
+        out = np.zeros(count, np.int32)
+        check(lib.bf_siftmgr_get_num_keypoints(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def download_image(self, i):
+        img = SiftImageGPU()
+        check(lib.bf_siftmgr_get_image(self._h, i, C.byref(img)))
+        n = max(int(self.num_keypoints(i, 1)[0]), 0)
+        keys = _d2h(img.d_keyPoints, 16 * n).view(np.float32).reshape(n, 4)
+        descs = _d2h(img.d_keyPointDescs, 128 * n).reshape(n, 128)
+        return keys, descs
+
+    def set_current_frame(self, i):
+        check(lib.bf_siftmgr_set_current_frame(self._h, i))
+
+    def current_frame(self):
+        n = C.c_uint32()
+        check(lib.bf_siftmgr_get_current_frame(self._h, C.byref(n)))
+        return n.value
+
+    def match(self, cur, start, num, dist_max=0.7, ratio_max=0.8):
+        check(lib.bf_siftmgr_match(self._h, cur, start, num, C.c_float(dist_max), C.c_float(ratio_max)))
+
+    def filter_keypoint_matches(self, cur, start, num, Kinv, min_matches=5, max_res2=0.0004):
+        check(lib.bf_siftmgr_filter_keypoint_matches(self._h, cur, start, num, _f16(Kinv), min_matches, C.c_float(max_res2)))
+
+    def filter_surface_area(self, cur, start, num, Kinv, area_thresh=0.032):
+        check(lib.bf_siftmgr_filter_matches_by_surface_area(self._h, cur, start, num, _f16(Kinv), C.c_float(area_thresh)))
+
+    def filter_dense_verify(self, cur, start, num, W, H, K, d_frames, dist_thresh=0.15, normal_thresh=0.97, color_thresh=0.1, err_thresh=0.075,
+                            corr_thresh=0.02, dmin=0.1, dmax=3.0):
+        check(lib.bf_siftmgr_filter_matches_by_dense_verify(self._h, cur, start, num, W, H, _f16(K), C.c_void_p(d_frames), C.c_float(dist_thresh),
+                                                            C.c_float(normal_thresh), C.c_float(color_thresh), C.c_float(err_thresh),
+                                                            C.c_float(corr_thresh), C.c_float(dmin), C.c_float(dmax)))
+
+    def filter_frames(self, cur, start, num):
+        last = C.c_uint32()
+        check(lib.bf_siftmgr_filter_frames(self._h, cur, start, num, C.byref(last)))
+        return last.value
+
+    def filter_frames_async(self, cur, start, num):
+        check(lib.bf_siftmgr_filter_frames_async(self._h, cur, start, num))
+
+    def add_curr_to_residuals(self, cur, start, num, Kinv):
+        check(lib.bf_siftmgr_add_curr_to_residuals(self._h, cur, start, num, _f16(Kinv)))
+
+    def sync_frame_result(self, cur):
+        last = C.c_uint32(); nk = C.c_int32()
+        check(lib.bf_siftmgr_sync_frame_result(self._h, cur, C.byref(last), C.byref(nk)))
+        return last.value, nk.value
+
+    def invalidate_image_to_image(self, i, j):
+        check(lib.bf_siftmgr_invalidate_image_to_image(self._h, i, j))
+
+    def check_for_invalid_frames(self, d_num_entries, num_vars, simple=False):
+        f = lib.bf_siftmgr_check_for_invalid_frames_simple if simple else lib.bf_siftmgr_check_for_invalid_frames
+        check(f(self._h, C.c_void_p(d_num_entries), num_vars))
+
+    def verify_trajectory(self, num_images, d_traj, W, H, K, d_frames, dist_thresh=0.15, normal_thresh=0.97, color_thresh=0.1, err_thresh=0.05,
+                          corr_thresh=0.001, dmin=0.1, dmax=3.0):
+        v = C.c_int32()
+        check(lib.bf_siftmgr_verify_trajectory(self._h, num_images, C.c_void_p(d_traj), W, H, _f16(K), C.c_void_p(d_frames), C.c_float(dist_thresh),
+                                               C.c_float(normal_thresh), C.c_float(color_thresh), C.c_float(err_thresh), C.c_float(corr_thresh),
+                                               C.c_float(dmin), C.c_float(dmax), C.byref(v)))
+        return v.value
+
+    def valid_images(self, count=None):
+        count = self.num_images() if count is None else count
+        out = np.zeros(count, np.int32)
+        check(lib.bf_siftmgr_get_valid_images(self._h, out.ctypes.data_as(C.c_void_p), count))
+        return out
+
+    def set_valid_image(self, frame, valid):
+        check(lib.bf_siftmgr_set_valid_image(self._h, frame, int(valid)))
+
+    def update_gpu_valid_images(self):
+        check(lib.bf_siftmgr_update_gpu_valid_images(self._h))
+
+    def valid_images_gpu(self):
+        p = C.c_void_p()
+        check(lib.bf_siftmgr_get_valid_images_gpu(self._h, C.byref(p)))
+        return p.value
+
+    def num_global_correspondences(self):
+        n = C.c_uint32()
+        check(lib.bf_siftmgr_get_num_global_correspondences(self._h, C.byref(n)))
+        return n.value
+
+    def global_correspondences_gpu(self):
+        p = C.c_void_p()
+        check(lib.bf_siftmgr_get_global_correspondences_gpu(self._h, C.byref(p)))
+        return p.value
+
+    def download_global_correspondences(self):
+        n = self.num_global_correspondences()
+        corr = _d2h(self.global_correspondences_gpu(), 32 * n).view(ENTRYJ_DTYPE)
+        p = C.c_void_p()
+        check(lib.bf_siftmgr_get_global_correspondence_keys_gpu(self._h, C.byref(p)))
+        keys = _d2h(p.value, 8 * n).view(np.uint32).reshape(n, 2)
+        return corr, keys
+
+    def set_global_correspondences(self, corr):
+        corr = np.ascontiguousarray(corr)
+        check(lib.bf_siftmgr_set_global_correspondences(self._h, corr.ctypes.data_as(C.c_void_p), len(corr)))
+
+    def raw_matches(self, pair):
+        n = C.c_int32(); idx = np.zeros((128, 2), np.uint32); dist = np.zeros(128, np.float32)
+        check(lib.bf_siftmgr_get_raw_matches(self._h, pair, C.byref(n), idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
+        return n.value, idx, dist
+
+    def filt_matches(self, pair):
+        n = C.c_int32(); idx = np.zeros((25, 2), np.uint32); dist = np.zeros(25, np.float32)
+        T = np.zeros((4, 4), np.float32); Ti = np.zeros((4, 4), np.float32)
+        check(lib.bf_siftmgr_get_filt_matches(self._h, pair, C.byref(n), idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p),
+                                              T.ctypes.data_as(C.c_void_p), Ti.ctypes.data_as(C.c_void_p)))
+        return n.value, idx, dist, T, Ti
+
+    def fuse_to_global(self, glob, K, d_transforms, Kinv):
+        check(lib.bf_siftmgr_fuse_to_global(self._h, glob._h, _f16(K), C.c_void_p(d_transforms), _f16(Kinv)))

@@ -24,13 +24,9 @@
 
 BF_DM_FN float bf_dm_from_bits(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 BF_DM_FN uint32_t bf_dm_bits(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
-BF_DM_FN float bf_dm_sqrt(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return __builtin_sqrtf(x);
-#endif
-}
+/* correctly rounded square root on both sides (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt
+ * expands this to the IEEE sequence; __fsqrt_rn would map to the 1-ulp native instruction) */
+BF_DM_FN float bf_dm_sqrt(float x) { return __builtin_sqrtf(x); }
 
 /* round to nearest integer, ties away from zero, |x| < 2^22 */
 BF_DM_FN float bf_dm_round(float x) { return (float)(int)(x >= 0.0f ? x + 0.5f : x - 0.5f); }

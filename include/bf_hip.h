@@ -41,6 +41,11 @@ BF_API const char* bf_last_error(void);
 BF_API const char* bf_version(void);
 /* number of visible HIP devices, <0 on error (never falls back to a CPU path) */
 BF_API int bf_device_count(void);
+/* Plumbing for hosts that hold raw pointers only: copies / a device-wide fence issued by this library's own HIP
+ * runtime (a process may hold more than one copy of libamdhip64; work is only ordered within one of them). */
+BF_API int bf_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+BF_API int bf_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+BF_API int bf_device_synchronize(void);
 
 /* ------------------------------------------------------------------------- */
 /* Voxel-hash TSDF:  DepthSensing/CUDASceneRepHashSDF.h                       */
@@ -295,6 +300,114 @@ BF_API int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_dept
                        int32_t* d_numKeys);
 BF_API int bf_sift_debug_level(bf_sift* s, uint32_t octave, uint32_t index, float* h_out);
 BF_API int bf_sift_debug_counts(bf_sift* s, int32_t out[26]);
+
+
+/* ------------------------------------------------------------------------- */
+/* Keypoint / match store, matcher, match filters:                            */
+/*   SiftGPU/SIFTImageManager.h, SiftGPU/SiftMatch.h                          */
+/* ------------------------------------------------------------------------- */
+
+/* SIFTImageGPU, SIFTImageManager.h:32-36.  d_numKeyPoints is this library's addition: the key count of an
+ * image stays on the device (bf_sift_run writes it) so detection -> matching needs no host read-back.
+ * Keys of image i start at element i * maxKeyPointsPerImage (fixed stride instead of the reference's packed
+ * prefix-sum layout); key indices in matches / correspondences are indices into that array.            */
+typedef struct bf_sift_image_gpu {
+    bf_sift_keypoint* d_keyPoints;
+    bf_sift_keypoint_desc* d_keyPointDescs;
+    int32_t* d_numKeyPoints;
+} bf_sift_image_gpu;
+
+typedef struct bf_siftmgr bf_siftmgr; /* == class SIFTImageManager (+ the SiftMatchGPU it feeds) */
+
+/* SIFTImageManager(maxImages, maxKeyPointsPerImage)            SIFTImageManager.cpp:7-15, alloc :274-313 */
+BF_API int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_siftmgr** out);
+BF_API int bf_siftmgr_destroy(bf_siftmgr* m);
+BF_API int bf_siftmgr_set_stream(bf_siftmgr* m, void* hip_stream);
+BF_API int bf_siftmgr_reset(bf_siftmgr* m);                                      /* reset()  .h:112-124 */
+/* createSIFTImageGPU / finalizeSIFTImageGPU(numKeyPoints)     .cpp:44-75.  numKeyPoints < 0: keep the count the
+ * detector wrote to d_numKeyPoints.                                                                   */
+BF_API int bf_siftmgr_create_image(bf_siftmgr* m, bf_sift_image_gpu* out);
+BF_API int bf_siftmgr_finalize_image(bf_siftmgr* m, int32_t numKeyPoints);
+BF_API int bf_siftmgr_get_image(bf_siftmgr* m, uint32_t imageIdx, bf_sift_image_gpu* out);          /* getImageGPU */
+BF_API int bf_siftmgr_get_num_images(bf_siftmgr* m, uint32_t* out);
+BF_API int bf_siftmgr_get_max_num_keypoints_per_image(bf_siftmgr* m, uint32_t* out);
+BF_API int bf_siftmgr_get_current_frame(bf_siftmgr* m, uint32_t* out);
+BF_API int bf_siftmgr_set_current_frame(bf_siftmgr* m, uint32_t idx);
+/* getNumKeyPointsPerImage for images [first, first+count) — D2H + sync */
+BF_API int bf_siftmgr_get_num_keypoints(bf_siftmgr* m, uint32_t first, uint32_t count, int32_t* h_out);
+
+/* The per-pair loop of Bundler::matchAndFilter (Bundler.cpp:117-136): SiftMatchGPU::GetSiftMatch
+ * (SiftMatch.cpp:160-196, ProgramCU.cu:1634-1936) of image curFrame against every image in
+ * [startFrame, numFrames) \ {curFrame}, followed by SortKeyPointMatchesCU (SIFTImageManager.cu:59-143).
+ * Pairs whose previous image is invalid or has no keys get 0 matches.  One launch, asynchronous.        */
+BF_API int bf_siftmgr_match(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames, float distMax,
+                            float ratioMax);
+/* FilterKeyPointMatchesCU                                      SIFTImageManager.cu:186-316 */
+BF_API int bf_siftmgr_filter_keypoint_matches(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames,
+                                              const float siftIntrinsicsInv[16], uint32_t minNumMatches,
+                                              float maxKabschRes2);
+/* FilterMatchesBySurfaceAreaCU                                 :318-416 */
+BF_API int bf_siftmgr_filter_matches_by_surface_area(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame,
+                                                     uint32_t numFrames, const float colorIntrinsicsInv[16],
+                                                     float areaThresh);
+/* FilterMatchesByDenseVerifyCU                                 :418-608 */
+BF_API int bf_siftmgr_filter_matches_by_dense_verify(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame,
+                                                     uint32_t numFrames, uint32_t imageWidth, uint32_t imageHeight,
+                                                     const float intrinsics[16], const bf_cached_frame* d_cachedFrames,
+                                                     float distThresh, float normalThresh, float colorThresh,
+                                                     float errThresh, float corrThresh, float sensorDepthMin,
+                                                     float sensorDepthMax);
+/* filterFrames                                                 SIFTImageManager.cpp:551-575 (syncs, returns the
+ * last matched frame or 0xFFFFFFFF).  The _async form only enqueues the decision; it is read back together with
+ * the residual count by bf_siftmgr_sync_frame_result (one D2H per frame).                              */
+BF_API int bf_siftmgr_filter_frames(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames,
+                                    uint32_t* lastMatchedFrame);
+BF_API int bf_siftmgr_filter_frames_async(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames);
+/* AddCurrToResidualsCU                                         SIFTImageManager.cu:610-690.  Skipped on the device
+ * when curFrame was not connected (Bundler.cpp:218-219); pairs are appended in ascending previous-image order. */
+BF_API int bf_siftmgr_add_curr_to_residuals(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames,
+                                            const float colorIntrinsicsInv[16]);
+BF_API int bf_siftmgr_sync_frame_result(bf_siftmgr* m, uint32_t curFrame, uint32_t* lastMatchedFrame,
+                                        int32_t* numKeyPointsCur);
+/* InvalidateImageToImageCU / CheckForInvalidFrames[Simple]CU   :692-795 */
+BF_API int bf_siftmgr_invalidate_image_to_image(bf_siftmgr* m, uint32_t imageIdx_i, uint32_t imageIdx_j);
+BF_API int bf_siftmgr_check_for_invalid_frames_simple(bf_siftmgr* m, const int32_t* d_varToCorrNumEntriesPerRow,
+                                                      uint32_t numVars);
+BF_API int bf_siftmgr_check_for_invalid_frames(bf_siftmgr* m, const int32_t* d_varToCorrNumEntriesPerRow,
+                                               uint32_t numVars);
+/* VerifyTrajectoryCU                                           :1036-1159 */
+BF_API int bf_siftmgr_verify_trajectory(bf_siftmgr* m, uint32_t numImages, const float* d_trajectory, uint32_t imageWidth,
+                                        uint32_t imageHeight, const float intrinsics[16],
+                                        const bf_cached_frame* d_cachedFrames, float distThresh, float normalThresh,
+                                        float colorThresh, float errThresh, float corrThresh, float sensorDepthMin,
+                                        float sensorDepthMax, int32_t* valid);
+/* getValidImages / invalidateFrame / updateGPUValidImages / getValidImagesGPU   .h:157-163 */
+BF_API int bf_siftmgr_get_valid_images(bf_siftmgr* m, int32_t* h_out, uint32_t count);
+BF_API int bf_siftmgr_set_valid_image(bf_siftmgr* m, uint32_t frame, int32_t valid);
+BF_API int bf_siftmgr_update_gpu_valid_images(bf_siftmgr* m);
+BF_API int bf_siftmgr_get_valid_images_gpu(bf_siftmgr* m, const int32_t** d_out);
+/* getGlobalCorrespondencesGPU / getNumGlobalCorrespondences / setGlobalCorrespondencesDEBUG   .h:182-188,251-253 */
+BF_API int bf_siftmgr_get_global_correspondences_gpu(bf_siftmgr* m, bf_entry_j** d_out);
+BF_API int bf_siftmgr_get_global_correspondence_keys_gpu(bf_siftmgr* m, const uint32_t** d_out /* uint2 per entry */);
+BF_API int bf_siftmgr_get_num_global_correspondences(bf_siftmgr* m, uint32_t* out);
+BF_API int bf_siftmgr_set_global_correspondences(bf_siftmgr* m, const bf_entry_j* h_corr, uint32_t n);
+/* getFiltTransformsToWorldGPU (= d_currFilteredTransformsInv) / getNumFiltMatchesGPU   .h:254-255 */
+BF_API int bf_siftmgr_get_filt_transforms_gpu(bf_siftmgr* m, const float** d_transforms, const float** d_transformsInv);
+BF_API int bf_siftmgr_get_num_filt_matches_gpu(bf_siftmgr* m, const int32_t** d_out);
+BF_API int bf_siftmgr_get_keys_gpu(bf_siftmgr* m, const bf_sift_keypoint** d_keys, const bf_sift_keypoint_desc** d_descs,
+                                   const int32_t** d_numKeys);
+/* get{Raw,Filt}KeyPointIndicesAndMatchDistancesDEBUG           .h:212-235 (128 / 25 slots are copied) */
+BF_API int bf_siftmgr_get_raw_matches(bf_siftmgr* m, uint32_t imagePairIndex, int32_t* numMatches,
+                                      uint32_t* h_keyPointIndices, float* h_distances);
+BF_API int bf_siftmgr_get_filt_matches(bf_siftmgr* m, uint32_t imagePairIndex, int32_t* numMatches,
+                                       uint32_t* h_keyPointIndices, float* h_distances, float* h_transform,
+                                       float* h_transformInv);
+/* addToRetryList / getTopRetryImage                            .h:263-271 */
+BF_API int bf_siftmgr_add_to_retry_list(bf_siftmgr* m, uint32_t idx);
+BF_API int bf_siftmgr_get_top_retry_image(bf_siftmgr* m, uint32_t* idx, int* found);
+/* fuseToGlobal(global, colorIntrinsics, d_transforms, colorIntrinsicsInv)   SIFTImageManager.cpp:367-476 */
+BF_API int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16],
+                                     const float* d_transforms, const float colorIntrinsicsInv[16]);
 
 #ifdef __cplusplus
 }

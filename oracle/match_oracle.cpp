@@ -541,3 +541,11 @@ void or_kabsch(const float* src3, const float* tgt3, int n, float* T16, float* e
 }
 
 }  // extern "C"
+
+extern "C" {
+void or_inverse44(const float* T16, float* out16) { m44 T; memcpy(T.e, T16, 64); const m44 r = inverse(T); memcpy(out16, r.e, 64); }
+void or_mul44(const float* A16, const float* B16, float* out16) {
+    m44 A, B; memcpy(A.e, A16, 64); memcpy(B.e, B16, 64);
+    const m44 r = mul(A, B); memcpy(out16, r.e, 64);
+}
+}

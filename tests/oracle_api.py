@@ -327,3 +327,23 @@ def kabsch(src, tgt):
     T = np.zeros((4, 4), np.float32); ev = np.zeros(3, np.float32)
     olib.or_kabsch(_fp(src), _fp(tgt), len(src), _fp(T), _fp(ev))
     return T, ev
+
+
+def inverse44(T):
+    T = np.ascontiguousarray(T, np.float32); out = np.zeros((4, 4), np.float32)
+    olib.or_inverse44(_fp(T), _fp(out))
+    return out
+
+
+def mul44(A, B):
+    A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32); out = np.zeros((4, 4), np.float32)
+    olib.or_mul44(_fp(A), _fp(B), _fp(out))
+    return out
+
+
+def make_entry(keys, ix, iy, img_i, img_j, Kinv):
+    from bundlefusion_amd.capi import ENTRYJ_DTYPE
+    e = np.zeros(1, ENTRYJ_DTYPE)
+    olib.or_make_entry(_fp(np.ascontiguousarray(keys, np.float32)), int(ix), int(iy), int(img_i), int(img_j),
+                       _fp(np.ascontiguousarray(Kinv, np.float32)), _fp(e))
+    return e[0]

@@ -1,0 +1,243 @@
+"""GPU parity tests (-m gpu): descriptor matching, the three match filters, frame filtering and the global
+correspondence list, through the C ABI (bf_siftmgr_*) against the CPU oracle — bit-exact (tol = 0): match index
+pairs and distances, filtered sets, the 4x4 Kabsch transforms and their inverses, filter decisions, EntryJ rows."""
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import rgbx_to_intensity, intrinsics_matrix, ENTRYJ_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit_descs(rng, n):
+    d = np.abs(rng.normal(size=(n, 128)))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.clip(np.floor(d * 512 + 0.5), 0, 255).astype(np.uint8)
+
+
+def _oracle_match(oracle, mgr, descs, prev, cur, **kw):
+    n, idx, dist = oracle.sift_match(descs[prev], descs[cur], off1=prev * mgr.max_keys, off2=cur * mgr.max_keys, **kw)
+    return n, idx, dist
+
+
+@pytest.mark.parametrize("sizes", [(90, 85, 300), (1024, 1000, 17), (16, 15, 1), (513, 64, 129)])
+def test_matcher_random_descriptors_bit_exact(gpu, oracle, sizes):
+    rng = np.random.default_rng(sum(sizes))
+    mgr = gpu.capi.SiftManager(len(sizes) + 1, 1024)
+    base = _unit_descs(rng, 1024)
+    descs = []
+    for n in sizes:
+        sel = rng.permutation(1024)[:n]
+        d = base[sel].astype(int) + rng.integers(-3, 4, (n, 128))
+        d = np.clip(d, 0, 255).astype(np.uint8)
+        if n > 40:
+            d[5] = d[6]                               # exact duplicates: ties in best / second best
+            d[n // 2] = 255                           # saturated descriptor: dot products beyond 2^18
+            d[n // 3] = 0                             # all-zero descriptor
+        descs.append(d)
+    cur = _unit_descs(rng, 700)
+    cur[:600] = np.clip(base[:600].astype(int) + rng.integers(-2, 3, (600, 128)), 0, 255)
+    cur[650] = cur[651]
+    descs.append(cur)
+    for d in descs:
+        mgr.add_image_host(np.zeros((len(d), 4), np.float32), d)
+    c = len(descs) - 1
+    for k in range(c):
+        mgr.set_valid_image(k, 1)
+    mgr.update_gpu_valid_images()
+    mgr.match(c, 0, c + 1)
+    for prev in range(c):
+        n, idx, dist = mgr.raw_matches(prev)
+        on, oidx, odist = _oracle_match(oracle, mgr, descs, prev, c)
+        assert n == on, (prev, n, on)
+        m = min(n, 128)
+        assert np.array_equal(idx[:m], oidx) and np.array_equal(dist[:m].view(np.uint32), odist.view(np.uint32)), prev
+    # a tighter ratio / distance threshold changes the accepted set the same way on both sides
+    mgr.match(c, 0, c + 1, dist_max=0.3, ratio_max=0.6)
+    n, idx, dist = mgr.raw_matches(0)
+    on, oidx, odist = _oracle_match(oracle, mgr, descs, 0, c, distmax=0.3, ratiomax=0.6)
+    assert n == on and np.array_equal(idx[:min(n, 128)], oidx)
+    # invalid previous image and empty images give zero matches
+    mgr.set_valid_image(0, 0); mgr.update_gpu_valid_images()
+    mgr.match(c, 0, c + 1)
+    assert mgr.raw_matches(0)[0] == 0 and mgr.raw_matches(1)[0] == _oracle_match(oracle, mgr, descs, 1, c)[0]
+
+
+def _chunk(gpu, n_frames, stride, first=30, w=640, h=480):
+    import torch
+    frames = [synth.scene_room(first + k * stride, w, h) for k in range(n_frames)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    sift = gpu.capi.Sift(w, h, w, h)
+    mgr = gpu.capi.SiftManager(n_frames + 1, 1024)
+    cache = gpu.capi.Cache(w, h, 80, 60, n_frames + 1, K)
+    for d, c, T, _ in frames:
+        I = torch.from_numpy(rgbx_to_intensity(c)).cuda(); dd = torch.from_numpy(d).cuda(); cc = torch.from_numpy(c).cuda()
+        mgr.add_image_sift(sift, I, dd)
+        cache.store_frame(dd, cc)
+    torch.cuda.synchronize()
+    return frames, K, sift, mgr, cache
+
+
+def test_match_and_filter_chain_bit_exact(gpu, oracle):
+    import torch
+    n_frames = 5
+    frames, K, sift, mgr, cache = _chunk(gpu, n_frames, 5)
+    Kinv = oracle.inverse44(K)
+    nk = mgr.num_keypoints()
+    assert (nk > 30).all()
+    img = [mgr.download_image(i) for i in range(n_frames)]
+    # the stored keys are the detector's output (bit-exact with the oracle detector)
+    for i in (0, n_frames - 1):
+        d, c = frames[i][0], frames[i][1]
+        on, okeys, odescs, _ = oracle.sift_run(rgbx_to_intensity(c), d)
+        assert on == nk[i] and np.array_equal(img[i][0], okeys) and np.array_equal(img[i][1], odescs)
+    mk = mgr.max_keys
+    allkeys = np.zeros((n_frames * mk, 4), np.float32)
+    for i in range(n_frames):
+        allkeys[i * mk:i * mk + nk[i]] = img[i][0]
+    gw, gh, gk = cache.geometry()
+    Kc = intrinsics_matrix(*gk)
+    oframes = [oracle.cache_store_frame(f[0], f[1], 80, 60, K) for f in frames]
+    ocorr = []
+    valid = [1] + [0] * (n_frames - 1)
+    for cur in range(1, n_frames):
+        for k in range(cur):                                   # validImages as the sequence so far left them
+            mgr.set_valid_image(k, valid[k])
+        mgr.update_gpu_valid_images()
+        mgr.set_current_frame(cur)
+        num = cur + 1
+        mgr.match(cur, 0, num)
+        mgr.filter_keypoint_matches(cur, 0, num, Kinv)
+        raw = [mgr.raw_matches(p) for p in range(cur)]
+        filt1 = [mgr.filt_matches(p) for p in range(cur)]
+        mgr.filter_surface_area(cur, 0, num, Kinv)
+        filt2 = [mgr.filt_matches(p)[0] for p in range(cur)]
+        mgr.filter_dense_verify(cur, 0, num, 80, 60, Kc, cache.frames_gpu())
+        filt3 = [mgr.filt_matches(p)[0] for p in range(cur)]
+        mgr.filter_frames_async(cur, 0, num)
+        mgr.add_curr_to_residuals(cur, 0, num, Kinv)
+        last, nkc = mgr.sync_frame_result(cur)
+        assert nkc == nk[cur]
+        exp_last = -1
+        for p in range(cur):
+            descs_p, descs_c = img[p][1], img[cur][1]
+            on, oidx, odist = (0, None, None) if not valid[p] else oracle.sift_match(descs_p, descs_c, off1=p * mk, off2=cur * mk)
+            n, idx, dist = raw[p]
+            assert n == on, (cur, p)
+            if on == 0:
+                assert filt1[p][0] == 0
+                continue
+            m = min(n, 128)
+            assert np.array_equal(idx[:m], oidx) and np.array_equal(dist[:m].view(np.uint32), odist.view(np.uint32))
+            pidx = np.zeros((128, 2), np.uint32); pidx[:m] = oidx
+            pdist = np.zeros(128, np.float32); pdist[:m] = odist
+            fn, fidx, fdist, fT = oracle.filter_matches(allkeys, pidx, pdist, m, Kinv)
+            gn, gidx, gdist, gT, gTi = filt1[p]
+            assert gn == fn, (cur, p, gn, fn)
+            assert np.array_equal(gidx[:fn], fidx) and np.array_equal(gdist[:fn].view(np.uint32), fdist.view(np.uint32))
+            assert np.array_equal(gT.view(np.uint32), fT.view(np.uint32))
+            assert np.array_equal(gTi.view(np.uint32), oracle.inverse44(fT).view(np.uint32))
+            if fn == 0:
+                continue
+            ok_area, _ = oracle.filter_surface_area(allkeys, fidx, Kinv)
+            assert (filt2[p] > 0) == ok_area
+            if not ok_area:
+                continue
+            ok_dense, err, corr = oracle.dense_verify(oframes[p], oframes[cur], 80, 60, Kc, fT, dmin=0.1, dmax=3.0)
+            assert (filt3[p] > 0) == ok_dense, (cur, p, err, corr)
+            if ok_dense:
+                exp_last = p
+                for k in range(fn):
+                    ocorr.append(oracle.make_entry(allkeys, fidx[k, 0], fidx[k, 1], p, cur, Kinv))
+        valid[cur] = 1 if exp_last >= 0 else 0
+        assert last == (exp_last & 0xFFFFFFFF)
+        assert mgr.valid_images(num).tolist() == valid[:num]
+        assert mgr.num_global_correspondences() == len(ocorr)
+    assert len(ocorr) > 40                                     # the chain actually produced correspondences
+    corr, ckeys = mgr.download_global_correspondences()
+    ocorr = np.array(ocorr, dtype=ENTRYJ_DTYPE)
+    assert np.array_equal(corr.view(np.uint8), ocorr.view(np.uint8))
+    # relative poses of the filter agree with the ground-truth camera motion
+    _, _, _, gT, _ = mgr.filt_matches(n_frames - 2)
+    rel = np.linalg.inv(frames[-1][2].astype(np.float64)) @ frames[-2][2].astype(np.float64)
+    assert np.abs(gT - rel).max() < 0.02
+
+    # invalidate one image pair, then the frame check (reference launch arithmetic, SIFTImageManager.cu:725-749)
+    mgr.invalidate_image_to_image(0, 1)
+    corr2, _ = mgr.download_global_correspondences()
+    sel = (ocorr["imgIdx_i"] == 0) & (ocorr["imgIdx_j"] == 1)
+    assert sel.any() and (corr2["imgIdx_i"][sel] == 0xFFFFFFFF).all(), (np.nonzero(sel)[0].tolist(), corr2["imgIdx_i"].tolist(), corr2["imgIdx_j"].tolist())
+    assert np.array_equal(corr2[~sel].view(np.uint8), ocorr[~sel].view(np.uint8))
+    rows = torch.tensor([3, 0, 2, 0, 1], dtype=torch.int32, device="cuda")
+    mgr.check_for_invalid_frames(rows.data_ptr(), n_frames)
+    assert mgr.valid_images(n_frames).tolist() == [v if r else 0 for v, r in zip(valid, [3, 0, 2, 0, 1])]
+
+    # VerifyTrajectory with the ground-truth poses (valid) and with one pose pushed away (invalid)
+    for k in range(n_frames):
+        mgr.set_valid_image(k, 1)
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    traj = np.stack([(T0inv @ f[2].astype(np.float64)).astype(np.float32) for f in frames])
+    dtraj = torch.from_numpy(traj).cuda()
+    assert mgr.verify_trajectory(n_frames, dtraj.data_ptr(), 80, 60, Kc, cache.frames_gpu()) == 1
+    exp = 1
+    for blk in range(n_frames * (n_frames - 1) // 2):          # the reference's pair decoding, quirk included
+        i0, i1 = blk // n_frames, blk % n_frames
+        if i0 >= i1:
+            continue
+        T = oracle.mul44(oracle.inverse44(traj[i1]), traj[i0])
+        ok, _, _ = oracle.dense_verify(oframes[i0], oframes[i1], 80, 60, Kc, T, err_thresh=0.05, corr_thresh=0.001)
+        exp &= int(ok)
+    assert exp == 1
+    traj[1, 0, 3] += 0.5
+    dtraj = torch.from_numpy(traj).cuda()
+    assert mgr.verify_trajectory(n_frames, dtraj.data_ptr(), 80, 60, Kc, cache.frames_gpu()) == 0
+
+
+def test_fuse_to_global_tracks(gpu, oracle):
+    """fuseToGlobal (SIFTImageManager.cpp:367-476): hand-built correspondences -> tracks -> one key per track."""
+    import torch
+    rng = np.random.default_rng(5)
+    K = intrinsics_matrix(583.0, 583.0, 319.5, 239.5)
+    Kinv = oracle.inverse44(K)
+    loc = gpu.capi.SiftManager(4, 64); glob = gpu.capi.SiftManager(8, 64)
+    nI, per = 3, 6
+    T = [np.eye(4, dtype=np.float32) for _ in range(nI)]
+    T[1][0, 3] = 0.1; T[2][1, 3] = -0.05
+    P = np.c_[rng.uniform(-0.5, 0.5, per), rng.uniform(-0.4, 0.4, per), rng.uniform(1.5, 2.5, per)].astype(np.float32)   # world points
+    keys, descs = [], []
+    for i in range(nI):
+        pc = (np.linalg.inv(T[i].astype(np.float64)) @ np.c_[P, np.ones(per)].T).T[:, :3]
+        uv = (K[:3, :3].astype(np.float64) @ pc.T).T
+        k = np.c_[uv[:, 0] / uv[:, 2], uv[:, 1] / uv[:, 2], np.full(per, 3.0 + i), pc[:, 2]].astype(np.float32)
+        keys.append(k); descs.append(rng.integers(0, 255, (per, 128)).astype(np.uint8))
+        loc.add_image_host(k, descs[-1])
+    corr = []
+    ck = []
+    def add(i, a, j, b, off=0.0):
+        pa = oracle.make_entry(np.concatenate(keys), i * per + a, j * per + b, i, j, Kinv)
+        if off:
+            pa["pos_j"] = pa["pos_j"] + np.float32(off)
+        corr.append(pa); ck.append((i * 64 + a, j * 64 + b))
+    add(0, 0, 1, 0); add(1, 0, 2, 0); add(0, 1, 2, 1); add(0, 2, 1, 2, off=0.2); add(1, 3, 2, 3)
+    corr = np.array(corr, dtype=ENTRYJ_DTYPE)
+    loc.set_global_correspondences(corr)
+    # the key-index side table is filled by AddCurrToResiduals in real runs; write it directly here
+    import ctypes as C
+    from bundlefusion_amd.capi import lib, check, _h2d
+    p = C.c_void_p(); check(lib.bf_siftmgr_get_global_correspondence_keys_gpu(loc._h, C.byref(p)))
+    _h2d(p.value, np.array(ck, np.uint32))
+    dT = torch.from_numpy(np.stack(T)).cuda()
+    loc.fuse_to_global(glob, K, dT.data_ptr(), Kinv)
+    assert glob.num_images() == 1
+    gk, gd = glob.download_image(0)
+    # tracks in key order: {img0 key0: (1,0),(2,0)}, {img0 key1: (2,1)}, {img0 key2: only an outlier corr -> dropped}, {img1 key3: (2,3)}
+    assert len(gk) == 3
+    exp_pts = [P[0], P[1], P[3]]
+    for k, pw in zip(gk, exp_pts):
+        uv = K[:3, :3].astype(np.float64) @ pw
+        assert abs(k[0] - uv[0] / uv[2]) < 0.05 and abs(k[1] - uv[1] / uv[2]) < 0.05 and abs(k[3] - pw[2]) < 1e-3
+    # representative descriptor/scale = first element of the track
+    assert np.array_equal(gd[0], descs[1][0]) and gk[0][2] == 4.0
+    assert np.array_equal(gd[1], descs[2][1]) and np.array_equal(gd[2], descs[2][3])
