@@ -138,9 +138,9 @@ class SceneRepHashSDF:
             self.set_stream(stream)
 
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             lib.bf_scene_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -669,3 +669,171 @@ class SiftManager:
 
     def fuse_to_global(self, glob, K, d_transforms, Kinv):
         check(lib.bf_siftmgr_fuse_to_global(self._h, glob._h, _f16(K), C.c_void_p(d_transforms), _f16(Kinv)))
+
+
+# --------------------------------------------------------------------------- host-level operators (include/bf_pipeline.h)
+class GlobalAppState(C.Structure):
+    _fields_ = [
+        ("s_sensorIdx", C.c_uint32), ("s_integrationWidth", C.c_uint32), ("s_integrationHeight", C.c_uint32),
+        ("s_maxFrameFixes", C.c_uint32), ("s_topNActive", C.c_uint32), ("s_minPoseDistSqrt", C.c_float),
+        ("s_sensorDepthMax", C.c_float), ("s_sensorDepthMin", C.c_float), ("s_renderDepthMax", C.c_float), ("s_renderDepthMin", C.c_float),
+        ("s_hashNumBuckets", C.c_uint32), ("s_hashNumSDFBlocks", C.c_uint32), ("s_hashMaxCollisionLinkedListSize", C.c_uint32),
+        ("s_SDFVoxelSize", C.c_float), ("s_SDFTruncation", C.c_float), ("s_SDFTruncationScale", C.c_float), ("s_SDFMaxIntegrationDistance", C.c_float),
+        ("s_SDFIntegrationWeightSample", C.c_uint32), ("s_SDFIntegrationWeightMax", C.c_uint32),
+        ("s_colorSigmaD", C.c_float), ("s_colorSigmaR", C.c_float), ("s_colorFilter", C.c_int32),
+        ("s_integrationEnabled", C.c_int32), ("s_garbageCollectionEnabled", C.c_int32), ("s_reconstructionEnabled", C.c_int32), ("s_streamingEnabled", C.c_int32),
+        ("s_bUseCameraCalibration", C.c_int32), ("s_binaryDumpSensorUseTrajectory", C.c_int32), ("s_garbageCollectionStarve", C.c_uint32),
+        ("s_streamingVoxelExtents", C.c_float * 3), ("s_streamingGridDimensions", C.c_int32 * 3), ("s_streamingMinGridPos", C.c_int32 * 3),
+        ("s_streamingInitialChunkListSize", C.c_uint32), ("s_numSolveFramesBeforeExit", C.c_uint32),
+    ]
+
+
+class GlobalBundlingState(C.Structure):
+    _fields_ = [
+        ("s_enableGlobalTimings", C.c_int32), ("s_enablePerFrameTimings", C.c_int32),
+        ("s_maxNumImages", C.c_uint32), ("s_submapSize", C.c_uint32), ("s_widthSIFT", C.c_uint32), ("s_heightSIFT", C.c_uint32), ("s_maxNumKeysPerImage", C.c_uint32),
+        ("s_numLocalNonLinIterations", C.c_uint32), ("s_numLocalLinIterations", C.c_uint32), ("s_numGlobalNonLinIterations", C.c_uint32),
+        ("s_numGlobalLinIterations", C.c_uint32), ("s_downsampledWidth", C.c_uint32), ("s_downsampledHeight", C.c_uint32),
+        ("s_verifySiftErrThresh", C.c_float), ("s_verifySiftCorrThresh", C.c_float), ("s_projCorrDistThres", C.c_float), ("s_projCorrNormalThres", C.c_float),
+        ("s_projCorrColorThresh", C.c_float), ("s_surfAreaPcaThresh", C.c_float),
+        ("s_recordSolverConvergence", C.c_int32), ("s_erodeSIFTdepth", C.c_int32),
+        ("s_verifyOptErrThresh", C.c_float), ("s_verifyOptCorrThresh", C.c_float),
+        ("s_verbose", C.c_int32), ("s_sendUplinkFeedbackImage", C.c_int32),
+        ("s_depthSigmaD", C.c_float), ("s_depthSigmaR", C.c_float), ("s_depthFilter", C.c_int32),
+        ("s_minNumMatchesLocal", C.c_uint32), ("s_minNumMatchesGlobal", C.c_uint32), ("s_useComprehensiveFrameInvalidation", C.c_int32),
+        ("s_maxKabschResidual2", C.c_float), ("s_minKeyScale", C.c_float), ("s_siftMatchThresh", C.c_float), ("s_siftMatchRatioMaxLocal", C.c_float),
+        ("s_siftMatchRatioMaxGlobal", C.c_float),
+        ("s_useLocalVerify", C.c_int32), ("s_useLocalDense", C.c_int32), ("s_numOptPerResidualRemoval", C.c_uint32),
+        ("s_colorDownSigma", C.c_float), ("s_depthDownSigmaD", C.c_float), ("s_depthDownSigmaR", C.c_float),
+        ("s_optMaxResThresh", C.c_float), ("s_denseDistThresh", C.c_float), ("s_denseNormalThresh", C.c_float), ("s_denseColorThresh", C.c_float),
+        ("s_denseColorGradientMin", C.c_float), ("s_denseDepthMin", C.c_float), ("s_denseDepthMax", C.c_float),
+        ("s_denseOverlapCheckSubsampleFactor", C.c_uint32),
+    ]
+
+
+class RGBDSensorDesc(C.Structure):
+    _fields_ = [("depthWidth", C.c_uint32), ("depthHeight", C.c_uint32), ("colorWidth", C.c_uint32), ("colorHeight", C.c_uint32),
+                ("depthIntrinsics", C.c_float * 16), ("colorIntrinsics", C.c_float * 16), ("depthExtrinsics", C.c_float * 16), ("colorExtrinsics", C.c_float * 16)]
+
+
+class FrameTiming(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("timeSensorProcess", "timeSiftDetection", "timeSiftMatching", "timeMatchFilter", "timeSolve", "timeReIntegrate",
+                                         "timeReconstruct", "timeTotal")]
+
+
+def default_app_state(path=None):
+    g = GlobalAppState()
+    if path is None:
+        check(lib.bf_global_app_state_default(C.byref(g)))
+    else:
+        check(lib.bf_global_app_state_read(path.encode(), C.byref(g), None))
+    return g
+
+
+def default_bundling_state(path=None):
+    g = GlobalBundlingState()
+    if path is None:
+        check(lib.bf_global_bundling_state_default(C.byref(g)))
+    else:
+        check(lib.bf_global_bundling_state_read(path.encode(), C.byref(g), None))
+    return g
+
+
+def sensor_desc(width, height, K):
+    """A sensor whose depth and colour cameras coincide (identity extrinsics), intrinsics K (4x4)."""
+    s = RGBDSensorDesc()
+    s.depthWidth = s.colorWidth = width
+    s.depthHeight = s.colorHeight = height
+    k = np.asarray(K, np.float32).reshape(16)
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    for i in range(16):
+        s.depthIntrinsics[i] = s.colorIntrinsics[i] = float(k[i])
+        s.depthExtrinsics[i] = s.colorExtrinsics[i] = float(eye[i])
+    return s
+
+
+class Pipeline:
+    """Python view of `bf_pipeline`: the serial frame loop of DepthSensing.cpp (ingest -> bundling input -> re-integration ->
+    integration of the current frame -> local / global optimisation)."""
+
+    def __init__(self, gas, gbs, sensor):
+        self._h = C.c_void_p()
+        self.gas, self.gbs, self.sensor = gas, gbs, sensor
+        check(lib.bf_pipeline_create(C.byref(gas), C.byref(gbs), C.byref(sensor), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.bf_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_frame(self, depth, color):
+        """depth float32 (H,W), color uint8 (H,W,4): host numpy arrays (PCIe path) or torch cuda tensors (HBM-resident path)."""
+        got = C.c_int()
+        if isinstance(depth, np.ndarray):
+            depth = np.ascontiguousarray(depth, np.float32); color = np.ascontiguousarray(color, np.uint8)
+            check(lib.bf_pipeline_process_frame(self._h, depth.ctypes.data_as(C.c_void_p), color.ctypes.data_as(C.c_void_p), C.byref(got)))
+        else:
+            check(lib.bf_pipeline_process_frame_device(self._h, C.c_void_p(depth.data_ptr()), C.c_void_p(color.data_ptr()), C.byref(got)))
+        return bool(got.value)
+
+    def process_end_of_sequence(self):
+        n = C.c_uint32()
+        check(lib.bf_pipeline_process_end_of_sequence(self._h, C.byref(n)))
+        return n.value
+
+    def synchronize(self):
+        check(lib.bf_pipeline_synchronize(self._h))
+
+    def num_frames(self):
+        n = C.c_uint32()
+        check(lib.bf_pipeline_get_num_frames(self._h, C.byref(n)))
+        return n.value
+
+    def integrated_trajectory(self):
+        n = self.num_frames()
+        out = np.zeros((max(n, 1), 4, 4), np.float32); cnt = C.c_uint32()
+        check(lib.bf_pipeline_get_integrated_trajectory(self._h, out.ctypes.data_as(C.c_void_p), n, C.byref(cnt)))
+        return out[:cnt.value]
+
+    def optimized_trajectory(self):
+        ob = C.c_void_p(); tm = C.c_void_p()
+        check(lib.bf_pipeline_get_online_bundler(self._h, C.byref(ob)))
+        check(lib.bf_online_bundler_get_trajectory_manager(ob, C.byref(tm)))
+        n = self.num_frames()
+        out = np.zeros((max(n, 1), 4, 4), np.float32); cnt = C.c_uint32()
+        check(lib.bf_trajectory_manager_get_optimized_transforms(tm, out.ctypes.data_as(C.c_void_p), n, C.byref(cnt)))
+        return out[:cnt.value]
+
+    def counters(self):
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib.bf_pipeline_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(integrate=a.value, deintegrate=b.value, local_solves=c.value, global_solves=d.value)
+
+    def enable_timings(self, on=True):
+        check(lib.bf_pipeline_enable_timings(self._h, int(on)))
+
+    def last_timing(self):
+        t = FrameTiming()
+        check(lib.bf_pipeline_get_last_timing(self._h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in FrameTiming._fields_}
+
+    def scene(self):
+        """Borrowed SceneRepHashSDF view of the pipeline's voxel-hash volume."""
+        h = C.c_void_p()
+        check(lib.bf_pipeline_get_scene(self._h, C.byref(h)))
+        s = SceneRepHashSDF.__new__(SceneRepHashSDF)
+        s._h = h; s._borrowed = True
+        hp = HashParams(); check(lib.bf_scene_get_hash_params(h, C.byref(hp))); s.params = hp
+        return s
+
+    def bundler(self, which):
+        ob = C.c_void_p(); b = C.c_void_p()
+        check(lib.bf_pipeline_get_online_bundler(self._h, C.byref(ob)))
+        check(lib.bf_online_bundler_get_bundler(ob, {"local": 0, "optLocal": 1, "global": 2}[which], C.byref(b)))
+        return b

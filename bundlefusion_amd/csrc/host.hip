@@ -1,0 +1,1371 @@
+// Host-level operators of the hot path: CUDAImageManager, Bundler (+ the SBA wrapper), TrajectoryManager, OnlineBundler and
+// the headless frame loop, behind the C ABI of include/bf_pipeline.h.  Control flow follows the reference
+// (CUDAImageManager.cpp, Bundler.cpp, SBA.cpp, OnlineBundler.cpp/.cu, TrajectoryManager.cpp, DepthSensing.cpp:723-762,
+// :854-902, :966-1095; paths relative to /root/reference/FriedLiver/Source); the execution model is the MI355X one:
+//  * one HIP stream carries a frame from ingest to integration; the only host read-back per frame is a 96-byte record
+//    (last matched frame, validity, #residuals, #keys, SIFT pose) — the reference blocks on ~20 small D2H copies per frame;
+//  * all frames stay resident in HBM at integration resolution (the reference keeps them on the host and re-uploads a
+//    frame for every integrate / de-integrate), slab-allocated so that ingest never calls hipMalloc in steady state;
+//  * bundling reads the ingest buffers in place (the reference's copyToBundling makes three device-to-device copies per
+//    frame because its bundler lives on a second GPU).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <limits>
+#include <list>
+#include <vector>
+
+#include "../../include/bf_pipeline.h"
+#include "bf_device.h"
+#include "bf_internal.h"
+#include "bf_se3.h"
+
+using namespace bf;
+
+#define BF_TRY(expr) do { int _rc = (expr); if (_rc != BF_OK) return _rc; } while (0)
+
+namespace {
+
+const float NINF = -std::numeric_limits<float>::infinity();
+
+m44 toM(const float* p) { m44 m; memcpy(m.e, p, 64); return m; }
+m44 minfM() { m44 m; for (int i = 0; i < 16; ++i) m.e[i] = NINF; return m; }
+
+// intrinsics rescale rule of CUDAImageManager.h:162-168 / OnlineBundlerHelper.h:46-50
+m44 scaleIntrinsics(const float* K, uint32_t wOut, uint32_t hOut, uint32_t wIn, uint32_t hIn) {
+    m44 m = toM(K);
+    m.e[0] *= (float)wOut / (float)wIn;
+    m.e[5] *= (float)hOut / (float)hIn;
+    m.e[2] *= (float)(wOut - 1) / (float)(wIn - 1);
+    m.e[6] *= (float)(hOut - 1) / (float)(hIn - 1);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------ OnlineBundler.cu
+__global__ void k_sift_transform(uint32_t curFrameIndex, const m44* completeTrajectory, uint32_t lastValidCompleteTransform, m44* siftTrajectory,
+                                 uint32_t curFrameIndexAll, const int* numFilt, const m44* filteredTransformsInv, m44* currIntegrateTrans) {   // :5-52
+    for (int i = (int)curFrameIndex - 1; i >= 0; i--) {
+        if (numFilt[i] > 0) {
+            const uint32_t idxPrevSiftKnown = curFrameIndexAll - (curFrameIndex - (uint32_t)i);
+            const m44 cur = mul44(siftTrajectory[idxPrevSiftKnown], filteredTransformsInv[i]);
+            siftTrajectory[curFrameIndexAll] = cur;
+            m44 transform;
+            if (lastValidCompleteTransform == 0) transform = cur;
+            else if (idxPrevSiftKnown < lastValidCompleteTransform) transform = mul44(completeTrajectory[idxPrevSiftKnown], filteredTransformsInv[i]);
+            else {
+                const m44 offset = mul44(inverse44(siftTrajectory[lastValidCompleteTransform]), siftTrajectory[idxPrevSiftKnown]);
+                transform = mul44(mul44(completeTrajectory[lastValidCompleteTransform], offset), filteredTransformsInv[i]);
+            }
+            currIntegrateTrans[0] = transform;
+            break;
+        }
+    }
+}
+
+__global__ void k_update_trajectory(const m44* globalTrajectory, m44* completeTrajectory, uint32_t numCompleteTransforms, const m44* localTrajectories,
+                                    uint32_t numLocalTransformsPerTrajectory, const int* imageInvalidateList) {      // :73-92
+    const uint32_t idxComplete = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t submapSize = numLocalTransformsPerTrajectory - 1;
+    if (idxComplete < numCompleteTransforms) {
+        const uint32_t idxGlobal = idxComplete / submapSize, idxLocal = idxComplete % submapSize;
+        m44 r;
+        if (imageInvalidateList[idxComplete] == 0) { for (int i = 0; i < 16; ++i) r.e[i] = BF_MINF; }
+        else r = mul44(globalTrajectory[idxGlobal], localTrajectories[idxGlobal * numLocalTransformsPerTrajectory + idxLocal]);
+        completeTrajectory[idxComplete] = r;
+    }
+}
+
+__global__ void k_init_next_global(m44* globalTrajectory, uint32_t numGlobalTransforms, uint32_t initGlobalIdx, const m44* localTrajectories,
+                                   uint32_t lastValidLocal, uint32_t numLocalTransformsPerTrajectory) {              // :116-126
+    globalTrajectory[numGlobalTransforms] =
+        mul44(globalTrajectory[initGlobalIdx], localTrajectories[numGlobalTransforms * numLocalTransformsPerTrajectory - (numLocalTransformsPerTrajectory - lastValidLocal)]);
+}
+
+__global__ void k_fill_identity(m44* T, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) T[i] = identity44();
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_compute_sift_transform(const float* d_currFilteredTransformsInv, const int32_t* d_numFilt, const float* d_completeTrajectory,
+                              uint32_t lastValidCompleteTransform, float* d_siftTrajectory, uint32_t curFrameIndexAll, uint32_t curFrameIndex,
+                              float* d_currIntegrateTrans, void* stream) {
+    if (curFrameIndex == 0) return BF_OK;
+    BF_REQUIRE(d_currFilteredTransformsInv && d_numFilt && d_completeTrajectory && d_siftTrajectory && d_currIntegrateTrans, "null argument");
+    k_sift_transform<<<1, 1, 0, (hipStream_t)stream>>>(curFrameIndex, (const m44*)d_completeTrajectory, lastValidCompleteTransform, (m44*)d_siftTrajectory,
+                                                      curFrameIndexAll, d_numFilt, (const m44*)d_currFilteredTransformsInv, (m44*)d_currIntegrateTrans);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+int bf_update_trajectory(const float* d_globalTrajectory, uint32_t numGlobalTransforms, float* d_completeTrajectory, uint32_t numCompleteTransforms,
+                         const float* d_localTrajectories, uint32_t numLocalTransformsPerTrajectory, uint32_t numLocalTrajectories,
+                         const int32_t* d_imageInvalidateList, void* stream) {
+    (void)numGlobalTransforms; (void)numLocalTrajectories;
+    if (numCompleteTransforms == 0) return BF_OK;
+    BF_REQUIRE(d_globalTrajectory && d_completeTrajectory && d_localTrajectories && d_imageInvalidateList && numLocalTransformsPerTrajectory > 1, "bad argument");
+    k_update_trajectory<<<div_up(numCompleteTransforms, 128), 128, 0, (hipStream_t)stream>>>((const m44*)d_globalTrajectory, (m44*)d_completeTrajectory,
+                                                                                           numCompleteTransforms, (const m44*)d_localTrajectories,
+                                                                                           numLocalTransformsPerTrajectory, d_imageInvalidateList);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+int bf_init_next_global_transform(float* d_globalTrajectory, uint32_t numGlobalTransforms, uint32_t initGlobalIdx, const float* d_localTrajectories,
+                                  uint32_t lastValidLocal, uint32_t numLocalTransformsPerTrajectory, void* stream) {
+    BF_REQUIRE(d_globalTrajectory && d_localTrajectories && numGlobalTransforms >= 1, "bad argument");
+    k_init_next_global<<<1, 1, 0, (hipStream_t)stream>>>((m44*)d_globalTrajectory, numGlobalTransforms, initGlobalIdx, (const m44*)d_localTrajectories,
+                                                        lastValidLocal, numLocalTransformsPerTrajectory);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================ CUDAImageManager
+struct bf_image_manager {
+    bf_rgbd_sensor_desc sensor;
+    bf_global_bundling_state gbs;
+    uint32_t wInt = 0, hInt = 0, wSIFT = 0, hSIFT = 0;
+    bool onGPU = true;
+    hipStream_t stream = nullptr;
+    m44 depthIntrinsics, depthIntrinsicsInv, colorIntrinsics, colorIntrinsicsInv, depthExtrinsics, depthExtrinsicsInv, siftDepthIntrinsics;
+    float *d_depthInputRaw = nullptr, *d_depthInputFiltered = nullptr;
+    uint8_t* d_colorInput = nullptr;
+    // frames at integration resolution: slabs of SLAB frames in HBM (onGPU) or host vectors + one staging pair (reference default)
+    static const uint32_t SLAB = 256;
+    std::vector<float*> depthSlabs; std::vector<uint8_t*> colorSlabs;
+    std::vector<std::vector<float>> hostDepth; std::vector<std::vector<uint8_t>> hostColor;
+    float* d_stageDepth = nullptr; uint8_t* d_stageColor = nullptr;
+    int activeDepth = -1, activeColor = -1;
+    uint32_t currFrame = 0;
+    size_t nInt() const { return (size_t)wInt * hInt; }
+};
+
+extern "C" {
+
+int bf_image_manager_create(uint32_t wInt, uint32_t hInt, uint32_t wSIFT, uint32_t hSIFT, const bf_rgbd_sensor_desc* sensor,
+                            const bf_global_bundling_state* gbs, int storeFramesOnGPU, bf_image_manager** out) {
+    BF_REQUIRE(sensor && gbs && out, "null argument");
+    BF_REQUIRE(wInt > 1 && hInt > 1 && sensor->depthWidth > 1 && sensor->depthHeight > 1 && sensor->colorWidth > 1 && sensor->colorHeight > 1, "bad image size");
+    bf_image_manager* im = new bf_image_manager;
+    im->sensor = *sensor; im->gbs = *gbs;
+    im->wInt = wInt; im->hInt = hInt; im->wSIFT = wSIFT; im->hSIFT = hSIFT; im->onGPU = storeFramesOnGPU != 0;
+    im->siftDepthIntrinsics = toM(sensor->depthIntrinsics);
+    im->depthIntrinsics = scaleIntrinsics(sensor->depthIntrinsics, wInt, hInt, sensor->depthWidth, sensor->depthHeight);
+    im->depthIntrinsicsInv = inverse44(im->depthIntrinsics);
+    im->colorIntrinsics = scaleIntrinsics(sensor->colorIntrinsics, wInt, hInt, sensor->colorWidth, sensor->colorHeight);
+    im->colorIntrinsicsInv = inverse44(im->colorIntrinsics);
+    im->depthExtrinsics = toM(sensor->depthExtrinsics);
+    im->depthExtrinsicsInv = inverse44(im->depthExtrinsics);
+    const size_t nd = (size_t)sensor->depthWidth * sensor->depthHeight, nc = (size_t)sensor->colorWidth * sensor->colorHeight;
+    BF_HIP_TRY(hipMalloc((void**)&im->d_depthInputRaw, nd * 4));
+    BF_HIP_TRY(hipMalloc((void**)&im->d_depthInputFiltered, nd * 4));
+    BF_HIP_TRY(hipMalloc((void**)&im->d_colorInput, nc * 4));
+    if (!im->onGPU) {
+        BF_HIP_TRY(hipMalloc((void**)&im->d_stageDepth, im->nInt() * 4));
+        BF_HIP_TRY(hipMalloc((void**)&im->d_stageColor, im->nInt() * 4));
+    }
+    *out = im;
+    return BF_OK;
+}
+
+int bf_image_manager_reset(bf_image_manager* im) {
+    BF_REQUIRE(im, "null manager");
+    (void)hipStreamSynchronize(im->stream);
+    for (auto p : im->depthSlabs) (void)hipFree(p);
+    for (auto p : im->colorSlabs) (void)hipFree(p);
+    im->depthSlabs.clear(); im->colorSlabs.clear(); im->hostDepth.clear(); im->hostColor.clear();
+    im->activeDepth = im->activeColor = -1;
+    im->currFrame = 0;
+    return BF_OK;
+}
+
+int bf_image_manager_destroy(bf_image_manager* im) {
+    if (!im) return BF_OK;
+    bf_image_manager_reset(im);
+    (void)hipFree(im->d_depthInputRaw); (void)hipFree(im->d_depthInputFiltered); (void)hipFree(im->d_colorInput);
+    (void)hipFree(im->d_stageDepth); (void)hipFree(im->d_stageColor);
+    delete im;
+    return BF_OK;
+}
+
+int bf_image_manager_set_stream(bf_image_manager* im, void* s) { BF_REQUIRE(im, "null manager"); im->stream = (hipStream_t)s; return BF_OK; }
+
+static int im_process(bf_image_manager* im, const float* depth, const uint8_t* color, hipMemcpyKind kind, int* gotFrame) {
+    BF_REQUIRE(im && gotFrame, "null argument");
+    *gotFrame = 0;
+    if (!depth || !color) return BF_OK;                     // sensor->processDepth()/processColor() returned false
+    if (im->currFrame + 1 > im->gbs.s_maxNumImages * im->gbs.s_submapSize) return BF_OK;      // .cpp:26-29 "reached max #images"
+    const bf_rgbd_sensor_desc& sn = im->sensor;
+    const size_t nd = (size_t)sn.depthWidth * sn.depthHeight, nc = (size_t)sn.colorWidth * sn.colorHeight, ni = im->nInt();
+    hipStream_t st = im->stream;
+    const uint32_t f = im->currFrame;
+    float* frameDepth = nullptr; uint8_t* frameColor = nullptr;
+    if (im->onGPU) {
+        if (f / bf_image_manager::SLAB >= im->depthSlabs.size()) {
+            float* pd = nullptr; uint8_t* pc = nullptr;
+            BF_HIP_TRY(hipMalloc((void**)&pd, ni * 4 * bf_image_manager::SLAB));
+            BF_HIP_TRY(hipMalloc((void**)&pc, ni * 4 * bf_image_manager::SLAB));
+            im->depthSlabs.push_back(pd); im->colorSlabs.push_back(pc);
+        }
+        frameDepth = im->depthSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni;
+        frameColor = im->colorSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni * 4;
+    } else {
+        im->hostDepth.emplace_back(ni); im->hostColor.emplace_back(ni * 4);
+    }
+    // ---- colour  (.cpp:39-60)
+    BF_HIP_TRY(hipMemcpyAsync(im->d_colorInput, color, nc * 4, kind, st));
+    const bool sameC = sn.colorWidth == im->wInt && sn.colorHeight == im->hInt;
+    uint8_t* colorDst = im->onGPU ? frameColor : im->d_stageColor;
+    if (sameC) BF_HIP_TRY(hipMemcpyAsync(colorDst, im->d_colorInput, ni * 4, hipMemcpyDeviceToDevice, st));
+    else BF_TRY(bf_image_resample_uchar4(colorDst, im->wInt, im->hInt, im->d_colorInput, sn.colorWidth, sn.colorHeight, st));
+    // ---- depth  (.cpp:66-112): two 7x7 erosions ping-pong (the twice-eroded map ends in d_depthInputRaw), then the range-gated Gaussian
+    BF_HIP_TRY(hipMemcpyAsync(im->d_depthInputRaw, depth, nd * 4, kind, st));
+    if (im->gbs.s_erodeSIFTdepth) {
+        BF_TRY(bf_image_erode_depth_map(im->d_depthInputFiltered, im->d_depthInputRaw, 3, sn.depthWidth, sn.depthHeight, 0.05f, 0.3f, st));
+        BF_TRY(bf_image_erode_depth_map(im->d_depthInputRaw, im->d_depthInputFiltered, 3, sn.depthWidth, sn.depthHeight, 0.05f, 0.3f, st));
+    }
+    if (im->gbs.s_depthFilter) BF_TRY(bf_image_gauss_filter_depth_map(im->d_depthInputFiltered, im->d_depthInputRaw, im->gbs.s_depthSigmaD, im->gbs.s_depthSigmaR,
+                                                                     sn.depthWidth, sn.depthHeight, st));
+    else BF_HIP_TRY(hipMemcpyAsync(im->d_depthInputFiltered, im->d_depthInputRaw, nd * 4, hipMemcpyDeviceToDevice, st));
+    // ---- integration-resolution depth (.cpp:121-147): the filtered map, or the sensor's own samples when erosion is off
+    const bool sameD = sn.depthWidth == im->wInt && sn.depthHeight == im->hInt;
+    float* depthDst = im->onGPU ? frameDepth : im->d_stageDepth;
+    if (sameD) BF_HIP_TRY(hipMemcpyAsync(depthDst, im->gbs.s_erodeSIFTdepth ? im->d_depthInputFiltered : im->d_depthInputRaw, ni * 4, hipMemcpyDeviceToDevice, st));
+    else BF_TRY(bf_image_resample_float(depthDst, im->wInt, im->hInt, im->d_depthInputFiltered, sn.depthWidth, sn.depthHeight, st));
+    if (!im->onGPU) {
+        BF_HIP_TRY(hipMemcpyAsync(im->hostDepth.back().data(), im->d_stageDepth, ni * 4, hipMemcpyDeviceToHost, st));
+        BF_HIP_TRY(hipMemcpyAsync(im->hostColor.back().data(), im->d_stageColor, ni * 4, hipMemcpyDeviceToHost, st));
+        BF_HIP_TRY(hipStreamSynchronize(st));
+        im->activeDepth = im->activeColor = (int)f;
+    }
+    im->currFrame++;
+    *gotFrame = 1;
+    return BF_OK;
+}
+
+int bf_image_manager_process(bf_image_manager* im, const float* h_depth, const uint8_t* h_color, int* gotFrame) {
+    return im_process(im, h_depth, h_color, hipMemcpyHostToDevice, gotFrame);
+}
+int bf_image_manager_process_device(bf_image_manager* im, const float* d_depth, const uint8_t* d_color, int* gotFrame) {
+    return im_process(im, d_depth, d_color, hipMemcpyDeviceToDevice, gotFrame);
+}
+
+int bf_image_manager_copy_to_bundling(bf_image_manager* im, float* d_depthRaw, float* d_depthFilt, uint8_t* d_color) {
+    BF_REQUIRE(im && d_depthRaw && d_depthFilt && d_color, "null argument");
+    const size_t nd = (size_t)im->sensor.depthWidth * im->sensor.depthHeight, nc = (size_t)im->sensor.colorWidth * im->sensor.colorHeight;
+    BF_HIP_TRY(hipMemcpyAsync(d_depthRaw, im->d_depthInputRaw, nd * 4, hipMemcpyDeviceToDevice, im->stream));
+    BF_HIP_TRY(hipMemcpyAsync(d_depthFilt, im->d_depthInputFiltered, nd * 4, hipMemcpyDeviceToDevice, im->stream));
+    BF_HIP_TRY(hipMemcpyAsync(d_color, im->d_colorInput, nc * 4, hipMemcpyDeviceToDevice, im->stream));
+    return BF_OK;
+}
+
+int bf_image_manager_get_input_gpu(bf_image_manager* im, const float** raw, const float** filt, const uint8_t** color) {
+    BF_REQUIRE(im, "null manager");
+    if (raw) *raw = im->d_depthInputRaw;
+    if (filt) *filt = im->d_depthInputFiltered;
+    if (color) *color = im->d_colorInput;
+    return BF_OK;
+}
+
+int bf_image_manager_get_integrate_frame_gpu(bf_image_manager* im, uint32_t frame, const float** d_depth, const uint8_t** d_color) {
+    BF_REQUIRE(im && d_depth && d_color && frame < im->currFrame, "frame out of range");
+    const size_t ni = im->nInt();
+    if (im->onGPU) {
+        *d_depth = im->depthSlabs[frame / bf_image_manager::SLAB] + (size_t)(frame % bf_image_manager::SLAB) * ni;
+        *d_color = im->colorSlabs[frame / bf_image_manager::SLAB] + (size_t)(frame % bf_image_manager::SLAB) * ni * 4;
+    } else {                                       // one frame globally valid on the GPU at a time (.h:71-96)
+        if (im->activeDepth != (int)frame) { BF_HIP_TRY(hipMemcpyAsync(im->d_stageDepth, im->hostDepth[frame].data(), ni * 4, hipMemcpyHostToDevice, im->stream)); im->activeDepth = (int)frame; }
+        if (im->activeColor != (int)frame) { BF_HIP_TRY(hipMemcpyAsync(im->d_stageColor, im->hostColor[frame].data(), ni * 4, hipMemcpyHostToDevice, im->stream)); im->activeColor = (int)frame; }
+        *d_depth = im->d_stageDepth; *d_color = im->d_stageColor;
+    }
+    return BF_OK;
+}
+
+int bf_image_manager_get_curr_frame_number(bf_image_manager* im, uint32_t* out) {
+    BF_REQUIRE(im && out, "null argument");
+    BF_REQUIRE(im->currFrame > 0, "getCurrFrameNumber before the first process()");
+    *out = im->currFrame - 1;
+    return BF_OK;
+}
+int bf_image_manager_get_num_frames(bf_image_manager* im, uint32_t* out) { BF_REQUIRE(im && out, "null argument"); *out = im->currFrame; return BF_OK; }
+int bf_image_manager_get_integration_size(bf_image_manager* im, uint32_t* w, uint32_t* h) { BF_REQUIRE(im && w && h, "null argument"); *w = im->wInt; *h = im->hInt; return BF_OK; }
+int bf_image_manager_get_depth_intrinsics(bf_image_manager* im, float K[16], float Kinv[16]) {
+    BF_REQUIRE(im, "null manager");
+    if (K) memcpy(K, im->depthIntrinsics.e, 64);
+    if (Kinv) memcpy(Kinv, im->depthIntrinsicsInv.e, 64);
+    return BF_OK;
+}
+int bf_image_manager_get_depth_extrinsics(bf_image_manager* im, float E[16], float Einv[16]) {
+    BF_REQUIRE(im, "null manager");
+    if (E) memcpy(E, im->depthExtrinsics.e, 64);
+    if (Einv) memcpy(Einv, im->depthExtrinsicsInv.e, 64);
+    return BF_OK;
+}
+int bf_image_manager_get_sift_depth(bf_image_manager* im, uint32_t* w, uint32_t* h, float K[16]) {
+    BF_REQUIRE(im, "null manager");
+    if (w) *w = im->sensor.depthWidth;
+    if (h) *h = im->sensor.depthHeight;
+    if (K) memcpy(K, im->siftDepthIntrinsics.e, 64);
+    return BF_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================ Bundler (+ SBA)
+struct bf_bundler {
+    bf_global_app_state gas; bf_global_bundling_state gbs;
+    uint32_t maxImages = 0, maxKeys = 0;
+    bool isLocal = true;
+    hipStream_t stream = nullptr;
+    bf_sift* sift = nullptr; bf_siftmgr* mgr = nullptr; bf_cache* cache = nullptr; bf_solver* solver = nullptr;
+    m44 siftIntrinsics, siftIntrinsicsInv;
+    m44* d_trajectory = nullptr;
+    float *d_xRot = nullptr, *d_xTrans = nullptr;
+    int continueRetry = 0;
+    uint32_t revalidatedIdx = 0xFFFFFFFFu;
+    // SBA state (SBA.cpp:20-51)
+    std::vector<float> localWS, localWD, localWC, globalWS, globalWD, globalWC;
+    bool useGlobalDenseOpt = false, useLocalDense = true, comprehensive = false, sbaVerify = false;
+    float maxResidual = -1.0f;
+    uint32_t numSolves = 0;
+    std::vector<int> validScratch;
+};
+
+namespace {
+
+int bundlerValid(bf_bundler* b, std::vector<int>& v, uint32_t n) {
+    v.assign(std::max<uint32_t>(n, 1), 0);
+    return bf_siftmgr_get_valid_images(b->mgr, v.data(), n);
+}
+
+int cacheK(bf_bundler* b, uint32_t& w, uint32_t& h, float k4[4], m44& K) {
+    BF_TRY(bf_cache_get_geometry(b->cache, &w, &h, k4));
+    K = identity44();
+    K.e[0] = k4[0]; K.e[5] = k4[1]; K.e[2] = k4[2]; K.e[6] = k4[3];
+    return BF_OK;
+}
+
+// the asynchronous half of Bundler::matchAndFilter (:103-221): everything up to the read-back of the frame result
+int matchAndFilterEnqueue(bf_bundler* b, uint32_t& curFrame, uint32_t& startFrame, uint32_t& numFrames) {
+    BF_TRY(bf_siftmgr_get_num_images(b->mgr, &numFrames));
+    BF_REQUIRE(numFrames > 1, "matchAndFilter needs more than one frame");
+    BF_TRY(bf_siftmgr_get_current_frame(b->mgr, &curFrame));
+    startFrame = numFrames == curFrame + 1 ? 0 : curFrame + 1;
+    const float ratioMax = b->isLocal ? b->gbs.s_siftMatchRatioMaxLocal : b->gbs.s_siftMatchRatioMaxGlobal;
+    BF_TRY(bf_siftmgr_update_gpu_valid_images(b->mgr));
+    BF_TRY(bf_siftmgr_match(b->mgr, curFrame, startFrame, numFrames, b->gbs.s_siftMatchThresh, ratioMax));
+    if (curFrame > 0) {
+        const uint32_t minNumMatches = b->isLocal ? b->gbs.s_minNumMatchesLocal : b->gbs.s_minNumMatchesGlobal;
+        BF_TRY(bf_siftmgr_filter_keypoint_matches(b->mgr, curFrame, startFrame, numFrames, b->siftIntrinsicsInv.e, minNumMatches, b->gbs.s_maxKabschResidual2));
+        BF_TRY(bf_siftmgr_filter_matches_by_surface_area(b->mgr, curFrame, startFrame, numFrames, b->siftIntrinsicsInv.e, b->gbs.s_surfAreaPcaThresh));
+        uint32_t cw, ch; float k4[4]; m44 K;
+        BF_TRY(cacheK(b, cw, ch, k4, K));
+        const bf_cached_frame* d_frames = nullptr;
+        BF_TRY(bf_cache_get_frames_gpu(b->cache, &d_frames));
+        BF_TRY(bf_siftmgr_filter_matches_by_dense_verify(b->mgr, curFrame, startFrame, numFrames, cw, ch, K.e, d_frames, b->gbs.s_projCorrDistThres,
+                                                         b->gbs.s_projCorrNormalThres, b->gbs.s_projCorrColorThresh, b->gbs.s_verifySiftErrThresh,
+                                                         b->gbs.s_verifySiftCorrThresh, b->gas.s_sensorDepthMin, b->gas.s_sensorDepthMax));
+        BF_TRY(bf_siftmgr_filter_frames_async(b->mgr, curFrame, startFrame, numFrames));
+        BF_TRY(bf_siftmgr_add_curr_to_residuals(b->mgr, curFrame, startFrame, numFrames, b->siftIntrinsicsInv.e));
+    }
+    return BF_OK;
+}
+
+int tryRevalidation(bf_bundler* b, uint32_t curGlobalFrame, bool bIsScanDone, uint32_t* out);
+
+// the host half after the read-back (:223-248)
+int matchAndFilterFinish(bf_bundler* b, uint32_t curFrame, uint32_t numFrames, uint32_t* lastMatchedFrame) {
+    *lastMatchedFrame = 0xFFFFFFFFu;
+    if (curFrame == 0) return BF_OK;
+    uint32_t last = 0xFFFFFFFFu; int32_t numKeysCur = 0;
+    BF_TRY(bf_siftmgr_sync_frame_result(b->mgr, curFrame, &last, &numKeysCur));
+    if (numKeysCur < 0) { set_error("too many keypoints"); return BF_ERR_CAPACITY; }       // Bundler.cpp:98
+    if (numKeysCur == 0) return BF_OK;                                                     // :115 (nothing was matched; the frame stays invalid)
+    *lastMatchedFrame = last;
+    if (!b->isLocal) {
+        if (last != 0xFFFFFFFFu && last + 1 != curFrame) {                                  // re-initialise from the last match (:224-227)
+            BF_HIP_TRY(hipMemcpyAsync(b->d_trajectory + curFrame, b->d_trajectory + last, sizeof(m44), hipMemcpyDeviceToDevice, b->stream));
+            if (curFrame + 1 < b->maxImages) BF_HIP_TRY(hipMemcpyAsync(b->d_trajectory + curFrame + 1, b->d_trajectory + last, sizeof(m44), hipMemcpyDeviceToDevice, b->stream));
+        }
+        if (curFrame + 1 == numFrames) {
+            if (last != 0xFFFFFFFFu) { uint32_t r; BF_TRY(tryRevalidation(b, curFrame, false, &r)); }
+            else BF_TRY(bf_siftmgr_add_to_retry_list(b->mgr, curFrame));
+        }
+    }
+    return BF_OK;
+}
+
+int matchAndFilter(bf_bundler* b, uint32_t* lastMatchedFrame) {
+    uint32_t cur, start, num;
+    BF_TRY(matchAndFilterEnqueue(b, cur, start, num));
+    return matchAndFilterFinish(b, cur, num, lastMatchedFrame);
+}
+
+int tryRevalidation(bf_bundler* b, uint32_t curGlobalFrame, bool bIsScanDone, uint32_t* out) {       // Bundler.cpp:306-352 (USE_RETRY)
+    b->revalidatedIdx = 0xFFFFFFFFu;
+    *out = 0xFFFFFFFFu;
+    if (b->continueRetry < 0) { *out = 0; return BF_OK; }            // "return false" from a function returning unsigned
+    uint32_t idx; int found = 0;
+    BF_TRY(bf_siftmgr_get_top_retry_image(b->mgr, &idx, &found));
+    if (found) {
+        if (bIsScanDone) {
+            if (b->continueRetry == 0) b->continueRetry = (int)idx;
+            else if (b->continueRetry == (int)idx) { b->continueRetry = -1; return BF_OK; }
+        }
+        BF_TRY(bf_siftmgr_set_current_frame(b->mgr, idx));
+        uint32_t lastMatchedGlobal;
+        BF_TRY(matchAndFilter(b, &lastMatchedGlobal));
+        std::vector<int> v;
+        uint32_t n; BF_TRY(bf_siftmgr_get_num_images(b->mgr, &n));
+        BF_TRY(bundlerValid(b, v, n));
+        if (v[idx] != 0) {
+            BF_REQUIRE(lastMatchedGlobal != 0xFFFFFFFFu, "revalidated frame without a match");
+            BF_HIP_TRY(hipMemcpyAsync(b->d_trajectory + idx, b->d_trajectory + lastMatchedGlobal, sizeof(m44), hipMemcpyDeviceToDevice, b->stream));
+            b->revalidatedIdx = idx;
+        } else BF_TRY(bf_siftmgr_add_to_retry_list(b->mgr, idx));
+        BF_TRY(bf_siftmgr_set_current_frame(b->mgr, curGlobalFrame));
+    }
+    *out = b->revalidatedIdx;
+    return BF_OK;
+}
+
+// SBA::align + alignCUDA + removeMaxResidualCUDA (SBA.cpp:53-204)
+int sbaAlign(bf_bundler* b, uint32_t maxNumIters, uint32_t numPCGits, bool useVerify, bool isEnd, uint32_t revalidateIdx, bool* removed) {
+    *removed = false;
+    b->sbaVerify = false; b->maxResidual = -1.0f;
+    const std::vector<float>*wS, *wD, *wC;
+    std::vector<float> zeros;
+    bool useCache = true;
+    if (b->isLocal) {
+        wS = &b->localWS;
+        if (b->useLocalDense) { wD = &b->localWD; wC = &b->localWC; }
+        else { useCache = false; zeros.assign(b->localWD.size(), 0.0f); wD = wC = &zeros; }
+    } else {
+        wS = &b->globalWS;
+        if (!b->useGlobalDenseOpt) { useCache = false; zeros.assign(b->globalWD.size(), 0.0f); wD = wC = &zeros; }
+        else { wD = &b->globalWD; wC = &b->globalWC; }
+    }
+    uint32_t numImages, numCorr;
+    BF_TRY(bf_siftmgr_get_num_images(b->mgr, &numImages));
+    BF_TRY(bf_siftmgr_get_num_global_correspondences(b->mgr, &numCorr));
+    const int32_t* d_valid = nullptr; bf_entry_j* d_corr = nullptr;
+    BF_TRY(bf_siftmgr_get_valid_images_gpu(b->mgr, &d_valid));
+    BF_TRY(bf_siftmgr_get_global_correspondences_gpu(b->mgr, &d_corr));
+    BF_TRY(bf_convert_matrices_to_poses((const float*)b->d_trajectory, numImages, b->d_xRot, b->d_xTrans, d_valid, b->stream));
+    uint32_t cw = 0, ch = 0; float k4[4] = {0, 0, 0, 0}; m44 K;
+    const bf_cached_frame* d_frames = nullptr;
+    if (useCache) { BF_TRY(cacheK(b, cw, ch, k4, K)); BF_TRY(bf_cache_get_frames_gpu(b->cache, &d_frames)); }
+    BF_TRY(bf_solver_solve(b->solver, d_corr, numCorr, d_valid, numImages, maxNumIters, numPCGits, d_frames, cw, ch, k4, wS->data(), wD->data(), wC->data(),
+                           (uint32_t)wS->size(), 1, b->d_xRot, b->d_xTrans, 1, isEnd ? 1 : 0, revalidateIdx));
+    b->numSolves++;
+    if (isEnd && wS->front() > 0) {                                            // removeMaxResidualCUDA :168-204
+        uint32_t curFrame;
+        BF_TRY(bf_siftmgr_get_current_frame(b->mgr, &curFrame));
+        if (revalidateIdx != 0xFFFFFFFFu) curFrame = revalidateIdx;
+        uint32_t pair[2]; int remove = 0;
+        BF_TRY(bf_solver_get_max_residual_pair(b->solver, curFrame, d_corr, pair, &b->maxResidual, &remove));
+        if (remove) {
+            BF_TRY(bf_siftmgr_invalidate_image_to_image(b->mgr, pair[0], pair[1]));
+            const int32_t* d_rows = nullptr;
+            BF_TRY(bf_solver_get_var_to_corr_num_entries_per_row(b->solver, &d_rows));
+            if (b->comprehensive) BF_TRY(bf_siftmgr_check_for_invalid_frames(b->mgr, d_rows, numImages));
+            else BF_TRY(bf_siftmgr_check_for_invalid_frames_simple(b->mgr, d_rows, numImages));
+            *removed = true;
+        }
+    }
+    if (useVerify) {
+        if (wS->front() > 0 && numCorr > 0) { int v = 0; BF_TRY(bf_solver_use_verification(b->solver, d_corr, numCorr, &v)); b->sbaVerify = v != 0; }
+        else b->sbaVerify = true;
+    }
+    BF_TRY(bf_convert_poses_to_matrices(b->d_xRot, b->d_xTrans, numImages, (float*)b->d_trajectory, d_valid, b->stream));
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_bundler_create(uint32_t maxNumImages, uint32_t maxNumKeysPerImage, const float siftIntrinsicsInv[16], bf_image_manager* manager, int isLocal,
+                      const bf_global_app_state* gas, const bf_global_bundling_state* gbs, bf_bundler** out) {
+    BF_REQUIRE(siftIntrinsicsInv && manager && gas && gbs && out && maxNumImages >= 2, "bad argument");
+    bf_bundler* b = new bf_bundler;
+    b->gas = *gas; b->gbs = *gbs; b->maxImages = maxNumImages; b->maxKeys = maxNumKeysPerImage; b->isLocal = isLocal != 0;
+    b->siftIntrinsicsInv = toM(siftIntrinsicsInv);
+    b->siftIntrinsics = inverse44(b->siftIntrinsicsInv);
+    int rc = BF_OK;
+    const bf_rgbd_sensor_desc& sn = manager->sensor;
+    if (b->isLocal)              // initSift: SetParams(w, h, false, 150, depthMin, depthMax) (:57-69)
+        rc = bf_sift_create(gbs->s_widthSIFT, gbs->s_heightSIFT, sn.depthWidth, sn.depthHeight, 150, gas->s_sensorDepthMin, gas->s_sensorDepthMax, gbs->s_minKeyScale,
+                            maxNumKeysPerImage, &b->sift);
+    const uint32_t maxNumResiduals = 25 * (maxNumImages * (maxNumImages - 1)) / 2;
+    bf_solver_config cfg;
+    cfg.optMaxResThresh = gbs->s_optMaxResThresh; cfg.denseDistThresh = gbs->s_denseDistThresh; cfg.denseNormalThresh = gbs->s_denseNormalThresh;
+    cfg.denseColorThresh = gbs->s_denseColorThresh; cfg.denseColorGradientMin = gbs->s_denseColorGradientMin; cfg.denseDepthMin = gbs->s_denseDepthMin;
+    cfg.denseDepthMax = gbs->s_denseDepthMax; cfg.denseOverlapCheckSubsampleFactor = gbs->s_denseOverlapCheckSubsampleFactor;
+    cfg.verifyOptDistThresh = 0.02f; cfg.verifyOptPercentThresh = 0.05f; cfg.recordConvergence = gbs->s_recordSolverConvergence;
+    if (!rc) rc = bf_solver_create(maxNumImages, maxNumResiduals, &cfg, &b->solver);
+    if (!rc) rc = bf_cache_create(sn.depthWidth, sn.depthHeight, gbs->s_downsampledWidth, gbs->s_downsampledHeight, maxNumImages, manager->siftDepthIntrinsics.e,
+                                  gbs->s_colorDownSigma, gbs->s_depthDownSigmaD, gbs->s_depthDownSigmaR, &b->cache);
+    if (!rc) rc = bf_siftmgr_create(maxNumImages, maxNumKeysPerImage, &b->mgr);
+    if (rc) { bf_bundler_destroy(b); return rc; }
+    BF_HIP_TRY(hipMalloc((void**)&b->d_trajectory, sizeof(m44) * (maxNumImages + 1)));
+    BF_HIP_TRY(hipMalloc((void**)&b->d_xRot, sizeof(float) * 3 * maxNumImages));
+    BF_HIP_TRY(hipMalloc((void**)&b->d_xTrans, sizeof(float) * 3 * maxNumImages));
+    k_fill_identity<<<div_up(maxNumImages + 1, 64), 64>>>(b->d_trajectory, maxNumImages + 1);
+    BF_HIP_TRY(hipDeviceSynchronize());
+    const uint32_t maxNumIts = std::max(gbs->s_numGlobalNonLinIterations, gbs->s_numLocalNonLinIterations);     // SBA.cpp:28-38
+    b->localWS.assign(maxNumIts, 1.0f); b->localWD.resize(maxNumIts); b->localWC.assign(maxNumIts, 0.0f);
+    for (uint32_t i = 0; i < maxNumIts; ++i) b->localWD[i] = (float)i + 1.0f;
+    b->globalWS.assign(maxNumIts, 1.0f); b->globalWD.assign(maxNumIts, 1.0f); b->globalWC.assign(maxNumIts, 0.1f);
+    for (uint32_t i = 2; i < maxNumIts; ++i) b->globalWD[i] = (float)i;
+    b->useGlobalDenseOpt = false;
+    b->comprehensive = gbs->s_useComprehensiveFrameInvalidation != 0;          // SBA.h:31-32
+    b->useLocalDense = gbs->s_useLocalDense != 0;
+    *out = b;
+    return BF_OK;
+}
+
+int bf_bundler_destroy(bf_bundler* b) {
+    if (!b) return BF_OK;
+    bf_sift_destroy(b->sift); bf_solver_destroy(b->solver); bf_cache_destroy(b->cache); bf_siftmgr_destroy(b->mgr);
+    (void)hipFree(b->d_trajectory); (void)hipFree(b->d_xRot); (void)hipFree(b->d_xTrans);
+    delete b;
+    return BF_OK;
+}
+
+int bf_bundler_set_stream(bf_bundler* b, void* s) {
+    BF_REQUIRE(b, "null bundler");
+    b->stream = (hipStream_t)s;
+    if (b->sift) BF_TRY(bf_sift_set_stream(b->sift, s));
+    BF_TRY(bf_solver_set_stream(b->solver, s)); BF_TRY(bf_cache_set_stream(b->cache, s)); BF_TRY(bf_siftmgr_set_stream(b->mgr, s));
+    return BF_OK;
+}
+
+int bf_bundler_get_trajectory_gpu(bf_bundler* b, float** d) { BF_REQUIRE(b && d, "null argument"); *d = (float*)b->d_trajectory; return BF_OK; }
+int bf_bundler_get_valid_images(bf_bundler* b, int32_t* h_out, uint32_t count) { BF_REQUIRE(b, "null bundler"); return bf_siftmgr_get_valid_images(b->mgr, h_out, count); }
+int bf_bundler_get_cache_intrinsics(bf_bundler* b, float K[16], float Kinv[16]) {
+    BF_REQUIRE(b, "null bundler");
+    uint32_t w, h; float k4[4]; m44 M;
+    BF_TRY(cacheK(b, w, h, k4, M));
+    if (K) memcpy(K, M.e, 64);
+    if (Kinv) { const m44 I = inverse44(M); memcpy(Kinv, I.e, 64); }
+    return BF_OK;
+}
+int bf_bundler_get_curr_frame_number(bf_bundler* b, uint32_t* out) { BF_REQUIRE(b, "null bundler"); return bf_siftmgr_get_current_frame(b->mgr, out); }
+int bf_bundler_get_num_frames(bf_bundler* b, uint32_t* out) { BF_REQUIRE(b, "null bundler"); return bf_siftmgr_get_num_images(b->mgr, out); }
+
+int bf_bundler_is_valid(bf_bundler* b, int* out) {
+    BF_REQUIRE(b && out, "null argument");
+    uint32_t n; BF_TRY(bf_siftmgr_get_num_images(b->mgr, &n));
+    std::vector<int> v; BF_TRY(bundlerValid(b, v, n));
+    *out = 0;
+    for (uint32_t i = 1; i < n; ++i) if (v[i] != 0) { *out = 1; break; }
+    return BF_OK;
+}
+
+int bf_bundler_reset(bf_bundler* b) {
+    BF_REQUIRE(b, "null bundler");
+    uint32_t n; BF_TRY(bf_siftmgr_get_num_images(b->mgr, &n));
+    if (n) k_fill_identity<<<div_up(n, 64), 64, 0, b->stream>>>(b->d_trajectory, n);
+    BF_TRY(bf_siftmgr_reset(b->mgr));
+    BF_TRY(bf_cache_reset(b->cache));
+    return BF_OK;
+}
+
+int bf_bundler_detect_features(bf_bundler* b, const float* d_intensitySift, const float* d_inputDepthFilt) {
+    BF_REQUIRE(b && b->sift && d_intensitySift && d_inputDepthFilt, "detectFeatures needs a local bundler");
+    bf_sift_image_gpu img;
+    BF_TRY(bf_siftmgr_create_image(b->mgr, &img));
+    BF_TRY(bf_sift_run(b->sift, d_intensitySift, d_inputDepthFilt, (float*)img.d_keyPoints, (uint8_t*)img.d_keyPointDescs, img.d_numKeyPoints));
+    return bf_siftmgr_finalize_image(b->mgr, -1);       // the count stays on the device; "too many keypoints" surfaces at the frame read-back
+}
+
+int bf_bundler_store_cached_frame(bf_bundler* b, uint32_t dw, uint32_t dh, const uint8_t* d_color, uint32_t cw, uint32_t ch, const float* d_depthRaw) {
+    BF_REQUIRE(b, "null bundler");
+    return bf_cache_store_frame(b->cache, d_depthRaw, dw, dh, d_color, cw, ch);
+}
+
+int bf_bundler_copy_frame(bf_bundler* b, bf_bundler* from, uint32_t frame) {
+    BF_REQUIRE(b && from, "null bundler");
+    bf_sift_image_gpu next, cur;
+    BF_TRY(bf_siftmgr_get_image(from->mgr, frame, &cur));
+    BF_TRY(bf_siftmgr_create_image(b->mgr, &next));
+    const uint32_t mk = std::min(b->maxKeys, from->maxKeys);
+    BF_HIP_TRY(hipMemcpyAsync(next.d_keyPoints, cur.d_keyPoints, sizeof(bf_sift_keypoint) * mk, hipMemcpyDeviceToDevice, b->stream));
+    BF_HIP_TRY(hipMemcpyAsync(next.d_keyPointDescs, cur.d_keyPointDescs, sizeof(bf_sift_keypoint_desc) * mk, hipMemcpyDeviceToDevice, b->stream));
+    BF_HIP_TRY(hipMemcpyAsync(next.d_numKeyPoints, cur.d_numKeyPoints, sizeof(int32_t), hipMemcpyDeviceToDevice, b->stream));
+    BF_TRY(bf_siftmgr_finalize_image(b->mgr, -1));
+    return bf_cache_copy_cache_frame_from(b->cache, from->cache, frame);
+}
+
+int bf_bundler_add_invalid_frame(bf_bundler* b) {
+    BF_REQUIRE(b, "null bundler");
+    BF_TRY(bf_cache_increment(b->cache));
+    bf_sift_image_gpu img;
+    BF_TRY(bf_siftmgr_create_image(b->mgr, &img));
+    BF_TRY(bf_siftmgr_finalize_image(b->mgr, 0));
+    uint32_t n; BF_TRY(bf_siftmgr_get_num_images(b->mgr, &n));        // initializeNextTransformUnknown (Bundler.h:78-82)
+    BF_HIP_TRY(hipMemcpyAsync(b->d_trajectory + n, b->d_trajectory + n - 1, sizeof(m44), hipMemcpyDeviceToDevice, b->stream));
+    return BF_OK;
+}
+
+int bf_bundler_invalidate_last_frame(bf_bundler* b) {
+    BF_REQUIRE(b, "null bundler");
+    uint32_t n; BF_TRY(bf_siftmgr_get_num_images(b->mgr, &n));
+    if (n <= 1) { set_error("INVALID_FIRST_CHUNK"); return BF_ERR_STATE; }      // the reference writes processed.txt and exits (:377-384)
+    return bf_siftmgr_set_valid_image(b->mgr, n - 1, 0);
+}
+
+int bf_bundler_get_current_sift_transforms_gpu(bf_bundler* b, const float** d_out) { BF_REQUIRE(b && d_out, "null argument"); return bf_siftmgr_get_filt_transforms_gpu(b->mgr, nullptr, d_out); }
+int bf_bundler_get_num_filt_matches_gpu(bf_bundler* b, const int32_t** d_out) { BF_REQUIRE(b && d_out, "null argument"); return bf_siftmgr_get_num_filt_matches_gpu(b->mgr, d_out); }
+
+int bf_bundler_match_and_filter(bf_bundler* b, uint32_t* lastMatchedFrame) {
+    BF_REQUIRE(b && lastMatchedFrame, "null argument");
+    return matchAndFilter(b, lastMatchedFrame);
+}
+
+int bf_bundler_optimize(bf_bundler* b, uint32_t numNonLin, uint32_t numLin, int bUseVerify, int bRemoveMaxResidual, int bIsScanDone, int* bOptRemoved, int* valid) {
+    (void)bIsScanDone;
+    BF_REQUIRE(b && bOptRemoved && valid, "null argument");
+    uint32_t numImages; BF_TRY(bf_siftmgr_get_num_images(b->mgr, &numImages));
+    BF_REQUIRE(numImages > 1, "optimize needs more than one image");
+    bool removed = false;
+    BF_TRY(sbaAlign(b, numNonLin, numLin, bUseVerify != 0, bRemoveMaxResidual != 0, b->revalidatedIdx, &removed));
+    *bOptRemoved = removed ? 1 : 0;
+    *valid = 1;
+    if (b->sbaVerify) {                                                        // Bundler.cpp:259-273
+        uint32_t cw, ch; float k4[4]; m44 K;
+        BF_TRY(cacheK(b, cw, ch, k4, K));
+        const bf_cached_frame* d_frames = nullptr;
+        BF_TRY(bf_cache_get_frames_gpu(b->cache, &d_frames));
+        int32_t v = 0;
+        BF_TRY(bf_siftmgr_verify_trajectory(b->mgr, numImages, (const float*)b->d_trajectory, cw, ch, K.e, d_frames, b->gbs.s_projCorrDistThres,
+                                            b->gbs.s_projCorrNormalThres, b->gbs.s_projCorrColorThresh, b->gbs.s_verifyOptErrThresh, b->gbs.s_verifyOptCorrThresh,
+                                            0.1f, 3.0f, &v));
+        *valid = v > 0 ? 1 : 0;
+    }
+    return BF_OK;
+}
+
+int bf_bundler_set_solve_weights(bf_bundler* b, const float* sparse, const float* denseDepth, const float* denseColor, uint32_t n) {
+    BF_REQUIRE(b && sparse && denseDepth && denseColor && n > 0, "bad argument");
+    b->globalWS.assign(sparse, sparse + n); b->globalWD.assign(denseDepth, denseDepth + n); b->globalWC.assign(denseColor, denseColor + n);
+    b->useGlobalDenseOpt = denseDepth[n - 1] > 0 || denseColor[n - 1] > 0;      // Bundler.h:51-54
+    return BF_OK;
+}
+
+int bf_bundler_fuse_to_global(bf_bundler* b, bf_bundler* glob) {
+    BF_REQUIRE(b && glob, "null bundler");
+    BF_TRY(bf_siftmgr_fuse_to_global(b->mgr, glob->mgr, b->siftIntrinsics.e, (const float*)b->d_trajectory, b->siftIntrinsicsInv.e));
+    return bf_cache_copy_cache_frame_from(glob->cache, b->cache, 0);
+}
+
+int bf_bundler_try_revalidation(bf_bundler* b, uint32_t curGlobalFrame, int bIsScanDone, uint32_t* revalidatedIdx) {
+    BF_REQUIRE(b && revalidatedIdx, "null argument");
+    return tryRevalidation(b, curGlobalFrame, bIsScanDone != 0, revalidatedIdx);
+}
+int bf_bundler_get_revalidated_idx(bf_bundler* b, uint32_t* out) { BF_REQUIRE(b && out, "null argument"); *out = b->revalidatedIdx; return BF_OK; }
+
+int bf_bundler_save_sparse_corrs_to_file(bf_bundler* b, const char* filename) {       // UINT64 count + EntryJ[count]
+    BF_REQUIRE(b && filename, "null argument");
+    uint32_t n; BF_TRY(bf_siftmgr_get_num_global_correspondences(b->mgr, &n));
+    if (n == 0) return BF_OK;                                                    // "warning: no sparse correspondences to save"
+    bf_entry_j* d_corr = nullptr;
+    BF_TRY(bf_siftmgr_get_global_correspondences_gpu(b->mgr, &d_corr));
+    std::vector<bf_entry_j> corr(n);
+    BF_HIP_TRY(hipMemcpyAsync(corr.data(), d_corr, sizeof(bf_entry_j) * n, hipMemcpyDeviceToHost, b->stream));
+    BF_HIP_TRY(hipStreamSynchronize(b->stream));
+    std::ofstream out(filename, std::ios::binary);
+    if (!out.is_open()) { set_error("cannot open %s", filename); return BF_ERR_INVALID_ARG; }
+    const uint64_t cnt = n;
+    out.write((const char*)&cnt, sizeof cnt);
+    out.write((const char*)corr.data(), sizeof(bf_entry_j) * n);
+    return BF_OK;
+}
+
+int bf_bundler_get_sift_manager(bf_bundler* b, bf_siftmgr** out) { BF_REQUIRE(b && out, "null argument"); *out = b->mgr; return BF_OK; }
+int bf_bundler_get_cache(bf_bundler* b, bf_cache** out) { BF_REQUIRE(b && out, "null argument"); *out = b->cache; return BF_OK; }
+int bf_bundler_get_solver(bf_bundler* b, bf_solver** out) { BF_REQUIRE(b && out, "null argument"); *out = b->solver; return BF_OK; }
+
+}  // extern "C"
+
+// ================================================================================================ TrajectoryManager
+struct bf_trajectory_manager {
+    struct Frame { int type; uint32_t frameIdx; m44 integratedTransform; float dist; };
+    std::vector<m44> optimizedTransforms;
+    std::vector<Frame> frames;
+    std::vector<Frame*> framesSort;
+    uint32_t numAddedFrames = 0, numOptimizedFrames = 0;
+    std::list<Frame*> toDeIntegrate, toIntegrate, toReIntegrate;
+    uint32_t topNActive = 30;
+    float minPoseDistSqrt = 0.0f, featureRescaleRotToTrans = 2.0f;
+    m44& opt(const Frame& f) { return optimizedTransforms[f.frameIdx]; }
+};
+
+namespace {
+void tmInvalidate(bf_trajectory_manager* tm, uint32_t idx) {                       // TrajectoryManager.cpp:190-199
+    auto& f = tm->frames[idx];
+    if (f.type == BF_TF_INVALID) return;
+    const int before = f.type;
+    f.type = BF_TF_INVALID;
+    if (before == BF_TF_INTEGRATED) tm->toDeIntegrate.push_back(&f);
+}
+}  // namespace
+
+extern "C" {
+
+int bf_trajectory_manager_create(uint32_t numMaxImage, uint32_t topNActive, float minPoseDistSqrt, bf_trajectory_manager** out) {
+    BF_REQUIRE(out && numMaxImage > 0, "bad argument");
+    bf_trajectory_manager* tm = new bf_trajectory_manager;
+    tm->optimizedTransforms.assign(numMaxImage, minfM());
+    tm->frames.resize(numMaxImage);
+    for (uint32_t i = 0; i < numMaxImage; ++i) { tm->frames[i].type = BF_TF_NOT_INTEGRATED_NO_TRANSFORM; tm->frames[i].frameIdx = i; tm->frames[i].integratedTransform = minfM(); tm->frames[i].dist = 0.0f; }
+    tm->framesSort.reserve(numMaxImage);
+    tm->topNActive = topNActive; tm->minPoseDistSqrt = minPoseDistSqrt;
+    *out = tm;
+    return BF_OK;
+}
+int bf_trajectory_manager_destroy(bf_trajectory_manager* tm) { delete tm; return BF_OK; }
+
+int bf_trajectory_manager_add_frame(bf_trajectory_manager* tm, int type, const float transform[16], uint32_t idx) {
+    BF_REQUIRE(tm && transform && idx < tm->frames.size(), "frame out of range");
+    auto& f = tm->frames[idx];
+    f.type = type; f.frameIdx = idx; f.integratedTransform = toM(transform);
+    tm->optimizedTransforms[idx] = f.integratedTransform;
+    tm->framesSort.push_back(&f);
+    tm->numAddedFrames++;
+    return BF_OK;
+}
+
+int bf_trajectory_manager_update_optimized_transform(bf_trajectory_manager* tm, const float* d_trajectory, uint32_t numFrames, void* stream) {
+    BF_REQUIRE(tm && (d_trajectory || numFrames == 0), "null argument");
+    tm->numOptimizedFrames = numFrames;
+    numFrames = std::min(numFrames, tm->numAddedFrames);
+    if (numFrames) {
+        BF_HIP_TRY(hipMemcpyAsync(tm->optimizedTransforms.data(), d_trajectory, sizeof(m44) * numFrames, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        BF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    }
+    return BF_OK;
+}
+
+int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm) {        // :47-111
+    BF_REQUIRE(tm, "null manager");
+    const uint32_t numFrames = std::min(tm->numOptimizedFrames, tm->numAddedFrames);
+    for (uint32_t i = 0; i < numFrames; ++i) {
+        auto& f = tm->frames[i];
+        const m44& T = tm->opt(f);
+        if (T.e[0] == NINF) tmInvalidate(tm, i);
+        else {
+            if (f.type == BF_TF_NOT_INTEGRATED_NO_TRANSFORM || f.type == BF_TF_INVALID) { f.type = BF_TF_NOT_INTEGRATED_WITH_TRANSFORM; tm->toIntegrate.push_back(&f); }
+            f3 ro, to, ri, ti;
+            matrixToPose(T, ro, to);
+            matrixToPose(f.integratedTransform, ri, ti);
+            const float s = tm->featureRescaleRotToTrans;
+            const float d[6] = {ri.x * s - ro.x * s, ri.y * s - ro.y * s, ri.z * s - ro.z * s, ti.x - to.x, ti.y - to.y, ti.z - to.z};
+            f.dist = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+        }
+    }
+    // std::sort in the reference; a stable sort makes the order of equal distances reproducible
+    std::stable_sort(tm->framesSort.begin(), tm->framesSort.begin() + numFrames, [](const bf_trajectory_manager::Frame* l, const bf_trajectory_manager::Frame* r) {
+        if (l->type == BF_TF_INTEGRATED && r->type != BF_TF_INTEGRATED) return true;
+        if (l->type != BF_TF_INTEGRATED) return false;
+        return l->dist > r->dist;
+    });
+    for (uint32_t i = (uint32_t)tm->toReIntegrate.size(); i < tm->topNActive && i < numFrames; ++i) {
+        auto* f = tm->framesSort[i];
+        if (f->dist > tm->minPoseDistSqrt && f->type == BF_TF_INTEGRATED) { f->type = BF_TF_REINTEGRATION; tm->toReIntegrate.push_back(f); }
+        else break;
+    }
+    return BF_OK;
+}
+
+int bf_trajectory_manager_confirm_integration(bf_trajectory_manager* tm, uint32_t frameIdx) {
+    BF_REQUIRE(tm && frameIdx < tm->frames.size(), "frame out of range");
+    tm->frames[frameIdx].type = BF_TF_INTEGRATED;
+    return BF_OK;
+}
+
+int bf_trajectory_manager_get_top_from_reintegrate_list(bf_trajectory_manager* tm, float oldT[16], float newT[16], uint32_t* frameIdx, int* found) {
+    BF_REQUIRE(tm && oldT && newT && frameIdx && found, "null argument");
+    *found = 0;
+    if (tm->toReIntegrate.empty()) return BF_OK;
+    while (!tm->toReIntegrate.empty()) {                     // some may have been invalidated in the meantime (:123-134)
+        auto* f = tm->toReIntegrate.front();
+        const m44 nT = tm->opt(*f);
+        memcpy(newT, nT.e, 64); memcpy(oldT, f->integratedTransform.e, 64);
+        *frameIdx = f->frameIdx;
+        tm->toReIntegrate.pop_front();
+        if (nT.e[0] != NINF) { f->integratedTransform = nT; break; }
+    }
+    *found = 1;
+    return BF_OK;
+}
+
+int bf_trajectory_manager_get_top_from_integrate_list(bf_trajectory_manager* tm, float trans[16], uint32_t* frameIdx, int* found) {
+    BF_REQUIRE(tm && trans && frameIdx && found, "null argument");
+    *found = 0;
+    if (tm->toIntegrate.empty()) return BF_OK;
+    auto* f = tm->toIntegrate.front();
+    BF_REQUIRE(f->type == BF_TF_NOT_INTEGRATED_WITH_TRANSFORM, "integrate list holds an invalidated frame");
+    const m44 T = tm->opt(*f);
+    memcpy(trans, T.e, 64);
+    *frameIdx = f->frameIdx;
+    f->integratedTransform = T;
+    tm->toIntegrate.pop_front();
+    *found = 1;
+    return BF_OK;
+}
+
+int bf_trajectory_manager_get_top_from_deintegrate_list(bf_trajectory_manager* tm, float trans[16], uint32_t* frameIdx, int* found) {
+    BF_REQUIRE(tm && trans && frameIdx && found, "null argument");
+    *found = 0;
+    if (tm->toDeIntegrate.empty()) return BF_OK;
+    auto* f = tm->toDeIntegrate.front();
+    memcpy(trans, f->integratedTransform.e, 64);
+    *frameIdx = f->frameIdx;
+    tm->toDeIntegrate.pop_front();
+    *found = 1;
+    return BF_OK;
+}
+
+int bf_trajectory_manager_get_num_optimized_frames(bf_trajectory_manager* tm, uint32_t* out) { BF_REQUIRE(tm && out, "null argument"); *out = tm->numOptimizedFrames; return BF_OK; }
+int bf_trajectory_manager_get_num_added_frames(bf_trajectory_manager* tm, uint32_t* out) { BF_REQUIRE(tm && out, "null argument"); *out = tm->numAddedFrames; return BF_OK; }
+int bf_trajectory_manager_get_num_active_operations(bf_trajectory_manager* tm, uint32_t* out) {
+    BF_REQUIRE(tm && out, "null argument");
+    *out = (uint32_t)(tm->toDeIntegrate.size() + tm->toIntegrate.size() + tm->toReIntegrate.size());
+    return BF_OK;
+}
+int bf_trajectory_manager_get_optimized_transforms(bf_trajectory_manager* tm, float* h_out, uint32_t capacity, uint32_t* count) {    // .h:49-69
+    BF_REQUIRE(tm && h_out && count, "null argument");
+    const uint32_t n = std::min(std::min(tm->numAddedFrames, tm->numOptimizedFrames), capacity);
+    for (uint32_t i = 0; i < n; ++i) {
+        const m44 T = tm->frames[i].type == BF_TF_INVALID ? minfM() : tm->optimizedTransforms[i];
+        memcpy(h_out + 16 * (size_t)i, T.e, 64);
+    }
+    *count = n;
+    return BF_OK;
+}
+int bf_trajectory_manager_get_frame(bf_trajectory_manager* tm, uint32_t idx, int* type, float integratedTransform[16], float* dist) {
+    BF_REQUIRE(tm && idx < tm->frames.size(), "frame out of range");
+    if (type) *type = tm->frames[idx].type;
+    if (integratedTransform) memcpy(integratedTransform, tm->frames[idx].integratedTransform.e, 64);
+    if (dist) *dist = tm->frames[idx].dist;
+    return BF_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================ OnlineBundler
+struct bf_online_bundler {
+    enum State { DO_NOTHING, PROCESS, INVALIDATE };
+    bf_global_app_state gas; bf_global_bundling_state gbs;
+    bf_image_manager* im = nullptr;
+    hipStream_t stream = nullptr;
+    // BundlerInputData (OnlineBundlerHelper.h:7-66): ingest buffers are read in place, only the SIFT intensity image is owned
+    uint32_t depthW = 0, depthH = 0, colorW = 0, colorH = 0, widthSIFT = 0, heightSIFT = 0;
+    m44 siftIntrinsics, siftIntrinsicsInv;
+    float *d_intensitySIFT = nullptr, *d_intensityFilterHelper = nullptr;
+    uint32_t submapSize = 10, numOptPerResidualRemoval = 1;
+    bf_bundler *local = nullptr, *optLocal = nullptr, *global = nullptr;
+    bf_trajectory_manager* tm = nullptr;
+    m44 *d_completeTrajectory = nullptr, *d_localTrajectories = nullptr, *d_siftTrajectory = nullptr, *d_currIntegrateTransform = nullptr;
+    int* d_imageInvalidateList = nullptr;
+    std::vector<std::vector<int>> localTrajectoriesValid;
+    std::vector<int> invalidImagesList;
+    std::vector<m44> currIntegrateTransform;
+    m44* h_pinT = nullptr;
+    // BundlerState (OnlineBundlerHelper.h:70-109)
+    int lastFrameProcessed = -1; bool bLastFrameValid = false;
+    int localToSolve = -1, lastLocalSolved = -1;
+    uint32_t numFramesPastEnd = 0, numCompleteTransforms = 0, lastValidCompleteTransform = 0;
+    bool bGlobalTrackingLost = false;
+    State processState = DO_NOTHING;
+    bool bUseSolve = true;
+    uint32_t totalNumOptLocalFrames = 0;
+    uint32_t numLocalSolves = 0, numGlobalSolves = 0;
+    bool isLastLocalFrame(uint32_t curFrame) const { return curFrame >= submapSize && (curFrame % submapSize) == 0; }
+    void invalidateImages(uint32_t s, uint32_t e = 0xFFFFFFFFu) { if (e == 0xFFFFFFFFu) invalidImagesList[s] = 0; else for (uint32_t i = s; i < e; ++i) invalidImagesList[i] = 0; }
+    void validateImages(uint32_t s) { invalidImagesList[s] = 1; }
+};
+
+namespace {
+
+const int ID_MARK_OFFSET = 2;
+
+int obPrepareLocalSolve(bf_online_bundler* ob, uint32_t curFrame, bool isSequenceEnd) {            // OnlineBundler.cpp:134-165
+    ob->processState = bf_online_bundler::DO_NOTHING;
+    uint32_t curLocalIdx = (std::max(curFrame, 1u) - 1) / ob->submapSize;
+    if (isSequenceEnd && (curFrame % ob->submapSize) == 0) {
+        curLocalIdx++;
+        ob->localToSolve = -((int)curLocalIdx + ID_MARK_OFFSET);
+        ob->processState = bf_online_bundler::INVALIDATE;
+    } else {
+        int valid = 0;
+        BF_TRY(bf_bundler_is_valid(ob->local, &valid));
+        if (valid) { ob->localToSolve = (int)curLocalIdx; ob->processState = bf_online_bundler::PROCESS; }
+        else { ob->localToSolve = -((int)curLocalIdx + ID_MARK_OFFSET); ob->processState = bf_online_bundler::INVALIDATE; }
+    }
+    std::swap(ob->local, ob->optLocal);
+    return BF_OK;
+}
+
+int obOptimizeLocal(bf_online_bundler* ob, uint32_t numNonLin, uint32_t numLin) {                    // :242-271
+    if (ob->processState == bf_online_bundler::DO_NOTHING) return BF_OK;
+    const bf_online_bundler::State optLocalState = ob->processState;
+    ob->processState = bf_online_bundler::DO_NOTHING;
+    uint32_t curLocalIdx = 0xFFFFFFFFu, nOpt;
+    BF_TRY(bf_bundler_get_num_frames(ob->optLocal, &nOpt));
+    const uint32_t numLocalFrames = std::min(ob->submapSize, nOpt);
+    if (optLocalState == bf_online_bundler::PROCESS) {
+        curLocalIdx = (uint32_t)ob->localToSolve;
+        int removed = 0, valid = 0;
+        BF_TRY(bf_bundler_optimize(ob->optLocal, numNonLin, numLin, ob->gbs.s_useLocalVerify, 0, ob->numFramesPastEnd != 0, &removed, &valid));
+        ob->numLocalSolves++;
+        if (valid) {
+            BF_HIP_TRY(hipMemcpyAsync(ob->d_localTrajectories + (size_t)(ob->submapSize + 1) * curLocalIdx, ob->optLocal->d_trajectory, sizeof(m44) * (ob->submapSize + 1),
+                                      hipMemcpyDeviceToDevice, ob->stream));
+            ob->processState = bf_online_bundler::PROCESS;
+        } else ob->processState = bf_online_bundler::INVALIDATE;
+    } else if (optLocalState == bf_online_bundler::INVALIDATE) {
+        curLocalIdx = (uint32_t)(-ob->localToSolve - ID_MARK_OFFSET);
+        ob->processState = bf_online_bundler::INVALIDATE;
+    }
+    ob->localToSolve = -1;
+    ob->lastLocalSolved = (int)curLocalIdx;
+    ob->totalNumOptLocalFrames = ob->submapSize * (uint32_t)ob->lastLocalSolved + numLocalFrames;
+    return BF_OK;
+}
+
+int obProcessGlobal(bf_online_bundler* ob) {                                                       // :280-361
+    const bf_online_bundler::State processState = ob->processState;
+    if (processState == bf_online_bundler::DO_NOTHING) {
+        if (ob->numFramesPastEnd != 0) {
+            uint32_t idx;
+            BF_TRY(bf_bundler_try_revalidation(ob->global, (uint32_t)ob->lastLocalSolved, 1, &idx));
+            if (idx != 0xFFFFFFFFu && idx < ob->localTrajectoriesValid.size()) {
+                const std::vector<int>& validLocal = ob->localTrajectoriesValid[idx];
+                for (uint32_t i = 0; i < validLocal.size(); ++i) if (validLocal[i] == 1) ob->validateImages(idx * ob->submapSize + i);
+                ob->processState = bf_online_bundler::PROCESS;
+            }
+        }
+        return BF_OK;
+    }
+    ob->processState = bf_online_bundler::DO_NOTHING;
+    if (processState == bf_online_bundler::PROCESS) {
+        BF_TRY(bf_bundler_fuse_to_global(ob->optLocal, ob->global));
+        uint32_t curGlobalFrame, nOpt;
+        BF_TRY(bf_bundler_get_curr_frame_number(ob->global, &curGlobalFrame));
+        BF_TRY(bf_bundler_get_num_frames(ob->optLocal, &nOpt));
+        std::vector<int> validImagesLocal(ob->submapSize + 1, 0);
+        BF_TRY(bf_bundler_get_valid_images(ob->optLocal, validImagesLocal.data(), ob->submapSize + 1));
+        const uint32_t numLocalFrames = std::min(ob->submapSize, nOpt);
+        uint32_t lastValidLocal = 0;
+        for (int i = (int)nOpt - 1; i >= 0; --i) if (validImagesLocal[i]) { lastValidLocal = (uint32_t)i; break; }
+        for (uint32_t i = 0; i < numLocalFrames; ++i) if (validImagesLocal[i] == 0) ob->invalidateImages(curGlobalFrame * ob->submapSize + i);
+        ob->localTrajectoriesValid[curGlobalFrame] = validImagesLocal;
+        ob->localTrajectoriesValid[curGlobalFrame].resize(numLocalFrames);
+        uint32_t nGlob;
+        BF_TRY(bf_bundler_get_num_frames(ob->global, &nGlob));
+        BF_TRY(bf_init_next_global_transform((float*)ob->global->d_trajectory, nGlob, curGlobalFrame, (const float*)ob->d_localTrajectories, lastValidLocal,
+                                             ob->submapSize + 1, ob->stream));
+        BF_TRY(bf_bundler_reset(ob->optLocal));
+        if (nGlob > 1) {
+            uint32_t lastMatchedGlobal;
+            BF_TRY(bf_bundler_match_and_filter(ob->global, &lastMatchedGlobal));
+            if (lastMatchedGlobal == 0xFFFFFFFFu) { ob->bGlobalTrackingLost = true; ob->processState = bf_online_bundler::INVALIDATE; }
+            else {
+                ob->bGlobalTrackingLost = false;
+                const uint32_t revalidateIdx = ob->global->revalidatedIdx;
+                if (revalidateIdx != 0xFFFFFFFFu) {
+                    const std::vector<int>& validLocal = ob->localTrajectoriesValid[revalidateIdx];
+                    for (uint32_t i = 0; i < validLocal.size(); ++i) if (validLocal[i] == 1) ob->validateImages(revalidateIdx * ob->submapSize + i);
+                }
+                ob->processState = bf_online_bundler::PROCESS;
+            }
+        }
+    } else if (processState == bf_online_bundler::INVALIDATE) {
+        ob->processState = bf_online_bundler::INVALIDATE;
+        BF_TRY(bf_bundler_add_invalid_frame(ob->global));
+        BF_TRY(bf_bundler_reset(ob->optLocal));
+        ob->invalidateImages(ob->submapSize * (uint32_t)ob->lastLocalSolved, ob->totalNumOptLocalFrames);
+    }
+    return BF_OK;
+}
+
+int obUpdateTrajectory(bf_online_bundler* ob, uint32_t curFrame) {                                    // :363-371
+    if (curFrame) BF_HIP_TRY(hipMemcpyAsync(ob->d_imageInvalidateList, ob->invalidImagesList.data(), sizeof(int) * curFrame, hipMemcpyHostToDevice, ob->stream));
+    uint32_t nGlob;
+    BF_TRY(bf_bundler_get_num_frames(ob->global, &nGlob));
+    return bf_update_trajectory((const float*)ob->global->d_trajectory, nGlob, (float*)ob->d_completeTrajectory, curFrame, (const float*)ob->d_localTrajectories,
+                                ob->submapSize + 1, nGlob, ob->d_imageInvalidateList, ob->stream);
+}
+
+int obOptimizeGlobal(bf_online_bundler* ob, uint32_t numNonLin, uint32_t numLin) {                   // :373-408
+    const bool isSequenceDone = ob->numFramesPastEnd > 0;
+    if (!isSequenceDone && ob->processState == bf_online_bundler::DO_NOTHING) return BF_OK;
+    if (ob->lastLocalSolved < 0) return BF_OK;       // MLIB_ASSERT(m_lastLocalSolved >= 0): nothing was ever solved (sequence shorter than one chunk)
+    const bf_online_bundler::State state = isSequenceDone ? bf_online_bundler::PROCESS : ob->processState;
+    const uint32_t numTotalFrames = ob->totalNumOptLocalFrames;
+    if (state == bf_online_bundler::PROCESS) {
+        uint32_t nGlob;
+        BF_TRY(bf_bundler_get_num_frames(ob->global, &nGlob));
+        const uint32_t countNumFrames = (ob->numFramesPastEnd > 0) ? ob->numFramesPastEnd : numTotalFrames / ob->submapSize;
+        const bool bRemoveMaxResidual = (countNumFrames % ob->numOptPerResidualRemoval) == (ob->numOptPerResidualRemoval - 1);
+        int removed = 0, valid = 1;
+        if (nGlob > 1) {                               // MLIB_ASSERT(getNumImages() > 1) in Bundler::optimize: a one-keyframe global problem has nothing to solve
+            BF_TRY(bf_bundler_optimize(ob->global, numNonLin, numLin, 0, bRemoveMaxResidual, ob->numFramesPastEnd > 0, &removed, &valid));
+            ob->numGlobalSolves++;
+        }
+        if (removed) {
+            std::vector<int> v(nGlob, 0);
+            BF_TRY(bf_bundler_get_valid_images(ob->global, v.data(), nGlob));
+            for (uint32_t i = 0; i < nGlob; ++i) if (v[i] == 0) ob->invalidateImages(i * ob->submapSize, std::min((i + 1) * ob->submapSize, numTotalFrames));
+        }
+        BF_TRY(obUpdateTrajectory(ob, numTotalFrames));
+        BF_TRY(bf_trajectory_manager_update_optimized_transform(ob->tm, (const float*)ob->d_completeTrajectory, numTotalFrames, ob->stream));
+        ob->numCompleteTransforms = numTotalFrames;
+        if (valid) ob->lastValidCompleteTransform = ob->submapSize * (uint32_t)ob->lastLocalSolved;
+    } else if (state == bf_online_bundler::INVALIDATE) {
+        BF_TRY(bf_bundler_invalidate_last_frame(ob->global));
+        ob->invalidateImages(ob->submapSize * (uint32_t)ob->lastLocalSolved, ob->totalNumOptLocalFrames);
+        BF_TRY(obUpdateTrajectory(ob, numTotalFrames));
+        BF_TRY(bf_trajectory_manager_update_optimized_transform(ob->tm, (const float*)ob->d_completeTrajectory, numTotalFrames, ob->stream));
+        ob->numCompleteTransforms = numTotalFrames;
+    }
+    ob->processState = bf_online_bundler::DO_NOTHING;
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager* im, const bf_global_app_state* gas, const bf_global_bundling_state* gbs,
+                             bf_online_bundler** out) {
+    BF_REQUIRE(sensor && im && gas && gbs && out, "null argument");
+    bf_online_bundler* ob = new bf_online_bundler;
+    ob->gas = *gas; ob->gbs = *gbs; ob->im = im;
+    ob->depthW = sensor->depthWidth; ob->depthH = sensor->depthHeight; ob->colorW = sensor->colorWidth; ob->colorH = sensor->colorHeight;
+    ob->widthSIFT = gbs->s_widthSIFT; ob->heightSIFT = gbs->s_heightSIFT;
+    ob->siftIntrinsics = scaleIntrinsics(sensor->colorIntrinsics, ob->widthSIFT, ob->heightSIFT, ob->colorW, ob->colorH);
+    ob->siftIntrinsicsInv = inverse44(ob->siftIntrinsics);
+    ob->submapSize = gbs->s_submapSize; ob->numOptPerResidualRemoval = std::max(gbs->s_numOptPerResidualRemoval, 1u);
+    const uint32_t maxNumImages = gbs->s_maxNumImages, S = ob->submapSize;
+    int rc = bf_bundler_create(S + 1, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 1, gas, gbs, &ob->local);
+    if (!rc) rc = bf_bundler_create(S + 1, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 1, gas, gbs, &ob->optLocal);
+    if (!rc) rc = bf_bundler_create(maxNumImages, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 0, gas, gbs, &ob->global);
+    if (!rc) rc = bf_trajectory_manager_create(maxNumImages * S, gas->s_topNActive, gas->s_minPoseDistSqrt, &ob->tm);
+    if (rc) { bf_online_bundler_destroy(ob); return rc; }
+    const size_t nAll = (size_t)maxNumImages * S;
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_intensitySIFT, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_intensityFilterHelper, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_completeTrajectory, sizeof(m44) * nAll));
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_localTrajectories, sizeof(m44) * (size_t)maxNumImages * (S + 1)));
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_siftTrajectory, sizeof(m44) * nAll));
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_currIntegrateTransform, sizeof(m44) * nAll));
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_imageInvalidateList, sizeof(int) * nAll));
+    BF_HIP_TRY(hipHostMalloc((void**)&ob->h_pinT, sizeof(m44)));
+    k_fill_identity<<<div_up((uint32_t)(maxNumImages * (S + 1)), 64), 64>>>(ob->d_localTrajectories, maxNumImages * (S + 1));
+    k_fill_identity<<<1, 64>>>(ob->d_siftTrajectory, 1);
+    k_fill_identity<<<1, 64>>>(ob->d_currIntegrateTransform, 1);
+    BF_HIP_TRY(hipMemset(ob->d_completeTrajectory, 0, sizeof(m44) * nAll));
+    BF_HIP_TRY(hipDeviceSynchronize());
+    ob->localTrajectoriesValid.resize(maxNumImages);
+    ob->invalidImagesList.assign(nAll, 1);
+    ob->currIntegrateTransform.assign(nAll, minfM());
+    ob->currIntegrateTransform[0] = identity44();
+    *out = ob;
+    return BF_OK;
+}
+
+int bf_online_bundler_destroy(bf_online_bundler* ob) {
+    if (!ob) return BF_OK;
+    bf_bundler_destroy(ob->local); bf_bundler_destroy(ob->optLocal); bf_bundler_destroy(ob->global); bf_trajectory_manager_destroy(ob->tm);
+    (void)hipFree(ob->d_intensitySIFT); (void)hipFree(ob->d_intensityFilterHelper); (void)hipFree(ob->d_completeTrajectory); (void)hipFree(ob->d_localTrajectories);
+    (void)hipFree(ob->d_siftTrajectory); (void)hipFree(ob->d_currIntegrateTransform); (void)hipFree(ob->d_imageInvalidateList);
+    if (ob->h_pinT) (void)hipHostFree(ob->h_pinT);
+    delete ob;
+    return BF_OK;
+}
+
+int bf_online_bundler_set_stream(bf_online_bundler* ob, void* s) {
+    BF_REQUIRE(ob, "null bundler");
+    ob->stream = (hipStream_t)s;
+    BF_TRY(bf_bundler_set_stream(ob->local, s)); BF_TRY(bf_bundler_set_stream(ob->optLocal, s)); BF_TRY(bf_bundler_set_stream(ob->global, s));
+    return BF_OK;
+}
+
+int bf_online_bundler_process_input(bf_online_bundler* ob) {                                         // :167-227
+    BF_REQUIRE(ob, "null bundler");
+    uint32_t curFrame;
+    BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &curFrame));
+    const bool bIsLastLocal = ob->isLastLocalFrame(curFrame);
+    if (curFrame > 0 && ob->lastFrameProcessed == (int)curFrame) {                 // sequence has ended
+        if (ob->numFramesPastEnd == 0 && ob->localToSolve == -1) { if (!bIsLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, true)); }
+        const uint32_t numSolveFramesBeforeExit = ob->gas.s_numSolveFramesBeforeExit;
+        if (numSolveFramesBeforeExit != 0xFFFFFFFFu) {
+            if (ob->numFramesPastEnd == numSolveFramesBeforeExit) {                 // USE_GLOBAL_DENSE_AT_END (GlobalBundlingState.h:9)
+                if (ob->lastFrameProcessed < 10000) {
+                    ob->gbs.s_numGlobalNonLinIterations = 3;
+                    const float sp[3] = {1.0f, 1.0f, 1.0f}, dd[3] = {15.0f, 15.0f, 15.0f}, dc[3] = {0.0f, 0.0f, 0.0f};
+                    BF_TRY(bf_bundler_set_solve_weights(ob->global, sp, dd, dc, 3));
+                }
+            }
+            if (ob->numFramesPastEnd == numSolveFramesBeforeExit + 1) ob->bUseSolve = false;       // "stopping solve"
+        }
+        ob->numFramesPastEnd++;
+        return BF_OK;
+    }
+    // getCurrentFrame (:106-116): luminance at SIFT resolution straight from the ingest buffer
+    BF_TRY(bf_image_resample_to_intensity(ob->d_intensitySIFT, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->stream));
+    if (ob->gas.s_colorFilter) {
+        BF_TRY(bf_image_gauss_filter_intensity(ob->d_intensityFilterHelper, ob->d_intensitySIFT, ob->gas.s_colorSigmaD, ob->widthSIFT, ob->heightSIFT, ob->stream));
+        std::swap(ob->d_intensityFilterHelper, ob->d_intensitySIFT);
+    }
+    BF_TRY(bf_bundler_detect_features(ob->local, ob->d_intensitySIFT, ob->im->d_depthInputFiltered));
+    BF_TRY(bf_bundler_store_cached_frame(ob->local, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->im->d_depthInputRaw));
+    uint32_t curLocalFrame;
+    BF_TRY(bf_bundler_get_curr_frame_number(ob->local, &curLocalFrame));
+    if (bIsLastLocal) BF_TRY(bf_bundler_copy_frame(ob->optLocal, ob->local, curLocalFrame));
+    ob->bLastFrameValid = true;
+    if (curLocalFrame > 0) {
+        // matchAndFilter + computeCurrentSiftTransform (:118-132) with ONE read-back: the pose kernel is enqueued before the frame
+        // result is fetched (it writes nothing when no pair survived the filters, which is exactly the "invalid" case)
+        uint32_t cur, start, num, last;
+        BF_TRY(matchAndFilterEnqueue(ob->local, cur, start, num));
+        const float* d_Tinv = nullptr; const int32_t* d_nf = nullptr;
+        BF_TRY(bf_bundler_get_current_sift_transforms_gpu(ob->local, &d_Tinv));
+        BF_TRY(bf_bundler_get_num_filt_matches_gpu(ob->local, &d_nf));
+        BF_TRY(bf_compute_sift_transform(d_Tinv, d_nf, (const float*)ob->d_completeTrajectory, ob->lastValidCompleteTransform, (float*)ob->d_siftTrajectory, curFrame,
+                                         curLocalFrame, (float*)(ob->d_currIntegrateTransform + curFrame), ob->stream));
+        BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT, ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
+        BF_TRY(matchAndFilterFinish(ob->local, cur, num, &last));
+        ob->bLastFrameValid = last != 0xFFFFFFFFu;
+        if (!ob->bLastFrameValid) {
+            ob->currIntegrateTransform[curFrame] = minfM();
+            BF_HIP_TRY(hipMemcpyAsync(ob->d_siftTrajectory + curFrame, ob->d_siftTrajectory + curFrame - 1, sizeof(m44), hipMemcpyDeviceToDevice, ob->stream));
+        } else ob->currIntegrateTransform[curFrame] = *ob->h_pinT;
+    }
+    if (bIsLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, false));
+    ob->lastFrameProcessed = (int)curFrame;
+    return BF_OK;
+}
+
+int bf_online_bundler_process(bf_online_bundler* ob, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
+    BF_REQUIRE(ob, "null bundler");
+    if (!ob->bUseSolve) return BF_OK;
+    BF_TRY(obOptimizeLocal(ob, nlLocal, linLocal));
+    BF_TRY(obProcessGlobal(ob));
+    BF_TRY(obOptimizeGlobal(ob, nlGlobal, linGlobal));
+    return BF_OK;
+}
+
+int bf_online_bundler_get_current_integration_frame(bf_online_bundler* ob, float siftTransform[16], uint32_t* frameIdx, int* bGlobalTrackingLost, int* valid) {
+    BF_REQUIRE(ob && siftTransform && frameIdx && bGlobalTrackingLost && valid, "null argument");
+    *bGlobalTrackingLost = ob->bGlobalTrackingLost ? 1 : 0;
+    if (ob->bLastFrameValid && ob->lastFrameProcessed >= 0) {
+        memcpy(siftTransform, ob->currIntegrateTransform[ob->lastFrameProcessed].e, 64);
+        *frameIdx = (uint32_t)ob->lastFrameProcessed;
+        *valid = 1;
+    } else *valid = 0;
+    return BF_OK;
+}
+
+int bf_online_bundler_get_trajectory_manager(bf_online_bundler* ob, bf_trajectory_manager** out) { BF_REQUIRE(ob && out, "null argument"); *out = ob->tm; return BF_OK; }
+int bf_online_bundler_get_curr_processed_frame(bf_online_bundler* ob, int32_t* out) { BF_REQUIRE(ob && out, "null argument"); *out = ob->lastFrameProcessed; return BF_OK; }
+int bf_online_bundler_get_bundler(bf_online_bundler* ob, int which, bf_bundler** out) {
+    BF_REQUIRE(ob && out && which >= 0 && which <= 2, "bad argument");
+    *out = which == 0 ? ob->local : which == 1 ? ob->optLocal : ob->global;
+    return BF_OK;
+}
+int bf_online_bundler_get_complete_trajectory(bf_online_bundler* ob, float* h_out, uint32_t capacity, uint32_t* count) {
+    BF_REQUIRE(ob && h_out && count, "null argument");
+    const uint32_t n = std::min(ob->numCompleteTransforms, capacity);
+    if (n) { BF_HIP_TRY(hipMemcpyAsync(h_out, ob->d_completeTrajectory, sizeof(m44) * n, hipMemcpyDeviceToHost, ob->stream)); BF_HIP_TRY(hipStreamSynchronize(ob->stream)); }
+    *count = n;
+    return BF_OK;
+}
+int bf_online_bundler_save_global_sparse_corrs_to_file(bf_online_bundler* ob, const char* filename) { BF_REQUIRE(ob, "null bundler"); return bf_bundler_save_sparse_corrs_to_file(ob->global, filename); }
+
+}  // extern "C"
+
+// ================================================================================================ frame loop
+struct bf_pipeline {
+    bf_global_app_state gas; bf_global_bundling_state gbs; bf_rgbd_sensor_desc sensor;
+    bf_image_manager* im = nullptr; bf_online_bundler* ob = nullptr; bf_scene* scene = nullptr;
+    bf_depth_camera_params cam;
+    hipStream_t stream = nullptr;
+    uint32_t numIntegrate = 0, numDeIntegrate = 0;
+    bool timings = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bf_frame_timing last;
+};
+
+namespace {
+
+int plIntegrate(bf_pipeline* p, uint32_t frameIdx, const float* T, bool de) {                      // DepthSensing.cpp:723-762
+    if (!p->gas.s_integrationEnabled) return BF_OK;
+    bf_depth_camera_data data;
+    BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frameIdx, &data.d_depthData, &data.d_colorData));
+    if (de) { p->numDeIntegrate++; return bf_scene_deintegrate(p->scene, T, &data, &p->cam, nullptr); }
+    p->numIntegrate++;
+    return bf_scene_integrate(p->scene, T, &data, &p->cam, nullptr);
+}
+
+int plReintegrate(bf_pipeline* p) {                                                                 // :854-902
+    const uint32_t maxPerFrameFixes = p->gas.s_maxFrameFixes;
+    bf_trajectory_manager* tm = p->ob->tm;
+    uint32_t active;
+    BF_TRY(bf_trajectory_manager_get_num_active_operations(tm, &active));
+    if (active < maxPerFrameFixes) BF_TRY(bf_trajectory_manager_generate_update_lists(tm));
+    for (uint32_t fixes = 0; fixes < maxPerFrameFixes; ++fixes) {
+        float newT[16], oldT[16]; uint32_t frameIdx = 0xFFFFFFFFu; int found = 0;
+        BF_TRY(bf_trajectory_manager_get_top_from_deintegrate_list(tm, oldT, &frameIdx, &found));
+        if (found) { BF_TRY(plIntegrate(p, frameIdx, oldT, true)); continue; }
+        BF_TRY(bf_trajectory_manager_get_top_from_integrate_list(tm, newT, &frameIdx, &found));
+        if (found) { BF_TRY(plIntegrate(p, frameIdx, newT, false)); BF_TRY(bf_trajectory_manager_confirm_integration(tm, frameIdx)); continue; }
+        BF_TRY(bf_trajectory_manager_get_top_from_reintegrate_list(tm, oldT, newT, &frameIdx, &found));
+        if (found) {
+            if (newT[0] == NINF) continue;          // every candidate was invalidated meanwhile; it is de-integrated on the next list update
+            BF_TRY(plIntegrate(p, frameIdx, oldT, true));
+            BF_TRY(plIntegrate(p, frameIdx, newT, false));
+            BF_TRY(bf_trajectory_manager_confirm_integration(tm, frameIdx));
+            continue;
+        }
+        break;
+    }
+    if (p->gas.s_garbageCollectionEnabled) BF_TRY(bf_scene_garbage_collect(p->scene));
+    return BF_OK;
+}
+
+int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool device, bool haveInput, int* gotFrame) {    // :966-1095 (serial branch)
+    hipStream_t st = p->stream;
+    if (p->timings) (void)hipEventRecord(p->ev[0], st);
+    int got = 0;
+    if (haveInput) BF_TRY(device ? bf_image_manager_process_device(p->im, depth, color, &got) : bf_image_manager_process(p->im, depth, color, &got));
+    if (p->timings) (void)hipEventRecord(p->ev[1], st);
+    if (p->im->currFrame > 0) BF_TRY(bf_online_bundler_process_input(p->ob));
+    if (p->timings) (void)hipEventRecord(p->ev[2], st);
+    BF_TRY(plReintegrate(p));
+    if (p->timings) (void)hipEventRecord(p->ev[3], st);
+    if (got) {
+        float T[16]; uint32_t frameIdx = 0; int lost = 0, valid = 0;
+        BF_TRY(bf_online_bundler_get_current_integration_frame(p->ob, T, &frameIdx, &lost, &valid));
+        uint32_t cur;
+        BF_TRY(bf_image_manager_get_curr_frame_number(p->im, &cur));
+        if (valid && p->gas.s_reconstructionEnabled) {
+            BF_TRY(plIntegrate(p, frameIdx, T, false));
+            BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_INTEGRATED, T, cur));
+        } else {
+            const m44 inv = minfM();
+            BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_NOT_INTEGRATED_NO_TRANSFORM, inv.e, cur));
+        }
+    }
+    if (p->timings) (void)hipEventRecord(p->ev[4], st);
+    if (p->im->currFrame > 0)
+        BF_TRY(bf_online_bundler_process(p->ob, p->gbs.s_numLocalNonLinIterations, p->gbs.s_numLocalLinIterations, p->ob->gbs.s_numGlobalNonLinIterations,
+                                         p->gbs.s_numGlobalLinIterations));
+    if (p->timings) {
+        (void)hipEventRecord(p->ev[5], st);
+        (void)hipEventSynchronize(p->ev[5]);
+        float ms[5];
+        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]);
+        memset(&p->last, 0, sizeof p->last);
+        p->last.timeSensorProcess = ms[0]; p->last.timeSiftDetection = ms[1]; p->last.timeReIntegrate = ms[2]; p->last.timeReconstruct = ms[3]; p->last.timeSolve = ms[4];
+        p->last.timeTotal = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+    }
+    if (gotFrame) *gotFrame = got;
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_state* gbs, const bf_rgbd_sensor_desc* sensor, bf_pipeline** out) {
+    BF_REQUIRE(gas && gbs && sensor && out, "null argument");
+    BF_REQUIRE(!gas->s_streamingEnabled, "chunk streaming is not part of the BundleFusion path (zParametersDefault.txt:100)");
+    bf_pipeline* p = new bf_pipeline;
+    p->gas = *gas; p->gbs = *gbs; p->sensor = *sensor;
+    memset(&p->last, 0, sizeof p->last);
+    int rc = bf_image_manager_create(gas->s_integrationWidth, gas->s_integrationHeight, gbs->s_widthSIFT, gbs->s_heightSIFT, sensor, gbs, 1, &p->im);
+    if (!rc) rc = bf_online_bundler_create(sensor, p->im, gas, gbs, &p->ob);
+    bf_hash_params hp;                                          // CUDASceneRepHashSDF::parametersFromGlobalAppState :39-59
+    memset(&hp, 0, sizeof hp);
+    const m44 I = identity44();
+    memcpy(hp.m_rigidTransform, I.e, 64); memcpy(hp.m_rigidTransformInverse, I.e, 64);
+    hp.m_hashNumBuckets = gas->s_hashNumBuckets; hp.m_hashBucketSize = 4; hp.m_hashMaxCollisionLinkedListSize = gas->s_hashMaxCollisionLinkedListSize;
+    hp.m_SDFBlockSize = 8; hp.m_numSDFBlocks = gas->s_hashNumSDFBlocks; hp.m_virtualVoxelSize = gas->s_SDFVoxelSize;
+    hp.m_maxIntegrationDistance = gas->s_SDFMaxIntegrationDistance; hp.m_truncation = gas->s_SDFTruncation; hp.m_truncScale = gas->s_SDFTruncationScale;
+    hp.m_integrationWeightSample = gas->s_SDFIntegrationWeightSample; hp.m_integrationWeightMax = gas->s_SDFIntegrationWeightMax;
+    for (int i = 0; i < 3; ++i) { hp.m_streamingVoxelExtents[i] = gas->s_streamingVoxelExtents[i]; hp.m_streamingGridDimensions[i] = gas->s_streamingGridDimensions[i]; hp.m_streamingMinGridPos[i] = gas->s_streamingMinGridPos[i]; }
+    hp.m_streamingInitialChunkListSize = gas->s_streamingInitialChunkListSize;
+    if (!rc) rc = bf_scene_create(&hp, &p->scene);
+    if (rc) { bf_pipeline_destroy(p); return rc; }
+    p->cam.fx = p->im->depthIntrinsics.e[0]; p->cam.fy = p->im->depthIntrinsics.e[5]; p->cam.mx = p->im->depthIntrinsics.e[2]; p->cam.my = p->im->depthIntrinsics.e[6];
+    p->cam.m_sensorDepthWorldMin = gas->s_renderDepthMin; p->cam.m_sensorDepthWorldMax = gas->s_renderDepthMax;      // DepthSensing.cpp:636-643
+    p->cam.m_imageWidth = gas->s_integrationWidth; p->cam.m_imageHeight = gas->s_integrationHeight;
+    for (auto& e : p->ev) BF_HIP_TRY(hipEventCreate(&e));
+    *out = p;
+    return BF_OK;
+}
+
+int bf_pipeline_destroy(bf_pipeline* p) {
+    if (!p) return BF_OK;
+    (void)hipDeviceSynchronize();
+    bf_online_bundler_destroy(p->ob); bf_image_manager_destroy(p->im); bf_scene_destroy(p->scene);
+    for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+    delete p;
+    return BF_OK;
+}
+
+int bf_pipeline_process_frame(bf_pipeline* p, const float* h_depth, const uint8_t* h_color, int* gotFrame) {
+    BF_REQUIRE(p, "null pipeline");
+    return plFrame(p, h_depth, h_color, false, true, gotFrame);
+}
+int bf_pipeline_process_frame_device(bf_pipeline* p, const float* d_depth, const uint8_t* d_color, int* gotFrame) {
+    BF_REQUIRE(p, "null pipeline");
+    return plFrame(p, d_depth, d_color, true, true, gotFrame);
+}
+int bf_pipeline_process_end_of_sequence(bf_pipeline* p, uint32_t* numActiveOperations) {
+    BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFrame(p, nullptr, nullptr, false, false, nullptr));
+    if (numActiveOperations) BF_TRY(bf_trajectory_manager_get_num_active_operations(p->ob->tm, numActiveOperations));
+    return BF_OK;
+}
+int bf_pipeline_synchronize(bf_pipeline* p) { BF_REQUIRE(p, "null pipeline"); BF_HIP_TRY(hipStreamSynchronize(p->stream)); return BF_OK; }
+int bf_pipeline_get_scene(bf_pipeline* p, bf_scene** out) { BF_REQUIRE(p && out, "null argument"); *out = p->scene; return BF_OK; }
+int bf_pipeline_get_image_manager(bf_pipeline* p, bf_image_manager** out) { BF_REQUIRE(p && out, "null argument"); *out = p->im; return BF_OK; }
+int bf_pipeline_get_online_bundler(bf_pipeline* p, bf_online_bundler** out) { BF_REQUIRE(p && out, "null argument"); *out = p->ob; return BF_OK; }
+int bf_pipeline_get_num_frames(bf_pipeline* p, uint32_t* out) { BF_REQUIRE(p && out, "null argument"); *out = p->im->currFrame; return BF_OK; }
+int bf_pipeline_get_integrated_trajectory(bf_pipeline* p, float* h_out, uint32_t capacity, uint32_t* count) {
+    BF_REQUIRE(p && h_out && count, "null argument");
+    const uint32_t n = std::min(p->ob->tm->numAddedFrames, capacity);
+    for (uint32_t i = 0; i < n; ++i) {
+        const auto& f = p->ob->tm->frames[i];
+        const bool in = f.type == BF_TF_INTEGRATED || f.type == BF_TF_REINTEGRATION;
+        const m44 T = in ? f.integratedTransform : minfM();
+        memcpy(h_out + 16 * (size_t)i, T.e, 64);
+    }
+    *count = n;
+    return BF_OK;
+}
+int bf_pipeline_get_counters(bf_pipeline* p, uint32_t* numIntegrate, uint32_t* numDeIntegrate, uint32_t* numLocalSolves, uint32_t* numGlobalSolves) {
+    BF_REQUIRE(p, "null pipeline");
+    if (numIntegrate) *numIntegrate = p->numIntegrate;
+    if (numDeIntegrate) *numDeIntegrate = p->numDeIntegrate;
+    if (numLocalSolves) *numLocalSolves = p->ob->numLocalSolves;
+    if (numGlobalSolves) *numGlobalSolves = p->ob->numGlobalSolves;
+    return BF_OK;
+}
+int bf_pipeline_enable_timings(bf_pipeline* p, int enable) { BF_REQUIRE(p, "null pipeline"); p->timings = enable != 0; return BF_OK; }
+int bf_pipeline_get_last_timing(bf_pipeline* p, bf_frame_timing* out) { BF_REQUIRE(p && out, "null argument"); *out = p->last; return BF_OK; }
+
+}  // extern "C"

@@ -765,6 +765,11 @@ __global__ void k_check_invalid(const int* numEntriesPerRow, int* validImages, u
 }
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
+__global__ void k_reset_valid(int* valid, uint32_t n, int* globNum) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) valid[i] = i == 0 ? 1 : 0;
+    if (i == 0) *globNum = 0;
+}
 
 template <class T>
 int dalloc(T*& p, size_t n) { BF_HIP_TRY(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return BF_OK; }
@@ -785,6 +790,7 @@ struct bf_siftmgr {
     std::vector<int> validImages;
     uint32_t numImages = 0, currentImage = 0, globNumResiduals = 0;
     bool finalized = true;
+    bool validDirty = false;          // host copy of the valid flags changed since the last upload
     std::deque<uint32_t> retry;
 };
 
@@ -832,11 +838,11 @@ int bf_siftmgr_set_stream(bf_siftmgr* m, void* s) { BF_REQUIRE(m, "null manager"
 int bf_siftmgr_reset(bf_siftmgr* m) {                 // SIFTImageManager.h:112-124
     BF_REQUIRE(m, "null manager");
     m->numImages = 0; m->currentImage = 0; m->globNumResiduals = 0; m->finalized = true;
-    BF_HIP_TRY(hipMemsetAsync(m->d_globNum, 0, sizeof(int), m->stream));
     m->validImages.assign(m->maxImages, 0);
     m->validImages[0] = 1;
-    BF_HIP_TRY(hipMemcpyAsync(m->d_validImages, m->validImages.data(), sizeof(int) * m->maxImages, hipMemcpyHostToDevice, m->stream));
-    BF_HIP_TRY(hipStreamSynchronize(m->stream));
+    m->validDirty = false;
+    k_reset_valid<<<div_up(m->maxImages, 256), 256, 0, m->stream>>>(m->d_validImages, m->maxImages, m->d_globNum);     // asynchronous: no host wait
+    BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
 
@@ -1027,14 +1033,16 @@ int bf_siftmgr_get_valid_images(bf_siftmgr* m, int32_t* h_out, uint32_t count) {
 }
 int bf_siftmgr_set_valid_image(bf_siftmgr* m, uint32_t frame, int32_t valid) {     // invalidateFrame / setValidImagesDEBUG
     BF_REQUIRE(m && frame < m->maxImages, "frame out of range");
+    if (m->validImages[frame] != valid) m->validDirty = true;
     m->validImages[frame] = valid;
     return BF_OK;
 }
 int bf_siftmgr_update_gpu_valid_images(bf_siftmgr* m) {                            // updateGPUValidImages .h:160-162
     BF_REQUIRE(m, "null manager");
-    if (m->numImages == 0) return BF_OK;
+    if (m->numImages == 0 || !m->validDirty) return BF_OK;       // device flags already mirror the host's
     BF_HIP_TRY(hipMemcpyAsync(m->d_validImages, m->validImages.data(), sizeof(int) * m->numImages, hipMemcpyHostToDevice, m->stream));
     BF_HIP_TRY(hipStreamSynchronize(m->stream));
+    m->validDirty = false;
     return BF_OK;
 }
 int bf_siftmgr_get_valid_images_gpu(bf_siftmgr* m, const int32_t** d_out) { BF_REQUIRE(m && d_out, "null argument"); *d_out = m->d_validImages; return BF_OK; }

@@ -61,6 +61,7 @@ struct Dev {
     int* flags;
     float* energies;
     float* maxRes; int* maxIdx; int* highCount;
+    int* numEntriesPerRow;
     uint32_t maxSlots, maxPairs;
 };
 
@@ -86,6 +87,16 @@ __global__ void k_key_count(Dev d) {
     if (!validCorr(e) || e.imgIdx_i >= d.N || e.imgIdx_j >= d.N) return;
     atomicAdd(&d.keyCount[e.imgIdx_i * d.N + e.imgIdx_j], 1u);     // integer atomics: order-independent
     atomicAdd(&d.keyCount[e.imgIdx_j * d.N + e.imgIdx_i], 1u);
+}
+
+// d_numEntriesPerRow of the reference's variable -> correspondence table (SolverBundling.cu:1226-1248): the number of
+// valid correspondences that touch image i == the sum of row i of the directed key counts
+__global__ void k_row_entries(Dev d) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < d.N; ++j) n += d.keyCount[i * d.N + j];
+    d.numEntriesPerRow[i] = (int)n;
 }
 
 // single-workgroup three-channel exclusive scan over the N*N directed keys (key order = CSR order)
@@ -799,7 +810,7 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
               sAlloc(s, &d.delta, N * 6) && sAlloc(s, &d.r, N * 6) && sAlloc(s, &d.p, N * 6) && sAlloc(s, &d.Ap, N * 6) &&
               sAlloc(s, &d.densePairs, (size_t)d.maxPairs) && sAlloc(s, &d.denseWeight, (size_t)d.maxPairs) &&
               sAlloc(s, &d.denseBlocks, (size_t)d.maxPairs * DENSE_BLK) && sAlloc(s, &d.flags, FL_COUNT) && sAlloc(s, &d.energies, 40) &&
-              sAlloc(s, &d.maxRes, 1) && sAlloc(s, &d.maxIdx, 1) && sAlloc(s, &d.highCount, 1);
+              sAlloc(s, &d.maxRes, 1) && sAlloc(s, &d.maxIdx, 1) && sAlloc(s, &d.highCount, 1) && sAlloc(s, &d.numEntriesPerRow, N);
     if (!ok) { set_error("bf_solver_create: hipMalloc failed"); bf_solver_destroy(s); return BF_ERR_HIP; }
     (void)hipMemset(d.flags, 0, FL_COUNT * sizeof(int));
     *out = s;
@@ -862,6 +873,7 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
             hipLaunchKernelGGL(k_dense_overlap, grid, dim3(512), 0, st, d, c);
         }
         if (numCorr) hipLaunchKernelGGL(k_key_count, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
+        if (it == 0) hipLaunchKernelGGL(k_row_entries, dim3(div_up(N, 64)), dim3(64), 0, st, d);     // table as of solve start (rebuildJT)
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, d, useDense);
         if (numCorr) hipLaunchKernelGGL(k_fill, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
         if (useDense) {
@@ -893,6 +905,12 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
         s->convergence.assign(nNonLin + 1, -1.0f);                           // .cpp:202
         for (int k = 0; k <= flags[FL_GN_ITERS] && k <= (int)nNonLin; ++k) s->convergence[k] = en[k];
     }
+    return BF_OK;
+}
+
+int bf_solver_get_var_to_corr_num_entries_per_row(bf_solver* s, const int32_t** d_out) {
+    BF_REQUIRE(s && d_out, "null argument");
+    *d_out = s->d.numEntriesPerRow;
     return BF_OK;
 }
 

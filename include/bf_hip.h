@@ -253,6 +253,9 @@ BF_API int bf_solver_solve(bf_solver* s, bf_entry_j* d_correspondences, uint32_t
                            const float* weightsDenseDepth, const float* weightsDenseColor, uint32_t numWeights,
                            int usePairwiseDense, float* d_rot, float* d_trans, int rebuildJT, int findMaxResidual,
                            uint32_t revalidateIdx);
+/* getVarToCorrNumEntriesPerRow(): device int[numberOfImages], #valid correspondences touching each image at the
+ * last solve                                                    CUDASolverBundling.h:48 */
+BF_API int bf_solver_get_var_to_corr_num_entries_per_row(bf_solver* s, const int32_t** d_out);
 /* getMaxResidual(max, index)                                   CUDASolverBundling.h:37-40 */
 BF_API int bf_solver_get_max_residual(bf_solver* s, float* max, int32_t* index);
 /* getMaxResidual(curFrame, d_corr, imageIndices, maxRes) -> remove?   .cpp:429-452 */
@@ -408,6 +411,28 @@ BF_API int bf_siftmgr_get_top_retry_image(bf_siftmgr* m, uint32_t* idx, int* fou
 /* fuseToGlobal(global, colorIntrinsics, d_transforms, colorIntrinsicsInv)   SIFTImageManager.cpp:367-476 */
 BF_API int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16],
                                      const float* d_transforms, const float colorIntrinsicsInv[16]);
+
+
+/* ------------------------------------------------------------------------- */
+/* Frame-ingest image operators:  CUDAImageUtil.h / CUDAImageUtil.cu          */
+/* (device pointers, asynchronous on hip_stream)                              */
+/* ------------------------------------------------------------------------- */
+/* erodeDepthMap(d_output, d_input, structureSize, w, h, dThresh, fracReq)     CUDAImageUtil.cu:701-757 */
+BF_API int bf_image_erode_depth_map(float* d_output, const float* d_input, int structureSize, uint32_t width, uint32_t height,
+                                    float dThresh, float fracReq, void* hip_stream);
+/* gaussFilterDepthMap(d_output, d_input, sigmaD, sigmaR, w, h)                :759-809 */
+BF_API int bf_image_gauss_filter_depth_map(float* d_output, const float* d_input, float sigmaD, float sigmaR, uint32_t width,
+                                           uint32_t height, void* hip_stream);
+/* gaussFilterIntensity(d_output, d_input, sigmaD, w, h)                       :811-859 */
+BF_API int bf_image_gauss_filter_intensity(float* d_output, const float* d_input, float sigmaD, uint32_t width, uint32_t height,
+                                           void* hip_stream);
+/* resampleFloat / resampleUCHAR4 / resampleToIntensity                        :93-124, :160-191, :201-258 */
+BF_API int bf_image_resample_float(float* d_output, uint32_t outputWidth, uint32_t outputHeight, const float* d_input,
+                                   uint32_t inputWidth, uint32_t inputHeight, void* hip_stream);
+BF_API int bf_image_resample_uchar4(uint8_t* d_output, uint32_t outputWidth, uint32_t outputHeight, const uint8_t* d_input,
+                                    uint32_t inputWidth, uint32_t inputHeight, void* hip_stream);
+BF_API int bf_image_resample_to_intensity(float* d_output, uint32_t outputWidth, uint32_t outputHeight, const uint8_t* d_input,
+                                          uint32_t inputWidth, uint32_t inputHeight, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,244 @@
+/*
+ * bf_pipeline.h — C ABI of the host-level operators of the BundleFusion hot path on MI355X:
+ * the parameter files, CUDAImageManager, Bundler, OnlineBundler, TrajectoryManager and the
+ * headless per-frame loop.  Kernel-level entry points live in bf_hip.h.
+ *
+ * Every entry cites the reference interface it replaces (paths relative to
+ * /root/reference/FriedLiver/Source).  Pointers named d_* are device pointers on the GPU the object was
+ * created on, h_* host pointers; 4x4 matrices are 16 floats, row-major (mat4f / float4x4).
+ * All functions return BF_OK (0) or a bf_status error; bf_last_error() holds the message
+ * (the reference throws MLIB_EXCEPTION in those places).
+ */
+#ifndef BF_PIPELINE_H
+#define BF_PIPELINE_H
+
+#include "bf_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Parameter files:  GlobalAppState.h:24-104, GlobalBundlingState.h:15-65     */
+/* (name = value; lines, // comments; parsed like ml::ParameterFile)          */
+/* ------------------------------------------------------------------------- */
+
+/* the GlobalAppState fields the hot path reads (rendering / recording / streaming keys are accepted and ignored) */
+typedef struct bf_global_app_state {
+    uint32_t s_sensorIdx;
+    uint32_t s_integrationWidth, s_integrationHeight;
+    uint32_t s_maxFrameFixes, s_topNActive;
+    float s_minPoseDistSqrt;
+    float s_sensorDepthMax, s_sensorDepthMin;
+    float s_renderDepthMax, s_renderDepthMin;
+    uint32_t s_hashNumBuckets, s_hashNumSDFBlocks, s_hashMaxCollisionLinkedListSize;
+    float s_SDFVoxelSize, s_SDFTruncation, s_SDFTruncationScale, s_SDFMaxIntegrationDistance;
+    uint32_t s_SDFIntegrationWeightSample, s_SDFIntegrationWeightMax;
+    float s_colorSigmaD, s_colorSigmaR;
+    int32_t s_colorFilter;
+    int32_t s_integrationEnabled, s_garbageCollectionEnabled, s_reconstructionEnabled, s_streamingEnabled;
+    int32_t s_bUseCameraCalibration, s_binaryDumpSensorUseTrajectory;
+    uint32_t s_garbageCollectionStarve;
+    float s_streamingVoxelExtents[3];
+    int32_t s_streamingGridDimensions[3], s_streamingMinGridPos[3];
+    uint32_t s_streamingInitialChunkListSize;
+    uint32_t s_numSolveFramesBeforeExit;
+} bf_global_app_state;
+
+typedef struct bf_global_bundling_state {
+    int32_t s_enableGlobalTimings, s_enablePerFrameTimings;
+    uint32_t s_maxNumImages, s_submapSize, s_widthSIFT, s_heightSIFT, s_maxNumKeysPerImage;
+    uint32_t s_numLocalNonLinIterations, s_numLocalLinIterations, s_numGlobalNonLinIterations, s_numGlobalLinIterations;
+    uint32_t s_downsampledWidth, s_downsampledHeight;
+    float s_verifySiftErrThresh, s_verifySiftCorrThresh, s_projCorrDistThres, s_projCorrNormalThres, s_projCorrColorThresh;
+    float s_surfAreaPcaThresh;
+    int32_t s_recordSolverConvergence, s_erodeSIFTdepth;
+    float s_verifyOptErrThresh, s_verifyOptCorrThresh;
+    int32_t s_verbose, s_sendUplinkFeedbackImage;
+    float s_depthSigmaD, s_depthSigmaR;
+    int32_t s_depthFilter;
+    uint32_t s_minNumMatchesLocal, s_minNumMatchesGlobal;
+    int32_t s_useComprehensiveFrameInvalidation;
+    float s_maxKabschResidual2, s_minKeyScale, s_siftMatchThresh, s_siftMatchRatioMaxLocal, s_siftMatchRatioMaxGlobal;
+    int32_t s_useLocalVerify, s_useLocalDense;
+    uint32_t s_numOptPerResidualRemoval;
+    float s_colorDownSigma, s_depthDownSigmaD, s_depthDownSigmaR;
+    float s_optMaxResThresh, s_denseDistThresh, s_denseNormalThresh, s_denseColorThresh, s_denseColorGradientMin;
+    float s_denseDepthMin, s_denseDepthMax;
+    uint32_t s_denseOverlapCheckSubsampleFactor;
+} bf_global_bundling_state;
+
+/* defaults = the values of zParametersDefault.txt / zParametersBundlingDefault.txt as shipped */
+BF_API int bf_global_app_state_default(bf_global_app_state* out);
+BF_API int bf_global_bundling_state_default(bf_global_bundling_state* out);
+/* GlobalAppState::readMembers(ParameterFile) GlobalAppState.h:128-136 / GlobalBundlingState.h:90-98.  Starts from
+ * the defaults; *numMissing (optional) counts fields that the file did not set (the reference warns per field). */
+BF_API int bf_global_app_state_read(const char* filename, bf_global_app_state* out, uint32_t* numMissing);
+BF_API int bf_global_bundling_state_read(const char* filename, bf_global_bundling_state* out, uint32_t* numMissing);
+
+/* ------------------------------------------------------------------------- */
+/* RGBDSensor accessor contract (RGBDSensor.h:25-61) as plain data            */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_rgbd_sensor_desc {
+    uint32_t depthWidth, depthHeight, colorWidth, colorHeight;
+    float depthIntrinsics[16], colorIntrinsics[16];
+    float depthExtrinsics[16], colorExtrinsics[16];
+} bf_rgbd_sensor_desc;
+
+/* ------------------------------------------------------------------------- */
+/* CUDAImageManager:  CUDAImageManager.h:10-337, .cpp:22-158                  */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_image_manager bf_image_manager;
+
+/* CUDAImageManager(widthIntegration, heightIntegration, widthSIFT, heightSIFT, sensor, storeFramesOnGPU)  .h:140-194 */
+BF_API int bf_image_manager_create(uint32_t widthIntegration, uint32_t heightIntegration, uint32_t widthSIFT, uint32_t heightSIFT,
+                                   const bf_rgbd_sensor_desc* sensor, const bf_global_bundling_state* gbs, int storeFramesOnGPU,
+                                   bf_image_manager** out);
+BF_API int bf_image_manager_destroy(bf_image_manager* im);
+BF_API int bf_image_manager_set_stream(bf_image_manager* im, void* hip_stream);
+BF_API int bf_image_manager_reset(bf_image_manager* im);
+/* process()  .cpp:22-158.  h_depth = sensor->getDepthFloat() (metres, -inf invalid), h_colorRGBX = getColorRGBX().
+ * *gotFrame = 0 when the frame capacity (s_maxNumImages * s_submapSize) is reached.
+ * The _device form takes the same two images already resident in HBM (no PCIe transfer).          */
+BF_API int bf_image_manager_process(bf_image_manager* im, const float* h_depth, const uint8_t* h_colorRGBX, int* gotFrame);
+BF_API int bf_image_manager_process_device(bf_image_manager* im, const float* d_depth, const uint8_t* d_colorRGBX, int* gotFrame);
+/* copyToBundling(d_depthRaw, d_depthFilt, d_color)  .h:223-227 */
+BF_API int bf_image_manager_copy_to_bundling(bf_image_manager* im, float* d_depthRaw, float* d_depthFilt, uint8_t* d_color);
+/* the device input buffers themselves (d_depthInputRaw, d_depthInputFiltered, d_colorInput) */
+BF_API int bf_image_manager_get_input_gpu(bf_image_manager* im, const float** d_depthRaw, const float** d_depthFilt, const uint8_t** d_color);
+/* getIntegrateFrame(i).getDepthFrameGPU() / getColorFrameGPU()  .h:71-96 */
+BF_API int bf_image_manager_get_integrate_frame_gpu(bf_image_manager* im, uint32_t frame, const float** d_depth, const uint8_t** d_color);
+BF_API int bf_image_manager_get_curr_frame_number(bf_image_manager* im, uint32_t* out);   /* getCurrFrameNumber (after process) */
+BF_API int bf_image_manager_get_num_frames(bf_image_manager* im, uint32_t* out);
+BF_API int bf_image_manager_get_integration_size(bf_image_manager* im, uint32_t* width, uint32_t* height);
+BF_API int bf_image_manager_get_depth_intrinsics(bf_image_manager* im, float intrinsics[16], float intrinsicsInv[16]);
+BF_API int bf_image_manager_get_depth_extrinsics(bf_image_manager* im, float extrinsics[16], float extrinsicsInv[16]);
+BF_API int bf_image_manager_get_sift_depth(bf_image_manager* im, uint32_t* width, uint32_t* height, float intrinsics[16]);
+
+/* ------------------------------------------------------------------------- */
+/* Bundler:  Bundler.h:17-104, Bundler.cpp                                     */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_bundler bf_bundler;
+
+/* Bundler(maxNumImages, maxNumKeysPerImage, siftIntrinsicsInv, imageManager, isLocal)  Bundler.cpp:19-54 */
+BF_API int bf_bundler_create(uint32_t maxNumImages, uint32_t maxNumKeysPerImage, const float siftIntrinsicsInv[16],
+                             bf_image_manager* manager, int isLocal, const bf_global_app_state* gas,
+                             const bf_global_bundling_state* gbs, bf_bundler** out);
+BF_API int bf_bundler_destroy(bf_bundler* b);
+BF_API int bf_bundler_set_stream(bf_bundler* b, void* hip_stream);
+BF_API int bf_bundler_get_trajectory_gpu(bf_bundler* b, float** d_trajectory);                 /* getTrajectoryGPU */
+BF_API int bf_bundler_get_valid_images(bf_bundler* b, int32_t* h_out, uint32_t count);          /* getValidImages */
+BF_API int bf_bundler_get_cache_intrinsics(bf_bundler* b, float intrinsics[16], float intrinsicsInv[16]);
+BF_API int bf_bundler_get_curr_frame_number(bf_bundler* b, uint32_t* out);
+BF_API int bf_bundler_get_num_frames(bf_bundler* b, uint32_t* out);
+BF_API int bf_bundler_is_valid(bf_bundler* b, int* out);                                        /* isValid :295-304 */
+BF_API int bf_bundler_reset(bf_bundler* b);                                                     /* :354-360 */
+BF_API int bf_bundler_detect_features(bf_bundler* b, const float* d_intensitySift, const float* d_inputDepthFilt);  /* :91-101 */
+BF_API int bf_bundler_store_cached_frame(bf_bundler* b, uint32_t depthWidth, uint32_t depthHeight, const uint8_t* d_inputColor,
+                                         uint32_t colorWidth, uint32_t colorHeight, const float* d_inputDepthRaw);  /* :279-282 */
+BF_API int bf_bundler_copy_frame(bf_bundler* b, bf_bundler* from, uint32_t frame);              /* :284-293 */
+BF_API int bf_bundler_add_invalid_frame(bf_bundler* b);                                         /* :362-368 */
+BF_API int bf_bundler_invalidate_last_frame(bf_bundler* b);                                     /* :375-386 */
+BF_API int bf_bundler_get_current_sift_transforms_gpu(bf_bundler* b, const float** d_out);      /* getCurrentSiftTransformsGPU */
+BF_API int bf_bundler_get_num_filt_matches_gpu(bf_bundler* b, const int32_t** d_out);
+BF_API int bf_bundler_match_and_filter(bf_bundler* b, uint32_t* lastMatchedFrame);              /* :103-249 */
+BF_API int bf_bundler_optimize(bf_bundler* b, uint32_t numNonLinIterations, uint32_t numLinIterations, int bUseVerify,
+                               int bRemoveMaxResidual, int bIsScanDone, int* bOptRemoved, int* valid);   /* :251-277 */
+BF_API int bf_bundler_set_solve_weights(bf_bundler* b, const float* sparse, const float* denseDepth, const float* denseColor, uint32_t n);
+BF_API int bf_bundler_fuse_to_global(bf_bundler* b, bf_bundler* glob);                           /* :388-394 */
+BF_API int bf_bundler_try_revalidation(bf_bundler* b, uint32_t curGlobalFrame, int bIsScanDone, uint32_t* revalidatedIdx);  /* :306-352 */
+BF_API int bf_bundler_get_revalidated_idx(bf_bundler* b, uint32_t* out);
+BF_API int bf_bundler_save_sparse_corrs_to_file(bf_bundler* b, const char* filename);           /* :396-409 */
+/* the operators a Bundler owns (for inspection) */
+BF_API int bf_bundler_get_sift_manager(bf_bundler* b, bf_siftmgr** out);
+BF_API int bf_bundler_get_cache(bf_bundler* b, bf_cache** out);
+BF_API int bf_bundler_get_solver(bf_bundler* b, bf_solver** out);
+
+/* ------------------------------------------------------------------------- */
+/* TrajectoryManager:  TrajectoryManager.h:6-116, .cpp                        */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_trajectory_manager bf_trajectory_manager;
+enum { BF_TF_INTEGRATED = 0, BF_TF_NOT_INTEGRATED_NO_TRANSFORM = 1, BF_TF_NOT_INTEGRATED_WITH_TRANSFORM = 2, BF_TF_INVALID = 3, BF_TF_REINTEGRATION = 4 };
+
+BF_API int bf_trajectory_manager_create(uint32_t numMaxImage, uint32_t topNActive, float minPoseDistSqrt, bf_trajectory_manager** out);
+BF_API int bf_trajectory_manager_destroy(bf_trajectory_manager* tm);
+BF_API int bf_trajectory_manager_add_frame(bf_trajectory_manager* tm, int type, const float transform[16], uint32_t idx);
+BF_API int bf_trajectory_manager_update_optimized_transform(bf_trajectory_manager* tm, const float* d_trajectory, uint32_t numFrames, void* hip_stream);
+BF_API int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm);
+BF_API int bf_trajectory_manager_confirm_integration(bf_trajectory_manager* tm, uint32_t frameIdx);
+BF_API int bf_trajectory_manager_get_top_from_reintegrate_list(bf_trajectory_manager* tm, float oldTransform[16], float newTransform[16], uint32_t* frameIdx, int* found);
+BF_API int bf_trajectory_manager_get_top_from_integrate_list(bf_trajectory_manager* tm, float trans[16], uint32_t* frameIdx, int* found);
+BF_API int bf_trajectory_manager_get_top_from_deintegrate_list(bf_trajectory_manager* tm, float trans[16], uint32_t* frameIdx, int* found);
+BF_API int bf_trajectory_manager_get_num_optimized_frames(bf_trajectory_manager* tm, uint32_t* out);
+BF_API int bf_trajectory_manager_get_num_added_frames(bf_trajectory_manager* tm, uint32_t* out);
+BF_API int bf_trajectory_manager_get_num_active_operations(bf_trajectory_manager* tm, uint32_t* out);
+BF_API int bf_trajectory_manager_get_optimized_transforms(bf_trajectory_manager* tm, float* h_out, uint32_t capacity, uint32_t* count);
+/* getFrames(): type and integrated transform of frame i */
+BF_API int bf_trajectory_manager_get_frame(bf_trajectory_manager* tm, uint32_t idx, int* type, float integratedTransform[16], float* dist);
+
+/* ------------------------------------------------------------------------- */
+/* OnlineBundler:  OnlineBundler.h:10-106, .cpp, .cu                          */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_online_bundler bf_online_bundler;
+
+/* OnlineBundler(sensor, imageManager)  OnlineBundler.cpp:31-91 */
+BF_API int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager* imageManager, const bf_global_app_state* gas,
+                                    const bf_global_bundling_state* gbs, bf_online_bundler** out);
+BF_API int bf_online_bundler_destroy(bf_online_bundler* ob);
+BF_API int bf_online_bundler_set_stream(bf_online_bundler* ob, void* hip_stream);
+BF_API int bf_online_bundler_process_input(bf_online_bundler* ob);                               /* processInput :167-227 */
+BF_API int bf_online_bundler_process(bf_online_bundler* ob, uint32_t numNonLinItersLocal, uint32_t numLinItersLocal,
+                                     uint32_t numNonLinItersGlobal, uint32_t numLinItersGlobal);  /* process :410-416 */
+/* getCurrentIntegrationFrame(siftTransform, frameIdx, bGlobalTrackingLost) -> valid  :229-240 */
+BF_API int bf_online_bundler_get_current_integration_frame(bf_online_bundler* ob, float siftTransform[16], uint32_t* frameIdx,
+                                                           int* bGlobalTrackingLost, int* valid);
+BF_API int bf_online_bundler_get_trajectory_manager(bf_online_bundler* ob, bf_trajectory_manager** out);
+BF_API int bf_online_bundler_get_curr_processed_frame(bf_online_bundler* ob, int32_t* out);
+BF_API int bf_online_bundler_get_bundler(bf_online_bundler* ob, int which /* 0 local, 1 optLocal, 2 global */, bf_bundler** out);
+BF_API int bf_online_bundler_get_complete_trajectory(bf_online_bundler* ob, float* h_out, uint32_t capacity, uint32_t* count);
+BF_API int bf_online_bundler_save_global_sparse_corrs_to_file(bf_online_bundler* ob, const char* filename);
+/* the three trajectory kernels of OnlineBundler.cu (computeSiftTransformCU / updateTrajectoryCU / initNextGlobalTransformCU) */
+BF_API int bf_compute_sift_transform(const float* d_currFilteredTransformsInv, const int32_t* d_currNumFilteredMatchesPerImagePair,
+                                     const float* d_completeTrajectory, uint32_t lastValidCompleteTransform, float* d_siftTrajectory,
+                                     uint32_t curFrameIndexAll, uint32_t curFrameIndex, float* d_currIntegrateTrans, void* hip_stream);
+BF_API int bf_update_trajectory(const float* d_globalTrajectory, uint32_t numGlobalTransforms, float* d_completeTrajectory,
+                                uint32_t numCompleteTransforms, const float* d_localTrajectories, uint32_t numLocalTransformsPerTrajectory,
+                                uint32_t numLocalTrajectories, const int32_t* d_imageInvalidateList, void* hip_stream);
+BF_API int bf_init_next_global_transform(float* d_globalTrajectory, uint32_t numGlobalTransforms, uint32_t initGlobalIdx,
+                                         const float* d_localTrajectories, uint32_t lastValidLocal, uint32_t numLocalTransformsPerTrajectory,
+                                         void* hip_stream);
+
+/* ------------------------------------------------------------------------- */
+/* Headless frame loop: the serial (non RUN_MULTITHREADED) body of            */
+/* OnD3D11FrameRender, DepthSensing/DepthSensing.cpp:966-1095, with           */
+/* integrate / deIntegrate / reintegrate :723-762, :854-902                   */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_pipeline bf_pipeline;
+
+typedef struct bf_frame_timing {      /* TimingLog::FrameTiming, TimingLog.h:9-21 (milliseconds, hipEvent based) */
+    float timeSensorProcess, timeSiftDetection, timeSiftMatching, timeMatchFilter, timeSolve, timeReIntegrate, timeReconstruct, timeTotal;
+} bf_frame_timing;
+
+BF_API int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_state* gbs, const bf_rgbd_sensor_desc* sensor,
+                              bf_pipeline** out);
+BF_API int bf_pipeline_destroy(bf_pipeline* p);
+/* one iteration of the frame loop with a new sensor frame (host or device resident) */
+BF_API int bf_pipeline_process_frame(bf_pipeline* p, const float* h_depth, const uint8_t* h_colorRGBX, int* gotFrame);
+BF_API int bf_pipeline_process_frame_device(bf_pipeline* p, const float* d_depth, const uint8_t* d_colorRGBX, int* gotFrame);
+/* one iteration after the sensor stopped delivering frames (solve + re-integration continue, :175-196) */
+BF_API int bf_pipeline_process_end_of_sequence(bf_pipeline* p, uint32_t* numActiveOperations);
+BF_API int bf_pipeline_synchronize(bf_pipeline* p);
+BF_API int bf_pipeline_get_scene(bf_pipeline* p, bf_scene** out);
+BF_API int bf_pipeline_get_image_manager(bf_pipeline* p, bf_image_manager** out);
+BF_API int bf_pipeline_get_online_bundler(bf_pipeline* p, bf_online_bundler** out);
+BF_API int bf_pipeline_get_num_frames(bf_pipeline* p, uint32_t* out);
+/* camera-to-world poses the frames are currently integrated with (-inf matrix: not integrated) */
+BF_API int bf_pipeline_get_integrated_trajectory(bf_pipeline* p, float* h_out, uint32_t capacity, uint32_t* count);
+BF_API int bf_pipeline_get_counters(bf_pipeline* p, uint32_t* numIntegrate, uint32_t* numDeIntegrate, uint32_t* numLocalSolves, uint32_t* numGlobalSolves);
+BF_API int bf_pipeline_enable_timings(bf_pipeline* p, int enable);
+BF_API int bf_pipeline_get_last_timing(bf_pipeline* p, bf_frame_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BF_PIPELINE_H */
