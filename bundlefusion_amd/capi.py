@@ -214,6 +214,11 @@ class SceneRepHashSDF:
         check(lib.bf_scene_kernel_timing_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def kernel_timing_occupied(self):
+        v = C.c_uint64()
+        check(lib.bf_scene_kernel_timing_occupied(self._h, C.byref(v)))
+        return v.value
+
     # ---- test helpers: copy raw arrays back (hipMemcpy through torch) ----
     def download(self):
         """Returns (hash[numBuckets*4], heap[numSDFBlocks], heapCounter, voxels[numSDFBlocks*512]) as numpy."""

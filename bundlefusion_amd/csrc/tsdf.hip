@@ -63,6 +63,7 @@ struct Dev {
     uint32_t* overflowCount;
     uint32_t* tileCounts;
     uint32_t* stats;
+    unsigned long long* occSum;      // sum of frustum-list lengths over the timed voxel-update launches
 };
 
 struct Frame {          // per-call constants (kernarg => scalar loads)
@@ -544,6 +545,8 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f) {
     }
 }
 
+__global__ void k_occ_accum(Dev d) { d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[0]; }
+
 __global__ void k_list_commit(Dev d) {
     const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
@@ -815,6 +818,7 @@ int launchUpdate(bf_scene* s, const bf_depth_camera_data* data) {
             s->events.push_back({a, b});
         }
         ev = &s->events[s->eventsUsed++];
+        hipLaunchKernelGGL(k_occ_accum, dim3(1), dim3(1), 0, s->stream, s->d);
         BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
     }
     hipLaunchKernelGGL(k_update<DEINT>, dim3(s->gridUpdate), dim3(512), 0, s->stream, s->d, f, data->d_depthData,
@@ -862,6 +866,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     A(s->d.compact, N);
     A(s->d.compactSrc, N);
     A(s->d.compactCount, 1);
+    A(s->d.occSum, 1);
     A(s->d.allocList, N);
     A(s->d.allocListAlt, N);
     A(s->d.allocCount, 1);
@@ -1048,6 +1053,7 @@ int bf_scene_kernel_timing(bf_scene* s, int enable) {
     BF_REQUIRE(s, "null scene");
     s->timing = enable != 0;
     s->eventsUsed = 0;
+    BF_HIP_TRY(hipMemsetAsync(s->d.occSum, 0, sizeof(unsigned long long), s->stream));
     return BF_OK;
 }
 
@@ -1063,6 +1069,15 @@ int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms) {
     *count = (uint32_t)s->eventsUsed;
     *total_ms = tot;
     s->eventsUsed = 0;
+    return BF_OK;
+}
+
+int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks) {
+    BF_REQUIRE(s && sumOccupiedBlocks, "null argument");
+    unsigned long long v = 0;
+    BF_HIP_TRY(hipMemcpyAsync(&v, s->d.occSum, sizeof v, hipMemcpyDeviceToHost, s->stream));
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    *sumOccupiedBlocks = v;
     return BF_OK;
 }
 

@@ -191,3 +191,42 @@ def scene_room(k, width=640, height=480, frames_per_loop=1800, bob=0.0):
         color[m] = _rgbx(u[m], v[m], int(s))
     depth = best_t          # camera-space z == t because dc.z == 1
     return _finish_depth(depth), color, T.astype(np.float32), K
+
+
+# ---------------------------------------------------------------- parallel rendering of a stream
+def render_frames(indices, width=640, height=480, workers=None, frames_per_loop=1800, bob=0.0):
+    """[scene_room(k) for k in indices], rendered by `workers` plain-python subprocesses that execute this file
+    (no torch / HIP in the children, so it is safe to call from a process that already holds a GPU context)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    indices = list(indices)
+    workers = max(1, min(workers or min(os.cpu_count() or 1, 64), len(indices)))
+    if workers == 1 or len(indices) < 4:
+        return [scene_room(k, width, height, frames_per_loop, bob) for k in indices]
+    with tempfile.TemporaryDirectory() as td:
+        procs = []
+        for w in range(workers):
+            part = indices[w::workers]
+            out = os.path.join(td, "part%d.npz" % w)
+            procs.append((part, out, subprocess.Popen([sys.executable, os.path.abspath(__file__), out, str(width), str(height), str(frames_per_loop), repr(bob)]
+                                                      + [str(k) for k in part])))
+        res = {}
+        for part, out, p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("frame render worker failed")
+            z = np.load(out)
+            for i, k in enumerate(part):
+                res[k] = (z["d%d" % i], z["c%d" % i], z["T%d" % i], intrinsics(width, height))
+    return [res[k] for k in indices]
+
+
+if __name__ == "__main__":
+    import sys
+    _out, _w, _h, _fpl, _bob = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
+    _arrs = {}
+    for _i, _k in enumerate(int(a) for a in sys.argv[6:]):
+        _d, _c, _T, _ = scene_room(_k, _w, _h, _fpl, _bob)
+        _arrs["d%d" % _i], _arrs["c%d" % _i], _arrs["T%d" % _i] = _d, _c, _T
+    np.savez(_out, **_arrs)

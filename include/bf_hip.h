@@ -168,6 +168,8 @@ BF_API int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out);
  * (read synchronises the stream and clears the accumulator).                       */
 BF_API int bf_scene_kernel_timing(bf_scene* s, int enable);
 BF_API int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms);
+/* sum of m_numOccupiedBlocks over the launches timed since bf_scene_kernel_timing(s, 1) (call before _read) */
+BF_API int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks);
 
 
 /* ------------------------------------------------------------------------- */

@@ -1,0 +1,117 @@
+"""GPU parity test (-m gpu): the whole frame loop (ingest -> SIFT -> match/filter -> local + global Gauss-Newton -> TSDF
+integrate / re-integrate) through bf_pipeline_* against the CPU oracle pipeline on the same synthetic S2 stream.
+
+Every stage up to the first pose optimisation is bit-exact with the oracle, so the SIFT-tracked poses and the voxel
+volume are compared exactly while no optimised pose has entered the loop; afterwards the solver's float tolerance
+(poses 1e-4, tests/test_solver_gpu.py) propagates: trajectories are compared to 5e-4 m / rad, the operation counts
+exactly, the allocated-block sets by overlap and the common voxels' TSDF values to 2e-3 (truncation is 0.06+)."""
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, sensor_desc
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+
+
+def _params(voxel=0.02, buckets=50000, blocks=20000, max_images=8):
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = voxel, buckets, blocks
+    gbs.s_maxNumImages = max_images
+    return gas, gbs
+
+
+def _block_dict(hash_entries, voxels):
+    occ = hash_entries[hash_entries["ptr"] != -2]
+    return {tuple(int(v) for v in e["pos"]): int(e["ptr"]) for e in occ}
+
+
+def test_first_chunk_bit_exact(gpu, oracle):
+    """11 frames: SIFT poses, correspondences and the volume before any optimised pose is used."""
+    import torch
+    from tests.oracle_pipeline import OraclePipeline
+    frames = synth.render_frames(range(0, 20, 2))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gas, gbs = _params()
+    gp = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    gas2, gbs2 = _params()
+    op = OraclePipeline(gas2, gbs2, W, H, K)
+    for d, c, T, _ in frames:
+        assert gp.process_frame(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda())
+        op.process_frame(d, c)
+    gp.synchronize()
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert len(gt) == len(ot) == len(frames)
+    assert np.isfinite(gt[:, 0, 0]).all()
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32))                 # SIFT-tracked poses: bit-exact
+    # correspondences of the running chunk
+    mgr = gpu.capi.SiftManager.__new__(gpu.capi.SiftManager)
+    import ctypes as C
+    h = C.c_void_p(); gpu.capi.check(gpu.capi.lib.bf_bundler_get_sift_manager(gp.bundler("local"), C.byref(h)))
+    mgr._h = h; mgr.max_keys = 1024; mgr.max_images = 11
+    corr, _ = mgr.download_global_correspondences()
+    mgr._h = C.c_void_p()
+    assert len(corr) == len(op.local.corr) > 100 and np.array_equal(corr.view(np.uint8), op.local.corr.view(np.uint8))
+    # the volume
+    sc = gp.scene()
+    gh, gheap, gcnt, gvox = sc.download()
+    assert gcnt == op.scene.heap_counter()
+    assert np.array_equal(gh["pos"], op.scene.hash()["pos"]) and np.array_equal(gh["ptr"], op.scene.hash()["ptr"])
+    assert np.array_equal(gvox.view(np.uint8), op.scene.voxels().view(np.uint8))
+    assert sc.debug_hash()["duplicate_keys"] == 0
+    c = gp.counters()
+    assert c["integrate"] == sum(1 for k, _, _ in op.integrate_ops if k == "in") and c["deintegrate"] == 0
+
+
+def test_three_chunks_with_reintegration(gpu, oracle):
+    import torch
+    from tests.oracle_pipeline import OraclePipeline
+    n = 33
+    frames = synth.render_frames(range(n))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gas, gbs = _params()
+    gp = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    gas2, gbs2 = _params()
+    op = OraclePipeline(gas2, gbs2, W, H, K)
+    for d, c, T, _ in frames:
+        assert gp.process_frame(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda())
+        op.process_frame(d, c)
+    for _ in range(4):
+        gp.process_end_of_sequence(); op.process_end_of_sequence()
+    gp.synchronize()
+    c = gp.counters()
+    o_in = sum(1 for k, _, _ in op.integrate_ops if k == "in"); o_de = sum(1 for k, _, _ in op.integrate_ops if k == "de")
+    assert (c["integrate"], c["deintegrate"]) == (o_in, o_de) and o_de > 20          # re-integration really happened
+    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves == 4 and c["global_solves"] == op.glob.num_solves >= 3
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert len(gt) == len(ot) == n
+    assert np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).all()
+    assert np.abs(gt - ot).max() < 5e-4
+    gopt, oopt = gp.optimized_trajectory(), np.stack([op.tm.opt[i] for i in range(len(gp.optimized_trajectory()))])
+    assert np.abs(gopt - oopt).max() < 5e-4
+    # against ground truth (relative to frame 0): a few mm
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    ref = np.stack([T0inv @ f[2].astype(np.float64) for f in frames])
+    assert np.linalg.norm(gt[:, :3, 3] - ref[:, :3, 3], axis=1).max() < 0.01
+    # the volume: same blocks up to boundary effects of the 1e-4 pose differences, same TSDF on the common blocks
+    sc = gp.scene()
+    gh, gheap, gcnt, gvox = sc.download()
+    dbg = sc.debug_hash()
+    assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0
+    gb = _block_dict(gh, gvox); ob = _block_dict(op.scene.hash(), op.scene.voxels())
+    common = set(gb) & set(ob)
+    assert len(common) / max(len(set(gb) | set(ob)), 1) > 0.97
+    ovox = op.scene.voxels()
+    worst_sdf = 0.0; worst_w = 0.0
+    for key in list(common)[:400]:
+        a = gvox[gb[key]:gb[key] + 512]; b = ovox[ob[key]:ob[key] + 512]
+        both = (a["weight"] > 0) & (b["weight"] > 0)
+        worst_w = max(worst_w, float(np.abs(a["weight"] - b["weight"]).max()))
+        if both.any():
+            worst_sdf = max(worst_sdf, float(np.abs(a["sdf"][both] - b["sdf"][both]).max()))
+    assert worst_sdf < 2e-3 and worst_w <= 1.0, (worst_sdf, worst_w)
