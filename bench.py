@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py — BundleFusion hot path on MI355X.
+"""bench.py — BundleFusion hot path on MI355X, end to end.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 
-Workload (round 1): the volumetric half of the pipeline on a synthetic 640x480 RGB-D stream at
-4 mm voxels (scene S2) — per input frame ("step"): integrate the new frame at its
-pose and re-integrate (de-integrate at the old pose + integrate at the corrected pose) `--fixes`
-earlier frames, then garbage-collect: DepthSensing.cpp:854-902 + :1047-1050.  SIFT + SBA are not yet
-inside the timed region; `config.stages` lists exactly what is.  Inputs are resident in HBM before
-the timed region starts.
+Workload (BASELINE.json configs[1], synthetic stand-in for the recorded .sens sequence): the S2 "room"
+stream, 640x480 depth + colour, 4 mm voxels.  One step = one input frame through the whole serial frame loop of the
+reference (DepthSensing.cpp:966-1095): ingest (2x erode + range-gated Gaussian), SIFT detect, 80x60 dense cache, descriptor
+matching against the chunk, Kabsch / surface-area / dense-verify filters, SIFT pose, up to s_maxFrameFixes re-integrations
+(de-integrate + integrate) with garbage collection, integration of the new frame, and — every s_submapSize frames — the
+local Gauss-Newton/PCG solve (sparse + dense), chunk-to-keyframe fusion, global matching and the global solve.
+Nothing is skipped inside the timed region.  Frames are resident in HBM before the timed region starts
+(bf_pipeline_process_frame_device); `--host` hands over host buffers instead (PCIe-inclusive rate).
 
-Multi-GPU (N>1): frames are sharded round-robin over ranks, every rank integrates its share into its
-own volume shard-replica (weak scaling, no data-path collective).
+Multi-GPU (N>1, weak scaling): every rank runs the full loop on its own contiguous segment of the stream (frame chunks
+sharded over ranks, each with its own volume); there is no data-path collective — the barrier + max-over-ranks timing
+is the only communication.
 """
 import argparse
 import json
@@ -22,29 +25,39 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s HBM3E
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--fixes", type=int, default=10, help="re-integrated frames per input frame (s_maxFrameFixes)")
-    ap.add_argument("--frames", type=int, default=24, help="distinct synthetic frames kept resident")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--voxel", type=float, default=0.004)
+    ap.add_argument("--buckets", type=int, default=1000000)
+    ap.add_argument("--blocks", type=int, default=600000)
+    ap.add_argument("--host", action="store_true", help="hand over host buffers each frame (PCIe-inclusive)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=11, help="frames of the stream the CPU baseline processes (one local chunk)")
     args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    W, H = 640, 480
+    total = args.warmup + args.steps
+
+    # synthetic stream, rendered by plain-python subprocesses before HIP is initialised
+    from bundlefusion_amd import synth                      # (imports torch; no device context yet)
+    import numpy as np
+    ncpu = os.cpu_count() or 1
+    first = rank * total                                     # each rank: its own contiguous segment of the S2 loop
+    t_gen = time.perf_counter()
+    frames = synth.render_frames(range(first, first + total), W, H, workers=max(1, min(64, ncpu // max(world, 1))))
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -52,84 +65,67 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import bundlefusion_amd as bf
-    from bundlefusion_amd import synth
-    from bundlefusion_amd.capi import default_hash_params, camera_params
+    from bundlefusion_amd.capi import intrinsics_matrix, default_app_state, default_bundling_state, sensor_desc
 
-    W, H = args.width, args.height
-    F = args.frames
-    # each rank renders its own slice of the stream (frame stride 8 => ~115 deg of the S2 circle for 72 frames)
-    frames = [synth.scene_room((rank * F + i) * 8, W, H) for i in range(F)]
-    K = frames[0][3]
-    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
-    params = default_hash_params(num_buckets=500000, num_sdf_blocks=400000, voxel_size=args.voxel)
-    stream = torch.cuda.current_stream()
-    scene = bf.capi.SceneRepHashSDF(params, stream=stream.cuda_stream)
-    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
-    poses = [f[2].copy() for f in frames]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
 
-    def perturbed(T, k):
-        rng = np.random.default_rng(777 + k)
-        T2 = T.copy()
-        T2[:3, 3] += rng.normal(0, 0.01, 3).astype(np.float32)
-        return T2
+    def params(buckets=None, blocks=None):
+        gas = default_app_state(); gbs = default_bundling_state()      # zParametersDefault.txt / zParametersBundlingDefault.txt values
+        gas.s_integrationWidth, gas.s_integrationHeight = W, H
+        gas.s_SDFVoxelSize = args.voxel
+        gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = buckets or args.buckets, blocks or args.blocks
+        gbs.s_maxNumImages = max(total // 10 + 8, 16)
+        return gas, gbs
 
-    cur = list(poses)
-    for i in range(F):                                   # initial volume: every frame integrated once
-        scene.integrate(cur[i], dev[i][0], dev[i][1], cam)
+    gas, gbs = params()
+    pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    if args.host:
+        feed = [(f[0], f[1]) for f in frames]
+    else:
+        feed = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
     torch.cuda.synchronize()
 
-    counter = [0]
-
-    def step(k):
-        i = k % F
-        # "new" frame: swap it out and in again at its current pose => one integrate of new data
-        scene.deintegrate(cur[i], dev[i][0], dev[i][1], cam)
-        scene.integrate(cur[i], dev[i][0], dev[i][1], cam)
-        for r in range(args.fixes):                      # reintegrate(): DepthSensing.cpp:882-889
-            j = (i + 1 + r) % F
-            new = perturbed(poses[j], counter[0])
-            counter[0] += 1
-            scene.deintegrate(cur[j], dev[j][0], dev[j][1], cam)
-            scene.integrate(new, dev[j][0], dev[j][1], cam)
-            cur[j] = new
-        scene.garbage_collect()
-
     for k in range(args.warmup):
-        step(k)
+        assert pipe.process_frame(*feed[k])
+    pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    scene.kernel_timing(True)
+    sc = pipe.scene()
+    sc.kernel_timing(True)                                   # HIP events around every voxel-update launch, on the pipeline's stream
+    c0 = pipe.counters()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
+    for k in range(args.warmup, total):
+        ok = pipe.process_frame(*feed[k])
+        assert ok
+    pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n_launch, kernel_ms = scene.kernel_timing_read()
-    scene.kernel_timing(False)
+    c1 = pipe.counters()
+    occ_sum = sc.kernel_timing_occupied()
+    n_launch, kernel_ms = sc.kernel_timing_read()
+    sc.kernel_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # accounting pass (untimed): N_occ of every voxel-update launch of one more step
-    # => algorithmic bytes per launch = N_occ*(512*24+32) + W*H*8   
-    occ = []
-    i = (args.warmup + args.steps) % F
-    for j in [i] + [(i + 1 + r) % F for r in range(min(args.fixes, 4))]:
-        scene.deintegrate(cur[j], dev[j][0], dev[j][1], cam)
-        occ.append(scene.hash_params().m_numOccupiedBlocks)
-        scene.integrate(cur[j], dev[j][0], dev[j][1], cam)
-        occ.append(scene.hash_params().m_numOccupiedBlocks)
-    n_occ = float(np.mean(occ))
+    # dominant kernel: the TSDF voxel update.  algorithmic bytes per launch = N_occ*(512*24+32) + W*H*8  
+    n_occ = occ_sum / max(n_launch, 1)
     bytes_per_launch = n_occ * (512 * 24 + 32) + W * H * 8
     avg_kernel_s = (kernel_ms / 1e3) / max(n_launch, 1)
-    achieved = bytes_per_launch / avg_kernel_s / 1e9
-    dbg = scene.debug_hash()
+    achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    dbg = sc.debug_hash()
+    traj = pipe.integrated_trajectory()
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    gt = np.stack([T0inv @ f[2].astype(np.float64) for f in frames])
+    valid = np.isfinite(traj[:, 0, 0])
+    ate = float(np.sqrt(np.mean(np.sum((traj[valid][:, :3, 3] - gt[:len(traj)][valid][:, :3, 3]) ** 2, axis=1)))) if valid.any() else None
 
     if rank == 0:
         out = {
@@ -146,50 +142,49 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "S2 room stream %dx%d @%.0f mm voxels; per frame: 1 integrate + %d re-integrations "
-                            "(de-integrate+integrate) + GC" % (W, H, args.voxel * 1e3, args.fixes),
-                "stages": ["tsdf_alloc", "tsdf_compactify", "tsdf_integrate", "tsdf_deintegrate", "tsdf_gc"],
-                "stages_missing": ["sift_detect", "sift_match", "match_filters", "local_gn_solve", "global_gn_solve"],
-                "resident_frames": F, "hash_buckets": params.m_hashNumBuckets, "sdf_blocks": params.m_numSDFBlocks,
+                "workload": "BASELINE configs[1] stand-in: %d-frame S2 room stream %dx%d @%.0f mm voxels through the full frame loop "
+                            "(ingest, SIFT, match+filters, local+global GN/PCG, TSDF integrate + re-integration + GC); "
+                            "1 step = 1 input frame" % (args.steps, W, H, args.voxel * 1e3),
+                "input": "host buffers per frame (PCIe inclusive)" if args.host else "frames resident in HBM",
+                "params": "zParametersDefault.txt + zParametersBundlingDefault.txt values; s_integrationWidth/Height=640/480, "
+                          "s_SDFVoxelSize=%.3f, s_hashNumBuckets=%d, s_hashNumSDFBlocks=%d" % (args.voxel, args.buckets, args.blocks),
+                "timed_ops": {k: c1[k] - c0[k] for k in c1},
+                "frames_valid": int(valid.sum()), "frames_total": int(len(traj)), "ate_rmse_vs_ground_truth_m": ate,
                 "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
-                "parallelism": "frames sharded round-robin over %d rank(s)" % world,
+                "render_seconds_untimed": round(t_gen, 1),
+                "parallelism": "stream segments sharded over %d rank(s), no data-path collective" % world,
             },
             "roofline": {
-                "kernel": "k_update<integrate|deintegrate>",
+                "kernel": "k_update<integrate|deintegrate> (TSDF voxel update)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "launches": n_launch, "avg_launch_us": 1e6 * avg_kernel_s,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "n_occ_mean": n_occ,
+                "share_of_step_time": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None,
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames[0], cam, args.voxel, 2 * (1 + args.fixes))
+            out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], params, K, W, H)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(frame, cam, voxel, ops_per_frame):
-    """The oracle (kind 'port': the reference has no CPU path) timed on this box's host cores on a
-    bounded sample: integrate ONE frame (alloc+compactify+voxel update) into an empty volume, repeated."""
-    from tests import oracle_api
-    from bundlefusion_amd.capi import default_hash_params
-    ncores = os.cpu_count() or 1
-    depth, color, T, _ = frame
-    p = default_hash_params(num_buckets=100000, num_sdf_blocks=60000, voxel_size=voxel)
-    osc = oracle_api.OracleScene(p)
-    osc.integrate(T, depth, color, cam, threads=ncores)        # warm-up, allocates
+def cpu_baseline(frames, params, K, W, H):
+    """The oracle frame loop (kind 'port': the reference has no runnable CPU path) on this box's host cores,
+    on a bounded sample of the same stream: its first local chunk (11 frames => SIFT, matching, filters, TSDF integration at
+    4 mm and one local solve).  Orchestration is single-threaded Python; the voxel update runs on all cores (OpenMP)."""
+    from tests.oracle_pipeline import OraclePipeline
+    gas, gbs = params(400000, 200000)      # one chunk touches < 100k blocks; a smaller heap keeps the host allocation out of the timing
+    op0 = time.perf_counter()
+    op = OraclePipeline(gas, gbs, W, H, K)
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 10.0 and reps < 40:
-        osc.deintegrate(T, depth, color, cam, threads=ncores)
-        osc.integrate(T, depth, color, cam, threads=ncores)
-        reps += 1
+    for d, c, _, _ in frames:
+        op.process_frame(d, c)
     dt = time.perf_counter() - t0
-    ops_per_s = 2 * reps / dt
-    return {"value": ops_per_s / ops_per_frame, "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": "%d x (de-integrate + integrate) of one S2 frame, voxel update on %d OpenMP threads, alloc+frustum "
-                      "list single-threaded; frames/s = ops/s / %d ops per frame" % (reps, ncores, ops_per_frame)}
+    return {"value": len(frames) / dt, "unit": "frames/s", "cores": op.threads, "kind": "port",
+            "sample": "first %d frames of the same stream (one local chunk incl. its solve), %.1f s; stage kernels in C++ "
+                      "(voxel update on %d OpenMP threads, the rest single-threaded)" % (len(frames), dt, op.threads)}
 
 
 if __name__ == "__main__":
