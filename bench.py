@@ -51,7 +51,8 @@ def main():
     from bundlefusion_amd import synth                      # (imports torch; no device context yet)
     import numpy as np
     ncpu = os.cpu_count() or 1
-    first = rank * total                                     # each rank: its own contiguous segment of the S2 loop
+    from bundlefusion_amd.shard import segment, max_over_ranks
+    first, _ = segment(rank, world, total)                   # each rank: its own contiguous segment of the S2 loop
     t_gen = time.perf_counter()
     frames = synth.render_frames(range(first, first + total), W, H, workers=max(1, min(64, ncpu // max(world, 1))))
     t_gen = time.perf_counter() - t_gen
@@ -110,10 +111,7 @@ def main():
     occ_sum = sc.kernel_timing_occupied()
     n_launch, kernel_ms = sc.kernel_timing_read()
     sc.kernel_timing(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, "cuda")
 
     # dominant kernel: the TSDF voxel update.  algorithmic bytes per launch = N_occ*(512*24+32) + W*H*8  
     n_occ = occ_sum / max(n_launch, 1)

@@ -209,7 +209,9 @@ BF_DEV float det3(const float* m) {
     return m[0] * m[4] * m[8] + m[1] * m[5] * m[6] + m[2] * m[3] * m[7] - m[6] * m[4] * m[2] - m[7] * m[5] * m[0] - m[8] * m[3] * m[1];
 }
 BF_DEV void mm3(const float* A, const float* B, float* C) {
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
 }
 
@@ -249,7 +251,7 @@ BF_DEV void qrGivens(float a1, float a2, float& ch, float& sh) {
     const float wv = rsq(ch * ch + sh * sh);
     ch *= wv; sh *= wv;
 }
-__device__ __noinline__ void svd3(const float* A, float* U, float* S, float* V) {
+BF_DEV void svd3(const float* A, float* U, float* S, float* V) {
     const float a11 = A[0], a12 = A[1], a13 = A[2], a21 = A[3], a22 = A[4], a23 = A[5], a31 = A[6], a32 = A[7], a33 = A[8];
     float s11 = a11 * a11 + a21 * a21 + a31 * a31, s21 = a12 * a11 + a22 * a21 + a32 * a31, s22 = a12 * a12 + a22 * a22 + a32 * a32;
     float s31 = a13 * a11 + a23 * a21 + a33 * a31, s32 = a13 * a12 + a23 * a22 + a33 * a32, s33 = a13 * a13 + a23 * a23 + a33 * a33;
@@ -316,6 +318,7 @@ BF_DEV f3 eigenValues3(const float* A) {
     p = sqrtf(p / 6.0f);
     float B[9];
     const float ip = 1.0f / p;
+#pragma unroll
     for (int i = 0; i < 9; ++i) B[i] = (A[i] - ((i % 4 == 0) ? q : 0.0f)) * ip;
     const float r = det3(B) / 2.0f;
     float phi;
@@ -335,9 +338,9 @@ BF_DEV f3 backProject(const m44& Kinv, const Key& k) {      // Kinv * (depth * (
     return xform(Kinv, mk3(k.depth * k.x, k.depth * k.y, k.depth * 1.0f));
 }
 
-struct Sel { uint32_t ix, iy; float dist; };
+struct Sel { uint32_t ix, iy; float dist; uint32_t r; };     // r: slot of the match in the raw (distance-sorted) list
 
-__device__ __noinline__ m44 kabsch(const f3* src, const f3* tgt, unsigned n, f3& evs) {       // cuda_kabsch.h:73-211
+BF_DEV m44 kabsch(const f3* src, const f3* tgt, unsigned n, f3& evs) {       // cuda_kabsch.h:73-211
     f3 p0 = mk3(0, 0, 0), q0 = mk3(0, 0, 0);
     for (unsigned i = 0; i < n; ++i) { p0 = p0 + src[i]; q0 = q0 + tgt[i]; }
     p0 = p0 / (float)n; q0 = q0 / (float)n;
@@ -345,13 +348,20 @@ __device__ __noinline__ m44 kabsch(const f3* src, const f3* tgt, unsigned n, f3&
     for (unsigned i = 0; i < n; ++i) {
         const f3 p = src[i] - p0, q = tgt[i] - q0;
         const float pv[3] = {p.x, p.y, p.z}, qv[3] = {q.x, q.y, q.z};
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * qv[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * qv[c];
     }
+#pragma unroll
     for (int i = 0; i < 9; ++i) V[i] /= (float)n;
     float U[9], S[9], W[9];
     svd3(V, U, S, W);
     float s[3] = {S[0], S[4], S[8]};
-    for (int i = 0; i < 3; ++i) if (s[i] < 0.0f) { s[i] *= -1.0f; for (int j = 0; j < 3; ++j) U[j * 3 + i] *= -1.0f; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (s[i] < 0.0f) { s[i] *= -1.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) U[j * 3 + i] *= -1.0f; }
     evs = mk3(s[0], s[1], s[2]);
     if (evs.x < evs.y) { const float t = evs.x; evs.x = evs.y; evs.y = t; }
     if (evs.y < evs.z) { const float t = evs.y; evs.y = evs.z; evs.z = t; }
@@ -366,14 +376,17 @@ __device__ __noinline__ m44 kabsch(const f3* src, const f3* tgt, unsigned n, f3&
     mm3(W, I, WI);
     mm3(WI, Ut, R);
     m44 ret = identity44();
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) ret.e[i * 4 + j] = R[i * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ret.e[i * 4 + j] = R[i * 3 + j];
     ret.e[3] = q0.x - (R[0] * p0.x + R[1] * p0.y + R[2] * p0.z);
     ret.e[7] = q0.y - (R[3] * p0.x + R[4] * p0.y + R[5] * p0.z);
     ret.e[11] = q0.z - (R[6] * p0.x + R[7] * p0.y + R[8] * p0.z);
     return ret;
 }
 
-__device__ __noinline__ f3 covarianceEig(const f3* pts, unsigned n) {
+BF_DEV f3 covarianceEig(const f3* pts, unsigned n) {
     f3 p0 = mk3(0, 0, 0);
     for (unsigned i = 0; i < n; ++i) p0 = p0 + pts[i];
     p0 = p0 / (float)n;
@@ -381,8 +394,12 @@ __device__ __noinline__ f3 covarianceEig(const f3* pts, unsigned n) {
     for (unsigned i = 0; i < n; ++i) {
         const f3 p = pts[i] - p0;
         const float pv[3] = {p.x, p.y, p.z};
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * pv[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * pv[c];
     }
+#pragma unroll
     for (int i = 0; i < 9; ++i) V[i] /= (float)n;
     return eigenValues3(V);
 }
@@ -412,7 +429,9 @@ struct FilterArgs {
     m44 Kinv; int minNumMatches; float maxKabschRes2;
 };
 
-// one wave per previous image; the greedy filter is inherently sequential, lane 0 runs it out of LDS
+// One wave per previous image.  The greedy filter is inherently sequential (every accepted match changes the Kabsch fit
+// the next decision depends on), so lane 0 runs it — but entirely out of LDS: the 64 lanes first stage the <= 128 raw
+// matches' key positions and back-projected 3-D points, so the serial loop never waits on HBM.
 __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
@@ -420,10 +439,18 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
     const int numRaw = min(MAX_RAW, max(a.numMatches[prev], 0));
     if (numRaw == 0) { if (tid == 0) a.numFilt[prev] = 0; return; }
     __shared__ Sel sel[MAX_RAW + MAX_FILT];
+    __shared__ float2 posI[MAX_RAW], posJ[MAX_RAW];
+    __shared__ f3 ptI[MAX_RAW], ptJ[MAX_RAW];
     __shared__ f3 src[MAX_FILT], tgt[MAX_FILT];
     __shared__ float res[MAX_FILT];
     __shared__ unsigned sCur;
-    for (int i = (int)tid; i < numRaw; i += 64) { const uint2 k = a.idx[prev * MAX_RAW + i]; sel[i].ix = k.x; sel[i].iy = k.y; sel[i].dist = a.dist[prev * MAX_RAW + i]; }
+    for (int i = (int)tid; i < numRaw; i += 64) {
+        const uint2 k = a.idx[prev * MAX_RAW + i];
+        sel[i].ix = k.x; sel[i].iy = k.y; sel[i].dist = a.dist[prev * MAX_RAW + i]; sel[i].r = (uint32_t)i;
+        const Key ki = a.keys[k.x], kj = a.keys[k.y];
+        posI[i] = make_float2(ki.x, ki.y); posJ[i] = make_float2(kj.x, kj.y);
+        ptI[i] = backProject(a.Kinv, ki); ptJ[i] = backProject(a.Kinv, kj);
+    }
     __syncthreads();
     if (tid == 0) {          // filterKeyPointMatches, cuda_kabsch.h:422-502
         unsigned cur = 0;
@@ -438,9 +465,9 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
             }
             bool add = true;        // addMatch :278-294: at least 5 px from every kept match in both images
             {
-                const Key ai = a.keys[sel[i].ix], aj = a.keys[sel[i].iy];
+                const float2 ai = posI[i], aj = posJ[i];          // sel[i].r == i: raw entries beyond `cur` are never permuted
                 for (unsigned k = 0; k < cur; ++k) {
-                    const Key ki = a.keys[sel[k].ix], kj = a.keys[sel[k].iy];
+                    const float2 ki = posI[sel[k].r], kj = posJ[sel[k].r];
                     const float d0 = sqrtf((ai.x - ki.x) * (ai.x - ki.x) + (ai.y - ki.y) * (ai.y - ki.y));
                     const float d1 = sqrtf((aj.x - kj.x) * (aj.x - kj.x) + (aj.y - kj.y) * (aj.y - kj.y));
                     if (d0 <= 5 || d1 <= 5) { add = false; break; }
@@ -450,7 +477,7 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
                 sel[cur] = sel[i];
                 cur++;
                 if (cur >= 3) {
-                    for (unsigned k = 0; k < cur; ++k) { src[k] = backProject(a.Kinv, a.keys[sel[k].ix]); tgt[k] = backProject(a.Kinv, a.keys[sel[k].iy]); }
+                    for (unsigned k = 0; k < cur; ++k) { src[k] = ptI[sel[k].r]; tgt[k] = ptJ[sel[k].r]; }
                     validT = computeReprojection(src, tgt, cur, res, T, sel);
                     const bool b = validT;
                     const m44 prevT = T;
@@ -540,22 +567,34 @@ struct AreaArgs { const Key* keys; uint32_t curFrame, startFrame; int* numFilt; 
 
 __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
     const uint32_t prev = blockIdx.x + a.startFrame;
-    if (prev == a.curFrame || threadIdx.x != 0) return;
-    const int n = a.numFilt[prev];
+    if (prev == a.curFrame) return;
+    const int n = min(a.numFilt[prev], MAX_FILT);
     if (n <= 0) return;
+    __shared__ f3 ptsAll[2][MAX_FILT];
+    __shared__ float px[MAX_FILT], py[MAX_FILT];
+    if ((int)threadIdx.x < 2 * n) {                  // back-project both images' keys in parallel
+        const int which = (int)threadIdx.x / n, i = (int)threadIdx.x % n;
+        const uint2 k = a.fidx[prev * MAX_FILT + i];
+        ptsAll[which][i] = backProject(a.Kinv, a.keys[which ? k.y : k.x]);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     float area[2] = {0.0f, 0.0f};
-    f3 pts[MAX_FILT];
-    float px[MAX_FILT], py[MAX_FILT];
     for (int which = 0; which < 2; ++which) {
+        const f3* pts = ptsAll[which];
         f3 mean = mk3(0, 0, 0);
-        for (int i = 0; i < n; ++i) { const uint2 k = a.fidx[prev * MAX_FILT + i]; pts[i] = backProject(a.Kinv, a.keys[which ? k.y : k.x]); mean = mean + pts[i]; }
+        for (int i = 0; i < n; ++i) mean = mean + pts[i];
         mean = mean / (float)n;
         float V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < n; ++i) {
             const f3 p = pts[i] - mean;
             const float pv[3] = {p.x, p.y, p.z};
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * pv[c];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * pv[c];
         }
+#pragma unroll
         for (int i = 0; i < 9; ++i) V[i] /= (float)n;
         float evals[3], ev[3][3];
         if (!eigenSystem3(V, evals, ev)) continue;
