@@ -1,0 +1,280 @@
+// Header-only C++ view of libbf_hip.so with the reference's class names and method signatures (the drop-in
+// boundary of SURVEY.md §8b): CUDAImageManager, Bundler, OnlineBundler, TrajectoryManager, CUDASceneRepHashSDF,
+// GlobalAppState / GlobalBundlingState.  Every method forwards to the C ABI of bf_hip.h / bf_pipeline.h; errors are
+// thrown as std::runtime_error carrying bf_last_error() where the reference throws MLIB_EXCEPTION.
+//
+// Matrix arguments are `mat4f` = 16 floats, row-major (same memory as ml::mat4f / float4x4).
+#pragma once
+#include <array>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../bf_pipeline.h"
+
+namespace bundlefusion {
+
+struct mat4f {
+    float m[16];
+    static mat4f identity() { mat4f r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f; return r; }
+    float& operator()(int r, int c) { return m[r * 4 + c]; }
+    float operator()(int r, int c) const { return m[r * 4 + c]; }
+    const float* getData() const { return m; }
+    float* getData() { return m; }
+};
+typedef mat4f float4x4;
+
+inline void check(int rc) { if (rc != BF_OK) throw std::runtime_error(std::string("bundlefusion: ") + bf_last_error()); }
+
+// ---- GlobalAppState / GlobalBundlingState (GlobalAppState.h:106-160, GlobalBundlingState.h:67-120): singletons filled from the two files
+class GlobalAppState : public bf_global_app_state {
+public:
+    static GlobalAppState& get() { static GlobalAppState s; return s; }
+    static GlobalAppState& getInstance() { return get(); }
+    void readMembers(const std::string& parameterFile) { check(bf_global_app_state_read(parameterFile.c_str(), this, nullptr)); }
+private:
+    GlobalAppState() { bf_global_app_state_default(this); }
+};
+class GlobalBundlingState : public bf_global_bundling_state {
+public:
+    static GlobalBundlingState& get() { static GlobalBundlingState s; return s; }
+    static GlobalBundlingState& getInstance() { return get(); }
+    void readMembers(const std::string& parameterFile) { check(bf_global_bundling_state_read(parameterFile.c_str(), this, nullptr)); }
+private:
+    GlobalBundlingState() { bf_global_bundling_state_default(this); }
+};
+
+// ---- RGBDSensor accessor contract (RGBDSensor.h:25-61); derive and fill the host buffers in processDepth/processColor
+class RGBDSensor {
+public:
+    virtual ~RGBDSensor() {}
+    virtual bool processDepth() = 0;
+    virtual bool processColor() = 0;
+    virtual const float* getDepthFloat() const = 0;               // metres, -inf invalid
+    virtual const unsigned char* getColorRGBX() const = 0;        // 4 x u8 per pixel
+    unsigned int getDepthWidth() const { return m_desc.depthWidth; }
+    unsigned int getDepthHeight() const { return m_desc.depthHeight; }
+    unsigned int getColorWidth() const { return m_desc.colorWidth; }
+    unsigned int getColorHeight() const { return m_desc.colorHeight; }
+    const bf_rgbd_sensor_desc& desc() const { return m_desc; }
+protected:
+    bf_rgbd_sensor_desc m_desc;
+};
+
+// ---- CUDAImageManager (CUDAImageManager.h:10-337)
+class CUDAImageManager {
+public:
+    class ManagedRGBDInputFrame {
+    public:
+        const float* getDepthFrameGPU() { const float* d; const uint8_t* c; check(bf_image_manager_get_integrate_frame_gpu(m_im, m_idx, &d, &c)); return d; }
+        const unsigned char* getColorFrameGPU() { const float* d; const uint8_t* c; check(bf_image_manager_get_integrate_frame_gpu(m_im, m_idx, &d, &c)); return c; }
+    private:
+        friend class CUDAImageManager;
+        bf_image_manager* m_im = nullptr; unsigned int m_idx = 0;
+    };
+    CUDAImageManager(unsigned int widthIntegration, unsigned int heightIntegration, unsigned int widthSIFT, unsigned int heightSIFT, RGBDSensor* sensor,
+                     bool storeFramesOnGPU = true) : m_sensor(sensor) {
+        check(bf_image_manager_create(widthIntegration, heightIntegration, widthSIFT, heightSIFT, &sensor->desc(), &GlobalBundlingState::get(), storeFramesOnGPU, &m_h));
+    }
+    ~CUDAImageManager() { bf_image_manager_destroy(m_h); }
+    CUDAImageManager(const CUDAImageManager&) = delete;
+    void reset() { check(bf_image_manager_reset(m_h)); }
+    bool process() {
+        if (!m_sensor->processDepth()) return false;       // order is important (CUDAImageManager.cpp:24-25)
+        if (!m_sensor->processColor()) return false;
+        int got = 0;
+        check(bf_image_manager_process(m_h, m_sensor->getDepthFloat(), m_sensor->getColorRGBX(), &got));
+        return got != 0;
+    }
+    void copyToBundling(float* d_depthRaw, float* d_depthFilt, unsigned char* d_color) const { check(bf_image_manager_copy_to_bundling(m_h, d_depthRaw, d_depthFilt, d_color)); }
+    ManagedRGBDInputFrame getIntegrateFrame(unsigned int frame) { ManagedRGBDInputFrame f; f.m_im = m_h; f.m_idx = frame; return f; }
+    ManagedRGBDInputFrame getLastIntegrateFrame() { return getIntegrateFrame(getCurrFrameNumber()); }
+    unsigned int getCurrFrameNumber() const { uint32_t n; check(bf_image_manager_get_curr_frame_number(m_h, &n)); return n; }
+    unsigned int getIntegrationWidth() const { uint32_t w, h; check(bf_image_manager_get_integration_size(m_h, &w, &h)); return w; }
+    unsigned int getIntegrationHeight() const { uint32_t w, h; check(bf_image_manager_get_integration_size(m_h, &w, &h)); return h; }
+    mat4f getDepthIntrinsics() const { mat4f k; check(bf_image_manager_get_depth_intrinsics(m_h, k.m, nullptr)); return k; }
+    mat4f getDepthIntrinsicsInv() const { mat4f k; check(bf_image_manager_get_depth_intrinsics(m_h, nullptr, k.m)); return k; }
+    mat4f getDepthExtrinsics() const { mat4f k; check(bf_image_manager_get_depth_extrinsics(m_h, k.m, nullptr)); return k; }
+    mat4f getDepthExtrinsicsInv() const { mat4f k; check(bf_image_manager_get_depth_extrinsics(m_h, nullptr, k.m)); return k; }
+    unsigned int getSIFTDepthWidth() const { uint32_t w; check(bf_image_manager_get_sift_depth(m_h, &w, nullptr, nullptr)); return w; }
+    unsigned int getSIFTDepthHeight() const { uint32_t h; check(bf_image_manager_get_sift_depth(m_h, nullptr, &h, nullptr)); return h; }
+    mat4f getSIFTDepthIntrinsics() const { mat4f k; check(bf_image_manager_get_sift_depth(m_h, nullptr, nullptr, k.m)); return k; }
+    bool hasBundlingFrameRdy() const { return m_bHasBundlingFrameRdy; }
+    void setBundlingFrameRdy() { m_bHasBundlingFrameRdy = true; }
+    void confirmRdyBundlingFrame() { m_bHasBundlingFrameRdy = false; }
+    bf_image_manager* handle() const { return m_h; }
+    const RGBDSensor* sensor() const { return m_sensor; }
+private:
+    bf_image_manager* m_h = nullptr;
+    RGBDSensor* m_sensor;
+    bool m_bHasBundlingFrameRdy = false;
+};
+
+// ---- Bundler (Bundler.h:17-104)
+class Bundler {
+public:
+    Bundler(unsigned int maxNumImages, unsigned int maxNumKeysPerImage, const mat4f& siftIntrinsicsInv, const CUDAImageManager* manager, bool isLocal) {
+        check(bf_bundler_create(maxNumImages, maxNumKeysPerImage, siftIntrinsicsInv.m, manager->handle(), isLocal, &GlobalAppState::get(), &GlobalBundlingState::get(), &m_h));
+        m_own = true;
+    }
+    explicit Bundler(bf_bundler* borrowed) : m_h(borrowed), m_own(false) {}
+    ~Bundler() { if (m_own) bf_bundler_destroy(m_h); }
+    Bundler(const Bundler&) = delete;
+    float4x4* getTrajectoryGPU() { float* d; check(bf_bundler_get_trajectory_gpu(m_h, &d)); return reinterpret_cast<float4x4*>(d); }
+    const std::vector<int>& getValidImages() const {
+        uint32_t n; check(bf_bundler_get_num_frames(m_h, &n));
+        m_valid.assign(n ? n : 1, 0);
+        check(bf_bundler_get_valid_images(m_h, m_valid.data(), n));
+        return m_valid;
+    }
+    void getCacheIntrinsics(float4x4& intrinsics, float4x4& intrinsicsInv) { check(bf_bundler_get_cache_intrinsics(m_h, intrinsics.m, intrinsicsInv.m)); }
+    unsigned int getCurrFrameNumber() const { uint32_t n; check(bf_bundler_get_curr_frame_number(m_h, &n)); return n; }
+    unsigned int getNumFrames() const { uint32_t n; check(bf_bundler_get_num_frames(m_h, &n)); return n; }
+    bool isValid() const { int v; check(bf_bundler_is_valid(m_h, &v)); return v != 0; }
+    void reset() { check(bf_bundler_reset(m_h)); }
+    void detectFeatures(float* d_intensitySift, const float* d_inputDepthFilt) { check(bf_bundler_detect_features(m_h, d_intensitySift, d_inputDepthFilt)); }
+    void storeCachedFrame(unsigned int depthWidth, unsigned int depthHeight, const unsigned char* d_inputColor, unsigned int colorWidth, unsigned int colorHeight,
+                          const float* d_inputDepthRaw) { check(bf_bundler_store_cached_frame(m_h, depthWidth, depthHeight, d_inputColor, colorWidth, colorHeight, d_inputDepthRaw)); }
+    void copyFrame(const Bundler* b, unsigned int frame) { check(bf_bundler_copy_frame(m_h, b->m_h, frame)); }
+    void addInvalidFrame() { check(bf_bundler_add_invalid_frame(m_h)); }
+    void invalidateLastFrame() { check(bf_bundler_invalidate_last_frame(m_h)); }
+    const float4x4* getCurrentSiftTransformsGPU() const { const float* d; check(bf_bundler_get_current_sift_transforms_gpu(m_h, &d)); return reinterpret_cast<const float4x4*>(d); }
+    const int* getNumFiltMatchesGPU() const { const int32_t* d; check(bf_bundler_get_num_filt_matches_gpu(m_h, &d)); return d; }
+    unsigned int matchAndFilter() { uint32_t last; check(bf_bundler_match_and_filter(m_h, &last)); return last; }
+    bool optimize(unsigned int numNonLinIterations, unsigned int numLinIterations, bool bUseVerify, bool bRemoveMaxResidual, bool bIsScanDone, bool& bOptRemoved) {
+        int removed = 0, valid = 0;
+        check(bf_bundler_optimize(m_h, numNonLinIterations, numLinIterations, bUseVerify, bRemoveMaxResidual, bIsScanDone, &removed, &valid));
+        bOptRemoved = removed != 0;
+        return valid != 0;
+    }
+    void setSolveWeights(const std::vector<float>& sparse, const std::vector<float>& densedepth, const std::vector<float>& densecolor) {
+        check(bf_bundler_set_solve_weights(m_h, sparse.data(), densedepth.data(), densecolor.data(), (uint32_t)sparse.size()));
+    }
+    void fuseToGlobal(Bundler* glob) { check(bf_bundler_fuse_to_global(m_h, glob->m_h)); }
+    unsigned int tryRevalidation(unsigned int curGlobalFrame, bool bIsScanDone) { uint32_t r; check(bf_bundler_try_revalidation(m_h, curGlobalFrame, bIsScanDone, &r)); return r; }
+    unsigned int getRevalidatedIdx() const { uint32_t r; check(bf_bundler_get_revalidated_idx(m_h, &r)); return r; }
+    void saveSparseCorrsToFile(const std::string& filename) const { check(bf_bundler_save_sparse_corrs_to_file(m_h, filename.c_str())); }
+    bf_bundler* handle() const { return m_h; }
+private:
+    bf_bundler* m_h = nullptr;
+    bool m_own = false;
+    mutable std::vector<int> m_valid;
+};
+
+// ---- TrajectoryManager (TrajectoryManager.h:6-116)
+class TrajectoryManager {
+public:
+    struct TrajectoryFrame {
+        enum TYPE { Integrated = 0, NotIntegrated_NoTransform = 1, NotIntegrated_WithTransform = 2, Invalid = 3, ReIntegration = 4 };
+    };
+    explicit TrajectoryManager(bf_trajectory_manager* borrowed) : m_h(borrowed) {}
+    void addFrame(TrajectoryFrame::TYPE what, const mat4f& transform, unsigned int idx) { check(bf_trajectory_manager_add_frame(m_h, what, transform.m, idx)); }
+    void updateOptimizedTransform(const float4x4* d_trajectory, unsigned int numFrames) {
+        check(bf_trajectory_manager_update_optimized_transform(m_h, reinterpret_cast<const float*>(d_trajectory), numFrames, nullptr));
+    }
+    void generateUpdateLists() { check(bf_trajectory_manager_generate_update_lists(m_h)); }
+    void confirmIntegration(unsigned int frameIdx) { check(bf_trajectory_manager_confirm_integration(m_h, frameIdx)); }
+    bool getTopFromReIntegrateList(mat4f& oldTransform, mat4f& newTransform, unsigned int& frameIdx) {
+        int f; check(bf_trajectory_manager_get_top_from_reintegrate_list(m_h, oldTransform.m, newTransform.m, &frameIdx, &f)); return f != 0;
+    }
+    bool getTopFromIntegrateList(mat4f& trans, unsigned int& frameIdx) { int f; check(bf_trajectory_manager_get_top_from_integrate_list(m_h, trans.m, &frameIdx, &f)); return f != 0; }
+    bool getTopFromDeIntegrateList(mat4f& trans, unsigned int& frameIdx) { int f; check(bf_trajectory_manager_get_top_from_deintegrate_list(m_h, trans.m, &frameIdx, &f)); return f != 0; }
+    unsigned int getNumOptimizedFrames() const { uint32_t n; check(bf_trajectory_manager_get_num_optimized_frames(m_h, &n)); return n; }
+    unsigned int getNumAddedFrames() const { uint32_t n; check(bf_trajectory_manager_get_num_added_frames(m_h, &n)); return n; }
+    unsigned int getNumActiveOperations() const { uint32_t n; check(bf_trajectory_manager_get_num_active_operations(m_h, &n)); return n; }
+    void getOptimizedTransforms(std::vector<mat4f>& transforms) {
+        const unsigned int n = getNumAddedFrames();
+        transforms.resize(n ? n : 1);
+        uint32_t cnt = 0;
+        check(bf_trajectory_manager_get_optimized_transforms(m_h, transforms[0].m, n, &cnt));
+        transforms.resize(cnt);
+    }
+private:
+    bf_trajectory_manager* m_h;
+};
+
+// ---- OnlineBundler (OnlineBundler.h:10-106)
+class OnlineBundler {
+public:
+    OnlineBundler(const RGBDSensor* sensor, const CUDAImageManager* imageManager) {
+        check(bf_online_bundler_create(&sensor->desc(), imageManager->handle(), &GlobalAppState::get(), &GlobalBundlingState::get(), &m_h));
+        bf_trajectory_manager* tm; check(bf_online_bundler_get_trajectory_manager(m_h, &tm));
+        m_tm = new TrajectoryManager(tm);
+    }
+    ~OnlineBundler() { delete m_tm; bf_online_bundler_destroy(m_h); }
+    OnlineBundler(const OnlineBundler&) = delete;
+    bool getCurrentIntegrationFrame(mat4f& siftTransform, unsigned int& frameIdx, bool& bGlobalTrackingLost) {
+        int lost = 0, valid = 0;
+        check(bf_online_bundler_get_current_integration_frame(m_h, siftTransform.m, &frameIdx, &lost, &valid));
+        bGlobalTrackingLost = lost != 0;
+        return valid != 0;
+    }
+    void processInput() { check(bf_online_bundler_process_input(m_h)); }
+    void process(unsigned int numNonLinItersLocal, unsigned int numLinItersLocal, unsigned int numNonLinItersGlobal, unsigned int numLinItersGlobal) {
+        check(bf_online_bundler_process(m_h, numNonLinItersLocal, numLinItersLocal, numNonLinItersGlobal, numLinItersGlobal));
+    }
+    TrajectoryManager* getTrajectoryManager() { return m_tm; }
+    bool hasProcssedInputFrame() const { return m_bHasProcessedInputFrame; }
+    void setProcessedInputFrame() { m_bHasProcessedInputFrame = true; }
+    void confirmProcessedInputFrame() { m_bHasProcessedInputFrame = false; }
+    void exitBundlingThread() { m_bExitBundlingThread = true; }
+    bool getExitBundlingThread() const { return m_bExitBundlingThread; }
+    unsigned int getCurrProcessedFrame() const { int32_t f; check(bf_online_bundler_get_curr_processed_frame(m_h, &f)); return (unsigned int)f; }
+    void saveGlobalSparseCorrsToFile(const std::string& filename) const { check(bf_online_bundler_save_global_sparse_corrs_to_file(m_h, filename.c_str())); }
+    bf_online_bundler* handle() const { return m_h; }
+private:
+    bf_online_bundler* m_h = nullptr;
+    TrajectoryManager* m_tm = nullptr;
+    bool m_bHasProcessedInputFrame = false, m_bExitBundlingThread = false;
+};
+
+// ---- voxel-hash volume (DepthSensing/CUDASceneRepHashSDF.h, CUDAHashParams.h, CUDADepthCameraParams.h, DepthCameraUtil.h)
+typedef bf_hash_params HashParams;
+typedef bf_depth_camera_params DepthCameraParams;
+typedef bf_hash_data HashDataStruct;
+struct DepthCameraData {
+    DepthCameraData() { d.d_depthData = nullptr; d.d_colorData = nullptr; }
+    DepthCameraData(const float* d_depth, const unsigned char* d_color) { d.d_depthData = d_depth; d.d_colorData = d_color; }
+    bf_depth_camera_data d;
+};
+
+class CUDASceneRepHashSDF {
+public:
+    explicit CUDASceneRepHashSDF(const HashParams& params) { check(bf_scene_create(&params, &m_h)); }
+    ~CUDASceneRepHashSDF() { bf_scene_destroy(m_h); }
+    CUDASceneRepHashSDF(const CUDASceneRepHashSDF&) = delete;
+    static HashParams parametersFromGlobalAppState(const GlobalAppState& gas) {          // CUDASceneRepHashSDF.h:39-59
+        HashParams p;
+        std::memset(&p, 0, sizeof p);
+        const mat4f I = mat4f::identity();
+        std::memcpy(p.m_rigidTransform, I.m, 64); std::memcpy(p.m_rigidTransformInverse, I.m, 64);
+        p.m_hashNumBuckets = gas.s_hashNumBuckets; p.m_hashBucketSize = 4; p.m_hashMaxCollisionLinkedListSize = gas.s_hashMaxCollisionLinkedListSize;
+        p.m_SDFBlockSize = 8; p.m_numSDFBlocks = gas.s_hashNumSDFBlocks; p.m_virtualVoxelSize = gas.s_SDFVoxelSize;
+        p.m_maxIntegrationDistance = gas.s_SDFMaxIntegrationDistance; p.m_truncation = gas.s_SDFTruncation; p.m_truncScale = gas.s_SDFTruncationScale;
+        p.m_integrationWeightSample = gas.s_SDFIntegrationWeightSample; p.m_integrationWeightMax = gas.s_SDFIntegrationWeightMax;
+        for (int i = 0; i < 3; ++i) { p.m_streamingVoxelExtents[i] = gas.s_streamingVoxelExtents[i]; p.m_streamingGridDimensions[i] = gas.s_streamingGridDimensions[i]; p.m_streamingMinGridPos[i] = gas.s_streamingMinGridPos[i]; }
+        p.m_streamingInitialChunkListSize = gas.s_streamingInitialChunkListSize;
+        return p;
+    }
+    void integrate(const mat4f& lastRigidTransform, const DepthCameraData& data, const DepthCameraParams& params, unsigned int* d_bitMask) {
+        check(bf_scene_integrate(m_h, lastRigidTransform.m, &data.d, &params, d_bitMask));
+    }
+    void deIntegrate(const mat4f& lastRigidTransform, const DepthCameraData& data, const DepthCameraParams& params, unsigned int* d_bitMask) {
+        check(bf_scene_deintegrate(m_h, lastRigidTransform.m, &data.d, &params, d_bitMask));
+    }
+    void garbageCollect() { check(bf_scene_garbage_collect(m_h)); }
+    void reset() { check(bf_scene_reset(m_h)); }
+    void setLastRigidTransformAndCompactify(const mat4f& lastRigidTransform, const DepthCameraParams& params) {
+        check(bf_scene_set_last_rigid_transform_and_compactify(m_h, lastRigidTransform.m, &params));
+    }
+    HashDataStruct getHashData() { HashDataStruct d; check(bf_scene_get_hash_data(m_h, &d)); return d; }
+    HashParams getHashParams() { HashParams p; check(bf_scene_get_hash_params(m_h, &p)); return p; }
+    unsigned int getHeapFreeCount() { uint32_t n; check(bf_scene_get_heap_free_count(m_h, &n)); return n; }
+    unsigned int getNumIntegratedFrames() { uint32_t n; check(bf_scene_get_num_integrated_frames(m_h, &n)); return n; }
+    bf_scene* handle() const { return m_h; }
+private:
+    bf_scene* m_h = nullptr;
+};
+
+}  // namespace bundlefusion

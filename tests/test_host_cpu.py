@@ -136,3 +136,15 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert [(int(r[1]), int(r[2])) for r in rows] == [(0, 20), (20, 40)]
     assert all(abs(float(r[3]) - 1.5) < 1e-9 for r in rows)                 # MAX over ranks
     assert all(abs(float(r[4]) - 2 * 20 / 1.5) < 1e-9 for r in rows)        # whole-job units / slowest rank
+
+
+def test_cpp_header_classes_compile_and_link(built, tmp_path):
+    """include/bundlefusion/bundlefusion.hpp (reference class names over the C ABI) builds with plain g++ — no HIP headers
+    needed on the integrator's side — and every forwarded symbol resolves against libbf_hip.so."""
+    exe = tmp_path / "headless_driver"
+    libdir = os.path.join(ROOT, "bundlefusion_amd", "lib")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "headless_driver.cpp"),
+                        "-L", libdir, "-lbf_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "usage:" in out.stdout
