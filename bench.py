@@ -108,14 +108,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     c1 = pipe.counters()
-    occ_sum = sc.kernel_timing_occupied()
+    occ_sum, n_ops = sc.kernel_timing_occupied()
     n_launch, kernel_ms = sc.kernel_timing_read()
     sc.kernel_timing(False)
     elapsed = max_over_ranks(elapsed, "cuda")
 
-    # dominant kernel: the TSDF voxel update.  algorithmic bytes per launch = N_occ*(512*24+32) + W*H*8  
-    n_occ = occ_sum / max(n_launch, 1)
-    bytes_per_launch = n_occ * (512 * 24 + 32) + W * H * 8
+    # dominant kernel: the TSDF voxel update.  algorithmic bytes of ONE integrate / de-integrate op = N_occ*(512*24+32) + W*H*8
+    # (SURVEY.md §8d); a fused re-integration launch performs two ops (de-integrate old pose + integrate new pose) in one pass
+    n_occ = occ_sum / max(n_ops, 1)
+    bytes_per_launch = (occ_sum * (512 * 24 + 32) + n_ops * W * H * 8) / max(n_launch, 1)
     avg_kernel_s = (kernel_ms / 1e3) / max(n_launch, 1)
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     dbg = sc.debug_hash()
@@ -153,11 +154,11 @@ def main():
                 "parallelism": "stream segments sharded over %d rank(s), no data-path collective" % world,
             },
             "roofline": {
-                "kernel": "k_update<integrate|deintegrate> (TSDF voxel update)",
+                "kernel": "k_update<integrate> + k_reupdate (fused de-integrate+integrate) — TSDF voxel update",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "launches": n_launch, "avg_launch_us": 1e6 * avg_kernel_s,
-                "algorithmic_bytes_per_launch": bytes_per_launch, "n_occ_mean": n_occ,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": n_occ,
                 "share_of_step_time": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None,
             },
         }

@@ -169,6 +169,11 @@ class SceneRepHashSDF:
         d = self._data(depth, color)
         check(lib.bf_scene_deintegrate(self._h, mat16(cam_to_world), C.byref(d), C.byref(cam), None))
 
+    def reintegrate(self, old_cam_to_world, new_cam_to_world, depth, color, cam):
+        """fused deintegrate(old) + integrate(new) of the same frame"""
+        data = self._data(depth, color)
+        check(lib.bf_scene_reintegrate(self._h, mat16(old_cam_to_world), mat16(new_cam_to_world), C.byref(data), C.byref(cam)))
+
     def garbage_collect(self):
         check(lib.bf_scene_garbage_collect(self._h))
 
@@ -215,9 +220,9 @@ class SceneRepHashSDF:
         return n.value, ms.value
 
     def kernel_timing_occupied(self):
-        v = C.c_uint64()
-        check(lib.bf_scene_kernel_timing_occupied(self._h, C.byref(v)))
-        return v.value
+        v = C.c_uint64(); n = C.c_uint32()
+        check(lib.bf_scene_kernel_timing_occupied(self._h, C.byref(v), C.byref(n)))
+        return v.value, n.value
 
     # ---- test helpers: copy raw arrays back (hipMemcpy through torch) ----
     def download(self):

@@ -1234,8 +1234,12 @@ int plReintegrate(bf_pipeline* p) {                                             
         BF_TRY(bf_trajectory_manager_get_top_from_reintegrate_list(tm, oldT, newT, &frameIdx, &found));
         if (found) {
             if (newT[0] == NINF) continue;          // every candidate was invalidated meanwhile; it is de-integrated on the next list update
-            BF_TRY(plIntegrate(p, frameIdx, oldT, true));
-            BF_TRY(plIntegrate(p, frameIdx, newT, false));
+            if (p->gas.s_integrationEnabled) {          // deIntegrate(old) + integrate(new) (:885-886) as one fused pass over the volume
+                bf_depth_camera_data data;
+                BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frameIdx, &data.d_depthData, &data.d_colorData));
+                BF_TRY(bf_scene_reintegrate(p->scene, oldT, newT, &data, &p->cam));
+                p->numDeIntegrate++; p->numIntegrate++;
+            }
             BF_TRY(bf_trajectory_manager_confirm_integration(tm, frameIdx));
             continue;
         }

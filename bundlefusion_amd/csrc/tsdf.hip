@@ -456,15 +456,19 @@ __global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
 //   MODE 0: frustum list (replaces compactifyHashAllInOneKernel, .cu:324-366)
 //   MODE 1: drop holes from the allocated list (after GC)
 // ---------------------------------------------------------------------------------------
+// MODE 0: blocks in the frustum of f;  MODE 1: every live block (list maintenance);  MODE 2: blocks in the frustum of f
+// (bit 0 of the result) or of fo (bit 1) — the union list of a fused re-integration
 template <int MODE>
-BF_DEV bool keepRec(const Frame& f, const AllocRec& r) {
-    if (r.ptr == BF_FREE_ENTRY) return false;
-    if (MODE == 1) return true;
-    return blockInFrustum(f, unpackKey(r.key));
+BF_DEV uint32_t keepRec(const Frame& f, const Frame& fo, const AllocRec& r) {
+    if (r.ptr == BF_FREE_ENTRY) return 0u;
+    if (MODE == 1) return 1u;
+    const i3 b = unpackKey(r.key);
+    if (MODE == 0) return blockInFrustum(f, b) ? 1u : 0u;
+    return (blockInFrustum(f, b) ? 1u : 0u) | (blockInFrustum(fo, b) ? 2u : 0u);
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f) {
+__global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f, Frame fo) {
     __shared__ uint32_t wsum[4];
     const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f) {
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
-            if (i < n) c += keepRec<MODE>(f, d.allocList[i]) ? 1u : 0u;
+            if (i < n) c += keepRec<MODE>(f, fo, d.allocList[i]) ? 1u : 0u;
         }
         c = (uint32_t)wave_sum_i((int)c);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -484,14 +488,14 @@ __global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f) {
+__global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame fo) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t wscan[4];
     const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (numTiles == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { if (MODE == 0) d.compactCount[0] = 0; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { if (MODE != 1) d.compactCount[0] = 0; }
         return;
     }
     for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
@@ -504,13 +508,13 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f) {
         const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
         AllocRec recs[4];
-        bool keep[4];
+        uint32_t keep[4];
         uint32_t c = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
-            keep[k] = false;
-            if (i < n) { recs[k] = d.allocList[i]; keep[k] = keepRec<MODE>(f, recs[k]); }
+            keep[k] = 0u;
+            if (i < n) { recs[k] = d.allocList[i]; keep[k] = keepRec<MODE>(f, fo, recs[k]); }
             c += keep[k] ? 1u : 0u;
         }
         // exclusive scan of c across the block: wave scan + wave totals
@@ -526,11 +530,11 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f) {
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             if (!keep[k]) continue;
-            if (MODE == 0) {
+            if (MODE != 1) {
                 const i3 b = unpackKey(recs[k].key);
                 uint4* o4 = reinterpret_cast<uint4*>(d.compact + pos);
                 o4[0] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)recs[k].ptr);
-                o4[1] = make_uint4(0u, 0u, 0u, 0u);
+                o4[1] = make_uint4(MODE == 2 ? keep[k] : 0u, 0u, 0u, 0u);     // offset field doubles as the frustum flags of the union list
                 d.compactSrc[pos] = tile * TILE + threadIdx.x * 4 + k;
             } else {
                 d.allocListAlt[pos] = recs[k];
@@ -538,14 +542,12 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f) {
             ++pos;
         }
         if (tile == numTiles - 1 && threadIdx.x == 0) {
-            if (MODE == 0) d.compactCount[0] = (int32_t)(base + tileTotal);
+            if (MODE != 1) d.compactCount[0] = (int32_t)(base + tileTotal);
             else d.tileCounts[numTiles] = base + tileTotal;      // new list length, committed by k_list_commit
         }
         __syncthreads();
     }
 }
-
-__global__ void k_occ_accum(Dev d) { d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[0]; }
 
 __global__ void k_list_commit(Dev d) {
     const uint32_t n = d.allocCount[0];
@@ -557,65 +559,114 @@ __global__ void k_list_commit(Dev d) {
 // voxel update: integrate / de-integrate (CUDASceneRepHashSDF.cu:420-521)
 // one 512-thread workgroup per SDF block, persistent grid-stride over the frustum list
 // ---------------------------------------------------------------------------------------
+// projection of one voxel into the frame and the truncated signed distance sample (the part before the voxel is touched)
+BF_DEV bool voxelSample(const Frame& f, int4 e, int lx, int ly, int lz, const float* __restrict__ depth, uint32_t W, uint32_t H, float& sdf, size_t& pix) {
+    f3 pf = mk3((float)(e.x * BS + lx), (float)(e.y * BS + ly), (float)(e.z * BS + lz)) * f.voxelSize;
+    pf = xform(f.Tinv, pf);
+    const float sx = pf.x * f.cam.fx / pf.z + f.cam.mx;
+    const float sy = pf.y * f.cam.fy / pf.z + f.cam.my;
+    const uint32_t px = (uint32_t)f2i(sx + 0.5f), py = (uint32_t)f2i(sy + 0.5f);
+    if (!(px < W && py < H)) return false;
+    pix = (size_t)py * W + px;
+    const float dep = depth[pix];
+    if (dep == BF_MINF) return false;
+    if (!(dep < f.maxIntegrationDistance)) return false;
+    sdf = dep - pf.z;
+    const float trunc = f.truncation + f.truncScale * dep;
+    if (!(fabsf(sdf) < trunc)) return false;
+    if (sdf >= 0.0f) sdf = fminf(trunc, sdf); else sdf = fmaxf(-trunc, sdf);
+    return true;
+}
+
+// combineVoxel / its inverse on (sdf, weight, packed colour); DEINT resets a voxel whose weight drops to zero
+template <bool DEINT>
+BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float& vW, uint32_t& vC) {
+    const float c0 = (float)cc.x, c1 = (float)cc.y, c2 = (float)cc.z;
+    const float oSdf = vSdf, oW = vW;
+    const uint32_t oC = vC;
+    const float o0 = (float)(oC & 0xFF), o1 = (float)((oC >> 8) & 0xFF), o2 = (float)((oC >> 16) & 0xFF);
+    float nSdf, nW;
+    uint32_t nC;
+    if (!DEINT) {
+        float r0, r1, r2;
+        if (oW == 0.0f) { r0 = c0; r1 = c1; r2 = c2; }
+        else { r0 = 0.2f * c0 + 0.8f * o0; r1 = 0.2f * c1 + 0.8f * o1; r2 = 0.2f * c2 + 0.8f * o2; }
+        r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
+        r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
+        r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
+        nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
+        nSdf = (sdf * 1.0f + oSdf * oW) / (1.0f + oW);
+        nW = fminf(f.weightMax, 1.0f + oW);
+    } else {
+        float r0 = (o0 * oW - c0 * 1.0f) / (oW - 1.0f);
+        float r1 = (o1 * oW - c1 * 1.0f) / (oW - 1.0f);
+        float r2 = (o2 * oW - c2 * 1.0f) / (oW - 1.0f);
+        r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
+        r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
+        r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
+        nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
+        nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
+        nW = fmaxf(0.0f, oW - 1.0f);
+        if (nW <= 0.001f) { nSdf = 0.0f; nC = 0u; nW = 0.0f; }
+    }
+    vSdf = nSdf; vW = nW; vC = nC;
+}
+
 template <bool DEINT>
 __global__ __launch_bounds__(512) void k_update(Dev d, Frame f, const float* __restrict__ depth,
-                                                const uchar4* __restrict__ color) {
+                                                const uchar4* __restrict__ color, int accumulate) {
     if (color == nullptr) return;   // .cu:441-448: without colour data `color.x != MINF` never holds
     const uint32_t n = (uint32_t)d.compactCount[0];
+    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) d.occSum[0] += (unsigned long long)n;
     const uint32_t i = threadIdx.x;
     const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
     for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
         const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];   // wave-uniform
-        f3 pf = mk3((float)(e.x * BS + lx), (float)(e.y * BS + ly), (float)(e.z * BS + lz)) * f.voxelSize;
-        pf = xform(f.Tinv, pf);
-        const float sx = pf.x * f.cam.fx / pf.z + f.cam.mx;
-        const float sy = pf.y * f.cam.fy / pf.z + f.cam.my;
-        const uint32_t px = (uint32_t)f2i(sx + 0.5f), py = (uint32_t)f2i(sy + 0.5f);
-        if (!(px < W && py < H)) continue;
-        const size_t pix = (size_t)py * W + px;
-        const float dep = depth[pix];
-        if (dep == BF_MINF) continue;
-        if (!(dep < f.maxIntegrationDistance)) continue;
-        float sdf = dep - pf.z;
-        const float trunc = f.truncation + f.truncScale * dep;
-        if (!(fabsf(sdf) < trunc)) continue;
-        if (sdf >= 0.0f) sdf = fminf(trunc, sdf); else sdf = fmaxf(-trunc, sdf);
+        float sdf; size_t pix;
+        if (!voxelSample(f, e, lx, ly, lz, depth, W, H, sdf, pix)) continue;
         const uchar4 cc = color[pix];
-        const float c0 = (float)cc.x, c1 = (float)cc.y, c2 = (float)cc.z;
         uint32_t* vp = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + i));
-        const float oSdf = __uint_as_float(vp[0]);
-        const float oW = __uint_as_float(vp[1]);
-        const uint32_t oC = vp[2];
-        const float o0 = (float)(oC & 0xFF), o1 = (float)((oC >> 8) & 0xFF), o2 = (float)((oC >> 16) & 0xFF);
-        float nSdf, nW;
-        uint32_t nC;
-        if (!DEINT) {
-            float r0, r1, r2;
-            if (oW == 0.0f) { r0 = c0; r1 = c1; r2 = c2; }
-            else { r0 = 0.2f * c0 + 0.8f * o0; r1 = 0.2f * c1 + 0.8f * o1; r2 = 0.2f * c2 + 0.8f * o2; }
-            r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
-            r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
-            r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
-            nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
-            nSdf = (sdf * 1.0f + oSdf * oW) / (1.0f + oW);
-            nW = fminf(f.weightMax, 1.0f + oW);
-        } else {
-            float r0 = (o0 * oW - c0 * 1.0f) / (oW - 1.0f);
-            float r1 = (o1 * oW - c1 * 1.0f) / (oW - 1.0f);
-            float r2 = (o2 * oW - c2 * 1.0f) / (oW - 1.0f);
-            r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
-            r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
-            r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
-            nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
-            nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
-            nW = fmaxf(0.0f, oW - 1.0f);
-            if (nW <= 0.001f) { nSdf = 0.0f; nC = 0u; nW = 0.0f; }
-        }
-        vp[0] = __float_as_uint(nSdf);
-        vp[1] = __float_as_uint(nW);
-        vp[2] = nC;
+        float vSdf = __uint_as_float(vp[0]), vW = __uint_as_float(vp[1]);
+        uint32_t vC = vp[2];
+        voxelApply<DEINT>(f, sdf, cc, vSdf, vW, vC);
+        vp[0] = __float_as_uint(vSdf);
+        vp[1] = __float_as_uint(vW);
+        vp[2] = vC;
     }
+}
+
+// Fused re-integration of one frame: de-integrate at the old pose (fo), then integrate at the new pose (f), in ONE pass over the
+// union of the two frustum lists — every touched voxel is read once and written once instead of twice.  Per voxel this is the
+// exact operation sequence of deIntegrate followed by integrate (DepthSensing.cpp:882-889): blocks carry their frustum
+// membership flags, the intermediate value goes through the same packed representation, and a block the new pose allocated
+// inside the old frustum sees a no-op de-integration (weight 0 -> reset to 0), as if it had not existed yet.
+__global__ __launch_bounds__(512) void k_reupdate(Dev d, Frame f, Frame fo, const float* __restrict__ depth,
+                                                  const uchar4* __restrict__ color, int accumulate) {
+    if (color == nullptr) return;
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t i = threadIdx.x;
+    const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
+    const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
+    uint32_t opBlocks = 0;          // blocks of the de-integrate list + blocks of the integrate list handled by this workgroup
+    for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
+        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];
+        const uint32_t flags = reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4];
+        opBlocks += (flags & 1u) + ((flags >> 1) & 1u);
+        float sdfDe = 0.0f, sdfIn = 0.0f; size_t pixDe = 0, pixIn = 0;
+        const bool doDe = (flags & 2u) && voxelSample(fo, e, lx, ly, lz, depth, W, H, sdfDe, pixDe);
+        const bool doIn = (flags & 1u) && voxelSample(f, e, lx, ly, lz, depth, W, H, sdfIn, pixIn);
+        if (!doDe && !doIn) continue;
+        uint32_t* vp = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + i));
+        float vSdf = __uint_as_float(vp[0]), vW = __uint_as_float(vp[1]);
+        uint32_t vC = vp[2];
+        if (doDe) voxelApply<true>(fo, sdfDe, color[pixDe], vSdf, vW, vC);
+        if (doIn) voxelApply<false>(f, sdfIn, color[pixIn], vSdf, vW, vC);
+        vp[0] = __float_as_uint(vSdf);
+        vp[1] = __float_as_uint(vW);
+        vp[2] = vC;
+    }
+    if (accumulate && threadIdx.x == 0 && opBlocks) atomicAdd(d.occSum, (unsigned long long)opBlocks);      // integer: order-independent
 }
 
 // ---------------------------------------------------------------------------------------
@@ -745,6 +796,8 @@ struct bf_scene {
     uint32_t dedupeSize = 0;
     uint32_t gridCompact = 0, gridUpdate = 0;
     int32_t* d_hashDecision = nullptr;
+    uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
+    bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
     // optional HIP-event timing of the voxel-update kernel
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -790,9 +843,10 @@ void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepH
 
 int launchCompactify(bf_scene* s) {                              // compactifyHashEntries :355-391
     const Frame f = makeFrame(s);
-    hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
-    hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
+    hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     BF_HIP_TRY(hipGetLastError());
+    s->compactStale = false;
     return BF_OK;
 }
 
@@ -818,11 +872,11 @@ int launchUpdate(bf_scene* s, const bf_depth_camera_data* data) {
             s->events.push_back({a, b});
         }
         ev = &s->events[s->eventsUsed++];
-        hipLaunchKernelGGL(k_occ_accum, dim3(1), dim3(1), 0, s->stream, s->d);
+        s->opsTimed += 1;
         BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
     }
     hipLaunchKernelGGL(k_update<DEINT>, dim3(s->gridUpdate), dim3(512), 0, s->stream, s->d, f, data->d_depthData,
-                       reinterpret_cast<const uchar4*>(data->d_colorData));
+                       reinterpret_cast<const uchar4*>(data->d_colorData), s->timing ? 1 : 0);
     if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -942,6 +996,41 @@ int bf_scene_deintegrate(bf_scene* s, const float T[16], const bf_depth_camera_d
     return BF_OK;
 }
 
+// De-integrate the frame at oldT and integrate it at newT as one fused pass (MI355X addition; the reference issues the two
+// operators back to back, DepthSensing.cpp:882-889).  Bit-identical to bf_scene_deintegrate(oldT) + bf_scene_integrate(newT).
+int bf_scene_reintegrate(bf_scene* s, const float oldT[16], const float newT[16], const bf_depth_camera_data* data,
+                         const bf_depth_camera_params* cam) {
+    int rc = checkCall(s, newT, data, cam, nullptr);
+    if (rc) return rc;
+    BF_REQUIRE(oldT, "null argument");
+    s->cam = *cam; s->haveCam = true;
+    setLastRigidTransform(s, oldT);
+    const Frame fo = makeFrame(s);
+    setLastRigidTransform(s, newT);
+    const Frame f = makeFrame(s);
+    if ((rc = launchAlloc(s, data->d_depthData))) return rc;            // de-integration neither allocates nor frees: same result as after it
+    hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, fo);
+    hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, fo);
+    s->compactStale = true;
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (s->timing) {
+        if (s->eventsUsed == s->events.size()) {
+            hipEvent_t a, b;
+            BF_HIP_TRY(hipEventCreate(&a));
+            BF_HIP_TRY(hipEventCreate(&b));
+            s->events.push_back({a, b});
+        }
+        ev = &s->events[s->eventsUsed++];
+        s->opsTimed += 2;
+        BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
+    }
+    hipLaunchKernelGGL(k_reupdate, dim3(s->gridUpdate), dim3(512), 0, s->stream, s->d, f, fo, data->d_depthData,
+                       reinterpret_cast<const uchar4*>(data->d_colorData), s->timing ? 1 : 0);
+    if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
 int bf_scene_set_last_rigid_transform_and_compactify(bf_scene* s, const float T[16], const bf_depth_camera_params* cam) {
     BF_REQUIRE(s && T && cam, "null argument");
     s->cam = *cam; s->haveCam = true;
@@ -952,12 +1041,13 @@ int bf_scene_set_last_rigid_transform_and_compactify(bf_scene* s, const float T[
 int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
     BF_REQUIRE(s, "null scene");
     if (!s->haveCam) return BF_OK;                                  // nothing was ever compactified
+    if (s->compactStale) { int rc = launchCompactify(s); if (rc) return rc; }
     const Frame f = makeFrame(s);
     hipLaunchKernelGGL(k_gc_identify, dim3(s->gridUpdate), dim3(256), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_delete, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_finish, dim3(1), dim3(256), 0, s->stream, s->d);
-    hipLaunchKernelGGL(k_compact_count<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
-    hipLaunchKernelGGL(k_compact_scatter<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_compact_count<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
+    hipLaunchKernelGGL(k_compact_scatter<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     hipLaunchKernelGGL(k_list_commit, dim3(1), dim3(1), 0, s->stream, s->d);
     std::swap(s->d.allocList, s->d.allocListAlt);
     BF_HIP_TRY(hipGetLastError());
@@ -966,6 +1056,7 @@ int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
 
 int bf_scene_get_hash_data(bf_scene* s, bf_hash_data* out) {
     BF_REQUIRE(s && out, "null argument");
+    if (s->compactStale) { int rc = launchCompactify(s); if (rc) return rc; }
     out->d_heap = s->d.heap;
     out->d_heapCounter = s->d.heapCounter;
     out->d_hashDecision = s->d_hashDecision;
@@ -980,6 +1071,7 @@ int bf_scene_get_hash_data(bf_scene* s, bf_hash_data* out) {
 
 int bf_scene_get_hash_params(bf_scene* s, bf_hash_params* out) {
     BF_REQUIRE(s && out, "null argument");
+    if (s->compactStale) { int rc = launchCompactify(s); if (rc) return rc; }
     int32_t n = 0;
     BF_HIP_TRY(hipMemcpyAsync(&n, s->d.compactCount, 4, hipMemcpyDeviceToHost, s->stream));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1053,6 +1145,7 @@ int bf_scene_kernel_timing(bf_scene* s, int enable) {
     BF_REQUIRE(s, "null scene");
     s->timing = enable != 0;
     s->eventsUsed = 0;
+    s->opsTimed = 0;
     BF_HIP_TRY(hipMemsetAsync(s->d.occSum, 0, sizeof(unsigned long long), s->stream));
     return BF_OK;
 }
@@ -1072,8 +1165,9 @@ int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms) {
     return BF_OK;
 }
 
-int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks) {
+int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks, uint32_t* numOps) {
     BF_REQUIRE(s && sumOccupiedBlocks, "null argument");
+    if (numOps) *numOps = s->opsTimed;
     unsigned long long v = 0;
     BF_HIP_TRY(hipMemcpyAsync(&v, s->d.occSum, sizeof v, hipMemcpyDeviceToHost, s->stream));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));

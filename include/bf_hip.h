@@ -142,6 +142,10 @@ BF_API int bf_scene_integrate(bf_scene* s, const float cam_to_world[16],
 BF_API int bf_scene_deintegrate(bf_scene* s, const float cam_to_world[16],
                                 const bf_depth_camera_data* data,
                                 const bf_depth_camera_params* cam, const uint32_t* d_bitMask);
+/* MI355X addition: deIntegrate(oldT) + integrate(newT) of the same frame (DepthSensing.cpp:882-889) as ONE pass over
+ * the union of the two frustum lists — each touched voxel is read and written once.  Bit-identical to the two calls. */
+BF_API int bf_scene_reintegrate(bf_scene* s, const float old_cam_to_world[16], const float new_cam_to_world[16],
+                                const bf_depth_camera_data* data, const bf_depth_camera_params* cam);
 /* garbageCollect()                                         :110-126              */
 BF_API int bf_scene_garbage_collect(bf_scene* s);
 /* setLastRigidTransformAndCompactify(T)                    :136-139
@@ -168,8 +172,10 @@ BF_API int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out);
  * (read synchronises the stream and clears the accumulator).                       */
 BF_API int bf_scene_kernel_timing(bf_scene* s, int enable);
 BF_API int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms);
-/* sum of m_numOccupiedBlocks over the launches timed since bf_scene_kernel_timing(s, 1) (call before _read) */
-BF_API int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks);
+/* over the launches timed since bf_scene_kernel_timing(s, 1) (call before _read): the sum of the frustum-list lengths
+ * (m_numOccupiedBlocks) of the integrate / de-integrate operations they performed, and the number of those operations
+ * (a fused re-integration launch performs two).                                                                     */
+BF_API int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks, uint32_t* numOps);
 
 
 /* ------------------------------------------------------------------------- */

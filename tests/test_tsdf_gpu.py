@@ -98,6 +98,40 @@ def test_sequence_integrate_deintegrate_gc_bit_exact(gpu, oracle):
     assert not gvox.view(np.uint8).any()
 
 
+def test_fused_reintegrate_equals_deintegrate_plus_integrate(gpu, oracle):
+    """bf_scene_reintegrate (one pass over the union of both frustum lists) vs the oracle's deIntegrate + integrate
+    (DepthSensing.cpp:882-889): small and large pose changes (frusta overlapping fully, partly, hardly), followed by GC."""
+    W, H = 160, 120
+    frames = [synth.scene_room(k * 12, W, H) for k in range(5)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=50000, num_sdf_blocks=40000, voxel_size=0.02)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    osc = oracle.OracleScene(p)
+    dev = [_to_dev(f[0], f[1]) for f in frames]
+    poses = [f[2].copy() for f in frames]
+    for i, (depth, color, T, _) in enumerate(frames):
+        gs.integrate(T, dev[i][0], dev[i][1], cam)
+        osc.integrate(T, depth, color, cam)
+    rng = np.random.default_rng(3)
+    for step, (i, dt, drot) in enumerate([(1, 0.002, 0.0), (3, 0.05, 0.0), (0, 0.4, 0.0), (2, 0.0, 0.6), (4, 0.01, 0.01), (1, 0.02, 0.0)]):
+        depth, color, _, _ = frames[i]
+        T2 = poses[i].copy()
+        T2[:3, 3] += (rng.normal(size=3) * dt).astype(np.float32)
+        if drot:
+            c_, s_ = np.float32(np.cos(drot)), np.float32(np.sin(drot))
+            R = np.array([[c_, 0, s_], [0, 1, 0], [-s_, 0, c_]], np.float32)
+            T2[:3, :3] = R @ T2[:3, :3]
+        gs.reintegrate(poses[i], T2, dev[i][0], dev[i][1], cam)
+        osc.deintegrate(poses[i], depth, color, cam)
+        osc.integrate(T2, depth, color, cam)
+        poses[i] = T2
+        if step % 2 == 1:
+            gs.garbage_collect(); osc.garbage_collect()
+        assert_same_state(gs, osc, "after fused re-integration %d:" % step)
+    assert gs.num_integrated_frames() == 5
+
+
 def test_collision_chains_and_drops_bit_exact(gpu, oracle):
     depth, color, T, cam, p = _setup(160, 120, 0.01, 400, 6000)
     gs = gpu.capi.SceneRepHashSDF(p)
