@@ -406,18 +406,45 @@ BF_DEV f3 covarianceEig(const f3* pts, unsigned n) {
 
 template <class T> BF_DEV void swp(T& a, T& b) { const T t = a; a = b; b = t; }
 
-__device__ __noinline__ bool computeReprojection(f3* src, f3* tgt, unsigned n, float* res, m44& T, Sel* sel) {   // :386-419
-    f3 ev;
-    T = kabsch(src, tgt, n, ev);
-    for (unsigned i = 0; i < n; ++i) { const f3 d = xform(T, src[i]) - tgt[i]; res[i] = dot3(d, d); }
-    for (unsigned i = 0; i < n; ++i)
-        for (unsigned j = i; j < n; ++j)
-            if (res[i] > res[j]) { swp(res[i], res[j]); swp(src[i], src[j]); swp(tgt[i], tgt[j]); swp(sel[i], sel[j]); }
-    const float c1 = ev.x / ev.y;
-    f3 e = covarianceEig(src, n);
-    const float cp = e.x / e.y;
-    e = covarianceEig(tgt, n);
-    const float cq = e.x / e.y;
+// ComputeReprojection (cuda_kabsch.h:386-419) executed by one wave.  The arithmetic of every value is the sequential
+// reference sequence; only independent pieces run on different lanes:
+//   lane 0          Kabsch fit (sums in index order, SVD)                 -> T, singular values
+//   lanes < n       residual of point `lane`
+//   lanes < n       rank of each residual = its slot after sortKabschResiduals (:376-384); the selection sort's result is
+//                   unique when all residuals are finite and distinct — otherwise lane 0 runs the literal sort
+//   lanes 0 and 1   covariance eigenvalues of the (sorted) source / target points
+struct ReprojShared { m44 T; float ev[3]; float cond[2]; };
+
+__device__ __noinline__ bool computeReprojection(uint32_t lane, f3* src, f3* tgt, unsigned n, float* res, Sel* sel, ReprojShared* sh) {
+    if (lane == 0) {
+        f3 ev;
+        sh->T = kabsch(src, tgt, n, ev);
+        sh->ev[0] = ev.x; sh->ev[1] = ev.y; sh->ev[2] = ev.z;
+    }
+    __syncthreads();
+    float my = 0.0f;
+    if (lane < n) { const f3 d = xform(sh->T, src[lane]) - tgt[lane]; my = dot3(d, d); res[lane] = my; }
+    __syncthreads();
+    unsigned rank = 0;
+    bool odd = false;               // NaN or a tie: the generic sort order is not determined by the values alone
+    if (lane < n) {
+        odd = my != my;
+        for (unsigned j = 0; j < n; ++j) { const float rj = res[j]; rank += rj < my ? 1u : 0u; odd = odd || (j != lane && rj == my); }
+    }
+    if (__ballot(odd) == 0ull) {
+        f3 s_ = mk3(0, 0, 0), t_ = mk3(0, 0, 0); Sel e_ = {0u, 0u, 0.0f, 0u};
+        if (lane < n) { s_ = src[lane]; t_ = tgt[lane]; e_ = sel[lane]; }
+        __syncthreads();
+        if (lane < n) { src[rank] = s_; tgt[rank] = t_; sel[rank] = e_; res[rank] = my; }
+    } else if (lane == 0) {
+        for (unsigned i = 0; i < n; ++i)
+            for (unsigned j = i; j < n; ++j)
+                if (res[i] > res[j]) { swp(res[i], res[j]); swp(src[i], src[j]); swp(tgt[i], tgt[j]); swp(sel[i], sel[j]); }
+    }
+    __syncthreads();
+    if (lane < 2) { const f3 e = covarianceEig(lane == 0 ? src : tgt, n); sh->cond[lane] = e.x / e.y; }
+    __syncthreads();
+    const float c1 = sh->ev[0] / sh->ev[1], cp = sh->cond[0], cq = sh->cond[1];
     if (c1 != c1 || cp != cp || cq != cq || fabsf(c1) > 100.0f || fabsf(cp) > 100.0f || fabsf(cq) > 100.0f) return false;
     return true;
 }
@@ -430,8 +457,9 @@ struct FilterArgs {
 };
 
 // One wave per previous image.  The greedy filter is inherently sequential (every accepted match changes the Kabsch fit
-// the next decision depends on), so lane 0 runs it — but entirely out of LDS: the 64 lanes first stage the <= 128 raw
-// matches' key positions and back-projected 3-D points, so the serial loop never waits on HBM.
+// the next decision depends on); the wave walks it in lock step — control state is replicated in all lanes, data lives in
+// LDS (the <= 128 raw matches' key positions and back-projected points are staged once), and the independent pieces of each
+// step (distance checks, residuals, sort ranks, the two covariance solves) are spread over lanes.
 __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
@@ -443,7 +471,8 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
     __shared__ f3 ptI[MAX_RAW], ptJ[MAX_RAW];
     __shared__ f3 src[MAX_FILT], tgt[MAX_FILT];
     __shared__ float res[MAX_FILT];
-    __shared__ unsigned sCur;
+    __shared__ ReprojShared sh;
+    __shared__ m44 prevT;
     for (int i = (int)tid; i < numRaw; i += 64) {
         const uint2 k = a.idx[prev * MAX_RAW + i];
         sel[i].ix = k.x; sel[i].iy = k.y; sel[i].dist = a.dist[prev * MAX_RAW + i]; sel[i].r = (uint32_t)i;
@@ -451,63 +480,67 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
         posI[i] = make_float2(ki.x, ki.y); posJ[i] = make_float2(kj.x, kj.y);
         ptI[i] = backProject(a.Kinv, ki); ptJ[i] = backProject(a.Kinv, kj);
     }
+    if (tid == 0) sh.T = identity44();
     __syncthreads();
-    if (tid == 0) {          // filterKeyPointMatches, cuda_kabsch.h:422-502
-        unsigned cur = 0;
-        int i = 0;
-        float curMaxRes = 100.0f;
-        bool validT = false;
-        m44 T = identity44();
-        for (;;) {
-            if (i == numRaw || cur >= (unsigned)MAX_FILT) {
-                if ((int)cur < a.minNumMatches || curMaxRes >= a.maxKabschRes2 || !validT) cur = 0;
-                break;
-            }
-            bool add = true;        // addMatch :278-294: at least 5 px from every kept match in both images
-            {
-                const float2 ai = posI[i], aj = posJ[i];          // sel[i].r == i: raw entries beyond `cur` are never permuted
-                for (unsigned k = 0; k < cur; ++k) {
-                    const float2 ki = posI[sel[k].r], kj = posJ[sel[k].r];
-                    const float d0 = sqrtf((ai.x - ki.x) * (ai.x - ki.x) + (ai.y - ki.y) * (ai.y - ki.y));
-                    const float d1 = sqrtf((aj.x - kj.x) * (aj.x - kj.x) + (aj.y - kj.y) * (aj.y - kj.y));
-                    if (d0 <= 5 || d1 <= 5) { add = false; break; }
-                }
-            }
-            if (add) {
-                sel[cur] = sel[i];
-                cur++;
-                if (cur >= 3) {
-                    for (unsigned k = 0; k < cur; ++k) { src[k] = ptI[sel[k].r]; tgt[k] = ptJ[sel[k].r]; }
-                    validT = computeReprojection(src, tgt, cur, res, T, sel);
-                    const bool b = validT;
-                    const m44 prevT = T;
-                    curMaxRes = res[cur - 1];
-                    if (curMaxRes > a.maxKabschRes2) {
-                        float lastRes = -1;
-                        const int startIdx = (int)cur - 1;
-                        for (int k = startIdx; k >= 3; --k) {
-                            lastRes = res[k];
-                            cur--;
-                            validT = computeReprojection(src, tgt, cur, res, T, sel);
-                            curMaxRes = res[cur - 1];
-                            if (cur == 3 && (curMaxRes > a.maxKabschRes2 || (b && !validT))) {
-                                cur++; curMaxRes = lastRes; validT = b; T = prevT;
-                                break;
-                            }
-                            if (curMaxRes < a.maxKabschRes2) break;
+    // filterKeyPointMatches, cuda_kabsch.h:422-502
+    unsigned cur = 0;
+    int i = 0;
+    float curMaxRes = 100.0f;
+    bool validT = false;
+    for (;;) {
+        if (i == numRaw || cur >= (unsigned)MAX_FILT) {
+            if ((int)cur < a.minNumMatches || curMaxRes >= a.maxKabschRes2 || !validT) cur = 0;
+            break;
+        }
+        bool close = false;         // addMatch :278-294: at least 5 px from every kept match in both images
+        if (tid < cur) {
+            const float2 ai = posI[i], aj = posJ[i];          // raw entries at positions >= cur are never permuted: sel[i].r == i
+            const float2 ki = posI[sel[tid].r], kj = posJ[sel[tid].r];
+            const float d0 = sqrtf((ai.x - ki.x) * (ai.x - ki.x) + (ai.y - ki.y) * (ai.y - ki.y));
+            const float d1 = sqrtf((aj.x - kj.x) * (aj.x - kj.x) + (aj.y - kj.y) * (aj.y - kj.y));
+            close = d0 <= 5 || d1 <= 5;
+        }
+        if (__ballot(close) == 0ull) {
+            if (tid == 0) sel[cur] = sel[i];
+            __syncthreads();
+            cur++;
+            if (cur >= 3) {
+                if (tid < cur) { src[tid] = ptI[sel[tid].r]; tgt[tid] = ptJ[sel[tid].r]; }
+                __syncthreads();
+                validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
+                const bool b = validT;
+                if (tid < 16) prevT.e[tid] = sh.T.e[tid];
+                curMaxRes = res[cur - 1];
+                if (curMaxRes > a.maxKabschRes2) {
+                    float lastRes = -1;
+                    const int startIdx = (int)cur - 1;
+                    for (int k = startIdx; k >= 3; --k) {
+                        lastRes = res[k];
+                        cur--;
+                        __syncthreads();
+                        validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
+                        curMaxRes = res[cur - 1];
+                        if (cur == 3 && (curMaxRes > a.maxKabschRes2 || (b && !validT))) {
+                            cur++; curMaxRes = lastRes; validT = b;
+                            __syncthreads();
+                            if (tid < 16) sh.T.e[tid] = prevT.e[tid];
+                            break;
                         }
+                        if (curMaxRes < a.maxKabschRes2) break;
                     }
                 }
             }
-            i++;
         }
-        sCur = cur;
+        __syncthreads();
+        i++;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const m44 T = sh.T;
         a.T[prev] = T;
         a.Tinv[prev] = inverse44(T);
         a.numFilt[prev] = (int)cur;
     }
-    __syncthreads();
-    const unsigned cur = sCur;
     if (tid < (unsigned)MAX_FILT) {
         if (tid < cur) { a.fidx[prev * MAX_FILT + tid] = make_uint2(sel[tid].ix, sel[tid].iy); a.fdist[prev * MAX_FILT + tid] = sel[tid].dist; }
         else { a.fidx[prev * MAX_FILT + tid] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); a.fdist[prev * MAX_FILT + tid] = 999.0f; }
