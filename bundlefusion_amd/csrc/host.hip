@@ -890,6 +890,8 @@ struct bf_online_bundler {
     bool bUseSolve = true;
     uint32_t totalNumOptLocalFrames = 0;
     uint32_t numLocalSolves = 0, numGlobalSolves = 0;
+    // processInput in flight (between _begin and _end)
+    int pendPhase = 0; uint32_t pendFrame = 0, pendCur = 0, pendNum = 0; bool pendLastLocal = false, pendMatch = false;
     bool isLastLocalFrame(uint32_t curFrame) const { return curFrame >= submapSize && (curFrame % submapSize) == 0; }
     void invalidateImages(uint32_t s, uint32_t e = 0xFFFFFFFFu) { if (e == 0xFFFFFFFFu) invalidImagesList[s] = 0; else for (uint32_t i = s; i < e; ++i) invalidImagesList[i] = 0; }
     void validateImages(uint32_t s) { invalidImagesList[s] = 1; }
@@ -1102,11 +1104,16 @@ int bf_online_bundler_set_stream(bf_online_bundler* ob, void* s) {
     return BF_OK;
 }
 
-int bf_online_bundler_process_input(bf_online_bundler* ob) {                                         // :167-227
+// processInput (:167-227) in two halves: _begin enqueues everything up to the frame read-back, _end fetches the result and
+// finishes the host logic.  A caller may enqueue independent work (the re-integration of old frames on another stream)
+// between the two; bf_online_bundler_process_input is simply begin + end.
+int bf_online_bundler_process_input_begin(bf_online_bundler* ob) {
     BF_REQUIRE(ob, "null bundler");
+    BF_REQUIRE(ob->pendPhase == 0, "processInput already in flight");
     uint32_t curFrame;
     BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &curFrame));
     const bool bIsLastLocal = ob->isLastLocalFrame(curFrame);
+    ob->pendFrame = curFrame; ob->pendLastLocal = bIsLastLocal; ob->pendMatch = false;
     if (curFrame > 0 && ob->lastFrameProcessed == (int)curFrame) {                 // sequence has ended
         if (ob->numFramesPastEnd == 0 && ob->localToSolve == -1) { if (!bIsLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, true)); }
         const uint32_t numSolveFramesBeforeExit = ob->gas.s_numSolveFramesBeforeExit;
@@ -1121,6 +1128,7 @@ int bf_online_bundler_process_input(bf_online_bundler* ob) {                    
             if (ob->numFramesPastEnd == numSolveFramesBeforeExit + 1) ob->bUseSolve = false;       // "stopping solve"
         }
         ob->numFramesPastEnd++;
+        ob->pendPhase = 2;                                                          // nothing to read back
         return BF_OK;
     }
     // getCurrentFrame (:106-116): luminance at SIFT resolution straight from the ingest buffer
@@ -1138,24 +1146,44 @@ int bf_online_bundler_process_input(bf_online_bundler* ob) {                    
     if (curLocalFrame > 0) {
         // matchAndFilter + computeCurrentSiftTransform (:118-132) with ONE read-back: the pose kernel is enqueued before the frame
         // result is fetched (it writes nothing when no pair survived the filters, which is exactly the "invalid" case)
-        uint32_t cur, start, num, last;
-        BF_TRY(matchAndFilterEnqueue(ob->local, cur, start, num));
+        uint32_t start;
+        BF_TRY(matchAndFilterEnqueue(ob->local, ob->pendCur, start, ob->pendNum));
         const float* d_Tinv = nullptr; const int32_t* d_nf = nullptr;
         BF_TRY(bf_bundler_get_current_sift_transforms_gpu(ob->local, &d_Tinv));
         BF_TRY(bf_bundler_get_num_filt_matches_gpu(ob->local, &d_nf));
         BF_TRY(bf_compute_sift_transform(d_Tinv, d_nf, (const float*)ob->d_completeTrajectory, ob->lastValidCompleteTransform, (float*)ob->d_siftTrajectory, curFrame,
                                          curLocalFrame, (float*)(ob->d_currIntegrateTransform + curFrame), ob->stream));
         BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT, ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
-        BF_TRY(matchAndFilterFinish(ob->local, cur, num, &last));
+        ob->pendMatch = true;
+    }
+    ob->pendPhase = 1;
+    return BF_OK;
+}
+
+int bf_online_bundler_process_input_end(bf_online_bundler* ob) {
+    BF_REQUIRE(ob, "null bundler");
+    BF_REQUIRE(ob->pendPhase != 0, "process_input_end without process_input_begin");
+    const int phase = ob->pendPhase;
+    ob->pendPhase = 0;
+    if (phase == 2) return BF_OK;
+    const uint32_t curFrame = ob->pendFrame;
+    if (ob->pendMatch) {
+        uint32_t last;
+        BF_TRY(matchAndFilterFinish(ob->local, ob->pendCur, ob->pendNum, &last));
         ob->bLastFrameValid = last != 0xFFFFFFFFu;
         if (!ob->bLastFrameValid) {
             ob->currIntegrateTransform[curFrame] = minfM();
             BF_HIP_TRY(hipMemcpyAsync(ob->d_siftTrajectory + curFrame, ob->d_siftTrajectory + curFrame - 1, sizeof(m44), hipMemcpyDeviceToDevice, ob->stream));
         } else ob->currIntegrateTransform[curFrame] = *ob->h_pinT;
     }
-    if (bIsLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, false));
+    if (ob->pendLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, false));
     ob->lastFrameProcessed = (int)curFrame;
     return BF_OK;
+}
+
+int bf_online_bundler_process_input(bf_online_bundler* ob) {                                         // :167-227
+    BF_TRY(bf_online_bundler_process_input_begin(ob));
+    return bf_online_bundler_process_input_end(ob);
 }
 
 int bf_online_bundler_process(bf_online_bundler* ob, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
@@ -1201,10 +1229,14 @@ struct bf_pipeline {
     bf_global_app_state gas; bf_global_bundling_state gbs; bf_rgbd_sensor_desc sensor;
     bf_image_manager* im = nullptr; bf_online_bundler* ob = nullptr; bf_scene* scene = nullptr;
     bf_depth_camera_params cam;
-    hipStream_t stream = nullptr;
+    // Two HIP streams: the bundling stream carries ingest, SIFT, matching, filters and the solves; the volume stream carries every
+    // TSDF operator.  Re-integration of old frames depends only on host-side lists and on frames ingested earlier, so it runs
+    // concurrently with the current frame's feature pipeline; integration of the current frame waits for its ingest (evIngest).
+    hipStream_t sBundle = nullptr, sVolume = nullptr;
+    hipEvent_t evIngest = nullptr;
     uint32_t numIntegrate = 0, numDeIntegrate = 0;
     bool timings = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bf_frame_timing last;
 };
 
@@ -1250,21 +1282,33 @@ int plReintegrate(bf_pipeline* p) {                                             
 }
 
 int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool device, bool haveInput, int* gotFrame) {    // :966-1095 (serial branch)
-    hipStream_t st = p->stream;
-    if (p->timings) (void)hipEventRecord(p->ev[0], st);
+    hipStream_t sa = p->sBundle, sv = p->sVolume;
+    const bool tm = p->timings;
+    // ---- read input (bundling stream)
+    if (tm) (void)hipEventRecord(p->ev[0], sa);
     int got = 0;
     if (haveInput) BF_TRY(device ? bf_image_manager_process_device(p->im, depth, color, &got) : bf_image_manager_process(p->im, depth, color, &got));
-    if (p->timings) (void)hipEventRecord(p->ev[1], st);
-    if (p->im->currFrame > 0) BF_TRY(bf_online_bundler_process_input(p->ob));
-    if (p->timings) (void)hipEventRecord(p->ev[2], st);
+    if (got) BF_HIP_TRY(hipEventRecord(p->evIngest, sa));
+    if (tm) (void)hipEventRecord(p->ev[1], sa);
+    // ---- processInput: enqueue (bundling stream) ...
+    const bool haveFrames = p->im->currFrame > 0;
+    if (haveFrames) BF_TRY(bf_online_bundler_process_input_begin(p->ob));
+    // ---- fix old frames (volume stream), concurrently with the feature pipeline
+    if (tm) (void)hipEventRecord(p->ev[4], sv);
     BF_TRY(plReintegrate(p));
-    if (p->timings) (void)hipEventRecord(p->ev[3], st);
+    if (tm) (void)hipEventRecord(p->ev[5], sv);
+    // ---- ... and its read-back
+    if (haveFrames) BF_TRY(bf_online_bundler_process_input_end(p->ob));
+    if (tm) (void)hipEventRecord(p->ev[2], sa);
+    // ---- reconstruction of the current frame (volume stream, after this frame's ingest)
+    if (tm) (void)hipEventRecord(p->ev[6], sv);
     if (got) {
         float T[16]; uint32_t frameIdx = 0; int lost = 0, valid = 0;
         BF_TRY(bf_online_bundler_get_current_integration_frame(p->ob, T, &frameIdx, &lost, &valid));
         uint32_t cur;
         BF_TRY(bf_image_manager_get_curr_frame_number(p->im, &cur));
         if (valid && p->gas.s_reconstructionEnabled) {
+            BF_HIP_TRY(hipStreamWaitEvent(sv, p->evIngest, 0));
             BF_TRY(plIntegrate(p, frameIdx, T, false));
             BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_INTEGRATED, T, cur));
         } else {
@@ -1272,18 +1316,22 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
             BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_NOT_INTEGRATED_NO_TRANSFORM, inv.e, cur));
         }
     }
-    if (p->timings) (void)hipEventRecord(p->ev[4], st);
-    if (p->im->currFrame > 0)
+    if (tm) (void)hipEventRecord(p->ev[7], sv);
+    // ---- bundling optimisation (bundling stream)
+    if (haveFrames)
         BF_TRY(bf_online_bundler_process(p->ob, p->gbs.s_numLocalNonLinIterations, p->gbs.s_numLocalLinIterations, p->ob->gbs.s_numGlobalNonLinIterations,
                                          p->gbs.s_numGlobalLinIterations));
-    if (p->timings) {
-        (void)hipEventRecord(p->ev[5], st);
-        (void)hipEventSynchronize(p->ev[5]);
-        float ms[5];
-        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]);
+    if (tm) {
+        (void)hipEventRecord(p->ev[3], sa);
+        (void)hipEventSynchronize(p->ev[3]);
+        (void)hipEventSynchronize(p->ev[7]);
         memset(&p->last, 0, sizeof p->last);
-        p->last.timeSensorProcess = ms[0]; p->last.timeSiftDetection = ms[1]; p->last.timeReIntegrate = ms[2]; p->last.timeReconstruct = ms[3]; p->last.timeSolve = ms[4];
-        p->last.timeTotal = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+        (void)hipEventElapsedTime(&p->last.timeSensorProcess, p->ev[0], p->ev[1]);
+        (void)hipEventElapsedTime(&p->last.timeSiftDetection, p->ev[1], p->ev[2]);        // SIFT + cache + match + filters + read-back
+        (void)hipEventElapsedTime(&p->last.timeSolve, p->ev[2], p->ev[3]);
+        (void)hipEventElapsedTime(&p->last.timeReIntegrate, p->ev[4], p->ev[5]);
+        (void)hipEventElapsedTime(&p->last.timeReconstruct, p->ev[6], p->ev[7]);
+        (void)hipEventElapsedTime(&p->last.timeTotal, p->ev[0], p->ev[3]);
     }
     if (gotFrame) *gotFrame = got;
     return BF_OK;
@@ -1317,6 +1365,13 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
     p->cam.m_sensorDepthWorldMin = gas->s_renderDepthMin; p->cam.m_sensorDepthWorldMax = gas->s_renderDepthMax;      // DepthSensing.cpp:636-643
     p->cam.m_imageWidth = gas->s_integrationWidth; p->cam.m_imageHeight = gas->s_integrationHeight;
     for (auto& e : p->ev) BF_HIP_TRY(hipEventCreate(&e));
+    BF_HIP_TRY(hipEventCreateWithFlags(&p->evIngest, hipEventDisableTiming));
+    BF_HIP_TRY(hipDeviceSynchronize());                                  // creation-time work was issued on the null stream
+    BF_HIP_TRY(hipStreamCreateWithFlags(&p->sBundle, hipStreamNonBlocking));
+    BF_HIP_TRY(hipStreamCreateWithFlags(&p->sVolume, hipStreamNonBlocking));
+    BF_TRY(bf_image_manager_set_stream(p->im, p->sBundle));
+    BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
+    BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     *out = p;
     return BF_OK;
 }
@@ -1326,6 +1381,9 @@ int bf_pipeline_destroy(bf_pipeline* p) {
     (void)hipDeviceSynchronize();
     bf_online_bundler_destroy(p->ob); bf_image_manager_destroy(p->im); bf_scene_destroy(p->scene);
     for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+    if (p->evIngest) (void)hipEventDestroy(p->evIngest);
+    if (p->sBundle) (void)hipStreamDestroy(p->sBundle);
+    if (p->sVolume) (void)hipStreamDestroy(p->sVolume);
     delete p;
     return BF_OK;
 }
@@ -1344,7 +1402,12 @@ int bf_pipeline_process_end_of_sequence(bf_pipeline* p, uint32_t* numActiveOpera
     if (numActiveOperations) BF_TRY(bf_trajectory_manager_get_num_active_operations(p->ob->tm, numActiveOperations));
     return BF_OK;
 }
-int bf_pipeline_synchronize(bf_pipeline* p) { BF_REQUIRE(p, "null pipeline"); BF_HIP_TRY(hipStreamSynchronize(p->stream)); return BF_OK; }
+int bf_pipeline_synchronize(bf_pipeline* p) {
+    BF_REQUIRE(p, "null pipeline");
+    BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
+    BF_HIP_TRY(hipStreamSynchronize(p->sVolume));
+    return BF_OK;
+}
 int bf_pipeline_get_scene(bf_pipeline* p, bf_scene** out) { BF_REQUIRE(p && out, "null argument"); *out = p->scene; return BF_OK; }
 int bf_pipeline_get_image_manager(bf_pipeline* p, bf_image_manager** out) { BF_REQUIRE(p && out, "null argument"); *out = p->im; return BF_OK; }
 int bf_pipeline_get_online_bundler(bf_pipeline* p, bf_online_bundler** out) { BF_REQUIRE(p && out, "null argument"); *out = p->ob; return BF_OK; }

@@ -187,6 +187,10 @@ BF_API int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_
 BF_API int bf_online_bundler_destroy(bf_online_bundler* ob);
 BF_API int bf_online_bundler_set_stream(bf_online_bundler* ob, void* hip_stream);
 BF_API int bf_online_bundler_process_input(bf_online_bundler* ob);                               /* processInput :167-227 */
+/* the same in two halves: _begin enqueues all device work of processInput, _end performs its single read-back and the host
+ * logic; independent work (e.g. re-integration on another stream) may be enqueued in between */
+BF_API int bf_online_bundler_process_input_begin(bf_online_bundler* ob);
+BF_API int bf_online_bundler_process_input_end(bf_online_bundler* ob);
 BF_API int bf_online_bundler_process(bf_online_bundler* ob, uint32_t numNonLinItersLocal, uint32_t numLinItersLocal,
                                      uint32_t numNonLinItersGlobal, uint32_t numLinItersGlobal);  /* process :410-416 */
 /* getCurrentIntegrationFrame(siftTransform, frameIdx, bGlobalTrackingLost) -> valid  :229-240 */
