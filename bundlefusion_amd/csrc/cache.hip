@@ -6,7 +6,7 @@
 // W x H = 80 x 60 point samples.  Here ONE kernel evaluates exactly those samples: a thread per
 // cached pixel computes the filtered depth at its sample position and its 4-neighbourhood (the only
 // filtered depths the normal at that sample depends on), i.e. 125 taps instead of a 640x480x25
-// sweep (~12x less traffic, 1 launch).  A second single-workgroup kernel does the intensity chain
+// sweep (~12x less traffic, 1 launch).  A second kernel (one workgroup per 16x12 tile, chain evaluated in LDS on tile + halo) does the intensity chain
 // (sample -> 11x11 Gaussian -> Sobel).  Per-pixel arithmetic and summation order are the reference's
 // (taps summed x-outer / y-inner), so results are bit-identical to the CPU restatement.
 #include <hip/hip_runtime.h>
@@ -104,48 +104,65 @@ __global__ __launch_bounds__(256) void k_cache_geometry(CacheGeom g, Taps t, con
     reinterpret_cast<uchar4*>(f.d_normalsDownsampledUCHAR4)[idx] = nu;
 }
 
-// resampleToIntensity (:224) -> gaussFilterIntensity (:811) -> computeIntensityDerivatives (:260);
-// one workgroup, phases separated by barriers (global scratch is private to this workgroup).
-__global__ __launch_bounds__(1024) void k_cache_intensity(CacheGeom g, Taps t, int useFilter, const uchar4* __restrict__ color,
-                                                         float* scratch, bf_cached_frame f) {
-    const uint32_t n = g.W * g.H;
-    float* inten = useFilter ? scratch : f.d_intensityDownsampled;
-    for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
-        const uint32_t x = idx % g.W, y = idx / g.W;
-        uint32_t xi, yi;
-        sampleIdx(x, y, g.W, g.H, g.cw, g.ch, xi, yi);
-        if (xi < g.cw && yi < g.ch) {
-            const uchar4 c = color[(size_t)yi * g.cw + xi];
-            inten[idx] = (0.299f * (float)c.x + 0.587f * (float)c.y + 0.114f * (float)c.z) / 255.0f;
+// resampleToIntensity (:224) -> gaussFilterIntensity (:811) -> computeIntensityDerivatives (:260) for one IT_W x IT_H tile of
+// the W x H cache image per workgroup.  The chain is evaluated in LDS on the tile plus its halo (Sobel needs 1 ring of
+// filtered values, the filter needs r rings of samples), so the tiles are independent and no pass over global memory
+// separates the three operators; every value is produced by the same tap order as a whole-image pass.
+constexpr int IT_W = 16, IT_H = 12;
+__global__ __launch_bounds__(256) void k_cache_intensity(CacheGeom g, Taps t, int useFilter, const uchar4* __restrict__ color, bf_cached_frame f) {
+    constexpr int MAXS = (IT_W + 2 * (MAX_R + 1)) * (IT_H + 2 * (MAX_R + 1));
+    __shared__ float sSamp[MAXS];
+    __shared__ float sFilt[(IT_W + 2) * (IT_H + 2)];
+    const int W = (int)g.W, H = (int)g.H;
+    const int r = useFilter ? t.r : 0, nt = 2 * r + 1;
+    const int x0 = (int)blockIdx.x * IT_W, y0 = (int)blockIdx.y * IT_H;
+    const int sw = IT_W + 2 * (r + 1), sh = IT_H + 2 * (r + 1);
+    for (int i = (int)threadIdx.x; i < sw * sh; i += 256) {                    // samples (x0-r-1 .. ) of the point-sampled intensity
+        const int x = x0 - r - 1 + i % sw, y = y0 - r - 1 + i / sw;
+        float v = 0.0f;
+        if (x >= 0 && y >= 0 && x < W && y < H) {
+            uint32_t xi, yi;
+            sampleIdx((uint32_t)x, (uint32_t)y, g.W, g.H, g.cw, g.ch, xi, yi);
+            if (xi < g.cw && yi < g.ch) {
+                const uchar4 c = color[(size_t)yi * g.cw + xi];
+                v = (0.299f * (float)c.x + 0.587f * (float)c.y + 0.114f * (float)c.z) / 255.0f;
+            }
         }
+        sSamp[i] = v;
     }
     __syncthreads();
-    if (useFilter) {
-        const int r = t.r, nt = 2 * r + 1;
-        for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
-            const int x = (int)(idx % g.W), y = (int)(idx / g.W);
-            float sum = 0.0f, sumW = 0.0f;
-            for (int m = x - r; m <= x + r; ++m)
-                for (int k = y - r; k <= y + r; ++k)
-                    if (m >= 0 && k >= 0 && m < (int)g.W && k < (int)g.H) {
-                        const float w = t.w[(m - x + r) * nt + (k - y + r)];
-                        sumW += w;
-                        sum += w * scratch[k * g.W + m];
-                    }
-            if (sumW > 0.0f) f.d_intensityDownsampled[idx] = sum / sumW;
+    const int fw = IT_W + 2, fh = IT_H + 2;
+    for (int i = (int)threadIdx.x; i < fw * fh; i += 256) {                    // filtered values of the tile + 1 ring
+        const int x = x0 - 1 + i % fw, y = y0 - 1 + i / fw;
+        float v = 0.0f;
+        if (x >= 0 && y >= 0 && x < W && y < H) {
+            if (useFilter) {
+                float sum = 0.0f, sumW = 0.0f;
+                for (int m = x - r; m <= x + r; ++m)
+                    for (int k = y - r; k <= y + r; ++k)
+                        if (m >= 0 && k >= 0 && m < W && k < H) {
+                            const float w = t.w[(m - x + r) * nt + (k - y + r)];
+                            sumW += w;
+                            sum += w * sSamp[(k - (y0 - r - 1)) * sw + (m - (x0 - r - 1))];
+                        }
+                v = sum / sumW;                                               // sumW > 0: the centre tap is always inside
+            } else v = sSamp[(y - (y0 - r - 1)) * sw + (x - (x0 - r - 1))];
+            if (x >= x0 && x < x0 + IT_W && y >= y0 && y < y0 + IT_H) f.d_intensityDownsampled[y * W + x] = v;
         }
-        __syncthreads();
+        sFilt[i] = v;
     }
-    const float* in = f.d_intensityDownsampled;
+    __syncthreads();
     float2* out = reinterpret_cast<float2*>(f.d_intensityDerivsDownsampled);
-    const uint32_t W = g.W, H = g.H;
-    for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
-        const uint32_t x = idx % W, y = idx / W;
+    for (int i = (int)threadIdx.x; i < IT_W * IT_H; i += 256) {
+        const int x = x0 + i % IT_W, y = y0 + i / IT_W;
+        if (x >= W || y >= H) continue;
         float2 o = make_float2(BF_MINF, BF_MINF);
         if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
-            const float p00 = in[(y - 1) * W + (x - 1)], p01 = in[y * W + (x - 1)], p02 = in[(y + 1) * W + (x - 1)];
-            const float p10 = in[(y - 1) * W + x], p12 = in[(y + 1) * W + x];
-            const float p20 = in[(y - 1) * W + (x + 1)], p21 = in[y * W + (x + 1)], p22 = in[(y + 1) * W + (x + 1)];
+#define BF_P(dx, dy) sFilt[(y + (dy) - (y0 - 1)) * fw + (x + (dx) - (x0 - 1))]
+            const float p00 = BF_P(-1, -1), p01 = BF_P(-1, 0), p02 = BF_P(-1, 1);
+            const float p10 = BF_P(0, -1), p12 = BF_P(0, 1);
+            const float p20 = BF_P(1, -1), p21 = BF_P(1, 0), p22 = BF_P(1, 1);
+#undef BF_P
             if (!(p00 == BF_MINF || p01 == BF_MINF || p02 == BF_MINF || p10 == BF_MINF || p12 == BF_MINF || p20 == BF_MINF ||
                   p21 == BF_MINF || p22 == BF_MINF)) {
                 float u = (-1.0f) * p00 + (1.0f) * p20 + (-2.0f) * p01 + (2.0f) * p21 + (-1.0f) * p02 + (1.0f) * p22;
@@ -155,7 +172,7 @@ __global__ __launch_bounds__(1024) void k_cache_intensity(CacheGeom g, Taps t, i
                 o = make_float2(u, v);
             }
         }
-        out[idx] = o;
+        out[y * W + x] = o;
     }
 }
 
@@ -248,8 +265,8 @@ int bf_cache_store_frame(bf_cache* c, const float* d_depth, uint32_t dw, uint32_
     const bf_cached_frame f = c->frames[c->current];
     const uint32_t n = c->W * c->H;
     hipLaunchKernelGGL(k_cache_geometry, dim3(div_up(n, 256)), dim3(256), 0, c->stream, g, c->tapsDepth, d_depth, f);
-    hipLaunchKernelGGL(k_cache_intensity, dim3(1), dim3(1024), 0, c->stream, g, c->tapsIntensity, (int)(c->sigmaIntensity > 0.0f),
-                       reinterpret_cast<const uchar4*>(d_color), c->d_scratch, f);
+    hipLaunchKernelGGL(k_cache_intensity, dim3(div_up(c->W, IT_W), div_up(c->H, IT_H)), dim3(256), 0, c->stream, g, c->tapsIntensity,
+                       (int)(c->sigmaIntensity > 0.0f), reinterpret_cast<const uchar4*>(d_color), f);
     BF_HIP_TRY(hipGetLastError());
     c->current++;
     return BF_OK;

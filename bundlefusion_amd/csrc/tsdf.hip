@@ -594,7 +594,7 @@ BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float&
         r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
         r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
         r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
-        nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
+        nC = (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;      // r in [0, 254.5] after the clamps, never NaN
         nSdf = (sdf * 1.0f + oSdf * oW) / (1.0f + oW);
         nW = fminf(f.weightMax, 1.0f + oW);
     } else {
@@ -604,7 +604,7 @@ BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float&
         r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
         r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
         r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
-        nC = (uint32_t)f2i(r0) | ((uint32_t)f2i(r1) << 8) | ((uint32_t)f2i(r2) << 16) | 0xFF000000u;
+        nC = (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;
         nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
         nW = fmaxf(0.0f, oW - 1.0f);
         if (nW <= 0.001f) { nSdf = 0.0f; nC = 0u; nW = 0.0f; }
