@@ -119,6 +119,7 @@ def main():
     bytes_per_launch = (occ_sum * (512 * 24 + 32) + n_ops * W * H * 8) / max(n_launch, 1)
     avg_kernel_s = (kernel_ms / 1e3) / max(n_launch, 1)
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    traffic = pmc_traffic(args, c1["deintegrate"] - c0["deintegrate"], n_launch)
     dbg = sc.debug_hash()
     traj = pipe.integrated_trajectory()
     T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
@@ -156,7 +157,7 @@ def main():
             "roofline": {
                 "kernel": "k_update<integrate> + k_reupdate (fused de-integrate+integrate) — TSDF voxel update",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "launches": n_launch, "avg_launch_us": 1e6 * avg_kernel_s,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": n_occ,
                 "share_of_step_time": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None,
@@ -167,6 +168,21 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, n_fused, n_launch):
+    """HBM bytes per voxel-update launch from the committed PMC passes (profiles/r01_pmc_tsdf_update.json: rocprofv3
+    FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, collected in their own runs of this same command), weighted by the
+    launch mix of THIS run; None when the run is not the configuration the counters were collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_tsdf_update.json")
+    if not os.path.exists(path) or n_launch == 0:
+        return None
+    pmc = json.load(open(path))
+    cfg = pmc["config"]
+    if (cfg["steps"], cfg["warmup"], cfg["voxel"], cfg["buckets"], cfg["blocks"]) != (args.steps, args.warmup, args.voxel, args.buckets, args.blocks) or args.host:
+        return None
+    n_plain = n_launch - n_fused
+    return (n_fused * pmc["k_reupdate"]["hbm_bytes_per_launch"] + n_plain * pmc["k_update_integrate"]["hbm_bytes_per_launch"]) / n_launch
 
 
 def cpu_baseline(frames, params, K, W, H):
