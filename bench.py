@@ -119,7 +119,7 @@ def main():
     bytes_per_launch = (occ_sum * (512 * 24 + 32) + n_ops * W * H * 8) / max(n_launch, 1)
     avg_kernel_s = (kernel_ms / 1e3) / max(n_launch, 1)
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-    traffic = pmc_traffic(args, c1["deintegrate"] - c0["deintegrate"], n_launch)
+    traffic = pmc_traffic(args, n_ops - n_launch, n_launch)      # ops = plain + 2*fused, launches = plain + fused
     dbg = sc.debug_hash()
     traj = pipe.integrated_trajectory()
     T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
