@@ -163,7 +163,7 @@ def main():
                 "share_of_step_time": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], params, K, W, H)
         print(json.dumps(out))
     if world > 1:
