@@ -196,3 +196,53 @@ def test_short_dropout_inside_a_chunk(gpu, oracle):
     c = gp.counters()
     assert c["integrate"] == sum(1 for k, _, _ in op.integrate_ops if k == "in") and c["deintegrate"] == sum(1 for k, _, _ in op.integrate_ops if k == "de")
     assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves == 3
+
+
+def test_global_optimize_removes_outlier_pair_and_orphan_frame(gpu, oracle):
+    """Bundler::optimize with bRemoveMaxResidual on a hand-built global problem (SBA.cpp:129-204): the pair carrying the largest
+    residual is invalidated, a key frame without any correspondence loses its valid flag (CheckForInvalidFramesCU), the rest is
+    solved; C ABI (bf_bundler_optimize) vs the oracle restatement."""
+    import ctypes as C
+    import torch
+    from tests import bundle_synth as bs
+    from tests.oracle_pipeline import OBundler
+    from bundlefusion_amd.capi import lib, check, _h2d, _d2h
+    Kd = synth.intrinsics(W, H)
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gas, gbs = _params(max_images=8)
+    gp = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    gb = gp.bundler("global")
+    n = 7
+    corr, T_gt, T_init = bs.sparse_problem(n_images=n, pair_prob=1.0, seed=11, outlier_pair=(3, 4))
+    keep = (corr["imgIdx_i"] != 6) & (corr["imgIdx_j"] != 6)                 # image 6: no correspondences at all
+    corr = corr[keep]
+    h = C.c_void_p(); check(lib.bf_bundler_get_sift_manager(gb, C.byref(h)))
+    mgr = gpu.capi.SiftManager.__new__(gpu.capi.SiftManager); mgr._h = h; mgr.max_keys = 1024; mgr.max_images = 8
+    for i in range(n):
+        mgr.add_image_host(np.zeros((4, 4), np.float32), np.zeros((4, 128), np.uint8))
+        mgr.set_valid_image(i, 1)
+    mgr.update_gpu_valid_images()
+    mgr.set_global_correspondences(corr)
+    dT = C.c_void_p(); check(lib.bf_bundler_get_trajectory_gpu(gb, C.byref(dT)))
+    _h2d(dT.value, T_init)
+    removed = C.c_int(); valid = C.c_int()
+    check(lib.bf_bundler_optimize(gb, 3, 150, 0, 1, 0, C.byref(removed), C.byref(valid)))
+    gvalid = mgr.valid_images(n).tolist()
+    gcorr, _ = mgr.download_global_correspondences()
+    gT = _d2h(dT.value, 64 * n).view(np.float32).reshape(n, 4, 4)
+    mgr._h = C.c_void_p()
+    # oracle
+    gas2, gbs2 = _params(max_images=8)
+    gas2._depthW, gas2._depthH = W, H
+    ob = OBundler(8, 1024, oracle.inverse44(K), K, False, gas2, gbs2)
+    for i in range(n):
+        ob._add_image(np.zeros((4, 4), np.float32), np.zeros((4, 128), np.uint8)); ob.valid[i] = 1
+    ob.corr = corr.copy(); ob.corr_keys = np.zeros((len(corr), 2), np.uint32)
+    ob.trajectory[:n] = T_init
+    ok, orem = ob.optimize(3, 150, False, True)
+    assert bool(removed.value) == orem is True and bool(valid.value) == ok
+    sel = (corr["imgIdx_i"] == 3) & (corr["imgIdx_j"] == 4)
+    assert (gcorr["imgIdx_i"][sel] == 0xFFFFFFFF).all() and (gcorr["imgIdx_i"][~sel] != 0xFFFFFFFF).all()
+    assert np.array_equal(gcorr.view(np.uint8), ob.corr.view(np.uint8))
+    assert gvalid == ob.valid[:n] == [1, 1, 1, 1, 1, 1, 0]
+    assert np.abs(gT[:6] - ob.trajectory[:6]).max() < 2e-4
