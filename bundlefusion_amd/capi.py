@@ -169,6 +169,9 @@ class SceneRepHashSDF:
         d = self._data(depth, color)
         check(lib.bf_scene_deintegrate(self._h, mat16(cam_to_world), C.byref(d), C.byref(cam), None))
 
+    def set_shard(self, rank, world):
+        check(lib.bf_scene_set_shard(self._h, rank, world))
+
     def reintegrate(self, old_cam_to_world, new_cam_to_world, depth, color, cam):
         """fused deintegrate(old) + integrate(new) of the same frame"""
         data = self._data(depth, color)
@@ -781,6 +784,9 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+    def set_volume_shard(self, rank, world):
+        check(lib.bf_pipeline_set_volume_shard(self._h, rank, world))
 
     def process_frame(self, depth, color):
         """depth float32 (H,W), color uint8 (H,W,4): host numpy arrays (PCIe path) or torch cuda tensors (HBM-resident path)."""

@@ -1388,6 +1388,11 @@ int bf_pipeline_destroy(bf_pipeline* p) {
     return BF_OK;
 }
 
+int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world) {
+    BF_REQUIRE(p, "null pipeline");
+    return bf_scene_set_shard(p->scene, rank, world);
+}
+
 int bf_pipeline_process_frame(bf_pipeline* p, const float* h_depth, const uint8_t* h_color, int* gotFrame) {
     BF_REQUIRE(p, "null pipeline");
     return plFrame(p, h_depth, h_color, false, true, gotFrame);

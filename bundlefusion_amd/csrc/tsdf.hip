@@ -76,6 +76,7 @@ struct Frame {          // per-call constants (kernarg => scalar loads)
     float maxIntegrationDistance;
     float truncScale;
     float truncation;
+    uint32_t shardLo, shardHi;       // owned home-bucket range (whole table when the volume is not sharded)
     float weightMax;
 };
 
@@ -189,6 +190,7 @@ __global__ void k_reset(Dev d, uint32_t numSDFBlocks, uint32_t numEntries, uint3
 BF_DEV void emitCandidate(const Dev& d, const Frame& f, i3 b) {
     if (!keyable(b)) return;
     const uint32_t h = hashPos(f.numBuckets, b);
+    if (h < f.shardLo || h >= f.shardHi) return;      // hash-bucket sharding: this volume owns the home buckets [shardLo, shardHi)
     if (blockPresent(d, f, b, h)) return;
     const uint64_t key = packKey(b);
     // 64-bit CAS claim in the open-addressing de-dup set (linear probing)
@@ -796,6 +798,7 @@ struct bf_scene {
     uint32_t dedupeSize = 0;
     uint32_t gridCompact = 0, gridUpdate = 0;
     int32_t* d_hashDecision = nullptr;
+    uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
     bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
     // optional HIP-event timing of the voxel-update kernel
@@ -830,6 +833,7 @@ Frame makeFrame(const bf_scene* s) {
     f.truncScale = s->params.m_truncScale;
     f.truncation = s->params.m_truncation;
     f.weightMax = (float)s->params.m_integrationWeightMax;
+    f.shardLo = s->shardLo; f.shardHi = s->shardHi;
     return f;
 }
 
@@ -993,6 +997,19 @@ int bf_scene_deintegrate(bf_scene* s, const float T[16], const bf_depth_camera_d
     if ((rc = launchCompactify(s))) return rc;
     if ((rc = launchUpdate<true>(s, data))) return rc;
     s->numIntegrated--;
+    return BF_OK;
+}
+
+// Hash-bucket sharding: this volume keeps only blocks whose home bucket lies in
+// [rank * numBuckets / world, (rank + 1) * numBuckets / world).  Every shard sees every frame and pose; allocation inserts the
+// owned keys only, so frustum lists, voxel updates and garbage collection shrink to the shard without further changes and
+// without any exchange between shards.  The union of the shards' (key -> voxels) maps is the unsharded volume.
+int bf_scene_set_shard(bf_scene* s, uint32_t rank, uint32_t world) {
+    BF_REQUIRE(s && world >= 1 && rank < world, "bad shard");
+    BF_REQUIRE(s->numIntegrated == 0, "set the shard before the first integration");
+    const uint64_t nb = s->params.m_hashNumBuckets;
+    s->shardLo = (uint32_t)(nb * rank / world);
+    s->shardHi = (uint32_t)(nb * (rank + 1) / world);
     return BF_OK;
 }
 

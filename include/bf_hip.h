@@ -142,6 +142,10 @@ BF_API int bf_scene_integrate(bf_scene* s, const float cam_to_world[16],
 BF_API int bf_scene_deintegrate(bf_scene* s, const float cam_to_world[16],
                                 const bf_depth_camera_data* data,
                                 const bf_depth_camera_params* cam, const uint32_t* d_bitMask);
+/* Multi-GPU hash-bucket sharding (one process per GPU): the volume owns the home buckets
+ * [rank*numBuckets/world, (rank+1)*numBuckets/world) and allocates / integrates / collects only blocks hashing there.
+ * Call before the first integrate; every shard is fed every frame and pose, there is no exchange between shards. */
+BF_API int bf_scene_set_shard(bf_scene* s, uint32_t rank, uint32_t world);
 /* MI355X addition: deIntegrate(oldT) + integrate(newT) of the same frame (DepthSensing.cpp:882-889) as ONE pass over
  * the union of the two frustum lists — each touched voxel is read and written once.  Bit-identical to the two calls. */
 BF_API int bf_scene_reintegrate(bf_scene* s, const float old_cam_to_world[16], const float new_cam_to_world[16],

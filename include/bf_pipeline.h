@@ -226,6 +226,9 @@ typedef struct bf_frame_timing {      /* TimingLog::FrameTiming, TimingLog.h:9-2
 BF_API int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_state* gbs, const bf_rgbd_sensor_desc* sensor,
                               bf_pipeline** out);
 BF_API int bf_pipeline_destroy(bf_pipeline* p);
+/* Multi-GPU mode "volume shard": every rank runs the (bit-deterministic) bundling on the whole stream and integrates only
+ * its hash-bucket shard of the volume (bf_scene_set_shard).  Call before the first frame. */
+BF_API int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world);
 /* one iteration of the frame loop with a new sensor frame (host or device resident) */
 BF_API int bf_pipeline_process_frame(bf_pipeline* p, const float* h_depth, const uint8_t* h_colorRGBX, int* gotFrame);
 BF_API int bf_pipeline_process_frame_device(bf_pipeline* p, const float* d_depth, const uint8_t* d_colorRGBX, int* gotFrame);

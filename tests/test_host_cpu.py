@@ -111,7 +111,8 @@ _WORKER = '''
 import os, sys, time
 sys.path.insert(0, %r)
 import torch.distributed as dist
-from bundlefusion_amd.shard import segment, max_over_ranks, whole_job_rate
+import torch
+from bundlefusion_amd.shard import segment, max_over_ranks, whole_job_rate, same_over_ranks
 dist.init_process_group("gloo")
 r, w = dist.get_rank(), dist.get_world_size()
 first, last = segment(r, w, 20)
@@ -119,7 +120,9 @@ elapsed = 0.5 + r                      # rank 1 is the slow one
 dist.barrier()
 mx = max_over_ranks(elapsed)
 rate = whole_job_rate(last - first, elapsed)
-print("RESULT", r, first, last, mx, rate, flush=True)
+same = same_over_ranks(torch.arange(12, dtype=torch.float32).reshape(3, 4) * 0.37)
+diff = same_over_ranks(torch.full((4,), 1.0 + 1e-7 * r))
+print("RESULT", r, first, last, mx, rate, int(same), int(diff), flush=True)
 dist.destroy_process_group()
 '''
 
@@ -136,6 +139,7 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert [(int(r[1]), int(r[2])) for r in rows] == [(0, 20), (20, 40)]
     assert all(abs(float(r[3]) - 1.5) < 1e-9 for r in rows)                 # MAX over ranks
     assert all(abs(float(r[4]) - 2 * 20 / 1.5) < 1e-9 for r in rows)        # whole-job units / slowest rank
+    assert all(r[5] == "1" and r[6] == "0" for r in rows)                   # bit-identical tensors pass, a 1-ulp difference is caught
 
 
 def test_cpp_header_classes_compile_and_link(built, tmp_path):

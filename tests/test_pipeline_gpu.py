@@ -246,3 +246,36 @@ def test_global_optimize_removes_outlier_pair_and_orphan_frame(gpu, oracle):
     assert np.array_equal(gcorr.view(np.uint8), ob.corr.view(np.uint8))
     assert gvalid == ob.valid[:n] == [1, 1, 1, 1, 1, 1, 0]
     assert np.abs(gT[:6] - ob.trajectory[:6]).max() < 2e-4
+
+
+def test_volume_shard_mode_equals_single_volume(gpu, oracle):
+    """Multi-GPU mode 'volume-shard' emulated on one GPU: two pipelines fed the same stream, each owning half of the hash-bucket
+    range, against the unsharded pipeline — identical trajectories (replicated bundling is deterministic, no pose exchange needed)
+    and the union of the two volume shards is the single volume, bit for bit."""
+    import torch
+    from bundlefusion_amd.capi import FREE_ENTRY, VOX_PER_BLOCK
+    n = 24
+    src = synth.render_frames(range(n))
+    Kd = src[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in src]
+    runs = []
+    for shard in (None, (0, 2), (1, 2)):
+        gas, gbs = _params()
+        p = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+        if shard:
+            p.set_volume_shard(*shard)
+        for d, c in dev:
+            assert p.process_frame(d, c)
+        for _ in range(3):
+            p.process_end_of_sequence()
+        p.synchronize()
+        gh, gheap, gcnt, gvox = p.scene().download()
+        occ = gh[gh["ptr"] != FREE_ENTRY]
+        blocks = {tuple(int(v) for v in e["pos"]): gvox[int(e["ptr"]):int(e["ptr"]) + VOX_PER_BLOCK].tobytes() for e in occ}
+        runs.append((p.integrated_trajectory().copy(), p.counters(), blocks))
+    (t0, c0, b0), (t1, c1, b1), (t2, c2, b2) = runs
+    assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(t0.view(np.uint32), t2.view(np.uint32))
+    assert c0 == c1 == c2 and c0["deintegrate"] > 5
+    assert not (b1.keys() & b2.keys()) and (b1.keys() | b2.keys()) == b0.keys() and len(b1) > 50 and len(b2) > 50
+    assert all((b1.get(k) or b2.get(k)) == v for k, v in b0.items())

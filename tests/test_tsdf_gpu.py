@@ -213,3 +213,47 @@ def test_config1_full_size_properties(gpu, oracle):
     assert gcnt + 1 == p.m_numSDFBlocks and np.all(gh["ptr"] == FREE_ENTRY)
     assert not gvox.view(np.uint8).any()
     assert sorted(gheap.tolist()) == list(range(p.m_numSDFBlocks))
+
+
+def test_hash_bucket_shards_partition_the_volume(gpu, oracle):
+    """G volumes, each owning a contiguous range of home buckets, fed the same operation sequence (integrate,
+    fused re-integrate, de-integrate, GC).  Their (key -> voxels) maps are disjoint and their union is the unsharded volume,
+    bit for bit; every shard's table passes the structural invariants."""
+    W, H = 160, 120
+    frames = [synth.scene_room(k * 10, W, H) for k in range(5)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=50000, num_sdf_blocks=40000, voxel_size=0.02)
+    G = 4
+    scenes = [gpu.capi.SceneRepHashSDF(p) for _ in range(G + 1)]         # last one: unsharded
+    for r in range(G):
+        scenes[r].set_shard(r, G)
+    dev = [_to_dev(f[0], f[1]) for f in frames]
+    for s in scenes:
+        poses = [f[2].copy() for f in frames]
+        for i in range(5):
+            s.integrate(poses[i], dev[i][0], dev[i][1], cam)
+        T2 = poses[2].copy(); T2[:3, 3] += np.float32(0.04)
+        s.reintegrate(poses[2], T2, dev[2][0], dev[2][1], cam)
+        s.deintegrate(poses[0], dev[0][0], dev[0][1], cam)
+        s.garbage_collect()
+
+    def blocks(s):
+        gh, gheap, gcnt, gvox = s.download()
+        occ = gh[gh["ptr"] != FREE_ENTRY]
+        return {tuple(int(v) for v in e["pos"]): gvox[int(e["ptr"]):int(e["ptr"]) + VOX_PER_BLOCK].tobytes() for e in occ}
+
+    whole = blocks(scenes[G])
+    parts = [blocks(s) for s in scenes[:G]]
+    assert sum(len(b) for b in parts) == len(whole) > 200
+    union = {}
+    for r, b in enumerate(parts):
+        assert len(b) > 0.1 * len(whole) / G                                # every shard got work
+        for key in b:
+            assert oracle.hash_pos(p.m_hashNumBuckets, *key) * G // p.m_hashNumBuckets == r      # ownership = home bucket range
+        union.update(b)
+    assert union.keys() == whole.keys()
+    assert all(union[k] == whole[k] for k in whole)
+    for s in scenes:
+        dbg = s.debug_hash()
+        assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0 and dbg["dropped"] == 0
