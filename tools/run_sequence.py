@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--timings", action="store_true")
     a = ap.parse_args()
     W, H = 640, 480
-    frames = [synth.scene_room(a.first + k * a.stride, W, H) for k in range(a.frames)]
+    frames = synth.render_frames([a.first + k * a.stride for k in range(a.frames)], W, H)
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     gas = bf.capi.default_app_state(); gbs = bf.capi.default_bundling_state()
