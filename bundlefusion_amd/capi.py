@@ -169,6 +169,9 @@ class SceneRepHashSDF:
         d = self._data(depth, color)
         check(lib.bf_scene_deintegrate(self._h, mat16(cam_to_world), C.byref(d), C.byref(cam), None))
 
+    def set_overlap(self, enable=True):
+        check(lib.bf_scene_set_overlap(self._h, int(enable)))
+
     def set_shard(self, rank, world):
         check(lib.bf_scene_set_shard(self._h, rank, world))
 

@@ -9,12 +9,16 @@
 //  * bundling reads the ingest buffers in place (the reference's copyToBundling makes three device-to-device copies per
 //    frame because its bundler lives on a second GPU).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <fstream>
 #include <limits>
 #include <list>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/bf_pipeline.h"
@@ -1154,6 +1158,7 @@ int bf_online_bundler_process_input_begin(bf_online_bundler* ob) {
         BF_TRY(bf_compute_sift_transform(d_Tinv, d_nf, (const float*)ob->d_completeTrajectory, ob->lastValidCompleteTransform, (float*)ob->d_siftTrajectory, curFrame,
                                          curLocalFrame, (float*)(ob->d_currIntegrateTransform + curFrame), ob->stream));
         BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT, ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
+        BF_TRY(bf_siftmgr_prefetch_frame_result(ob->local->mgr));      // the read-back itself is enqueued now; _end only waits for it
         ob->pendMatch = true;
     }
     ob->pendPhase = 1;
@@ -1233,7 +1238,20 @@ struct bf_pipeline {
     // TSDF operator.  Re-integration of old frames depends only on host-side lists and on frames ingested earlier, so it runs
     // concurrently with the current frame's feature pipeline; integration of the current frame waits for its ingest (evIngest).
     hipStream_t sBundle = nullptr, sVolume = nullptr;
-    hipEvent_t evIngest = nullptr;
+    static const int NEV = 8;
+    hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
+    // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
+    // and posts commands; the worker issues the launches, so the ~55 TSDF launches per frame do not serialize with the ~60
+    // launches of the bundling stream on one CPU thread.
+    struct VolCmd { int kind; bf_depth_camera_data data; float T0[16], T1[16]; int waitEv; };   // kind: 0 integrate, 1 de-integrate, 2 fused re-integrate, 3 GC
+    static const size_t MAX_QUEUE = 48;          // back-pressure: the volume thread may lag the bundling thread by a few frames at most
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cvWork, cvIdle;
+    std::deque<VolCmd> queue;
+    bool stop = false, busy = false;
+    int workerError = BF_OK;
+    std::string workerMessage;
     uint32_t numIntegrate = 0, numDeIntegrate = 0;
     bool timings = false;
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1242,13 +1260,61 @@ struct bf_pipeline {
 
 namespace {
 
-int plIntegrate(bf_pipeline* p, uint32_t frameIdx, const float* T, bool de) {                      // DepthSensing.cpp:723-762
+int volExecute(bf_pipeline* p, const bf_pipeline::VolCmd& c) {                                     // DepthSensing.cpp:723-762
+    if (c.kind == 3) return bf_scene_garbage_collect(p->scene);
+    if (c.waitEv >= 0) BF_TRY(bf_scene_wait_event(p->scene, p->evIngest[c.waitEv]));
+    if (c.kind == 0) return bf_scene_integrate(p->scene, c.T0, &c.data, &p->cam, nullptr);
+    if (c.kind == 1) return bf_scene_deintegrate(p->scene, c.T0, &c.data, &p->cam, nullptr);
+    return bf_scene_reintegrate(p->scene, c.T0, c.T1, &c.data, &p->cam);
+}
+
+void volWorker(bf_pipeline* p) {
+    for (;;) {
+        bf_pipeline::VolCmd c;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cvWork.wait(lk, [p] { return p->stop || !p->queue.empty(); });
+            if (p->queue.empty()) return;             // stop requested and drained
+            c = p->queue.front(); p->queue.pop_front();
+            p->busy = true;
+        }
+        const int rc = volExecute(p, c);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (rc != BF_OK && p->workerError == BF_OK) { p->workerError = rc; p->workerMessage = bf_last_error(); }
+            p->busy = false;
+            p->cvIdle.notify_all();
+        }
+    }
+}
+
+int volPost(bf_pipeline* p, int kind, uint32_t frame, const float* T0, const float* T1, int waitEv) {
+    bf_pipeline::VolCmd c;
+    c.kind = kind; c.waitEv = waitEv;
+    c.data.d_depthData = nullptr; c.data.d_colorData = nullptr;
+    if (kind != 3) BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frame, &c.data.d_depthData, &c.data.d_colorData));   // resolved on the calling thread
+    if (T0) memcpy(c.T0, T0, 64);
+    if (T1) memcpy(c.T1, T1, 64);
+    if (p->timings) return volExecute(p, c);        // stage timings are taken with everything issued from the calling thread
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cvIdle.wait(lk, [p] { return p->queue.size() < bf_pipeline::MAX_QUEUE || p->workerError != BF_OK; });
+    if (p->workerError != BF_OK) { set_error("volume worker: %s", p->workerMessage.c_str()); return p->workerError; }
+    p->queue.push_back(c);
+    p->cvWork.notify_one();
+    return BF_OK;
+}
+
+int volDrain(bf_pipeline* p) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cvIdle.wait(lk, [p] { return p->queue.empty() && !p->busy; });
+    if (p->workerError != BF_OK) { set_error("volume worker: %s", p->workerMessage.c_str()); return p->workerError; }
+    return BF_OK;
+}
+
+int plIntegrate(bf_pipeline* p, uint32_t frameIdx, const float* T, bool de, int waitEv = -1) {
     if (!p->gas.s_integrationEnabled) return BF_OK;
-    bf_depth_camera_data data;
-    BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frameIdx, &data.d_depthData, &data.d_colorData));
-    if (de) { p->numDeIntegrate++; return bf_scene_deintegrate(p->scene, T, &data, &p->cam, nullptr); }
-    p->numIntegrate++;
-    return bf_scene_integrate(p->scene, T, &data, &p->cam, nullptr);
+    if (de) p->numDeIntegrate++; else p->numIntegrate++;
+    return volPost(p, de ? 1 : 0, frameIdx, T, nullptr, waitEv);
 }
 
 int plReintegrate(bf_pipeline* p) {                                                                 // :854-902
@@ -1267,9 +1333,7 @@ int plReintegrate(bf_pipeline* p) {                                             
         if (found) {
             if (newT[0] == NINF) continue;          // every candidate was invalidated meanwhile; it is de-integrated on the next list update
             if (p->gas.s_integrationEnabled) {          // deIntegrate(old) + integrate(new) (:885-886) as one fused pass over the volume
-                bf_depth_camera_data data;
-                BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frameIdx, &data.d_depthData, &data.d_colorData));
-                BF_TRY(bf_scene_reintegrate(p->scene, oldT, newT, &data, &p->cam));
+                BF_TRY(volPost(p, 2, frameIdx, oldT, newT, -1));
                 p->numDeIntegrate++; p->numIntegrate++;
             }
             BF_TRY(bf_trajectory_manager_confirm_integration(tm, frameIdx));
@@ -1277,7 +1341,7 @@ int plReintegrate(bf_pipeline* p) {                                             
         }
         break;
     }
-    if (p->gas.s_garbageCollectionEnabled) BF_TRY(bf_scene_garbage_collect(p->scene));
+    if (p->gas.s_garbageCollectionEnabled) BF_TRY(volPost(p, 3, 0, nullptr, nullptr, -1));
     return BF_OK;
 }
 
@@ -1288,12 +1352,13 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (tm) (void)hipEventRecord(p->ev[0], sa);
     int got = 0;
     if (haveInput) BF_TRY(device ? bf_image_manager_process_device(p->im, depth, color, &got) : bf_image_manager_process(p->im, depth, color, &got));
-    if (got) BF_HIP_TRY(hipEventRecord(p->evIngest, sa));
+    const int evSlot = got ? (int)((p->im->currFrame - 1) % bf_pipeline::NEV) : -1;
+    if (got) BF_HIP_TRY(hipEventRecord(p->evIngest[evSlot], sa));
     if (tm) (void)hipEventRecord(p->ev[1], sa);
     // ---- processInput: enqueue (bundling stream) ...
     const bool haveFrames = p->im->currFrame > 0;
     if (haveFrames) BF_TRY(bf_online_bundler_process_input_begin(p->ob));
-    // ---- fix old frames (volume stream), concurrently with the feature pipeline
+    // ---- fix old frames (volume stream; launches issued by the volume thread), concurrently with the feature pipeline
     if (tm) (void)hipEventRecord(p->ev[4], sv);
     BF_TRY(plReintegrate(p));
     if (tm) (void)hipEventRecord(p->ev[5], sv);
@@ -1308,8 +1373,7 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
         uint32_t cur;
         BF_TRY(bf_image_manager_get_curr_frame_number(p->im, &cur));
         if (valid && p->gas.s_reconstructionEnabled) {
-            BF_HIP_TRY(hipStreamWaitEvent(sv, p->evIngest, 0));
-            BF_TRY(plIntegrate(p, frameIdx, T, false));
+            BF_TRY(plIntegrate(p, frameIdx, T, false, evSlot));
             BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_INTEGRATED, T, cur));
         } else {
             const m44 inv = minfM();
@@ -1365,23 +1429,32 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
     p->cam.m_sensorDepthWorldMin = gas->s_renderDepthMin; p->cam.m_sensorDepthWorldMax = gas->s_renderDepthMax;      // DepthSensing.cpp:636-643
     p->cam.m_imageWidth = gas->s_integrationWidth; p->cam.m_imageHeight = gas->s_integrationHeight;
     for (auto& e : p->ev) BF_HIP_TRY(hipEventCreate(&e));
-    BF_HIP_TRY(hipEventCreateWithFlags(&p->evIngest, hipEventDisableTiming));
+    for (auto& e : p->evIngest) BF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     BF_HIP_TRY(hipDeviceSynchronize());                                  // creation-time work was issued on the null stream
     BF_HIP_TRY(hipStreamCreateWithFlags(&p->sBundle, hipStreamNonBlocking));
     BF_HIP_TRY(hipStreamCreateWithFlags(&p->sVolume, hipStreamNonBlocking));
     BF_TRY(bf_image_manager_set_stream(p->im, p->sBundle));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
+    BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
+    int dev = 0;
+    BF_HIP_TRY(hipGetDevice(&dev));
+    p->worker = std::thread([p, dev] { (void)hipSetDevice(dev); volWorker(p); });
     *out = p;
     return BF_OK;
 }
 
 int bf_pipeline_destroy(bf_pipeline* p) {
     if (!p) return BF_OK;
+    if (p->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+        p->cvWork.notify_all();
+        p->worker.join();
+    }
     (void)hipDeviceSynchronize();
     bf_online_bundler_destroy(p->ob); bf_image_manager_destroy(p->im); bf_scene_destroy(p->scene);
     for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
-    if (p->evIngest) (void)hipEventDestroy(p->evIngest);
+    for (auto& e : p->evIngest) if (e) (void)hipEventDestroy(e);
     if (p->sBundle) (void)hipStreamDestroy(p->sBundle);
     if (p->sVolume) (void)hipStreamDestroy(p->sVolume);
     delete p;
@@ -1409,11 +1482,17 @@ int bf_pipeline_process_end_of_sequence(bf_pipeline* p, uint32_t* numActiveOpera
 }
 int bf_pipeline_synchronize(bf_pipeline* p) {
     BF_REQUIRE(p, "null pipeline");
+    BF_TRY(volDrain(p));
     BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
     BF_HIP_TRY(hipStreamSynchronize(p->sVolume));
     return BF_OK;
 }
-int bf_pipeline_get_scene(bf_pipeline* p, bf_scene** out) { BF_REQUIRE(p && out, "null argument"); *out = p->scene; return BF_OK; }
+int bf_pipeline_get_scene(bf_pipeline* p, bf_scene** out) {         // the volume thread is drained first: the caller may use the scene directly
+    BF_REQUIRE(p && out, "null argument");
+    BF_TRY(volDrain(p));
+    *out = p->scene;
+    return BF_OK;
+}
 int bf_pipeline_get_image_manager(bf_pipeline* p, bf_image_manager** out) { BF_REQUIRE(p && out, "null argument"); *out = p->im; return BF_OK; }
 int bf_pipeline_get_online_bundler(bf_pipeline* p, bf_online_bundler** out) { BF_REQUIRE(p && out, "null argument"); *out = p->ob; return BF_OK; }
 int bf_pipeline_get_num_frames(bf_pipeline* p, uint32_t* out) { BF_REQUIRE(p && out, "null argument"); *out = p->im->currFrame; return BF_OK; }
@@ -1437,7 +1516,12 @@ int bf_pipeline_get_counters(bf_pipeline* p, uint32_t* numIntegrate, uint32_t* n
     if (numGlobalSolves) *numGlobalSolves = p->ob->numGlobalSolves;
     return BF_OK;
 }
-int bf_pipeline_enable_timings(bf_pipeline* p, int enable) { BF_REQUIRE(p, "null pipeline"); p->timings = enable != 0; return BF_OK; }
+int bf_pipeline_enable_timings(bf_pipeline* p, int enable) {
+    BF_REQUIRE(p, "null pipeline");
+    BF_TRY(volDrain(p));
+    p->timings = enable != 0;
+    return BF_OK;
+}
 int bf_pipeline_get_last_timing(bf_pipeline* p, bf_frame_timing* out) { BF_REQUIRE(p && out, "null argument"); *out = p->last; return BF_OK; }
 
 }  // extern "C"

@@ -862,6 +862,7 @@ struct bf_siftmgr {
     std::vector<int> validImages;
     uint32_t numImages = 0, currentImage = 0, globNumResiduals = 0;
     bool finalized = true;
+    bool resPrefetched = false;
     bool validDirty = false;          // host copy of the valid flags changed since the last upload
     std::deque<uint32_t> retry;
 };
@@ -1019,10 +1020,19 @@ int bf_siftmgr_add_curr_to_residuals(bf_siftmgr* m, uint32_t curFrame, uint32_t 
     return BF_OK;
 }
 
+// enqueue the D2H of the frame result behind the work issued so far (optional; lets the caller do other things before it waits)
+int bf_siftmgr_prefetch_frame_result(bf_siftmgr* m) {
+    BF_REQUIRE(m, "null manager");
+    BF_HIP_TRY(hipMemcpyAsync(m->h_res, m->d_res, sizeof(FrameResult), hipMemcpyDeviceToHost, m->stream));
+    m->resPrefetched = true;
+    return BF_OK;
+}
+
 // the frame's single read-back: last matched frame, validity, #residuals, #keys of the current frame
 int bf_siftmgr_sync_frame_result(bf_siftmgr* m, uint32_t curFrame, uint32_t* lastMatchedFrame, int32_t* numKeysCur) {
     BF_REQUIRE(m && curFrame < m->maxImages, "frame out of range");
-    BF_HIP_TRY(hipMemcpyAsync(m->h_res, m->d_res, sizeof(FrameResult), hipMemcpyDeviceToHost, m->stream));
+    if (!m->resPrefetched) BF_HIP_TRY(hipMemcpyAsync(m->h_res, m->d_res, sizeof(FrameResult), hipMemcpyDeviceToHost, m->stream));
+    m->resPrefetched = false;
     BF_HIP_TRY(hipStreamSynchronize(m->stream));
     m->validImages[curFrame] = m->h_res->valid;
     m->globNumResiduals = (uint32_t)m->h_res->numResiduals;

@@ -800,6 +800,16 @@ struct bf_scene {
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
+    // Software pipelining of consecutive operators (bf_scene_set_overlap): allocation + frustum compaction of operator n+1 run on
+    // the internal `prep` stream while the voxel update of operator n runs on `stream`.  The update never reads the hash table and
+    // allocation never touches voxels; the only shared object is the frustum list, which is double-buffered.
+    bool overlap = false;
+    hipStream_t prep = nullptr;
+    bf_hash_entry* cbuf[2] = {nullptr, nullptr}; uint32_t* csrc[2] = {nullptr, nullptr}; int32_t* ccnt[2] = {nullptr, nullptr};
+    int cur = 0;                    // buffer that holds the latest list (== d.compact / d.compactSrc / d.compactCount)
+    hipEvent_t evPrep[2] = {nullptr, nullptr}, evUpd[2] = {nullptr, nullptr}, evBarrier = nullptr, evTmp = nullptr;
+    bool updRecorded[2] = {false, false}, barrierPending = false;
+    hipEvent_t pendingEv = nullptr; // bf_scene_wait_event: the next operator's first kernel waits for it
     bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
     // optional HIP-event timing of the voxel-update kernel
     bool timing = false;
@@ -807,6 +817,8 @@ struct bf_scene {
     size_t eventsUsed = 0;
     std::vector<void*> allocations;
 };
+
+#define BF_TRY_RC(expr) do { int _rc = (expr); if (_rc != BF_OK) return _rc; } while (0)
 
 namespace {
 
@@ -845,7 +857,33 @@ void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepH
     memcpy(s->params.m_rigidTransformInverse, inv.e, 64);
 }
 
-int launchCompactify(bf_scene* s) {                              // compactifyHashEntries :355-391
+Dev devBuf(const bf_scene* s, int b) {
+    Dev d = s->d;
+    d.compact = s->cbuf[b]; d.compactSrc = s->csrc[b]; d.compactCount = s->ccnt[b];
+    return d;
+}
+void useBuf(bf_scene* s, int b) { s->cur = b; s->d.compact = s->cbuf[b]; s->d.compactSrc = s->csrc[b]; s->d.compactCount = s->ccnt[b]; }
+
+// exclusive section on the main stream: everything issued on `prep` so far happens before, everything issued on `prep` later after
+int beginExclusive(bf_scene* s) {
+    if (!s->overlap) return BF_OK;
+    BF_HIP_TRY(hipEventRecord(s->evTmp, s->prep));
+    BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTmp, 0));
+    return BF_OK;
+}
+int endExclusive(bf_scene* s) {
+    if (!s->overlap) return BF_OK;
+    BF_HIP_TRY(hipEventRecord(s->evBarrier, s->stream));
+    s->barrierPending = true;
+    return BF_OK;
+}
+int syncAll(bf_scene* s) {
+    if (s->prep) BF_HIP_TRY(hipStreamSynchronize(s->prep));
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    return BF_OK;
+}
+
+int launchCompactify(bf_scene* s) {                              // compactifyHashEntries :355-391 (main stream, current buffer)
     const Frame f = makeFrame(s);
     hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
@@ -853,36 +891,65 @@ int launchCompactify(bf_scene* s) {                              // compactifyHa
     s->compactStale = false;
     return BF_OK;
 }
-
-int launchAlloc(bf_scene* s, const float* d_depth) {             // alloc :328-352
-    const Frame f = makeFrame(s);
-    const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
-    hipLaunchKernelGGL(k_alloc_candidates, dim3(div_up(tiles, 4)), dim3(256), 0, s->stream, s->d, f, d_depth);
-    hipLaunchKernelGGL(k_alloc_insert, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
-    hipLaunchKernelGGL(k_alloc_finish, dim3(1), dim3(1024), 0, s->stream, s->d, f);
-    BF_HIP_TRY(hipGetLastError());
-    return BF_OK;
+int refreshStaleList(bf_scene* s) {                              // a fused re-integration left a union list behind
+    if (!s->compactStale) return BF_OK;
+    BF_TRY_RC(beginExclusive(s));
+    BF_TRY_RC(launchCompactify(s));
+    return endExclusive(s);
 }
 
-template <bool DEINT>
-int launchUpdate(bf_scene* s, const bf_depth_camera_data* data) {
-    const Frame f = makeFrame(s);
+void launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_depth) {      // alloc :328-352
+    const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
+    hipLaunchKernelGGL(k_alloc_candidates, dim3(div_up(tiles, 4)), dim3(256), 0, st, s->d, f, d_depth);
+    hipLaunchKernelGGL(k_alloc_insert, dim3(NBINS), dim3(1024), 0, st, s->d, f);
+    hipLaunchKernelGGL(k_alloc_finish, dim3(1), dim3(1024), 0, st, s->d, f);
+}
+
+// One operator = [allocation] -> frustum list -> voxel update.  kind 0 integrate(f), 1 de-integrate(f), 2 fused: de-integrate(fo) +
+// integrate(f).  With overlap enabled the first two phases go to the prep stream and only the update to the main stream.
+int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf_depth_camera_data* data) {
+    const int b = s->overlap ? 1 - s->cur : s->cur;
+    hipStream_t ps = s->overlap ? s->prep : s->stream;
+    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->pendingEv = nullptr; }
+    if (s->overlap) {
+        if (s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
+        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer two operators ago
+    }
+    const Dev dv = devBuf(s, b);
+    if (kind != 1) launchAllocOn(s, ps, f, data->d_depthData);      // de-integration neither allocates nor frees
+    if (kind == 2) {
+        hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
+        hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
+    } else {
+        hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
+        hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
+    }
+    if (s->overlap) {
+        BF_HIP_TRY(hipEventRecord(s->evPrep[b], ps));
+        BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
+    }
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (s->timing) {
         if (s->eventsUsed == s->events.size()) {
-            hipEvent_t a, b;
-            BF_HIP_TRY(hipEventCreate(&a));
-            BF_HIP_TRY(hipEventCreate(&b));
-            s->events.push_back({a, b});
+            hipEvent_t e0, e1;
+            BF_HIP_TRY(hipEventCreate(&e0));
+            BF_HIP_TRY(hipEventCreate(&e1));
+            s->events.push_back({e0, e1});
         }
         ev = &s->events[s->eventsUsed++];
-        s->opsTimed += 1;
+        s->opsTimed += kind == 2 ? 2 : 1;
         BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
     }
-    hipLaunchKernelGGL(k_update<DEINT>, dim3(s->gridUpdate), dim3(512), 0, s->stream, s->d, f, data->d_depthData,
-                       reinterpret_cast<const uchar4*>(data->d_colorData), s->timing ? 1 : 0);
+    const uchar4* color = reinterpret_cast<const uchar4*>(data->d_colorData);
+    const int acc = s->timing ? 1 : 0;
+    if (kind == 0) hipLaunchKernelGGL(k_update<false>, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, data->d_depthData, color, acc);
+    else if (kind == 1) hipLaunchKernelGGL(k_update<true>, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, data->d_depthData, color, acc);
+    else hipLaunchKernelGGL(k_reupdate, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, fo, data->d_depthData, color, acc);
     if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
+    if (s->overlap) { BF_HIP_TRY(hipEventRecord(s->evUpd[b], s->stream)); s->updRecorded[b] = true; }
     BF_HIP_TRY(hipGetLastError());
+    useBuf(s, b);
+    s->compactStale = kind == 2;
     return BF_OK;
 }
 
@@ -921,9 +988,9 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     A(s->d.heap, N);
     A(s->d.heapCounter, 1);
     A(s->d.vox, N * VOX);
-    A(s->d.compact, N);
-    A(s->d.compactSrc, N);
-    A(s->d.compactCount, 1);
+    A(s->cbuf[0], N); A(s->cbuf[1], N);
+    A(s->csrc[0], N); A(s->csrc[1], N);
+    A(s->ccnt[0], 1); A(s->ccnt[1], 1);
     A(s->d.occSum, 1);
     A(s->d.allocList, N);
     A(s->d.allocListAlt, N);
@@ -939,6 +1006,10 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
 #undef A
     if (rc != BF_OK) { bf_scene_destroy(s); return rc; }
     s->d.dedupeMask = ds - 1;
+    useBuf(s, 0);
+    BF_HIP_TRY(hipStreamCreateWithFlags(&s->prep, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&s->evPrep[0], &s->evPrep[1], &s->evUpd[0], &s->evUpd[1], &s->evBarrier, &s->evTmp})
+        BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
     s->gridUpdate = 256 * 8;     // 256 CUs x 8 resident 512-thread workgroups' worth of queue depth
     *out = s;
@@ -947,16 +1018,33 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
 
 int bf_scene_destroy(bf_scene* s) {
     if (!s) return BF_OK;
-    hipStreamSynchronize(s->stream);
+    (void)syncAll(s);
     for (void* q : s->allocations) hipFree(q);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (hipEvent_t e : {s->evPrep[0], s->evPrep[1], s->evUpd[0], s->evUpd[1], s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
+    if (s->prep) hipStreamDestroy(s->prep);
     delete s;
     return BF_OK;
 }
 
 int bf_scene_set_stream(bf_scene* s, void* hip_stream) {
     BF_REQUIRE(s, "null scene");
+    BF_TRY_RC(syncAll(s));
     s->stream = (hipStream_t)hip_stream;
+    return BF_OK;
+}
+
+int bf_scene_set_overlap(bf_scene* s, int enable) {
+    BF_REQUIRE(s, "null scene");
+    BF_TRY_RC(syncAll(s));
+    s->overlap = enable != 0;
+    s->updRecorded[0] = s->updRecorded[1] = false; s->barrierPending = false;
+    return BF_OK;
+}
+
+int bf_scene_wait_event(bf_scene* s, void* hip_event) {
+    BF_REQUIRE(s, "null scene");
+    s->pendingEv = (hipEvent_t)hip_event;
     return BF_OK;
 }
 
@@ -967,6 +1055,10 @@ int bf_scene_reset(bf_scene* s) {                                  // CUDASceneR
     memcpy(s->params.m_rigidTransform, I.e, 64);
     memcpy(s->params.m_rigidTransformInverse, I.e, 64);
     s->params.m_numOccupiedBlocks = 0;
+    BF_TRY_RC(syncAll(s));
+    s->compactStale = false; s->updRecorded[0] = s->updRecorded[1] = false; s->barrierPending = false; s->pendingEv = nullptr;
+    BF_HIP_TRY(hipMemsetAsync(s->ccnt[0], 0, 4, s->stream));
+    BF_HIP_TRY(hipMemsetAsync(s->ccnt[1], 0, 4, s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
     BF_HIP_TRY(hipMemsetAsync(s->d.vox, 0, (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel), s->stream));
     hipLaunchKernelGGL(k_reset, dim3(2048), dim3(256), 0, s->stream, s->d, s->params.m_numSDFBlocks, (uint32_t)numEntries,
@@ -981,9 +1073,8 @@ int bf_scene_integrate(bf_scene* s, const float T[16], const bf_depth_camera_dat
     if (rc) return rc;
     s->cam = *cam; s->haveCam = true;
     setLastRigidTransform(s, T);
-    if ((rc = launchAlloc(s, data->d_depthData))) return rc;
-    if ((rc = launchCompactify(s))) return rc;
-    if ((rc = launchUpdate<false>(s, data))) return rc;
+    const Frame f = makeFrame(s);
+    if ((rc = runOperator(s, 0, f, f, data))) return rc;
     s->numIntegrated++;
     return BF_OK;
 }
@@ -994,8 +1085,8 @@ int bf_scene_deintegrate(bf_scene* s, const float T[16], const bf_depth_camera_d
     if (rc) return rc;
     s->cam = *cam; s->haveCam = true;
     setLastRigidTransform(s, T);
-    if ((rc = launchCompactify(s))) return rc;
-    if ((rc = launchUpdate<true>(s, data))) return rc;
+    const Frame f = makeFrame(s);
+    if ((rc = runOperator(s, 1, f, f, data))) return rc;
     s->numIntegrated--;
     return BF_OK;
 }
@@ -1025,40 +1116,23 @@ int bf_scene_reintegrate(bf_scene* s, const float oldT[16], const float newT[16]
     const Frame fo = makeFrame(s);
     setLastRigidTransform(s, newT);
     const Frame f = makeFrame(s);
-    if ((rc = launchAlloc(s, data->d_depthData))) return rc;            // de-integration neither allocates nor frees: same result as after it
-    hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, fo);
-    hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, fo);
-    s->compactStale = true;
-    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (s->timing) {
-        if (s->eventsUsed == s->events.size()) {
-            hipEvent_t a, b;
-            BF_HIP_TRY(hipEventCreate(&a));
-            BF_HIP_TRY(hipEventCreate(&b));
-            s->events.push_back({a, b});
-        }
-        ev = &s->events[s->eventsUsed++];
-        s->opsTimed += 2;
-        BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
-    }
-    hipLaunchKernelGGL(k_reupdate, dim3(s->gridUpdate), dim3(512), 0, s->stream, s->d, f, fo, data->d_depthData,
-                       reinterpret_cast<const uchar4*>(data->d_colorData), s->timing ? 1 : 0);
-    if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
-    BF_HIP_TRY(hipGetLastError());
-    return BF_OK;
+    return runOperator(s, 2, f, fo, data);
 }
 
 int bf_scene_set_last_rigid_transform_and_compactify(bf_scene* s, const float T[16], const bf_depth_camera_params* cam) {
     BF_REQUIRE(s && T && cam, "null argument");
     s->cam = *cam; s->haveCam = true;
     setLastRigidTransform(s, T);
-    return launchCompactify(s);
+    BF_TRY_RC(beginExclusive(s));
+    BF_TRY_RC(launchCompactify(s));
+    return endExclusive(s);
 }
 
 int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
     BF_REQUIRE(s, "null scene");
     if (!s->haveCam) return BF_OK;                                  // nothing was ever compactified
-    if (s->compactStale) { int rc = launchCompactify(s); if (rc) return rc; }
+    BF_TRY_RC(beginExclusive(s));
+    if (s->compactStale) BF_TRY_RC(launchCompactify(s));
     const Frame f = makeFrame(s);
     hipLaunchKernelGGL(k_gc_identify, dim3(s->gridUpdate), dim3(256), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_delete, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
@@ -1068,12 +1142,14 @@ int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
     hipLaunchKernelGGL(k_list_commit, dim3(1), dim3(1), 0, s->stream, s->d);
     std::swap(s->d.allocList, s->d.allocListAlt);
     BF_HIP_TRY(hipGetLastError());
-    return launchCompactify(s);
+    BF_TRY_RC(launchCompactify(s));
+    return endExclusive(s);
 }
 
 int bf_scene_get_hash_data(bf_scene* s, bf_hash_data* out) {
     BF_REQUIRE(s && out, "null argument");
-    if (s->compactStale) { int rc = launchCompactify(s); if (rc) return rc; }
+    BF_TRY_RC(refreshStaleList(s));
+    BF_TRY_RC(syncAll(s));
     out->d_heap = s->d.heap;
     out->d_heapCounter = s->d.heapCounter;
     out->d_hashDecision = s->d_hashDecision;
@@ -1088,7 +1164,8 @@ int bf_scene_get_hash_data(bf_scene* s, bf_hash_data* out) {
 
 int bf_scene_get_hash_params(bf_scene* s, bf_hash_params* out) {
     BF_REQUIRE(s && out, "null argument");
-    if (s->compactStale) { int rc = launchCompactify(s); if (rc) return rc; }
+    BF_TRY_RC(refreshStaleList(s));
+    BF_TRY_RC(syncAll(s));
     int32_t n = 0;
     BF_HIP_TRY(hipMemcpyAsync(&n, s->d.compactCount, 4, hipMemcpyDeviceToHost, s->stream));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1099,6 +1176,7 @@ int bf_scene_get_hash_params(bf_scene* s, bf_hash_params* out) {
 
 int bf_scene_get_heap_free_count(bf_scene* s, uint32_t* out) {       // :168-172
     BF_REQUIRE(s && out, "null argument");
+    BF_TRY_RC(syncAll(s));
     uint32_t c = 0;
     BF_HIP_TRY(hipMemcpyAsync(&c, s->d.heapCounter, 4, hipMemcpyDeviceToHost, s->stream));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1114,6 +1192,7 @@ int bf_scene_get_num_integrated_frames(bf_scene* s, uint32_t* out) {
 
 int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out) {
     BF_REQUIRE(s && out, "null argument");
+    BF_TRY_RC(syncAll(s));
     uint32_t n = 0;
     BF_HIP_TRY(hipMemcpyAsync(&n, s->d.allocCount, 4, hipMemcpyDeviceToHost, s->stream));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1127,6 +1206,7 @@ int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out) {
 
 int bf_scene_debug_hash(bf_scene* s, uint32_t out[6]) {              // debugHash :179-314
     BF_REQUIRE(s && out, "null argument");
+    BF_TRY_RC(syncAll(s));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
     const uint32_t N = s->params.m_numSDFBlocks;

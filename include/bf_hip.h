@@ -142,6 +142,13 @@ BF_API int bf_scene_integrate(bf_scene* s, const float cam_to_world[16],
 BF_API int bf_scene_deintegrate(bf_scene* s, const float cam_to_world[16],
                                 const bf_depth_camera_data* data,
                                 const bf_depth_camera_params* cam, const uint32_t* d_bitMask);
+/* Software pipelining of consecutive operators: with overlap enabled, allocation + frustum compaction of operator n+1 run on
+ * an internal stream while the voxel update of operator n runs on the scene's stream (the frustum list is double-buffered;
+ * the update never reads the hash table, allocation never touches voxels).  Results are unchanged.  The caller then must
+ * order its input frames against the scene with bf_scene_wait_event (or have them complete) instead of relying on stream
+ * order: bf_scene_wait_event makes the next operator's first kernel wait for `hip_event`.                               */
+BF_API int bf_scene_set_overlap(bf_scene* s, int enable);
+BF_API int bf_scene_wait_event(bf_scene* s, void* hip_event);
 /* Multi-GPU hash-bucket sharding (one process per GPU): the volume owns the home buckets
  * [rank*numBuckets/world, (rank+1)*numBuckets/world) and allocates / integrates / collects only blocks hashing there.
  * Call before the first integrate; every shard is fed every frame and pose, there is no exchange between shards. */
@@ -384,6 +391,8 @@ BF_API int bf_siftmgr_add_curr_to_residuals(bf_siftmgr* m, uint32_t curFrame, ui
                                             const float colorIntrinsicsInv[16]);
 BF_API int bf_siftmgr_sync_frame_result(bf_siftmgr* m, uint32_t curFrame, uint32_t* lastMatchedFrame,
                                         int32_t* numKeyPointsCur);
+/* optional: enqueue that read-back now (after filter_frames_async / add_curr_to_residuals); sync_frame_result then only waits */
+BF_API int bf_siftmgr_prefetch_frame_result(bf_siftmgr* m);
 /* InvalidateImageToImageCU / CheckForInvalidFrames[Simple]CU   :692-795 */
 BF_API int bf_siftmgr_invalidate_image_to_image(bf_siftmgr* m, uint32_t imageIdx_i, uint32_t imageIdx_j);
 BF_API int bf_siftmgr_check_for_invalid_frames_simple(bf_siftmgr* m, const int32_t* d_varToCorrNumEntriesPerRow,

@@ -98,15 +98,20 @@ def test_sequence_integrate_deintegrate_gc_bit_exact(gpu, oracle):
     assert not gvox.view(np.uint8).any()
 
 
-def test_fused_reintegrate_equals_deintegrate_plus_integrate(gpu, oracle):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_fused_reintegrate_equals_deintegrate_plus_integrate(gpu, oracle, overlap):
     """bf_scene_reintegrate (one pass over the union of both frustum lists) vs the oracle's deIntegrate + integrate
-    (DepthSensing.cpp:882-889): small and large pose changes (frusta overlapping fully, partly, hardly), followed by GC."""
+    (DepthSensing.cpp:882-889): small and large pose changes (frusta overlapping fully, partly, hardly), followed by GC.
+    overlap=True additionally software-pipelines consecutive operators (allocation + frustum list of operator n+1 on the
+    internal stream while operator n updates voxels) — same results."""
     W, H = 160, 120
     frames = [synth.scene_room(k * 12, W, H) for k in range(5)]
     K = frames[0][3]
     cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
     p = default_hash_params(num_buckets=50000, num_sdf_blocks=40000, voxel_size=0.02)
     gs = gpu.capi.SceneRepHashSDF(p)
+    if overlap:
+        gs.set_overlap(True)
     osc = oracle.OracleScene(p)
     dev = [_to_dev(f[0], f[1]) for f in frames]
     poses = [f[2].copy() for f in frames]
@@ -128,7 +133,8 @@ def test_fused_reintegrate_equals_deintegrate_plus_integrate(gpu, oracle):
         poses[i] = T2
         if step % 2 == 1:
             gs.garbage_collect(); osc.garbage_collect()
-        assert_same_state(gs, osc, "after fused re-integration %d:" % step)
+        if not overlap or step in (2, 5):           # with overlap: several operators in flight between checks
+            assert_same_state(gs, osc, "after fused re-integration %d:" % step)
     assert gs.num_integrated_frames() == 5
 
 
