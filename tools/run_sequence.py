@@ -22,13 +22,15 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--voxel", type=float, default=0.01)
+    ap.add_argument("--width", type=int, default=640, help="sensor (depth = colour) width; SIFT stays at 640x480")
+    ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--buckets", type=int, default=800000)
     ap.add_argument("--blocks", type=int, default=200000)
     ap.add_argument("--host", action="store_true", help="hand over host buffers (PCIe path) instead of HBM-resident frames")
     ap.add_argument("--tail", type=int, default=5, help="end-of-sequence iterations")
     ap.add_argument("--timings", action="store_true")
     a = ap.parse_args()
-    W, H = 640, 480
+    W, H = a.width, a.height
     frames = synth.render_frames([a.first + k * a.stride for k in range(a.frames)], W, H)
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
@@ -36,6 +38,7 @@ def main():
     gas.s_integrationWidth, gas.s_integrationHeight = W, H
     gas.s_SDFVoxelSize = a.voxel; gas.s_hashNumBuckets = a.buckets; gas.s_hashNumSDFBlocks = a.blocks
     gbs.s_maxNumImages = max(8, a.frames // 10 + 4)
+    gbs.s_widthSIFT, gbs.s_heightSIFT = 640, 480
     p = bf.capi.Pipeline(gas, gbs, bf.capi.sensor_desc(W, H, K))
     if a.timings:
         p.enable_timings(True)
