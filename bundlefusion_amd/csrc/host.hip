@@ -1431,8 +1431,13 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
     for (auto& e : p->ev) BF_HIP_TRY(hipEventCreate(&e));
     for (auto& e : p->evIngest) BF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     BF_HIP_TRY(hipDeviceSynchronize());                                  // creation-time work was issued on the null stream
-    BF_HIP_TRY(hipStreamCreateWithFlags(&p->sBundle, hipStreamNonBlocking));
-    BF_HIP_TRY(hipStreamCreateWithFlags(&p->sVolume, hipStreamNonBlocking));
+    {   // the feature pipeline is a chain of small latency-bound kernels with a host read-back at its end: it gets priority over
+        // the wide, throughput-bound voxel updates of the volume stream
+        int least = 0, greatest = 0;
+        BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sBundle, hipStreamNonBlocking, greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
+    }
     BF_TRY(bf_image_manager_set_stream(p->im, p->sBundle));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));

@@ -32,7 +32,7 @@ namespace {
 
 constexpr int BS = BF_SDF_BLOCK_SIZE;
 constexpr int VOX = BS * BS * BS;
-constexpr uint32_t NBINS = 256;        // one LDS sort workgroup per bin (~1 per CU)
+constexpr uint32_t NBINS = 256;        // one LDS sort workgroup per bin (~1 per CU); 1024 lighter bins (256 threads, 17 KB) measured 2 % slower
 constexpr uint32_t BINCAP = 4096;      // records per bin (64 KB of LDS when sorting)
 constexpr uint32_t OVCAP = 4096;       // bucket-full keys per alloc handled by the tail
 constexpr uint32_t TILE = 1024;        // entries per ordered-compaction tile
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
         d.overflowCount[0] = 0;
     }
     __syncthreads();
-    if (threadIdx.x < NBINS) d.binCount[threadIdx.x] = 0;
+    for (uint32_t b = threadIdx.x; b < NBINS; b += blockDim.x) d.binCount[b] = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void k_gc_finish(Dev d) {
     const uint32_t D = binPrefix(d.binCount, NBINS, scratch);
     if (threadIdx.x == 0) d.heapCounter[0] += D;
     __syncthreads();
-    if (threadIdx.x < NBINS) d.binCount[threadIdx.x] = 0;
+    for (uint32_t b = threadIdx.x; b < NBINS; b += blockDim.x) d.binCount[b] = 0;
 }
 
 }  // namespace
@@ -1008,7 +1008,11 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (rc != BF_OK) { bf_scene_destroy(s); return rc; }
     s->d.dedupeMask = ds - 1;
     useBuf(s, 0);
-    BF_HIP_TRY(hipStreamCreateWithFlags(&s->prep, hipStreamNonBlocking));
+    {   // allocation / compaction are short and sit on the critical path of the next voxel update: give them queue priority
+        int least = 0, greatest = 0;
+        BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&s->prep, hipStreamNonBlocking, greatest));
+    }
     for (hipEvent_t* e : {&s->evPrep[0], &s->evPrep[1], &s->evUpd[0], &s->evUpd[1], &s->evBarrier, &s->evTmp})
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
