@@ -605,29 +605,39 @@ __global__ __launch_bounds__(1024) void k_pcg(Dev d, uint32_t nLin, uint32_t gnI
         bool last = (lin == nLin - 1);
         ++it;
         __syncthreads();
-        // Ap = A p : block-row gather (replaces PCGStep_Kernel0/1a/_Dense, :870-928)
-        for (uint32_t i = 1 + wave; i < N; i += nWaves) {
-            float acc[6] = {0, 0, 0, 0, 0, 0};
-            const uint32_t s0 = d.rowStart[i], s1 = d.rowStart[i + 1];
-            for (uint32_t s = s0 + lane; s < s1; s += 64) {
-                const float* O = d.slotO + (size_t)s * 36;
-                const float* pj = d.p + 6 * d.slotCol[s];
-                const float q0 = pj[0], q1 = pj[1], q2 = pj[2], q3 = pj[3], q4 = pj[4], q5 = pj[5];
+        // Ap = A p : block-row gather (replaces PCGStep_Kernel0/1a/_Dense, :870-928).  A quarter wave (16 lanes) per block row, so 64
+        // rows are in flight per pass: the gather is latency-bound (one 144-byte block per slot from L2/HBM), and key-frame
+        // graphs have ~10-30 neighbours per row, which 16 lanes cover in one or two strides.
+        {
+            const uint32_t q = lane >> 4, l16 = lane & 15;
+            for (uint32_t i0 = 1; i0 < N; i0 += 4 * nWaves) {
+                const uint32_t i = i0 + wave * 4 + q;
+                float acc[6] = {0, 0, 0, 0, 0, 0};
+                if (i < N) {
+                    const uint32_t s0 = d.rowStart[i], s1 = d.rowStart[i + 1];
+                    for (uint32_t s = s0 + l16; s < s1; s += 16) {
+                        const float* O = d.slotO + (size_t)s * 36;
+                        const float* pj = d.p + 6 * d.slotCol[s];
+                        const float q0 = pj[0], q1 = pj[1], q2 = pj[2], q3 = pj[3], q4 = pj[4], q5 = pj[5];
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+                            acc[a] += ((((O[a * 6 + 0] * q0 + O[a * 6 + 1] * q1) + O[a * 6 + 2] * q2) + O[a * 6 + 3] * q3) + O[a * 6 + 4] * q4) + O[a * 6 + 5] * q5;
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
-                    acc[a] += ((((O[a * 6 + 0] * q0 + O[a * 6 + 1] * q1) + O[a * 6 + 2] * q2) + O[a * 6 + 3] * q3) + O[a * 6 + 4] * q4) + O[a * 6 + 5] * q5;
-            }
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[a] = wave_sum(acc[a]);
-            if (lane < 6) {
-                const float* A = d.diagA + (size_t)i * 36 + lane * 6;
-                const float* pi = d.p + 6 * i;
-                float v = 0.0f;
+                    for (int o = 8; o > 0; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);      // butterfly inside the 16-lane group
+                if (i < N && l16 < 6) {
+                    const float* A = d.diagA + (size_t)i * 36 + l16 * 6;
+                    const float* pi = d.p + 6 * i;
+                    float v = 0.0f;
 #pragma unroll
-                for (int b = 0; b < 6; ++b) v += A[b] * pi[b];
-                float sel = acc[0];
-                if (lane == 1) sel = acc[1]; else if (lane == 2) sel = acc[2]; else if (lane == 3) sel = acc[3]; else if (lane == 4) sel = acc[4]; else if (lane == 5) sel = acc[5];
-                d.Ap[6 * i + lane] = v + sel;
+                    for (int b = 0; b < 6; ++b) v += A[b] * pi[b];
+                    float sel = acc[0];
+                    if (l16 == 1) sel = acc[1]; else if (l16 == 2) sel = acc[2]; else if (l16 == 3) sel = acc[3]; else if (l16 == 4) sel = acc[4]; else if (l16 == 5) sel = acc[5];
+                    d.Ap[6 * i + l16] = v + sel;
+                }
             }
         }
         __syncthreads();

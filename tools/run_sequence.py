@@ -29,33 +29,50 @@ def main():
     ap.add_argument("--host", action="store_true", help="hand over host buffers (PCIe path) instead of HBM-resident frames")
     ap.add_argument("--tail", type=int, default=5, help="end-of-sequence iterations")
     ap.add_argument("--timings", action="store_true")
+    ap.add_argument("--bob", type=float, default=0.0, help="vertical sinusoid amplitude of the trajectory [m] (SURVEY.md 8d config 4: 0.3)")
+    ap.add_argument("--maximages", type=int, default=0)
     a = ap.parse_args()
     W, H = a.width, a.height
-    frames = synth.render_frames([a.first + k * a.stride for k in range(a.frames)], W, H)
+    idx = [a.first + k * a.stride for k in range(a.frames)]
+    frames = []
+    dev_all = []
+    for c0 in range(0, len(idx), 512):                      # render and upload in batches: a 5000-frame stream is 12 GB
+        part = synth.render_frames(idx[c0:c0 + 512], W, H, bob=a.bob)
+        if a.host:
+            frames += part
+        else:
+            dev_all += [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in part]
+            frames += [(None, None, f[2], f[3]) for f in part]
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     gas = bf.capi.default_app_state(); gbs = bf.capi.default_bundling_state()
     gas.s_integrationWidth, gas.s_integrationHeight = W, H
     gas.s_SDFVoxelSize = a.voxel; gas.s_hashNumBuckets = a.buckets; gas.s_hashNumSDFBlocks = a.blocks
-    gbs.s_maxNumImages = max(8, a.frames // 10 + 4)
+    gbs.s_maxNumImages = a.maximages or max(8, a.frames // 10 + 4)
     gbs.s_widthSIFT, gbs.s_heightSIFT = 640, 480
     p = bf.capi.Pipeline(gas, gbs, bf.capi.sensor_desc(W, H, K))
     if a.timings:
         p.enable_timings(True)
-    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames] if not a.host else None
+    dev = dev_all if not a.host else None
     torch.cuda.synchronize()
     t0 = time.time()
     tl = []
+    marks = []
     for k in range(a.frames):
         ok = p.process_frame(*(dev[k] if dev else (frames[k][0], frames[k][1])))
         assert ok
         if a.timings:
             tl.append(p.last_timing())
+        if (k + 1) % 1000 == 0:
+            p.synchronize(); marks.append((k + 1, time.time() - t0))
     for _ in range(a.tail):
         p.process_end_of_sequence()
     p.synchronize()
     dt = time.time() - t0
     print("frames %d  wall %.3f s  -> %.1f frames/s (incl. %d end-of-sequence iterations)" % (a.frames, dt, a.frames / dt, a.tail))
+    prev = (0, 0.0)
+    for m in marks:
+        print("  frames %d-%d: %.1f frames/s" % (prev[0], m[0], (m[0] - prev[0]) / (m[1] - prev[1]))); prev = m
     print("counters", p.counters())
     T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
     gt = np.stack([(T0inv @ f[2].astype(np.float64)) for f in frames])
