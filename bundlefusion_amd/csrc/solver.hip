@@ -35,7 +35,7 @@ constexpr int DENSE_BLK = 120;                   // ii(36) jj(36) ij(36) gi(6) g
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Flag { FL_DONE = 0, FL_NUM_SLOTS = 1, FL_NUM_PAIRS = 2, FL_LIST_LEN = 3, FL_GN_ITERS = 4, FL_PCG_ITERS = 8, FL_COUNT = 40 };
+enum Flag { FL_DONE = 0, FL_NUM_SLOTS = 1, FL_NUM_PAIRS = 2, FL_LIST_LEN = 3, FL_GN_ITERS = 4, FL_BARRIER_FAIL = 5, FL_PCG_ITERS = 8, FL_COUNT = 40 };
 
 struct Cfg {
     float denseDistThresh, denseNormalThresh, denseColorThresh, denseColorGradientMin, denseDepthMin, denseDepthMax;
@@ -59,6 +59,7 @@ struct Dev {
     uint2* densePairs; float* denseWeight; float* denseBlocks;
     const bf_cached_frame* cache;
     int* flags;
+    int* gridBar;                    // one grid-barrier counter per Gauss-Newton iteration (k_pcg_coop)
     float* energies;
     float* maxRes; int* maxIdx; int* highCount;
     int* numEntriesPerRow;
@@ -585,18 +586,36 @@ BF_DEV float blockMax(float v, float* sh) {
     return t;
 }
 
+constexpr size_t PCG_LDS_MAX = 160 * 1024 - 1024;      // dynamic LDS of k_pcg<true> (gfx950: 160 KB per workgroup)
+// The CG vectors (p, r, delta, M^-1, Ap) and the row offsets live in LDS when they fit (VEC_LDS; 124 N + 4 bytes, N <= ~1300 key
+// frames): every phase of an iteration is then one LDS round trip instead of a store -> barrier -> load trip through L2, and
+// what is left per iteration is streaming the off-diagonal blocks once.  The arithmetic and its order are the same in both
+// variants.
+template <bool VEC_LDS>
 __global__ __launch_bounds__(1024) void k_pcg(Dev d, uint32_t nLin, uint32_t gnIter, int lastGN) {
     if (d.flags[FL_DONE]) return;
+    extern __shared__ float dynLds[];
     __shared__ float sh[16];
     const uint32_t N = d.N, n6 = 6 * N;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    float* const P = VEC_LDS ? dynLds : d.p;
+    float* const R = VEC_LDS ? dynLds + n6 : d.r;
+    float* const X = VEC_LDS ? dynLds + 2 * n6 : d.delta;
+    float* const AP = VEC_LDS ? dynLds + 3 * n6 : d.Ap;
+    const float* const M = VEC_LDS ? dynLds + 4 * n6 : d.prec;
+    const uint32_t* const RS = VEC_LDS ? (const uint32_t*)(dynLds + 5 * n6) : d.rowStart;
+    if (VEC_LDS) {
+        for (uint32_t t = threadIdx.x; t < n6; t += blockDim.x) dynLds[4 * n6 + t] = d.prec[t];
+        for (uint32_t t = threadIdx.x; t <= N; t += blockDim.x) ((uint32_t*)(dynLds + 5 * n6))[t] = d.rowStart[t];
+        __syncthreads();
+    }
     // Initialization (SolverBundling.cu:755-794): r = -J^T F, p = M^-1 r, delta = 0
     float part = 0.0f;
     for (uint32_t t = threadIdx.x; t < n6; t += blockDim.x) {
         const bool var = t >= 6;
         const float rr = var ? d.rhs[t] : 0.0f;
-        const float pp = var ? d.prec[t] * rr : 0.0f;
-        d.r[t] = rr; d.p[t] = pp; d.delta[t] = 0.0f;
+        const float pp = var ? M[t] * rr : 0.0f;
+        R[t] = rr; P[t] = pp; X[t] = 0.0f;
         part += rr * pp;
     }
     float rzOld = blockSum(part, sh);
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(1024) void k_pcg(Dev d, uint32_t nLin, uint32_t gnI
         ++it;
         __syncthreads();
         // Ap = A p : block-row gather (replaces PCGStep_Kernel0/1a/_Dense, :870-928).  A quarter wave (16 lanes) per block row, so 64
-        // rows are in flight per pass: the gather is latency-bound (one 144-byte block per slot from L2/HBM), and key-frame
+        // rows are in flight per pass and a lane has its whole 144-byte block (nine 16-byte loads) in flight at once; key-frame
         // graphs have ~10-30 neighbours per row, which 16 lanes cover in one or two strides.
         {
             const uint32_t q = lane >> 4, l16 = lane & 15;
@@ -614,10 +633,14 @@ __global__ __launch_bounds__(1024) void k_pcg(Dev d, uint32_t nLin, uint32_t gnI
                 const uint32_t i = i0 + wave * 4 + q;
                 float acc[6] = {0, 0, 0, 0, 0, 0};
                 if (i < N) {
-                    const uint32_t s0 = d.rowStart[i], s1 = d.rowStart[i + 1];
+                    const uint32_t s0 = RS[i], s1 = RS[i + 1];
                     for (uint32_t s = s0 + l16; s < s1; s += 16) {
-                        const float* O = d.slotO + (size_t)s * 36;
-                        const float* pj = d.p + 6 * d.slotCol[s];
+                        const float4* O4 = reinterpret_cast<const float4*>(d.slotO + (size_t)s * 36);     // 144-byte stride: 16-byte aligned
+                        const uint32_t col = d.slotCol[s];
+                        float O[36];
+#pragma unroll
+                        for (int v = 0; v < 9; ++v) { const float4 o = O4[v]; O[4 * v] = o.x; O[4 * v + 1] = o.y; O[4 * v + 2] = o.z; O[4 * v + 3] = o.w; }
+                        const float* pj = P + 6 * col;
                         const float q0 = pj[0], q1 = pj[1], q2 = pj[2], q3 = pj[3], q4 = pj[4], q5 = pj[5];
 #pragma unroll
                         for (int a = 0; a < 6; ++a)
@@ -630,40 +653,198 @@ __global__ __launch_bounds__(1024) void k_pcg(Dev d, uint32_t nLin, uint32_t gnI
                     for (int o = 8; o > 0; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);      // butterfly inside the 16-lane group
                 if (i < N && l16 < 6) {
                     const float* A = d.diagA + (size_t)i * 36 + l16 * 6;
-                    const float* pi = d.p + 6 * i;
+                    const float* pi = P + 6 * i;
                     float v = 0.0f;
 #pragma unroll
                     for (int b = 0; b < 6; ++b) v += A[b] * pi[b];
                     float sel = acc[0];
                     if (l16 == 1) sel = acc[1]; else if (l16 == 2) sel = acc[2]; else if (l16 == 3) sel = acc[3]; else if (l16 == 4) sel = acc[4]; else if (l16 == 5) sel = acc[5];
-                    d.Ap[6 * i + l16] = v + sel;
+                    AP[6 * i + l16] = v + sel;
                 }
             }
         }
         __syncthreads();
         part = 0.0f;
-        for (uint32_t t = 6 + threadIdx.x; t < n6; t += blockDim.x) part += d.p[t] * d.Ap[t];
+        for (uint32_t t = 6 + threadIdx.x; t < n6; t += blockDim.x) part += P[t] * AP[t];
         const float pAp = blockSum(part, sh);                                      // PCGStep_Kernel1b
         const float alpha = pAp > FLOAT_EPSILON ? rzOld / pAp : 0.0f;             // PCGStep_Kernel2 :948-983
         part = 0.0f;
         for (uint32_t t = 6 + threadIdx.x; t < n6; t += blockDim.x) {
-            d.delta[t] = d.delta[t] + alpha * d.p[t];
-            const float rr = d.r[t] - alpha * d.Ap[t];
-            d.r[t] = rr;
-            part += (d.prec[t] * rr) * rr;
+            X[t] = X[t] + alpha * P[t];
+            const float rr = R[t] - alpha * AP[t];
+            R[t] = rr;
+            part += (M[t] * rr) * rr;
         }
         const float rzNew = blockSum(part, sh);
         if (fabsf(pAp) < 5e-7f) last = true;                                      // :1088-1093
         const float beta = rzOld > FLOAT_EPSILON ? rzNew / rzOld : 0.0f;          // PCGStep_Kernel3 :985-1022
         rzOld = rzNew;
-        for (uint32_t t = 6 + threadIdx.x; t < n6; t += blockDim.x) d.p[t] = d.prec[t] * d.r[t] + beta * d.p[t];
+        for (uint32_t t = 6 + threadIdx.x; t < n6; t += blockDim.x) P[t] = M[t] * R[t] + beta * P[t];
         if (last) break;
     }
     __syncthreads();
     // Lie update (computeLieUpdate, LieDerivUtil.h:301-307) + GN convergence (EvalGNConvergence :694-749)
     float mx = 0.0f;
     for (uint32_t i = 1 + threadIdx.x; i < N; i += blockDim.x) {
-        const f3 dT = ld3(d.delta + 6 * i), dW = ld3(d.delta + 6 * i + 3);
+        const f3 dT = ld3(X + 6 * i), dW = ld3(X + 6 * i + 3);
+        f3 nw, nt;
+        lieUpdate(dW, dT, ld3(d.xRot + 3 * i), ld3(d.xTrans + 3 * i), nw, nt);
+        d.xRot[3 * i] = nw.x; d.xRot[3 * i + 1] = nw.y; d.xRot[3 * i + 2] = nw.z;
+        d.xTrans[3 * i] = nt.x; d.xTrans[3 * i + 1] = nt.y; d.xTrans[3 * i + 2] = nt.z;
+        if (d.valid[i] != 0) mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(dW.x), fabsf(dT.x)), fmaxf(fabsf(dW.y), fabsf(dT.y))), fmaxf(fabsf(dW.z), fabsf(dT.z))));
+    }
+    mx = blockMax(mx, sh);
+    if (threadIdx.x == 0) {
+        d.flags[FL_GN_ITERS] = (int)gnIter + 1;
+        d.flags[FL_PCG_ITERS + gnIter] = (int)it;
+        if (!lastGN && mx < 0.005f) d.flags[FL_DONE] = 1;                         // :1204-1210
+    }
+}
+
+// Cooperative variant: G workgroups of 256 threads, each owning a contiguous range of block rows whose off-diagonal blocks,
+// column indices and diagonal blocks stay in its LDS for the whole solve (a key-frame graph of N=500 with ~45 neighbours per
+// row is 3 MB: one CU streams that in ~25 us per iteration, 64 CUs hold it on chip).  Per iteration a workgroup computes Ap for
+// its rows, publishes them (agent-scope stores into a double-buffered exchange vector) and waits on ONE grid barrier; every
+// workgroup then reads the whole Ap and carries the CG vectors redundantly in its own LDS - the dot products and updates are
+// the same arithmetic in the same order on every workgroup, so alpha, beta and the early-out decision agree bit for bit and
+// no second exchange is needed.  The result does not depend on G (row arithmetic is per row, reductions are per 256 threads).
+// Exchanged data and the barrier counter use relaxed agent-scope atomics (sc1 accesses: coherent across the 8 XCD L2s) and an
+// explicit s_waitcnt instead of fences, so no L2 write-back / invalidate disturbs the voxel kernels running beside it.
+constexpr uint32_t COOP_THREADS = 256, COOP_MAX_GROUPS = 64, COOP_ROWS_PER_GROUP = 8, COOP_SPIN_LIMIT = 1u << 22;
+
+BF_DEV void coopPublish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BF_DEV float coopRead(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all workgroups of the launch arrive; returns false when a peer never shows up (never expected: every group is resident
+// on its own CU; the bound turns a scheduling surprise into an error instead of a hung queue)
+BF_DEV bool gridBarrier(uint32_t* counter, uint32_t target, int* shFail) {
+    __builtin_amdgcn_s_waitcnt(0);                   // this wave's published stores have reached the coherence point
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > COOP_SPIN_LIMIT) { *shFail = 1; break; }
+        }
+    }
+    __syncthreads();
+    return *shFail == 0;
+}
+
+__global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t gnIter, int lastGN, uint32_t ldsFloats) {
+    if (d.flags[FL_DONE]) return;
+    extern __shared__ __align__(16) float coopLds[];
+    float* const dynLds = coopLds;
+    __shared__ float sh[16];
+    __shared__ int shFail;
+    const uint32_t N = d.N, n6 = 6 * N, G = gridDim.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = COOP_THREADS >> 6;
+    float* const P = dynLds;
+    float* const R = dynLds + n6;
+    float* const X = dynLds + 2 * n6;
+    float* const AP = dynLds + 3 * n6;
+    float* const M = dynLds + 4 * n6;
+    uint32_t* const RS = reinterpret_cast<uint32_t*>(dynLds + 5 * n6);
+    // rows [r0, r1) belong to this workgroup
+    const uint32_t rpg = (N - 1 + G - 1) / G;
+    const uint32_t r0 = min(N, 1 + blockIdx.x * rpg), r1 = min(N, r0 + rpg);
+    float* const DG = dynLds + 5 * n6 + (N + 1);                              // diagonal blocks of the own rows
+    float* const OL = dynLds + ((5 * n6 + (N + 1) + rpg * 36 + 3) & ~3u);      // off-diagonal blocks (16-byte aligned), then one column index per slot
+    if (threadIdx.x == 0) shFail = 0;
+    for (uint32_t t = threadIdx.x; t < n6; t += COOP_THREADS) M[t] = d.prec[t];
+    for (uint32_t t = threadIdx.x; t <= N; t += COOP_THREADS) RS[t] = d.rowStart[t];
+    for (uint32_t t = threadIdx.x; t < (r1 - r0) * 36; t += COOP_THREADS) DG[t] = d.diagA[(size_t)r0 * 36 + t];
+    __syncthreads();
+    const uint32_t sBase = RS[r0], sEnd = RS[r1];
+    const uint32_t ldsSlots = min(sEnd - sBase, (ldsFloats - (uint32_t)(OL - dynLds)) / 37u);
+    uint32_t* const CL = reinterpret_cast<uint32_t*>(OL + (size_t)ldsSlots * 36);
+    {
+        const float4* src = reinterpret_cast<const float4*>(d.slotO + (size_t)sBase * 36);
+        float4* dst = reinterpret_cast<float4*>(OL);
+        for (uint32_t t = threadIdx.x; t < ldsSlots * 9; t += COOP_THREADS) dst[t] = src[t];
+        for (uint32_t t = threadIdx.x; t < ldsSlots; t += COOP_THREADS) CL[t] = d.slotCol[sBase + t];
+    }
+    // Initialization (SolverBundling.cu:755-794): r = -J^T F, p = M^-1 r, delta = 0
+    float part = 0.0f;
+    for (uint32_t t = threadIdx.x; t < n6; t += COOP_THREADS) {
+        const bool var = t >= 6;
+        const float rr = var ? d.rhs[t] : 0.0f;
+        const float pp = var ? M[t] * rr : 0.0f;
+        R[t] = rr; P[t] = pp; X[t] = 0.0f;
+        part += rr * pp;
+    }
+    float rzOld = blockSum(part, sh);
+    float* const xchg[2] = {d.Ap, d.p};                                        // exchange vectors (the single-workgroup kernel's Ap and p)
+    uint32_t* const counter = reinterpret_cast<uint32_t*>(d.gridBar) + gnIter;
+    uint32_t it = 0;
+    for (uint32_t lin = 0; lin < nLin; ++lin) {
+        bool last = (lin == nLin - 1);
+        ++it;
+        __syncthreads();
+        float* const out = G > 1 ? xchg[lin & 1] : AP;
+        // Ap for the own rows: one wave per row, 8 lanes per off-diagonal block (lane a < 6 = row a of the 6x6 block)
+        {
+            const uint32_t g8 = lane >> 3, a = lane & 7;
+            for (uint32_t i = r0 + wave; i < r1; i += nWaves) {
+                const uint32_t s0 = RS[i], s1 = RS[i + 1];
+                float acc = 0.0f;
+                if (a < 6) {
+                    for (uint32_t s = s0 + g8; s < s1; s += 8) {
+                        const uint32_t ls = s - sBase;
+                        float o0, o1, o2, o3, o4, o5; uint32_t col;
+                        if (ls < ldsSlots) {
+                            const float* O = OL + (size_t)ls * 36 + a * 6;
+                            o0 = O[0]; o1 = O[1]; o2 = O[2]; o3 = O[3]; o4 = O[4]; o5 = O[5]; col = CL[ls];
+                        } else {
+                            const float* O = d.slotO + (size_t)s * 36 + a * 6;
+                            o0 = O[0]; o1 = O[1]; o2 = O[2]; o3 = O[3]; o4 = O[4]; o5 = O[5]; col = d.slotCol[s];
+                        }
+                        const float* pj = P + 6 * col;
+                        acc += ((((o0 * pj[0] + o1 * pj[1]) + o2 * pj[2]) + o3 * pj[3]) + o4 * pj[4]) + o5 * pj[5];
+                    }
+                }
+                acc += __shfl_xor(acc, 8, 64); acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
+                if (lane < 6) {
+                    const float* A = DG + (size_t)(i - r0) * 36 + lane * 6;
+                    const float* pi = P + 6 * i;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) v += A[b] * pi[b];
+                    if (G > 1) coopPublish(out + 6 * i + lane, v + acc); else out[6 * i + lane] = v + acc;
+                }
+            }
+        }
+        part = 0.0f;
+        if (G > 1) {
+            if (!gridBarrier(counter, G * it, &shFail)) { if (threadIdx.x == 0) d.flags[FL_BARRIER_FAIL] = 1; return; }
+            for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) { const float ap = coopRead(out + t); AP[t] = ap; part += P[t] * ap; }
+        } else {
+            __syncthreads();
+            for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) part += P[t] * AP[t];
+        }
+        const float pAp = blockSum(part, sh);                                      // PCGStep_Kernel1b
+        const float alpha = pAp > FLOAT_EPSILON ? rzOld / pAp : 0.0f;             // PCGStep_Kernel2 :948-983
+        part = 0.0f;
+        for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) {           // each thread re-reads its own AP[t]: no barrier needed
+            X[t] = X[t] + alpha * P[t];
+            const float rr = R[t] - alpha * AP[t];
+            R[t] = rr;
+            part += (M[t] * rr) * rr;
+        }
+        const float rzNew = blockSum(part, sh);
+        if (fabsf(pAp) < 5e-7f) last = true;                                      // :1088-1093
+        const float beta = rzOld > FLOAT_EPSILON ? rzNew / rzOld : 0.0f;          // PCGStep_Kernel3 :985-1022
+        rzOld = rzNew;
+        for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) P[t] = M[t] * R[t] + beta * P[t];
+        if (last) break;
+    }
+    if (blockIdx.x != 0) return;
+    __syncthreads();
+    // Lie update (computeLieUpdate, LieDerivUtil.h:301-307) + GN convergence (EvalGNConvergence :694-749)
+    float mx = 0.0f;
+    for (uint32_t i = 1 + threadIdx.x; i < N; i += COOP_THREADS) {
+        const f3 dT = ld3(X + 6 * i), dW = ld3(X + 6 * i + 3);
         f3 nw, nt;
         lieUpdate(dW, dT, ld3(d.xRot + 3 * i), ld3(d.xTrans + 3 * i), nw, nt);
         d.xRot[3 * i] = nw.x; d.xRot[3 * i + 1] = nw.y; d.xRot[3 * i + 2] = nw.z;
@@ -780,7 +961,8 @@ struct bf_solver {
     hipStream_t stream = nullptr;
     std::vector<void*> allocations;
     std::vector<float> convergence;
-    float hMaxRes = 0.0f; int hMaxIdx = 0;
+    float hMaxRes = 0.0f; int hMaxIdx = 0; int hBarrierFail = 0;
+    int pcgGroups = -1;                  // BF_PCG_GROUPS: -1 automatic, 0 single-workgroup kernel, n forced group count
     uint32_t lastN = 0, lastGNrequested = 0;
     float lastWeightSparse = 1.0f;
     bool lastUsedDense = false;
@@ -805,6 +987,9 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
     bf_solver* s = new bf_solver();
     s->cfg = *cfg;
     s->maxImages = maxNumberOfImages; s->maxResiduals = maxNumResiduals;
+    BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
+    BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
+    if (const char* e = getenv("BF_PCG_GROUPS")) s->pcgGroups = atoi(e);        // 0: single-workgroup kernel, n > 0: force n groups
     s->maxCorrPerImage = std::min(std::max(maxNumResiduals / maxNumberOfImages, 1000u), 4000u);   // .cpp:39
     const size_t N = maxNumberOfImages, M = N * N, C = maxNumResiduals;
     Dev& d = s->d;
@@ -819,7 +1004,7 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
               sAlloc(s, &d.slotP, (size_t)d.maxSlots * 4) && sAlloc(s, &d.diagA, N * 36) && sAlloc(s, &d.rhs, N * 6) && sAlloc(s, &d.prec, N * 6) &&
               sAlloc(s, &d.delta, N * 6) && sAlloc(s, &d.r, N * 6) && sAlloc(s, &d.p, N * 6) && sAlloc(s, &d.Ap, N * 6) &&
               sAlloc(s, &d.densePairs, (size_t)d.maxPairs) && sAlloc(s, &d.denseWeight, (size_t)d.maxPairs) &&
-              sAlloc(s, &d.denseBlocks, (size_t)d.maxPairs * DENSE_BLK) && sAlloc(s, &d.flags, FL_COUNT) && sAlloc(s, &d.energies, 40) &&
+              sAlloc(s, &d.denseBlocks, (size_t)d.maxPairs * DENSE_BLK) && sAlloc(s, &d.flags, FL_COUNT) && sAlloc(s, &d.gridBar, 32) && sAlloc(s, &d.energies, 40) &&
               sAlloc(s, &d.maxRes, 1) && sAlloc(s, &d.maxIdx, 1) && sAlloc(s, &d.highCount, 1) && sAlloc(s, &d.numEntriesPerRow, N);
     if (!ok) { set_error("bf_solver_create: hipMalloc failed"); bf_solver_destroy(s); return BF_ERR_HIP; }
     (void)hipMemset(d.flags, 0, FL_COUNT * sizeof(int));
@@ -866,6 +1051,7 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
     hipStream_t st = s->stream;
     const size_t M = (size_t)N * N;
     BF_HIP_TRY(hipMemsetAsync(d.flags, 0, FL_COUNT * sizeof(int), st));
+    BF_HIP_TRY(hipMemsetAsync(d.gridBar, 0, 32 * sizeof(int), st));
     const bool record = s->cfg.recordConvergence != 0;
     if (record) hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, st, d, wS[0], 0u, 0);
     bool anyDense = false;
@@ -893,7 +1079,18 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
         }
         hipLaunchKernelGGL(k_slots, dim3(std::min<uint32_t>(div_up(d.maxSlots, 4), 2048u)), dim3(256), 0, st, d, c, useDense);
         hipLaunchKernelGGL(k_rows, dim3(div_up(N, 4)), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(k_pcg, dim3(1), dim3(1024), 0, st, d, nLin, it, (int)(it == nNonLin - 1));
+        {
+            uint32_t G = N <= 32 ? 1u : std::min(COOP_MAX_GROUPS, div_up(N - 1, COOP_ROWS_PER_GROUP));
+            if (s->pcgGroups > 0) G = std::min<uint32_t>((uint32_t)s->pcgGroups, N - 1);
+            const uint32_t rpg = div_up(N - 1, G);
+            const size_t baseFloats = ((size_t)31 * N + 1 + (size_t)rpg * 36 + 3) & ~(size_t)3;    // 5 vectors, row offsets, own diagonal blocks
+            const size_t ldsFloats = std::min<size_t>(PCG_LDS_MAX / 4, baseFloats + (size_t)rpg * std::min<uint32_t>(N - 1, 96u) * 37);
+            if (s->pcgGroups != 0 && nNonLin <= 32 && baseFloats + 37 * 8 <= PCG_LDS_MAX / 4)
+                hipLaunchKernelGGL(k_pcg_coop, dim3(G), dim3(COOP_THREADS), ldsFloats * 4, st, d, nLin, it, (int)(it == nNonLin - 1), (uint32_t)ldsFloats);
+            else if ((size_t)N * 124 + 4 <= PCG_LDS_MAX)                              // 5 vectors of 6N floats + N+1 row offsets
+                hipLaunchKernelGGL(k_pcg<true>, dim3(1), dim3(1024), (size_t)N * 124 + 4, st, d, nLin, it, (int)(it == nNonLin - 1));
+            else hipLaunchKernelGGL(k_pcg<false>, dim3(1), dim3(1024), 0, st, d, nLin, it, (int)(it == nNonLin - 1));
+        }
         if (record) hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, st, d, c.wSparse, it + 1, 1);
     }
     BF_HIP_TRY(hipGetLastError());
@@ -903,7 +1100,9 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
             hipLaunchKernelGGL(k_max_residual, dim3(1), dim3(1024), 0, st, d, s->lastWeightSparse);
             BF_HIP_TRY(hipMemcpyAsync(&s->hMaxRes, d.maxRes, 4, hipMemcpyDeviceToHost, st));
             BF_HIP_TRY(hipMemcpyAsync(&s->hMaxIdx, d.maxIdx, 4, hipMemcpyDeviceToHost, st));
+            BF_HIP_TRY(hipMemcpyAsync(&s->hBarrierFail, d.flags + FL_BARRIER_FAIL, 4, hipMemcpyDeviceToHost, st));
             BF_HIP_TRY(hipStreamSynchronize(st));
+            BF_REQUIRE(s->hBarrierFail == 0, "PCG grid barrier timed out (a workgroup of k_pcg_coop was never scheduled)");
         } else { s->hMaxRes = 0.0f; s->hMaxIdx = 0; }
     }
     if (record) {
@@ -971,6 +1170,7 @@ int bf_solver_get_iteration_counts(bf_solver* s, int32_t* out, uint32_t cap) {
     int flags[FL_COUNT];
     BF_HIP_TRY(hipMemcpyAsync(flags, s->d.flags, sizeof flags, hipMemcpyDeviceToHost, s->stream));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    BF_REQUIRE(flags[FL_BARRIER_FAIL] == 0, "PCG grid barrier timed out (a workgroup of k_pcg_coop was never scheduled)");
     out[0] = flags[FL_GN_ITERS];
     for (uint32_t k = 1; k < cap && k <= 32; ++k) out[k] = (int)k <= flags[FL_GN_ITERS] ? flags[FL_PCG_ITERS + k - 1] : 0;
     return BF_OK;

@@ -113,6 +113,32 @@ def test_invalid_entries_and_run_to_run_determinism(gpu, oracle):
     assert np.abs(a[4][0] - a[3][0]).max() < 1e-4 and np.abs(a[4][1] - a[3][1]).max() < 1e-4
 
 
+def test_pcg_result_independent_of_workgroup_count(gpu, oracle, monkeypatch):
+    """The cooperative PCG (one grid barrier per iteration, CG vectors carried redundantly per workgroup) must give the same
+    bits for any number of workgroups; the single-workgroup kernel (another reduction partition) agrees to round-off."""
+    n = 150
+    corr, T_gt, T_init = bs.sparse_problem(n_images=n, pair_prob=0.3, seed=4)
+    rot0, tr0 = oracle.matrices_to_poses(T_init)
+    valid = np.ones(n, np.int32)
+    out = {}
+    for groups in ("", "1", "7", "64", "0"):
+        if groups:
+            monkeypatch.setenv("BF_PCG_GROUPS", groups)
+        else:
+            monkeypatch.delenv("BF_PCG_GROUPS", raising=False)
+        solver = gpu.capi.Solver(n, len(corr), default_solver_config(record_convergence=False))
+        grot, gtr = _dev(rot0.copy()), _dev(tr0.copy())
+        solver.solve(_dev(corr.view(np.uint8)), len(corr), _dev(valid), n, 3, 150, None, [1.0] * 3, [0.0] * 3, [0.0] * 3, grot, gtr, find_max_residual=True)
+        out[groups] = (grot.cpu().numpy(), gtr.cpu().numpy(), solver.iteration_counts())
+    monkeypatch.delenv("BF_PCG_GROUPS", raising=False)
+    for groups in ("1", "7", "64"):
+        assert np.array_equal(out[groups][0], out[""][0]) and np.array_equal(out[groups][1], out[""][1]), groups
+        assert out[groups][2] == out[""][2]
+    assert np.abs(out["0"][0] - out[""][0]).max() < 1e-4 and np.abs(out["0"][1] - out[""][1]).max() < 1e-4
+    dt, dR = bs.pose_errors(oracle.poses_to_matrices(*out[""][:2]), T_gt)
+    assert dt < 2e-2 and dR < 2e-2
+
+
 def _dense_pair(gpu, oracle, n_frames, width=160, height=120, perturb=(0.004, 0.01)):
     frames, K, T_gt, T_init = bs.dense_chunk(n_frames=n_frames, width=width, height=height, perturb=perturb)
     Kin = intrinsics_matrix(K["fx"], K["fy"], K["mx"], K["my"])

@@ -1,15 +1,26 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd sqlite database (`*_results.db`) as a per-kernel stats table
-(the same content as `rocprofv3 --stats` CSV output).  usage: rocpd_stats.py <db> [out.md]"""
+(the same content as `rocprofv3 --stats` CSV output).  usage: rocpd_stats.py <db> [out.md] [--last FRACTION]
+`--last 0.15` restricts the table to dispatches that start in the last 15 % of the traced time span."""
 import sqlite3
 import sys
 
 
 def main():
+    where = ""
+    if "--last" in sys.argv:
+        i = sys.argv.index("--last")
+        frac = float(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
+    else:
+        frac = None
     db = sys.argv[1]
     c = sqlite3.connect(db)
+    if frac is not None:
+        t0, t1 = c.execute("select min(start), max(end) from kernels").fetchone()
+        where = " where start >= %d" % int(t1 - frac * (t1 - t0))
     rows = c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
-                     "max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
+                     "max(end-start)/1e3 from kernels" + where + " group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows) or 1.0
     lines = ["| kernel | calls | total_us | avg_us | min_us | max_us | pct |", "|---|---|---|---|---|---|---|"]
     for r in rows:

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--host", action="store_true", help="hand over host buffers (PCIe path) instead of HBM-resident frames")
     ap.add_argument("--tail", type=int, default=5, help="end-of-sequence iterations")
     ap.add_argument("--timings", action="store_true")
+    ap.add_argument("--timings-from", type=int, default=-1, help="switch the synchronous per-stage timings on at this frame")
     ap.add_argument("--bob", type=float, default=0.0, help="vertical sinusoid amplitude of the trajectory [m] (SURVEY.md 8d config 4: 0.3)")
     ap.add_argument("--maximages", type=int, default=0)
     a = ap.parse_args()
@@ -59,10 +60,12 @@ def main():
     tl = []
     marks = []
     for k in range(a.frames):
+        if k == a.timings_from:
+            p.synchronize(); p.enable_timings(True); a.timings = True
         ok = p.process_frame(*(dev[k] if dev else (frames[k][0], frames[k][1])))
         assert ok
         if a.timings:
-            tl.append(p.last_timing())
+            tl.append(dict(p.last_timing(), frame=k))
         if (k + 1) % 1000 == 0:
             p.synchronize(); marks.append((k + 1, time.time() - t0))
     for _ in range(a.tail):
@@ -87,10 +90,12 @@ def main():
     sc = p.scene()
     print("allocated blocks", sc.num_allocated_blocks(), "heap free", sc.heap_free_count(), "debug", sc.debug_hash())
     if tl:
-        keys = list(tl[0].keys())
-        arr = np.array([[t[k] for k in keys] for t in tl[2:]])
-        print("mean ms per stage:", {k: round(float(v), 3) for k, v in zip(keys, arr.mean(0))})
-        print("max  ms per stage:", {k: round(float(v), 3) for k, v in zip(keys, arr.max(0))})
+        keys = [k for k in tl[0].keys() if k != "frame"]
+        for name, sel in (("all frames", lambda f: True), ("chunk-end frames", lambda f: f % 10 == 9), ("other frames", lambda f: f % 10 != 9)):
+            arr = np.array([[t[k] for k in keys] for t in tl[2:] if sel(t["frame"])])
+            if len(arr):
+                print(name, "mean ms per stage:", {k: round(float(v), 3) for k, v in zip(keys, arr.mean(0))})
+                print(name, "max  ms per stage:", {k: round(float(v), 3) for k, v in zip(keys, arr.max(0))})
 
 
 if __name__ == "__main__":
