@@ -217,6 +217,10 @@ BF_DEV void emitCandidate(const Dev& d, const Frame& f, i3 b) {
     atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
 }
 
+// Neighbouring pixels of the 8x8 tile walk through the same 8^3 block at the same DDA step most of the time (a block is ~9
+// pixels wide at 2 m); a lane whose left or upper neighbour holds the same block this step leaves the frustum test and the
+// hash-bucket look-up (320 bytes of random traffic) to that neighbour.  Queuing a block is idempotent, so the set of
+// candidates is unchanged.  All 64 lanes stay in the loop (alive flag) so that the lane exchange is well defined.
 __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth) {
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
     const uint32_t tilesX = (W + 7) / 8;
@@ -224,14 +228,14 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7);
     const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
-    if (x >= W || y >= H) return;
-    const float dd = depth[(size_t)y * W + x];
-    if (dd == BF_MINF || dd == 0.0f) return;
-    if (dd >= f.maxIntegrationDistance) return;
+    bool alive = x < W && y < H;
+    const float dd = alive ? depth[(size_t)y * W + x] : BF_MINF;
+    if (dd == BF_MINF || dd == 0.0f) alive = false;
+    if (dd >= f.maxIntegrationDistance) alive = false;
     const float t = f.truncation + f.truncScale * dd;
     const float minDepth = fminf(f.maxIntegrationDistance, dd - t);
     const float maxDepth = fminf(f.maxIntegrationDistance, dd + t);
-    if (minDepth >= maxDepth) return;
+    if (minDepth >= maxDepth) alive = false;
     const float kx = ((float)x - f.cam.mx) / f.cam.fx;
     const float ky = ((float)y - f.cam.my) / f.cam.fy;
     const f3 rayMin = xform(f.T, mk3(minDepth * kx, minDepth * ky, minDepth));
@@ -262,19 +266,27 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
     if (rayDir.z == 0.0f) { tMax.z = BF_PINF; tDelta.z = BF_PINF; }
     if (boundary.z - rayMin.z == 0.0f) { tMax.z = BF_PINF; tDelta.z = BF_PINF; }
     for (unsigned iter = 0; iter < 1024; ++iter) {
-        if (blockInFrustum(f, cur)) emitCandidate(d, f, cur);
-        if (tMax.x < tMax.y && tMax.x < tMax.z) {
-            cur.x = f2i((float)cur.x + step.x);
-            if (cur.x == bound.x) return;
-            tMax.x += tDelta.x;
-        } else if (tMax.z < tMax.y) {
-            cur.z = f2i((float)cur.z + step.z);
-            if (cur.z == bound.z) return;
-            tMax.z += tDelta.z;
-        } else {
-            cur.y = f2i((float)cur.y + step.y);
-            if (cur.y == bound.y) return;
-            tMax.y += tDelta.y;
+        if (!__any((int)alive)) break;
+        const int live = alive ? 1 : 0;
+        const int lx = __shfl_up(cur.x, 1, 64), ly = __shfl_up(cur.y, 1, 64), lz = __shfl_up(cur.z, 1, 64), ll = __shfl_up(live, 1, 64);
+        const int ux = __shfl_up(cur.x, 8, 64), uy = __shfl_up(cur.y, 8, 64), uz = __shfl_up(cur.z, 8, 64), ul = __shfl_up(live, 8, 64);
+        const bool sameLeft = (lane & 7) != 0 && ll && lx == cur.x && ly == cur.y && lz == cur.z;
+        const bool sameUp = lane >= 8 && ul && ux == cur.x && uy == cur.y && uz == cur.z;
+        if (alive) {
+            if (!sameLeft && !sameUp && blockInFrustum(f, cur)) emitCandidate(d, f, cur);
+            if (tMax.x < tMax.y && tMax.x < tMax.z) {
+                cur.x = f2i((float)cur.x + step.x);
+                if (cur.x == bound.x) alive = false;
+                tMax.x += tDelta.x;
+            } else if (tMax.z < tMax.y) {
+                cur.z = f2i((float)cur.z + step.z);
+                if (cur.z == bound.z) alive = false;
+                tMax.z += tDelta.z;
+            } else {
+                cur.y = f2i((float)cur.y + step.y);
+                if (cur.y == bound.y) alive = false;
+                tMax.y += tDelta.y;
+            }
         }
     }
 }
@@ -343,7 +355,9 @@ BF_DEV uint32_t binPrefix(const uint32_t* binCount, uint32_t limit, uint32_t* sc
 // alloc, pass B: one workgroup per bin — sort, rank, place into home buckets
 //   (serial-equivalent of allocBlock's in-bucket branch, VoxelUtilHashSDF.h:553-612)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_alloc_insert(Dev d, Frame f) {
+// 256 threads: the usual bin holds a handful of new keys, and four waves find a free CU next to the voxel kernels much sooner
+// than sixteen; a full bin (4096 records, first frames of a scan) sorts in ~10 us either way.
+__global__ __launch_bounds__(256) void k_alloc_insert(Dev d, Frame f) {
     __shared__ SortLds s;
     __shared__ uint32_t scratch[16];
     __shared__ int8_t sel[BINCAP];
@@ -581,7 +595,17 @@ BF_DEV bool voxelSample(const Frame& f, int4 e, int lx, int ly, int lz, const fl
     return true;
 }
 
-// combineVoxel / its inverse on (sdf, weight, packed colour); DEINT resets a voxel whose weight drops to zero
+// combineVoxel / its inverse on (sdf, weight, packed colour); DEINT resets a voxel whose weight drops to zero.
+//
+// The update kernels are VALU-bound (nine IEEE divisions and six roundf per re-integrated voxel), so the colour channels use
+// two shortcuts that give the same bytes as the reference expressions (the CPU oracle keeps those expressions; the parity
+// tests compare the volumes bit for bit).  Both rest on the fact that weights are whole numbers (0, +1 per frame, capped at the
+// integer integrationWeightMax) and colours are bytes:
+//   * integrate: 0.2 c + 0.8 o = (c + 4 o) / 5 is never within 0.1 of a half, so roundf == round-to-nearest-even (v_rndne);
+//   * de-integrate: (o w - c) / (w - 1) is a ratio of integers I / J with 1 <= J <= 98.  Its distance to a rounding tie k + 1/2
+//     is either 0 or at least 1/196, so a reciprocal-based quotient (error < 1e-4 below 256) plus a 1/512 guard reproduces
+//     roundf(RN(I / J)) exactly, ties included; everything at or above 254 ends at 254 and everything negative at 0 like the
+//     reference's clamps.  Voxels whose weight drops to zero (J <= 0) are reset, whatever the quotient was.
 template <bool DEINT>
 BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float& vW, uint32_t& vC) {
     const float c0 = (float)cc.x, c1 = (float)cc.y, c2 = (float)cc.z;
@@ -594,23 +618,31 @@ BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float&
         float r0, r1, r2;
         if (oW == 0.0f) { r0 = c0; r1 = c1; r2 = c2; }
         else { r0 = 0.2f * c0 + 0.8f * o0; r1 = 0.2f * c1 + 0.8f * o1; r2 = 0.2f * c2 + 0.8f * o2; }
-        r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
-        r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
-        r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
+        r0 = fmaxf(0.0f, fminf(__builtin_rintf(r0), 254.5f));
+        r1 = fmaxf(0.0f, fminf(__builtin_rintf(r1), 254.5f));
+        r2 = fmaxf(0.0f, fminf(__builtin_rintf(r2), 254.5f));
         nC = (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;      // r in [0, 254.5] after the clamps, never NaN
         nSdf = (sdf * 1.0f + oSdf * oW) / (1.0f + oW);
         nW = fminf(f.weightMax, 1.0f + oW);
     } else {
-        float r0 = (o0 * oW - c0 * 1.0f) / (oW - 1.0f);
-        float r1 = (o1 * oW - c1 * 1.0f) / (oW - 1.0f);
-        float r2 = (o2 * oW - c2 * 1.0f) / (oW - 1.0f);
-        r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
-        r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
-        r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
-        nC = (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;
-        nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
         nW = fmaxf(0.0f, oW - 1.0f);
-        if (nW <= 0.001f) { nSdf = 0.0f; nC = 0u; nW = 0.0f; }
+        if (nW <= 0.001f) {
+            nSdf = 0.0f; nC = 0u; nW = 0.0f;
+        } else {
+            const float J = oW - 1.0f;                                   // whole number >= 1
+            const float y = __builtin_amdgcn_rcpf(J);
+            const float i0 = o0 * oW - c0 * 1.0f, i1 = o1 * oW - c1 * 1.0f, i2 = o2 * oW - c2 * 1.0f;   // exact integers
+            float q0 = i0 * y, q1 = i1 * y, q2 = i2 * y;
+            q0 = __builtin_fmaf(__builtin_fmaf(-J, q0, i0), y, q0);      // one residual correction: |q - I/J| < 1e-4 for |q| < 256
+            q1 = __builtin_fmaf(__builtin_fmaf(-J, q1, i1), y, q1);
+            q2 = __builtin_fmaf(__builtin_fmaf(-J, q2, i2), y, q2);
+            const float half = 0.5f + 1.0f / 512.0f;
+            const float r0 = fmaxf(0.0f, fminf(truncf(q0 + half), 254.0f));
+            const float r1 = fmaxf(0.0f, fminf(truncf(q1 + half), 254.0f));
+            const float r2 = fmaxf(0.0f, fminf(truncf(q2 + half), 254.0f));
+            nC = (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;
+            nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
+        }
     }
     vSdf = nSdf; vW = nW; vC = nC;
 }
@@ -902,7 +934,7 @@ int refreshStaleList(bf_scene* s) {                              // a fused re-i
 void launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_depth) {      // alloc :328-352
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
     hipLaunchKernelGGL(k_alloc_candidates, dim3(div_up(tiles, 4)), dim3(256), 0, st, s->d, f, d_depth);
-    hipLaunchKernelGGL(k_alloc_insert, dim3(NBINS), dim3(1024), 0, st, s->d, f);
+    hipLaunchKernelGGL(k_alloc_insert, dim3(NBINS), dim3(256), 0, st, s->d, f);
     hipLaunchKernelGGL(k_alloc_finish, dim3(1), dim3(1024), 0, st, s->d, f);
 }
 

@@ -122,7 +122,7 @@ mx = max_over_ranks(elapsed)
 rate = whole_job_rate(last - first, elapsed)
 same = same_over_ranks(torch.arange(12, dtype=torch.float32).reshape(3, 4) * 0.37)
 diff = same_over_ranks(torch.full((4,), 1.0 + 1e-7 * r))
-print("RESULT", r, first, last, mx, rate, int(same), int(diff), flush=True)
+os.write(1, ("RESULT {} {} {} {!r} {!r} {} {}\\n".format(r, first, last, mx, rate, int(same), int(diff))).encode())   # one write: lines of two ranks never interleave
 dist.destroy_process_group()
 '''
 
