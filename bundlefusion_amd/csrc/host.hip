@@ -894,6 +894,13 @@ struct bf_online_bundler {
     bool bUseSolve = true;
     uint32_t totalNumOptLocalFrames = 0;
     uint32_t numLocalSolves = 0, numGlobalSolves = 0;
+    // Detect-ahead (bf_online_bundler_detect_ahead): SIFT detection and the dense cache frame of a frame depend on its pixels only,
+    // so they can be computed on their own stream into a two-slot staging bundler while the previous frame is still being
+    // matched / solved; processInput then commits the staged slot (one copy kernel) instead of detecting.
+    bf_bundler* stage = nullptr;
+    hipStream_t detectStream = nullptr;
+    hipEvent_t evDetect[2] = {nullptr, nullptr}, evStageFree[2] = {nullptr, nullptr};
+    int stagedFrame[2] = {-1, -1};
     // processInput in flight (between _begin and _end)
     int pendPhase = 0; uint32_t pendFrame = 0, pendCur = 0, pendNum = 0; bool pendLastLocal = false, pendMatch = false;
     bool isLastLocalFrame(uint32_t curFrame) const { return curFrame >= submapSize && (curFrame % submapSize) == 0; }
@@ -1068,7 +1075,17 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
     if (!rc) rc = bf_bundler_create(S + 1, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 1, gas, gbs, &ob->optLocal);
     if (!rc) rc = bf_bundler_create(maxNumImages, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 0, gas, gbs, &ob->global);
     if (!rc) rc = bf_trajectory_manager_create(maxNumImages * S, gas->s_topNActive, gas->s_minPoseDistSqrt, &ob->tm);
+    if (!rc) rc = bf_bundler_create(2, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 1, gas, gbs, &ob->stage);
+    for (int k = 0; k < 2 && !rc; ++k) {                     // the two staging slots exist from the start (empty images)
+        bf_sift_image_gpu img;
+        rc = bf_siftmgr_create_image(ob->stage->mgr, &img);
+        if (!rc) rc = bf_siftmgr_finalize_image(ob->stage->mgr, 0);
+    }
     if (rc) { bf_online_bundler_destroy(ob); return rc; }
+    for (int k = 0; k < 2; ++k) {
+        BF_HIP_TRY(hipEventCreateWithFlags(&ob->evDetect[k], hipEventDisableTiming));
+        BF_HIP_TRY(hipEventCreateWithFlags(&ob->evStageFree[k], hipEventDisableTiming));
+    }
     const size_t nAll = (size_t)maxNumImages * S;
     BF_HIP_TRY(hipMalloc((void**)&ob->d_intensitySIFT, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
     BF_HIP_TRY(hipMalloc((void**)&ob->d_intensityFilterHelper, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
@@ -1093,7 +1110,8 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
 
 int bf_online_bundler_destroy(bf_online_bundler* ob) {
     if (!ob) return BF_OK;
-    bf_bundler_destroy(ob->local); bf_bundler_destroy(ob->optLocal); bf_bundler_destroy(ob->global); bf_trajectory_manager_destroy(ob->tm);
+    bf_bundler_destroy(ob->local); bf_bundler_destroy(ob->optLocal); bf_bundler_destroy(ob->global); bf_bundler_destroy(ob->stage); bf_trajectory_manager_destroy(ob->tm);
+    for (int k = 0; k < 2; ++k) { if (ob->evDetect[k]) (void)hipEventDestroy(ob->evDetect[k]); if (ob->evStageFree[k]) (void)hipEventDestroy(ob->evStageFree[k]); }
     (void)hipFree(ob->d_intensitySIFT); (void)hipFree(ob->d_intensityFilterHelper); (void)hipFree(ob->d_completeTrajectory); (void)hipFree(ob->d_localTrajectories);
     (void)hipFree(ob->d_siftTrajectory); (void)hipFree(ob->d_currIntegrateTransform); (void)hipFree(ob->d_imageInvalidateList);
     if (ob->h_pinT) (void)hipHostFree(ob->h_pinT);
@@ -1111,11 +1129,105 @@ int bf_online_bundler_set_stream(bf_online_bundler* ob, void* s) {
 // processInput (:167-227) in two halves: _begin enqueues everything up to the frame read-back, _end fetches the result and
 // finishes the host logic.  A caller may enqueue independent work (the re-integration of old frames on another stream)
 // between the two; bf_online_bundler_process_input is simply begin + end.
+int bf_online_bundler_set_detect_stream(bf_online_bundler* ob, void* s) {
+    BF_REQUIRE(ob, "null bundler");
+    ob->detectStream = (hipStream_t)s;
+    return bf_bundler_set_stream(ob->stage, s);
+}
+
+// Feature detection + dense cache frame of the image manager's current frame, into staging slot (frame & 1), on the detect
+// stream (which must also be the image manager's stream, so that it is ordered after the ingest).  No bundler state changes.
+int bf_online_bundler_detect_ahead(bf_online_bundler* ob) {
+    BF_REQUIRE(ob && ob->detectStream, "detect_ahead needs bf_online_bundler_set_detect_stream");
+    uint32_t frame;
+    BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &frame));
+    const int slot = (int)(frame & 1u);
+    BF_REQUIRE(ob->stagedFrame[slot] < 0, "staging slot still holds an uncommitted frame");
+    hipStream_t sd = ob->detectStream;
+    BF_HIP_TRY(hipStreamWaitEvent(sd, ob->evStageFree[slot], 0));          // the commit that last read this slot
+    BF_TRY(bf_image_resample_to_intensity(ob->d_intensitySIFT, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, sd));
+    if (ob->gas.s_colorFilter) {
+        BF_TRY(bf_image_gauss_filter_intensity(ob->d_intensityFilterHelper, ob->d_intensitySIFT, ob->gas.s_colorSigmaD, ob->widthSIFT, ob->heightSIFT, sd));
+        std::swap(ob->d_intensityFilterHelper, ob->d_intensitySIFT);
+    }
+    bf_sift_image_gpu img;
+    BF_TRY(bf_siftmgr_get_image(ob->stage->mgr, (uint32_t)slot, &img));
+    BF_TRY(bf_sift_run(ob->stage->sift, ob->d_intensitySIFT, ob->im->d_depthInputFiltered, (float*)img.d_keyPoints, (uint8_t*)img.d_keyPointDescs, img.d_numKeyPoints));
+    BF_TRY(bf_cache_set_current_frame(ob->stage->cache, (uint32_t)slot));
+    BF_TRY(bf_cache_store_frame(ob->stage->cache, ob->im->d_depthInputRaw, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH));
+    BF_HIP_TRY(hipEventRecord(ob->evDetect[slot], sd));
+    ob->stagedFrame[slot] = (int)frame;
+    return BF_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct CopySeg { uint32_t* dst; const uint32_t* src; uint32_t words; };
+struct CopySegs { CopySeg s[9]; };
+__global__ __launch_bounds__(256) void k_copy_segments(CopySegs j) {
+    const CopySeg c = j.s[blockIdx.y];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words; i += gridDim.x * blockDim.x) c.dst[i] = c.src[i];
+}
+
+// the staged detection of `frame` becomes the local bundler's next image (what detectFeatures + storeCachedFrame would have produced)
+int obCommitStaged(bf_online_bundler* ob, uint32_t frame) {
+    const int slot = (int)(frame & 1u);
+    BF_HIP_TRY(hipStreamWaitEvent(ob->stream, ob->evDetect[slot], 0));
+    bf_bundler *b = ob->local, *from = ob->stage;
+    bf_sift_image_gpu src, dst;
+    BF_TRY(bf_siftmgr_get_image(from->mgr, (uint32_t)slot, &src));
+    BF_TRY(bf_siftmgr_create_image(b->mgr, &dst));
+    uint32_t ci;
+    BF_TRY(bf_cache_get_num_frames(b->cache, &ci));
+    bf_cached_frame cs, cd;
+    BF_TRY(bf_cache_get_frame(from->cache, (uint32_t)slot, &cs));
+    BF_TRY(bf_cache_get_frame(b->cache, ci, &cd));
+    uint32_t cw, ch; float k4[4];
+    BF_TRY(bf_cache_get_geometry(b->cache, &cw, &ch, k4));
+    const uint32_t n = cw * ch, mk = std::min(b->maxKeys, from->maxKeys);
+    CopySegs j;
+    j.s[0] = {(uint32_t*)dst.d_keyPoints, (const uint32_t*)src.d_keyPoints, (uint32_t)(sizeof(bf_sift_keypoint) / 4) * mk};
+    j.s[1] = {(uint32_t*)dst.d_keyPointDescs, (const uint32_t*)src.d_keyPointDescs, (uint32_t)(sizeof(bf_sift_keypoint_desc) / 4) * mk};
+    j.s[2] = {(uint32_t*)dst.d_numKeyPoints, (const uint32_t*)src.d_numKeyPoints, 1u};
+    j.s[3] = {(uint32_t*)cd.d_depthDownsampled, (const uint32_t*)cs.d_depthDownsampled, n};
+    j.s[4] = {(uint32_t*)cd.d_cameraposDownsampled, (const uint32_t*)cs.d_cameraposDownsampled, 4 * n};
+    j.s[5] = {(uint32_t*)cd.d_intensityDownsampled, (const uint32_t*)cs.d_intensityDownsampled, n};
+    j.s[6] = {(uint32_t*)cd.d_intensityDerivsDownsampled, (const uint32_t*)cs.d_intensityDerivsDownsampled, 2 * n};
+    j.s[7] = {(uint32_t*)cd.d_normalsDownsampledUCHAR4, (const uint32_t*)cs.d_normalsDownsampledUCHAR4, n};
+    j.s[8] = {(uint32_t*)cd.d_normalsDownsampled, (const uint32_t*)cs.d_normalsDownsampled, 4 * n};
+    hipLaunchKernelGGL(k_copy_segments, dim3(32, 9), dim3(256), 0, ob->stream, j);
+    BF_HIP_TRY(hipGetLastError());
+    BF_TRY(bf_siftmgr_finalize_image(b->mgr, -1));
+    BF_TRY(bf_cache_increment(b->cache));
+    BF_HIP_TRY(hipEventRecord(ob->evStageFree[slot], ob->stream));
+    ob->stagedFrame[slot] = -1;
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int bf_online_bundler_process_input_begin(bf_online_bundler* ob) {
     BF_REQUIRE(ob, "null bundler");
-    BF_REQUIRE(ob->pendPhase == 0, "processInput already in flight");
     uint32_t curFrame;
     BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &curFrame));
+    return bf_online_bundler_process_input_begin_frame(ob, curFrame);
+}
+
+// processInput for an explicit frame: either the image manager's current frame (detected here, like the reference), or an
+// earlier frame whose detection was staged by bf_online_bundler_detect_ahead while newer frames were already ingested.
+int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t curFrame) {
+    BF_REQUIRE(ob, "null bundler");
+    BF_REQUIRE(ob->pendPhase == 0, "processInput already in flight");
+    const bool staged = ob->stagedFrame[curFrame & 1u] == (int)curFrame;
+    {
+        uint32_t imFrame;
+        BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &imFrame));
+        BF_REQUIRE(staged || imFrame == curFrame, "frame is neither staged nor the image manager's current frame");
+    }
     const bool bIsLastLocal = ob->isLastLocalFrame(curFrame);
     ob->pendFrame = curFrame; ob->pendLastLocal = bIsLastLocal; ob->pendMatch = false;
     if (curFrame > 0 && ob->lastFrameProcessed == (int)curFrame) {                 // sequence has ended
@@ -1135,14 +1247,17 @@ int bf_online_bundler_process_input_begin(bf_online_bundler* ob) {
         ob->pendPhase = 2;                                                          // nothing to read back
         return BF_OK;
     }
-    // getCurrentFrame (:106-116): luminance at SIFT resolution straight from the ingest buffer
-    BF_TRY(bf_image_resample_to_intensity(ob->d_intensitySIFT, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->stream));
-    if (ob->gas.s_colorFilter) {
-        BF_TRY(bf_image_gauss_filter_intensity(ob->d_intensityFilterHelper, ob->d_intensitySIFT, ob->gas.s_colorSigmaD, ob->widthSIFT, ob->heightSIFT, ob->stream));
-        std::swap(ob->d_intensityFilterHelper, ob->d_intensitySIFT);
+    if (staged) BF_TRY(obCommitStaged(ob, curFrame));
+    else {
+        // getCurrentFrame (:106-116): luminance at SIFT resolution straight from the ingest buffer
+        BF_TRY(bf_image_resample_to_intensity(ob->d_intensitySIFT, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->stream));
+        if (ob->gas.s_colorFilter) {
+            BF_TRY(bf_image_gauss_filter_intensity(ob->d_intensityFilterHelper, ob->d_intensitySIFT, ob->gas.s_colorSigmaD, ob->widthSIFT, ob->heightSIFT, ob->stream));
+            std::swap(ob->d_intensityFilterHelper, ob->d_intensitySIFT);
+        }
+        BF_TRY(bf_bundler_detect_features(ob->local, ob->d_intensitySIFT, ob->im->d_depthInputFiltered));
+        BF_TRY(bf_bundler_store_cached_frame(ob->local, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->im->d_depthInputRaw));
     }
-    BF_TRY(bf_bundler_detect_features(ob->local, ob->d_intensitySIFT, ob->im->d_depthInputFiltered));
-    BF_TRY(bf_bundler_store_cached_frame(ob->local, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->im->d_depthInputRaw));
     uint32_t curLocalFrame;
     BF_TRY(bf_bundler_get_curr_frame_number(ob->local, &curLocalFrame));
     if (bIsLastLocal) BF_TRY(bf_bundler_copy_frame(ob->optLocal, ob->local, curLocalFrame));
@@ -1238,6 +1353,12 @@ struct bf_pipeline {
     // TSDF operator.  Re-integration of old frames depends only on host-side lists and on frames ingested earlier, so it runs
     // concurrently with the current frame's feature pipeline; integration of the current frame waits for its ingest (evIngest).
     hipStream_t sBundle = nullptr, sVolume = nullptr;
+    // Look-ahead: ingest + feature detection + dense cache frame of frame k+1 run on a third stream (sDetect) while frame k is
+    // matched, filtered, integrated and solved; the body of frame k is executed by the call that delivers frame k+1 (or by the
+    // first call that needs its result).  The per-frame work and its order are unchanged, so are the results.
+    hipStream_t sDetect = nullptr;
+    bool lookahead = true;
+    int deferred = -1;              // frame whose body has not run yet
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
@@ -1345,53 +1466,75 @@ int plReintegrate(bf_pipeline* p) {                                             
     return BF_OK;
 }
 
-int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool device, bool haveInput, int* gotFrame) {    // :966-1095 (serial branch)
+// everything of the frame loop after the ingest, for frame `frame` (got: a new frame, as opposed to an iteration after the
+// sequence ended)                                                                                     :966-1095 (serial branch)
+int plBody(bf_pipeline* p, uint32_t frame, bool got) {
     hipStream_t sa = p->sBundle, sv = p->sVolume;
     const bool tm = p->timings;
-    // ---- read input (bundling stream)
-    if (tm) (void)hipEventRecord(p->ev[0], sa);
-    int got = 0;
-    if (haveInput) BF_TRY(device ? bf_image_manager_process_device(p->im, depth, color, &got) : bf_image_manager_process(p->im, depth, color, &got));
-    const int evSlot = got ? (int)((p->im->currFrame - 1) % bf_pipeline::NEV) : -1;
-    if (got) BF_HIP_TRY(hipEventRecord(p->evIngest[evSlot], sa));
-    if (tm) (void)hipEventRecord(p->ev[1], sa);
+    const int evSlot = got ? (int)(frame % bf_pipeline::NEV) : -1;
     // ---- processInput: enqueue (bundling stream) ...
-    const bool haveFrames = p->im->currFrame > 0;
-    if (haveFrames) BF_TRY(bf_online_bundler_process_input_begin(p->ob));
+    BF_TRY(bf_online_bundler_process_input_begin_frame(p->ob, frame));
     // ---- fix old frames (volume stream; launches issued by the volume thread), concurrently with the feature pipeline
     if (tm) (void)hipEventRecord(p->ev[4], sv);
     BF_TRY(plReintegrate(p));
     if (tm) (void)hipEventRecord(p->ev[5], sv);
     // ---- ... and its read-back
-    if (haveFrames) BF_TRY(bf_online_bundler_process_input_end(p->ob));
+    BF_TRY(bf_online_bundler_process_input_end(p->ob));
     if (tm) (void)hipEventRecord(p->ev[2], sa);
     // ---- reconstruction of the current frame (volume stream, after this frame's ingest)
     if (tm) (void)hipEventRecord(p->ev[6], sv);
     if (got) {
         float T[16]; uint32_t frameIdx = 0; int lost = 0, valid = 0;
         BF_TRY(bf_online_bundler_get_current_integration_frame(p->ob, T, &frameIdx, &lost, &valid));
-        uint32_t cur;
-        BF_TRY(bf_image_manager_get_curr_frame_number(p->im, &cur));
         if (valid && p->gas.s_reconstructionEnabled) {
             BF_TRY(plIntegrate(p, frameIdx, T, false, evSlot));
-            BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_INTEGRATED, T, cur));
+            BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_INTEGRATED, T, frame));
         } else {
             const m44 inv = minfM();
-            BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_NOT_INTEGRATED_NO_TRANSFORM, inv.e, cur));
+            BF_TRY(bf_trajectory_manager_add_frame(p->ob->tm, BF_TF_NOT_INTEGRATED_NO_TRANSFORM, inv.e, frame));
         }
     }
     if (tm) (void)hipEventRecord(p->ev[7], sv);
     // ---- bundling optimisation (bundling stream)
-    if (haveFrames)
-        BF_TRY(bf_online_bundler_process(p->ob, p->gbs.s_numLocalNonLinIterations, p->gbs.s_numLocalLinIterations, p->ob->gbs.s_numGlobalNonLinIterations,
-                                         p->gbs.s_numGlobalLinIterations));
+    BF_TRY(bf_online_bundler_process(p->ob, p->gbs.s_numLocalNonLinIterations, p->gbs.s_numLocalLinIterations, p->ob->gbs.s_numGlobalNonLinIterations,
+                                     p->gbs.s_numGlobalLinIterations));
+    return BF_OK;
+}
+
+// run the body of the frame that is still waiting for it
+int plFlush(bf_pipeline* p) {
+    if (p->deferred < 0) return BF_OK;
+    const uint32_t f = (uint32_t)p->deferred;
+    p->deferred = -1;
+    return plBody(p, f, true);
+}
+
+int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool device, bool haveInput, int* gotFrame) {
+    hipStream_t sa = p->sBundle, sd = p->sDetect;
+    const bool tm = p->timings;
+    // ---- read input (detect stream)
+    if (tm) (void)hipEventRecord(p->ev[0], sd);
+    int got = 0;
+    if (haveInput) BF_TRY(device ? bf_image_manager_process_device(p->im, depth, color, &got) : bf_image_manager_process(p->im, depth, color, &got));
+    const uint32_t frame = p->im->currFrame > 0 ? p->im->currFrame - 1 : 0;
+    if (got) BF_HIP_TRY(hipEventRecord(p->evIngest[frame % bf_pipeline::NEV], sd));
+    if (tm) { (void)hipEventRecord(p->ev[1], sd); BF_HIP_TRY(hipStreamWaitEvent(sa, p->ev[1], 0)); (void)hipEventRecord(p->ev[8], sa); }
+    if (got) BF_TRY(bf_online_bundler_detect_ahead(p->ob));
+    if (p->lookahead && !tm) {
+        BF_TRY(plFlush(p));                                   // frame - 1 (its detection was staged by the previous call)
+        if (got) p->deferred = (int)frame;
+        else if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, false));
+    } else {
+        BF_TRY(plFlush(p));
+        if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, got != 0));
+    }
     if (tm) {
         (void)hipEventRecord(p->ev[3], sa);
         (void)hipEventSynchronize(p->ev[3]);
         (void)hipEventSynchronize(p->ev[7]);
         memset(&p->last, 0, sizeof p->last);
         (void)hipEventElapsedTime(&p->last.timeSensorProcess, p->ev[0], p->ev[1]);
-        (void)hipEventElapsedTime(&p->last.timeSiftDetection, p->ev[1], p->ev[2]);        // SIFT + cache + match + filters + read-back
+        (void)hipEventElapsedTime(&p->last.timeSiftDetection, p->ev[8], p->ev[2]);        // SIFT + cache + match + filters + read-back
         (void)hipEventElapsedTime(&p->last.timeSolve, p->ev[2], p->ev[3]);
         (void)hipEventElapsedTime(&p->last.timeReIntegrate, p->ev[4], p->ev[5]);
         (void)hipEventElapsedTime(&p->last.timeReconstruct, p->ev[6], p->ev[7]);
@@ -1437,9 +1580,12 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sBundle, hipStreamNonBlocking, greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
     }
-    BF_TRY(bf_image_manager_set_stream(p->im, p->sBundle));
+    if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
+    BF_TRY(bf_image_manager_set_stream(p->im, p->sDetect));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
+    BF_TRY(bf_online_bundler_set_detect_stream(p->ob, p->sDetect));
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
     int dev = 0;
@@ -1462,6 +1608,7 @@ int bf_pipeline_destroy(bf_pipeline* p) {
     for (auto& e : p->evIngest) if (e) (void)hipEventDestroy(e);
     if (p->sBundle) (void)hipStreamDestroy(p->sBundle);
     if (p->sVolume) (void)hipStreamDestroy(p->sVolume);
+    if (p->sDetect) (void)hipStreamDestroy(p->sDetect);
     delete p;
     return BF_OK;
 }
@@ -1487,22 +1634,31 @@ int bf_pipeline_process_end_of_sequence(bf_pipeline* p, uint32_t* numActiveOpera
 }
 int bf_pipeline_synchronize(bf_pipeline* p) {
     BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFlush(p));
     BF_TRY(volDrain(p));
+    BF_HIP_TRY(hipStreamSynchronize(p->sDetect));
     BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
     BF_HIP_TRY(hipStreamSynchronize(p->sVolume));
     return BF_OK;
 }
 int bf_pipeline_get_scene(bf_pipeline* p, bf_scene** out) {         // the volume thread is drained first: the caller may use the scene directly
     BF_REQUIRE(p && out, "null argument");
+    BF_TRY(plFlush(p));
     BF_TRY(volDrain(p));
     *out = p->scene;
     return BF_OK;
 }
 int bf_pipeline_get_image_manager(bf_pipeline* p, bf_image_manager** out) { BF_REQUIRE(p && out, "null argument"); *out = p->im; return BF_OK; }
-int bf_pipeline_get_online_bundler(bf_pipeline* p, bf_online_bundler** out) { BF_REQUIRE(p && out, "null argument"); *out = p->ob; return BF_OK; }
+int bf_pipeline_get_online_bundler(bf_pipeline* p, bf_online_bundler** out) {      // every frame handed in so far has been processed when this returns
+    BF_REQUIRE(p && out, "null argument");
+    BF_TRY(plFlush(p));
+    *out = p->ob;
+    return BF_OK;
+}
 int bf_pipeline_get_num_frames(bf_pipeline* p, uint32_t* out) { BF_REQUIRE(p && out, "null argument"); *out = p->im->currFrame; return BF_OK; }
 int bf_pipeline_get_integrated_trajectory(bf_pipeline* p, float* h_out, uint32_t capacity, uint32_t* count) {
     BF_REQUIRE(p && h_out && count, "null argument");
+    BF_TRY(plFlush(p));
     const uint32_t n = std::min(p->ob->tm->numAddedFrames, capacity);
     for (uint32_t i = 0; i < n; ++i) {
         const auto& f = p->ob->tm->frames[i];
@@ -1515,6 +1671,7 @@ int bf_pipeline_get_integrated_trajectory(bf_pipeline* p, float* h_out, uint32_t
 }
 int bf_pipeline_get_counters(bf_pipeline* p, uint32_t* numIntegrate, uint32_t* numDeIntegrate, uint32_t* numLocalSolves, uint32_t* numGlobalSolves) {
     BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFlush(p));
     if (numIntegrate) *numIntegrate = p->numIntegrate;
     if (numDeIntegrate) *numDeIntegrate = p->numDeIntegrate;
     if (numLocalSolves) *numLocalSolves = p->ob->numLocalSolves;
@@ -1523,6 +1680,7 @@ int bf_pipeline_get_counters(bf_pipeline* p, uint32_t* numIntegrate, uint32_t* n
 }
 int bf_pipeline_enable_timings(bf_pipeline* p, int enable) {
     BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFlush(p));
     BF_TRY(volDrain(p));
     p->timings = enable != 0;
     return BF_OK;

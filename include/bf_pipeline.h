@@ -191,6 +191,14 @@ BF_API int bf_online_bundler_process_input(bf_online_bundler* ob);              
  * logic; independent work (e.g. re-integration on another stream) may be enqueued in between */
 BF_API int bf_online_bundler_process_input_begin(bf_online_bundler* ob);
 BF_API int bf_online_bundler_process_input_end(bf_online_bundler* ob);
+/* Detect-ahead: feature detection and the dense cache frame depend only on a frame's pixels.  _detect_ahead computes them for the
+ * image manager's current frame on `detect stream` (the stream the image manager ingests on) into a two-slot staging area,
+ * without touching bundler state; _process_input_begin_frame(frame) later commits that staged frame instead of detecting, even
+ * when the image manager has ingested a newer frame meanwhile.  A host loop can so overlap detection of frame k+1 with the
+ * matching / solving of frame k (what the reference's bundling thread does with its one-frame lag, OnlineBundler.cpp:167). */
+BF_API int bf_online_bundler_set_detect_stream(bf_online_bundler* ob, void* hip_stream);
+BF_API int bf_online_bundler_detect_ahead(bf_online_bundler* ob);
+BF_API int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t frame);
 BF_API int bf_online_bundler_process(bf_online_bundler* ob, uint32_t numNonLinItersLocal, uint32_t numLinItersLocal,
                                      uint32_t numNonLinItersGlobal, uint32_t numLinItersGlobal);  /* process :410-416 */
 /* getCurrentIntegrationFrame(siftTransform, frameIdx, bGlobalTrackingLost) -> valid  :229-240 */
