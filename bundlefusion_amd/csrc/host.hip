@@ -1467,13 +1467,17 @@ int plReintegrate(bf_pipeline* p) {                                             
 }
 
 // everything of the frame loop after the ingest, for frame `frame` (got: a new frame, as opposed to an iteration after the
-// sequence ended)                                                                                     :966-1095 (serial branch)
-int plBody(bf_pipeline* p, uint32_t frame, bool got) {
+// sequence ended), in two parts so that a caller can put host work between the enqueue of processInput and its read-back
+//                                                                                                   :966-1095 (serial branch)
+int plBodyBegin(bf_pipeline* p, uint32_t frame) {
+    // ---- processInput: enqueue (bundling stream) ...
+    return bf_online_bundler_process_input_begin_frame(p->ob, frame);
+}
+
+int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
     hipStream_t sa = p->sBundle, sv = p->sVolume;
     const bool tm = p->timings;
     const int evSlot = got ? (int)(frame % bf_pipeline::NEV) : -1;
-    // ---- processInput: enqueue (bundling stream) ...
-    BF_TRY(bf_online_bundler_process_input_begin_frame(p->ob, frame));
     // ---- fix old frames (volume stream; launches issued by the volume thread), concurrently with the feature pipeline
     if (tm) (void)hipEventRecord(p->ev[4], sv);
     BF_TRY(plReintegrate(p));
@@ -1501,6 +1505,11 @@ int plBody(bf_pipeline* p, uint32_t frame, bool got) {
     return BF_OK;
 }
 
+int plBody(bf_pipeline* p, uint32_t frame, bool got) {
+    BF_TRY(plBodyBegin(p, frame));
+    return plBodyRest(p, frame, got);
+}
+
 // run the body of the frame that is still waiting for it
 int plFlush(bf_pipeline* p) {
     if (p->deferred < 0) return BF_OK;
@@ -1512,6 +1521,12 @@ int plFlush(bf_pipeline* p) {
 int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool device, bool haveInput, int* gotFrame) {
     hipStream_t sa = p->sBundle, sd = p->sDetect;
     const bool tm = p->timings;
+    const bool ahead = p->lookahead && !tm;
+    // ---- look-ahead: the previous frame's matching chain is enqueued first, so the GPU works on it while this thread issues
+    //      the ~35 launches of the new frame's ingest and detection
+    const int prev = ahead ? p->deferred : -1;
+    if (prev >= 0) BF_TRY(plBodyBegin(p, (uint32_t)prev));
+    else BF_TRY(plFlush(p));
     // ---- read input (detect stream)
     if (tm) (void)hipEventRecord(p->ev[0], sd);
     int got = 0;
@@ -1520,14 +1535,9 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (got) BF_HIP_TRY(hipEventRecord(p->evIngest[frame % bf_pipeline::NEV], sd));
     if (tm) { (void)hipEventRecord(p->ev[1], sd); BF_HIP_TRY(hipStreamWaitEvent(sa, p->ev[1], 0)); (void)hipEventRecord(p->ev[8], sa); }
     if (got) BF_TRY(bf_online_bundler_detect_ahead(p->ob));
-    if (p->lookahead && !tm) {
-        BF_TRY(plFlush(p));                                   // frame - 1 (its detection was staged by the previous call)
-        if (got) p->deferred = (int)frame;
-        else if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, false));
-    } else {
-        BF_TRY(plFlush(p));
-        if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, got != 0));
-    }
+    if (prev >= 0) { p->deferred = -1; BF_TRY(plBodyRest(p, (uint32_t)prev, true)); }
+    if (ahead && got) p->deferred = (int)frame;
+    else if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, got != 0));
     if (tm) {
         (void)hipEventRecord(p->ev[3], sa);
         (void)hipEventSynchronize(p->ev[3]);
