@@ -56,7 +56,7 @@ def build_lib(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-o", LIB_PATH]      # zlib: depth frames of .sens files
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode())

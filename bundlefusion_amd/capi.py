@@ -701,6 +701,7 @@ class GlobalAppState(C.Structure):
         ("s_bUseCameraCalibration", C.c_int32), ("s_binaryDumpSensorUseTrajectory", C.c_int32), ("s_garbageCollectionStarve", C.c_uint32),
         ("s_streamingVoxelExtents", C.c_float * 3), ("s_streamingGridDimensions", C.c_int32 * 3), ("s_streamingMinGridPos", C.c_int32 * 3),
         ("s_streamingInitialChunkListSize", C.c_uint32), ("s_numSolveFramesBeforeExit", C.c_uint32),
+        ("s_binaryDumpSensorFile", C.c_char * 512),
     ]
 
 

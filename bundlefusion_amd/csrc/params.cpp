@@ -85,6 +85,11 @@ void readApp(Reader& r, bf_global_app_state& g) {
     r.fv("s_streamingVoxelExtents", g.s_streamingVoxelExtents, 3); r.iv("s_streamingGridDimensions", g.s_streamingGridDimensions, 3);
     r.iv("s_streamingMinGridPos", g.s_streamingMinGridPos, 3); r.u("s_streamingInitialChunkListSize", g.s_streamingInitialChunkListSize);
     if (auto* s = r.find("s_numSolveFramesBeforeExit")) g.s_numSolveFramesBeforeExit = (uint32_t)strtol(s->c_str(), nullptr, 10);   // may be -1
+    if (auto* s = r.find("s_binaryDumpSensorFile")) {                                    // a quoted string
+        std::string v = *s;
+        if (v.size() >= 2 && v.front() == '"' && v.back() == '"') v = v.substr(1, v.size() - 2);
+        snprintf(g.s_binaryDumpSensorFile, sizeof g.s_binaryDumpSensorFile, "%s", v.c_str());
+    }
 }
 
 void readBundling(Reader& r, bf_global_bundling_state& g) {
@@ -136,6 +141,7 @@ int bf_global_app_state_default(bf_global_app_state* g) {           // zParamete
     g->s_streamingMinGridPos[0] = g->s_streamingMinGridPos[1] = g->s_streamingMinGridPos[2] = -128;
     g->s_streamingInitialChunkListSize = 2000;
     g->s_numSolveFramesBeforeExit = 30;
+    snprintf(g->s_binaryDumpSensorFile, sizeof g->s_binaryDumpSensorFile, "%s", "../data/sequence.sens");
     return BF_OK;
 }
 

@@ -1,0 +1,277 @@
+// Recorded sequences: the ".sens" container (ml::SensorData version 4) as used by SensorDataReader.cpp:40-128.
+// Host-only.  The byte layout is documented in include/bf_sensordata.h; frames are indexed at open time and read on demand.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/bf_sensordata.h"
+#include "bf_internal.h"
+
+using namespace bf;
+
+struct bf_sensor_data {
+    FILE* f = nullptr;
+    bf_sensor_data_info info;
+    struct Frame { float T[16]; uint64_t tsColor, tsDepth, colorSize, depthSize; int64_t colorOffset, depthOffset; };
+    std::vector<Frame> frames;
+    bf_sens_color_decoder decoder = nullptr;
+    void* decoderUser = nullptr;
+    std::vector<uint8_t> scratch;
+};
+
+struct bf_sensor_data_writer {
+    FILE* f = nullptr;
+    bf_sensor_data_info info;
+    int64_t numFramesOffset = 0;
+    uint64_t numFrames = 0;
+    std::vector<uint8_t> scratch;
+};
+
+namespace {
+
+const uint32_t SENS_VERSION = 4;                 // M_SENS_VERSION_NUMBER of the SensorData revision BundleFusion was written against
+const uint64_t IMU_FRAME_BYTES = 5 * 3 * 8 + 8;  // rotationRate, acceleration, magneticField, attitude, gravity (vec3d) + timeStamp
+
+template <class T> bool rd(FILE* f, T* v, size_t n = 1) { return fread(v, sizeof(T), n, f) == n; }
+template <class T> bool wr(FILE* f, const T* v, size_t n = 1) { return fwrite(v, sizeof(T), n, f) == n; }
+
+int64_t fileSize(FILE* f) {
+    const int64_t cur = ftello(f);
+    fseeko(f, 0, SEEK_END);
+    const int64_t end = ftello(f);
+    fseeko(f, cur, SEEK_SET);
+    return end;
+}
+
+int readBytes(bf_sensor_data* sd, int64_t offset, uint64_t size, uint8_t* out) {
+    if (fseeko(sd->f, offset, SEEK_SET) != 0 || fread(out, 1, size, sd->f) != size) { set_error("sens: short read at offset %lld", (long long)offset); return BF_ERR_STATE; }
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
+    BF_REQUIRE(filename && out, "null argument");
+    FILE* f = fopen(filename, "rb");
+    if (!f) { set_error("could not open file %s", filename); return BF_ERR_INVALID_ARG; }          // "could not open file" (SensorData::loadFromFile)
+    bf_sensor_data* sd = new bf_sensor_data;
+    sd->f = f;
+    bf_sensor_data_info& h = sd->info;
+    memset(&h, 0, sizeof h);
+    const int64_t total = fileSize(f);
+    bool ok = rd(f, &h.versionNumber);
+    if (ok && h.versionNumber != SENS_VERSION) {
+        set_error("sens: version %u, expected %u", h.versionNumber, SENS_VERSION);                   // "Invalid file format" / version mismatch
+        bf_sensor_data_close(sd);
+        return BF_ERR_INVALID_ARG;
+    }
+    uint64_t strLen = 0;
+    ok = ok && rd(f, &strLen) && (int64_t)strLen <= total;
+    if (ok) {
+        std::string name(strLen, '\0');
+        ok = strLen == 0 || rd(f, &name[0], strLen);
+        snprintf(h.sensorName, sizeof h.sensorName, "%s", name.c_str());
+    }
+    ok = ok && rd(f, h.colorIntrinsic, 16) && rd(f, h.colorExtrinsic, 16) && rd(f, h.depthIntrinsic, 16) && rd(f, h.depthExtrinsic, 16) &&
+         rd(f, &h.colorCompressionType) && rd(f, &h.depthCompressionType) && rd(f, &h.colorWidth) && rd(f, &h.colorHeight) &&
+         rd(f, &h.depthWidth) && rd(f, &h.depthHeight) && rd(f, &h.depthShift) && rd(f, &h.numFrames);
+    if (!ok || (int64_t)h.numFrames > total) { set_error("sens: truncated or invalid header in %s", filename); bf_sensor_data_close(sd); return BF_ERR_INVALID_ARG; }
+    sd->frames.resize(h.numFrames);
+    for (uint64_t i = 0; i < h.numFrames; ++i) {
+        bf_sensor_data::Frame& fr = sd->frames[i];
+        ok = rd(f, fr.T, 16) && rd(f, &fr.tsColor) && rd(f, &fr.tsDepth) && rd(f, &fr.colorSize) && rd(f, &fr.depthSize);
+        if (ok) {
+            fr.colorOffset = ftello(f);
+            fr.depthOffset = fr.colorOffset + (int64_t)fr.colorSize;
+            ok = fr.colorSize <= (uint64_t)total && fr.depthSize <= (uint64_t)total && fr.depthOffset + (int64_t)fr.depthSize <= total &&
+                 fseeko(f, fr.depthOffset + (int64_t)fr.depthSize, SEEK_SET) == 0;
+        }
+        if (!ok) { set_error("sens: truncated at frame %llu of %llu in %s", (unsigned long long)i, (unsigned long long)h.numFrames, filename); bf_sensor_data_close(sd); return BF_ERR_INVALID_ARG; }
+    }
+    uint64_t numIMU = 0;
+    if (rd(f, &numIMU) && ftello(f) + (int64_t)(numIMU * IMU_FRAME_BYTES) <= total) h.numIMUFrames = numIMU;     // the IMU block is optional
+    *out = sd;
+    return BF_OK;
+}
+
+int bf_sensor_data_close(bf_sensor_data* sd) {
+    if (!sd) return BF_OK;
+    if (sd->f) fclose(sd->f);
+    delete sd;
+    return BF_OK;
+}
+
+int bf_sensor_data_get_info(bf_sensor_data* sd, bf_sensor_data_info* out) { BF_REQUIRE(sd && out, "null argument"); *out = sd->info; return BF_OK; }
+
+int bf_sensor_data_get_sensor_desc(bf_sensor_data* sd, bf_rgbd_sensor_desc* out) {                // SensorDataReader.cpp:57-63
+    BF_REQUIRE(sd && out, "null argument");
+    const bf_sensor_data_info& h = sd->info;
+    memset(out, 0, sizeof *out);
+    out->depthWidth = h.depthWidth; out->depthHeight = h.depthHeight;
+    out->colorWidth = h.colorWidth > 1u ? h.colorWidth : 1u; out->colorHeight = h.colorHeight > 1u ? h.colorHeight : 1u;   // std::max(.., 1u) :57
+    // initializeDepth/ColorIntrinsics(fx, fy, mx, my) build a 4x4 from the four scalars (RGBDSensor.cpp:142-147, 161-166); extrinsics are taken whole
+    const float* src[2] = {h.depthIntrinsic, h.colorIntrinsic};
+    float* dst[2] = {out->depthIntrinsics, out->colorIntrinsics};
+    for (int k = 0; k < 2; ++k) {
+        float* K = dst[k];
+        for (int i = 0; i < 16; ++i) K[i] = 0.0f;
+        K[0] = src[k][0]; K[5] = src[k][5]; K[2] = src[k][2]; K[6] = src[k][6]; K[10] = 1.0f; K[15] = 1.0f;
+    }
+    memcpy(out->depthExtrinsics, h.depthExtrinsic, 64);
+    memcpy(out->colorExtrinsics, h.colorExtrinsic, 64);
+    return BF_OK;
+}
+
+int bf_sensor_data_set_color_decoder(bf_sensor_data* sd, bf_sens_color_decoder fn, void* user) {
+    BF_REQUIRE(sd, "null argument");
+    sd->decoder = fn; sd->decoderUser = user;
+    return BF_OK;
+}
+
+int bf_sensor_data_get_frame_pose(bf_sensor_data* sd, uint64_t frame, float T[16], uint64_t* tsColor, uint64_t* tsDepth) {
+    BF_REQUIRE(sd && frame < sd->frames.size(), "frame index out of range");
+    if (T) memcpy(T, sd->frames[frame].T, 64);
+    if (tsColor) *tsColor = sd->frames[frame].tsColor;
+    if (tsDepth) *tsDepth = sd->frames[frame].tsDepth;
+    return BF_OK;
+}
+
+int bf_sensor_data_get_frame_sizes(bf_sensor_data* sd, uint64_t frame, uint64_t* colorSize, uint64_t* depthSize) {
+    BF_REQUIRE(sd && frame < sd->frames.size(), "frame index out of range");
+    if (colorSize) *colorSize = sd->frames[frame].colorSize;
+    if (depthSize) *depthSize = sd->frames[frame].depthSize;
+    return BF_OK;
+}
+
+int bf_sensor_data_read_depth_raw(bf_sensor_data* sd, uint64_t frame, uint16_t* out) {             // SensorData::decompressDepthAlloc
+    BF_REQUIRE(sd && out && frame < sd->frames.size(), "bad argument");
+    const bf_sensor_data::Frame& fr = sd->frames[frame];
+    const uint64_t bytes = (uint64_t)sd->info.depthWidth * sd->info.depthHeight * 2;
+    if (sd->info.depthCompressionType == BF_SENS_DEPTH_RAW_USHORT) {
+        if (fr.depthSize != bytes) { set_error("sens: frame %llu: raw depth has %llu bytes, expected %llu", (unsigned long long)frame, (unsigned long long)fr.depthSize, (unsigned long long)bytes); return BF_ERR_STATE; }
+        return readBytes(sd, fr.depthOffset, bytes, reinterpret_cast<uint8_t*>(out));
+    }
+    if (sd->info.depthCompressionType == BF_SENS_DEPTH_ZLIB_USHORT) {
+        sd->scratch.resize(fr.depthSize);
+        const int rc = readBytes(sd, fr.depthOffset, fr.depthSize, sd->scratch.data());
+        if (rc) return rc;
+        uLongf dstLen = (uLongf)bytes;
+        const int z = uncompress(reinterpret_cast<Bytef*>(out), &dstLen, sd->scratch.data(), (uLong)fr.depthSize);
+        if (z != Z_OK || dstLen != bytes) { set_error("sens: frame %llu: zlib depth does not inflate to %llu bytes (zlib %d)", (unsigned long long)frame, (unsigned long long)bytes, z); return BF_ERR_STATE; }
+        return BF_OK;
+    }
+    set_error("sens: depth compression type %d is not supported (raw and zlib u16 are)", sd->info.depthCompressionType);   // "unknown depth compression type"
+    return BF_ERR_INVALID_ARG;
+}
+
+int bf_sensor_data_read_depth(bf_sensor_data* sd, uint64_t frame, float* out) {                    // SensorDataReader::processDepth :98-103
+    BF_REQUIRE(sd && out && frame < sd->frames.size(), "bad argument");
+    const size_t n = (size_t)sd->info.depthWidth * sd->info.depthHeight;
+    std::vector<uint16_t> raw(n);
+    const int rc = bf_sensor_data_read_depth_raw(sd, frame, raw.data());
+    if (rc) return rc;
+    const float shift = sd->info.depthShift;
+    for (size_t i = 0; i < n; ++i) out[i] = raw[i] == 0 ? -std::numeric_limits<float>::infinity() : (float)raw[i] / shift;
+    return BF_OK;
+}
+
+int bf_sensor_data_read_color_compressed(bf_sensor_data* sd, uint64_t frame, uint8_t* out, uint64_t capacity, uint64_t* size) {
+    BF_REQUIRE(sd && size && frame < sd->frames.size(), "bad argument");
+    const bf_sensor_data::Frame& fr = sd->frames[frame];
+    *size = fr.colorSize;
+    if (!out) return BF_OK;                                                       // size query
+    BF_REQUIRE(capacity >= fr.colorSize, "buffer too small");
+    return readBytes(sd, fr.colorOffset, fr.colorSize, out);
+}
+
+int bf_sensor_data_read_color_rgbx(bf_sensor_data* sd, uint64_t frame, uint8_t* out) {            // decompressColorAlloc + :107-111
+    BF_REQUIRE(sd && out && frame < sd->frames.size(), "bad argument");
+    const bf_sensor_data::Frame& fr = sd->frames[frame];
+    const size_t n = (size_t)sd->info.colorWidth * sd->info.colorHeight;
+    if (fr.colorSize == 0) { memset(out, 0, std::max<size_t>(n, 1) * 4); return BF_OK; }            // m_bHasColorData == false
+    std::vector<uint8_t> rgb(n * 3);
+    if (sd->info.colorCompressionType == BF_SENS_COLOR_RAW) {
+        if (fr.colorSize != n * 3) { set_error("sens: frame %llu: raw colour has %llu bytes, expected %llu", (unsigned long long)frame, (unsigned long long)fr.colorSize, (unsigned long long)(n * 3)); return BF_ERR_STATE; }
+        const int rc = readBytes(sd, fr.colorOffset, fr.colorSize, rgb.data());
+        if (rc) return rc;
+    } else if (sd->info.colorCompressionType == BF_SENS_COLOR_PNG || sd->info.colorCompressionType == BF_SENS_COLOR_JPEG) {
+        if (!sd->decoder) { set_error("sens: colour is %s-compressed and no decoder was set (bf_sensor_data_set_color_decoder)", sd->info.colorCompressionType == BF_SENS_COLOR_PNG ? "PNG" : "JPEG"); return BF_ERR_STATE; }
+        sd->scratch.resize(fr.colorSize);
+        const int rc = readBytes(sd, fr.colorOffset, fr.colorSize, sd->scratch.data());
+        if (rc) return rc;
+        if (sd->decoder(sd->decoderUser, sd->scratch.data(), fr.colorSize, sd->info.colorCompressionType, sd->info.colorWidth, sd->info.colorHeight, rgb.data()) != 0) {
+            set_error("sens: frame %llu: the colour decoder failed", (unsigned long long)frame);
+            return BF_ERR_STATE;
+        }
+    } else {
+        set_error("sens: colour compression type %d is not supported", sd->info.colorCompressionType);                 // "unknown compression type"
+        return BF_ERR_INVALID_ARG;
+    }
+    for (size_t i = 0; i < n; ++i) { out[4 * i] = rgb[3 * i]; out[4 * i + 1] = rgb[3 * i + 1]; out[4 * i + 2] = rgb[3 * i + 2]; out[4 * i + 3] = 255; }   // vec4uc(vec3uc): w = 255
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ writer
+int bf_sensor_data_writer_create(const char* filename, const bf_sensor_data_info* info, bf_sensor_data_writer** out) {
+    BF_REQUIRE(filename && info && out, "null argument");
+    BF_REQUIRE(info->depthCompressionType == BF_SENS_DEPTH_RAW_USHORT || info->depthCompressionType == BF_SENS_DEPTH_ZLIB_USHORT, "depth compression must be raw or zlib u16");
+    BF_REQUIRE(info->depthWidth > 0 && info->depthHeight > 0 && info->depthShift > 0.0f, "bad depth geometry");
+    FILE* f = fopen(filename, "wb");
+    if (!f) { set_error("could not open file %s for writing", filename); return BF_ERR_INVALID_ARG; }
+    bf_sensor_data_writer* w = new bf_sensor_data_writer;
+    w->f = f; w->info = *info;
+    const bf_sensor_data_info& h = w->info;
+    const uint32_t version = SENS_VERSION;
+    const uint64_t strLen = strnlen(h.sensorName, sizeof h.sensorName);
+    const uint64_t zero = 0;
+    bool ok = wr(f, &version) && wr(f, &strLen) && (strLen == 0 || wr(f, h.sensorName, strLen)) && wr(f, h.colorIntrinsic, 16) && wr(f, h.colorExtrinsic, 16) &&
+              wr(f, h.depthIntrinsic, 16) && wr(f, h.depthExtrinsic, 16) && wr(f, &h.colorCompressionType) && wr(f, &h.depthCompressionType) &&
+              wr(f, &h.colorWidth) && wr(f, &h.colorHeight) && wr(f, &h.depthWidth) && wr(f, &h.depthHeight) && wr(f, &h.depthShift);
+    w->numFramesOffset = ftello(f);
+    ok = ok && wr(f, &zero);
+    if (!ok) { set_error("sens: write failed (%s)", filename); fclose(f); delete w; return BF_ERR_STATE; }
+    *out = w;
+    return BF_OK;
+}
+
+int bf_sensor_data_writer_add_frame(bf_sensor_data_writer* w, const float T[16], uint64_t tsColor, uint64_t tsDepth, const uint8_t* colorBytes,
+                                    uint64_t colorSize, const uint16_t* depth) {
+    BF_REQUIRE(w && T && depth && (colorBytes || colorSize == 0), "null argument");
+    const uint64_t rawBytes = (uint64_t)w->info.depthWidth * w->info.depthHeight * 2;
+    const uint8_t* depthBytes = reinterpret_cast<const uint8_t*>(depth);
+    uint64_t depthSize = rawBytes;
+    if (w->info.depthCompressionType == BF_SENS_DEPTH_ZLIB_USHORT) {
+        uLongf bound = compressBound((uLong)rawBytes);
+        w->scratch.resize(bound);
+        if (compress2(w->scratch.data(), &bound, depthBytes, (uLong)rawBytes, 8) != Z_OK) { set_error("sens: zlib compression failed"); return BF_ERR_STATE; }
+        depthBytes = w->scratch.data(); depthSize = bound;
+    }
+    FILE* f = w->f;
+    const bool ok = wr(f, T, 16) && wr(f, &tsColor) && wr(f, &tsDepth) && wr(f, &colorSize) && wr(f, &depthSize) &&
+                    (colorSize == 0 || wr(f, colorBytes, colorSize)) && wr(f, depthBytes, depthSize);
+    if (!ok) { set_error("sens: write failed at frame %llu", (unsigned long long)w->numFrames); return BF_ERR_STATE; }
+    w->numFrames++;
+    return BF_OK;
+}
+
+int bf_sensor_data_writer_close(bf_sensor_data_writer* w) {
+    if (!w) return BF_OK;
+    const uint64_t zero = 0;
+    bool ok = wr(w->f, &zero);                                                    // no IMU frames
+    ok = ok && fseeko(w->f, w->numFramesOffset, SEEK_SET) == 0 && wr(w->f, &w->numFrames);
+    ok = (fclose(w->f) == 0) && ok;
+    delete w;
+    if (!ok) { set_error("sens: finishing the file failed"); return BF_ERR_STATE; }
+    return BF_OK;
+}
+
+}  // extern "C"

@@ -597,15 +597,10 @@ BF_DEV bool voxelSample(const Frame& f, int4 e, int lx, int ly, int lz, const fl
 
 // combineVoxel / its inverse on (sdf, weight, packed colour); DEINT resets a voxel whose weight drops to zero.
 //
-// The update kernels are VALU-bound (nine IEEE divisions and six roundf per re-integrated voxel), so the colour channels use
-// two shortcuts that give the same bytes as the reference expressions (the CPU oracle keeps those expressions; the parity
-// tests compare the volumes bit for bit).  Both rest on the fact that weights are whole numbers (0, +1 per frame, capped at the
-// integer integrationWeightMax) and colours are bytes:
-//   * integrate: 0.2 c + 0.8 o = (c + 4 o) / 5 is never within 0.1 of a half, so roundf == round-to-nearest-even (v_rndne);
-//   * de-integrate: (o w - c) / (w - 1) is a ratio of integers I / J with 1 <= J <= 98.  Its distance to a rounding tie k + 1/2
-//     is either 0 or at least 1/196, so a reciprocal-based quotient (error < 1e-4 below 256) plus a 1/512 guard reproduces
-//     roundf(RN(I / J)) exactly, ties included; everything at or above 254 ends at 254 and everything negative at 0 like the
-//     reference's clamps.  Voxels whose weight drops to zero (J <= 0) are reset, whatever the quotient was.
+// Integrate: 0.2 c + 0.8 o with bytes c, o is (c + 4 o) / 5, never within 0.1 of a rounding tie, so roundf equals
+// round-to-nearest-even (one v_rndne instead of the five-instruction roundf; all 65536 (c, o) pairs are checked on the CPU in
+// tests/test_host_cpu.py).  De-integrate keeps the reference expressions: (o w - c) / (w - 1) has ties and its distance to a tie
+// shrinks with the weight (1 / (2 (w - 1))), so no shortcut is safe for long sequences.
 template <bool DEINT>
 BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float& vW, uint32_t& vC) {
     const float c0 = (float)cc.x, c1 = (float)cc.y, c2 = (float)cc.z;
@@ -625,24 +620,16 @@ BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float&
         nSdf = (sdf * 1.0f + oSdf * oW) / (1.0f + oW);
         nW = fminf(f.weightMax, 1.0f + oW);
     } else {
+        float r0 = (o0 * oW - c0 * 1.0f) / (oW - 1.0f);
+        float r1 = (o1 * oW - c1 * 1.0f) / (oW - 1.0f);
+        float r2 = (o2 * oW - c2 * 1.0f) / (oW - 1.0f);
+        r0 = fmaxf(0.0f, fminf(roundf(r0), 254.5f));
+        r1 = fmaxf(0.0f, fminf(roundf(r1), 254.5f));
+        r2 = fmaxf(0.0f, fminf(roundf(r2), 254.5f));
+        nC = (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;
+        nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
         nW = fmaxf(0.0f, oW - 1.0f);
-        if (nW <= 0.001f) {
-            nSdf = 0.0f; nC = 0u; nW = 0.0f;
-        } else {
-            const float J = oW - 1.0f;                                   // whole number >= 1
-            const float y = __builtin_amdgcn_rcpf(J);
-            const float i0 = o0 * oW - c0 * 1.0f, i1 = o1 * oW - c1 * 1.0f, i2 = o2 * oW - c2 * 1.0f;   // exact integers
-            float q0 = i0 * y, q1 = i1 * y, q2 = i2 * y;
-            q0 = __builtin_fmaf(__builtin_fmaf(-J, q0, i0), y, q0);      // one residual correction: |q - I/J| < 1e-4 for |q| < 256
-            q1 = __builtin_fmaf(__builtin_fmaf(-J, q1, i1), y, q1);
-            q2 = __builtin_fmaf(__builtin_fmaf(-J, q2, i2), y, q2);
-            const float half = 0.5f + 1.0f / 512.0f;
-            const float r0 = fmaxf(0.0f, fminf(truncf(q0 + half), 254.0f));
-            const float r1 = fmaxf(0.0f, fminf(truncf(q1 + half), 254.0f));
-            const float r2 = fmaxf(0.0f, fminf(truncf(q2 + half), 254.0f));
-            nC = (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;
-            nSdf = (oSdf * oW - sdf * 1.0f) / (oW - 1.0f);
-        }
+        if (nW <= 0.001f) { nSdf = 0.0f; nC = 0u; nW = 0.0f; }
     }
     vSdf = nSdf; vW = nW; vC = nC;
 }

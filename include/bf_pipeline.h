@@ -43,6 +43,7 @@ typedef struct bf_global_app_state {
     int32_t s_streamingGridDimensions[3], s_streamingMinGridPos[3];
     uint32_t s_streamingInitialChunkListSize;
     uint32_t s_numSolveFramesBeforeExit;
+    char s_binaryDumpSensorFile[512];      /* the .sens file played when s_sensorIdx == 8 (SensorDataReader.cpp:44) */
 } bf_global_app_state;
 
 typedef struct bf_global_bundling_state {

@@ -1,0 +1,85 @@
+/* bf_sensordata.h — recorded RGB-D sequences (".sens") for the BundleFusion path.
+ *
+ * Replaces, for the frame loop, the reference's `SensorDataReader` (FriedLiver/Source/SensorDataReader.h/.cpp) and the part
+ * of mLib's `ml::SensorData` it calls (`loadFromFile`, `RGBDFrameCacheRead::getNext`, `decompressDepthAlloc`,
+ * `decompressColorAlloc`; call sites SensorDataReader.cpp:40-83, 85-128).  mLib is a git submodule of the reference that is
+ * NOT vendored under /root/reference (external/mLib is empty, .gitmodules pins no commit), so the container format is restated
+ * from its published description (the ScanNet "SensorData" reader documents the same byte layout):
+ *
+ *   u32  version (= 4)
+ *   u64  strlen, char[strlen] sensor name
+ *   f32[16] colour intrinsic, f32[16] colour extrinsic, f32[16] depth intrinsic, f32[16] depth extrinsic   (row-major mat4f)
+ *   i32  colour compression (-1 unknown, 0 raw RGB8, 1 PNG, 2 JPEG)
+ *   i32  depth compression  (-1 unknown, 0 raw u16, 1 zlib-compressed u16, 2 "occi" u16)
+ *   u32  colourWidth, colourHeight, depthWidth, depthHeight
+ *   f32  depthShift          (depth in metres = u16 / depthShift; 0 = invalid)
+ *   u64  numFrames, then per frame:
+ *        f32[16] cameraToWorld, u64 timeStampColour, u64 timeStampDepth, u64 colourSizeBytes, u64 depthSizeBytes,
+ *        colour bytes, depth bytes
+ *   u64  numIMUFrames, then per IMU frame 5 x f64[3] + u64 time stamp (128 B)      (may be absent in older files)
+ *
+ * All functions run on the host only (no GPU needed); status / error conventions as in bf_hip.h.
+ */
+#ifndef BF_SENSORDATA_H
+#define BF_SENSORDATA_H
+
+#include "bf_pipeline.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { BF_SENS_COLOR_UNKNOWN = -1, BF_SENS_COLOR_RAW = 0, BF_SENS_COLOR_PNG = 1, BF_SENS_COLOR_JPEG = 2 };
+enum { BF_SENS_DEPTH_UNKNOWN = -1, BF_SENS_DEPTH_RAW_USHORT = 0, BF_SENS_DEPTH_ZLIB_USHORT = 1, BF_SENS_DEPTH_OCCI_USHORT = 2 };
+
+typedef struct bf_sensor_data_info {          /* ml::SensorData header fields */
+    uint32_t versionNumber;
+    char sensorName[256];
+    float colorIntrinsic[16], colorExtrinsic[16], depthIntrinsic[16], depthExtrinsic[16];
+    int32_t colorCompressionType, depthCompressionType;
+    uint32_t colorWidth, colorHeight, depthWidth, depthHeight;
+    float depthShift;
+    uint64_t numFrames, numIMUFrames;
+} bf_sensor_data_info;
+
+typedef struct bf_sensor_data bf_sensor_data;               /* a .sens file opened for reading */
+typedef struct bf_sensor_data_writer bf_sensor_data_writer; /* a .sens file being written      */
+
+/* colour decoder for PNG / JPEG frames: decode `size` bytes into width*height RGB8; return 0 on success.  Raw colour needs
+ * none.  (ml::SensorData decodes with stb_image; this library ships no image codec, the host application supplies one.) */
+typedef int (*bf_sens_color_decoder)(void* user, const uint8_t* data, uint64_t size, int32_t compressionType, uint32_t width,
+                                     uint32_t height, uint8_t* rgbOut);
+
+/* SensorData::loadFromFile (frames are indexed and read on demand, so a file larger than host memory can be played) */
+BF_API int bf_sensor_data_open(const char* filename, bf_sensor_data** out);
+BF_API int bf_sensor_data_close(bf_sensor_data* sd);
+BF_API int bf_sensor_data_get_info(bf_sensor_data* sd, bf_sensor_data_info* out);
+/* RGBDSensor::init + initializeDepth/ColorIntrinsics/Extrinsics as done by createFirstConnected (SensorDataReader.cpp:57-63) */
+BF_API int bf_sensor_data_get_sensor_desc(bf_sensor_data* sd, bf_rgbd_sensor_desc* out);
+BF_API int bf_sensor_data_set_color_decoder(bf_sensor_data* sd, bf_sens_color_decoder fn, void* user);
+/* RGBDFrame fields */
+BF_API int bf_sensor_data_get_frame_pose(bf_sensor_data* sd, uint64_t frame, float cameraToWorld[16], uint64_t* timeStampColor,
+                                         uint64_t* timeStampDepth);
+BF_API int bf_sensor_data_get_frame_sizes(bf_sensor_data* sd, uint64_t frame, uint64_t* colorSizeBytes, uint64_t* depthSizeBytes);
+/* decompressDepthAlloc: depthWidth*depthHeight u16 */
+BF_API int bf_sensor_data_read_depth_raw(bf_sensor_data* sd, uint64_t frame, uint16_t* h_out);
+/* what SensorDataReader::processDepth hands to the image manager (:98-103): metres, 0 -> -inf */
+BF_API int bf_sensor_data_read_depth(bf_sensor_data* sd, uint64_t frame, float* h_depthMetres);
+/* the stored colour bytes as they are (for an external decoder) */
+BF_API int bf_sensor_data_read_color_compressed(bf_sensor_data* sd, uint64_t frame, uint8_t* h_out, uint64_t capacity, uint64_t* size);
+/* decompressColorAlloc + the vec4uc(vec3uc) widening of processDepth (:107-111): colourWidth*colourHeight RGBX, X = 255.
+ * A file without colour (size 0) yields zeros like the reference's untouched m_colorRGBX. */
+BF_API int bf_sensor_data_read_color_rgbx(bf_sensor_data* sd, uint64_t frame, uint8_t* h_rgbx);
+
+/* SensorData::saveToFile, incrementally.  info: sensorName, calibration, compression types (colour: frames are stored as
+ * given; depth: RAW_USHORT or ZLIB_USHORT, compressed here), sizes, depthShift; numFrames is filled in by _close. */
+BF_API int bf_sensor_data_writer_create(const char* filename, const bf_sensor_data_info* info, bf_sensor_data_writer** out);
+BF_API int bf_sensor_data_writer_add_frame(bf_sensor_data_writer* w, const float cameraToWorld[16], uint64_t timeStampColor,
+                                           uint64_t timeStampDepth, const uint8_t* colorBytes, uint64_t colorSizeBytes,
+                                           const uint16_t* depth);
+BF_API int bf_sensor_data_writer_close(bf_sensor_data_writer* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BF_SENSORDATA_H */

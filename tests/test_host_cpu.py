@@ -19,11 +19,11 @@ def _declared(header):
     return sorted(set(re.findall(r"BF_API\s+[\w\s\*]+?\b(bf_\w+)\s*\(", txt)))
 
 
-@pytest.mark.parametrize("header", ["bf_hip.h", "bf_pipeline.h"])
+@pytest.mark.parametrize("header", ["bf_hip.h", "bf_pipeline.h", "bf_sensordata.h"])
 def test_library_exports_every_declared_symbol(built, header):
     lib = C.CDLL(os.path.join(ROOT, "bundlefusion_amd", "lib", "libbf_hip.so"))
     names = _declared(header)
-    assert len(names) > (60 if header == "bf_hip.h" else 80)
+    assert len(names) > {"bf_hip.h": 60, "bf_pipeline.h": 80, "bf_sensordata.h": 13}[header]
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
 
@@ -152,3 +152,15 @@ def test_cpp_header_classes_compile_and_link(built, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "usage:" in out.stdout
+
+
+def test_integrate_colour_rounding_shortcut_is_exact():
+    """tsdf.hip voxelApply<integrate> rounds 0.2f*c + 0.8f*o with round-to-nearest-even (v_rndne) where the reference uses
+    roundf (half away from zero, VoxelUtilHashSDF.h combineVoxel): identical for every pair of bytes, in float32 arithmetic."""
+    c, o = np.meshgrid(np.arange(256, dtype=np.float32), np.arange(256, dtype=np.float32), indexing="ij")
+    r = (np.float32(0.2) * c).astype(np.float32) + (np.float32(0.8) * o).astype(np.float32)
+    assert r.dtype == np.float32
+    half_away = np.copysign(np.floor(np.abs(r) + np.float32(0.5)), r)            # roundf
+    assert np.array_equal(np.rint(r), half_away)
+    frac = np.abs(r - np.floor(r) - 0.5)
+    assert frac.min() > 0.09                                                      # never near a tie: (c + 4 o) / 5

@@ -1,0 +1,212 @@
+"""CPU tests of the .sens reader / writer (include/bf_sensordata.h).
+
+The C ABI is checked against an independent struct.pack / struct.unpack restatement of the published SensorData
+version-4 byte layout (written in this file), in both directions, plus the conversion rules of
+SensorDataReader::processDepth (SensorDataReader.cpp:98-111): metres = u16 / depthShift, 0 -> -inf, RGB -> RGBX.
+"""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from bundlefusion_amd import sensordata as sdm
+from bundlefusion_amd.capi import BFError
+
+
+def _K(fx=583.0, fy=584.0, cx=319.5, cy=239.5):
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, cx, cy
+    return K
+
+
+def _frames(n, w, h, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        depth = rng.integers(400, 4000, size=(h, w)).astype(np.uint16)
+        depth[rng.random((h, w)) < 0.1] = 0
+        color = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = rng.normal(size=3)
+        T[0, 1] = 0.01 * k
+        out.append((T, depth, color, 1000 + k, 2000 + k))
+    return out
+
+
+def _py_write(path, frames, w, h, cw, ch, depth_comp, color_comp, shift, name=b"StructureSensor", imu=0, color_payload=None):
+    """Independent writer: the SensorData v4 layout with struct.pack."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 4))
+        f.write(struct.pack("<Q", len(name)) + name)
+        for m in (_K(500, 501, 31.5, 23.5), np.eye(4), _K(), np.eye(4)):          # colour intr, colour extr, depth intr, depth extr
+            f.write(np.asarray(m, "<f4").tobytes())
+        f.write(struct.pack("<ii", color_comp, depth_comp))
+        f.write(struct.pack("<IIII", cw, ch, w, h))
+        f.write(struct.pack("<f", shift))
+        f.write(struct.pack("<Q", len(frames)))
+        for i, (T, depth, color, tc, td) in enumerate(frames):
+            cbytes = color.tobytes() if color_payload is None else color_payload[i]
+            dbytes = depth.astype("<u2").tobytes()
+            if depth_comp == 1:
+                dbytes = zlib.compress(dbytes)
+            f.write(np.asarray(T, "<f4").tobytes())
+            f.write(struct.pack("<QQQQ", tc, td, len(cbytes), len(dbytes)))
+            f.write(cbytes)
+            f.write(dbytes)
+        f.write(struct.pack("<Q", imu))
+        f.write(b"\x00" * (128 * imu))
+
+
+def _py_read(path):
+    """Independent reader (the layout the public ScanNet SensorData reader documents)."""
+    with open(path, "rb") as f:
+        ver, = struct.unpack("<I", f.read(4))
+        n, = struct.unpack("<Q", f.read(8))
+        name = f.read(n)
+        mats = [np.frombuffer(f.read(64), "<f4").reshape(4, 4) for _ in range(4)]
+        cc, dc = struct.unpack("<ii", f.read(8))
+        cw, ch, w, h = struct.unpack("<IIII", f.read(16))
+        shift, = struct.unpack("<f", f.read(4))
+        nf, = struct.unpack("<Q", f.read(8))
+        frames = []
+        for _ in range(nf):
+            T = np.frombuffer(f.read(64), "<f4").reshape(4, 4)
+            tc, td, cs, ds = struct.unpack("<QQQQ", f.read(32))
+            cb, db = f.read(cs), f.read(ds)
+            frames.append((T, tc, td, cb, db))
+        nimu, = struct.unpack("<Q", f.read(8))
+        rest = f.read()
+    return dict(version=ver, name=name, mats=mats, cc=cc, dc=dc, cw=cw, ch=ch, w=w, h=h, shift=shift, frames=frames, nimu=nimu, rest=rest)
+
+
+@pytest.mark.parametrize("depth_comp", [sdm.DEPTH_RAW_USHORT, sdm.DEPTH_ZLIB_USHORT])
+def test_reader_on_independently_written_file(tmp_path, depth_comp):
+    w, h = 64, 48
+    frames = _frames(5, w, h)
+    path = tmp_path / "a.sens"
+    _py_write(path, frames, w, h, w, h, depth_comp, sdm.COLOR_RAW, 1000.0, imu=3)
+    sd = sdm.SensorData(path)
+    assert len(sd) == 5 and sd.sensor_name == "StructureSensor"
+    i = sd.info
+    assert (i.versionNumber, i.depthWidth, i.depthHeight, i.colorWidth, i.colorHeight) == (4, w, h, w, h)
+    assert i.depthShift == 1000.0 and i.numIMUFrames == 3
+    assert i.depthCompressionType == depth_comp and i.colorCompressionType == sdm.COLOR_RAW
+    assert np.array_equal(np.array(i.depthIntrinsic, np.float32).reshape(4, 4), _K())
+    assert np.array_equal(np.array(i.colorIntrinsic, np.float32).reshape(4, 4), _K(500, 501, 31.5, 23.5))
+    for k, (T, depth, color, tc, td) in enumerate(frames):
+        Tk, a, b = sd.pose(k)
+        assert np.array_equal(Tk, T) and (a, b) == (tc, td)
+        assert np.array_equal(sd.depth_raw(k), depth)
+        d = sd.depth(k)
+        assert np.array_equal(np.isneginf(d), depth == 0)                                   # 0 -> -inf  (SensorDataReader.cpp:99)
+        assert np.array_equal(d[depth != 0], depth[depth != 0].astype(np.float32) / np.float32(1000.0))   # (float)u16 / m_depthShift (:100)
+        c = sd.color_rgbx(k)
+        assert np.array_equal(c[..., :3], color) and (c[..., 3] == 255).all()               # vec4uc(vec3uc) (:109)
+        assert sd.color_compressed(k) == color.tobytes()
+    with pytest.raises(BFError):
+        sd.pose(5)
+    sd.close()
+
+
+def test_writer_output_parses_with_the_independent_reader(tmp_path):
+    w, h = 40, 30
+    frames = _frames(4, w, h, seed=3)
+    path = tmp_path / "w.sens"
+    with sdm.SensorDataWriter(path, (w, h), (w, h), _K(), color_intrinsic=_K(500, 501, 31.5, 23.5), depth_shift=1000.0, sensor_name="synthetic S2") as wr:
+        for T, depth, color, tc, td in frames:
+            wr.add_frame(T, depth, color.tobytes(), tc, td)
+    r = _py_read(path)
+    assert r["version"] == 4 and r["name"] == b"synthetic S2" and r["nimu"] == 0 and r["rest"] == b""
+    assert (r["cc"], r["dc"], r["cw"], r["ch"], r["w"], r["h"], r["shift"]) == (sdm.COLOR_RAW, sdm.DEPTH_ZLIB_USHORT, w, h, w, h, 1000.0)
+    assert np.array_equal(r["mats"][0], _K(500, 501, 31.5, 23.5)) and np.array_equal(r["mats"][2], _K())
+    assert np.array_equal(r["mats"][1], np.eye(4)) and np.array_equal(r["mats"][3], np.eye(4))
+    assert len(r["frames"]) == 4
+    for (T, depth, color, tc, td), (T2, tc2, td2, cb, db) in zip(frames, r["frames"]):
+        assert np.array_equal(T, T2) and (tc, td) == (tc2, td2)
+        assert cb == color.tobytes()
+        assert np.array_equal(np.frombuffer(zlib.decompress(db), "<u2").reshape(h, w), depth)
+    # and back through the C reader
+    sd = sdm.SensorData(path)
+    assert np.array_equal(sd.depth_raw(2), frames[2][1])
+    sd.close()
+
+
+def test_jpeg_colour_through_the_decoder_callback(tmp_path):
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    w, h = 64, 48
+    frames = _frames(2, w, h, seed=5)
+    payload = []
+    for _, _, color, _, _ in frames:
+        smooth = np.asarray(Image.fromarray(color).resize((8, 6)).resize((w, h), Image.BILINEAR))
+        buf = io.BytesIO()
+        Image.fromarray(smooth).save(buf, format="JPEG", quality=92)
+        payload.append(buf.getvalue())
+    path = tmp_path / "j.sens"
+    _py_write(path, frames, w, h, w, h, 1, sdm.COLOR_JPEG, 1000.0, color_payload=payload)
+    sd = sdm.SensorData(path)
+    for k in range(2):
+        ref = np.asarray(Image.open(io.BytesIO(payload[k])).convert("RGB"))
+        c = sd.color_rgbx(k)
+        assert np.array_equal(c[..., :3], ref) and (c[..., 3] == 255).all()
+        assert sd.color_compressed(k) == payload[k]
+        assert sd.frame_sizes(k)[0] == len(payload[k])
+    sd.close()
+    sd = sdm.SensorData(path, use_pillow=False)              # no decoder: fail loudly, never a silent zero image
+    with pytest.raises(BFError, match="no decoder"):
+        sd.color_rgbx(0)
+    sd.close()
+
+
+def test_sensor_desc_follows_create_first_connected(tmp_path):
+    w, h = 32, 24
+    frames = _frames(1, w, h)
+    path = tmp_path / "d.sens"
+    _py_write(path, [(frames[0][0], frames[0][1], np.zeros((0,), np.uint8), 0, 0)], w, h, 0, 0, 0, sdm.COLOR_RAW, 1000.0)
+    sd = sdm.SensorData(path)
+    d = sd.sensor_desc()
+    assert (d.depthWidth, d.depthHeight, d.colorWidth, d.colorHeight) == (w, h, 1, 1)        # std::max(colour size, 1u) (:57)
+    K = np.array(d.depthIntrinsics, np.float32).reshape(4, 4)
+    assert np.array_equal(K, _K())                                                             # rebuilt from fx, fy, mx, my (RGBDSensor.cpp:142-147)
+    assert np.array_equal(np.array(d.depthExtrinsics, np.float32).reshape(4, 4), np.eye(4))
+    assert not sd.color_rgbx(0).any()                                                          # no colour data: m_colorRGBX stays untouched
+    sd.close()
+
+
+def test_malformed_files_are_rejected(tmp_path):
+    w, h = 16, 12
+    frames = _frames(2, w, h)
+    good = tmp_path / "g.sens"
+    _py_write(good, frames, w, h, w, h, 1, sdm.COLOR_RAW, 1000.0)
+    blob = good.read_bytes()
+    bad_version = tmp_path / "v.sens"
+    bad_version.write_bytes(struct.pack("<I", 3) + blob[4:])
+    with pytest.raises(BFError, match="version"):
+        sdm.SensorData(bad_version)
+    truncated = tmp_path / "t.sens"
+    truncated.write_bytes(blob[: len(blob) - 200])
+    with pytest.raises(BFError, match="truncated"):
+        sdm.SensorData(truncated)
+    with pytest.raises(BFError, match="could not open"):
+        sdm.SensorData(tmp_path / "missing.sens")
+    occi = tmp_path / "o.sens"
+    _py_write(occi, frames, w, h, w, h, sdm.DEPTH_OCCI_USHORT, sdm.COLOR_RAW, 1000.0)
+    sd = sdm.SensorData(occi)
+    with pytest.raises(BFError, match="not supported"):
+        sd.depth(0)
+    sd.close()
+    wrong = tmp_path / "s.sens"                          # raw depth of the wrong size
+    fr = [(frames[0][0], frames[0][1][:6], frames[0][2], 0, 0)]
+    _py_write(wrong, fr, w, h, w, h, 0, sdm.COLOR_RAW, 1000.0)
+    sd = sdm.SensorData(wrong)
+    with pytest.raises(BFError, match="raw depth"):
+        sd.depth_raw(0)
+    sd.close()
+
+
+def test_depth_quantisation_helper():
+    d = np.array([[0.4004, np.inf, -np.inf, 0.0, 70.0, 1.2345678]], np.float32)
+    q = sdm.depth_to_u16(d, 1000.0)
+    assert q.tolist() == [[400, 0, 0, 0, 65535, 1235]]
