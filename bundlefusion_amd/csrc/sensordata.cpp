@@ -3,6 +3,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -272,6 +273,162 @@ int bf_sensor_data_writer_close(bf_sensor_data_writer* w) {
     delete w;
     if (!ok) { set_error("sens: finishing the file failed"); return BF_ERR_STATE; }
     return BF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ trajectory I/O and evaluation
+int bf_sensor_data_save_with_trajectory(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms) {
+    BF_REQUIRE(sd && filename && (trajectory || numTransforms == 0), "null argument");
+    FILE* f = fopen(filename, "wb");
+    if (!f) { set_error("could not open file %s for writing", filename); return BF_ERR_INVALID_ARG; }
+    const bf_sensor_data_info& h = sd->info;
+    const uint32_t version = SENS_VERSION;
+    const uint64_t strLen = strnlen(h.sensorName, sizeof h.sensorName), numFrames = sd->frames.size(), zero = 0;
+    bool ok = wr(f, &version) && wr(f, &strLen) && (strLen == 0 || wr(f, h.sensorName, strLen)) && wr(f, h.colorIntrinsic, 16) && wr(f, h.colorExtrinsic, 16) &&
+              wr(f, h.depthIntrinsic, 16) && wr(f, h.depthExtrinsic, 16) && wr(f, &h.colorCompressionType) && wr(f, &h.depthCompressionType) &&
+              wr(f, &h.colorWidth) && wr(f, &h.colorHeight) && wr(f, &h.depthWidth) && wr(f, &h.depthHeight) && wr(f, &h.depthShift) && wr(f, &numFrames);
+    float invalid[16];
+    for (float& v : invalid) v = -std::numeric_limits<float>::infinity();
+    std::vector<uint8_t> buf;
+    for (uint64_t i = 0; ok && i < numFrames; ++i) {
+        const bf_sensor_data::Frame& fr = sd->frames[i];
+        const float* T = i < numTransforms ? trajectory + 16 * i : invalid;
+        buf.resize(fr.colorSize + fr.depthSize);
+        if (readBytes(sd, fr.colorOffset, fr.colorSize + fr.depthSize, buf.data()) != BF_OK) { fclose(f); return BF_ERR_STATE; }
+        ok = wr(f, T, 16) && wr(f, &fr.tsColor) && wr(f, &fr.tsDepth) && wr(f, &fr.colorSize) && wr(f, &fr.depthSize) && (buf.empty() || wr(f, buf.data(), buf.size()));
+    }
+    ok = ok && wr(f, &zero);                                                      // IMU frames are not carried over
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { set_error("sens: writing %s failed", filename); return BF_ERR_STATE; }
+    return BF_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations (double precision): A = V diag(w) V^T
+void jacobiEigen3(double A[3][3], double V[3][3], double w[3]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
+                for (int k = 0; k < 3; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
+                for (int k = 0; k < 3; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+            }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+}
+
+// rigid alignment R p + t ~ r (Kabsch): R = argmax tr(R H), H = sum (p - pc)(r - rc)^T, via the polar factor of H^T
+void kabschAlign(const std::vector<std::array<double, 3>>& p, const std::vector<std::array<double, 3>>& r, double R[3][3], double t[3]) {
+    const size_t n = p.size();
+    double pc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { pc[k] += p[i][k]; rc[k] += r[i][k]; }
+    for (int k = 0; k < 3; ++k) { pc[k] /= (double)n; rc[k] /= (double)n; }
+    double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (size_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) H[a][b] += (p[i][a] - pc[a]) * (r[i][b] - rc[b]);
+    // H = U S V^T  =>  R = V D U^T with D = diag(1, 1, det(V U^T)).  V, S^2 from the eigen-decomposition of H^T H; U = H V S^-1.
+    double HtH[3][3], V[3][3], w[3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { HtH[a][b] = 0; for (int k = 0; k < 3; ++k) HtH[a][b] += H[k][a] * H[k][b]; }
+    jacobiEigen3(HtH, V, w);
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int a, int b) { return w[a] > w[b]; });
+    double Vs[3][3], U[3][3], sv[3];
+    for (int j = 0; j < 3; ++j) { sv[j] = sqrt(std::max(w[order[j]], 0.0)); for (int k = 0; k < 3; ++k) Vs[k][j] = V[k][order[j]]; }
+    for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) { double v = 0; for (int m = 0; m < 3; ++m) v += H[k][m] * Vs[m][j]; U[k][j] = v; }
+    // orthonormalise U's columns (Gram-Schmidt); a vanishing singular value (planar / collinear positions) is completed by a cross product
+    auto norm = [](double* v) { const double l = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); if (l > 0) { v[0] /= l; v[1] /= l; v[2] /= l; } return l; };
+    double u0[3] = {U[0][0], U[1][0], U[2][0]}, u1[3] = {U[0][1], U[1][1], U[2][1]}, u2[3];
+    if (norm(u0) == 0.0) { u0[0] = 1; u0[1] = 0; u0[2] = 0; }
+    { const double d = u0[0] * u1[0] + u0[1] * u1[1] + u0[2] * u1[2]; for (int k = 0; k < 3; ++k) u1[k] -= d * u0[k]; }
+    if (norm(u1) < 1e-12 || sv[1] <= 1e-12 * std::max(sv[0], 1e-300)) {          // rank 1: any unit vector orthogonal to u0
+        const int m = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0}; e[m] = 1;
+        u1[0] = u0[1] * e[2] - u0[2] * e[1]; u1[1] = u0[2] * e[0] - u0[0] * e[2]; u1[2] = u0[0] * e[1] - u0[1] * e[0];
+        norm(u1);                                                                   // collinear positions: any rotation about the line is optimal
+    }
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1]; u2[1] = u0[2] * u1[0] - u0[0] * u1[2]; u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+    double v0[3] = {Vs[0][0], Vs[1][0], Vs[2][0]}, v1[3] = {Vs[0][1], Vs[1][1], Vs[2][1]}, v2[3];
+    v2[0] = v0[1] * v1[2] - v0[2] * v1[1]; v2[1] = v0[2] * v1[0] - v0[0] * v1[2]; v2[2] = v0[0] * v1[1] - v0[1] * v1[0];
+    // u2 = u0 x u1 and v2 = v0 x v1 make both bases right-handed, so R = sum v_j u_j^T is a proper rotation; this equals the usual
+    // V diag(1, 1, det(V U^T)) U^T (the direction of the smallest singular value is the one that flips when H contains a reflection)
+    const double* uu[3] = {u0, u1, u2};
+    const double* vv[3] = {v0, v1, v2};
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { R[a][b] = 0; for (int j = 0; j < 3; ++j) R[a][b] += vv[j][a] * uu[j][b]; }
+    for (int a = 0; a < 3; ++a) { t[a] = rc[a]; for (int b = 0; b < 3; ++b) t[a] -= R[a][b] * pc[b]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_evaluate_ate_rmse(const float* traj, const float* ref, uint32_t numTransforms, float* rmse, uint32_t* numEvaluated) {     // PoseHelper.h:35-79
+    BF_REQUIRE((traj && ref) || numTransforms == 0, "null argument");
+    BF_REQUIRE(rmse && numEvaluated, "null argument");
+    const float NINF = -std::numeric_limits<float>::infinity();
+    auto tr = [](const float* T, uint32_t i, int k) { return (double)T[16 * (size_t)i + 4 * k + 3]; };
+    if (numTransforms < 3) {
+        *rmse = NINF; *numEvaluated = numTransforms;
+        if (numTransforms == 2) {
+            const double l = sqrt(tr(ref, 0, 0) * tr(ref, 0, 0) + tr(ref, 0, 1) * tr(ref, 0, 1) + tr(ref, 0, 2) * tr(ref, 0, 2));
+            if (!(l > 0.0001)) {
+                double d = 0;
+                for (int k = 0; k < 3; ++k) d += (tr(traj, 1, k) - tr(ref, 1, k)) * (tr(traj, 1, k) - tr(ref, 1, k));
+                *rmse = (float)sqrt(d);
+            }
+        }
+        return BF_OK;
+    }
+    std::vector<std::array<double, 3>> pts, refPts;
+    for (uint32_t i = 0; i < numTransforms; ++i)
+        if (traj[16 * (size_t)i] != NINF && ref[16 * (size_t)i] != NINF) {
+            pts.push_back({tr(traj, i, 0), tr(traj, i, 1), tr(traj, i, 2)});
+            refPts.push_back({tr(ref, i, 0), tr(ref, i, 1), tr(ref, i, 2)});
+        }
+    if (pts.empty()) { *rmse = NINF; *numEvaluated = 0; return BF_OK; }                    // "ERROR no points to evaluate"
+    double R[3][3], t[3];
+    kabschAlign(pts, refPts, R, t);
+    double err = 0;
+    for (size_t i = 0; i < pts.size(); ++i)
+        for (int a = 0; a < 3; ++a) {
+            double v = t[a] - refPts[i][a];
+            for (int b = 0; b < 3; ++b) v += R[a][b] * pts[i][b];
+            err += v * v;
+        }
+    *rmse = (float)sqrt(err / (double)pts.size());
+    *numEvaluated = (uint32_t)pts.size();
+    return BF_OK;
+}
+
+int bf_sensor_data_evaluate_trajectory(bf_sensor_data* sd, const float* trajectory, uint64_t numTransforms, float* rmse, uint32_t* numEvaluated) {   // :167-189
+    BF_REQUIRE(sd && trajectory && rmse && numEvaluated, "null argument");
+    const size_t nRef = sd->frames.size();
+    BF_REQUIRE(nRef > 0, "no frames");
+    // offset = referenceTrajectory.front().getInverse(); reference[i] = offset * reference[i]  (row-major 4x4, general inverse of a rigid pose)
+    const float* F = sd->frames[0].T;
+    double Rinv[3][3], tinv[3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) Rinv[a][b] = F[4 * b + a];
+    for (int a = 0; a < 3; ++a) { tinv[a] = 0; for (int b = 0; b < 3; ++b) tinv[a] -= Rinv[a][b] * F[4 * b + 3]; }
+    std::vector<float> ref(16 * nRef);
+    const float NINF = -std::numeric_limits<float>::infinity();
+    for (size_t i = 0; i < nRef; ++i) {
+        const float* T = sd->frames[i].T;
+        float* o = ref.data() + 16 * i;
+        if (T[0] == NINF) { for (int k = 0; k < 16; ++k) o[k] = NINF; continue; }
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 4; ++b) { double v = b == 3 ? tinv[a] : 0.0; for (int k = 0; k < 3; ++k) v += Rinv[a][k] * T[4 * k + b]; o[4 * a + b] = (float)v; }
+        }
+        o[12] = o[13] = o[14] = 0.0f; o[15] = 1.0f;
+    }
+    const uint32_t n = (uint32_t)std::min<uint64_t>(numTransforms, nRef);
+    return bf_evaluate_ate_rmse(trajectory, ref.data(), n, rmse, numEvaluated);
 }
 
 }  // extern "C"

@@ -43,6 +43,9 @@ lib.bf_sensor_data_read_color_rgbx.argtypes = [C.c_void_p, C.c_uint64, C.c_void_
 lib.bf_sensor_data_writer_create.argtypes = [C.c_char_p, C.POINTER(SensorDataInfo), C.POINTER(C.c_void_p)]
 lib.bf_sensor_data_writer_add_frame.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
 lib.bf_sensor_data_writer_close.argtypes = [C.c_void_p]
+lib.bf_sensor_data_save_with_trajectory.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+lib.bf_evaluate_ate_rmse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+lib.bf_sensor_data_evaluate_trajectory.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
 
 
 def _pillow_decode(_user, data, size, _ctype, width, height, out):
@@ -131,6 +134,22 @@ class SensorData:
         check(lib.bf_sensor_data_read_color_rgbx(self._h, i, out.ctypes.data))
         return out
 
+    def trajectory(self):
+        """cameraToWorld of every frame (SensorDataReader::getTrajectory)."""
+        return np.stack([self.pose(i)[0] for i in range(len(self))]) if len(self) else np.zeros((0, 4, 4), np.float32)
+
+    def save_with_trajectory(self, filename, trajectory):
+        """SensorDataReader::saveToFile(filename, trajectory): frames beyond the trajectory get an all -inf pose."""
+        T = np.ascontiguousarray(trajectory, np.float32).reshape(-1, 16)
+        check(lib.bf_sensor_data_save_with_trajectory(self._h, str(filename).encode(), T.ctypes.data if len(T) else None, len(T)))
+
+    def evaluate_trajectory(self, trajectory):
+        """SensorDataReader::evaluateTrajectory: (ATE RMSE [m], number of poses used) against the stored poses re-based to identity."""
+        T = np.ascontiguousarray(trajectory, np.float32).reshape(-1, 16)
+        rmse, n = C.c_float(), C.c_uint32()
+        check(lib.bf_sensor_data_evaluate_trajectory(self._h, T.ctypes.data, len(T), C.byref(rmse), C.byref(n)))
+        return rmse.value, n.value
+
 
 class SensorDataWriter:
     """SensorData::saveToFile, frame by frame."""
@@ -180,3 +199,13 @@ def depth_to_u16(depth_m, depth_shift=1000.0):
     q = np.zeros(d.shape, np.uint16)
     q[ok] = np.clip(np.rint(d[ok] * depth_shift), 1, 65535).astype(np.uint16)
     return q
+
+
+def ate_rmse(trajectory, reference):
+    """PoseHelper::evaluateAteRmse: (RMSE of the camera positions after a rigid alignment, number of poses used)."""
+    A = np.ascontiguousarray(trajectory, np.float32).reshape(-1, 16)
+    B = np.ascontiguousarray(reference, np.float32).reshape(-1, 16)
+    n = min(len(A), len(B))
+    rmse, num = C.c_float(), C.c_uint32()
+    check(lib.bf_evaluate_ate_rmse(A.ctypes.data if n else None, B.ctypes.data if n else None, n, C.byref(rmse), C.byref(num)))
+    return rmse.value, num.value

@@ -1,8 +1,9 @@
 // Headless driver written against the reference's class names (include/bundlefusion/bundlefusion.hpp):
 // the serial body of DepthSensing.cpp's OnD3D11FrameRender without DirectX.  Build:
 //   g++ -std=c++17 -I include examples/headless_driver.cpp -L bundlefusion_amd/lib -lbf_hip -Wl,-rpath,$PWD/bundlefusion_amd/lib -o headless_driver
-// Run:  ./headless_driver zParametersDefault.txt zParametersBundlingDefault.txt   (feeds a constant-depth dummy sensor;
-// plug a real RGBDSensor subclass in for recorded data).
+// Run:  ./headless_driver zParametersDefault.txt zParametersBundlingDefault.txt
+// With s_sensorIdx = 8 the file named by s_binaryDumpSensorFile is played (SensorDataReader, FriedLiver.cpp:89-94) and the
+// optimised trajectory is evaluated against the poses stored in it; any other sensor index feeds a constant-depth dummy sensor.
 #include <cstdio>
 #include <limits>
 
@@ -34,7 +35,11 @@ int main(int argc, char** argv) {
         GlobalBundlingState::get().readMembers(argv[2]);
         const GlobalAppState& gas = GlobalAppState::get();
         const GlobalBundlingState& gbs = GlobalBundlingState::get();
-        DummySensor sensor(640, 480, 30);
+        DummySensor dummy(640, 480, 30);
+        SensorDataReader reader;
+        const bool useFile = gas.s_sensorIdx == 8;
+        if (useFile) reader.createFirstConnected();
+        RGBDSensor& sensor = useFile ? static_cast<RGBDSensor&>(reader) : static_cast<RGBDSensor&>(dummy);
         CUDAImageManager imageManager(gas.s_integrationWidth, gas.s_integrationHeight, gbs.s_widthSIFT, gbs.s_heightSIFT, &sensor);
         OnlineBundler bundler(&sensor, &imageManager);
         CUDASceneRepHashSDF sceneRep(CUDASceneRepHashSDF::parametersFromGlobalAppState(gas));
@@ -79,6 +84,11 @@ int main(int argc, char** argv) {
             }
             bundler.process(gbs.s_numLocalNonLinIterations, gbs.s_numLocalLinIterations, gbs.s_numGlobalNonLinIterations, gbs.s_numGlobalLinIterations);
             std::printf("<<< [Frame: %u ] %u >>>\n", imageManager.getCurrFrameNumber(), sceneRep.getHeapFreeCount());
+        }
+        if (useFile) {                                          // DepthSensing.cpp:905-910 (StopScanningAndExit): evaluate against the recorded trajectory
+            std::vector<mat4f> trajectory;
+            tm->getOptimizedTransforms(trajectory);
+            reader.evaluateTrajectory(trajectory);
         }
     } catch (const std::exception& e) {
         std::printf("error: %s\n", e.what());

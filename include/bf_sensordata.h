@@ -79,6 +79,21 @@ BF_API int bf_sensor_data_writer_add_frame(bf_sensor_data_writer* w, const float
                                            const uint16_t* depth);
 BF_API int bf_sensor_data_writer_close(bf_sensor_data_writer* w);
 
+/* SensorDataReader::saveToFile(filename, trajectory) (SensorDataReader.cpp:152-165, "kind of a hack"): the same frames with
+ * cameraToWorld replaced by trajectory[i] (16 floats each) for i < numTransforms and by an all -inf matrix for the rest. */
+BF_API int bf_sensor_data_save_with_trajectory(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms);
+
+/* PoseHelper::evaluateAteRmse (PoseHelper.h:35-79): absolute trajectory error after a rigid (Kabsch) alignment of the camera
+ * positions; transforms whose first element is -inf are skipped on either side.  *rmse = -inf when fewer than 3 transforms are
+ * given (except the reference's special case for 2).  *numEvaluated = number of positions used.  mLib's EigenWrapperf::kabsch is
+ * not in the tree: the alignment here is the textbook SVD solution (double precision). */
+BF_API int bf_evaluate_ate_rmse(const float* trajectory, const float* referenceTrajectory, uint32_t numTransforms, float* rmse,
+                                uint32_t* numEvaluated);
+/* SensorDataReader::evaluateTrajectory (:167-189): the file's cameraToWorld poses, re-based so that the first is identity, are
+ * the reference. */
+BF_API int bf_sensor_data_evaluate_trajectory(bf_sensor_data* sd, const float* trajectory, uint64_t numTransforms, float* rmse,
+                                              uint32_t* numEvaluated);
+
 #ifdef __cplusplus
 }
 #endif

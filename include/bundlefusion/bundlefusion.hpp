@@ -6,12 +6,16 @@
 // Matrix arguments are `mat4f` = 16 floats, row-major (same memory as ml::mat4f / float4x4).
 #pragma once
 #include <array>
+#include <cstdio>
 #include <cstring>
+#include <limits>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../bf_pipeline.h"
+#include "../bf_sensordata.h"
 
 namespace bundlefusion {
 
@@ -60,6 +64,82 @@ public:
     const bf_rgbd_sensor_desc& desc() const { return m_desc; }
 protected:
     bf_rgbd_sensor_desc m_desc;
+};
+
+// ---- SensorDataReader (SensorDataReader.h:19-68): plays a recorded ".sens" file through the RGBDSensor contract
+class SensorDataReader : public RGBDSensor {
+public:
+    SensorDataReader() { std::memset(&m_desc, 0, sizeof m_desc); }
+    ~SensorDataReader() { releaseData(); }
+    SensorDataReader(const SensorDataReader&) = delete;
+    // optional PNG / JPEG decoder (the reference decodes inside mLib with stb_image); raw colour needs none
+    void setColorDecoder(bf_sens_color_decoder fn, void* user) { m_decoder = fn; m_decoderUser = user; if (m_sd) check(bf_sensor_data_set_color_decoder(m_sd, fn, user)); }
+    void createFirstConnected() { createFirstConnected(GlobalAppState::get().s_binaryDumpSensorFile); }         // .cpp:40-83
+    void createFirstConnected(const std::string& filename) {
+        releaseData();
+        check(bf_sensor_data_open(filename.c_str(), &m_sd));
+        if (m_decoder) check(bf_sensor_data_set_color_decoder(m_sd, m_decoder, m_decoderUser));
+        check(bf_sensor_data_get_info(m_sd, &m_info));
+        check(bf_sensor_data_get_sensor_desc(m_sd, &m_desc));
+        m_numFrames = (unsigned int)m_info.numFrames;
+        const GlobalBundlingState& gbs = GlobalBundlingState::get();
+        if (m_numFrames > gbs.s_maxNumImages * gbs.s_submapSize)                                               // :65-67
+            throw std::runtime_error("sens file #frames = " + std::to_string(m_numFrames) + ", please change param file to accommodate");
+        uint64_t colorBytes = 0, depthBytes = 0;
+        if (m_numFrames > 0) check(bf_sensor_data_get_frame_sizes(m_sd, 0, &colorBytes, &depthBytes));
+        m_bHasColorData = m_numFrames > 0 && colorBytes > 0;                                                   // :73-78
+        m_depth.assign((size_t)m_desc.depthWidth * m_desc.depthHeight, 0.0f);
+        m_colorRGBX.assign((size_t)m_desc.colorWidth * m_desc.colorHeight * 4, 0);
+        m_currFrame = 0; m_playData = true; m_bIsReceivingFrames = true;
+    }
+    bool processDepth() override {                                                                              // .cpp:85-122
+        if (!m_sd) return false;
+        if (m_currFrame >= m_numFrames) { m_playData = false; stopReceivingFrames(); m_currFrame = 0; }        // "binary dump sequence complete"
+        if (!m_playData) return false;
+        check(bf_sensor_data_read_depth(m_sd, m_currFrame, m_depth.data()));                                   // 0 -> -inf, u16 / depthShift
+        if (m_bHasColorData) check(bf_sensor_data_read_color_rgbx(m_sd, m_currFrame, m_colorRGBX.data()));
+        m_currFrame++;
+        return true;
+    }
+    bool processColor() override { return true; }                 // everything is done in processDepth (.h:35-38)
+    const float* getDepthFloat() const override { return m_depth.data(); }
+    const unsigned char* getColorRGBX() const override { return m_colorRGBX.data(); }
+    std::string getSensorName() const { return m_info.sensorName; }
+    unsigned int getNumFrames() const { return m_numFrames; }
+    bool isReceivingFrames() const { return m_bIsReceivingFrames; }
+    void stopReceivingFrames() { m_bIsReceivingFrames = false; }
+    mat4f getRigidTransform(int offset) const {                                                                 // .cpp:128-135
+        const unsigned int idx = m_currFrame - 1 + offset;
+        if (!m_sd || idx >= m_numFrames) throw std::runtime_error("invalid trajectory index " + std::to_string(idx));
+        mat4f T; check(bf_sensor_data_get_frame_pose(m_sd, idx, T.m, nullptr, nullptr));
+        return T;
+    }
+    void getTrajectory(std::vector<mat4f>& trajectory) const {                                                  // .cpp:191-201
+        trajectory.clear();
+        if (!m_sd) return;
+        trajectory.resize(m_numFrames);
+        for (unsigned int f = 0; f < m_numFrames; f++) {
+            check(bf_sensor_data_get_frame_pose(m_sd, f, trajectory[f].m, nullptr, nullptr));
+            if (trajectory[f].m[0] == -std::numeric_limits<float>::infinity()) throw std::runtime_error("ERROR invalid transform in reference trajectory");
+        }
+    }
+    void saveToFile(const std::string& filename, const std::vector<mat4f>& trajectory) const {                 // .cpp:152-165
+        check(bf_sensor_data_save_with_trajectory(m_sd, filename.c_str(), trajectory.empty() ? nullptr : trajectory[0].m, trajectory.size()));
+    }
+    std::pair<float, unsigned int> evaluateTrajectory(const std::vector<mat4f>& trajectory) const {            // .cpp:167-189 (prints "ate rmse = ..")
+        float rmse = 0.0f; uint32_t n = 0;
+        check(bf_sensor_data_evaluate_trajectory(m_sd, trajectory.empty() ? nullptr : trajectory[0].m, trajectory.size(), &rmse, &n));
+        std::printf("*********************************\nate rmse = %g, %u\n*********************************\n", rmse, n);
+        return std::make_pair(rmse, (unsigned int)n);
+    }
+private:
+    void releaseData() { if (m_sd) bf_sensor_data_close(m_sd); m_sd = nullptr; m_currFrame = 0; m_bHasColorData = false; }
+    bf_sensor_data* m_sd = nullptr;
+    bf_sensor_data_info m_info;
+    bf_sens_color_decoder m_decoder = nullptr; void* m_decoderUser = nullptr;
+    std::vector<float> m_depth; std::vector<unsigned char> m_colorRGBX;
+    unsigned int m_numFrames = 0, m_currFrame = 0;
+    bool m_bHasColorData = false, m_playData = true, m_bIsReceivingFrames = false;
 };
 
 // ---- CUDAImageManager (CUDAImageManager.h:10-337)

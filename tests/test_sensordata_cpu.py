@@ -210,3 +210,94 @@ def test_depth_quantisation_helper():
     d = np.array([[0.4004, np.inf, -np.inf, 0.0, 70.0, 1.2345678]], np.float32)
     q = sdm.depth_to_u16(d, 1000.0)
     assert q.tolist() == [[400, 0, 0, 0, 65535, 1235]]
+
+
+# ---------------------------------------------------------------------------------------- trajectory evaluation (PoseHelper.h:35-79)
+def _rigid(rng, angle=1.0, trans=1.0):
+    a = rng.normal(size=3); a /= np.linalg.norm(a)
+    th = angle * rng.uniform(0.2, 1.0)
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = trans * rng.normal(size=3)
+    return T
+
+
+def _np_ate(traj, ref):
+    """independent restatement: numpy SVD Kabsch on the camera positions, poses with -inf skipped"""
+    ok = np.isfinite(traj[:, 0, 0]) & np.isfinite(ref[:, 0, 0])
+    p, r = traj[ok][:, :3, 3].astype(np.float64), ref[ok][:, :3, 3].astype(np.float64)
+    pc, rc = p.mean(0), r.mean(0)
+    H = (p - pc).T @ (r - rc)
+    U, S, Vt = np.linalg.svd(H)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    t = rc - R @ pc
+    e = (R @ p.T).T + t - r
+    return float(np.sqrt((e ** 2).sum(1).mean())), int(ok.sum())
+
+
+def test_ate_rmse_matches_numpy_kabsch():
+    rng = np.random.default_rng(7)
+    for n, noise, planar in ((50, 0.0, False), (200, 0.02, False), (30, 0.01, True), (3, 0.05, False)):
+        ref = np.stack([_rigid(rng) for _ in range(n)]).astype(np.float32)
+        if planar:
+            ref[:, 2, 3] = 0.25
+        G = _rigid(rng, 2.0, 3.0)
+        traj = np.stack([G @ T for T in ref.astype(np.float64)])
+        traj[:, :3, 3] += noise * rng.normal(size=(n, 3))
+        traj = traj.astype(np.float32)
+        if n > 10:
+            traj[5] = -np.inf; ref[9] = -np.inf                     # invalid poses are skipped on either side (:52)
+        got, num = sdm.ate_rmse(traj, ref)
+        want, wnum = _np_ate(traj, ref)
+        assert num == wnum
+        assert abs(got - want) < 2e-6 + 1e-4 * want, (n, got, want)
+        if noise == 0.0:
+            assert got < 1e-5
+    # a mirrored point set must not be "aligned" by a reflection
+    ref = np.stack([_rigid(rng) for _ in range(40)]).astype(np.float32)
+    mir = ref.copy(); mir[:, 0, 3] *= -1
+    got, _ = sdm.ate_rmse(mir, ref)
+    want, _ = _np_ate(mir, ref)
+    assert abs(got - want) < 1e-5 and got > 0.1
+    # fewer than three transforms (:37-47)
+    assert sdm.ate_rmse(ref[:1], ref[:1]) == (-np.inf, 1)
+    two_ref = np.stack([np.eye(4), _rigid(rng)]).astype(np.float32)
+    two = two_ref.copy(); two[1, :3, 3] += [0.03, 0.0, 0.04]
+    got, num = sdm.ate_rmse(two, two_ref)
+    assert num == 2 and abs(got - 0.05) < 1e-6
+    two_ref[0, 0, 3] = 0.5                                           # "cannot evaluate 2 with reference[0] not identity"
+    assert sdm.ate_rmse(two, two_ref)[0] == -np.inf
+    allbad = ref.copy(); allbad[:] = -np.inf
+    assert sdm.ate_rmse(allbad, ref) == (-np.inf, 0)
+
+
+def test_save_with_trajectory_and_evaluate(tmp_path):
+    w, h = 24, 16
+    rng = np.random.default_rng(11)
+    frames = _frames(6, w, h, seed=2)
+    poses = [_rigid(rng).astype(np.float32) for _ in range(6)]
+    frames = [(poses[k],) + frames[k][1:] for k in range(6)]
+    src = tmp_path / "src.sens"
+    _py_write(src, frames, w, h, w, h, 1, sdm.COLOR_RAW, 1000.0, imu=2)
+    sd = sdm.SensorData(src)
+    assert np.array_equal(sd.trajectory(), np.stack(poses))
+    # the stored poses, re-based to identity, evaluate to zero against themselves re-based (SensorDataReader.cpp:172-175)
+    base = np.linalg.inv(poses[0].astype(np.float64))
+    rebased = np.stack([(base @ p.astype(np.float64)) for p in poses]).astype(np.float32)
+    rmse, n = sd.evaluate_trajectory(rebased)
+    assert n == 6 and rmse < 1e-5
+    moved = rebased.copy(); moved[:, :3, 3] += rng.normal(scale=0.01, size=(6, 3)).astype(np.float32)
+    want, _ = _np_ate(moved, rebased)
+    assert abs(sd.evaluate_trajectory(moved)[0] - want) < 1e-5
+    # saveToFile(filename, trajectory) with a shorter trajectory: the rest becomes -inf, payloads are untouched
+    out = tmp_path / "out.sens"
+    sd.save_with_trajectory(out, moved[:4])
+    r = _py_read(out)
+    assert len(r["frames"]) == 6 and r["nimu"] == 0
+    for k in range(6):
+        T2, tc, td, cb, db = r["frames"][k]
+        assert np.array_equal(T2, moved[k]) if k < 4 else np.isneginf(T2).all()
+        assert (tc, td) == (frames[k][3], frames[k][4]) and cb == frames[k][2].tobytes()
+        assert np.array_equal(np.frombuffer(zlib.decompress(db), "<u2").reshape(h, w), frames[k][1])
+    sd.close()
