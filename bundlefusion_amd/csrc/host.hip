@@ -1550,6 +1550,9 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
         (void)hipEventElapsedTime(&p->last.timeReconstruct, p->ev[6], p->ev[7]);
         (void)hipEventElapsedTime(&p->last.timeTotal, p->ev[0], p->ev[3]);
     }
+    // the caller's depth / colour buffers (host or device) are free for reuse when this returns, like after the reference's
+    // synchronous CUDAImageManager::process: the ingest ran beside the previous frame's body, so this wait is normally over already
+    if (got) BF_HIP_TRY(hipEventSynchronize(p->evIngest[frame % bf_pipeline::NEV]));
     if (gotFrame) *gotFrame = got;
     return BF_OK;
 }

@@ -238,7 +238,9 @@ BF_API int bf_pipeline_destroy(bf_pipeline* p);
 /* Multi-GPU mode "volume shard": every rank runs the (bit-deterministic) bundling on the whole stream and integrates only
  * its hash-bucket shard of the volume (bf_scene_set_shard).  Call before the first frame. */
 BF_API int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world);
-/* one iteration of the frame loop with a new sensor frame (host or device resident) */
+/* one iteration of the frame loop with a new sensor frame (host or device resident).  The two buffers may be reused as soon as
+ * the call returns.  With the look-ahead (default; BF_PIPELINE_LOOKAHEAD=0 disables it) matching / integration / solves of this
+ * frame are completed by the next call, by bf_pipeline_synchronize or by any accessor below - results are those of the serial order. */
 BF_API int bf_pipeline_process_frame(bf_pipeline* p, const float* h_depth, const uint8_t* h_colorRGBX, int* gotFrame);
 BF_API int bf_pipeline_process_frame_device(bf_pipeline* p, const float* d_depth, const uint8_t* d_colorRGBX, int* gotFrame);
 /* one iteration after the sensor stopped delivering frames (solve + re-integration continue, :175-196) */
