@@ -759,6 +759,16 @@ int bf_trajectory_manager_update_optimized_transform(bf_trajectory_manager* tm, 
     return BF_OK;
 }
 
+// the same with the trajectory already on the host (updateOptimizedTransform takes a device pointer because the bundler's
+// trajectory lives there, TrajectoryManager.cpp:36-45)
+int bf_trajectory_manager_update_optimized_transform_host(bf_trajectory_manager* tm, const float* h_trajectory, uint32_t numFrames) {
+    BF_REQUIRE(tm && (h_trajectory || numFrames == 0), "null argument");
+    tm->numOptimizedFrames = numFrames;
+    numFrames = std::min(numFrames, tm->numAddedFrames);
+    if (numFrames) memcpy(tm->optimizedTransforms.data(), h_trajectory, sizeof(m44) * numFrames);
+    return BF_OK;
+}
+
 int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm) {        // :47-111
     BF_REQUIRE(tm, "null manager");
     const uint32_t numFrames = std::min(tm->numOptimizedFrames, tm->numAddedFrames);

@@ -165,6 +165,7 @@ BF_API int bf_trajectory_manager_create(uint32_t numMaxImage, uint32_t topNActiv
 BF_API int bf_trajectory_manager_destroy(bf_trajectory_manager* tm);
 BF_API int bf_trajectory_manager_add_frame(bf_trajectory_manager* tm, int type, const float transform[16], uint32_t idx);
 BF_API int bf_trajectory_manager_update_optimized_transform(bf_trajectory_manager* tm, const float* d_trajectory, uint32_t numFrames, void* hip_stream);
+BF_API int bf_trajectory_manager_update_optimized_transform_host(bf_trajectory_manager* tm, const float* h_trajectory, uint32_t numFrames);   /* host copy of the trajectory */
 BF_API int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm);
 BF_API int bf_trajectory_manager_confirm_integration(bf_trajectory_manager* tm, uint32_t frameIdx);
 BF_API int bf_trajectory_manager_get_top_from_reintegrate_list(bf_trajectory_manager* tm, float oldTransform[16], float newTransform[16], uint32_t* frameIdx, int* found);

@@ -1,0 +1,143 @@
+"""CPU test of the TrajectoryManager host logic (TrajectoryManager.cpp:24-200) through the C ABI,
+against the Python restatement the oracle frame loop uses (tests/oracle_pipeline.py::OTrajectoryManager +
+OraclePipeline._reintegrate's list consumers).  Both are driven by the same random script of frame-loop events."""
+import ctypes as C
+
+import numpy as np
+
+from bundlefusion_amd.capi import lib, check
+from tests.oracle_pipeline import OTrajectoryManager, NINF, _minf
+
+
+def _pose(rng, scale):
+    a = rng.normal(size=3); a /= np.linalg.norm(a)
+    th = scale * rng.uniform(0.0, 1.0)
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    T = np.eye(4)
+    T[:3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    T[:3, 3] = scale * rng.normal(size=3)
+    return T.astype(np.float32)
+
+
+class _CTM:
+    def __init__(self, n, top_n, min_dist):
+        self.h = C.c_void_p()
+        check(lib.bf_trajectory_manager_create(n, top_n, C.c_float(min_dist), C.byref(self.h)))
+
+    def close(self):
+        lib.bf_trajectory_manager_destroy(self.h)
+
+    def add(self, typ, T, idx):
+        check(lib.bf_trajectory_manager_add_frame(self.h, typ, np.ascontiguousarray(T, np.float32).ctypes.data_as(C.POINTER(C.c_float)), idx))
+
+    def update(self, traj):
+        a = np.ascontiguousarray(traj, np.float32)
+        check(lib.bf_trajectory_manager_update_optimized_transform_host(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), len(a)))
+
+    def generate(self):
+        check(lib.bf_trajectory_manager_generate_update_lists(self.h))
+
+    def active(self):
+        n = C.c_uint32()
+        check(lib.bf_trajectory_manager_get_num_active_operations(self.h, C.byref(n)))
+        return n.value
+
+    def _top(self, fn, two):
+        a, b = (C.c_float * 16)(), (C.c_float * 16)()
+        idx, found = C.c_uint32(), C.c_int()
+        if two:
+            check(fn(self.h, a, b, C.byref(idx), C.byref(found)))
+        else:
+            check(fn(self.h, a, C.byref(idx), C.byref(found)))
+        return bool(found.value), idx.value, np.array(a, np.float32).reshape(4, 4), np.array(b, np.float32).reshape(4, 4)
+
+    def top_de(self):
+        return self._top(lib.bf_trajectory_manager_get_top_from_deintegrate_list, False)
+
+    def top_in(self):
+        return self._top(lib.bf_trajectory_manager_get_top_from_integrate_list, False)
+
+    def top_re(self):
+        return self._top(lib.bf_trajectory_manager_get_top_from_reintegrate_list, True)
+
+    def confirm(self, idx):
+        check(lib.bf_trajectory_manager_confirm_integration(self.h, idx))
+
+    def frame(self, idx):
+        t, d = C.c_int(), C.c_float()
+        T = (C.c_float * 16)()
+        check(lib.bf_trajectory_manager_get_frame(self.h, idx, C.byref(t), T, C.byref(d)))
+        return t.value, np.array(T, np.float32).reshape(4, 4), d.value
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+def test_trajectory_manager_matches_restatement():
+    lib.bf_trajectory_manager_update_optimized_transform_host.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+    for seed, top_n, min_dist, max_fixes in ((0, 30, 0.0, 10), (1, 5, 0.0004, 3), (2, 8, 0.0, 1)):
+        rng = np.random.default_rng(seed)
+        n_max = 120
+        c, o = _CTM(n_max, top_n, min_dist), OTrajectoryManager(n_max, top_n, min_dist)
+        gt = [_pose(rng, 0.5) for _ in range(n_max)]
+        ops = []
+        for frame in range(n_max):
+            # ---- reintegrate() (DepthSensing.cpp:854-902) on both sides, logging what would be (de-)integrated
+            if c.active() < max_fixes:
+                c.generate()
+            if o.num_active() < max_fixes:
+                o.generate_update_lists()
+            assert c.active() == o.num_active()
+            for _ in range(max_fixes):
+                f, idx, T, _ = c.top_de()
+                if f:
+                    g = o.to_de.popleft()
+                    assert idx == g["idx"] and _same(T, g["integrated"])
+                    ops.append(("de", idx)); continue
+                f, idx, T, _ = c.top_in()
+                if f:
+                    g = o.to_in.popleft()
+                    assert g["type"] == 2 and idx == g["idx"] and _same(T, o.opt[g["idx"]])
+                    g["integrated"] = o.opt[g["idx"]].copy(); g["type"] = 0
+                    c.confirm(idx)
+                    ops.append(("in", idx)); continue
+                f, idx, oldT, newT = c.top_re()
+                if f:
+                    old = new = g = None
+                    while o.to_re:
+                        g = o.to_re.popleft()
+                        new = o.opt[g["idx"]].copy(); old = g["integrated"].copy()
+                        if new[0, 0] != NINF:
+                            g["integrated"] = new
+                            break
+                    assert g is not None and idx == g["idx"] and _same(oldT, old) and _same(newT, new)
+                    if newT[0, 0] == NINF:
+                        continue
+                    g["type"] = 0
+                    c.confirm(idx)
+                    ops.append(("re", idx)); continue
+                assert not (o.to_de or o.to_in or o.to_re)
+                break
+            # ---- the new frame: tracked (integrated at a slightly wrong pose) or not
+            if rng.random() < 0.85:
+                T = (gt[frame].astype(np.float64) @ _pose(rng, 0.01).astype(np.float64)).astype(np.float32)
+                c.add(0, T, frame); o.add_frame(0, T, frame)
+            else:
+                c.add(1, _minf(), frame); o.add_frame(1, _minf(), frame)
+            # ---- every 10 frames an optimisation result arrives: better poses, some frames invalidated, some recovered
+            if frame % 10 == 9:
+                n = frame + 1 - int(rng.integers(0, 3))
+                traj = np.stack([(gt[i].astype(np.float64) @ _pose(rng, 0.002).astype(np.float64)).astype(np.float32) for i in range(n)])
+                bad = rng.random(n) < 0.08
+                traj[bad] = -np.inf
+                c.update(traj); o.update_optimized(traj, n)
+            for i in range(frame + 1):
+                t, T, d = c.frame(i)
+                g = o.frames[i]
+                assert t == g["type"], (seed, frame, i)
+                assert _same(T, g["integrated"])
+                assert np.float32(d).view(np.uint32) == np.float32(g["dist"]).view(np.uint32), (seed, frame, i, d, g["dist"])
+        kinds = {k for k, _ in ops}
+        assert kinds == {"de", "in", "re"}, kinds            # the script exercised all three lists
+        c.close()
