@@ -8,6 +8,8 @@
 #include <array>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iostream>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -64,6 +66,122 @@ public:
     const bf_rgbd_sensor_desc& desc() const { return m_desc; }
 protected:
     bf_rgbd_sensor_desc m_desc;
+};
+
+// ---- TimingLog (TimingLog.h:6-283): per-frame timings in the reference's text / "excel" file formats, so that numbers are
+// comparable with a CUDA run of the reference.  Fed from bf_frame_timing (bf_pipeline_get_last_timing) or filled directly.
+class TimingLog {
+public:
+    struct FrameTiming {                                               // TimingLog.h:9-57
+        double timeSiftDetection = 0, timeSiftMatching = 0, timeMatchFilterKeyPoint = 0, timeMatchFilterSurfaceArea = 0, timeMatchFilterDenseVerify = 0;
+        double timeMisc = 0, timeSolve = 0; unsigned int numItersSolve = 0;
+        double timeSensorProcess = 0, timeReIntegrate = 0, timeReconstruct = 0, timeVisualize = 0;
+        FrameTiming() {}
+        explicit FrameTiming(const bf_frame_timing& t) {               // the loop's stage timings; the three filters are one stage here
+            timeSiftDetection = t.timeSiftDetection; timeSiftMatching = t.timeSiftMatching; timeMatchFilterKeyPoint = t.timeMatchFilter;
+            timeSolve = t.timeSolve; timeSensorProcess = t.timeSensorProcess; timeReIntegrate = t.timeReIntegrate; timeReconstruct = t.timeReconstruct;
+        }
+        void print(std::ostream* out, bool printDepthSensing) const {
+            *out << "\tTime SIFT Detection: " << std::to_string(timeSiftDetection) << "ms" << std::endl;
+            *out << "\tTime SIFT Matching: " << std::to_string(timeSiftMatching) << "ms" << std::endl;
+            *out << "\tTime Match Filter Key Point: " << std::to_string(timeMatchFilterKeyPoint) << "ms" << std::endl;
+            *out << "\tTime Match Filter Surface Area: " << std::to_string(timeMatchFilterSurfaceArea) << "ms" << std::endl;
+            *out << "\tTime Match Filter Dense Verify: " << std::to_string(timeMatchFilterDenseVerify) << "ms" << std::endl;
+            *out << "\tTime Misc: " << std::to_string(timeMisc) << "ms" << std::endl;
+            *out << "\tTime Solve: " << std::to_string(timeSolve) << "ms" << std::endl;
+            *out << "\t#iters solve: " << std::to_string(numItersSolve) << std::endl;
+            if (printDepthSensing) {
+                *out << "\tTime Process Input: " << std::to_string(timeSensorProcess) << "ms" << std::endl;
+                *out << "\tTime Re-Integrate: " << std::to_string(timeReIntegrate) << "ms" << std::endl;
+                *out << "\tTime Reconstruct: " << std::to_string(timeReconstruct) << std::endl;
+                *out << "\tTime Visualize: " << std::to_string(timeVisualize) << std::endl;
+            }
+        }
+    };
+    static void init() { resetTimings(); }
+    static void destroy() {}
+    static void resetTimings() { local().clear(); global().clear(); total().clear(); }
+    static void addLocalFrameTiming() { local().push_back(FrameTiming()); }
+    static void addGlobalFrameTiming() { global().push_back(FrameTiming()); }
+    static void addLocalFrameTiming(const bf_frame_timing& t) { local().push_back(FrameTiming(t)); total().push_back(t.timeTotal); }
+    static FrameTiming& getFrameTiming(bool isLocal) { return isLocal ? local().back() : global().back(); }
+    static void printAllTimings(const std::string& dir = "./timings/") {   // the directory must exist (the reference creates it with mLib's util)
+        printTimings(dir + (total().empty() ? "timingLog.txt" : "timingLogPerFrame.txt"));
+        printExcelTimings(dir + "excel");
+    }
+    static void printTimings(const std::string& filename) {             // TimingLog.h:83-121
+        std::ofstream outFile;
+        if (!filename.empty()) outFile.open(filename, std::ios::out);
+        std::ostream& out = filename.empty() ? std::cout : outFile;
+        if (!global().empty()) {
+            out << "Global Timings Per Frame:" << std::endl;
+            for (unsigned int i = 0; i < global().size(); i++) { out << "[ frame " << i << " ]" << std::endl; global()[i].print(&out, false); }
+            out << std::endl << std::endl;
+        }
+        if (!local().empty()) {
+            out << "Local Timings Per Frame:" << std::endl;
+            for (unsigned int i = 0; i < local().size(); i++) { out << "[ frame " << i << " ]" << std::endl; local()[i].print(&out, true); }
+            out << std::endl << std::endl;
+        }
+        if (!total().empty()) {
+            out << "Total Timings Per Frame:" << std::endl;
+            for (unsigned int i = 0; i < total().size(); i++) out << "[ frame " << i << " ] " << total()[i] << " ms" << std::endl;
+            out << std::endl << std::endl;
+        }
+    }
+    static void printExcelTimings(const std::string& prefix) {          // TimingLog.h:204-233
+        const std::string separator = ",";
+        if (!global().empty()) { std::ofstream out(prefix + "_global.txt"); printAverages(&out, separator, global(), false); printExcelTimings(&out, separator, global(), false); }
+        if (!local().empty()) { std::ofstream out(prefix + "_local.txt"); printAverages(&out, separator, local(), true); printExcelTimings(&out, separator, local(), true); }
+        if (!total().empty()) {
+            std::ofstream out(prefix + "_total.txt");
+            out << "Per Frame Timings";
+            for (unsigned int i = 0; i < total().size(); i++) out << separator << total()[i];
+        }
+    }
+private:
+    static std::vector<FrameTiming>& local() { static std::vector<FrameTiming> v; return v; }
+    static std::vector<FrameTiming>& global() { static std::vector<FrameTiming> v; return v; }
+    static std::vector<double>& total() { static std::vector<double> v; return v; }
+    template <class F> static void row(std::ofstream* out, const char* name, const std::string& sep, const std::vector<FrameTiming>& ft, F field) {
+        *out << name;
+        for (unsigned int i = 0; i < ft.size(); i++) *out << sep << field(ft[i]);
+        *out << std::endl;
+    }
+    static void printExcelTimings(std::ofstream* out, const std::string& sep, const std::vector<FrameTiming>& ft, bool printDepthSensing) {   // :123-162
+        row(out, "SIFT Detection", sep, ft, [](const FrameTiming& f) { return f.timeSiftDetection; });
+        row(out, "SIFT Matching", sep, ft, [](const FrameTiming& f) { return f.timeSiftMatching; });
+        row(out, "Match Filter Key Point", sep, ft, [](const FrameTiming& f) { return f.timeMatchFilterKeyPoint; });
+        row(out, "Match Filter Surface Area", sep, ft, [](const FrameTiming& f) { return f.timeMatchFilterSurfaceArea; });
+        row(out, "Match Filter Dense Verify", sep, ft, [](const FrameTiming& f) { return f.timeMatchFilterDenseVerify; });
+        row(out, "Misc", sep, ft, [](const FrameTiming& f) { return f.timeMisc; });
+        row(out, "Solve", sep, ft, [](const FrameTiming& f) { return f.timeSolve; });
+        row(out, "Solve #Iters", sep, ft, [](const FrameTiming& f) { return f.numItersSolve; });
+        if (printDepthSensing) {
+            row(out, "Process Input", sep, ft, [](const FrameTiming& f) { return f.timeSensorProcess; });
+            row(out, "Re-Integrate", sep, ft, [](const FrameTiming& f) { return f.timeReIntegrate; });
+            row(out, "Reconstruct", sep, ft, [](const FrameTiming& f) { return f.timeReconstruct; });
+            row(out, "Visualize", sep, ft, [](const FrameTiming& f) { return f.timeVisualize; });
+        }
+    }
+    template <class F> static void average(std::ofstream* out, const char* name, const std::string& sep, const std::vector<FrameTiming>& ft, F field) {
+        double sum = 0.0; unsigned int count = 0;
+        for (unsigned int i = 0; i < ft.size(); i++) { sum += field(ft[i]); count++; }
+        *out << name << sep << (sum / count) << sep << count << std::endl;
+    }
+    static void printAverages(std::ofstream* out, const std::string& sep, const std::vector<FrameTiming>& ft, bool printDepthSensing) {        // :164-202
+        *out << "Average times:" << std::endl;
+        average(out, "SIFT Detection", sep, ft, [](const FrameTiming& f) { return f.timeSiftDetection; });
+        average(out, "SIFT Matching", sep, ft, [](const FrameTiming& f) { return f.timeSiftMatching; });
+        average(out, "Corr Filter", sep, ft, [](const FrameTiming& f) { return f.timeMatchFilterKeyPoint + f.timeMatchFilterSurfaceArea + f.timeMatchFilterDenseVerify; });
+        average(out, "Misc", sep, ft, [](const FrameTiming& f) { return f.timeMisc; });
+        average(out, "Solve", sep, ft, [](const FrameTiming& f) { return f.timeSolve; });
+        if (printDepthSensing) {
+            average(out, "Re-Integrate", sep, ft, [](const FrameTiming& f) { return f.timeReIntegrate; });
+            average(out, "Misc", sep, ft, [](const FrameTiming& f) { return f.timeSensorProcess + f.timeReconstruct + f.timeVisualize; });
+        }
+        *out << std::endl << std::endl;
+    }
 };
 
 // ---- SensorDataReader (SensorDataReader.h:19-68): plays a recorded ".sens" file through the RGBDSensor contract

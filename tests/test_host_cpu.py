@@ -164,3 +164,49 @@ def test_integrate_colour_rounding_shortcut_is_exact():
     assert np.array_equal(np.rint(r), half_away)
     frac = np.abs(r - np.floor(r) - 0.5)
     assert frac.min() > 0.09                                                      # never near a tie: (c + 4 o) / 5
+
+
+_TIMING_CPP = r'''
+#include "bundlefusion/bundlefusion.hpp"
+using namespace bundlefusion;
+int main(int argc, char** argv) {
+    TimingLog::init();
+    for (int k = 0; k < 3; ++k) {
+        bf_frame_timing t; std::memset(&t, 0, sizeof t);
+        t.timeSensorProcess = 0.25f * (k + 1); t.timeSiftDetection = 1.5f; t.timeSiftMatching = 0.5f; t.timeMatchFilter = 0.125f * k; t.timeSolve = 2.0f * k;
+        t.timeReIntegrate = 1.0f; t.timeReconstruct = 0.75f; t.timeTotal = 4.0f + k;
+        TimingLog::addLocalFrameTiming(t);
+    }
+    TimingLog::addGlobalFrameTiming();
+    TimingLog::getFrameTiming(false).timeSolve = 12.5; TimingLog::getFrameTiming(false).numItersSolve = 3;
+    TimingLog::printAllTimings(std::string(argv[1]) + "/");
+    // SensorDataReader over a file that does not exist: the C ABI's message surfaces as an exception
+    try { SensorDataReader r; r.createFirstConnected(std::string(argv[1]) + "/missing.sens"); return 2; }
+    catch (const std::exception& e) { if (std::string(e.what()).find("could not open") == std::string::npos) return 3; }
+    return 0;
+}
+'''
+
+
+def test_timing_log_writes_the_reference_formats(built, tmp_path):
+    """TimingLog (TimingLog.h:39-233) in bundlefusion.hpp: the per-frame text log and the comma-separated "excel" files."""
+    src = tmp_path / "tl.cpp"
+    src.write_text(_TIMING_CPP)
+    exe = tmp_path / "tl"
+    libdir = os.path.join(ROOT, "bundlefusion_amd", "lib")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lbf_hip", "-Wl,-rpath," + libdir,
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = tmp_path / "timings"
+    out.mkdir()
+    assert subprocess.run([str(exe), str(out)], capture_output=True, text=True, timeout=60).returncode == 0
+    log = (out / "timingLogPerFrame.txt").read_text()
+    assert log.startswith("Global Timings Per Frame:\n[ frame 0 ]\n\tTime SIFT Detection: 0.000000ms\n")
+    assert "\tTime Solve: 12.500000ms\n\t#iters solve: 3\n\n\nLocal Timings Per Frame:\n[ frame 0 ]\n" in log
+    assert "\tTime Process Input: 0.500000ms\n\tTime Re-Integrate: 1.000000ms\n\tTime Reconstruct: 0.750000\n\tTime Visualize: 0.000000\n" in log
+    assert log.endswith("Total Timings Per Frame:\n[ frame 0 ] 4 ms\n[ frame 1 ] 5 ms\n[ frame 2 ] 6 ms\n\n\n")
+    loc = (out / "excel_local.txt").read_text().splitlines()
+    assert loc[:8] == ["Average times:", "SIFT Detection,1.5,3", "SIFT Matching,0.5,3", "Corr Filter,0.125,3", "Misc,0,3", "Solve,2,3", "Re-Integrate,1,3", "Misc,1.25,3"]
+    assert "Match Filter Key Point,0,0.125,0.25" in loc and "Process Input,0.25,0.5,0.75" in loc
+    assert (out / "excel_total.txt").read_text() == "Per Frame Timings,4,5,6"
+    assert (out / "excel_global.txt").read_text().splitlines()[5] == "Solve,12.5,1"
