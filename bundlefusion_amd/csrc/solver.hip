@@ -963,6 +963,7 @@ struct bf_solver {
     std::vector<float> convergence;
     float hMaxRes = 0.0f; int hMaxIdx = 0; int hBarrierFail = 0;
     int pcgGroups = -1;                  // BF_PCG_GROUPS: -1 automatic, 0 single-workgroup kernel, n forced group count
+    uint32_t maxCoopGroups = COOP_MAX_GROUPS;
     uint32_t lastN = 0, lastGNrequested = 0;
     float lastWeightSparse = 1.0f;
     bool lastUsedDense = false;
@@ -990,6 +991,13 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
     if (const char* e = getenv("BF_PCG_GROUPS")) s->pcgGroups = atoi(e);        // 0: single-workgroup kernel, n > 0: force n groups
+    {   // every group of the cooperative PCG must be resident at once (each may take a whole CU's LDS): never ask for more than
+        // half of the CUs this device (or compute partition) has
+        int dev = 0; hipDeviceProp_t prop;
+        BF_HIP_TRY(hipGetDevice(&dev));
+        BF_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        s->maxCoopGroups = std::max(1u, std::min(COOP_MAX_GROUPS, (uint32_t)prop.multiProcessorCount / 2u));
+    }
     s->maxCorrPerImage = std::min(std::max(maxNumResiduals / maxNumberOfImages, 1000u), 4000u);   // .cpp:39
     const size_t N = maxNumberOfImages, M = N * N, C = maxNumResiduals;
     Dev& d = s->d;
@@ -1080,8 +1088,8 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
         hipLaunchKernelGGL(k_slots, dim3(std::min<uint32_t>(div_up(d.maxSlots, 4), 2048u)), dim3(256), 0, st, d, c, useDense);
         hipLaunchKernelGGL(k_rows, dim3(div_up(N, 4)), dim3(256), 0, st, d);
         {
-            uint32_t G = N <= 32 ? 1u : std::min(COOP_MAX_GROUPS, div_up(N - 1, COOP_ROWS_PER_GROUP));
-            if (s->pcgGroups > 0) G = std::min<uint32_t>((uint32_t)s->pcgGroups, N - 1);
+            uint32_t G = N <= 32 ? 1u : std::min(s->maxCoopGroups, div_up(N - 1, COOP_ROWS_PER_GROUP));
+            if (s->pcgGroups > 0) G = std::min(std::min<uint32_t>((uint32_t)s->pcgGroups, N - 1), s->maxCoopGroups);
             const uint32_t rpg = div_up(N - 1, G);
             const size_t baseFloats = ((size_t)31 * N + 1 + (size_t)rpg * 36 + 3) & ~(size_t)3;    // 5 vectors, row offsets, own diagonal blocks
             const size_t ldsFloats = std::min<size_t>(PCG_LDS_MAX / 4, baseFloats + (size_t)rpg * std::min<uint32_t>(N - 1, 96u) * 37);
