@@ -161,6 +161,8 @@ def main():
                 "frames_valid": int(valid.sum()), "frames_total": int(len(traj)), "ate_rmse_vs_ground_truth_m": ate,
                 "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
                 "render_seconds_untimed": round(t_gen, 1),
+                "frame_loop": "serial order, detection of frame k+1 overlapped with matching/solve of frame k (BF_PIPELINE_LOOKAHEAD=%s)"
+                              % os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
                 "parallelism": ("one stream, bundling replicated on %d ranks, volume sharded by hash-bucket range" % world) if shard_volume
                                else "stream segments sharded over %d rank(s), no data-path collective" % world,
             },
