@@ -205,13 +205,17 @@ int bf_sensor_data_read_color_rgbx(bf_sensor_data* sd, uint64_t frame, uint8_t* 
         const int rc = readBytes(sd, fr.colorOffset, fr.colorSize, rgb.data());
         if (rc) return rc;
     } else if (sd->info.colorCompressionType == BF_SENS_COLOR_PNG || sd->info.colorCompressionType == BF_SENS_COLOR_JPEG) {
-        if (!sd->decoder) { set_error("sens: colour is %s-compressed and no decoder was set (bf_sensor_data_set_color_decoder)", sd->info.colorCompressionType == BF_SENS_COLOR_PNG ? "PNG" : "JPEG"); return BF_ERR_STATE; }
         sd->scratch.resize(fr.colorSize);
         const int rc = readBytes(sd, fr.colorOffset, fr.colorSize, sd->scratch.data());
         if (rc) return rc;
-        if (sd->decoder(sd->decoderUser, sd->scratch.data(), fr.colorSize, sd->info.colorCompressionType, sd->info.colorWidth, sd->info.colorHeight, rgb.data()) != 0) {
-            set_error("sens: frame %llu: the colour decoder failed", (unsigned long long)frame);
-            return BF_ERR_STATE;
+        if (sd->decoder) {
+            if (sd->decoder(sd->decoderUser, sd->scratch.data(), fr.colorSize, sd->info.colorCompressionType, sd->info.colorWidth, sd->info.colorHeight, rgb.data()) != 0) {
+                set_error("sens: frame %llu: the colour decoder failed", (unsigned long long)frame);
+                return BF_ERR_STATE;
+            }
+        } else {
+            const int drc = bf_decode_color_rgb(sd->scratch.data(), fr.colorSize, sd->info.colorCompressionType, sd->info.colorWidth, sd->info.colorHeight, rgb.data());
+            if (drc) return drc;                                                   // message set by the decoder
         }
     } else {
         set_error("sens: colour compression type %d is not supported", sd->info.colorCompressionType);                 // "unknown compression type"

@@ -45,10 +45,12 @@ typedef struct bf_sensor_data_info {          /* ml::SensorData header fields */
 typedef struct bf_sensor_data bf_sensor_data;               /* a .sens file opened for reading */
 typedef struct bf_sensor_data_writer bf_sensor_data_writer; /* a .sens file being written      */
 
-/* colour decoder for PNG / JPEG frames: decode `size` bytes into width*height RGB8; return 0 on success.  Raw colour needs
- * none.  (ml::SensorData decodes with stb_image; this library ships no image codec, the host application supplies one.) */
+/* colour decoder for PNG / JPEG frames: decode `size` bytes into width*height RGB8; return 0 on success.  ml::SensorData decodes
+ * with stb_image; this library has a built-in decoder (baseline JPEG, 8-bit non-interlaced PNG: bf_decode_color_rgb) that is used
+ * unless the host application installs its own with bf_sensor_data_set_color_decoder (e.g. for progressive JPEG). */
 typedef int (*bf_sens_color_decoder)(void* user, const uint8_t* data, uint64_t size, int32_t compressionType, uint32_t width,
                                      uint32_t height, uint8_t* rgbOut);
+BF_API int bf_decode_color_rgb(const uint8_t* data, uint64_t size, int32_t compressionType, uint32_t width, uint32_t height, uint8_t* rgbOut);
 
 /* SensorData::loadFromFile (frames are indexed and read on demand, so a file larger than host memory can be played) */
 BF_API int bf_sensor_data_open(const char* filename, bf_sensor_data** out);

@@ -154,9 +154,10 @@ def test_jpeg_colour_through_the_decoder_callback(tmp_path):
         assert sd.color_compressed(k) == payload[k]
         assert sd.frame_sizes(k)[0] == len(payload[k])
     sd.close()
-    sd = sdm.SensorData(path, use_pillow=False)              # no decoder: fail loudly, never a silent zero image
-    with pytest.raises(BFError, match="no decoder"):
-        sd.color_rgbx(0)
+    sd = sdm.SensorData(path, use_pillow=False)              # no callback installed: the library's own baseline decoder is used
+    for k in range(2):
+        ref = np.asarray(Image.open(io.BytesIO(payload[k])).convert("RGB"))
+        assert np.abs(sd.color_rgbx(k)[..., :3].astype(int) - ref.astype(int)).max() <= 1
     sd.close()
 
 
@@ -301,3 +302,74 @@ def test_save_with_trajectory_and_evaluate(tmp_path):
         assert (tc, td) == (frames[k][3], frames[k][4]) and cb == frames[k][2].tobytes()
         assert np.array_equal(np.frombuffer(zlib.decompress(db), "<u2").reshape(h, w), frames[k][1])
     sd.close()
+
+
+# ---------------------------------------------------------------------------------------- built-in colour decoders (csrc/imagecodec.cpp)
+def _decode(blob, ctype, w, h):
+    import ctypes as C
+    from bundlefusion_amd.capi import lib, check
+    lib.bf_decode_color_rgb.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]
+    out = np.empty((h, w, 3), np.uint8)
+    buf = np.frombuffer(blob, np.uint8)
+    check(lib.bf_decode_color_rgb(buf.ctypes.data, len(blob), ctype, w, h, out.ctypes.data))
+    return out
+
+
+def _test_image(w, h, kind, rng):
+    if kind == "smooth":
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([127 + 100 * np.sin(x / 17.0 + y / 29.0), 127 + 90 * np.cos(x / 11.0), 100 + 80 * np.sin(y / 7.0)], -1)
+        return np.clip(a, 0, 255).astype(np.uint8)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    a = np.zeros((h, w, 3), np.uint8)
+    a[:, w // 2:] = [255, 0, 0]; a[h // 3:, : w // 3] = [0, 0, 255]; a[::7] = [0, 255, 0]
+    return a
+
+
+def test_builtin_jpeg_decoder_against_libjpeg():
+    """Baseline JPEG: same inverse DCT / chroma interpolation / colour conversion as the IJG decoder Pillow links, so the
+    result is expected to be identical; one LSB of slack is allowed for other libjpeg builds.  (mLib decodes with stb_image;
+    lossy decoders are not pinned by the reference.)"""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for (w, h) in ((64, 48), (320, 240), (37, 29), (17, 9)):
+        for kind in ("smooth", "noise", "edges"):
+            img = _test_image(w, h, kind, rng)
+            for sub in (0, 1, 2):                                   # 4:4:4, 4:2:2, 4:2:0
+                for q, extra in ((50, {}), (92, {}), (85, {"restart_marker_blocks": 3})):
+                    buf = io.BytesIO()
+                    try:
+                        Image.fromarray(img).save(buf, format="JPEG", quality=q, subsampling=sub, **extra)
+                    except TypeError:                               # an older Pillow without restart markers
+                        continue
+                    ref = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+                    got = _decode(buf.getvalue(), sdm.COLOR_JPEG, w, h)
+                    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1, (w, h, kind, sub, q, extra)
+    g = Image.fromarray(_test_image(64, 48, "smooth", rng)).convert("L")
+    buf = io.BytesIO(); g.save(buf, format="JPEG", quality=90)
+    assert np.array_equal(_decode(buf.getvalue(), sdm.COLOR_JPEG, 64, 48), np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")))
+    buf = io.BytesIO(); Image.fromarray(_test_image(64, 48, "smooth", rng)).save(buf, format="JPEG", progressive=True)
+    with pytest.raises(BFError, match="progressive"):
+        _decode(buf.getvalue(), sdm.COLOR_JPEG, 64, 48)
+    with pytest.raises(BFError, match="expected"):                  # the container's size wins over the stream's
+        _decode(buf.getvalue().replace(b"\xff\xc2", b"\xff\xc0", 1), sdm.COLOR_JPEG, 32, 48)
+    with pytest.raises(BFError):
+        _decode(b"\xff\xd8\xff\xd9", sdm.COLOR_JPEG, 8, 8)
+
+
+def test_builtin_png_decoder_is_exact():
+    pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    for mode in ("RGB", "RGBA", "L", "LA", "P", "1"):
+        for kind in ("smooth", "noise", "edges"):
+            im = Image.fromarray(_test_image(61, 43, kind, rng))
+            im = im.convert(mode) if mode != "P" else im.convert("P", palette=Image.ADAPTIVE)
+            for opt in (False, True):
+                buf = io.BytesIO(); im.save(buf, format="PNG", optimize=opt)
+                ref = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+                assert np.array_equal(_decode(buf.getvalue(), sdm.COLOR_PNG, 61, 43), ref), (mode, kind, opt)
+    with pytest.raises(BFError, match="signature"):
+        _decode(b"not a png at all", sdm.COLOR_PNG, 4, 4)
