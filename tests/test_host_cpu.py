@@ -145,13 +145,21 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
 def test_cpp_header_classes_compile_and_link(built, tmp_path):
     """include/bundlefusion/bundlefusion.hpp (reference class names over the C ABI) builds with plain g++ — no HIP headers
     needed on the integrator's side — and every forwarded symbol resolves against libbf_hip.so."""
-    exe = tmp_path / "headless_driver"
     libdir = os.path.join(ROOT, "bundlefusion_amd", "lib")
-    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "headless_driver.cpp"),
-                        "-L", libdir, "-lbf_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0 and "usage:" in out.stdout
+    for name in ("headless_driver", "sens_pipeline"):
+        exe = tmp_path / name
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".cpp"),
+                            "-L", libdir, "-lbf_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "usage:" in out.stdout
+    import torch
+    if not torch.cuda.is_available():            # the C++ .sens player reads the file on the host and then fails loudly at the first device call
+        from bundlefusion_amd import sensordata as sdm
+        with sdm.SensorDataWriter(tmp_path / "t.sens", (16, 12), (16, 12), np.eye(4, dtype=np.float32)) as w:
+            w.add_frame(np.eye(4, dtype=np.float32), np.full((12, 16), 1500, np.uint16), bytes(16 * 12 * 3))
+        out = subprocess.run([str(tmp_path / "sens_pipeline"), str(tmp_path / "t.sens")], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 1 and "error: bundlefusion:" in out.stdout and "hip" in out.stdout.lower()
 
 
 def test_integrate_colour_rounding_shortcut_is_exact():
