@@ -41,7 +41,7 @@ def main():
                     help="N>1: 'segments' = each rank its own stream segment and volume (weak scaling); 'volume-shard' = one stream, "
                          "replicated bundling, the volume sharded by hash-bucket range (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=11, help="frames of the stream the CPU baseline processes (one local chunk)")
+    ap.add_argument("--cpu-frames", type=int, default=21, help="frames of the stream the CPU baseline processes (two local chunks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -199,10 +199,11 @@ def pmc_traffic(args, n_fused, n_launch):
 
 def cpu_baseline(frames, params, K, W, H):
     """The oracle frame loop (kind 'port': the reference has no runnable CPU path) on this box's host cores,
-    on a bounded sample of the same stream: its first local chunk (11 frames => SIFT, matching, filters, TSDF integration at
-    4 mm and one local solve).  Orchestration is single-threaded Python; the voxel update runs on all cores (OpenMP)."""
+    on a bounded sample of the same stream: its first two local chunks (21 frames => SIFT, matching, filters, TSDF integration
+    at 4 mm, two local solves, the first global matching + solve and the re-integration it triggers; about 7 s on the GPU
+    box).  Orchestration is single-threaded Python; the voxel update runs on all cores (OpenMP)."""
     from tests.oracle_pipeline import OraclePipeline
-    gas, gbs = params(400000, 200000)      # one chunk touches < 100k blocks; a smaller heap keeps the host allocation out of the timing
+    gas, gbs = params(400000, 200000)      # two chunks touch < 150k blocks; a smaller heap keeps the host allocation out of the timing
     op0 = time.perf_counter()
     op = OraclePipeline(gas, gbs, W, H, K)
     t0 = time.perf_counter()
@@ -210,7 +211,7 @@ def cpu_baseline(frames, params, K, W, H):
         op.process_frame(d, c)
     dt = time.perf_counter() - t0
     return {"value": len(frames) / dt, "unit": "frames/s", "cores": op.threads, "kind": "port",
-            "sample": "first %d frames of the same stream (one local chunk incl. its solve), %.1f s; stage kernels in C++ "
+            "sample": "first %d frames of the same stream (local chunks incl. their solves, global solve and re-integration), %.1f s; stage kernels in C++ "
                       "(voxel update on %d OpenMP threads, the rest single-threaded)" % (len(frames), dt, op.threads)}
 
 
