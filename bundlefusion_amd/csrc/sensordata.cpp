@@ -76,7 +76,7 @@ int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
         return BF_ERR_INVALID_ARG;
     }
     uint64_t strLen = 0;
-    ok = ok && rd(f, &strLen) && (int64_t)strLen <= total;
+    ok = ok && rd(f, &strLen) && strLen <= (uint64_t)total;
     if (ok) {
         std::string name(strLen, '\0');
         ok = strLen == 0 || rd(f, &name[0], strLen);
@@ -85,7 +85,13 @@ int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
     ok = ok && rd(f, h.colorIntrinsic, 16) && rd(f, h.colorExtrinsic, 16) && rd(f, h.depthIntrinsic, 16) && rd(f, h.depthExtrinsic, 16) &&
          rd(f, &h.colorCompressionType) && rd(f, &h.depthCompressionType) && rd(f, &h.colorWidth) && rd(f, &h.colorHeight) &&
          rd(f, &h.depthWidth) && rd(f, &h.depthHeight) && rd(f, &h.depthShift) && rd(f, &h.numFrames);
-    if (!ok || (int64_t)h.numFrames > total) { set_error("sens: truncated or invalid header in %s", filename); bf_sensor_data_close(sd); return BF_ERR_INVALID_ARG; }
+    if (!ok || h.numFrames > (uint64_t)total) { set_error("sens: truncated or invalid header in %s", filename); bf_sensor_data_close(sd); return BF_ERR_INVALID_ARG; }
+    const uint32_t MAXDIM = 1u << 15;                                      // image buffers are sized from these fields
+    if (h.depthWidth > MAXDIM || h.depthHeight > MAXDIM || h.colorWidth > MAXDIM || h.colorHeight > MAXDIM || !(h.depthShift > 0.0f) || !std::isfinite(h.depthShift)) {
+        set_error("sens: implausible header in %s (depth %ux%u, colour %ux%u, depthShift %g)", filename, h.depthWidth, h.depthHeight, h.colorWidth, h.colorHeight, (double)h.depthShift);
+        bf_sensor_data_close(sd);
+        return BF_ERR_INVALID_ARG;
+    }
     sd->frames.resize(h.numFrames);
     for (uint64_t i = 0; i < h.numFrames; ++i) {
         bf_sensor_data::Frame& fr = sd->frames[i];

@@ -198,6 +198,15 @@ def test_malformed_files_are_rejected(tmp_path):
     with pytest.raises(BFError, match="not supported"):
         sd.depth(0)
     sd.close()
+    # header fields that size allocations: a frame / name count with the top bit set, absurd image sizes, depthShift 0
+    name_len = struct.unpack("<Q", blob[4:12])[0]
+    off_frames = 4 + 8 + name_len + 4 * 64 + 8 + 16 + 4
+    for patch_off, patch in ((off_frames, struct.pack("<Q", 0xFFFFFFFFFFFFFFF0)), (4, struct.pack("<Q", 0x8000000000000010)),
+                             (off_frames - 12, struct.pack("<I", 0x7FFFFFFF)), (off_frames - 4, struct.pack("<f", 0.0))):
+        evil = tmp_path / "e.sens"
+        evil.write_bytes(blob[:patch_off] + patch + blob[patch_off + len(patch):])
+        with pytest.raises(BFError):
+            sdm.SensorData(evil)
     wrong = tmp_path / "s.sens"                          # raw depth of the wrong size
     fr = [(frames[0][0], frames[0][1][:6], frames[0][2], 0, 0)]
     _py_write(wrong, fr, w, h, w, h, 0, sdm.COLOR_RAW, 1000.0)
