@@ -1,0 +1,46 @@
+#!/usr/bin/env bash
+# One GPU call = the standard measurements of a round, written under gpurun_out/rNN/ (copy what is to be judged into profiles/).
+#   usage (on the GPU box, from the repository root):  bash tools/gpu_round.sh <NN> [tests] [bench] [trace] [pmc] [sq] [stream] [sens]
+#   e.g.  gpurun --timeout 1500 -- 'bash tools/gpu_round.sh 02 tests bench trace'
+# Every step has its own timeout; PMC passes are separate rocprofv3 runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do
+# not fit one pass; never combine --pmc with the sys/hip/hsa trace domains).  rocprofv3 runs from /tmp with TMPDIR=/tmp.
+set -u
+NN=${1:-00}; shift || true
+STEPS=${*:-tests bench trace}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r$NN
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+db() { ls -S "$1"/*/*_results.db "$1"/*_results.db 2>/dev/null | head -1; }
+for step in $STEPS; do
+  case $step in
+    tests)
+      (cd "$ROOT" && timeout 500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee "$OUT/pytest_gpu.txt") ;;
+    bench)
+      (cd "$ROOT" && timeout 300 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-260 "$OUT/bench.json") ;;
+    trace)
+      rm -rf /tmp/r_trace
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_traced.json" 2> /dev/null)
+      D=$(db /tmp/r_trace)
+      python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" | head -14
+      python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt" ;;
+    pmc)
+      for C in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/r_pmc
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc -o run -- python "$ROOT/bench.py" --no-cpu-baseline > /dev/null 2>&1)
+        python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_pmc)" update | tee "$OUT/pmc_$C.txt" | tail -4
+      done ;;
+    sq)   # where do the voxel-update waves spend their cycles: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
+      rm -rf /tmp/r_sq
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES \
+          -d /tmp/r_sq -o run -- python "$ROOT/bench.py" --no-cpu-baseline > /dev/null 2>&1)
+      python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_sq)" update | tee "$OUT/pmc_sq.txt" | tail -18 ;;
+    stream)
+      (cd "$ROOT" && timeout 500 python tools/run_sequence.py --frames 5000 --bob 0.3 --voxel 0.004 --buckets 4000000 --blocks 3000000 --tail 35 2>&1 \
+          | grep -E "frames|integrated|optimized|counters|allocated|rror" | tee "$OUT/stream5000.txt") ;;
+    sens)
+      (cd "$ROOT" && timeout 60 python tools/make_sens.py /tmp/r.sens --frames 200 --jpeg 92 | tail -1 && \
+          timeout 60 python tools/run_sens.py /tmp/r.sens --voxel 0.004 --buckets 1000000 --blocks 600000 --tail 5 2>&1 | grep -v amdgpu.ids | tee "$OUT/sens200.txt") ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
