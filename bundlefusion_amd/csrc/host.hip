@@ -292,6 +292,24 @@ int bf_image_manager_get_integrate_frame_gpu(bf_image_manager* im, uint32_t fram
     return BF_OK;
 }
 
+// ManagedRGBDInputFrame::getDepthFrameCPU / getColorFrameCPU (CUDAImageManager.h:97-119): host copies of a stored frame at
+// integration resolution (the reference keeps every frame on the host; here they live in HBM and are copied out on request)
+int bf_image_manager_get_integrate_frame_cpu(bf_image_manager* im, uint32_t frame, float* h_depth, uint8_t* h_color) {
+    BF_REQUIRE(im && frame < im->currFrame && (h_depth || h_color), "frame out of range");
+    const size_t ni = im->nInt();
+    if (!im->onGPU) {
+        if (h_depth) memcpy(h_depth, im->hostDepth[frame].data(), ni * 4);
+        if (h_color) memcpy(h_color, im->hostColor[frame].data(), ni * 4);
+        return BF_OK;
+    }
+    const float* d_depth = nullptr; const uint8_t* d_color = nullptr;
+    BF_TRY(bf_image_manager_get_integrate_frame_gpu(im, frame, &d_depth, &d_color));
+    if (h_depth) BF_HIP_TRY(hipMemcpyAsync(h_depth, d_depth, ni * 4, hipMemcpyDeviceToHost, im->stream));
+    if (h_color) BF_HIP_TRY(hipMemcpyAsync(h_color, d_color, ni * 4, hipMemcpyDeviceToHost, im->stream));
+    BF_HIP_TRY(hipStreamSynchronize(im->stream));
+    return BF_OK;
+}
+
 int bf_image_manager_get_curr_frame_number(bf_image_manager* im, uint32_t* out) {
     BF_REQUIRE(im && out, "null argument");
     BF_REQUIRE(im->currFrame > 0, "getCurrFrameNumber before the first process()");

@@ -109,6 +109,8 @@ BF_API int bf_image_manager_copy_to_bundling(bf_image_manager* im, float* d_dept
 BF_API int bf_image_manager_get_input_gpu(bf_image_manager* im, const float** d_depthRaw, const float** d_depthFilt, const uint8_t** d_color);
 /* getIntegrateFrame(i).getDepthFrameGPU() / getColorFrameGPU()  .h:71-96 */
 BF_API int bf_image_manager_get_integrate_frame_gpu(bf_image_manager* im, uint32_t frame, const float** d_depth, const uint8_t** d_color);
+/* getIntegrateFrame(i).getDepthFrameCPU() / getColorFrameCPU()  .h:97-119: copies into caller buffers (either may be NULL); syncs */
+BF_API int bf_image_manager_get_integrate_frame_cpu(bf_image_manager* im, uint32_t frame, float* h_depth, uint8_t* h_colorRGBX);
 BF_API int bf_image_manager_get_curr_frame_number(bf_image_manager* im, uint32_t* out);   /* getCurrFrameNumber (after process) */
 BF_API int bf_image_manager_get_num_frames(bf_image_manager* im, uint32_t* out);
 BF_API int bf_image_manager_get_integration_size(bf_image_manager* im, uint32_t* width, uint32_t* height);

@@ -267,9 +267,22 @@ public:
     public:
         const float* getDepthFrameGPU() { const float* d; const uint8_t* c; check(bf_image_manager_get_integrate_frame_gpu(m_im, m_idx, &d, &c)); return d; }
         const unsigned char* getColorFrameGPU() { const float* d; const uint8_t* c; check(bf_image_manager_get_integrate_frame_gpu(m_im, m_idx, &d, &c)); return c; }
+        const float* getDepthFrameCPU() {                // copied out of HBM on request; valid while this object lives
+            uint32_t w, h; check(bf_image_manager_get_integration_size(m_im, &w, &h));
+            m_depthCPU.resize((size_t)w * h);
+            check(bf_image_manager_get_integrate_frame_cpu(m_im, m_idx, m_depthCPU.data(), nullptr));
+            return m_depthCPU.data();
+        }
+        const unsigned char* getColorFrameCPU() {
+            uint32_t w, h; check(bf_image_manager_get_integration_size(m_im, &w, &h));
+            m_colorCPU.resize((size_t)w * h * 4);
+            check(bf_image_manager_get_integrate_frame_cpu(m_im, m_idx, nullptr, m_colorCPU.data()));
+            return m_colorCPU.data();
+        }
     private:
         friend class CUDAImageManager;
         bf_image_manager* m_im = nullptr; unsigned int m_idx = 0;
+        std::vector<float> m_depthCPU; std::vector<unsigned char> m_colorCPU;
     };
     CUDAImageManager(unsigned int widthIntegration, unsigned int heightIntegration, unsigned int widthSIFT, unsigned int heightSIFT, RGBDSensor* sensor,
                      bool storeFramesOnGPU = true) : m_sensor(sensor) {
@@ -434,6 +447,8 @@ typedef bf_hash_data HashDataStruct;
 struct DepthCameraData {
     DepthCameraData() { d.d_depthData = nullptr; d.d_colorData = nullptr; }
     DepthCameraData(const float* d_depth, const unsigned char* d_color) { d.d_depthData = d_depth; d.d_colorData = d_color; }
+    // DepthCameraUtil.h:50-53 uploads the camera parameters to constant memory; here they travel with every integrate() call
+    static void updateParams(const DepthCameraParams&) {}
     bf_depth_camera_data d;
 };
 
