@@ -286,13 +286,13 @@ int bf_sensor_data_writer_close(bf_sensor_data_writer* w) {
 }
 
 // ------------------------------------------------------------------------------------------------ trajectory I/O and evaluation
-int bf_sensor_data_save_with_trajectory(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms) {
-    BF_REQUIRE(sd && filename && (trajectory || numTransforms == 0), "null argument");
+static int saveCopy(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms, bool dropRest) {
     FILE* f = fopen(filename, "wb");
     if (!f) { set_error("could not open file %s for writing", filename); return BF_ERR_INVALID_ARG; }
     const bf_sensor_data_info& h = sd->info;
     const uint32_t version = SENS_VERSION;
-    const uint64_t strLen = strnlen(h.sensorName, sizeof h.sensorName), numFrames = sd->frames.size(), zero = 0;
+    const uint64_t strLen = strnlen(h.sensorName, sizeof h.sensorName), zero = 0;
+    const uint64_t numFrames = dropRest ? std::min<uint64_t>(numTransforms, sd->frames.size()) : sd->frames.size();
     bool ok = wr(f, &version) && wr(f, &strLen) && (strLen == 0 || wr(f, h.sensorName, strLen)) && wr(f, h.colorIntrinsic, 16) && wr(f, h.colorExtrinsic, 16) &&
               wr(f, h.depthIntrinsic, 16) && wr(f, h.depthExtrinsic, 16) && wr(f, &h.colorCompressionType) && wr(f, &h.depthCompressionType) &&
               wr(f, &h.colorWidth) && wr(f, &h.colorHeight) && wr(f, &h.depthWidth) && wr(f, &h.depthHeight) && wr(f, &h.depthShift) && wr(f, &numFrames);
@@ -310,6 +310,17 @@ int bf_sensor_data_save_with_trajectory(bf_sensor_data* sd, const char* filename
     ok = (fclose(f) == 0) && ok;
     if (!ok) { set_error("sens: writing %s failed", filename); return BF_ERR_STATE; }
     return BF_OK;
+}
+
+int bf_sensor_data_save_with_trajectory(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms) {
+    BF_REQUIRE(sd && filename && (trajectory || numTransforms == 0), "null argument");
+    return saveCopy(sd, filename, trajectory, numTransforms, false);
+}
+
+int bf_sensor_data_save_recorded(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms) {
+    BF_REQUIRE(sd && filename && trajectory && numTransforms > 0, "null argument");
+    if (numTransforms > sd->frames.size()) { set_error("something went wrong; found more transforms than frames"); return BF_ERR_INVALID_ARG; }   // RGBDSensor.cpp:365
+    return saveCopy(sd, filename, trajectory, numTransforms, true);
 }
 
 }  // extern "C"

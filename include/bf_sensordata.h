@@ -84,6 +84,9 @@ BF_API int bf_sensor_data_writer_close(bf_sensor_data_writer* w);
 /* SensorDataReader::saveToFile(filename, trajectory) (SensorDataReader.cpp:152-165, "kind of a hack"): the same frames with
  * cameraToWorld replaced by trajectory[i] (16 floats each) for i < numTransforms and by an all -inf matrix for the rest. */
 BF_API int bf_sensor_data_save_with_trajectory(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms);
+/* RGBDSensor::saveRecordedFramesToFile (RGBDSensor.cpp:353-398): only the first numTransforms frames, each with its pose; more
+ * transforms than frames is an error ("something went wrong; found more transforms than frames"). */
+BF_API int bf_sensor_data_save_recorded(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms);
 
 /* PoseHelper::evaluateAteRmse (PoseHelper.h:35-79): absolute trajectory error after a rigid (Kabsch) alignment of the camera
  * positions; transforms whose first element is -inf are skipped on either side.  *rmse = -inf when fewer than 3 transforms are

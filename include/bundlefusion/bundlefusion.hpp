@@ -6,6 +6,7 @@
 // Matrix arguments are `mat4f` = 16 floats, row-major (same memory as ml::mat4f / float4x4).
 #pragma once
 #include <array>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -54,18 +55,80 @@ private:
 // ---- RGBDSensor accessor contract (RGBDSensor.h:25-61); derive and fill the host buffers in processDepth/processColor
 class RGBDSensor {
 public:
-    virtual ~RGBDSensor() {}
+    virtual ~RGBDSensor() { if (m_recWriter) bf_sensor_data_writer_close(m_recWriter); if (!m_recTmp.empty()) std::remove(m_recTmp.c_str()); }
     virtual bool processDepth() = 0;
     virtual bool processColor() = 0;
     virtual const float* getDepthFloat() const = 0;               // metres, -inf invalid
     virtual const unsigned char* getColorRGBX() const = 0;        // 4 x u8 per pixel
+    virtual std::string getSensorName() const { return "RGBDSensor"; }
     unsigned int getDepthWidth() const { return m_desc.depthWidth; }
     unsigned int getDepthHeight() const { return m_desc.depthHeight; }
     unsigned int getColorWidth() const { return m_desc.colorWidth; }
     unsigned int getColorHeight() const { return m_desc.colorHeight; }
+    mat4f getDepthIntrinsics() const { mat4f m; std::memcpy(m.m, m_desc.depthIntrinsics, 64); return m; }
+    mat4f getColorIntrinsics() const { mat4f m; std::memcpy(m.m, m_desc.colorIntrinsics, 64); return m; }
+    mat4f getDepthExtrinsics() const { mat4f m; std::memcpy(m.m, m_desc.depthExtrinsics, 64); return m; }
+    mat4f getColorExtrinsics() const { mat4f m; std::memcpy(m.m, m_desc.colorExtrinsics, 64); return m; }
     const bf_rgbd_sensor_desc& desc() const { return m_desc; }
+
+    // ---- recording (RGBDSensor.cpp:264-312, 353-398, "modern .sens files"): every recordFrame() appends the current depth
+    // (u16 = round(1000 * metres), invalid -> 0, zlib) and colour to a temporary .sens; saveRecordedFramesToFile attaches the
+    // trajectory, drops frames without a pose and writes the final file.  Colour is stored raw RGB8 (the reference JPEG-encodes
+    // with stb_image_write; this library has no JPEG encoder - any reader of the format accepts raw).
+    void recordFrame() {
+        if (!m_recWriter) {
+            bf_sensor_data_info info; std::memset(&info, 0, sizeof info);
+            info.versionNumber = 4;
+            std::snprintf(info.sensorName, sizeof info.sensorName, "%s", getSensorName().c_str());
+            std::memcpy(info.colorIntrinsic, m_desc.colorIntrinsics, 64); std::memcpy(info.colorExtrinsic, m_desc.colorExtrinsics, 64);
+            std::memcpy(info.depthIntrinsic, m_desc.depthIntrinsics, 64); std::memcpy(info.depthExtrinsic, m_desc.depthExtrinsics, 64);
+            info.colorCompressionType = BF_SENS_COLOR_RAW; info.depthCompressionType = BF_SENS_DEPTH_ZLIB_USHORT;
+            info.colorWidth = m_desc.colorWidth; info.colorHeight = m_desc.colorHeight; info.depthWidth = m_desc.depthWidth; info.depthHeight = m_desc.depthHeight;
+            info.depthShift = 1000.0f;
+            m_recTmp = m_recordTmpPrefix + std::to_string((unsigned long long)(uintptr_t)this) + ".rec.sens";
+            check(bf_sensor_data_writer_create(m_recTmp.c_str(), &info, &m_recWriter));
+        }
+        const size_t nd = (size_t)m_desc.depthWidth * m_desc.depthHeight, nc = (size_t)m_desc.colorWidth * m_desc.colorHeight;
+        std::vector<uint16_t> depth(nd);
+        std::vector<unsigned char> color(nc * 3);
+        const float* d = getDepthFloat();
+        const unsigned char* c = getColorRGBX();
+        for (size_t i = 0; i < nd; ++i) {
+            const float v = d[i] * 1000.0f;                                       // (unsigned short) round(m_depthShift * d[i]) :305
+            depth[i] = (v > 0.0f && v < 65535.5f) ? (uint16_t)(v + 0.5f) : (uint16_t)0;
+        }
+        for (size_t i = 0; i < nc; ++i) { color[3 * i] = c[4 * i]; color[3 * i + 1] = c[4 * i + 1]; color[3 * i + 2] = c[4 * i + 2]; }
+        const mat4f I = mat4f::identity();
+        check(bf_sensor_data_writer_add_frame(m_recWriter, I.m, 0, 0, color.data(), color.size(), depth.data()));
+        m_numRecorded++;
+    }
+    unsigned int getNumRecordedFrames() const { return m_numRecorded; }
+    // returns the name actually written: unless overwriteExistingFile, an existing file gets a numeric suffix (:382-396)
+    std::string saveRecordedFramesToFile(const std::string& filename, const std::vector<mat4f>& trajectory, bool overwriteExistingFile = false) {
+        if (!m_recWriter || trajectory.empty()) return std::string();
+        check(bf_sensor_data_writer_close(m_recWriter)); m_recWriter = nullptr;
+        std::string actual = filename;
+        if (!overwriteExistingFile) {
+            const size_t dot = filename.find_last_of('.');
+            const std::string base = dot == std::string::npos ? filename : filename.substr(0, dot), ext = dot == std::string::npos ? "" : filename.substr(dot);
+            for (unsigned int num = 1; fileExists(actual); ++num) actual = base + std::to_string(num) + ext;
+        }
+        bf_sensor_data* sd = nullptr;
+        check(bf_sensor_data_open(m_recTmp.c_str(), &sd));
+        const int rc = bf_sensor_data_save_recorded(sd, actual.c_str(), trajectory[0].m, trajectory.size());
+        bf_sensor_data_close(sd);
+        std::remove(m_recTmp.c_str()); m_recTmp.clear(); m_numRecorded = 0;
+        check(rc);
+        return actual;
+    }
+    void setRecordTempPrefix(const std::string& prefix) { m_recordTmpPrefix = prefix; }   // where the temporary recording lives (default: ./)
 protected:
     bf_rgbd_sensor_desc m_desc;
+private:
+    static bool fileExists(const std::string& f) { if (FILE* fp = std::fopen(f.c_str(), "rb")) { std::fclose(fp); return true; } return false; }
+    bf_sensor_data_writer* m_recWriter = nullptr;
+    std::string m_recTmp, m_recordTmpPrefix = "./bf_";
+    unsigned int m_numRecorded = 0;
 };
 
 // ---- TimingLog (TimingLog.h:6-283): per-frame timings in the reference's text / "excel" file formats, so that numbers are
@@ -222,7 +285,7 @@ public:
     bool processColor() override { return true; }                 // everything is done in processDepth (.h:35-38)
     const float* getDepthFloat() const override { return m_depth.data(); }
     const unsigned char* getColorRGBX() const override { return m_colorRGBX.data(); }
-    std::string getSensorName() const { return m_info.sensorName; }
+    std::string getSensorName() const override { return m_info.sensorName; }
     unsigned int getNumFrames() const { return m_numFrames; }
     bool isReceivingFrames() const { return m_bIsReceivingFrames; }
     void stopReceivingFrames() { m_bIsReceivingFrames = false; }

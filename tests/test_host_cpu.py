@@ -218,3 +218,77 @@ def test_timing_log_writes_the_reference_formats(built, tmp_path):
     assert "Match Filter Key Point,0,0.125,0.25" in loc and "Process Input,0.25,0.5,0.75" in loc
     assert (out / "excel_total.txt").read_text() == "Per Frame Timings,4,5,6"
     assert (out / "excel_global.txt").read_text().splitlines()[5] == "Solve,12.5,1"
+
+
+_RECORD_CPP = r'''
+#include <limits>
+#include "bundlefusion/bundlefusion.hpp"
+using namespace bundlefusion;
+struct Fake : RGBDSensor {
+    std::vector<float> depth; std::vector<unsigned char> color; int k = 0;
+    Fake() {
+        std::memset(&m_desc, 0, sizeof m_desc);
+        m_desc.depthWidth = m_desc.colorWidth = 8; m_desc.depthHeight = m_desc.colorHeight = 6;
+        const mat4f I = mat4f::identity(); mat4f K = I; K(0, 0) = 500; K(1, 1) = 501; K(0, 2) = 3.5f; K(1, 2) = 2.5f;
+        std::memcpy(m_desc.depthIntrinsics, K.m, 64); std::memcpy(m_desc.colorIntrinsics, K.m, 64);
+        std::memcpy(m_desc.depthExtrinsics, I.m, 64); std::memcpy(m_desc.colorExtrinsics, I.m, 64);
+        depth.assign(48, 0.0f); color.assign(48 * 4, 0);
+    }
+    bool processDepth() override {
+        for (int i = 0; i < 48; ++i) { depth[i] = 1.0f + 0.0005f * (i + 100 * k); color[4 * i] = (unsigned char)(i + k); color[4 * i + 1] = (unsigned char)(2 * i); color[4 * i + 2] = 7; color[4 * i + 3] = 255; }
+        depth[0] = -std::numeric_limits<float>::infinity(); depth[1] = 1.2345f; depth[2] = 0.0f;
+        ++k; return true;
+    }
+    bool processColor() override { return true; }
+    const float* getDepthFloat() const override { return depth.data(); }
+    const unsigned char* getColorRGBX() const override { return color.data(); }
+    std::string getSensorName() const override { return "FakeSensor"; }
+};
+int main(int argc, char** argv) {
+    const std::string dir = argv[1];
+    Fake s; s.setRecordTempPrefix(dir + "/tmp_");
+    for (int i = 0; i < 3; ++i) { s.processDepth(); s.recordFrame(); }
+    std::vector<mat4f> traj(2, mat4f::identity()); traj[1](0, 3) = 0.25f; traj[1](2, 3) = -1.5f;
+    const std::string a = s.saveRecordedFramesToFile(dir + "/rec.sens", traj);            // rec.sens exists already -> rec1.sens
+    std::printf("%s\n", a.c_str());
+    for (int i = 0; i < 1; ++i) { s.processDepth(); s.recordFrame(); }
+    std::vector<mat4f> three(3, mat4f::identity());
+    try { s.saveRecordedFramesToFile(dir + "/x.sens", three, true); return 2; }           // more transforms than frames
+    catch (const std::exception& e) { std::printf("%s\n", e.what()); }
+    return 0;
+}
+'''
+
+
+def test_rgbd_sensor_recording_writes_a_sens_file(built, tmp_path):
+    """RGBDSensor::recordFrame / saveRecordedFramesToFile (RGBDSensor.cpp:264-312, 353-398) in bundlefusion.hpp."""
+    from bundlefusion_amd import sensordata as sdm
+    src = tmp_path / "rec.cpp"
+    src.write_text(_RECORD_CPP)
+    exe = tmp_path / "rec"
+    libdir = os.path.join(ROOT, "bundlefusion_amd", "lib")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lbf_hip", "-Wl,-rpath," + libdir,
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    (tmp_path / "rec.sens").write_bytes(b"already here")
+    out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0] == str(tmp_path / "rec1.sens") and "more transforms than frames" in lines[1]
+    assert (tmp_path / "rec.sens").read_bytes() == b"already here"                       # not overwritten
+    assert not [p for p in os.listdir(tmp_path) if p.startswith("tmp_")]                  # the temporary recording is gone
+    sd = sdm.SensorData(tmp_path / "rec1.sens")
+    assert len(sd) == 2 and sd.sensor_name == "FakeSensor"                                # the third frame had no pose: dropped
+    assert sd.info.depthShift == 1000.0 and sd.info.depthCompressionType == sdm.DEPTH_ZLIB_USHORT and sd.info.colorCompressionType == sdm.COLOR_RAW
+    assert np.array(sd.info.depthIntrinsic, np.float32).reshape(4, 4)[0, 0] == 500
+    T1 = sd.pose(1)[0]
+    assert T1[0, 3] == 0.25 and T1[2, 3] == -1.5 and np.array_equal(sd.pose(0)[0], np.eye(4, dtype=np.float32))
+    for k in range(2):
+        d = sd.depth_raw(k).reshape(-1)
+        want = np.array([np.float32(1.0) + np.float32(0.0005) * np.float32(i + 100 * k) for i in range(48)], np.float32)
+        q = np.floor(want * np.float32(1000.0) + np.float32(0.5)).astype(np.uint16)
+        q[0] = 0; q[1] = 1235; q[2] = 0                                                    # -inf and 0 are invalid; round(1234.5) = 1235
+        assert np.array_equal(d, q), k
+        c = sd.color_rgbx(k).reshape(-1, 4)
+        assert np.array_equal(c[:, 0], (np.arange(48) + k).astype(np.uint8)) and np.array_equal(c[:, 1], (2 * np.arange(48)).astype(np.uint8)) and (c[:, 2] == 7).all()
+    sd.close()
