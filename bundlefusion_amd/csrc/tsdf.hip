@@ -1215,6 +1215,12 @@ int bf_scene_get_num_integrated_frames(bf_scene* s, uint32_t* out) {
     return BF_OK;
 }
 
+int bf_scene_set_last_rigid_transform(bf_scene* s, const float camToWorld[16]) {            // CUDASceneRepHashSDF.h:128-134
+    BF_REQUIRE(s && camToWorld, "null argument");
+    setLastRigidTransform(s, camToWorld);
+    return BF_OK;
+}
+
 int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out) {
     BF_REQUIRE(s && out, "null argument");
     BF_TRY_RC(syncAll(s));

@@ -163,6 +163,8 @@ BF_API int bf_scene_garbage_collect(bf_scene* s);
  * (needs the camera of the following ray cast / GC for the frustum test)         */
 BF_API int bf_scene_set_last_rigid_transform_and_compactify(
     bf_scene* s, const float cam_to_world[16], const bf_depth_camera_params* cam);
+/* setLastRigidTransform(T)                                 :128-134 (host state only: m_rigidTransform and its inverse) */
+BF_API int bf_scene_set_last_rigid_transform(bf_scene* s, const float cam_to_world[16]);
 /* getHashData() / getHashParams()                          :158-164
  * get_hash_params synchronises and refreshes m_numOccupiedBlocks.               */
 BF_API int bf_scene_get_hash_data(bf_scene* s, bf_hash_data* out);

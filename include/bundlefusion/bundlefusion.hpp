@@ -12,6 +12,7 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -454,6 +455,10 @@ public:
     }
     bool getTopFromIntegrateList(mat4f& trans, unsigned int& frameIdx) { int f; check(bf_trajectory_manager_get_top_from_integrate_list(m_h, trans.m, &frameIdx, &f)); return f != 0; }
     bool getTopFromDeIntegrateList(mat4f& trans, unsigned int& frameIdx) { int f; check(bf_trajectory_manager_get_top_from_deintegrate_list(m_h, trans.m, &frameIdx, &f)); return f != 0; }
+    // the reference serialises updateOptimizedTransform against generateUpdateLists across its two threads (.h:70-77); callers of this
+    // layer that use two threads get the same two calls
+    void lockUpdateTransforms() { m_mutexUpdateTransforms.lock(); }
+    void unlockUpdateTransforms() { m_mutexUpdateTransforms.unlock(); }
     unsigned int getNumOptimizedFrames() const { uint32_t n; check(bf_trajectory_manager_get_num_optimized_frames(m_h, &n)); return n; }
     unsigned int getNumAddedFrames() const { uint32_t n; check(bf_trajectory_manager_get_num_added_frames(m_h, &n)); return n; }
     unsigned int getNumActiveOperations() const { uint32_t n; check(bf_trajectory_manager_get_num_active_operations(m_h, &n)); return n; }
@@ -466,6 +471,7 @@ public:
     }
 private:
     bf_trajectory_manager* m_h;
+    std::mutex m_mutexUpdateTransforms;
 };
 
 // ---- OnlineBundler (OnlineBundler.h:10-106)
@@ -543,6 +549,12 @@ public:
     void reset() { check(bf_scene_reset(m_h)); }
     void setLastRigidTransformAndCompactify(const mat4f& lastRigidTransform, const DepthCameraParams& params) {
         check(bf_scene_set_last_rigid_transform_and_compactify(m_h, lastRigidTransform.m, &params));
+    }
+    void setLastRigidTransform(const mat4f& lastRigidTransform) { check(bf_scene_set_last_rigid_transform(m_h, lastRigidTransform.m)); }
+    const mat4f getLastRigidTransform() { const HashParams p = getHashParams(); mat4f m; std::memcpy(m.m, p.m_rigidTransform, 64); return m; }
+    void debugHash() {                                             // :179-314: the invariants the reference prints, from the device-side check
+        uint32_t v[6]; check(bf_scene_debug_hash(m_h, v));
+        std::printf("number of occupied entries: %u\nfree heap: %u\nduplicate keys: %u\nallocated and free: %u\nleaked blocks: %u\ndropped: %u\n", v[0], v[1], v[2], v[3], v[4], v[5]);
     }
     HashDataStruct getHashData() { HashDataStruct d; check(bf_scene_get_hash_data(m_h, &d)); return d; }
     HashParams getHashParams() { HashParams p; check(bf_scene_get_hash_params(m_h, &p)); return p; }
