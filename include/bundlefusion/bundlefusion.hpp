@@ -30,6 +30,38 @@ struct mat4f {
     float operator()(int r, int c) const { return m[r * 4 + c]; }
     const float* getData() const { return m; }
     float* getData() { return m; }
+    // the handful of ml::mat4f operations the frame loop uses (g_transformWorld * transformation, getInverse(), setZero(-inf))
+    mat4f operator*(const mat4f& o) const {
+        mat4f r;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float v = 0.0f; for (int k = 0; k < 4; ++k) v += m[i * 4 + k] * o.m[k * 4 + j]; r.m[i * 4 + j] = v; }
+        return r;
+    }
+    void setZero(float v = 0.0f) { for (float& e : m) e = v; }
+    void setIdentity() { *this = identity(); }
+    mat4f getTranspose() const { mat4f r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i * 4 + j] = m[j * 4 + i]; return r; }
+    mat4f getInverse() const {                                     // general 4x4 inverse by cofactors
+        const float* a = m; mat4f r; float* o = r.m;
+        o[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+        o[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+        o[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+        o[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+        o[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+        o[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+        o[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+        o[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+        o[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+        o[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+        o[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+        o[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+        o[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+        o[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+        o[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+        o[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+        const float det = a[0] * o[0] + a[1] * o[4] + a[2] * o[8] + a[3] * o[12];
+        const float inv = 1.0f / det;
+        for (float& e : r.m) e *= inv;
+        return r;
+    }
 };
 typedef mat4f float4x4;
 
@@ -70,6 +102,10 @@ public:
     mat4f getColorIntrinsics() const { mat4f m; std::memcpy(m.m, m_desc.colorIntrinsics, 64); return m; }
     mat4f getDepthExtrinsics() const { mat4f m; std::memcpy(m.m, m_desc.depthExtrinsics, 64); return m; }
     mat4f getColorExtrinsics() const { mat4f m; std::memcpy(m.m, m_desc.colorExtrinsics, 64); return m; }
+    mat4f getDepthIntrinsicsInv() const { return getDepthIntrinsics().getInverse(); }
+    mat4f getColorIntrinsicsInv() const { return getColorIntrinsics().getInverse(); }
+    mat4f getDepthExtrinsicsInv() const { return getDepthExtrinsics().getInverse(); }
+    mat4f getColorExtrinsicsInv() const { return getColorExtrinsics().getInverse(); }
     const bf_rgbd_sensor_desc& desc() const { return m_desc; }
 
     // ---- recording (RGBDSensor.cpp:264-312, 353-398, "modern .sens files"): every recordFrame() appends the current depth

@@ -188,6 +188,14 @@ int main(int argc, char** argv) {
     TimingLog::addGlobalFrameTiming();
     TimingLog::getFrameTiming(false).timeSolve = 12.5; TimingLog::getFrameTiming(false).numItersSolve = 3;
     TimingLog::printAllTimings(std::string(argv[1]) + "/");
+    {   // mat4f: product and general inverse (what g_transformWorld * transformation / getInverse() need)
+        mat4f A = mat4f::identity();
+        const float v[16] = {0.36f, 0.48f, -0.8f, 1.5f, -0.8f, 0.6f, 0.0f, -2.0f, 0.48f, 0.64f, 0.6f, 0.25f, 0, 0, 0, 1};
+        for (int i = 0; i < 16; ++i) A.m[i] = v[i];
+        mat4f K = mat4f::identity(); K(0, 0) = 583; K(1, 1) = 584; K(0, 2) = 319.5f; K(1, 2) = 239.5f;
+        const mat4f P = A * A.getInverse(), Q = K.getInverse() * K;
+        for (int i = 0; i < 16; ++i) { const float id = (i % 5 == 0) ? 1.0f : 0.0f; if (P.m[i] - id > 1e-5f || id - P.m[i] > 1e-5f || Q.m[i] - id > 1e-5f || id - Q.m[i] > 1e-5f) return 4; }
+    }
     // SensorDataReader over a file that does not exist: the C ABI's message surfaces as an exception
     try { SensorDataReader r; r.createFirstConnected(std::string(argv[1]) + "/missing.sens"); return 2; }
     catch (const std::exception& e) { if (std::string(e.what()).find("could not open") == std::string::npos) return 3; }
