@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/bf_sensordata.h"
@@ -400,7 +401,7 @@ int decodePng(const uint8_t* data, size_t size, uint32_t width, uint32_t height,
 
 extern "C" {
 
-int bf_decode_color_rgb(const uint8_t* data, uint64_t size, int32_t compressionType, uint32_t width, uint32_t height, uint8_t* rgbOut) {
+int bf_decode_color_rgb(const uint8_t* data, uint64_t size, int32_t compressionType, uint32_t width, uint32_t height, uint8_t* rgbOut) try {
     BF_REQUIRE(data && rgbOut && width > 0 && height > 0, "null argument");
     if (compressionType == BF_SENS_COLOR_JPEG) return decodeJpeg(data, (size_t)size, width, height, rgbOut);
     if (compressionType == BF_SENS_COLOR_PNG) return decodePng(data, (size_t)size, width, height, rgbOut);
@@ -411,6 +412,9 @@ int bf_decode_color_rgb(const uint8_t* data, uint64_t size, int32_t compressionT
     }
     set_error("colour compression type %d is not supported", compressionType);
     return BF_ERR_INVALID_ARG;
+} catch (const std::exception& e) {                   // e.g. std::bad_alloc on an absurd image size: no exception leaves the C ABI
+    set_error("colour decoder: %s", e.what());
+    return BF_ERR_STATE;
 }
 
 }  // extern "C"

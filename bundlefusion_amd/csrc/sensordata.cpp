@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -51,6 +53,13 @@ int64_t fileSize(FILE* f) {
     return end;
 }
 
+// no C++ exception leaves the C ABI: allocation failures on absurd (but formally valid) inputs become status codes
+template <class F> int guarded(F f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { set_error("out of host memory"); return BF_ERR_CAPACITY; }
+    catch (const std::exception& e) { set_error("%s", e.what()); return BF_ERR_STATE; }
+}
+
 int readBytes(bf_sensor_data* sd, int64_t offset, uint64_t size, uint8_t* out) {
     if (fseeko(sd->f, offset, SEEK_SET) != 0 || fread(out, 1, size, sd->f) != size) { set_error("sens: short read at offset %lld", (long long)offset); return BF_ERR_STATE; }
     return BF_OK;
@@ -61,6 +70,7 @@ int readBytes(bf_sensor_data* sd, int64_t offset, uint64_t size, uint8_t* out) {
 extern "C" {
 
 int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
+    return guarded([&]() -> int {
     BF_REQUIRE(filename && out, "null argument");
     FILE* f = fopen(filename, "rb");
     if (!f) { set_error("could not open file %s", filename); return BF_ERR_INVALID_ARG; }          // "could not open file" (SensorData::loadFromFile)
@@ -108,6 +118,7 @@ int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
     if (rd(f, &numIMU) && ftello(f) + (int64_t)(numIMU * IMU_FRAME_BYTES) <= total) h.numIMUFrames = numIMU;     // the IMU block is optional
     *out = sd;
     return BF_OK;
+    });
 }
 
 int bf_sensor_data_close(bf_sensor_data* sd) {
@@ -160,6 +171,7 @@ int bf_sensor_data_get_frame_sizes(bf_sensor_data* sd, uint64_t frame, uint64_t*
 }
 
 int bf_sensor_data_read_depth_raw(bf_sensor_data* sd, uint64_t frame, uint16_t* out) {             // SensorData::decompressDepthAlloc
+    return guarded([&]() -> int {
     BF_REQUIRE(sd && out && frame < sd->frames.size(), "bad argument");
     const bf_sensor_data::Frame& fr = sd->frames[frame];
     const uint64_t bytes = (uint64_t)sd->info.depthWidth * sd->info.depthHeight * 2;
@@ -178,9 +190,11 @@ int bf_sensor_data_read_depth_raw(bf_sensor_data* sd, uint64_t frame, uint16_t* 
     }
     set_error("sens: depth compression type %d is not supported (raw and zlib u16 are)", sd->info.depthCompressionType);   // "unknown depth compression type"
     return BF_ERR_INVALID_ARG;
+    });
 }
 
 int bf_sensor_data_read_depth(bf_sensor_data* sd, uint64_t frame, float* out) {                    // SensorDataReader::processDepth :98-103
+    return guarded([&]() -> int {
     BF_REQUIRE(sd && out && frame < sd->frames.size(), "bad argument");
     const size_t n = (size_t)sd->info.depthWidth * sd->info.depthHeight;
     std::vector<uint16_t> raw(n);
@@ -189,6 +203,7 @@ int bf_sensor_data_read_depth(bf_sensor_data* sd, uint64_t frame, float* out) { 
     const float shift = sd->info.depthShift;
     for (size_t i = 0; i < n; ++i) out[i] = raw[i] == 0 ? -std::numeric_limits<float>::infinity() : (float)raw[i] / shift;
     return BF_OK;
+    });
 }
 
 int bf_sensor_data_read_color_compressed(bf_sensor_data* sd, uint64_t frame, uint8_t* out, uint64_t capacity, uint64_t* size) {
@@ -201,6 +216,7 @@ int bf_sensor_data_read_color_compressed(bf_sensor_data* sd, uint64_t frame, uin
 }
 
 int bf_sensor_data_read_color_rgbx(bf_sensor_data* sd, uint64_t frame, uint8_t* out) {            // decompressColorAlloc + :107-111
+    return guarded([&]() -> int {
     BF_REQUIRE(sd && out && frame < sd->frames.size(), "bad argument");
     const bf_sensor_data::Frame& fr = sd->frames[frame];
     const size_t n = (size_t)sd->info.colorWidth * sd->info.colorHeight;
@@ -229,6 +245,7 @@ int bf_sensor_data_read_color_rgbx(bf_sensor_data* sd, uint64_t frame, uint8_t* 
     }
     for (size_t i = 0; i < n; ++i) { out[4 * i] = rgb[3 * i]; out[4 * i + 1] = rgb[3 * i + 1]; out[4 * i + 2] = rgb[3 * i + 2]; out[4 * i + 3] = 255; }   // vec4uc(vec3uc): w = 255
     return BF_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------ writer
@@ -256,6 +273,7 @@ int bf_sensor_data_writer_create(const char* filename, const bf_sensor_data_info
 
 int bf_sensor_data_writer_add_frame(bf_sensor_data_writer* w, const float T[16], uint64_t tsColor, uint64_t tsDepth, const uint8_t* colorBytes,
                                     uint64_t colorSize, const uint16_t* depth) {
+    return guarded([&]() -> int {
     BF_REQUIRE(w && T && depth && (colorBytes || colorSize == 0), "null argument");
     const uint64_t rawBytes = (uint64_t)w->info.depthWidth * w->info.depthHeight * 2;
     const uint8_t* depthBytes = reinterpret_cast<const uint8_t*>(depth);
@@ -272,6 +290,7 @@ int bf_sensor_data_writer_add_frame(bf_sensor_data_writer* w, const float T[16],
     if (!ok) { set_error("sens: write failed at frame %llu", (unsigned long long)w->numFrames); return BF_ERR_STATE; }
     w->numFrames++;
     return BF_OK;
+    });
 }
 
 int bf_sensor_data_writer_close(bf_sensor_data_writer* w) {
@@ -313,14 +332,18 @@ static int saveCopy(bf_sensor_data* sd, const char* filename, const float* traje
 }
 
 int bf_sensor_data_save_with_trajectory(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms) {
+    return guarded([&]() -> int {
     BF_REQUIRE(sd && filename && (trajectory || numTransforms == 0), "null argument");
     return saveCopy(sd, filename, trajectory, numTransforms, false);
+    });
 }
 
 int bf_sensor_data_save_recorded(bf_sensor_data* sd, const char* filename, const float* trajectory, uint64_t numTransforms) {
+    return guarded([&]() -> int {
     BF_REQUIRE(sd && filename && trajectory && numTransforms > 0, "null argument");
     if (numTransforms > sd->frames.size()) { set_error("something went wrong; found more transforms than frames"); return BF_ERR_INVALID_ARG; }   // RGBDSensor.cpp:365
     return saveCopy(sd, filename, trajectory, numTransforms, true);
+    });
 }
 
 }  // extern "C"
@@ -391,6 +414,7 @@ void kabschAlign(const std::vector<std::array<double, 3>>& p, const std::vector<
 extern "C" {
 
 int bf_evaluate_ate_rmse(const float* traj, const float* ref, uint32_t numTransforms, float* rmse, uint32_t* numEvaluated) {     // PoseHelper.h:35-79
+    return guarded([&]() -> int {
     BF_REQUIRE((traj && ref) || numTransforms == 0, "null argument");
     BF_REQUIRE(rmse && numEvaluated, "null argument");
     const float NINF = -std::numeric_limits<float>::infinity();
@@ -426,9 +450,11 @@ int bf_evaluate_ate_rmse(const float* traj, const float* ref, uint32_t numTransf
     *rmse = (float)sqrt(err / (double)pts.size());
     *numEvaluated = (uint32_t)pts.size();
     return BF_OK;
+    });
 }
 
 int bf_sensor_data_evaluate_trajectory(bf_sensor_data* sd, const float* trajectory, uint64_t numTransforms, float* rmse, uint32_t* numEvaluated) {   // :167-189
+    return guarded([&]() -> int {
     BF_REQUIRE(sd && trajectory && rmse && numEvaluated, "null argument");
     const size_t nRef = sd->frames.size();
     BF_REQUIRE(nRef > 0, "no frames");
@@ -450,6 +476,7 @@ int bf_sensor_data_evaluate_trajectory(bf_sensor_data* sd, const float* trajecto
     }
     const uint32_t n = (uint32_t)std::min<uint64_t>(numTransforms, nRef);
     return bf_evaluate_ate_rmse(trajectory, ref.data(), n, rmse, numEvaluated);
+    });
 }
 
 }  // extern "C"
