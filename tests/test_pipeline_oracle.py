@@ -1,6 +1,10 @@
 """CPU test of the oracle frame loop itself (tests/oracle_pipeline.py + oracle/*.cpp): the checker that the GPU parity tests
 and smoke() compare against must reconstruct a known scene — camera poses against the synthetic ground truth, one local and
 one global solve, re-integration bookkeeping — before its output means anything.  Small frames keep it to a few seconds."""
+import hashlib
+import json
+import os
+
 import numpy as np
 
 from bundlefusion_amd import synth
@@ -8,7 +12,14 @@ from bundlefusion_amd.capi import default_app_state, default_bundling_state, int
 from tests.oracle_pipeline import OraclePipeline
 
 
-def test_oracle_frame_loop_tracks_the_synthetic_scene():
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_snapshot.json")
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_oracle_sequence():
     W, H, n = 320, 240, 13
     frames = [synth.scene_room(3 * k, W, H) for k in range(n)]
     Kd = frames[0][3]
@@ -22,6 +33,28 @@ def test_oracle_frame_loop_tracks_the_synthetic_scene():
         op.process_frame(d, c)
     for _ in range(3):
         op.process_end_of_sequence()
+    return op, frames, gas
+
+
+def snapshot(op):
+    """Digest of what the oracle frame loop produced (tests/golden/oracle_snapshot.json is written from this by
+    tests/golden/make_oracle_snapshot.py).  It is a regression pin of the ORACLE, not reference output: parity stays unpinned."""
+    traj = op.integrated_trajectory()
+    h = op.scene.hash()
+    return {
+        "trajectory_sha256": _sha(traj.astype("<f4")),
+        "pose_of_frame_12": [float(np.float32(v)) for v in traj[12].reshape(-1)],
+        "hash_pos_sha256": _sha(h["pos"]), "hash_ptr_sha256": _sha(h["ptr"]),
+        "voxels_sha256": _sha(op.scene.voxels().view(np.uint8)),
+        "heap_counter": int(op.scene.heap_counter()),
+        "operations": [[k, int(f)] for k, f, _ in op.integrate_ops],
+        "num_complete_transforms": int(op.num_complete),
+    }
+
+
+def test_oracle_frame_loop_tracks_the_synthetic_scene():
+    op, frames, gas = run_oracle_sequence()
+    n = len(frames)
     traj = op.integrated_trajectory()
     assert len(traj) == n and np.isfinite(traj[:, 0, 0]).all()                 # every frame tracked and integrated
     T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
@@ -39,3 +72,8 @@ def test_oracle_frame_loop_tracks_the_synthetic_scene():
     de = [f for k, f, _ in op.integrate_ops if k == "de"]
     assert len(de) > 0 and kinds.count("in") == n + len(de)
     assert op.scene.heap_counter() < gas.s_hashNumSDFBlocks - 1 - 200             # a few hundred 16 cm blocks allocated
+    # ---- regression pin of the oracle itself (a change of any oracle stage shows up here before it silently moves the GPU parity target)
+    snap = snapshot(op)
+    want = json.load(open(GOLDEN))
+    diff = [k for k in want if want[k] != snap.get(k)]
+    assert not diff, "oracle output changed in: %s (regenerate with tests/golden/make_oracle_snapshot.py if intended)" % diff
