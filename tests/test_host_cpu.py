@@ -130,9 +130,13 @@ dist.destroy_process_group()
 def test_two_rank_gloo_sharding_and_timing(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+    with socket.socket() as sock:                      # a free port: a fixed one collides with a concurrent run of the suite
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
+                          "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = sorted(l.split()[1:] for l in out.stdout.splitlines() if l.startswith("RESULT"))
     assert len(rows) == 2
