@@ -304,3 +304,21 @@ def test_rgbd_sensor_recording_writes_a_sens_file(built, tmp_path):
         c = sd.color_rgbx(k).reshape(-1, 4)
         assert np.array_equal(c[:, 0], (np.arange(48) + k).astype(np.uint8)) and np.array_equal(c[:, 1], (2 * np.arange(48)).astype(np.uint8)) and (c[:, 2] == 7).all()
     sd.close()
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench.json is what `python bench.py` printed on the MI355X box: one JSON object with the driver's keys plus the
+    roofline and cpu_baseline objects."""
+    import json
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], typ), key
+    assert "vs_baseline" in line and line["vs_baseline"] is None          # BASELINE.md holds no published number for this metric
+    assert line["unit"] == "frames/s" and line["scaling"] in ("weak", "strong") and "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - line["n_gpus"] * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
