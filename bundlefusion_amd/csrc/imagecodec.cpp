@@ -1,4 +1,4 @@
-// Colour decoders for recorded sequences (.sens): baseline JPEG and PNG to RGB8, host only.
+// Colour codecs for recorded sequences (.sens): baseline JPEG and PNG to RGB8, and a baseline JPEG encoder for recording; host only.
 //
 // ml::SensorData (mLib, not in the reference tree) decodes compressed colour frames with stb_image; this file is the
 // library's built-in replacement so that a C++ host needs no image library to play a BundleFusion / ScanNet recording:
@@ -12,6 +12,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -397,6 +398,156 @@ int decodePng(const uint8_t* data, size_t size, uint32_t width, uint32_t height,
     return BF_OK;
 }
 
+// ================================================================================================ JPEG encoder (recording)
+// Baseline, 4:4:4, quantisation tables of Annex K scaled by `quality` like the IJG code, and Huffman tables optimised for the
+// image (two passes; code lengths limited to 16 bits by the procedure of Annex K.2).  ml::SensorData records colour with
+// stb_image_write's encoder; an encoder's output is not pinned by anything - any baseline decoder reads this one's.
+const uint8_t STD_LUMA_Q[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                                18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t STD_CHROMA_Q[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+struct HuffEnc { uint8_t bits[17]; uint8_t vals[256]; int nvals; uint16_t code[256]; uint8_t len[256]; };
+
+// optimal code lengths from symbol counts (Annex K.2 / jpeg_gen_optimal_table): a reserved pseudo-symbol keeps the all-ones code free
+void buildOptimal(const long* freqIn, HuffEnc& h) {
+    long freq[257]; int codesize[257], others[257];
+    for (int i = 0; i < 256; ++i) freq[i] = freqIn[i];
+    freq[256] = 1;
+    for (int i = 0; i < 257; ++i) { codesize[i] = 0; others[i] = -1; }
+    for (;;) {
+        int c1 = -1, c2 = -1; long v = 1000000000L;
+        for (int i = 0; i <= 256; ++i) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+        v = 1000000000L;
+        for (int i = 0; i <= 256; ++i) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2]; freq[c2] = 0;
+        codesize[c1]++; while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+        others[c1] = c2;
+        codesize[c2]++; while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+    }
+    int bits[33];
+    for (int i = 0; i < 33; ++i) bits[i] = 0;
+    for (int i = 0; i <= 256; ++i) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
+    for (int i = 32; i > 16; --i)
+        while (bits[i] > 0) {
+            int j = i - 2;
+            while (bits[j] == 0) --j;
+            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+        }
+    int i = 16;
+    while (bits[i] == 0) --i;
+    bits[i]--;                                                       // remove the pseudo-symbol's code
+    h.bits[0] = 0;
+    for (int l = 1; l <= 16; ++l) h.bits[l] = (uint8_t)bits[l];
+    h.nvals = 0;
+    for (int l = 1; l <= 32; ++l) for (int sym = 0; sym < 256; ++sym) if (codesize[sym] == l) h.vals[h.nvals++] = (uint8_t)sym;
+    int code = 0, k = 0;
+    for (int sym = 0; sym < 256; ++sym) h.len[sym] = 0;
+    for (int l = 1; l <= 16; ++l) { for (int n = 0; n < h.bits[l]; ++n, ++k) { h.code[h.vals[k]] = (uint16_t)code++; h.len[h.vals[k]] = (uint8_t)l; } code <<= 1; }
+}
+
+struct BitWriter {
+    std::vector<uint8_t>& out; uint32_t acc = 0; int cnt = 0;
+    explicit BitWriter(std::vector<uint8_t>& o) : out(o) {}
+    void put(uint32_t code, int len) {
+        acc = (acc << len) | (code & ((1u << len) - 1)); cnt += len;
+        while (cnt >= 8) { const uint8_t b = (uint8_t)(acc >> (cnt - 8)); out.push_back(b); if (b == 0xFF) out.push_back(0); cnt -= 8; }
+    }
+    void flush() { if (cnt) put(0x7F, 8 - cnt); }
+};
+
+inline int bitSize(int v) { v = v < 0 ? -v : v; int n = 0; while (v) { ++n; v >>= 1; } return n; }
+
+void fdct8x8(float* d) {                                              // separable DCT-II, orthonormal scaling folded into the output (direct form: 8x8x8x2)
+    static float C[8][8]; static bool init = false;
+    if (!init) { for (int k = 0; k < 8; ++k) for (int n = 0; n < 8; ++n) C[k][n] = (k == 0 ? 0.35355339059327373f : 0.5f) * (float)std::cos((2 * n + 1) * k * 3.14159265358979323846 / 16.0); init = true; }
+    float t[64];
+    for (int r = 0; r < 8; ++r) for (int k = 0; k < 8; ++k) { float s = 0; for (int n = 0; n < 8; ++n) s += C[k][n] * d[r * 8 + n]; t[r * 8 + k] = s; }
+    for (int c = 0; c < 8; ++c) for (int k = 0; k < 8; ++k) { float s = 0; for (int n = 0; n < 8; ++n) s += C[k][n] * t[n * 8 + c]; d[k * 8 + c] = s; }
+}
+
+int encodeJpeg(const uint8_t* rgb, uint32_t W, uint32_t H, int quality, std::vector<uint8_t>& out) {
+    quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    uint8_t q[2][64];
+    for (int i = 0; i < 64; ++i) {
+        int a = ((int)STD_LUMA_Q[i] * scale + 50) / 100, b = ((int)STD_CHROMA_Q[i] * scale + 50) / 100;
+        q[0][i] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a)); q[1][i] = (uint8_t)(b < 1 ? 1 : (b > 255 ? 255 : b));
+    }
+    const uint32_t bx = (W + 7) / 8, by = (H + 7) / 8;
+    std::vector<int16_t> coef((size_t)bx * by * 3 * 64);              // quantised coefficients in zigzag order, per block: Y, Cb, Cr
+    float blk[3][64];
+    for (uint32_t y0 = 0; y0 < by; ++y0)
+        for (uint32_t x0 = 0; x0 < bx; ++x0) {
+            for (int yy = 0; yy < 8; ++yy)
+                for (int xx = 0; xx < 8; ++xx) {
+                    const uint32_t x = std::min(x0 * 8 + xx, W - 1), y = std::min(y0 * 8 + yy, H - 1);      // edge replication
+                    const uint8_t* p = rgb + ((size_t)y * W + x) * 3;
+                    const float r = p[0], g = p[1], b = p[2];
+                    blk[0][yy * 8 + xx] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+                    blk[1][yy * 8 + xx] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+                    blk[2][yy * 8 + xx] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+                }
+            for (int c = 0; c < 3; ++c) {
+                fdct8x8(blk[c]);
+                int16_t* o = coef.data() + (((size_t)y0 * bx + x0) * 3 + c) * 64;
+                const uint8_t* qt = q[c ? 1 : 0];
+                for (int i = 0; i < 64; ++i) { const float v = blk[c][ZIGZAG[i]] / (float)qt[ZIGZAG[i]]; o[i] = (int16_t)(v < 0 ? -(int)(-v + 0.5f) : (int)(v + 0.5f)); }
+            }
+        }
+    // pass 1: symbol statistics; pass 2: emit
+    HuffEnc dcT[2], acT[2];
+    std::vector<uint8_t> scan;
+    for (int pass = 0; pass < 2; ++pass) {
+        long fdc[2][256], fac[2][256];
+        memset(fdc, 0, sizeof fdc); memset(fac, 0, sizeof fac);
+        BitWriter bw(scan);
+        int pred[3] = {0, 0, 0};
+        for (size_t b = 0; b < (size_t)bx * by; ++b)
+            for (int c = 0; c < 3; ++c) {
+                const int16_t* o = coef.data() + (b * 3 + c) * 64;
+                const int t = c ? 1 : 0;
+                const int diff = o[0] - pred[c]; pred[c] = o[0];
+                const int s = bitSize(diff);
+                if (pass == 0) fdc[t][s]++; else { bw.put(dcT[t].code[s], dcT[t].len[s]); if (s) bw.put((uint32_t)(diff < 0 ? diff - 1 : diff), s); }
+                int run = 0;
+                for (int k = 1; k < 64; ++k) {
+                    const int v = o[k];
+                    if (v == 0) { ++run; continue; }
+                    while (run > 15) { if (pass == 0) fac[t][0xF0]++; else bw.put(acT[t].code[0xF0], acT[t].len[0xF0]); run -= 16; }
+                    const int sz = bitSize(v), sym = (run << 4) | sz;
+                    if (pass == 0) fac[t][sym]++; else { bw.put(acT[t].code[sym], acT[t].len[sym]); bw.put((uint32_t)(v < 0 ? v - 1 : v), sz); }
+                    run = 0;
+                }
+                if (run) { if (pass == 0) fac[t][0]++; else bw.put(acT[t].code[0], acT[t].len[0]); }
+            }
+        if (pass == 0) { for (int t = 0; t < 2; ++t) { buildOptimal(fdc[t], dcT[t]); buildOptimal(fac[t], acT[t]); } }
+        else bw.flush();
+    }
+    auto u16 = [&](int v) { out.push_back((uint8_t)(v >> 8)); out.push_back((uint8_t)v); };
+    out.clear();
+    out.push_back(0xFF); out.push_back(0xD8);
+    static const uint8_t JFIF[] = {0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+    out.insert(out.end(), JFIF, JFIF + sizeof JFIF);
+    for (int t = 0; t < 2; ++t) { out.push_back(0xFF); out.push_back(0xDB); u16(67); out.push_back((uint8_t)t); for (int i = 0; i < 64; ++i) out.push_back(q[t][ZIGZAG[i]]); }
+    out.push_back(0xFF); out.push_back(0xC0); u16(17); out.push_back(8); u16((int)H); u16((int)W); out.push_back(3);
+    for (int c = 0; c < 3; ++c) { out.push_back((uint8_t)(c + 1)); out.push_back(0x11); out.push_back((uint8_t)(c ? 1 : 0)); }
+    for (int t = 0; t < 2; ++t)
+        for (int cls = 0; cls < 2; ++cls) {
+            const HuffEnc& h = cls ? acT[t] : dcT[t];
+            out.push_back(0xFF); out.push_back(0xC4); u16(2 + 1 + 16 + h.nvals); out.push_back((uint8_t)((cls << 4) | t));
+            for (int l = 1; l <= 16; ++l) out.push_back(h.bits[l]);
+            out.insert(out.end(), h.vals, h.vals + h.nvals);
+        }
+    out.push_back(0xFF); out.push_back(0xDA); u16(12); out.push_back(3);
+    for (int c = 0; c < 3; ++c) { out.push_back((uint8_t)(c + 1)); out.push_back((uint8_t)(c ? 0x11 : 0x00)); }
+    out.push_back(0); out.push_back(63); out.push_back(0);
+    out.insert(out.end(), scan.begin(), scan.end());
+    out.push_back(0xFF); out.push_back(0xD9);
+    return BF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -414,6 +565,24 @@ int bf_decode_color_rgb(const uint8_t* data, uint64_t size, int32_t compressionT
     return BF_ERR_INVALID_ARG;
 } catch (const std::exception& e) {                   // e.g. std::bad_alloc on an absurd image size: no exception leaves the C ABI
     set_error("colour decoder: %s", e.what());
+    return BF_ERR_STATE;
+}
+
+// baseline JPEG of a width x height RGB8 image.  Call with out == NULL to get the size; the encoded stream is kept until the next call
+// of this function on the same thread.
+int bf_encode_jpeg_rgb(const uint8_t* rgb, uint32_t width, uint32_t height, int32_t quality, uint8_t* out, uint64_t capacity, uint64_t* size) try {
+    BF_REQUIRE(rgb && size && width > 0 && height > 0 && width < 65536 && height < 65536, "bad argument");
+    static thread_local std::vector<uint8_t> buf;
+    static thread_local const uint8_t* last = nullptr;
+    if (!out || last != rgb || buf.empty()) { const int rc = encodeJpeg(rgb, width, height, quality, buf); if (rc) return rc; last = rgb; }
+    *size = buf.size();
+    if (!out) return BF_OK;
+    BF_REQUIRE(capacity >= buf.size(), "buffer too small");
+    memcpy(out, buf.data(), buf.size());
+    last = nullptr;
+    return BF_OK;
+} catch (const std::exception& e) {
+    set_error("jpeg encoder: %s", e.what());
     return BF_ERR_STATE;
 }
 

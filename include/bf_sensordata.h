@@ -51,6 +51,9 @@ typedef struct bf_sensor_data_writer bf_sensor_data_writer; /* a .sens file bein
 typedef int (*bf_sens_color_decoder)(void* user, const uint8_t* data, uint64_t size, int32_t compressionType, uint32_t width,
                                      uint32_t height, uint8_t* rgbOut);
 BF_API int bf_decode_color_rgb(const uint8_t* data, uint64_t size, int32_t compressionType, uint32_t width, uint32_t height, uint8_t* rgbOut);
+/* baseline JPEG (4:4:4, image-optimised Huffman tables) of an RGB8 image, for recording colour frames the way the reference does
+ * (TYPE_JPEG, RGBDSensor.cpp:276).  out == NULL: only *size is returned (the stream is kept for the following call with a buffer). */
+BF_API int bf_encode_jpeg_rgb(const uint8_t* rgb, uint32_t width, uint32_t height, int32_t quality, uint8_t* out, uint64_t capacity, uint64_t* size);
 
 /* SensorData::loadFromFile (frames are indexed and read on demand, so a file larger than host memory can be played) */
 BF_API int bf_sensor_data_open(const char* filename, bf_sensor_data** out);

@@ -110,8 +110,8 @@ public:
 
     // ---- recording (RGBDSensor.cpp:264-312, 353-398, "modern .sens files"): every recordFrame() appends the current depth
     // (u16 = round(1000 * metres), invalid -> 0, zlib) and colour to a temporary .sens; saveRecordedFramesToFile attaches the
-    // trajectory, drops frames without a pose and writes the final file.  Colour is stored raw RGB8 (the reference JPEG-encodes
-    // with stb_image_write; this library has no JPEG encoder - any reader of the format accepts raw).
+    // trajectory, drops frames without a pose and writes the final file.  Colour is JPEG-compressed like the reference's recordings
+    // (TYPE_JPEG; baseline 4:4:4, quality 90 - mLib uses stb_image_write, an encoder's bytes are not pinned by anything).
     void recordFrame() {
         if (!m_recWriter) {
             bf_sensor_data_info info; std::memset(&info, 0, sizeof info);
@@ -119,7 +119,7 @@ public:
             std::snprintf(info.sensorName, sizeof info.sensorName, "%s", getSensorName().c_str());
             std::memcpy(info.colorIntrinsic, m_desc.colorIntrinsics, 64); std::memcpy(info.colorExtrinsic, m_desc.colorExtrinsics, 64);
             std::memcpy(info.depthIntrinsic, m_desc.depthIntrinsics, 64); std::memcpy(info.depthExtrinsic, m_desc.depthExtrinsics, 64);
-            info.colorCompressionType = BF_SENS_COLOR_RAW; info.depthCompressionType = BF_SENS_DEPTH_ZLIB_USHORT;
+            info.colorCompressionType = BF_SENS_COLOR_JPEG; info.depthCompressionType = BF_SENS_DEPTH_ZLIB_USHORT;
             info.colorWidth = m_desc.colorWidth; info.colorHeight = m_desc.colorHeight; info.depthWidth = m_desc.depthWidth; info.depthHeight = m_desc.depthHeight;
             info.depthShift = 1000.0f;
             m_recTmp = m_recordTmpPrefix + std::to_string((unsigned long long)(uintptr_t)this) + ".rec.sens";
@@ -135,8 +135,12 @@ public:
             depth[i] = (v > 0.0f && v < 65535.5f) ? (uint16_t)(v + 0.5f) : (uint16_t)0;
         }
         for (size_t i = 0; i < nc; ++i) { color[3 * i] = c[4 * i]; color[3 * i + 1] = c[4 * i + 1]; color[3 * i + 2] = c[4 * i + 2]; }
+        uint64_t jpegSize = 0;
+        check(bf_encode_jpeg_rgb(color.data(), m_desc.colorWidth, m_desc.colorHeight, 90, nullptr, 0, &jpegSize));
+        std::vector<unsigned char> jpeg(jpegSize);
+        check(bf_encode_jpeg_rgb(color.data(), m_desc.colorWidth, m_desc.colorHeight, 90, jpeg.data(), jpeg.size(), &jpegSize));
         const mat4f I = mat4f::identity();
-        check(bf_sensor_data_writer_add_frame(m_recWriter, I.m, 0, 0, color.data(), color.size(), depth.data()));
+        check(bf_sensor_data_writer_add_frame(m_recWriter, I.m, 0, 0, jpeg.data(), jpegSize, depth.data()));
         m_numRecorded++;
     }
     unsigned int getNumRecordedFrames() const { return m_numRecorded; }

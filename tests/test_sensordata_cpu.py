@@ -382,3 +382,42 @@ def test_builtin_png_decoder_is_exact():
                 assert np.array_equal(_decode(buf.getvalue(), sdm.COLOR_PNG, 61, 43), ref), (mode, kind, opt)
     with pytest.raises(BFError, match="signature"):
         _decode(b"not a png at all", sdm.COLOR_PNG, 4, 4)
+
+
+def test_builtin_jpeg_encoder_round_trip():
+    """bf_encode_jpeg_rgb (recording): a stream every baseline decoder reads - Pillow and the built-in decoder agree on it bit for bit -
+    at the quality / size of an optimised 4:4:4 libjpeg encode."""
+    pytest.importorskip("PIL")
+    import ctypes as C
+    from PIL import Image
+    from bundlefusion_amd.capi import lib, check
+    lib.bf_encode_jpeg_rgb.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+
+    def enc(img, q):
+        h, w, _ = img.shape
+        a = np.ascontiguousarray(img)
+        n = C.c_uint64()
+        check(lib.bf_encode_jpeg_rgb(a.ctypes.data, w, h, q, None, 0, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        check(lib.bf_encode_jpeg_rgb(a.ctypes.data, w, h, q, buf.ctypes.data, n.value, C.byref(n)))
+        return buf.tobytes()
+
+    def psnr(a, b):
+        return 10 * np.log10(255.0 ** 2 / max(np.mean((a.astype(float) - b.astype(float)) ** 2), 1e-9))
+
+    rng = np.random.default_rng(2)
+    for (w, h) in ((64, 48), (37, 29), (200, 120)):
+        for kind, floor50, floor90 in (("smooth", 36.0, 43.0), ("edges", 27.0, 33.0)):
+            img = _test_image(w, h, kind, rng)
+            for q, floor in ((50, floor50), (90, floor90)):
+                blob = enc(img, q)
+                assert blob[:2] == b"\xff\xd8" and blob[-2:] == b"\xff\xd9"
+                pil = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"))
+                assert np.array_equal(_decode(blob, sdm.COLOR_JPEG, w, h), pil)
+                assert psnr(pil, img) > floor, (w, h, kind, q, psnr(pil, img))
+                ref = io.BytesIO(); Image.fromarray(img).save(ref, format="JPEG", quality=q, subsampling=0)
+                assert len(blob) < 1.1 * len(ref.getvalue()) + 64                 # image-optimised Huffman tables: not larger than libjpeg's default
+    with pytest.raises(BFError):
+        lib.bf_encode_jpeg_rgb.restype = C.c_int
+        n = C.c_uint64()
+        check(lib.bf_encode_jpeg_rgb(None, 8, 8, 90, None, 0, C.byref(n)))
