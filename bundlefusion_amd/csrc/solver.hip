@@ -993,10 +993,10 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
     if (const char* e = getenv("BF_PCG_GROUPS")) s->pcgGroups = atoi(e);        // 0: single-workgroup kernel, n > 0: force n groups
     {   // every group of the cooperative PCG must be resident at once (each may take a whole CU's LDS): never ask for more than
         // half of the CUs this device (or compute partition) has
-        int dev = 0; hipDeviceProp_t prop;
-        BF_HIP_TRY(hipGetDevice(&dev));
-        BF_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        s->maxCoopGroups = std::max(1u, std::min(COOP_MAX_GROUPS, (uint32_t)prop.multiProcessorCount / 2u));
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            s->maxCoopGroups = std::max(1u, std::min(COOP_MAX_GROUPS, (uint32_t)cus / 2u));
+        else (void)hipGetLastError();                   // keep the default (a full MI355X has 256 CUs)
     }
     s->maxCorrPerImage = std::min(std::max(maxNumResiduals / maxNumberOfImages, 1000u), 4000u);   // .cpp:39
     const size_t N = maxNumberOfImages, M = N * N, C = maxNumResiduals;
