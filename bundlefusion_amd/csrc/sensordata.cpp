@@ -413,6 +413,18 @@ void kabschAlign(const std::vector<std::array<double, 3>>& p, const std::vector<
 
 extern "C" {
 
+static void validPositions(const float* traj, const float* ref, uint32_t n, std::vector<std::array<double, 3>>& pts, std::vector<std::array<double, 3>>& refPts,
+                           std::vector<uint32_t>* indices) {
+    const float NINF = -std::numeric_limits<float>::infinity();
+    auto tr = [](const float* T, uint32_t i, int k) { return (double)T[16 * (size_t)i + 4 * k + 3]; };
+    for (uint32_t i = 0; i < n; ++i)
+        if (traj[16 * (size_t)i] != NINF && ref[16 * (size_t)i] != NINF) {
+            pts.push_back({tr(traj, i, 0), tr(traj, i, 1), tr(traj, i, 2)});
+            refPts.push_back({tr(ref, i, 0), tr(ref, i, 1), tr(ref, i, 2)});
+            if (indices) indices->push_back(i);
+        }
+}
+
 int bf_evaluate_ate_rmse(const float* traj, const float* ref, uint32_t numTransforms, float* rmse, uint32_t* numEvaluated) {     // PoseHelper.h:35-79
     return guarded([&]() -> int {
     BF_REQUIRE((traj && ref) || numTransforms == 0, "null argument");
@@ -432,11 +444,7 @@ int bf_evaluate_ate_rmse(const float* traj, const float* ref, uint32_t numTransf
         return BF_OK;
     }
     std::vector<std::array<double, 3>> pts, refPts;
-    for (uint32_t i = 0; i < numTransforms; ++i)
-        if (traj[16 * (size_t)i] != NINF && ref[16 * (size_t)i] != NINF) {
-            pts.push_back({tr(traj, i, 0), tr(traj, i, 1), tr(traj, i, 2)});
-            refPts.push_back({tr(ref, i, 0), tr(ref, i, 1), tr(ref, i, 2)});
-        }
+    validPositions(traj, ref, numTransforms, pts, refPts, nullptr);
     if (pts.empty()) { *rmse = NINF; *numEvaluated = 0; return BF_OK; }                    // "ERROR no points to evaluate"
     double R[3][3], t[3];
     kabschAlign(pts, refPts, R, t);
@@ -449,6 +457,58 @@ int bf_evaluate_ate_rmse(const float* traj, const float* ref, uint32_t numTransf
         }
     *rmse = (float)sqrt(err / (double)pts.size());
     *numEvaluated = (uint32_t)pts.size();
+    return BF_OK;
+    });
+}
+
+int bf_trajectory_alignment(const float* traj, const float* ref, uint32_t numTransforms, float align[16]) {                       // PoseHelper.h:81-108
+    return guarded([&]() -> int {
+    BF_REQUIRE(align && ((traj && ref) || numTransforms == 0), "null argument");
+    for (int i = 0; i < 16; ++i) align[i] = -std::numeric_limits<float>::infinity();          // ret.setZero(-inf): "cannot evaluate"
+    if (numTransforms < 3) return BF_OK;
+    std::vector<std::array<double, 3>> pts, refPts;
+    validPositions(traj, ref, numTransforms, pts, refPts, nullptr);
+    if (pts.empty()) return BF_OK;
+    double R[3][3], t[3];
+    kabschAlign(pts, refPts, R, t);
+    for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) align[4 * a + b] = (float)R[a][b]; align[4 * a + 3] = (float)t[a]; }
+    align[12] = align[13] = align[14] = 0.0f; align[15] = 1.0f;
+    return BF_OK;
+    });
+}
+
+int bf_evaluate_err2_per_image(const float* traj, const float* ref, uint32_t numTransforms, uint32_t* imageIndices, float* err2, uint32_t* count) {   // :110-146
+    return guarded([&]() -> int {
+    BF_REQUIRE(imageIndices && err2 && count && ((traj && ref) || numTransforms == 0), "null argument");
+    *count = 0;
+    auto tr = [](const float* T, uint32_t i, int k) { return (double)T[16 * (size_t)i + 4 * k + 3]; };
+    if (numTransforms < 3) {
+        if (numTransforms == 2) {
+            const double l = sqrt(tr(ref, 0, 0) * tr(ref, 0, 0) + tr(ref, 0, 1) * tr(ref, 0, 1) + tr(ref, 0, 2) * tr(ref, 0, 2));
+            if (!(l > 0.0001)) {
+                double d = 0;
+                for (int k = 0; k < 3; ++k) d += (tr(traj, 1, k) - tr(ref, 1, k)) * (tr(traj, 1, k) - tr(ref, 1, k));
+                imageIndices[0] = 0; err2[0] = (float)sqrt(d); *count = 1;                     // the reference stores the distance (not squared) here
+            }
+        }
+        return BF_OK;
+    }
+    std::vector<std::array<double, 3>> pts, refPts;
+    std::vector<uint32_t> idx;
+    validPositions(traj, ref, numTransforms, pts, refPts, &idx);
+    if (pts.empty()) return BF_OK;
+    double R[3][3], t[3];
+    kabschAlign(pts, refPts, R, t);
+    for (size_t i = 0; i < pts.size(); ++i) {
+        double e = 0;
+        for (int a = 0; a < 3; ++a) {
+            double v = t[a] - refPts[i][a];
+            for (int b = 0; b < 3; ++b) v += R[a][b] * pts[i][b];
+            e += v * v;
+        }
+        imageIndices[i] = idx[i]; err2[i] = (float)e;
+    }
+    *count = (uint32_t)pts.size();
     return BF_OK;
     });
 }

@@ -97,6 +97,12 @@ BF_API int bf_sensor_data_save_recorded(bf_sensor_data* sd, const char* filename
  * not in the tree: the alignment here is the textbook SVD solution (double precision). */
 BF_API int bf_evaluate_ate_rmse(const float* trajectory, const float* referenceTrajectory, uint32_t numTransforms, float* rmse,
                                 uint32_t* numEvaluated);
+/* PoseHelper::getAlignmentBetweenTrajectories (PoseHelper.h:81-108): the rigid transform itself (all -inf when it cannot be evaluated) */
+BF_API int bf_trajectory_alignment(const float* trajectory, const float* referenceTrajectory, uint32_t numTransforms, float align[16]);
+/* PoseHelper::evaluateErr2PerImage (:110-146): squared position error of every pose that is valid on both sides, after the alignment;
+ * imageIndices / err2 need room for numTransforms entries */
+BF_API int bf_evaluate_err2_per_image(const float* trajectory, const float* referenceTrajectory, uint32_t numTransforms, uint32_t* imageIndices,
+                                      float* err2, uint32_t* count);
 /* SensorDataReader::evaluateTrajectory (:167-189): the file's cameraToWorld poses, re-based so that the first is identity, are
  * the reference. */
 BF_API int bf_sensor_data_evaluate_trajectory(bf_sensor_data* sd, const float* trajectory, uint64_t numTransforms, float* rmse,

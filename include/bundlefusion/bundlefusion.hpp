@@ -5,9 +5,11 @@
 //
 // Matrix arguments are `mat4f` = 16 floats, row-major (same memory as ml::mat4f / float4x4).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -171,6 +173,66 @@ private:
     std::string m_recTmp, m_recordTmpPrefix = "./bf_";
     unsigned int m_numRecorded = 0;
 };
+
+// ---- PoseHelper (PoseHelper.h:8-166): trajectory bookkeeping and evaluation on the host
+namespace PoseHelper {
+inline unsigned int countNumValidTransforms(const std::vector<mat4f>& trajectory) {
+    unsigned int count = 0;
+    for (const mat4f& T : trajectory) if (T.m[0] != -std::numeric_limits<float>::infinity()) count++;
+    return count;
+}
+// key-frame poses + per-chunk relative poses -> one pose per frame (:19-33)
+inline void composeTrajectory(unsigned int submapSize, const std::vector<mat4f>& keys, std::vector<mat4f>& all) {
+    std::vector<mat4f> transforms;
+    for (unsigned int i = 0; i < keys.size(); i++) {
+        const mat4f& key = keys[i];
+        transforms.push_back(key);
+        const mat4f offset = all[i * submapSize].getInverse();
+        const unsigned int num = (unsigned int)std::min((int)submapSize, (int)all.size() - (int)(i * submapSize));
+        for (unsigned int s = 1; s < num; s++) transforms.push_back(key * offset * all[i * submapSize + s]);
+    }
+    all = transforms;
+}
+inline std::pair<float, unsigned int> evaluateAteRmse(const std::vector<mat4f>& trajectory, const std::vector<mat4f>& referenceTrajectory,
+                                                      unsigned int numTransforms = (unsigned int)-1) {
+    if (numTransforms == (unsigned int)-1) numTransforms = (unsigned int)std::min(trajectory.size(), referenceTrajectory.size());
+    float rmse = 0.0f; uint32_t n = 0;
+    check(bf_evaluate_ate_rmse(numTransforms ? trajectory[0].m : nullptr, numTransforms ? referenceTrajectory[0].m : nullptr, numTransforms, &rmse, &n));
+    return std::make_pair(rmse, (unsigned int)n);
+}
+inline mat4f getAlignmentBetweenTrajectories(const std::vector<mat4f>& trajectory, const std::vector<mat4f>& referenceTrajectory,
+                                             unsigned int numTransforms = (unsigned int)-1) {
+    if (numTransforms == (unsigned int)-1) numTransforms = (unsigned int)std::min(trajectory.size(), referenceTrajectory.size());
+    mat4f ret;
+    check(bf_trajectory_alignment(numTransforms ? trajectory[0].m : nullptr, numTransforms ? referenceTrajectory[0].m : nullptr, numTransforms, ret.m));
+    return ret;
+}
+inline std::vector<std::pair<unsigned int, float>> evaluateErr2PerImage(const std::vector<mat4f>& trajectory, const std::vector<mat4f>& referenceTrajectory) {
+    const uint32_t n = (uint32_t)std::min(trajectory.size(), referenceTrajectory.size());
+    std::vector<uint32_t> idx(n ? n : 1); std::vector<float> e(n ? n : 1);
+    uint32_t cnt = 0;
+    check(bf_evaluate_err2_per_image(n ? trajectory[0].m : nullptr, n ? referenceTrajectory[0].m : nullptr, n, idx.data(), e.data(), &cnt));
+    std::vector<std::pair<unsigned int, float>> errors;
+    for (uint32_t i = 0; i < cnt; ++i) errors.push_back(std::make_pair((unsigned int)idx[i], e[i]));
+    return errors;
+}
+// "index tx ty tz qx qy qz qw" per valid pose (:148-165)
+inline void saveToPoseFile(const std::string& filename, const std::vector<mat4f>& trajectory) {
+    std::ofstream s(filename);
+    for (unsigned int i = 0; i < trajectory.size(); i++) {
+        const mat4f& T = trajectory[i];
+        if (T(0, 0) == -std::numeric_limits<float>::infinity()) continue;
+        // unit quaternion of the rotation block (largest-component branch, w >= 0 convention of ml::quatf(mat3f) is not pinned: q and -q are the same rotation)
+        const float m00 = T(0, 0), m11 = T(1, 1), m22 = T(2, 2), tr = m00 + m11 + m22;
+        float qw, qx, qy, qz;
+        if (tr > 0.0f) { const float r = std::sqrt(tr + 1.0f) * 2.0f; qw = 0.25f * r; qx = (T(2, 1) - T(1, 2)) / r; qy = (T(0, 2) - T(2, 0)) / r; qz = (T(1, 0) - T(0, 1)) / r; }
+        else if (m00 > m11 && m00 > m22) { const float r = std::sqrt(1.0f + m00 - m11 - m22) * 2.0f; qw = (T(2, 1) - T(1, 2)) / r; qx = 0.25f * r; qy = (T(0, 1) + T(1, 0)) / r; qz = (T(0, 2) + T(2, 0)) / r; }
+        else if (m11 > m22) { const float r = std::sqrt(1.0f + m11 - m00 - m22) * 2.0f; qw = (T(0, 2) - T(2, 0)) / r; qx = (T(0, 1) + T(1, 0)) / r; qy = 0.25f * r; qz = (T(1, 2) + T(2, 1)) / r; }
+        else { const float r = std::sqrt(1.0f + m22 - m00 - m11) * 2.0f; qw = (T(1, 0) - T(0, 1)) / r; qx = (T(0, 2) + T(2, 0)) / r; qy = (T(1, 2) + T(2, 1)) / r; qz = 0.25f * r; }
+        s << i << " " << T(0, 3) << " " << T(1, 3) << " " << T(2, 3) << " " << qx << " " << qy << " " << qz << " " << qw << std::endl;
+    }
+}
+}  // namespace PoseHelper
 
 // ---- TimingLog (TimingLog.h:6-283): per-frame timings in the reference's text / "excel" file formats, so that numbers are
 // comparable with a CUDA run of the reference.  Fed from bf_frame_timing (bf_pipeline_get_last_timing) or filled directly.

@@ -323,3 +323,51 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
+
+
+_POSEHELPER_CPP = r'''
+#include "bundlefusion/bundlefusion.hpp"
+using namespace bundlefusion;
+static mat4f rotZ(float a, float tx, float ty, float tz) { mat4f T = mat4f::identity(); T(0,0)=std::cos(a); T(0,1)=-std::sin(a); T(1,0)=std::sin(a); T(1,1)=std::cos(a); T(0,3)=tx; T(1,3)=ty; T(2,3)=tz; return T; }
+int main(int, char** argv) {
+    std::vector<mat4f> ref, traj;
+    const mat4f G = rotZ(0.7f, 1.0f, -2.0f, 0.5f);
+    for (int i = 0; i < 12; ++i) { ref.push_back(rotZ(0.1f * i, 0.3f * i, 0.1f * i * i, 0.05f * i)); traj.push_back(G * ref.back()); }
+    mat4f bad; bad.setZero(-std::numeric_limits<float>::infinity()); traj[4] = bad;
+    if (PoseHelper::countNumValidTransforms(traj) != 11) return 1;
+    const auto ate = PoseHelper::evaluateAteRmse(traj, ref);
+    if (!(ate.first < 1e-5f) || ate.second != 11) return 2;
+    const mat4f A = PoseHelper::getAlignmentBetweenTrajectories(traj, ref);      // maps trajectory positions onto the reference: inverse of G
+    const mat4f I = A * G;
+    for (int i = 0; i < 16; ++i) if (std::fabs(I.m[i] - ((i % 5 == 0) ? 1.0f : 0.0f)) > 1e-4f) return 3;
+    const auto per = PoseHelper::evaluateErr2PerImage(traj, ref);
+    if (per.size() != 11 || per[4].first != 5 || per[10].second > 1e-9f) return 4;
+    std::vector<mat4f> all; for (int i = 0; i < 6; ++i) all.push_back(rotZ(0.0f, (float)i, 0, 0));
+    std::vector<mat4f> keys = {rotZ(0.0f, 10.0f, 0, 0), rotZ(0.0f, 20.0f, 0, 0)};
+    PoseHelper::composeTrajectory(3, keys, all);                                  // two chunks of three frames, re-based on their key poses
+    const float want[6] = {10, 11, 12, 20, 21, 22};
+    for (int i = 0; i < 6; ++i) if (std::fabs(all[i](0, 3) - want[i]) > 1e-5f) return 5;
+    PoseHelper::saveToPoseFile(std::string(argv[1]) + "/poses.txt", traj);
+    return 0;
+}
+'''
+
+
+def test_pose_helper_functions(built, tmp_path):
+    """PoseHelper (PoseHelper.h:8-166) in bundlefusion.hpp: valid-pose count, composeTrajectory, ATE, alignment, per-image error, pose file."""
+    src = tmp_path / "ph.cpp"
+    src.write_text(_POSEHELPER_CPP)
+    exe = tmp_path / "ph"
+    libdir = os.path.join(ROOT, "bundlefusion_amd", "lib")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lbf_hip", "-Wl,-rpath," + libdir,
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.returncode
+    rows = [l.split() for l in (tmp_path / "poses.txt").read_text().splitlines()]
+    assert [int(r[0]) for r in rows] == [0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11]                   # the invalid pose is skipped, indices are kept
+    q = np.array([[float(v) for v in r[4:]] for r in rows])
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-5) and np.allclose(q[:, :2], 0.0, atol=1e-6)     # rotations about z: (0, 0, sin, cos)
+    ang = 2 * np.arctan2(q[:, 2], q[:, 3])
+    assert np.allclose(ang, 0.7 + 0.1 * np.array([0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11]), atol=1e-4)
+    assert abs(float(rows[0][1]) - 1.0) < 1e-6 and abs(float(rows[0][2]) + 2.0) < 1e-6 and abs(float(rows[0][3]) - 0.5) < 1e-6
