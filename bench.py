@@ -102,6 +102,7 @@ def main():
     sc = pipe.scene()
     sc.kernel_timing(True)                                   # HIP events around every voxel-update launch, on the pipeline's stream
     c0 = pipe.counters()
+    pipe.host_profile(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.warmup, total):
@@ -114,6 +115,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     c1 = pipe.counters()
+    hp = pipe.host_profile()
     occ_sum, n_ops = sc.kernel_timing_occupied()
     n_launch, kernel_ms = sc.kernel_timing_read()
     sc.kernel_timing(False)
@@ -161,6 +163,7 @@ def main():
                 "frames_valid": int(valid.sum()), "frames_total": int(len(traj)), "ate_rmse_vs_ground_truth_m": ate,
                 "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
                 "render_seconds_untimed": round(t_gen, 1),
+                "host_thread_ms_per_frame": {k: round(1e3 * v / max(hp["frames"], 1.0), 4) for k, v in hp.items() if k != "frames"},
                 "frame_loop": "serial order, detection of frame k+1 overlapped with matching/solve of frame k (BF_PIPELINE_LOOKAHEAD=%s)"
                               % os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
                 "parallelism": ("one stream, bundling replicated on %d ranks, volume sharded by hash-bucket range" % world) if shard_volume

@@ -835,6 +835,13 @@ class Pipeline:
         check(lib.bf_pipeline_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(integrate=a.value, deintegrate=b.value, local_solves=c.value, global_solves=d.value)
 
+    def host_profile(self, reset=False):
+        """Seconds the calling thread spent per part of the frame loop (accumulated) and the frame count: see bf_pipeline_get_host_profile."""
+        out = (C.c_double * 8)()
+        check(lib.bf_pipeline_get_host_profile(self._h, out, int(reset)))
+        names = ("enqueue_match_chain", "ingest_detect_enqueue", "reintegrate_commands", "wait_match_result", "integrate_command", "solves", "wait_ingest", "frames")
+        return dict(zip(names, [float(v) for v in out]))
+
     def enable_timings(self, on=True):
         check(lib.bf_pipeline_enable_timings(self._h, int(on)))
 

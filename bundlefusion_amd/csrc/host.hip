@@ -19,6 +19,7 @@
 #include <list>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/bf_pipeline.h"
@@ -1402,6 +1403,10 @@ struct bf_pipeline {
     int workerError = BF_OK;
     std::string workerMessage;
     uint32_t numIntegrate = 0, numDeIntegrate = 0;
+    // wall time the calling thread spent in each part of plFrame, accumulated (bf_pipeline_get_host_profile): where the frame loop's
+    // critical path lies without a profiler.  [0] enqueue of the previous frame's matching chain, [1] ingest + detection enqueue,
+    // [2] re-integration commands, [3] wait for the matching result + host logic, [4] integration command, [5] solves, [6] ingest wait, [7] frames
+    double hostProfile[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool timings = false;
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bf_frame_timing last;
@@ -1497,9 +1502,14 @@ int plReintegrate(bf_pipeline* p) {                                             
 // everything of the frame loop after the ingest, for frame `frame` (got: a new frame, as opposed to an iteration after the
 // sequence ended), in two parts so that a caller can put host work between the enqueue of processInput and its read-back
 //                                                                                                   :966-1095 (serial branch)
+inline double plNow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int plBodyBegin(bf_pipeline* p, uint32_t frame) {
     // ---- processInput: enqueue (bundling stream) ...
-    return bf_online_bundler_process_input_begin_frame(p->ob, frame);
+    const double t0 = plNow();
+    const int rc = bf_online_bundler_process_input_begin_frame(p->ob, frame);
+    p->hostProfile[0] += plNow() - t0;
+    return rc;
 }
 
 int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
@@ -1507,11 +1517,14 @@ int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
     const bool tm = p->timings;
     const int evSlot = got ? (int)(frame % bf_pipeline::NEV) : -1;
     // ---- fix old frames (volume stream; launches issued by the volume thread), concurrently with the feature pipeline
+    double t0 = plNow();
     if (tm) (void)hipEventRecord(p->ev[4], sv);
     BF_TRY(plReintegrate(p));
     if (tm) (void)hipEventRecord(p->ev[5], sv);
+    double t1 = plNow(); p->hostProfile[2] += t1 - t0; t0 = t1;
     // ---- ... and its read-back
     BF_TRY(bf_online_bundler_process_input_end(p->ob));
+    t1 = plNow(); p->hostProfile[3] += t1 - t0; t0 = t1;
     if (tm) (void)hipEventRecord(p->ev[2], sa);
     // ---- reconstruction of the current frame (volume stream, after this frame's ingest)
     if (tm) (void)hipEventRecord(p->ev[6], sv);
@@ -1527,9 +1540,12 @@ int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
         }
     }
     if (tm) (void)hipEventRecord(p->ev[7], sv);
+    t1 = plNow(); p->hostProfile[4] += t1 - t0; t0 = t1;
     // ---- bundling optimisation (bundling stream)
     BF_TRY(bf_online_bundler_process(p->ob, p->gbs.s_numLocalNonLinIterations, p->gbs.s_numLocalLinIterations, p->ob->gbs.s_numGlobalNonLinIterations,
                                      p->gbs.s_numGlobalLinIterations));
+    p->hostProfile[5] += plNow() - t0;
+    if (got) p->hostProfile[7] += 1.0;
     return BF_OK;
 }
 
@@ -1556,6 +1572,7 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (prev >= 0) BF_TRY(plBodyBegin(p, (uint32_t)prev));
     else BF_TRY(plFlush(p));
     // ---- read input (detect stream)
+    const double tIn = plNow();
     if (tm) (void)hipEventRecord(p->ev[0], sd);
     int got = 0;
     if (haveInput) BF_TRY(device ? bf_image_manager_process_device(p->im, depth, color, &got) : bf_image_manager_process(p->im, depth, color, &got));
@@ -1563,6 +1580,7 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (got) BF_HIP_TRY(hipEventRecord(p->evIngest[frame % bf_pipeline::NEV], sd));
     if (tm) { (void)hipEventRecord(p->ev[1], sd); BF_HIP_TRY(hipStreamWaitEvent(sa, p->ev[1], 0)); (void)hipEventRecord(p->ev[8], sa); }
     if (got) BF_TRY(bf_online_bundler_detect_ahead(p->ob));
+    p->hostProfile[1] += plNow() - tIn;
     if (prev >= 0) { p->deferred = -1; BF_TRY(plBodyRest(p, (uint32_t)prev, true)); }
     if (ahead && got) p->deferred = (int)frame;
     else if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, got != 0));
@@ -1580,7 +1598,7 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     }
     // the caller's depth / colour buffers (host or device) are free for reuse when this returns, like after the reference's
     // synchronous CUDAImageManager::process: the ingest ran beside the previous frame's body, so this wait is normally over already
-    if (got) BF_HIP_TRY(hipEventSynchronize(p->evIngest[frame % bf_pipeline::NEV]));
+    if (got) { const double tw = plNow(); BF_HIP_TRY(hipEventSynchronize(p->evIngest[frame % bf_pipeline::NEV])); p->hostProfile[6] += plNow() - tw; }
     if (gotFrame) *gotFrame = got;
     return BF_OK;
 }
@@ -1717,6 +1735,13 @@ int bf_pipeline_get_counters(bf_pipeline* p, uint32_t* numIntegrate, uint32_t* n
     if (numDeIntegrate) *numDeIntegrate = p->numDeIntegrate;
     if (numLocalSolves) *numLocalSolves = p->ob->numLocalSolves;
     if (numGlobalSolves) *numGlobalSolves = p->ob->numGlobalSolves;
+    return BF_OK;
+}
+int bf_pipeline_get_host_profile(bf_pipeline* p, double out[8], int reset) {
+    BF_REQUIRE(p && out, "null argument");
+    BF_TRY(plFlush(p));
+    for (int i = 0; i < 8; ++i) out[i] = p->hostProfile[i];
+    if (reset) for (double& v : p->hostProfile) v = 0.0;
     return BF_OK;
 }
 int bf_pipeline_enable_timings(bf_pipeline* p, int enable) {

@@ -256,6 +256,10 @@ BF_API int bf_pipeline_get_num_frames(bf_pipeline* p, uint32_t* out);
 /* camera-to-world poses the frames are currently integrated with (-inf matrix: not integrated) */
 BF_API int bf_pipeline_get_integrated_trajectory(bf_pipeline* p, float* h_out, uint32_t capacity, uint32_t* count);
 BF_API int bf_pipeline_get_counters(bf_pipeline* p, uint32_t* numIntegrate, uint32_t* numDeIntegrate, uint32_t* numLocalSolves, uint32_t* numGlobalSolves);
+/* Wall time (seconds, accumulated) the calling thread spent in the parts of the frame loop, without synchronising anything:
+ * [0] enqueue of the previous frame's matching chain, [1] ingest + detection enqueue, [2] re-integration commands, [3] wait for the
+ * matching result + host logic, [4] integration command, [5] local / global solves, [6] wait for the ingest, [7] number of frames. */
+BF_API int bf_pipeline_get_host_profile(bf_pipeline* p, double out[8], int reset);
 BF_API int bf_pipeline_enable_timings(bf_pipeline* p, int enable);
 BF_API int bf_pipeline_get_last_timing(bf_pipeline* p, bf_frame_timing* out);
 
