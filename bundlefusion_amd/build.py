@@ -74,6 +74,19 @@ def build_oracle(force=False):
     return ORACLE_LIB
 
 
+def build_ref():
+    """Compile oracle/_ref/libbfref.so — the reference's own device code for the pinned stages, built for the host from
+    /root/reference by oracle/ref/Makefile (test infrastructure).  Where the reference is absent (the GPU box) the prebuilt
+    library that travelled with the snapshot is kept; returns None when there is neither."""
+    ref_lib = os.path.join(ORACLE_DIR, "_ref", "libbfref.so")
+    if os.path.isdir("/root/reference/FriedLiver/Source"):
+        r = subprocess.run(["make", "-s", "-C", os.path.join(ORACLE_DIR, "ref")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("oracle/_ref build failed:\n" + r.stdout.decode())
+    return ref_lib if os.path.exists(ref_lib) else None
+
+
 if __name__ == "__main__":
     print(build_lib(force="-f" in sys.argv, verbose=True))
     print(build_oracle(force="-f" in sys.argv))
+    print(build_ref())

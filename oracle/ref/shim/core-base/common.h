@@ -1,0 +1,13 @@
+// oracle/ref/shim: the two names of mLib's core-base/common.h (un-vendored submodule) that the device-side headers of the
+// reference use — test infrastructure only
+#ifndef BF_REF_SHIM_MLIB_COMMON_H
+#define BF_REF_SHIM_MLIB_COMMON_H
+#include <stdexcept>
+#include <string>
+#define MLIB_EXCEPTION(s) std::runtime_error(std::string(s))
+#define MLIB_ASSERT(b) do { if (!(b)) throw std::runtime_error("MLIB_ASSERT " #b); } while (0)
+#define MLIB_ASSERT_STR(b, s) do { if (!(b)) throw std::runtime_error(std::string(s)); } while (0)
+#define MLIB_WARNING(s) ((void)0)
+#define SAFE_DELETE(p) do { delete (p); (p) = nullptr; } while (0)
+#define SAFE_DELETE_ARRAY(p) do { delete[] (p); (p) = nullptr; } while (0)
+#endif

@@ -1,0 +1,2 @@
+// oracle/ref/shim: forwards to the host stand-in (test infrastructure only)
+#include "cuda_runtime.h"

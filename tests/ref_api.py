@@ -1,0 +1,183 @@
+"""ctypes view of oracle/_ref/libbfref.so — TEST INFRASTRUCTURE ONLY: the REFERENCE's own device code for the pinned stages,
+compiled for the host by oracle/ref/Makefile (needs /root/reference at build time; the built library travels with the repository
+snapshot, is git-ignored, and is never loaded by the product)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "oracle", "_ref", "libbfref.so")
+REFERENCE = "/root/reference/FriedLiver"
+
+
+def available():
+    """Build when the reference sources are present; otherwise use a prebuilt library if it travelled with the snapshot."""
+    if os.path.isdir(os.path.join(REFERENCE, "Source")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref")])
+    return os.path.exists(PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(PATH)
+        for f in ("ref_scene_create", "ref_scene_hash", "ref_scene_heap", "ref_scene_voxels", "ref_scene_compactified"):
+            getattr(_lib, f).restype = C.c_void_p
+        for f in ("ref_scene_heap_counter", "ref_scene_num_occupied", "ref_compute_hash_pos", "ref_linearize_voxel_pos", "ref_filter_keypoint_matches"):
+            getattr(_lib, f).restype = C.c_uint32
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+from bundlefusion_amd.capi import HASH_ENTRY_DTYPE, VOXEL_DTYPE, HASH_BUCKET_SIZE, VOX_PER_BLOCK  # noqa: E402
+
+
+def _view(ptr, nbytes, dtype):
+    return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dtype)
+
+
+class RefScene:
+    """The reference's CUDASceneRepHashSDF operators (serial block emulation of its own kernels)."""
+
+    def __init__(self, params):
+        self.params = params
+        self._h = C.c_void_p(lib().ref_scene_create(C.byref(params)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ref_scene_destroy(self._h)
+            self._h = None
+
+    def integrate(self, T, depth, color, cam):
+        d = _f32(depth); c = np.ascontiguousarray(color, np.uint8)
+        lib().ref_scene_integrate(self._h, _fp(_f32(T).reshape(16)), _fp(d), _fp(c), C.byref(cam))
+
+    def deintegrate(self, T, depth, color, cam):
+        d = _f32(depth); c = np.ascontiguousarray(color, np.uint8)
+        lib().ref_scene_deintegrate(self._h, _fp(_f32(T).reshape(16)), _fp(d), _fp(c), C.byref(cam))
+
+    def compactify(self, T, cam):
+        lib().ref_scene_compactify(self._h, _fp(_f32(T).reshape(16)), C.byref(cam))
+
+    def garbage_collect(self):
+        lib().ref_scene_garbage_collect(self._h)
+
+    def hash(self):
+        return _view(lib().ref_scene_hash(self._h), self.params.m_hashNumBuckets * HASH_BUCKET_SIZE * 32, HASH_ENTRY_DTYPE)
+
+    def heap(self):
+        return _view(lib().ref_scene_heap(self._h), self.params.m_numSDFBlocks * 4, "<u4")
+
+    def heap_counter(self):
+        return lib().ref_scene_heap_counter(self._h)
+
+    def voxels(self):
+        return _view(lib().ref_scene_voxels(self._h), self.params.m_numSDFBlocks * VOX_PER_BLOCK * 12, VOXEL_DTYPE)
+
+    def num_occupied(self):
+        return lib().ref_scene_num_occupied(self._h)
+
+    def compactified(self):
+        n = self.num_occupied()
+        return _view(lib().ref_scene_compactified(self._h), n * 32, HASH_ENTRY_DTYPE) if n else np.zeros(0, HASH_ENTRY_DTYPE)
+
+
+def hash_pos(num_buckets, x, y, z):
+    return lib().ref_compute_hash_pos(C.c_uint32(num_buckets), C.c_int(x), C.c_int(y), C.c_int(z))
+
+
+def world_to_block(voxel_size, w):
+    out = (C.c_int * 6)()
+    lib().ref_world_to_block(C.c_float(voxel_size), _fp(_f32(w)), out)
+    return list(out[:3]), list(out[3:])
+
+
+def delinearize(idx):
+    out = (C.c_uint32 * 3)()
+    lib().ref_delinearize_voxel_index(C.c_uint32(idx), out)
+    return tuple(out)
+
+
+def linearize(x, y, z):
+    return lib().ref_linearize_voxel_pos(C.c_int(x), C.c_int(y), C.c_int(z))
+
+
+def mat4_inverse(m):
+    out = np.zeros(16, np.float32)
+    lib().ref_mat4_inverse(_fp(_f32(m).reshape(16)), _fp(out))
+    return out.reshape(4, 4)
+
+
+def exp_rotation(w):
+    R = np.zeros(9, np.float32)
+    lib().ref_exp_rotation(_fp(_f32(w)), _fp(R))
+    return R.reshape(3, 3)
+
+
+def ln_rotation(R):
+    w = np.zeros(3, np.float32)
+    lib().ref_ln_rotation(_fp(_f32(R).reshape(9)), _fp(w))
+    return w
+
+
+def matrix_to_pose(M):
+    r = np.zeros(3, np.float32); t = np.zeros(3, np.float32)
+    lib().ref_matrix_to_pose(_fp(_f32(M).reshape(16)), _fp(r), _fp(t))
+    return r, t
+
+
+def pose_to_matrix(rot, trans):
+    M = np.zeros(16, np.float32)
+    lib().ref_pose_to_matrix(_fp(_f32(rot)), _fp(_f32(trans)), _fp(M))
+    return M.reshape(4, 4)
+
+
+def lie_update(dW, dT, w, t):
+    nw = np.zeros(3, np.float32); nt = np.zeros(3, np.float32)
+    lib().ref_lie_update(_fp(_f32(dW)), _fp(_f32(dT)), _fp(_f32(w)), _fp(_f32(t)), _fp(nw), _fp(nt))
+    return nw, nt
+
+
+def lie_deriv(which, A, D, p):
+    out = np.zeros(18, np.float32)
+    lib().ref_lie_deriv(int(which), _fp(_f32(A).reshape(16)), _fp(_f32(D).reshape(16)), _fp(_f32(p)), _fp(out))
+    return out.reshape(3, 6)
+
+
+def svd3(A):
+    U = np.zeros(9, np.float32); S = np.zeros(9, np.float32); V = np.zeros(9, np.float32)
+    lib().ref_svd3(_fp(_f32(A).reshape(9)), _fp(U), _fp(S), _fp(V))
+    return U.reshape(3, 3), S.reshape(3, 3), V.reshape(3, 3)
+
+
+def eigenvalues3(A):
+    ev = np.zeros(3, np.float32)
+    lib().ref_eigenvalues3(_fp(_f32(A).reshape(9)), _fp(ev))
+    return ev
+
+
+def kabsch(src, tgt):
+    src = _f32(src); tgt = _f32(tgt)
+    T = np.zeros(16, np.float32); ev = np.zeros(3, np.float32)
+    lib().ref_kabsch(_fp(src), _fp(tgt), len(src), _fp(T), _fp(ev))
+    return T.reshape(4, 4), ev
+
+
+def filter_matches(keys, idx, dist, n_raw, Kinv, min_matches=5, max_res2=0.0004):
+    """filterKeyPointMatches: returns (n, idx[:n], dist[:n], T)"""
+    keys = _f32(keys); idx = np.ascontiguousarray(idx, np.uint32).copy(); dist = _f32(dist).copy()
+    T = np.zeros(16, np.float32)
+    n = lib().ref_filter_keypoint_matches(_fp(keys), _fp(idx), _fp(dist), int(n_raw), _fp(_f32(Kinv).reshape(16)), int(min_matches), C.c_float(max_res2), _fp(T))
+    return n, idx[:n], dist[:n], T.reshape(4, 4)

@@ -1,0 +1,233 @@
+"""CPU tests (-m "not gpu"): the oracle PINNED to reference source.
+
+oracle/_ref/libbfref.so is the reference's own device code (LieDerivUtil.h, cuda_svd3.h, cuda_EigenValue.h, cuda_kabsch.h,
+VoxelUtilHashSDF.h, CUDASceneRepHashSDF.cu), compiled for the host from /root/reference by oracle/ref/Makefile (shim headers +
+a serial block emulator; nothing copied).  Every test feeds the same seeded inputs to that library and to the oracle restatement
+(oracle/*.cpp) and demands:
+
+  * bit equality (tol = 0) wherever both sides evaluate +, -, *, /, sqrt only (both are compiled with -ffp-contract=off): the
+    integer maps, the 4x4 inverse, the McAdams SVD, Kabsch, the whole greedy Kabsch match filter, the TSDF integrate /
+    de-integrate voxel bytes, key sets, per-bucket occupancy, free-block count, frustum-list sets;
+  * |diff| <= the stated bound where an elementary function is involved: the reference calls sin/cos/acos/atan2 of the CUDA
+    math library (here: glibc), the oracle and the product use the fixed IEEE sequences of include/bf_detmath.h (~2 ulp).
+
+Order-dependent quantities (which of a bucket's four slots a key sits in, heap pointer values) are NOT parity targets
+(the CUDA reference itself varies from run to run); they are compared through their order-independent content.
+The tests skip (not fail) only when neither /root/reference nor a prebuilt library is present.
+"""
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_hash_params, camera_params, intrinsics_matrix, FREE_ENTRY, VOX_PER_BLOCK
+from tests import ref_api
+
+pytestmark = pytest.mark.skipif(not ref_api.available(), reason="oracle/_ref/libbfref.so is absent and /root/reference is not here to build it")
+
+
+# ------------------------------------------------------------------------------------------------ integer maps
+def test_hash_and_index_maps_exact(oracle):
+    rng = np.random.default_rng(10)
+    for nb in (1, 7, 4096, 800000, 1000003, 2 ** 31 - 1):
+        pts = rng.integers(-(1 << 20), 1 << 20, (300, 3))
+        pts[:6] = [[0, 0, 0], [-1, -1, -1], [1, 0, 0], [-(1 << 20), (1 << 20) - 1, 5], [29, -29, 2], [-8, 8, -16]]
+        for x, y, z in pts:
+            assert oracle.hash_pos(nb, int(x), int(y), int(z)) == ref_api.hash_pos(nb, int(x), int(y), int(z))
+    for vs in (0.004, 0.01, 0.002, 0.05):
+        w = rng.uniform(-6, 6, (400, 3)).astype(np.float32)
+        w[:8] *= 0.001                                   # around the origin: sign(0), negative half voxels, block floor-division
+        w[8:12] = [[0, 0, 0], [-0.0, 0.0, -0.0], [vs / 2, -vs / 2, vs * 7.5], [-vs * 8, vs * 8, -vs * 7.5]]
+        for p in w:
+            assert oracle.world_to_block(vs, p) == ref_api.world_to_block(vs, p)
+    for i in range(512):
+        x, y, z = ref_api.delinearize(i)
+        assert (x, y, z) == (i & 7, (i >> 3) & 7, i >> 6) and ref_api.linearize(x, y, z) == i      # z*64 + y*8 + x, as tsdf.hip / the oracle index voxels
+
+
+def test_mat4_inverse_exact(oracle):
+    from tests.bundle_synth import random_pose
+    rng = np.random.default_rng(11)
+    for k in range(40):
+        M = random_pose(rng, 1.0, 2.0).astype(np.float32)
+        if k % 4 == 0:
+            M = (M @ np.diag([2.0, 0.5, 3.0, 1.0])).astype(np.float32)        # not a rigid motion: the general cofactor inverse
+        assert np.array_equal(oracle.mat4_inverse(M).view(np.uint32), ref_api.mat4_inverse(M).view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ SE(3)
+def test_lie_maps_within_detmath_bound(oracle):
+    from tests.bundle_synth import random_pose
+    rng = np.random.default_rng(12)
+    Ts = np.stack([random_pose(rng, a, 1.5) for a in (1e-5, 1e-3, 0.05, 0.3, 1.0, 2.5, 3.1) for _ in range(6)]).astype(np.float32)
+    rot, trans = oracle.matrices_to_poses(Ts)
+    for i, T in enumerate(Ts):
+        r, t = ref_api.matrix_to_pose(T)
+        # ln_rotation: acos / sqrt; translation: a 3x3 solve with sin/cos coefficients.  bf_detmath vs glibc: <= 2 ulp per call.
+        assert np.abs(rot[i] - r).max() <= 4e-6 * max(1.0, np.abs(r).max()), (i, rot[i], r)
+        assert np.abs(trans[i] - t).max() <= 8e-6 * max(1.0, np.abs(t).max()), (i, trans[i], t)
+    M = oracle.poses_to_matrices(rot, trans)
+    for i in range(len(Ts)):
+        Mr = ref_api.pose_to_matrix(rot[i], trans[i])
+        assert np.abs(M[i] - Mr).max() <= 4e-6 * max(1.0, np.abs(Mr).max())
+        assert np.array_equal(M[i][3], Mr[3])
+    # small-angle branches (theta^2 < 1e-8, < 1e-6) are polynomial on both sides: exact
+    for w in ([1e-6, -2e-6, 3e-6], [0.0, 0.0, 0.0], [3e-5, 1e-5, -2e-5]):
+        m = oracle.poses_to_matrices(np.array([w], np.float32), np.array([[0.1, -0.2, 0.3]], np.float32))[0]
+        assert np.array_equal(m.view(np.uint32), ref_api.pose_to_matrix(w, [0.1, -0.2, 0.3]).view(np.uint32)), w
+
+
+# ------------------------------------------------------------------------------------------------ SVD / Kabsch / greedy filter
+def test_svd3_and_eigenvalues_exact(oracle):
+    rng = np.random.default_rng(13)
+    for k in range(200):
+        A = rng.normal(size=(3, 3)).astype(np.float32)
+        if k % 5 == 0:
+            A[2] = A[0] * np.float32(0.5)              # rank deficient
+        if k % 7 == 0:
+            A = (A * np.float32(1e-3)).astype(np.float32)
+        for a, b in zip(oracle.svd3(A), ref_api.svd3(A)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, a, b)
+
+
+def test_kabsch_exact(oracle):
+    from tests.bundle_synth import random_pose
+    rng = np.random.default_rng(14)
+    for k in range(60):
+        n = int(rng.integers(3, 26))
+        T = random_pose(rng, 0.5, 0.5)
+        src = (rng.uniform(-1, 1, (n, 3)) + [0, 0, 2]).astype(np.float32)
+        tgt = ((T[:3, :3] @ src.T).T + T[:3, 3] + rng.normal(0, 0.003, (n, 3))).astype(np.float32)
+        if k % 6 == 0:
+            src[:, 2] = 2.0                            # coplanar source
+        To, evo = oracle.kabsch(src, tgt)
+        Tr, evr = ref_api.kabsch(src, tgt)
+        assert np.array_equal(To.view(np.uint32), Tr.view(np.uint32)), (k, To, Tr)
+        assert np.array_equal(evo.view(np.uint32), evr.view(np.uint32)), (k, evo, evr)
+
+
+def _keys_from_points(P, K):
+    uv = (K[:3, :3] @ P.T).T
+    return np.c_[uv[:, 0] / uv[:, 2], uv[:, 1] / uv[:, 2], np.full(len(P), 3.0), P[:, 2]].astype(np.float32)
+
+
+def test_greedy_kabsch_filter_exact(oracle):
+    """filterKeyPointMatches (cuda_kabsch.h:422-502) of one image pair: kept index pairs, distances and the transform, bit for bit,
+    on inlier sets with planted outliers, duplicate key points, too few matches and pure garbage."""
+    from tests.bundle_synth import random_pose
+    K = intrinsics_matrix(580.0, 580.0, 320.0, 240.0)
+    Kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    rng = np.random.default_rng(15)
+    kept_total = 0
+    for case in range(40):
+        n = int(rng.integers(3, 60))
+        T = random_pose(rng, 0.15, 0.25)
+        P = np.c_[rng.uniform(-1, 1, n), rng.uniform(-0.8, 0.8, n), rng.uniform(1.2, 3.0, n)]
+        Q = (T[:3, :3] @ P.T).T + T[:3, 3] + rng.normal(0, 0.002, (n, 3))
+        bad = rng.choice(n, size=min(n // 4, case % 7), replace=False)
+        Q[bad] += rng.uniform(-0.4, 0.4, (len(bad), 3))
+        if case % 9 == 8:
+            Q = rng.uniform(-1, 1, (n, 3)) + [0, 0, 2]          # garbage
+        keys = np.concatenate([_keys_from_points(P, K), _keys_from_points(Q, K)])
+        idx = np.zeros((128, 2), np.uint32); idx[:n, 0] = np.arange(n); idx[:n, 1] = n + np.arange(n)
+        if case % 5 == 1 and n > 6:
+            idx[3] = idx[1]; idx[5, 0] = idx[2, 0]              # a repeated match and a shared source key: addMatch must refuse them
+        dist = np.zeros(128, np.float32); dist[:n] = np.sort(rng.uniform(0.05, 0.6, n)).astype(np.float32)
+        no, io, do, To = oracle.filter_matches(keys, idx, dist, n, Kinv)
+        nr, ir, dr, Tr = ref_api.filter_matches(keys, idx, dist, n, Kinv)
+        assert no == nr, (case, no, nr)
+        assert np.array_equal(io, ir) and np.array_equal(do.view(np.uint32), dr.view(np.uint32)), case
+        if no:
+            assert np.array_equal(To.view(np.uint32), Tr.view(np.uint32)), (case, To, Tr)
+        kept_total += no
+    assert kept_total > 150          # the comparison is not vacuous
+
+
+# ------------------------------------------------------------------------------------------------ voxel hash
+def _by_key(hash_np, vox_np):
+    """{(x, y, z): 512 voxel records} of every occupied entry, plus the home-bucket occupancy histogram support"""
+    occ = hash_np[hash_np["ptr"] != FREE_ENTRY]
+    v = vox_np.view(np.uint8).reshape(-1, VOX_PER_BLOCK * 12)
+    return {tuple(int(c) for c in e["pos"]): v[e["ptr"] // VOX_PER_BLOCK] for e in occ}
+
+
+def _assert_same_volume(osc, rsc, nb, what):
+    oh, rh = osc.hash(), rsc.hash()
+    ob, rb = _by_key(oh, osc.voxels()), _by_key(rh, rsc.voxels())
+    assert set(ob) == set(rb), what + ": allocated block keys"
+    assert osc.heap_counter() == rsc.heap_counter(), what + ": free blocks"
+    for k in ob:
+        assert np.array_equal(ob[k], rb[k]), what + ": voxel bytes of block %s" % (k,)
+    # per-bucket occupancy: entries stored inside each bucket's own four slots, and the number that went to its overflow chain
+    for h, name in ((oh, "oracle"), (rh, "reference")):
+        ptr = h["ptr"].reshape(nb, 4)
+        assert (ptr != FREE_ENTRY).sum() == len(ob), name
+    occ_o = (oh["ptr"].reshape(nb, 4) != FREE_ENTRY).sum(axis=1)
+    occ_r = (rh["ptr"].reshape(nb, 4) != FREE_ENTRY).sum(axis=1)
+    # a chained entry occupies a slot of a FOREIGN bucket chosen by arrival order, so bucket fill is compared on home buckets
+    home_o = np.bincount([osc_hash(nb, k) for k in ob], minlength=nb)
+    home_r = np.bincount([osc_hash(nb, k) for k in rb], minlength=nb)
+    assert np.array_equal(home_o, home_r), what + ": home-bucket occupancy"
+    assert occ_o.sum() == occ_r.sum()
+    # every heap slot that is free on one side is free on the other as a SET is not required (pointer values are order
+    # dependent); the free lists must be permutations of the unused block ids on each side
+    for sc in (osc, rsc):
+        free = set(int(x) for x in sc.heap()[: sc.heap_counter() + 1])
+        used = set(int(e["ptr"]) // VOX_PER_BLOCK for e in sc.hash() if e["ptr"] != FREE_ENTRY)
+        assert not (free & used) and len(free) + len(used) == len(sc.heap())
+    # frustum list (compactified hash) as a set of keys
+    co, cr = osc.compactified(), rsc.compactified()
+    assert osc.num_occupied() == rsc.num_occupied(), what + ": numOccupiedBlocks"
+    assert set(map(tuple, co["pos"].tolist())) == set(map(tuple, cr["pos"].tolist())), what + ": frustum list"
+
+
+_hash_fn = None
+
+
+def osc_hash(nb, k):
+    return _hash_fn(nb, k[0], k[1], k[2])
+
+
+@pytest.mark.parametrize("cfg", [dict(W=96, H=72, voxel=0.02, buckets=3001, blocks=6000, scene="wall"),
+                                 dict(W=96, H=72, voxel=0.02, buckets=500, blocks=6000, scene="room"),     # load factor > 1: overflow chains
+                                 dict(W=64, H=48, voxel=0.01, buckets=20011, blocks=12000, scene="room")])
+def test_tsdf_operators_vs_reference_kernels(oracle, cfg):
+    """integrate x3 (moving camera) -> de-integrate the middle frame -> re-integrate it at a perturbed pose -> garbage collection
+    -> de-integrate everything + GC: after every step the oracle volume equals the volume produced by the reference's own
+    allocKernel / compactifyHashAllInOneKernel / integrateDepthMapKernel<deIntegrate> / garbageCollect kernels."""
+    global _hash_fn
+    _hash_fn = oracle.hash_pos
+    W, H = cfg["W"], cfg["H"]
+    if cfg["scene"] == "wall":
+        frames = [synth.scene_wall(W, H)] * 1
+        d, c, T, K = frames[0]
+        frames = []
+        for k in range(3):
+            Tk = T.copy(); Tk[0, 3] += np.float32(0.05 * k); Tk[2, 3] -= np.float32(0.03 * k)
+            frames.append((d, c, Tk, K))
+    else:
+        frames = [synth.scene_room(20 * k, W, H) for k in range(3)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=cfg["buckets"], num_sdf_blocks=cfg["blocks"], voxel_size=cfg["voxel"])
+    osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p)
+    nb = cfg["buckets"]
+    for i, (d, c, T, _) in enumerate(frames):
+        osc.integrate(T, d, c, cam); rsc.integrate(T, d, c, cam)
+        _assert_same_volume(osc, rsc, nb, "integrate %d" % i)
+    assert len(_by_key(osc.hash(), osc.voxels())) > 300
+    d, c, T, _ = frames[1]
+    osc.deintegrate(T, d, c, cam); rsc.deintegrate(T, d, c, cam)
+    _assert_same_volume(osc, rsc, nb, "de-integrate")
+    T2 = T.copy(); T2[:3, 3] += np.float32(0.02)
+    osc.integrate(T2, d, c, cam); rsc.integrate(T2, d, c, cam)
+    _assert_same_volume(osc, rsc, nb, "re-integrate")
+    frames[1] = (d, c, T2, None)
+    osc.garbage_collect(); rsc.garbage_collect()
+    osc.compactify(T2, cam); rsc.compactify(T2, cam)
+    _assert_same_volume(osc, rsc, nb, "garbage collection")
+    for i, (d, c, T, _) in enumerate(frames):
+        osc.deintegrate(T, d, c, cam); rsc.deintegrate(T, d, c, cam)
+        osc.garbage_collect(); rsc.garbage_collect()
+        osc.compactify(T, cam); rsc.compactify(T, cam)
+        _assert_same_volume(osc, rsc, nb, "tear-down %d" % i)
+    assert len(_by_key(osc.hash(), osc.voxels())) == 0 and osc.heap_counter() + 1 == cfg["blocks"]

@@ -9,6 +9,7 @@ NN=${1:-00}; shift || true
 STEPS=${*:-tests bench trace}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r$NN
+SWEEP_ARGS=${SWEEP_ARGS:-}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 db() { ls -S "$1"/*/*_results.db "$1"/*_results.db 2>/dev/null | head -1; }
@@ -41,6 +42,23 @@ for step in $STEPS; do
     sens)
       (cd "$ROOT" && timeout 60 python tools/make_sens.py /tmp/r.sens --frames 200 --jpeg 92 | tail -1 && \
           timeout 60 python tools/run_sens.py /tmp/r.sens --voxel 0.004 --buckets 1000000 --blocks 600000 --tail 5 2>&1 | grep -v amdgpu.ids | tee "$OUT/sens200.txt") ;;
+    sweep)   # the volume operators alone (tools/tsdf_sweep.py): plain run, then PMC passes (each its own run, --kernel-trace only)
+      (cd "$ROOT" && timeout 200 python tools/tsdf_sweep.py $SWEEP_ARGS 2>/dev/null | tee "$OUT/sweep.json" | cut -c1-400)
+      (cd "$ROOT" && timeout 200 python tools/tsdf_sweep.py $SWEEP_ARGS --separate 2>/dev/null | tee "$OUT/sweep_separate.json" | cut -c1-400) ;;
+    sweep_pmc)
+      i=0
+      for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
+               "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU" \
+               "SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INST_LEVEL_VMEM SQ_WAVE_CYCLES TCC_HIT_sum TCC_MISS_sum" \
+               "FETCH_SIZE" "WRITE_SIZE"; do
+        i=$((i+1)); rm -rf /tmp/r_sw
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_sw -o run -- python "$ROOT/tools/tsdf_sweep.py" $SWEEP_ARGS > /dev/null 2>&1)
+        python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_sw)" "${PMC_FILTER:-update}" | grep '^|' > "$OUT/sweep_pmc_pass$i.txt"; tail -3 "$OUT/sweep_pmc_pass$i.txt" | cut -c1-200
+      done ;;
+    sweep_trace)
+      rm -rf /tmp/r_swt
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/r_swt -o run -- python "$ROOT/tools/tsdf_sweep.py" $SWEEP_ARGS > /dev/null 2>&1)
+      python "$ROOT/tools/rocpd_stats.py" "$(db /tmp/r_swt)" "$OUT/sweep_kernel_stats.md" | head -16 ;;
     *) echo "unknown step $step" ;;
   esac
 done

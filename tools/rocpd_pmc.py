@@ -18,7 +18,7 @@ def main():
     if "counters_collection" in tabs:
         q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
              "where kernel_name like ? group by kernel_name, counter_name order by 5 desc")
-        for r in c.execute(q, ("%" + flt + "%",)).fetchall()[:40]:
+        for r in c.execute(q, ("%" + flt + "%",)).fetchall()[:400]:
             print("| `%s` | %s | %d | %.1f | %.1f |" % (r[0][:80], r[1], r[2], r[3], r[4]))
 
 

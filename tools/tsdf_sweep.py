@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""TSDF re-integration sweep (BASELINE.json configs[4] in miniature): F frames of the S2 stream are integrated
+at their ground-truth poses, then every frame is re-integrated (de-integrate at P_k + integrate at P_k * exp(xi_k),
+xi ~ N(0, diag(0.01 rad, 0.01 m)), seed 777) and swept back.  Only the volume runs — no SIFT, no solver — so the numbers are those
+of the voxel-hash operators alone: per-operator wall time, HIP-event time of the voxel-update launches, algorithmic GB/s.
+
+    python tools/tsdf_sweep.py [--frames 24] [--stride 10] [--width 640 --height 480] [--voxel 0.004] [--sweeps 2] [--separate]
+
+Under `torch.distributed.run` the volume is sharded by hash-bucket range over the ranks (bf_scene_set_shard): every rank sees
+every frame and pose, integrates only its shard; value = operators of the ONE volume per second (strong scaling).
+Under `rocprofv3 --pmc ...` the same command gives the per-kernel counters (tools/rocpd_pmc.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def se3_exp(w, t):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=np.float64)
+    if th < 1e-12:
+        R = np.eye(3) + K
+        V = np.eye(3)
+    else:
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = V @ t
+    return M
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--stride", type=int, default=10)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--voxel", type=float, default=0.004)
+    ap.add_argument("--buckets", type=int, default=1000000)
+    ap.add_argument("--blocks", type=int, default=600000)
+    ap.add_argument("--sweeps", type=int, default=2)
+    ap.add_argument("--separate", action="store_true", help="de-integrate + integrate as two operators instead of the fused one")
+    ap.add_argument("--no-overlap", action="store_true", help="do not software-pipeline consecutive operators")
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    from bundlefusion_amd import synth
+    W, H = a.width, a.height
+    frames = synth.render_frames([k * a.stride for k in range(a.frames)], W, H, workers=min(32, os.cpu_count() or 1))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import bundlefusion_amd as bf
+    from bundlefusion_amd.capi import default_hash_params, camera_params
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=a.buckets, num_sdf_blocks=a.blocks, voxel_size=a.voxel)
+    sc = bf.capi.SceneRepHashSDF(p)
+    if world > 1:
+        sc.set_shard(rank, world)
+    if not a.no_overlap:
+        sc.set_overlap(True)
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    poses = [f[2].astype(np.float32) for f in frames]
+    rng = np.random.RandomState(777)
+    pert = []
+    for T in poses:
+        xi = rng.normal(0.0, 0.01, 6)
+        pert.append((T.astype(np.float64) @ se3_exp(xi[:3], xi[3:])).astype(np.float32))
+
+    def sync():
+        sc.hash_params()          # drains both internal streams
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
+    for k in range(a.frames):
+        sc.integrate(poses[k], dev[k][0], dev[k][1], cam)
+    sync()
+    t_int = time.perf_counter() - t0
+
+    sc.kernel_timing(True)
+    t0 = time.perf_counter()
+    cur = list(poses)
+    for s in range(a.sweeps):
+        tgt = pert if s % 2 == 0 else poses
+        for k in range(a.frames):
+            if a.separate:
+                sc.deintegrate(cur[k], dev[k][0], dev[k][1], cam)
+                sc.integrate(tgt[k], dev[k][0], dev[k][1], cam)
+            else:
+                sc.reintegrate(cur[k], tgt[k], dev[k][0], dev[k][1], cam)
+            cur[k] = tgt[k]
+    sync()
+    t_sweep = time.perf_counter() - t0
+    occ_sum, n_ops = sc.kernel_timing_occupied()
+    n_launch, kernel_ms = sc.kernel_timing_read()
+    sc.kernel_timing(False)
+    if world > 1:
+        v = torch.tensor([t_sweep, t_int], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        t_sweep, t_int = float(v[0]), float(v[1])
+    dbg = sc.debug_hash()
+    n_re = a.sweeps * a.frames
+    alg_bytes = occ_sum * (512 * 24 + 32) + n_ops * W * H * 8          # SURVEY.md §8d, per rank (its shard of the lists)
+    if rank == 0:
+        print(json.dumps({
+            "workload": "%d frames %dx%d @%.0f mm, %d re-integration sweeps (%s), %d rank(s)" %
+                        (a.frames, W, H, a.voxel * 1e3, a.sweeps, "separate operators" if a.separate else "fused operator", world),
+            "integrate_us_per_op": 1e6 * t_int / a.frames,
+            "reintegrate_us_per_frame": 1e6 * t_sweep / n_re,
+            "reintegrations_per_s": n_re / t_sweep,
+            "update_kernel_us_per_launch": 1e3 * kernel_ms / max(n_launch, 1),
+            "update_kernel_share_of_wall": (kernel_ms / 1e3) / t_sweep,
+            "n_occ_mean_per_op": occ_sum / max(n_ops, 1),
+            "algorithmic_GBps_of_update_kernel_rank0": alg_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else None,
+            "algorithmic_GBps_wall_rank0": alg_bytes / t_sweep / 1e9,
+            "blocks_allocated_rank0": dbg["occupied"], "dropped": dbg["dropped"],
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
