@@ -95,6 +95,16 @@ void or_resample_float(float* out, unsigned ow, unsigned oh, const float* in, un
         }
 }
 
+// resampleUCHAR4_Kernel, CUDAImageUtil.cu:160-177 (colour to the integration resolution, CUDAImageManager.cpp:72-78)
+void or_resample_uchar4(uint8_t* out, unsigned ow, unsigned oh, const uint8_t* in, unsigned iw, unsigned ih) {
+    for (unsigned y = 0; y < oh; ++y)
+        for (unsigned x = 0; x < ow; ++x) {
+            unsigned xi, yi;
+            resampleIdx(x, y, ow, oh, iw, ih, xi, yi);
+            if (xi < iw && yi < ih) memcpy(out + 4 * ((size_t)y * ow + x), in + 4 * ((size_t)yi * iw + xi), 4);
+        }
+}
+
 float or_intensity(const uint8_t* c) { return (0.299f * (float)c[0] + 0.587f * (float)c[1] + 0.114f * (float)c[2]) / 255.0f; }
 
 void or_resample_to_intensity(float* out, unsigned ow, unsigned oh, const uint8_t* in, unsigned iw, unsigned ih) {

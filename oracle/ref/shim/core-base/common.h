@@ -4,6 +4,9 @@
 #define BF_REF_SHIM_MLIB_COMMON_H
 #include <stdexcept>
 #include <string>
+typedef unsigned char uchar;
+typedef unsigned int UINT;
+typedef unsigned char BYTE;
 #define MLIB_EXCEPTION(s) std::runtime_error(std::string(s))
 #define MLIB_ASSERT(b) do { if (!(b)) throw std::runtime_error("MLIB_ASSERT " #b); } while (0)
 #define MLIB_ASSERT_STR(b, s) do { if (!(b)) throw std::runtime_error(std::string(s)); } while (0)

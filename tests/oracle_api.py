@@ -163,6 +163,35 @@ def gauss_filter_depth(depth, sigma_d, sigma_r):
     return out
 
 
+def gauss_filter_intensity(img, sigma_d):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    out = np.full_like(img, np.nan)
+    h, w = img.shape
+    olib.or_gauss_filter_intensity(_fp(out), _fp(img), C.c_float(sigma_d), w, h)
+    return out
+
+
+def resample_float(img, ow, oh):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    out = np.full((oh, ow), np.nan, np.float32)
+    olib.or_resample_float(_fp(out), ow, oh, _fp(img), img.shape[1], img.shape[0])
+    return out
+
+
+def resample_uchar4(img, ow, oh):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros((oh, ow, 4), np.uint8)
+    olib.or_resample_uchar4(_fp(out), ow, oh, _fp(img), img.shape[1], img.shape[0])
+    return out
+
+
+def resample_to_intensity(img, ow, oh):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.full((oh, ow), np.nan, np.float32)
+    olib.or_resample_to_intensity(_fp(out), ow, oh, _fp(img), img.shape[1], img.shape[0])
+    return out
+
+
 class _CacheFrameHost(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("campos4", C.c_void_p), ("intensity", C.c_void_p), ("derivs2", C.c_void_p),
                 ("normalsU4", C.c_void_p), ("normals4", C.c_void_p)]

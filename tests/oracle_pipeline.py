@@ -466,8 +466,12 @@ class OraclePipeline:
         if g.s_erodeSIFTdepth:
             raw = o.erode_depth(o.erode_depth(raw, 3, 0.05, 0.3), 3, 0.05, 0.3)
         filt = o.gauss_filter_depth(raw, g.s_depthSigmaD, g.s_depthSigmaR) if g.s_depthFilter else raw.copy()
-        assert (self.gas.s_integrationWidth, self.gas.s_integrationHeight) == (self.W, self.H), "oracle pipeline: integration at sensor resolution only"
-        self.frames.append((filt if g.s_erodeSIFTdepth else raw, np.ascontiguousarray(color, np.uint8)))
+        wi, hi = self.gas.s_integrationWidth, self.gas.s_integrationHeight
+        color = np.ascontiguousarray(color, np.uint8)
+        if (wi, hi) == (self.W, self.H):      # CUDAImageManager.cpp:43-50, :122-136
+            self.frames.append((filt if g.s_erodeSIFTdepth else raw, color))
+        else:                                 # resampling branch, :52-61 / :138-149 (the reference default: 640x480 sensor, 320x240 integration)
+            self.frames.append((o.resample_float(filt, wi, hi), o.resample_uchar4(color.reshape(self.H, self.W, 4), wi, hi)))
         return raw, filt
 
     def is_last_local(self, cur):

@@ -181,3 +181,60 @@ def filter_matches(keys, idx, dist, n_raw, Kinv, min_matches=5, max_res2=0.0004)
     T = np.zeros(16, np.float32)
     n = lib().ref_filter_keypoint_matches(_fp(keys), _fp(idx), _fp(dist), int(n_raw), _fp(_f32(Kinv).reshape(16)), int(min_matches), C.c_float(max_res2), _fp(T))
     return n, idx[:n], dist[:n], T.reshape(4, 4)
+
+
+# ---- image kernels (CUDAImageUtil.cu) ----
+def erode_depth(depth, structure_size=3, d_thresh=0.05, frac_req=0.3):
+    depth = _f32(depth); out = np.full_like(depth, np.nan); h, w = depth.shape
+    lib().ref_erode_depth(_fp(out), _fp(depth), structure_size, w, h, C.c_float(d_thresh), C.c_float(frac_req))
+    return out
+
+
+def gauss_filter_depth(depth, sigma_d, sigma_r):
+    depth = _f32(depth); out = np.full_like(depth, np.nan); h, w = depth.shape
+    lib().ref_gauss_filter_depth(_fp(out), _fp(depth), C.c_float(sigma_d), C.c_float(sigma_r), w, h)
+    return out
+
+
+def gauss_filter_intensity(img, sigma_d):
+    img = _f32(img); out = np.full_like(img, np.nan); h, w = img.shape
+    lib().ref_gauss_filter_intensity(_fp(out), _fp(img), C.c_float(sigma_d), w, h)
+    return out
+
+
+def resample_float(img, ow, oh):
+    img = _f32(img); out = np.full((oh, ow), np.nan, np.float32)
+    lib().ref_resample_float(_fp(out), ow, oh, _fp(img), img.shape[1], img.shape[0])
+    return out
+
+
+def resample_uchar4(img, ow, oh):
+    img = np.ascontiguousarray(img, np.uint8); out = np.zeros((oh, ow, 4), np.uint8)
+    lib().ref_resample_uchar4(_fp(out), ow, oh, _fp(img), img.shape[1], img.shape[0])
+    return out
+
+
+def resample_to_intensity(img, ow, oh):
+    img = np.ascontiguousarray(img, np.uint8); out = np.full((oh, ow), np.nan, np.float32)
+    lib().ref_resample_to_intensity(_fp(out), ow, oh, _fp(img), img.shape[1], img.shape[0])
+    return out
+
+
+def ingest(depth, wi, hi, erode=True, depth_filter=True, sigma_d=2.0, sigma_r=0.05):
+    """CUDAImageManager::process, device part -> (raw after erosion, filtered, integration frame)"""
+    raw = _f32(depth).copy(); h, w = raw.shape
+    filt = np.full_like(raw, np.nan); integ = np.full((hi, wi), np.nan, np.float32)
+    lib().ref_ingest(_fp(raw), _fp(filt), _fp(integ), w, h, wi, hi, int(erode), int(depth_filter), C.c_float(sigma_d), C.c_float(sigma_r))
+    return raw, filt, integ
+
+
+def cache_store_frame(depth, color, W, H, input_intrinsics_inv, sigma_intensity=2.5, sigma_d=1.0, sigma_r=0.05):
+    depth = _f32(depth); color = np.ascontiguousarray(color, np.uint8)
+    dh, dw = depth.shape; ch, cw = color.shape[:2]
+    out = dict(depth=np.full((H, W), np.nan, np.float32), campos=np.full((H, W, 4), np.nan, np.float32),
+               intensity=np.full((H, W), np.nan, np.float32), derivs=np.full((H, W, 2), np.nan, np.float32),
+               normals_u=np.zeros((H, W, 4), np.uint8), normals=np.full((H, W, 4), np.nan, np.float32))
+    lib().ref_cache_store_frame(_fp(depth), dw, dh, _fp(color), cw, ch, W, H, _fp(_f32(input_intrinsics_inv).reshape(16)), C.c_float(sigma_intensity),
+                                C.c_float(sigma_d), C.c_float(sigma_r), _fp(out["depth"]), _fp(out["campos"]), _fp(out["intensity"]), _fp(out["derivs"]),
+                                _fp(out["normals_u"]), _fp(out["normals"]))
+    return out

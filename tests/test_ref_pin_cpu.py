@@ -142,6 +142,56 @@ def test_greedy_kabsch_filter_exact(oracle):
     assert kept_total > 150          # the comparison is not vacuous
 
 
+# ------------------------------------------------------------------------------------------------ image kernels
+def _same(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_ingest_and_resample_kernels(oracle):
+    """CUDAImageUtil.cu kernels vs the oracle: erosion, nearest resampling (float / uchar4 / luminance) exact; the two Gaussian
+    filters evaluate exp(): glibc in the reference build, include/bf_detmath.h in the oracle (<= 2 ulp per weight), so their outputs
+    are compared to 3e-6 relative — and the SET of valid pixels exactly."""
+    rng = np.random.default_rng(20)
+    d, c, _, _ = synth.scene_room(30, 160, 120)
+    d = d.copy(); d[40:44, 50:70] = -np.inf; d[rng.random(d.shape) < 0.01] = -np.inf
+    e_o = oracle.erode_depth(oracle.erode_depth(d))
+    e_r = ref_api.erode_depth(ref_api.erode_depth(d))
+    assert _same(e_o, e_r) and np.isfinite(e_o).sum() < np.isfinite(d).sum()
+    g_o, g_r = oracle.gauss_filter_depth(e_o, 2.0, 0.05), ref_api.gauss_filter_depth(e_r, 2.0, 0.05)
+    assert np.array_equal(np.isfinite(g_o), np.isfinite(g_r))
+    v = np.isfinite(g_o)
+    assert np.abs(g_o[v] - g_r[v]).max() <= 3e-6 * np.abs(g_r[v]).max()
+    for (ow, oh) in ((80, 60), (160, 120), (53, 41), (320, 240)):
+        assert _same(oracle.resample_float(g_o, ow, oh), ref_api.resample_float(g_o, ow, oh))
+        assert _same(oracle.resample_uchar4(c, ow, oh), ref_api.resample_uchar4(c, ow, oh))
+        assert _same(oracle.resample_to_intensity(c, ow, oh), ref_api.resample_to_intensity(c, ow, oh))
+    I = oracle.resample_to_intensity(c, 160, 120)
+    io, ir = oracle.gauss_filter_intensity(I, 2.5), ref_api.gauss_filter_intensity(I, 2.5)
+    assert np.abs(io - ir).max() <= 3e-6
+    # CUDAImageManager::process, device part: the reference default configuration (sensor 160x120 -> integration 80x60 here)
+    raw_r, filt_r, integ_r = ref_api.ingest(d, 80, 60)
+    assert _same(raw_r, e_o)
+    assert np.array_equal(np.isfinite(filt_r), v) and np.abs(filt_r[v] - g_o[v]).max() <= 3e-6 * np.abs(g_o[v]).max()
+    assert _same(integ_r, ref_api.resample_float(filt_r, 80, 60))
+
+
+def test_cache_store_frame_vs_reference_kernels(oracle):
+    """CUDACache::storeFrame: the six arrays of one 80x60 cache frame from a 320x240 input."""
+    d, c, _, Kd = synth.scene_room(12, 320, 240)
+    d = d.copy(); d[100:110, 150:180] = -np.inf
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    fo = oracle.cache_store_frame(d, c, 80, 60, K)
+    fr = ref_api.cache_store_frame(d, c, 80, 60, oracle.mat4_inverse(K))
+    for k in ("depth", "campos", "normals", "intensity", "derivs"):
+        fin_o, fin_r = np.isfinite(fo[k]), np.isfinite(fr[k])
+        assert np.array_equal(fin_o, fin_r), k
+        tol = 3e-6 if k in ("depth", "campos", "intensity", "derivs") else 2e-5      # normals: a normalised cross product of differences of filtered positions
+        assert np.abs(fo[k][fin_o] - fr[k][fin_r]).max() <= tol * max(1.0, np.abs(fr[k][fin_r]).max()), k
+        assert fin_o.sum() > 0.5 * fin_o.size
+    assert np.abs(fo["normals_u"].astype(int) - fr["normals_u"].astype(int)).max() <= 1      # bytes of the float normals above
+
+
 # ------------------------------------------------------------------------------------------------ voxel hash
 def _by_key(hash_np, vox_np):
     """{(x, y, z): 512 voxel records} of every occupied entry, plus the home-bucket occupancy histogram support"""
