@@ -12,6 +12,10 @@ local Gauss-Newton/PCG solve (sparse + dense), chunk-to-keyframe fusion, global 
 Nothing is skipped inside the timed region.  Frames are resident in HBM before the timed region starts
 (bf_pipeline_process_frame_device); `--host` hands over host buffers instead (PCIe-inclusive rate).
 
+The timed region is the OPERATING POINT of the loop, not its start-up: `--preroll` frames (default 200) are processed untimed
+first, so that the re-integration queue is saturated (s_maxFrameFixes = 10 re-integrations per frame) and the global problem
+holds >= 20 key frames when the W warm-up and K timed steps run (with the driver's --steps 20 --warmup 5: frames 205..224).
+
 Multi-GPU (N>1, weak scaling): every rank runs the full loop on its own contiguous segment of the stream (frame chunks
 sharded over ranks, each with its own volume); there is no data-path collective — the barrier + max-over-ranks timing
 is the only communication.
@@ -33,6 +37,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--preroll", type=int, default=200, help="untimed frames processed before the warm-up (brings the loop to its operating point)")
+    ap.add_argument("--pmc-out", default=None, help="(profiling runs) write the launch / block accounting of the WHOLE run here, for tools/pmc_to_json.py")
     ap.add_argument("--voxel", type=float, default=0.004)
     ap.add_argument("--buckets", type=int, default=1000000)
     ap.add_argument("--blocks", type=int, default=600000)
@@ -48,7 +54,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     W, H = 640, 480
-    total = args.warmup + args.steps
+    pre = args.preroll + args.warmup
+    total = pre + args.steps
 
     # synthetic stream, rendered by plain-python subprocesses before HIP is initialised
     from bundlefusion_amd import synth                      # (imports torch; no device context yet)
@@ -93,19 +100,23 @@ def main():
         feed = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
     torch.cuda.synchronize()
 
-    for k in range(args.warmup):
+    sc = pipe.scene()
+    if args.pmc_out:
+        sc.kernel_timing(True)                               # profiling run: account every launch of the run (the PMC passes see all of them)
+    for k in range(pre):
         assert pipe.process_frame(*feed[k])
     pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     sc = pipe.scene()
-    sc.kernel_timing(True)                                   # HIP events around every voxel-update launch, on the pipeline's stream
+    if not args.pmc_out:
+        sc.kernel_timing(True)                               # HIP events around every voxel-update launch, on the pipeline's stream
     c0 = pipe.counters()
     pipe.host_profile(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.warmup, total):
+    for k in range(pre, total):
         ok = pipe.process_frame(*feed[k])
         assert ok
     pipe.synchronize()
@@ -116,7 +127,7 @@ def main():
     elapsed = time.perf_counter() - t0
     c1 = pipe.counters()
     hp = pipe.host_profile()
-    occ_sum, n_ops = sc.kernel_timing_occupied()
+    occ_sum, vis_plain, vis_fused, n_ops = sc.kernel_timing_blocks()
     n_launch, kernel_ms = sc.kernel_timing_read()
     sc.kernel_timing(False)
     elapsed = max_over_ranks(elapsed, "cuda")
@@ -124,13 +135,18 @@ def main():
         traj_dev = torch.from_numpy(np.nan_to_num(pipe.integrated_trajectory(), neginf=-1e30)).cuda()
         assert same_over_ranks(traj_dev), "ranks disagree on the trajectory"
 
-    # dominant kernel: the TSDF voxel update.  algorithmic bytes of ONE integrate / de-integrate op = N_occ*(512*24+32) + W*H*8
-    # (SURVEY.md §8d); a fused re-integration launch performs two ops (de-integrate old pose + integrate new pose) in one pass
+    # dominant kernel: the TSDF voxel update.  Algorithmic bytes: one integrate / de-integrate operator moves
+    # N_occ*(512*24+32) + W*H*8 bytes; a FUSED re-integration launch (de-integrate old pose + integrate new pose in one pass) reads and
+    # writes every voxel of the UNION of its two frustum lists once, so it is charged N_union*(512*24+32) + W*H*8, not 2 B.
+    n_fused = n_ops - n_launch                                   # operators = plain + 2 * fused, launches = plain + fused
     n_occ = occ_sum / max(n_ops, 1)
-    bytes_per_launch = (occ_sum * (512 * 24 + 32) + n_ops * W * H * 8) / max(n_launch, 1)
+    bytes_per_launch = ((vis_plain + vis_fused) * (512 * 24 + 32) + n_launch * W * H * 8) / max(n_launch, 1)
     avg_kernel_s = (kernel_ms / 1e3) / max(n_launch, 1)
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-    traffic = pmc_traffic(args, n_ops - n_launch, n_launch)      # ops = plain + 2*fused, launches = plain + fused
+    traffic = pmc_traffic(args, vis_plain, vis_fused, n_launch)
+    if args.pmc_out and rank == 0:
+        json.dump({"config": pmc_config(args), "launches": n_launch, "fused_launches": n_fused, "visited_blocks_plain": vis_plain,
+                   "visited_blocks_fused": vis_fused, "operator_blocks": occ_sum}, open(args.pmc_out, "w"))
     dbg = sc.debug_hash()
     traj = pipe.integrated_trajectory()
     T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
@@ -153,9 +169,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1] stand-in: %d-frame S2 room stream %dx%d @%.0f mm voxels through the full frame loop "
-                            "(ingest, SIFT, match+filters, local+global GN/PCG, TSDF integrate + re-integration + GC); "
-                            "1 step = 1 input frame" % (args.steps, W, H, args.voxel * 1e3),
+                "workload": "BASELINE configs[1] stand-in: S2 room stream %dx%d @%.0f mm voxels through the full frame loop (ingest, SIFT, "
+                            "match+filters, local+global GN/PCG, TSDF integrate + re-integration + GC); 1 step = 1 input frame; timed: frames "
+                            "%d..%d of the stream after an untimed pre-roll of %d + %d warm-up frames (re-integration queue saturated, %d key "
+                            "frames in the global problem)" % (W, H, args.voxel * 1e3, first + pre, first + total - 1, args.preroll, args.warmup, pre // 10),
                 "input": "host buffers per frame (PCIe inclusive)" if args.host else "frames resident in HBM",
                 "params": "zParametersDefault.txt + zParametersBundlingDefault.txt values; s_integrationWidth/Height=640/480, "
                           "s_SDFVoxelSize=%.3f, s_hashNumBuckets=%d, s_hashNumSDFBlocks=%d" % (args.voxel, args.buckets, args.blocks),
@@ -173,8 +190,12 @@ def main():
                 "kernel": "k_update<integrate> + k_reupdate (fused de-integrate+integrate) — TSDF voxel update",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "launches": n_launch, "avg_launch_us": 1e6 * avg_kernel_s,
+                "hbm_frac_measured": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_kernel_s > 0) else None,
+                "launches": n_launch, "fused_launches": n_fused, "avg_launch_us": 1e6 * avg_kernel_s,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": n_occ,
+                "blocks_visited_per_launch": (vis_plain + vis_fused) / max(n_launch, 1),
+                "accounting": "fused launch = union list once: N_union*(512*24+32) + W*H*8 B; traffic = PMC bytes per visited block "
+                              "(profiles/r02_pmc_tsdf_update.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes) x blocks visited here",
                 "share_of_step_time": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None,
             },
         }
@@ -185,19 +206,22 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, n_fused, n_launch):
-    """HBM bytes per voxel-update launch from the committed PMC passes (profiles/r01_pmc_tsdf_update.json: rocprofv3
-    FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, collected in their own runs of this same command), weighted by the
-    launch mix of THIS run; None when the run is not the configuration the counters were collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_tsdf_update.json")
+def pmc_config(args):
+    return {"preroll": args.preroll, "voxel": args.voxel, "buckets": args.buckets, "blocks": args.blocks, "host": bool(args.host)}
+
+
+def pmc_traffic(args, vis_plain, vis_fused, n_launch):
+    """HBM bytes per voxel-update launch of THIS run, from the committed PMC passes (profiles/r02_pmc_tsdf_update.json: rocprofv3
+    FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, each in its own run of this command with --pmc-out): bytes per visited SDF block
+    of the plain and of the fused kernel, times the blocks the timed launches of this run visited.  None when the counters were
+    collected on another configuration (pre-roll / volume parameters)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_tsdf_update.json")
     if not os.path.exists(path) or n_launch == 0:
         return None
     pmc = json.load(open(path))
-    cfg = pmc["config"]
-    if (cfg["steps"], cfg["warmup"], cfg["voxel"], cfg["buckets"], cfg["blocks"]) != (args.steps, args.warmup, args.voxel, args.buckets, args.blocks) or args.host:
+    if pmc["config"] != pmc_config(args):
         return None
-    n_plain = n_launch - n_fused
-    return (n_fused * pmc["k_reupdate"]["hbm_bytes_per_launch"] + n_plain * pmc["k_update_integrate"]["hbm_bytes_per_launch"]) / n_launch
+    return (vis_fused * pmc["k_reupdate"]["hbm_bytes_per_visited_block"] + vis_plain * pmc["k_update"]["hbm_bytes_per_visited_block"]) / n_launch
 
 
 def cpu_baseline(frames, params, K, W, H):

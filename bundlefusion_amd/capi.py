@@ -230,6 +230,12 @@ class SceneRepHashSDF:
         check(lib.bf_scene_kernel_timing_occupied(self._h, C.byref(v), C.byref(n)))
         return v.value, n.value
 
+    def kernel_timing_blocks(self):
+        """(operator blocks [a fused launch counts both lists], blocks visited by plain launches, blocks visited by fused launches [union list], #operators)"""
+        a = C.c_uint64(); b = C.c_uint64(); c = C.c_uint64(); n = C.c_uint32()
+        check(lib.bf_scene_kernel_timing_blocks(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
+
     # ---- test helpers: copy raw arrays back (hipMemcpy through torch) ----
     def download(self):
         """Returns (hash[numBuckets*4], heap[numSDFBlocks], heapCounter, voxels[numSDFBlocks*512]) as numpy."""
@@ -858,6 +864,15 @@ class Pipeline:
         s._h = h; s._borrowed = True
         hp = HashParams(); check(lib.bf_scene_get_hash_params(h, C.byref(hp))); s.params = hp
         return s
+
+    def integrate_frame_cpu(self, frame):
+        """Host copies (depth float32 (h,w), colour uint8 (h,w,4)) of the frame stored for integration — getIntegrateFrame(i).getDepthFrameCPU() / getColorFrameCPU()."""
+        im = C.c_void_p(); w = C.c_uint32(); h = C.c_uint32()
+        check(lib.bf_pipeline_get_image_manager(self._h, C.byref(im)))
+        check(lib.bf_image_manager_get_integration_size(im, C.byref(w), C.byref(h)))
+        d = np.zeros((h.value, w.value), np.float32); c = np.zeros((h.value, w.value, 4), np.uint8)
+        check(lib.bf_image_manager_get_integrate_frame_cpu(im, frame, d.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p)))
+        return d, c
 
     def bundler(self, which):
         ob = C.c_void_p(); b = C.c_void_p()

@@ -504,7 +504,9 @@ int sbaAlign(bf_bundler* b, uint32_t maxNumIters, uint32_t numPCGits, bool useVe
         }
     }
     if (useVerify) {
-        if (wS->front() > 0 && numCorr > 0) { int v = 0; BF_TRY(bf_solver_use_verification(b->solver, d_corr, numCorr, &v)); b->sbaVerify = v != 0; }
+        // SBA.cpp:106-109.  Without correspondences CUDASolverBundling::useVerification (:454-476) evaluates 0 / 0 >= thresh, which
+        // is false: no trajectory verification is requested then.
+        if (wS->front() > 0) { int v = 0; if (numCorr > 0) BF_TRY(bf_solver_use_verification(b->solver, d_corr, numCorr, &v)); b->sbaVerify = v != 0; }
         else b->sbaVerify = true;
     }
     BF_TRY(bf_convert_poses_to_matrices(b->d_xRot, b->d_xTrans, numImages, (float*)b->d_trajectory, d_valid, b->stream));
@@ -836,6 +838,12 @@ int bf_trajectory_manager_get_top_from_reintegrate_list(bf_trajectory_manager* t
         *frameIdx = f->frameIdx;
         tm->toReIntegrate.pop_front();
         if (nT.e[0] != NINF) { f->integratedTransform = nT; break; }
+        // Invalidated while queued.  The reference leaves the frame typed ReIntegration here and promises that it "will be added
+        // to the deintegrate list next time" (:133), but invalidateFrame (:191-199) queues a de-integration only for frames typed
+        // Integrated, so the geometry at the old pose would stay in the volume for good (and be integrated a second time when
+        // the frame becomes valid again).  The frame IS still integrated at its old pose: say so, and the next list update
+        // de-integrates it exactly once.  (Deviation from the reference, DESIGN.md "Deviations".)
+        f->type = BF_TF_INTEGRATED;
     }
     *found = 1;
     return BF_OK;
@@ -1485,7 +1493,7 @@ int plReintegrate(bf_pipeline* p) {                                             
         if (found) { BF_TRY(plIntegrate(p, frameIdx, newT, false)); BF_TRY(bf_trajectory_manager_confirm_integration(tm, frameIdx)); continue; }
         BF_TRY(bf_trajectory_manager_get_top_from_reintegrate_list(tm, oldT, newT, &frameIdx, &found));
         if (found) {
-            if (newT[0] == NINF) continue;          // every candidate was invalidated meanwhile; it is de-integrated on the next list update
+            if (newT[0] == NINF) continue;          // every candidate was invalidated meanwhile: no volume operation now; get_top re-typed them Integrated, so the next list update de-integrates them at their old poses
             if (p->gas.s_integrationEnabled) {          // deIntegrate(old) + integrate(new) (:885-886) as one fused pass over the volume
                 BF_TRY(volPost(p, 2, frameIdx, oldT, newT, -1));
                 p->numDeIntegrate++; p->numIntegrate++;

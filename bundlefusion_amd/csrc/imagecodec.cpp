@@ -209,6 +209,7 @@ int decodeJpeg(const uint8_t* data, size_t size, uint32_t width, uint32_t height
                 h.build(); h.present = true;
             }
         } else if (m == 0xC0 || m == 0xC1) {                                     // SOF0 / SOF1
+            if (seg + 6 > segEnd) { set_error("jpeg: short SOF segment"); return BF_ERR_INVALID_ARG; }      // precision, height, width, #components
             if (data[seg] != 8) { set_error("jpeg: only 8-bit samples are supported"); return BF_ERR_INVALID_ARG; }
             H = u16(seg + 1); W = u16(seg + 3);
             const int nc = data[seg + 5];
@@ -225,12 +226,15 @@ int decodeJpeg(const uint8_t* data, size_t size, uint32_t width, uint32_t height
             set_error("jpeg: progressive / lossless / arithmetic-coded files are not supported (SOF%d)", m - 0xC0);
             return BF_ERR_INVALID_ARG;
         } else if (m == 0xDD) {
+            if (seg + 2 > segEnd) { set_error("jpeg: short DRI segment"); return BF_ERR_INVALID_ARG; }
             restart = u16(seg);
         } else if (m == 0xDA) {                                                 // SOS: the (single) scan follows
             if (!sawSOF) { set_error("jpeg: SOS before SOF"); return BF_ERR_INVALID_ARG; }
             if ((uint32_t)W != width || (uint32_t)H != height) { set_error("jpeg: image is %dx%d, expected %ux%u", W, H, width, height); return BF_ERR_INVALID_ARG; }
+            if (seg + 1 > segEnd) { set_error("jpeg: short SOS segment"); return BF_ERR_INVALID_ARG; }
             const int ns = data[seg];
             if (ns != (int)comps.size()) { set_error("jpeg: non-interleaved scans are not supported"); return BF_ERR_INVALID_ARG; }
+            if (seg + 1 + 2 * (size_t)ns + 3 > segEnd) { set_error("jpeg: short SOS segment"); return BF_ERR_INVALID_ARG; }      // component selectors + Ss, Se, Ah/Al
             for (int i = 0; i < ns; ++i) {
                 const int cid = data[seg + 1 + 2 * i], t = data[seg + 2 + 2 * i];
                 bool found = false;

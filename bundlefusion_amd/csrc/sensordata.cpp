@@ -9,8 +9,10 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <new>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -74,7 +76,9 @@ int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
     BF_REQUIRE(filename && out, "null argument");
     FILE* f = fopen(filename, "rb");
     if (!f) { set_error("could not open file %s", filename); return BF_ERR_INVALID_ARG; }          // "could not open file" (SensorData::loadFromFile)
-    bf_sensor_data* sd = new bf_sensor_data;
+    struct Closer { void operator()(bf_sensor_data* p) const { bf_sensor_data_close(p); } };
+    std::unique_ptr<bf_sensor_data, Closer> guard(new bf_sensor_data);          // an exception below (bad_alloc) must not leak sd / its FILE*
+    bf_sensor_data* sd = guard.get();
     sd->f = f;
     bf_sensor_data_info& h = sd->info;
     memset(&h, 0, sizeof h);
@@ -82,7 +86,6 @@ int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
     bool ok = rd(f, &h.versionNumber);
     if (ok && h.versionNumber != SENS_VERSION) {
         set_error("sens: version %u, expected %u", h.versionNumber, SENS_VERSION);                   // "Invalid file format" / version mismatch
-        bf_sensor_data_close(sd);
         return BF_ERR_INVALID_ARG;
     }
     uint64_t strLen = 0;
@@ -95,11 +98,13 @@ int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
     ok = ok && rd(f, h.colorIntrinsic, 16) && rd(f, h.colorExtrinsic, 16) && rd(f, h.depthIntrinsic, 16) && rd(f, h.depthExtrinsic, 16) &&
          rd(f, &h.colorCompressionType) && rd(f, &h.depthCompressionType) && rd(f, &h.colorWidth) && rd(f, &h.colorHeight) &&
          rd(f, &h.depthWidth) && rd(f, &h.depthHeight) && rd(f, &h.depthShift) && rd(f, &h.numFrames);
-    if (!ok || h.numFrames > (uint64_t)total) { set_error("sens: truncated or invalid header in %s", filename); bf_sensor_data_close(sd); return BF_ERR_INVALID_ARG; }
+    // a frame record is at least 64 + 4 * 8 = 96 bytes (pose, two time stamps, two sizes): bound numFrames by what the rest of the
+    // file can hold before frames.resize() (112 B of bookkeeping per frame) — a small forged header cannot ask for 100x the file size
+    const int64_t afterHeader = ftello(f);
+    if (!ok || afterHeader < 0 || h.numFrames > (uint64_t)(total - afterHeader) / 96u) { set_error("sens: truncated or invalid header in %s", filename); return BF_ERR_INVALID_ARG; }
     const uint32_t MAXDIM = 1u << 15;                                      // image buffers are sized from these fields
     if (h.depthWidth > MAXDIM || h.depthHeight > MAXDIM || h.colorWidth > MAXDIM || h.colorHeight > MAXDIM || !(h.depthShift > 0.0f) || !std::isfinite(h.depthShift)) {
         set_error("sens: implausible header in %s (depth %ux%u, colour %ux%u, depthShift %g)", filename, h.depthWidth, h.depthHeight, h.colorWidth, h.colorHeight, (double)h.depthShift);
-        bf_sensor_data_close(sd);
         return BF_ERR_INVALID_ARG;
     }
     sd->frames.resize(h.numFrames);
@@ -112,11 +117,14 @@ int bf_sensor_data_open(const char* filename, bf_sensor_data** out) {
             ok = fr.colorSize <= (uint64_t)total && fr.depthSize <= (uint64_t)total && fr.depthOffset + (int64_t)fr.depthSize <= total &&
                  fseeko(f, fr.depthOffset + (int64_t)fr.depthSize, SEEK_SET) == 0;
         }
-        if (!ok) { set_error("sens: truncated at frame %llu of %llu in %s", (unsigned long long)i, (unsigned long long)h.numFrames, filename); bf_sensor_data_close(sd); return BF_ERR_INVALID_ARG; }
+        if (!ok) { set_error("sens: truncated at frame %llu of %llu in %s", (unsigned long long)i, (unsigned long long)h.numFrames, filename); return BF_ERR_INVALID_ARG; }
     }
     uint64_t numIMU = 0;
-    if (rd(f, &numIMU) && ftello(f) + (int64_t)(numIMU * IMU_FRAME_BYTES) <= total) h.numIMUFrames = numIMU;     // the IMU block is optional
-    *out = sd;
+    if (rd(f, &numIMU)) {                                                   // the IMU block is optional; no multiplication that could wrap
+        const int64_t pos = ftello(f);
+        if (pos >= 0 && pos <= total && numIMU <= (uint64_t)(total - pos) / IMU_FRAME_BYTES) h.numIMUFrames = numIMU;
+    }
+    *out = guard.release();
     return BF_OK;
     });
 }

@@ -42,8 +42,8 @@ constexpr int KEYLIM = 1 << 20;
 struct AllocRec { uint64_t key; int32_t ptr; uint32_t pad; };          // 16 B
 struct BinRec { uint64_t key; uint32_t bucket; uint32_t aux; };        // 16 B
 
-enum Stat { ST_DROPPED = 0, ST_ERROR = 1, ST_COUNT = 4 };
-enum ErrBits { ERR_BIN_OVERFLOW = 1, ERR_DEDUPE_FULL = 2, ERR_OV_OVERFLOW = 4, ERR_GC_MISSING = 8 };
+enum Stat { ST_DROPPED = 0, ST_ERROR = 1, ST_STUCK = 2, ST_COUNT = 4 };      // ST_STUCK: de-dup slots of keys that found their bin full (released by k_alloc_finish)
+enum ErrBits { ERR_BIN_OVERFLOW = 1, ERR_DEDUPE_FULL = 2, ERR_OV_OVERFLOW = 4, ERR_GC_MISSING = 8, ERR_LIST_FULL = 16 };
 
 struct Dev {
     bf_hash_entry* hash;
@@ -62,9 +62,10 @@ struct Dev {
     uint32_t* binCount;
     BinRec* overflow;
     uint32_t* overflowCount;
+    uint32_t* stuckSlots;
     uint32_t* tileCounts;
     uint32_t* stats;
-    unsigned long long* occSum;      // sum of frustum-list lengths over the timed voxel-update launches
+    unsigned long long* occSum;      // [0] sum of frustum-list lengths per OPERATOR (a fused launch counts its two lists), [1] / [2] sum of list lengths per LAUNCH of the plain / the fused kernel (the union list once) over the timed voxel-update launches
 };
 
 struct Frame {          // per-call constants (kernarg => scalar loads)
@@ -207,8 +208,11 @@ BF_DEV void emitCandidate(const Dev& d, const Frame& f, i3 b) {
                 BinRec r; r.key = key; r.bucket = h; r.aux = slot;
                 d.bins[(size_t)bin * BINCAP + pos] = r;
             } else {
+                // The slot stays claimed while other lanes are still probing (releasing it here would cut their linear-probe chains
+                // and let a key be claimed twice => two heap blocks for one key); k_alloc_finish releases the recorded slots.
                 atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW);
-                d.dedupe[slot] = EMPTY64;
+                const uint32_t q = atomicAdd(&d.stats[ST_STUCK], 1u);
+                if (q < OVCAP) d.stuckSlots[q] = slot;
             }
             return;
         }
@@ -367,8 +371,10 @@ __global__ __launch_bounds__(256) void k_alloc_insert(Dev d, Frame f) {
     loadBinSorted(s, d.bins + (size_t)bin * BINCAP, n);
     const uint32_t base = binPrefix(d.binCount, bin, scratch);
     const uint32_t heapC = d.heapCounter[0];
-    const uint32_t heapFree = heapC + 1u;
     const uint32_t allocBase = d.allocCount[0];
+    // blocks this pass may hand out: the free heap blocks, but never more than the allocated-block list can still record (holes left by
+    // exhausted collision windows are compacted only by GC, so live + holes can reach the list capacity before the heap is empty)
+    const uint32_t heapFree = min(heapC + 1u, f.numSDFBlocks - min(allocBase, f.numSDFBlocks));
     uint4* h4 = reinterpret_cast<uint4*>(d.hash);
     // phase 1 (reads only): rank among the bin's new keys of the same home bucket -> free slot
     for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
@@ -423,9 +429,11 @@ __global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
     if (nov > 0) loadBinSorted(s, d.overflow, nov);
     if (threadIdx.x == 0) {
         const uint32_t heapC = d.heapCounter[0];
-        const uint32_t heapFree = heapC + 1u;
-        const uint32_t Mp = min(M, heapFree);
         const uint32_t allocBase = d.allocCount[0];
+        const uint32_t listRoom = f.numSDFBlocks - min(allocBase, f.numSDFBlocks);
+        const uint32_t heapFree = min(heapC + 1u, listRoom);          // the same limit k_alloc_insert applied
+        if (M > listRoom && listRoom < heapC + 1u) atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_LIST_FULL);
+        const uint32_t Mp = min(M, heapFree);
         const uint32_t total = BF_HASH_BUCKET_SIZE * f.numBuckets;
         uint32_t newCounter = heapC - Mp;
         uint32_t dropped = 0;
@@ -465,6 +473,12 @@ __global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
         d.overflowCount[0] = 0;
     }
     __syncthreads();
+    {   // keys that found their bin full: release their de-dup slots now that nobody probes any more
+        const uint32_t stuck = min(d.stats[ST_STUCK], OVCAP);
+        for (uint32_t q = threadIdx.x; q < stuck; q += blockDim.x) d.dedupe[d.stuckSlots[q]] = EMPTY64;
+        __syncthreads();
+        if (threadIdx.x == 0) d.stats[ST_STUCK] = 0;
+    }
     for (uint32_t b = threadIdx.x; b < NBINS; b += blockDim.x) d.binCount[b] = 0;
 }
 
@@ -639,7 +653,7 @@ __global__ __launch_bounds__(512) void k_update(Dev d, Frame f, const float* __r
                                                 const uchar4* __restrict__ color, int accumulate) {
     if (color == nullptr) return;   // .cu:441-448: without colour data `color.x != MINF` never holds
     const uint32_t n = (uint32_t)d.compactCount[0];
-    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) d.occSum[0] += (unsigned long long)n;
+    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
     const uint32_t i = threadIdx.x;
     const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
@@ -667,6 +681,7 @@ __global__ __launch_bounds__(512) void k_reupdate(Dev d, Frame f, Frame fo, cons
                                                   const uchar4* __restrict__ color, int accumulate) {
     if (color == nullptr) return;
     const uint32_t n = (uint32_t)d.compactCount[0];
+    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) d.occSum[2] += (unsigned long long)n;      // length of the union list: the blocks this launch visits once
     const uint32_t i = threadIdx.x;
     const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
@@ -1011,7 +1026,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     A(s->cbuf[0], N); A(s->cbuf[1], N);
     A(s->csrc[0], N); A(s->csrc[1], N);
     A(s->ccnt[0], 1); A(s->ccnt[1], 1);
-    A(s->d.occSum, 1);
+    A(s->d.occSum, 3);
     A(s->d.allocList, N);
     A(s->d.allocListAlt, N);
     A(s->d.allocCount, 1);
@@ -1020,6 +1035,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     A(s->d.binCount, NBINS);
     A(s->d.overflow, OVCAP);
     A(s->d.overflowCount, 1);
+    A(s->d.stuckSlots, OVCAP);
     A(s->d.tileCounts, N / TILE + 4);
     A(s->d.stats, ST_COUNT);
     A(s->d_hashDecision, 4);
@@ -1274,7 +1290,7 @@ int bf_scene_kernel_timing(bf_scene* s, int enable) {
     s->timing = enable != 0;
     s->eventsUsed = 0;
     s->opsTimed = 0;
-    BF_HIP_TRY(hipMemsetAsync(s->d.occSum, 0, sizeof(unsigned long long), s->stream));
+    BF_HIP_TRY(hipMemsetAsync(s->d.occSum, 0, 3 * sizeof(unsigned long long), s->stream));
     return BF_OK;
 }
 
@@ -1294,12 +1310,18 @@ int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms) {
 }
 
 int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks, uint32_t* numOps) {
-    BF_REQUIRE(s && sumOccupiedBlocks, "null argument");
+    return bf_scene_kernel_timing_blocks(s, sumOccupiedBlocks, nullptr, nullptr, numOps);
+}
+
+int bf_scene_kernel_timing_blocks(bf_scene* s, uint64_t* sumOperatorBlocks, uint64_t* visitedPlain, uint64_t* visitedFused, uint32_t* numOps) {
+    BF_REQUIRE(s, "null argument");
     if (numOps) *numOps = s->opsTimed;
-    unsigned long long v = 0;
-    BF_HIP_TRY(hipMemcpyAsync(&v, s->d.occSum, sizeof v, hipMemcpyDeviceToHost, s->stream));
+    unsigned long long v[3] = {0, 0, 0};
+    BF_HIP_TRY(hipMemcpyAsync(v, s->d.occSum, sizeof v, hipMemcpyDeviceToHost, s->stream));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
-    *sumOccupiedBlocks = v;
+    if (sumOperatorBlocks) *sumOperatorBlocks = v[0];
+    if (visitedPlain) *visitedPlain = v[1];
+    if (visitedFused) *visitedFused = v[2];
     return BF_OK;
 }
 

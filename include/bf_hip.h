@@ -189,6 +189,10 @@ BF_API int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* tota
  * (m_numOccupiedBlocks) of the integrate / de-integrate operations they performed, and the number of those operations
  * (a fused re-integration launch performs two).                                                                     */
 BF_API int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks, uint32_t* numOps);
+/* the same plus the sum of the list lengths per LAUNCH, separately for the plain (integrate / de-integrate) and the fused
+ * re-integration kernel: a fused launch visits the union of its two frustum lists once (each voxel read and written once), so its
+ * algorithmic traffic is unionBlocks * (512*24 + 32) B, not 2 B                                                              */
+BF_API int bf_scene_kernel_timing_blocks(bf_scene* s, uint64_t* sumOperatorBlocks, uint64_t* visitedPlain, uint64_t* visitedFused, uint32_t* numOps);
 
 
 /* ------------------------------------------------------------------------- */

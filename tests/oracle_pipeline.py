@@ -238,7 +238,8 @@ class OBundler:
                 removed = True
         verify = False
         if use_verify:
-            verify = o.solver_use_verification(self.corr, rot, trans, N) if (ws[0] > 0 and len(self.corr)) else True
+            # SBA.cpp:106-109; with no correspondences useVerification's 0 / 0 >= thresh is false (CUDASolverBundling.cpp:474)
+            verify = (bool(len(self.corr)) and o.solver_use_verification(self.corr, rot, trans, N)) if ws[0] > 0 else True
         T = o.poses_to_matrices(rot, trans, valid)
         for i in range(N):
             if valid[i]:
@@ -443,6 +444,7 @@ class OraclePipeline:
         self.num_global_nl = gbs.s_numGlobalNonLinIterations
         self.frames = []                      # (depth, color) at integration resolution
         self.integrate_ops = []               # log of (kind, frame, T)
+        self.replay_log = []                  # the same with the garbage collections in between: ("in" | "de" | "gc", frame, T)
         hp = HashParams()
         eye = np.eye(4, dtype=np.float32).reshape(16)
         for i in range(16):
@@ -665,6 +667,7 @@ class OraclePipeline:
     # ---- integrate / reintegrate
     def _integrate(self, frame, T, de):
         self.integrate_ops.append(("de" if de else "in", frame, np.array(T, np.float32)))
+        self.replay_log.append(self.integrate_ops[-1])
         d, c = self.frames[frame]
         (self.scene.deintegrate if de else self.scene.integrate)(T, d, c, self.cam, threads=self.threads)
 
@@ -691,6 +694,7 @@ class OraclePipeline:
                     if new[0, 0] != NINF:
                         f["integrated"] = new
                         break
+                    f["type"] = 0      # invalidated while queued: still integrated at its old pose -> de-integrated by the next list update (see host.hip, deviation)
                 if new[0, 0] == NINF:
                     continue
                 self._integrate(f["idx"], old, True)
@@ -700,6 +704,7 @@ class OraclePipeline:
             break
         if self.gas.s_garbageCollectionEnabled:
             self.scene.garbage_collect()
+            self.replay_log.append(("gc", -1, None))
 
     def process_frame(self, depth, color):
         raw, filt = self._ingest(depth, color)

@@ -1,0 +1,165 @@
+"""GPU parity tests (-m gpu) at the BASELINE configuration: 640x480 frames, 4 mm voxels, 1 000 000 hash buckets — the
+configuration bench.py measures (BASELINE.json configs[1] / configs[2]) instead of the 20 mm volumes of test_pipeline_gpu.py.
+
+  * three chunks with re-integration through bf_pipeline_* vs the oracle frame loop (operation counts exact, trajectories 5e-4);
+  * REPLAY: the oracle's recorded (operator, frame, pose) log fed into bf_scene_integrate / _deintegrate / _reintegrate /
+    _garbage_collect on the oracle's ingested frames must reproduce the oracle volume BIT FOR BIT (hash table, heap, voxel bytes):
+    this isolates the volume operators from the solver's float tolerance (north_star: "bit-exact hash-bucket occupancy and voxel
+    indices");
+  * the integration-resolution resampling branch of the ingest (sensor 640x480 -> integration 320x240, the reference's default
+    zParametersDefault.txt; CUDAImageManager.cpp:52-61,138-149);
+  * a 200-frame run (configs[1]) against the oracle frame loop.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, sensor_desc, camera_params, default_hash_params
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+
+
+def _params(voxel=0.004, buckets=1000000, blocks=250000, max_images=8, wi=W, hi=H):
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = wi, hi
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = voxel, buckets, blocks
+    gbs.s_maxNumImages = max_images
+    return gas, gbs
+
+
+def _run_both(gpu, frames, K, tail, **kw):
+    import torch
+    from tests.oracle_pipeline import OraclePipeline
+    gp = gpu.capi.Pipeline(*_params(**kw), sensor_desc(W, H, K))
+    op = OraclePipeline(*_params(**kw), W, H, K)
+    for d, c, _, _ in frames:
+        assert gp.process_frame(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda())
+        op.process_frame(d, c)
+    for _ in range(tail):
+        gp.process_end_of_sequence(); op.process_end_of_sequence()
+    gp.synchronize()
+    return gp, op
+
+
+def _counts(op):
+    return (sum(1 for k, _, _ in op.integrate_ops if k == "in"), sum(1 for k, _, _ in op.integrate_ops if k == "de"))
+
+
+def _replay(gpu, op, fused):
+    """Feed the oracle's operator log into a fresh GPU volume; returns the GPU scene."""
+    import torch
+    p = op.scene.params
+    gs = gpu.capi.SceneRepHashSDF(p)
+    gs.set_overlap(True)                              # the frame loop's configuration: operators software-pipelined on two streams
+    dev = {}
+
+    def frame(i):
+        if i not in dev:
+            d, c = op.frames[i]
+            dev[i] = (torch.from_numpy(np.ascontiguousarray(d)).cuda(), torch.from_numpy(np.ascontiguousarray(c)).cuda())
+        return dev[i]
+
+    log = op.replay_log
+    k = 0
+    while k < len(log):
+        kind, i, T = log[k]
+        if kind == "gc":
+            gs.garbage_collect(); k += 1; continue
+        d, c = frame(i)
+        if fused and kind == "de" and k + 1 < len(log) and log[k + 1][0] == "in" and log[k + 1][1] == i:
+            gs.reintegrate(T, log[k + 1][2], d, c, op.cam); k += 2; continue
+        (gs.deintegrate if kind == "de" else gs.integrate)(T, d, c, op.cam)
+        k += 1
+    return gs
+
+
+def _assert_volume_bit_equal(gs, osc, what):
+    gh, gheap, gcnt, gvox = gs.download()
+    oh = osc.hash()
+    assert gcnt == osc.heap_counter(), what + ": heap counter"
+    for f in ("pos", "ptr", "offset"):
+        assert np.array_equal(gh[f], oh[f]), what + ": hash." + f
+    assert np.array_equal(gheap, osc.heap()), what + ": heap"
+    assert np.array_equal(gvox.view(np.uint8), osc.voxels().view(np.uint8)), what + ": voxel bytes"
+    dbg = gs.debug_hash()
+    assert dbg["duplicate_keys"] == 0 and dbg["free_and_allocated"] == 0 and dbg["leaked"] == 0 and dbg["dropped"] == osc.num_dropped()
+
+
+def test_three_chunks_4mm_and_oracle_log_replay(gpu, oracle):
+    n = 33
+    frames = synth.render_frames(range(n))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gp, op = _run_both(gpu, frames, K, tail=4)
+    c = gp.counters()
+    o_in, o_de = _counts(op)
+    assert (c["integrate"], c["deintegrate"]) == (o_in, o_de) and o_de > 20
+    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves == 4 and c["global_solves"] == op.glob.num_solves >= 3
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert len(gt) == len(ot) == n and np.isfinite(gt[:, 0, 0]).all() and np.isfinite(ot[:, 0, 0]).all()
+    assert np.abs(gt - ot).max() < 5e-4
+    gopt = gp.optimized_trajectory()
+    assert np.abs(gopt - np.stack([op.tm.opt[i] for i in range(len(gopt))])).max() < 5e-4
+    # the pipeline's own volume: same blocks up to boundary effects of the <= 5e-4 pose differences
+    sc = gp.scene()
+    gh = sc.download()[0]
+    dbg = sc.debug_hash()
+    assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0 and dbg["dropped"] == 0
+    gkeys = {tuple(int(v) for v in e) for e in gh["pos"][gh["ptr"] != -2]}
+    oh = op.scene.hash()
+    okeys = {tuple(int(v) for v in e) for e in oh["pos"][oh["ptr"] != -2]}
+    assert len(okeys) > 60000 and len(gkeys & okeys) / len(gkeys | okeys) > 0.985
+    del gp
+    # replay of the oracle's operator log: bit equality, with the fused re-integration operator and with separate operators
+    for fused in (True, False):
+        gs = _replay(gpu, op, fused)
+        _assert_volume_bit_equal(gs, op.scene, "replay (fused=%s)" % fused)
+        del gs
+
+
+def test_resample_branch_sensor_640_integration_320(gpu, oracle):
+    """The reference default: integration at 320x240 from a 640x480 sensor (resampleFloat / resampleUCHAR4).  One chunk, so that
+    every pose is a SIFT pose: trajectory and volume bit-exact; the frames stored for integration bit-exact."""
+    import torch
+    frames = synth.render_frames(range(0, 18, 2))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    kw = dict(voxel=0.01, buckets=400000, blocks=100000, wi=320, hi=240)
+    gp, op = _run_both(gpu, frames, K, tail=0, **kw)
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert len(gt) == len(frames) and np.isfinite(gt[:, 0, 0]).all()
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    for i in (0, 3, len(frames) - 1):
+        gd, gc = gp.integrate_frame_cpu(i)
+        assert gd.shape == (240, 320) and np.array_equal(gd.view(np.uint32), op.frames[i][0].view(np.uint32))
+        assert np.array_equal(gc, op.frames[i][1])
+    _assert_volume_bit_equal(gp.scene(), op.scene, "resample branch")
+    assert gp.scene().num_allocated_blocks() > 3000
+
+
+@pytest.mark.skipif(os.environ.get("BF_SKIP_LONG") == "1", reason="BF_SKIP_LONG=1")
+def test_config1_200_frames_vs_oracle_loop(gpu, oracle):
+    """BASELINE configs[1]: 200 frames of the stream at 4 mm through the whole loop (20 local chunks, 19 global solves,
+    ~10 re-integrations per frame) against the oracle frame loop."""
+    n = 200
+    frames = synth.render_frames(range(n))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gp, op = _run_both(gpu, frames, K, tail=0, blocks=400000, max_images=28)
+    c = gp.counters()
+    assert (c["integrate"], c["deintegrate"]) == _counts(op)
+    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves and c["global_solves"] == op.glob.num_solves >= 18
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).all()
+    assert np.abs(gt - ot).max() < 5e-4
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    ref = np.stack([T0inv @ f[2].astype(np.float64) for f in frames])
+    ate = np.sqrt(np.mean(np.sum((gt[:, :3, 3] - ref[:, :3, 3]) ** 2, axis=1)))
+    ate_o = np.sqrt(np.mean(np.sum((ot[:, :3, 3] - ref[:, :3, 3]) ** 2, axis=1)))
+    assert abs(ate - ate_o) < 1e-3          # north_star: ATE within 1 mm of the reference
+    dbg = gp.scene().debug_hash()
+    assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["dropped"] == 0

@@ -111,6 +111,7 @@ def test_trajectory_manager_matches_restatement():
                         if new[0, 0] != NINF:
                             g["integrated"] = new
                             break
+                        g["type"] = 0      # invalidated while queued: re-typed Integrated, de-integrated by the next list update
                     assert g is not None and idx == g["idx"] and _same(oldT, old) and _same(newT, new)
                     if newT[0, 0] == NINF:
                         continue
@@ -141,3 +142,60 @@ def test_trajectory_manager_matches_restatement():
         kinds = {k for k, _ in ops}
         assert kinds == {"de", "in", "re"}, kinds            # the script exercised all three lists
         c.close()
+
+
+def test_frame_invalidated_while_queued_for_reintegration_is_deintegrated_once():
+    """A frame sits in the re-integration list when an optimisation result invalidates it (optimised pose -inf).  Popping the
+    list must not touch the volume for it, and the NEXT list update must queue exactly one de-integration at the pose the frame
+    is integrated with; when the frame becomes valid again it is integrated once.  (The reference leaves such a frame typed
+    ReIntegration, which its invalidateFrame never de-integrates — TrajectoryManager.cpp:123-134 vs :191-199; host.hip documents
+    the deviation.)"""
+    lib.bf_trajectory_manager_update_optimized_transform_host.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+    rng = np.random.default_rng(7)
+    n = 6
+    c = _CTM(16, 30, 0.0)
+    T0 = [_pose(rng, 0.5) for _ in range(n)]
+    for i in range(n):
+        c.add(0, T0[i], i)                                   # Integrated at T0
+    T1 = np.stack([(T0[i].astype(np.float64) @ _pose(rng, 0.01).astype(np.float64)).astype(np.float32) for i in range(n)])
+    c.update(T1); c.generate()
+    assert c.active() == n and all(c.frame(i)[0] == 4 for i in range(n))      # all queued for re-integration
+    order = []
+    f, idx, oldT, newT = c.top_re(); assert f and newT[0, 0] != NINF; c.confirm(idx); order.append(idx)
+    T2 = T1.copy()
+    victims = [i for i in range(n) if i != idx][:2]
+    T2[victims] = -np.inf                                    # two queued frames lose their pose
+    c.update(T2)
+    popped = []
+    while True:
+        f, i2, oldT, newT = c.top_re()
+        if not f:
+            break
+        if newT[0, 0] == NINF:
+            continue                                         # the frame loop skips the volume operation (plReintegrate)
+        c.confirm(i2); popped.append(i2)
+    assert sorted(popped + order) == [i for i in range(n) if i not in victims]
+    for v in victims:
+        t, T, _ = c.frame(v)
+        assert t == 0 and _same(T, T0[v])                    # still integrated at the old pose, and typed so
+    c.generate()
+    des = []
+    while True:
+        f, i3, T = c.top_de()[:3]
+        if not f:
+            break
+        des.append(i3); assert _same(T, T0[i3])
+    assert sorted(des) == sorted(victims)                    # de-integrated exactly once, at the pose it was integrated with
+    assert all(c.frame(v)[0] == 3 for v in victims)          # Invalid
+    c.generate()
+    assert not c.top_de()[0]                                 # not a second time
+    T3 = T2.copy(); T3[victims] = T1[victims]
+    c.update(T3); c.generate()                               # valid again -> integrate list, once
+    ins = []
+    while True:
+        f, i4, T = c.top_in()[:3]
+        if not f:
+            break
+        c.confirm(i4); ins.append(i4); assert _same(T, T1[i4])
+    assert sorted(ins) == sorted(victims)
+    c.close()

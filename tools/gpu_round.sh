@@ -10,27 +10,32 @@ STEPS=${*:-tests bench trace}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r$NN
 SWEEP_ARGS=${SWEEP_ARGS:-}
+BENCH_ARGS=${BENCH_ARGS:-}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 db() { ls -S "$1"/*/*_results.db "$1"/*_results.db 2>/dev/null | head -1; }
 for step in $STEPS; do
   case $step in
     tests)
-      (cd "$ROOT" && timeout 500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee "$OUT/pytest_gpu.txt") ;;
+      (cd "$ROOT" && timeout 900 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | tail -16 | tee "$OUT/pytest_gpu.txt") ;;
+    tests_new)
+      (cd "$ROOT" && timeout 900 python -m pytest tests/test_pipeline_baseline_gpu.py -x -q --durations=8 2>&1 | tail -25 | tee "$OUT/pytest_new.txt") ;;
     bench)
-      (cd "$ROOT" && timeout 300 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-260 "$OUT/bench.json") ;;
+      (cd "$ROOT" && timeout 400 python bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-260 "$OUT/bench.json"; tail -3 "$OUT/bench.err") ;;
+    bench_driver)   # the driver's invocation
+      (cd "$ROOT" && timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"; cut -c1-260 "$OUT/bench_driver.json"; tail -3 "$OUT/bench_driver.err") ;;
     trace)
       rm -rf /tmp/r_trace
-      (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_traced.json" 2> /dev/null)
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS > "$OUT/bench_traced.json" 2> /dev/null)
       D=$(db /tmp/r_trace)
       python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" | head -14
       python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt" ;;
-    pmc)
+    pmc)   # HBM traffic of the voxel update in the bench configuration: two passes (FETCH_SIZE, WRITE_SIZE), then bytes per visited block
       for C in FETCH_SIZE WRITE_SIZE; do
-        rm -rf /tmp/r_pmc
-        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc -o run -- python "$ROOT/bench.py" --no-cpu-baseline > /dev/null 2>&1)
-        python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_pmc)" update | tee "$OUT/pmc_$C.txt" | tail -4
-      done ;;
+        rm -rf /tmp/r_pmc_$C
+        (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
+      done
+      python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" ;;
     sq)   # where do the voxel-update waves spend their cycles: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
       rm -rf /tmp/r_sq
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES \
