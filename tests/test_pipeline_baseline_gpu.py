@@ -112,7 +112,7 @@ def test_three_chunks_4mm_and_oracle_log_replay(gpu, oracle):
     gkeys = {tuple(int(v) for v in e) for e in gh["pos"][gh["ptr"] != -2]}
     oh = op.scene.hash()
     okeys = {tuple(int(v) for v in e) for e in oh["pos"][oh["ptr"] != -2]}
-    assert len(okeys) > 60000 and len(gkeys & okeys) / len(gkeys | okeys) > 0.985
+    assert len(okeys) > 20000 and len(gkeys & okeys) / len(gkeys | okeys) > 0.985
     del gp
     # replay of the oracle's operator log: bit equality, with the fused re-integration operator and with separate operators
     for fused in (True, False):
@@ -138,7 +138,7 @@ def test_resample_branch_sensor_640_integration_320(gpu, oracle):
         assert gd.shape == (240, 320) and np.array_equal(gd.view(np.uint32), op.frames[i][0].view(np.uint32))
         assert np.array_equal(gc, op.frames[i][1])
     _assert_volume_bit_equal(gp.scene(), op.scene, "resample branch")
-    assert gp.scene().num_allocated_blocks() > 3000
+    assert gp.scene().num_allocated_blocks() > 1500
 
 
 @pytest.mark.skipif(os.environ.get("BF_SKIP_LONG") == "1", reason="BF_SKIP_LONG=1")
