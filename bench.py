@@ -16,9 +16,14 @@ The timed region is the OPERATING POINT of the loop, not its start-up: `--prerol
 first, so that the re-integration queue is saturated (s_maxFrameFixes = 10 re-integrations per frame) and the global problem
 holds >= 20 key frames when the W warm-up and K timed steps run (with the driver's --steps 20 --warmup 5: frames 205..224).
 
-Multi-GPU (N>1, weak scaling): every rank runs the full loop on its own contiguous segment of the stream (frame chunks
-sharded over ranks, each with its own volume); there is no data-path collective — the barrier + max-over-ranks timing
-is the only communication.
+Multi-GPU (N>1, default mode "chunks", STRONG scaling of ONE stream — the partition north_star names): local chunks of
+10 frames are dealt round-robin to the ranks; each rank runs the chunk-local half (SIFT, matching + filters inside the chunk, local
+solve, key-frame fusion) for its chunks; ONE RCCL all-gather per round of N chunks (0.4 MB per chunk) hands every package to every
+rank; every rank then runs the global half (pose chaining, global match + solve, TrajectoryManager, re-integration scheduling) on all
+packages in stream order and integrates into its hash-bucket shard of the one volume.  The global solve is replicated: it is
+bit-deterministic, so the pose update needs no exchange beyond one RCCL MIN/MAX all-reduce that verifies it after the run.
+`value` = frames of the one stream / slowest rank.  Other modes: "segments" (independent stream segments per rank, weak scaling) and
+"volume-shard" (every rank bundles everything, the volume is sharded).
 """
 import argparse
 import json
@@ -43,9 +48,10 @@ def main():
     ap.add_argument("--buckets", type=int, default=1000000)
     ap.add_argument("--blocks", type=int, default=600000)
     ap.add_argument("--host", action="store_true", help="hand over host buffers each frame (PCIe-inclusive)")
-    ap.add_argument("--mode", choices=["segments", "volume-shard"], default="segments",
-                    help="N>1: 'segments' = each rank its own stream segment and volume (weak scaling); 'volume-shard' = one stream, "
-                         "replicated bundling, the volume sharded by hash-bucket range (strong scaling)")
+    ap.add_argument("--mode", choices=["auto", "serial", "chunks", "segments", "volume-shard"], default="auto",
+                    help="auto = 'serial' on one GPU, 'chunks' on N>1: one stream, local chunks round-robin over the ranks + all-gather of key-frame "
+                         "packages + replicated global half + volume sharded by hash bucket (strong scaling).  'segments' = each rank its own stream "
+                         "segment and volume (weak scaling); 'volume-shard' = one stream, bundling replicated, volume sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=21, help="frames of the stream the CPU baseline processes (two local chunks)")
     args = ap.parse_args()
@@ -61,11 +67,19 @@ def main():
     from bundlefusion_amd import synth                      # (imports torch; no device context yet)
     import numpy as np
     ncpu = os.cpu_count() or 1
-    from bundlefusion_amd.shard import segment, max_over_ranks, same_over_ranks
-    shard_volume = args.mode == "volume-shard" and world > 1
-    first = 0 if shard_volume else segment(rank, world, total)[0]   # segments: each rank its own contiguous part of the S2 loop
+    from bundlefusion_amd.shard import segment, max_over_ranks, same_over_ranks, ChunkedRunner
+    mode = args.mode if args.mode != "auto" else ("chunks" if world > 1 else "serial")
+    chunked = mode == "chunks"
+    shard_volume = (mode == "volume-shard" and world > 1) or chunked
+    one_stream = shard_volume or mode == "serial" or world == 1
+    first = 0 if one_stream else segment(rank, world, total)[0]   # segments: each rank its own contiguous part of the S2 loop
+    n_render = total
+    if chunked:                     # the last round of `world` chunks must be complete (its local halves run before the all-gather)
+        S0 = 10
+        last_chunk = 0 if total <= 1 else (total - 2) // S0
+        n_render = ((last_chunk // world + 1) * world) * S0 + 1
     t_gen = time.perf_counter()
-    frames = synth.render_frames(range(first, first + total), W, H, workers=max(1, min(64, ncpu // max(world, 1))))
+    frames = synth.render_frames(range(first, first + n_render), W, H, workers=max(1, min(64, ncpu // max(world, 1))))
     t_gen = time.perf_counter() - t_gen
 
     import torch
@@ -87,12 +101,12 @@ def main():
         gas.s_integrationWidth, gas.s_integrationHeight = W, H
         gas.s_SDFVoxelSize = args.voxel
         gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = buckets or args.buckets, blocks or args.blocks
-        gbs.s_maxNumImages = max(total // 10 + 8, 16)
+        gbs.s_maxNumImages = max(n_render // 10 + 8, 16)
         return gas, gbs
 
     gas, gbs = params()
     pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
-    if shard_volume:
+    if shard_volume and world > 1:
         pipe.set_volume_shard(rank, world)
     if args.host:
         feed = [(f[0], f[1]) for f in frames]
@@ -100,11 +114,20 @@ def main():
         feed = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
     torch.cuda.synchronize()
 
+    runner = None
+    if chunked:
+        assert not args.host, "chunks mode feeds HBM-resident frames"
+        gas_w, gbs_w = params()
+        runner = ChunkedRunner(pipe, bf.capi.ChunkWorker(gas_w, gbs_w, sensor_desc(W, H, K)), feed, gbs_w.s_submapSize, rank, world, "cuda")
+        assert runner.frames_needed(total) <= len(feed)
     sc = pipe.scene()
     if args.pmc_out:
         sc.kernel_timing(True)                               # profiling run: account every launch of the run (the PMC passes see all of them)
-    for k in range(pre):
-        assert pipe.process_frame(*feed[k])
+    if chunked:
+        runner.advance(pre)
+    else:
+        for k in range(pre):
+            assert pipe.process_frame(*feed[k])
     pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -116,9 +139,13 @@ def main():
     pipe.host_profile(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(pre, total):
-        ok = pipe.process_frame(*feed[k])
-        assert ok
+    if chunked:
+        rounds0 = runner.rounds
+        runner.advance(args.steps)
+    else:
+        for k in range(pre, total):
+            ok = pipe.process_frame(*feed[k])
+            assert ok
     pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -131,7 +158,7 @@ def main():
     n_launch, kernel_ms = sc.kernel_timing_read()
     sc.kernel_timing(False)
     elapsed = max_over_ranks(elapsed, "cuda")
-    if shard_volume:      # replicated bundling must have produced ONE trajectory (bit-identical on every rank): RCCL MIN/MAX all-reduce
+    if shard_volume and world > 1:      # the replicated global half must have produced ONE trajectory (bit-identical on every rank): RCCL MIN/MAX all-reduce
         traj_dev = torch.from_numpy(np.nan_to_num(pipe.integrated_trajectory(), neginf=-1e30)).cuda()
         assert same_over_ranks(traj_dev), "ranks disagree on the trajectory"
 
@@ -157,14 +184,14 @@ def main():
     if rank == 0:
         out = {
             "metric": "frames/sec end-to-end (SIFT+SBA+TSDF re-integrate), 640x480 @4mm",
-            "value": (1 if shard_volume else world) * args.steps / elapsed,
+            "value": (1 if one_stream else world) * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if shard_volume else "weak",
+            "scaling": "strong" if (one_stream and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -183,8 +210,11 @@ def main():
                 "host_thread_ms_per_frame": {k: round(1e3 * v / max(hp["frames"], 1.0), 4) for k, v in hp.items() if k != "frames"},
                 "frame_loop": "serial order, detection of frame k+1 overlapped with matching/solve of frame k (BF_PIPELINE_LOOKAHEAD=%s)"
                               % os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
-                "parallelism": ("one stream, bundling replicated on %d ranks, volume sharded by hash-bucket range" % world) if shard_volume
-                               else "stream segments sharded over %d rank(s), no data-path collective" % world,
+                "parallelism": ("one stream: local chunks round-robin over %d ranks, %d RCCL all-gathers of key-frame packages in the timed region, global half "
+                                "replicated, volume sharded by hash-bucket range" % (world, runner.rounds - rounds0)) if chunked
+                               else ("one stream, bundling replicated on %d ranks, volume sharded by hash-bucket range" % world) if (shard_volume and world > 1)
+                               else "one GPU, serial frame loop" if world == 1 else "stream segments sharded over %d rank(s), no data-path collective" % world,
+                "mode": mode,
             },
             "roofline": {
                 "kernel": "k_update<integrate> + k_reupdate (fused de-integrate+integrate) — TSDF voxel update",

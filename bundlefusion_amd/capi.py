@@ -865,6 +865,14 @@ class Pipeline:
         hp = HashParams(); check(lib.bf_scene_get_hash_params(h, C.byref(hp))); s.params = hp
         return s
 
+    def process_frame_chunked(self, depth, color, package, local_idx):
+        """One iteration for the next frame of the stream with its chunk-local half taken from `package` (a ChunkWorker.run result,
+        possibly of another rank): depth / colour are torch cuda tensors, package a contiguous uint8 numpy array."""
+        got = C.c_int()
+        check(lib.bf_pipeline_process_frame_chunked(self._h, C.c_void_p(depth.data_ptr()), C.c_void_p(color.data_ptr()),
+                                                    package.ctypes.data_as(C.c_void_p), int(local_idx), C.byref(got)))
+        return bool(got.value)
+
     def integrate_frame_cpu(self, frame):
         """Host copies (depth float32 (h,w), colour uint8 (h,w,4)) of the frame stored for integration — getIntegrateFrame(i).getDepthFrameCPU() / getColorFrameCPU()."""
         im = C.c_void_p(); w = C.c_uint32(); h = C.c_uint32()
@@ -879,3 +887,36 @@ class Pipeline:
         check(lib.bf_pipeline_get_online_bundler(self._h, C.byref(ob)))
         check(lib.bf_online_bundler_get_bundler(ob, {"local": 0, "optLocal": 1, "global": 2}[which], C.byref(b)))
         return b
+
+
+class ChunkWorker:
+    """Python view of `bf_chunk_worker`: the chunk-local half of the frame loop (SIFT, matching + filters inside the chunk, local
+    solve, key-frame fusion) for one local chunk at a time -> a flat package (numpy uint8) for Pipeline.process_frame_chunked."""
+
+    def __init__(self, gas, gbs, sensor):
+        self._h = C.c_void_p()
+        check(lib.bf_chunk_worker_create(C.byref(gas), C.byref(gbs), C.byref(sensor), C.byref(self._h)))
+        n = C.c_uint64()
+        check(lib.bf_chunk_worker_package_bytes(self._h, C.byref(n)))
+        self.package_bytes = int(n.value)
+
+    def close(self):
+        if self._h:
+            lib.bf_chunk_worker_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, chunk_index, frames, out=None):
+        """frames: list of (depth, colour) torch cuda tensors, the chunk's frames in stream order (the first one is shared with the
+        previous chunk).  Returns the package (uint8 numpy array of package_bytes)."""
+        n = len(frames)
+        dp = (C.c_void_p * n)(*[f[0].data_ptr() for f in frames])
+        cp = (C.c_void_p * n)(*[f[1].data_ptr() for f in frames])
+        pkg = out if out is not None else np.zeros(self.package_bytes, np.uint8)
+        check(lib.bf_chunk_worker_run(self._h, int(chunk_index), n, dp, cp, pkg.ctypes.data_as(C.c_void_p)))
+        return pkg

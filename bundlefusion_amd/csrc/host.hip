@@ -69,6 +69,33 @@ __global__ void k_sift_transform(uint32_t curFrameIndex, const m44* completeTraj
     }
 }
 
+// the same for a frame whose chunk-local matching ran elsewhere (chunk-parallel mode): `i` and filteredTransformsInv[i] arrive by value
+__global__ void k_sift_transform_ext(uint32_t curFrameIndex, const m44* completeTrajectory, uint32_t lastValidCompleteTransform, m44* siftTrajectory,
+                                     uint32_t curFrameIndexAll, int i, m44 filteredTransformInv, m44* currIntegrateTrans) {
+    const uint32_t idxPrevSiftKnown = curFrameIndexAll - (curFrameIndex - (uint32_t)i);
+    const m44 cur = mul44(siftTrajectory[idxPrevSiftKnown], filteredTransformInv);
+    siftTrajectory[curFrameIndexAll] = cur;
+    m44 transform;
+    if (lastValidCompleteTransform == 0) transform = cur;
+    else if (idxPrevSiftKnown < lastValidCompleteTransform) transform = mul44(completeTrajectory[idxPrevSiftKnown], filteredTransformInv);
+    else {
+        const m44 offset = mul44(inverse44(siftTrajectory[lastValidCompleteTransform]), siftTrajectory[idxPrevSiftKnown]);
+        transform = mul44(mul44(completeTrajectory[lastValidCompleteTransform], offset), filteredTransformInv);
+    }
+    currIntegrateTrans[0] = transform;
+}
+
+// chunk worker: which previous frame of the chunk does frame `cur` chain from (k_sift_transform's scan), and its relative transform
+__global__ void k_pick_relative(uint32_t cur, const int* numFilt, const m44* filteredTransformsInv, bf_chunk_frame_record* out) {
+    out->prevLocal = -1;
+    for (int i = (int)cur - 1; i >= 0; i--)
+        if (numFilt[i] > 0) {
+            out->prevLocal = i;
+            for (int k = 0; k < 16; ++k) out->relInv[k] = filteredTransformsInv[i].e[k];
+            break;
+        }
+}
+
 __global__ void k_update_trajectory(const m44* globalTrajectory, m44* completeTrajectory, uint32_t numCompleteTransforms, const m44* localTrajectories,
                                     uint32_t numLocalTransformsPerTrajectory, const int* imageInvalidateList) {      // :73-92
     const uint32_t idxComplete = blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,6 +165,7 @@ struct bf_image_manager {
     bf_global_bundling_state gbs;
     uint32_t wInt = 0, hInt = 0, wSIFT = 0, hSIFT = 0;
     bool onGPU = true;
+    bool scratch = false;          // storeFramesOnGPU == 2: one frame slot that every process() overwrites (chunk workers keep no history)
     hipStream_t stream = nullptr;
     m44 depthIntrinsics, depthIntrinsicsInv, colorIntrinsics, colorIntrinsicsInv, depthExtrinsics, depthExtrinsicsInv, siftDepthIntrinsics;
     float *d_depthInputRaw = nullptr, *d_depthInputFiltered = nullptr;
@@ -160,7 +188,7 @@ int bf_image_manager_create(uint32_t wInt, uint32_t hInt, uint32_t wSIFT, uint32
     BF_REQUIRE(wInt > 1 && hInt > 1 && sensor->depthWidth > 1 && sensor->depthHeight > 1 && sensor->colorWidth > 1 && sensor->colorHeight > 1, "bad image size");
     bf_image_manager* im = new bf_image_manager;
     im->sensor = *sensor; im->gbs = *gbs;
-    im->wInt = wInt; im->hInt = hInt; im->wSIFT = wSIFT; im->hSIFT = hSIFT; im->onGPU = storeFramesOnGPU != 0;
+    im->wInt = wInt; im->hInt = hInt; im->wSIFT = wSIFT; im->hSIFT = hSIFT; im->onGPU = storeFramesOnGPU != 0; im->scratch = storeFramesOnGPU == 2;
     im->siftDepthIntrinsics = toM(sensor->depthIntrinsics);
     im->depthIntrinsics = scaleIntrinsics(sensor->depthIntrinsics, wInt, hInt, sensor->depthWidth, sensor->depthHeight);
     im->depthIntrinsicsInv = inverse44(im->depthIntrinsics);
@@ -206,17 +234,18 @@ static int im_process(bf_image_manager* im, const float* depth, const uint8_t* c
     BF_REQUIRE(im && gotFrame, "null argument");
     *gotFrame = 0;
     if (!depth || !color) return BF_OK;                     // sensor->processDepth()/processColor() returned false
-    if (im->currFrame + 1 > im->gbs.s_maxNumImages * im->gbs.s_submapSize) return BF_OK;      // .cpp:26-29 "reached max #images"
+    if (!im->scratch && im->currFrame + 1 > im->gbs.s_maxNumImages * im->gbs.s_submapSize) return BF_OK;      // .cpp:26-29 "reached max #images"
     const bf_rgbd_sensor_desc& sn = im->sensor;
     const size_t nd = (size_t)sn.depthWidth * sn.depthHeight, nc = (size_t)sn.colorWidth * sn.colorHeight, ni = im->nInt();
     hipStream_t st = im->stream;
-    const uint32_t f = im->currFrame;
+    const uint32_t f = im->scratch ? 0u : im->currFrame;
     float* frameDepth = nullptr; uint8_t* frameColor = nullptr;
     if (im->onGPU) {
         if (f / bf_image_manager::SLAB >= im->depthSlabs.size()) {
             float* pd = nullptr; uint8_t* pc = nullptr;
-            BF_HIP_TRY(hipMalloc((void**)&pd, ni * 4 * bf_image_manager::SLAB));
-            BF_HIP_TRY(hipMalloc((void**)&pc, ni * 4 * bf_image_manager::SLAB));
+            const size_t slots = im->scratch ? 1 : bf_image_manager::SLAB;
+            BF_HIP_TRY(hipMalloc((void**)&pd, ni * 4 * slots));
+            BF_HIP_TRY(hipMalloc((void**)&pc, ni * 4 * slots));
             im->depthSlabs.push_back(pd); im->colorSlabs.push_back(pc);
         }
         frameDepth = im->depthSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni;
@@ -940,6 +969,8 @@ struct bf_online_bundler {
     int stagedFrame[2] = {-1, -1};
     // processInput in flight (between _begin and _end)
     int pendPhase = 0; uint32_t pendFrame = 0, pendCur = 0, pendNum = 0; bool pendLastLocal = false, pendMatch = false;
+    // chunk-parallel mode (bf_pipeline_process_frame_chunked): the local half of the chunk being closed comes from this package
+    const bf_chunk_header* extChunk = nullptr;
     bool isLastLocalFrame(uint32_t curFrame) const { return curFrame >= submapSize && (curFrame % submapSize) == 0; }
     void invalidateImages(uint32_t s, uint32_t e = 0xFFFFFFFFu) { if (e == 0xFFFFFFFFu) invalidImagesList[s] = 0; else for (uint32_t i = s; i < e; ++i) invalidImagesList[i] = 0; }
     void validateImages(uint32_t s) { invalidImagesList[s] = 1; }
@@ -948,6 +979,33 @@ struct bf_online_bundler {
 namespace {
 
 const int ID_MARK_OFFSET = 2;
+
+// chunk-parallel mode: what Bundler::fuseToGlobal (:388-394) leaves in the global bundler — one more image (the fused key points and
+// descriptors) and one more cache frame (the chunk's first) — taken from a chunk package instead of m_optLocal
+int obAppendKeyFrame(bf_bundler* glob, const bf_chunk_header* h) {
+    BF_REQUIRE(h->magic == BF_CHUNK_MAGIC && h->numKeys <= glob->maxKeys, "bad chunk package");
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(h);
+    bf_sift_image_gpu img;
+    BF_TRY(bf_siftmgr_create_image(glob->mgr, &img));
+    if (h->numKeys) {
+        BF_HIP_TRY(hipMemcpyAsync(img.d_keyPoints, base + h->offKeys, sizeof(bf_sift_keypoint) * h->numKeys, hipMemcpyHostToDevice, glob->stream));
+        BF_HIP_TRY(hipMemcpyAsync(img.d_keyPointDescs, base + h->offDescs, (size_t)128 * h->numKeys, hipMemcpyHostToDevice, glob->stream));
+    }
+    BF_TRY(bf_siftmgr_finalize_image(glob->mgr, (int32_t)h->numKeys));
+    uint32_t ci, cw, ch; float k4[4];
+    BF_TRY(bf_cache_get_num_frames(glob->cache, &ci));
+    BF_TRY(bf_cache_get_geometry(glob->cache, &cw, &ch, k4));
+    BF_REQUIRE(cw == h->cacheWidth && ch == h->cacheHeight, "chunk package: cache geometry differs");
+    bf_cached_frame cd;
+    BF_TRY(bf_cache_get_frame(glob->cache, ci, &cd));
+    const size_t n = (size_t)cw * ch;
+    void* dst[6] = {cd.d_depthDownsampled, cd.d_cameraposDownsampled, cd.d_intensityDownsampled, cd.d_intensityDerivsDownsampled, cd.d_normalsDownsampledUCHAR4, cd.d_normalsDownsampled};
+    const size_t bytes[6] = {n * 4, n * 16, n * 4, n * 8, n * 4, n * 16};
+    for (int k = 0; k < 6; ++k) BF_HIP_TRY(hipMemcpyAsync(dst[k], base + h->offCache[k], bytes[k], hipMemcpyHostToDevice, glob->stream));
+    BF_TRY(bf_cache_increment(glob->cache));
+    BF_HIP_TRY(hipStreamSynchronize(glob->stream));      // like fuseToGlobal: the package memory may be reused after the call
+    return BF_OK;
+}
 
 int obPrepareLocalSolve(bf_online_bundler* ob, uint32_t curFrame, bool isSequenceEnd) {            // OnlineBundler.cpp:134-165
     ob->processState = bf_online_bundler::DO_NOTHING;
@@ -971,15 +1029,19 @@ int obOptimizeLocal(bf_online_bundler* ob, uint32_t numNonLin, uint32_t numLin) 
     const bf_online_bundler::State optLocalState = ob->processState;
     ob->processState = bf_online_bundler::DO_NOTHING;
     uint32_t curLocalIdx = 0xFFFFFFFFu, nOpt;
-    BF_TRY(bf_bundler_get_num_frames(ob->optLocal, &nOpt));
+    if (ob->extChunk) nOpt = ob->extChunk->numFrames;
+    else BF_TRY(bf_bundler_get_num_frames(ob->optLocal, &nOpt));
     const uint32_t numLocalFrames = std::min(ob->submapSize, nOpt);
     if (optLocalState == bf_online_bundler::PROCESS) {
         curLocalIdx = (uint32_t)ob->localToSolve;
         int removed = 0, valid = 0;
-        BF_TRY(bf_bundler_optimize(ob->optLocal, numNonLin, numLin, ob->gbs.s_useLocalVerify, 0, ob->numFramesPastEnd != 0, &removed, &valid));
+        if (ob->extChunk) valid = ob->extChunk->solveValid;          // the chunk's worker ran Bundler::optimize
+        else BF_TRY(bf_bundler_optimize(ob->optLocal, numNonLin, numLin, ob->gbs.s_useLocalVerify, 0, ob->numFramesPastEnd != 0, &removed, &valid));
         ob->numLocalSolves++;
         if (valid) {
-            BF_HIP_TRY(hipMemcpyAsync(ob->d_localTrajectories + (size_t)(ob->submapSize + 1) * curLocalIdx, ob->optLocal->d_trajectory, sizeof(m44) * (ob->submapSize + 1),
+            if (ob->extChunk) BF_HIP_TRY(hipMemcpyAsync(ob->d_localTrajectories + (size_t)(ob->submapSize + 1) * curLocalIdx, ob->extChunk->localTrajectory,
+                                                        sizeof(m44) * (ob->submapSize + 1), hipMemcpyHostToDevice, ob->stream));
+            else BF_HIP_TRY(hipMemcpyAsync(ob->d_localTrajectories + (size_t)(ob->submapSize + 1) * curLocalIdx, ob->optLocal->d_trajectory, sizeof(m44) * (ob->submapSize + 1),
                                       hipMemcpyDeviceToDevice, ob->stream));
             ob->processState = bf_online_bundler::PROCESS;
         } else ob->processState = bf_online_bundler::INVALIDATE;
@@ -1009,12 +1071,18 @@ int obProcessGlobal(bf_online_bundler* ob) {                                    
     }
     ob->processState = bf_online_bundler::DO_NOTHING;
     if (processState == bf_online_bundler::PROCESS) {
-        BF_TRY(bf_bundler_fuse_to_global(ob->optLocal, ob->global));
         uint32_t curGlobalFrame, nOpt;
-        BF_TRY(bf_bundler_get_curr_frame_number(ob->global, &curGlobalFrame));
-        BF_TRY(bf_bundler_get_num_frames(ob->optLocal, &nOpt));
         std::vector<int> validImagesLocal(ob->submapSize + 1, 0);
-        BF_TRY(bf_bundler_get_valid_images(ob->optLocal, validImagesLocal.data(), ob->submapSize + 1));
+        if (ob->extChunk) {                          // the fused key frame, the chunk's size and its valid flags come with the package
+            BF_TRY(obAppendKeyFrame(ob->global, ob->extChunk));
+            nOpt = ob->extChunk->numFrames;
+            for (uint32_t i = 0; i <= ob->submapSize && i < BF_CHUNK_MAX_FRAMES; ++i) validImagesLocal[i] = ob->extChunk->validImages[i];
+        } else {
+            BF_TRY(bf_bundler_fuse_to_global(ob->optLocal, ob->global));
+            BF_TRY(bf_bundler_get_num_frames(ob->optLocal, &nOpt));
+            BF_TRY(bf_bundler_get_valid_images(ob->optLocal, validImagesLocal.data(), ob->submapSize + 1));
+        }
+        BF_TRY(bf_bundler_get_curr_frame_number(ob->global, &curGlobalFrame));
         const uint32_t numLocalFrames = std::min(ob->submapSize, nOpt);
         uint32_t lastValidLocal = 0;
         for (int i = (int)nOpt - 1; i >= 0; --i) if (validImagesLocal[i]) { lastValidLocal = (uint32_t)i; break; }
@@ -1025,7 +1093,7 @@ int obProcessGlobal(bf_online_bundler* ob) {                                    
         BF_TRY(bf_bundler_get_num_frames(ob->global, &nGlob));
         BF_TRY(bf_init_next_global_transform((float*)ob->global->d_trajectory, nGlob, curGlobalFrame, (const float*)ob->d_localTrajectories, lastValidLocal,
                                              ob->submapSize + 1, ob->stream));
-        BF_TRY(bf_bundler_reset(ob->optLocal));
+        if (!ob->extChunk) BF_TRY(bf_bundler_reset(ob->optLocal));
         if (nGlob > 1) {
             uint32_t lastMatchedGlobal;
             BF_TRY(bf_bundler_match_and_filter(ob->global, &lastMatchedGlobal));
@@ -1043,7 +1111,7 @@ int obProcessGlobal(bf_online_bundler* ob) {                                    
     } else if (processState == bf_online_bundler::INVALIDATE) {
         ob->processState = bf_online_bundler::INVALIDATE;
         BF_TRY(bf_bundler_add_invalid_frame(ob->global));
-        BF_TRY(bf_bundler_reset(ob->optLocal));
+        if (!ob->extChunk) BF_TRY(bf_bundler_reset(ob->optLocal));
         ob->invalidateImages(ob->submapSize * (uint32_t)ob->lastLocalSolved, ob->totalNumOptLocalFrames);
     }
     return BF_OK;
@@ -1760,5 +1828,222 @@ int bf_pipeline_enable_timings(bf_pipeline* p, int enable) {
     return BF_OK;
 }
 int bf_pipeline_get_last_timing(bf_pipeline* p, bf_frame_timing* out) { BF_REQUIRE(p && out, "null argument"); *out = p->last; return BF_OK; }
+
+}  // extern "C"
+
+// ================================================================================================ chunk-parallel bundling
+// Stage A — bf_chunk_worker: the chunk-local half of OnlineBundler for ONE local chunk.  Nothing here reads global state: the
+// frames of a chunk are ingested, detected, matched and filtered against each other (Bundler::matchAndFilter on m_local), the
+// chunk is solved (Bundler::optimize on m_optLocal) and fused into one key frame (fuseToGlobal).  The result is a flat host
+// package (bf_chunk_header + payload) that any rank can feed to bf_pipeline_process_frame_chunked.
+struct bf_chunk_worker {
+    bf_global_app_state gas; bf_global_bundling_state gbs; bf_rgbd_sensor_desc sensor;
+    bf_image_manager* im = nullptr;       // ingest only (scratch mode: no frame history)
+    bf_bundler* local = nullptr;          // the chunk: s_submapSize + 1 images
+    bf_siftmgr* fuseMgr = nullptr;        // one-image target of fuseToGlobal
+    float *d_intensity = nullptr, *d_intensityHelper = nullptr;
+    bf_chunk_frame_record* d_rec = nullptr;
+    m44 siftIntrinsics, siftIntrinsicsInv;
+    hipStream_t stream = nullptr;
+    uint32_t cacheW = 0, cacheH = 0;
+    uint64_t packageBytes = 0, offKeys = 0, offDescs = 0, offCache[6] = {0, 0, 0, 0, 0, 0};
+};
+
+extern "C" {
+
+int bf_chunk_worker_create(const bf_global_app_state* gas, const bf_global_bundling_state* gbs, const bf_rgbd_sensor_desc* sensor, bf_chunk_worker** out) {
+    BF_REQUIRE(gas && gbs && sensor && out, "null argument");
+    BF_REQUIRE(gbs->s_submapSize + 1 <= BF_CHUNK_MAX_FRAMES, "s_submapSize + 1 exceeds BF_CHUNK_MAX_FRAMES");
+    bf_chunk_worker* w = new bf_chunk_worker;
+    w->gas = *gas; w->gbs = *gbs; w->sensor = *sensor;
+    w->siftIntrinsics = scaleIntrinsics(sensor->colorIntrinsics, gbs->s_widthSIFT, gbs->s_heightSIFT, sensor->colorWidth, sensor->colorHeight);
+    w->siftIntrinsicsInv = inverse44(w->siftIntrinsics);
+    int rc = bf_image_manager_create(gas->s_integrationWidth, gas->s_integrationHeight, gbs->s_widthSIFT, gbs->s_heightSIFT, sensor, gbs, 2, &w->im);
+    if (!rc) rc = bf_bundler_create(gbs->s_submapSize + 1, gbs->s_maxNumKeysPerImage, w->siftIntrinsicsInv.e, w->im, 1, gas, gbs, &w->local);
+    if (!rc) rc = bf_siftmgr_create(2, gbs->s_maxNumKeysPerImage, &w->fuseMgr);
+    if (rc) { bf_chunk_worker_destroy(w); return rc; }
+    const size_t nS = (size_t)gbs->s_widthSIFT * gbs->s_heightSIFT;
+    BF_HIP_TRY(hipMalloc((void**)&w->d_intensity, nS * 4));
+    BF_HIP_TRY(hipMalloc((void**)&w->d_intensityHelper, nS * 4));
+    BF_HIP_TRY(hipMalloc((void**)&w->d_rec, sizeof(bf_chunk_frame_record) * BF_CHUNK_MAX_FRAMES));
+    float k4[4];
+    BF_TRY(bf_cache_get_geometry(w->local->cache, &w->cacheW, &w->cacheH, k4));
+    const uint64_t n = (uint64_t)w->cacheW * w->cacheH, mk = gbs->s_maxNumKeysPerImage;
+    uint64_t off = (sizeof(bf_chunk_header) + 255) / 256 * 256;
+    w->offKeys = off; off += mk * sizeof(bf_sift_keypoint);
+    w->offDescs = off; off += mk * 128;
+    const uint64_t cb[6] = {n * 4, n * 16, n * 4, n * 8, n * 4, n * 16};
+    for (int k = 0; k < 6; ++k) { w->offCache[k] = off; off += cb[k]; }
+    w->packageBytes = (off + 255) / 256 * 256;
+    BF_HIP_TRY(hipDeviceSynchronize());
+    *out = w;
+    return BF_OK;
+}
+
+int bf_chunk_worker_destroy(bf_chunk_worker* w) {
+    if (!w) return BF_OK;
+    (void)hipDeviceSynchronize();
+    bf_bundler_destroy(w->local); bf_siftmgr_destroy(w->fuseMgr); bf_image_manager_destroy(w->im);
+    (void)hipFree(w->d_intensity); (void)hipFree(w->d_intensityHelper); (void)hipFree(w->d_rec);
+    delete w;
+    return BF_OK;
+}
+
+int bf_chunk_worker_set_stream(bf_chunk_worker* w, void* s) {
+    BF_REQUIRE(w, "null worker");
+    w->stream = (hipStream_t)s;
+    BF_TRY(bf_image_manager_set_stream(w->im, s));
+    BF_TRY(bf_bundler_set_stream(w->local, s));
+    return bf_siftmgr_set_stream(w->fuseMgr, s);
+}
+
+int bf_chunk_worker_package_bytes(bf_chunk_worker* w, uint64_t* bytes) { BF_REQUIRE(w && bytes, "null argument"); *bytes = w->packageBytes; return BF_OK; }
+
+int bf_chunk_worker_run(bf_chunk_worker* w, uint32_t chunkIndex, uint32_t numFrames, const float* const* d_depth, const uint8_t* const* d_color, void* h_package) {
+    BF_REQUIRE(w && d_depth && d_color && h_package, "null argument");
+    BF_REQUIRE(numFrames >= 2 && numFrames <= w->gbs.s_submapSize + 1, "a chunk holds 2 .. s_submapSize + 1 frames");
+    const bf_rgbd_sensor_desc& sn = w->sensor;
+    hipStream_t st = w->stream;
+    bf_chunk_header* h = reinterpret_cast<bf_chunk_header*>(h_package);
+    uint8_t* base = reinterpret_cast<uint8_t*>(h_package);
+    memset(h, 0, sizeof *h);
+    h->magic = BF_CHUNK_MAGIC; h->chunkIndex = chunkIndex; h->numFrames = numFrames; h->submapSize = w->gbs.s_submapSize;
+    h->maxKeys = w->gbs.s_maxNumKeysPerImage; h->cacheWidth = w->cacheW; h->cacheHeight = w->cacheH;
+    h->offKeys = w->offKeys; h->offDescs = w->offDescs; for (int k = 0; k < 6; ++k) h->offCache[k] = w->offCache[k];
+    h->totalBytes = w->packageBytes;
+    BF_HIP_TRY(hipMemsetAsync(w->d_rec, 0, sizeof(bf_chunk_frame_record) * BF_CHUNK_MAX_FRAMES, st));
+    int validFlags[BF_CHUNK_MAX_FRAMES] = {0};
+    for (uint32_t j = 0; j < numFrames; ++j) {
+        int got = 0;
+        BF_TRY(bf_image_manager_process_device(w->im, d_depth[j], d_color[j], &got));
+        BF_REQUIRE(got, "chunk worker: ingest refused a frame");
+        // getCurrentFrame (OnlineBundler.cpp:106-116), detectFeatures, storeCachedFrame (:203-206)
+        BF_TRY(bf_image_resample_to_intensity(w->d_intensity, w->gbs.s_widthSIFT, w->gbs.s_heightSIFT, w->im->d_colorInput, sn.colorWidth, sn.colorHeight, st));
+        if (w->gas.s_colorFilter) {
+            BF_TRY(bf_image_gauss_filter_intensity(w->d_intensityHelper, w->d_intensity, w->gas.s_colorSigmaD, w->gbs.s_widthSIFT, w->gbs.s_heightSIFT, st));
+            std::swap(w->d_intensityHelper, w->d_intensity);
+        }
+        BF_TRY(bf_bundler_detect_features(w->local, w->d_intensity, w->im->d_depthInputFiltered));
+        BF_TRY(bf_bundler_store_cached_frame(w->local, sn.depthWidth, sn.depthHeight, w->im->d_colorInput, sn.colorWidth, sn.colorHeight, w->im->d_depthInputRaw));
+        if (j > 0) {                                            // matchAndFilter + the part of computeCurrentSiftTransform that is chunk-local (:118-132)
+            uint32_t cur, start, num;
+            BF_TRY(matchAndFilterEnqueue(w->local, cur, start, num));
+            const float* d_Tinv = nullptr; const int32_t* d_nf = nullptr;
+            BF_TRY(bf_bundler_get_current_sift_transforms_gpu(w->local, &d_Tinv));
+            BF_TRY(bf_bundler_get_num_filt_matches_gpu(w->local, &d_nf));
+            k_pick_relative<<<1, 1, 0, st>>>(j, d_nf, (const m44*)d_Tinv, w->d_rec + j);
+            BF_HIP_TRY(hipGetLastError());
+            BF_TRY(bf_siftmgr_prefetch_frame_result(w->local->mgr));
+            uint32_t last;
+            BF_TRY(matchAndFilterFinish(w->local, cur, num, &last));
+            validFlags[j] = last != 0xFFFFFFFFu ? 1 : 0;
+        }
+    }
+    BF_HIP_TRY(hipMemcpyAsync(h->frames, w->d_rec, sizeof(bf_chunk_frame_record) * BF_CHUNK_MAX_FRAMES, hipMemcpyDeviceToHost, st));
+    // prepareLocalSolve (:134-165), optimizeLocal (:242-271), fuseToGlobal (:297)
+    int valid = 0;
+    BF_TRY(bf_bundler_is_valid(w->local, &valid));
+    h->chunkValid = valid;
+    if (valid) {
+        int removed = 0, solveValid = 0;
+        BF_TRY(bf_bundler_optimize(w->local, w->gbs.s_numLocalNonLinIterations, w->gbs.s_numLocalLinIterations, w->gbs.s_useLocalVerify, 0, 0, &removed, &solveValid));
+        h->solveValid = solveValid;
+        if (solveValid) {
+            BF_HIP_TRY(hipMemcpyAsync(h->localTrajectory, w->local->d_trajectory, sizeof(m44) * (w->gbs.s_submapSize + 1), hipMemcpyDeviceToHost, st));
+            BF_TRY(bf_siftmgr_reset(w->fuseMgr));
+            BF_TRY(bf_siftmgr_fuse_to_global(w->local->mgr, w->fuseMgr, w->local->siftIntrinsics.e, (const float*)w->local->d_trajectory, w->local->siftIntrinsicsInv.e));
+            bf_sift_image_gpu img;
+            BF_TRY(bf_siftmgr_get_image(w->fuseMgr, 0, &img));
+            int32_t nk = 0;
+            BF_TRY(bf_siftmgr_get_num_keypoints(w->fuseMgr, 0, 1, &nk));
+            h->numKeys = (uint32_t)std::max(nk, 0);
+            if (h->numKeys) {
+                BF_HIP_TRY(hipMemcpyAsync(base + h->offKeys, img.d_keyPoints, sizeof(bf_sift_keypoint) * h->numKeys, hipMemcpyDeviceToHost, st));
+                BF_HIP_TRY(hipMemcpyAsync(base + h->offDescs, img.d_keyPointDescs, (size_t)128 * h->numKeys, hipMemcpyDeviceToHost, st));
+            }
+            bf_cached_frame cf;
+            BF_TRY(bf_cache_get_frame(w->local->cache, 0, &cf));
+            const size_t n = (size_t)w->cacheW * w->cacheH;
+            const void* src[6] = {cf.d_depthDownsampled, cf.d_cameraposDownsampled, cf.d_intensityDownsampled, cf.d_intensityDerivsDownsampled, cf.d_normalsDownsampledUCHAR4, cf.d_normalsDownsampled};
+            const size_t bytes[6] = {n * 4, n * 16, n * 4, n * 8, n * 4, n * 16};
+            for (int k = 0; k < 6; ++k) BF_HIP_TRY(hipMemcpyAsync(base + h->offCache[k], src[k], bytes[k], hipMemcpyDeviceToHost, st));
+        }
+        std::vector<int> v(w->gbs.s_submapSize + 1, 0);
+        BF_TRY(bf_bundler_get_valid_images(w->local, v.data(), w->gbs.s_submapSize + 1));
+        for (uint32_t i = 0; i <= w->gbs.s_submapSize; ++i) h->validImages[i] = v[i];
+    }
+    BF_HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t j = 0; j < numFrames; ++j) h->frames[j].valid = validFlags[j];
+    BF_TRY(bf_bundler_reset(w->local));
+    return BF_OK;
+}
+
+}  // extern "C"
+
+// Stage B — the global half, replicated on every rank, in stream order
+namespace {
+
+// processInput (:167-227) for a frame whose chunk-local results are in `pkg`
+int obProcessInputChunked(bf_online_bundler* ob, uint32_t curFrame, const bf_chunk_header* pkg, uint32_t localIdx) {
+    BF_REQUIRE(ob->pendPhase == 0, "processInput already in flight");
+    BF_REQUIRE(pkg && pkg->magic == BF_CHUNK_MAGIC && pkg->submapSize == ob->submapSize, "bad chunk package");
+    BF_REQUIRE(localIdx < pkg->numFrames && curFrame == pkg->chunkIndex * ob->submapSize + localIdx, "frame is not frame localIdx of the package's chunk");
+    BF_REQUIRE(!(curFrame > 0 && ob->lastFrameProcessed == (int)curFrame), "chunked mode: the sequence end is driven by bf_pipeline_process_end_of_sequence");
+    const bool bIsLastLocal = ob->isLastLocalFrame(curFrame);
+    ob->bLastFrameValid = true;
+    if (localIdx > 0) {
+        const bf_chunk_frame_record& rec = pkg->frames[localIdx];
+        ob->bLastFrameValid = rec.valid != 0;
+        if (rec.valid && rec.prevLocal >= 0) {                  // computeCurrentSiftTransform (:118-132) with the chunk's relative transform
+            m44 M; memcpy(M.e, rec.relInv, 64);
+            k_sift_transform_ext<<<1, 1, 0, ob->stream>>>(localIdx, ob->d_completeTrajectory, ob->lastValidCompleteTransform, ob->d_siftTrajectory, curFrame, rec.prevLocal, M,
+                                                         ob->d_currIntegrateTransform + curFrame);
+            BF_HIP_TRY(hipGetLastError());
+            BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT, ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
+            BF_HIP_TRY(hipStreamSynchronize(ob->stream));
+            ob->currIntegrateTransform[curFrame] = *ob->h_pinT;
+        }
+        if (!ob->bLastFrameValid) {
+            ob->currIntegrateTransform[curFrame] = minfM();
+            BF_HIP_TRY(hipMemcpyAsync(ob->d_siftTrajectory + curFrame, ob->d_siftTrajectory + curFrame - 1, sizeof(m44), hipMemcpyDeviceToDevice, ob->stream));
+        }
+    }
+    if (bIsLastLocal) {                                         // prepareLocalSolve (:134-165) without the bundler swap
+        BF_REQUIRE(localIdx + 1 == pkg->numFrames && pkg->numFrames == ob->submapSize + 1, "chunked mode needs complete chunks");
+        ob->processState = bf_online_bundler::DO_NOTHING;
+        const uint32_t curLocalIdx = (std::max(curFrame, 1u) - 1) / ob->submapSize;
+        if (pkg->chunkValid) { ob->localToSolve = (int)curLocalIdx; ob->processState = bf_online_bundler::PROCESS; }
+        else { ob->localToSolve = -((int)curLocalIdx + ID_MARK_OFFSET); ob->processState = bf_online_bundler::INVALIDATE; }
+    }
+    ob->lastFrameProcessed = (int)curFrame;
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, const uint8_t* d_color, const void* h_package, uint32_t localIdx, int* gotFrame) {
+    BF_REQUIRE(p && d_depth && d_color && h_package, "null argument");
+    BF_REQUIRE(!p->timings, "per-stage timings are not available in chunked mode");
+    BF_TRY(plFlush(p));                                         // (a pipeline is driven either serially or chunked; nothing is deferred in chunked mode)
+    const bf_chunk_header* pkg = reinterpret_cast<const bf_chunk_header*>(h_package);
+    hipStream_t sd = p->sDetect;
+    // ---- read input: the ingest filters produce the frame that is integrated (CUDAImageManager::process); no detection on this rank
+    int got = 0;
+    BF_TRY(bf_image_manager_process_device(p->im, d_depth, d_color, &got));
+    if (gotFrame) *gotFrame = got;
+    if (!got) return BF_OK;
+    const uint32_t frame = p->im->currFrame - 1;
+    BF_HIP_TRY(hipEventRecord(p->evIngest[frame % bf_pipeline::NEV], sd));
+    // ---- fix old frames, processInput, reconstruction of the current frame, bundling optimisation: plBodyRest with the package in place of m_local / m_optLocal
+    p->ob->extChunk = pkg;
+    int rc = obProcessInputChunked(p->ob, frame, pkg, localIdx);
+    if (rc == BF_OK) { p->ob->pendPhase = 2; rc = plBodyRest(p, frame, true); }      // phase 2: processInput already complete, _end has nothing to read back
+    p->ob->extChunk = nullptr;
+    BF_TRY(rc);
+    BF_HIP_TRY(hipEventSynchronize(p->evIngest[frame % bf_pipeline::NEV]));
+    return BF_OK;
+}
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <unordered_map>
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f, Frame fo)
     __shared__ uint32_t wsum[4];
     const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
+    if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) d.compactCount[1] = 0;      // the scatter pass (next launch) accumulates the operator blocks here
     for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
         uint32_t c = 0;
 #pragma unroll
@@ -572,6 +574,13 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame f
             }
             ++pos;
         }
+        if (MODE == 2) {           // blocks in the new pose's frustum + blocks in the old pose's: the two operators' list lengths (integer sum, order-free)
+            uint32_t ob = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) ob += (keep[k] & 1u) + ((keep[k] >> 1) & 1u);
+            ob = (uint32_t)wave_sum_i((int)ob);
+            if (lane == 0 && ob) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, ob);
+        }
         if (tile == numTiles - 1 && threadIdx.x == 0) {
             if (MODE != 1) d.compactCount[0] = (int32_t)(base + tileTotal);
             else d.tileCounts[numTiles] = base + tileTotal;      // new list length, committed by k_list_commit
@@ -615,8 +624,8 @@ BF_DEV bool voxelSample(const Frame& f, int4 e, int lx, int ly, int lz, const fl
 // round-to-nearest-even (one v_rndne instead of the five-instruction roundf; all 65536 (c, o) pairs are checked on the CPU in
 // tests/test_host_cpu.py).  De-integrate keeps the reference expressions: (o w - c) / (w - 1) has ties and its distance to a tie
 // shrinks with the weight (1 / (2 (w - 1))), so no shortcut is safe for long sequences.
-template <bool DEINT>
-BF_DEV void voxelApply(const Frame& f, float sdf, uchar4 cc, float& vSdf, float& vW, uint32_t& vC) {
+template <bool DEINT, class FR>
+BF_DEV void voxelApply(const FR& f, float sdf, uchar4 cc, float& vSdf, float& vW, uint32_t& vC) {
     const float c0 = (float)cc.x, c1 = (float)cc.y, c2 = (float)cc.z;
     const float oSdf = vSdf, oW = vW;
     const uint32_t oC = vC;
@@ -681,15 +690,13 @@ __global__ __launch_bounds__(512) void k_reupdate(Dev d, Frame f, Frame fo, cons
                                                   const uchar4* __restrict__ color, int accumulate) {
     if (color == nullptr) return;
     const uint32_t n = (uint32_t)d.compactCount[0];
-    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) d.occSum[2] += (unsigned long long)n;      // length of the union list: the blocks this launch visits once
+    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }      // union list length; operator blocks (counted by the compaction)
     const uint32_t i = threadIdx.x;
     const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
-    uint32_t opBlocks = 0;          // blocks of the de-integrate list + blocks of the integrate list handled by this workgroup
     for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
         const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];
         const uint32_t flags = reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4];
-        opBlocks += (flags & 1u) + ((flags >> 1) & 1u);
         float sdfDe = 0.0f, sdfIn = 0.0f; size_t pixDe = 0, pixIn = 0;
         const bool doDe = (flags & 2u) && voxelSample(fo, e, lx, ly, lz, depth, W, H, sdfDe, pixDe);
         const bool doIn = (flags & 1u) && voxelSample(f, e, lx, ly, lz, depth, W, H, sdfIn, pixIn);
@@ -703,7 +710,264 @@ __global__ __launch_bounds__(512) void k_reupdate(Dev d, Frame f, Frame fo, cons
         vp[1] = __float_as_uint(vW);
         vp[2] = vC;
     }
-    if (accumulate && threadIdx.x == 0 && opBlocks) atomicAdd(d.occSum, (unsigned long long)opBlocks);      // integer: order-independent
+}
+
+// ---------------------------------------------------------------------------------------
+// voxel update, column form: ONE WAVE per SDF block.  Lane (x, y) owns the z-column of 8 voxels and walks it in 4 steps of 2
+// voxels held in the two halves of packed-f32 registers (v_pk_mul/add/fma_f32: two IEEE operations per issue slot).
+//
+// Why: rocprofv3 SQ counters show the one-voxel-per-lane kernels above VALU-issue bound (profiles/r02_sq_tsdf_update.md: 234
+// vector instructions per 64 voxels, SQ_ACTIVE_INST_VALU ~ 86 % of the SIMD cycles), not HBM bound.  Per voxel the arithmetic is
+// unchanged — the same IEEE operation sequence as voxelSample / voxelApply, bit for bit — but
+//   * the terms of the camera transform that depend on (x, y) only are computed once per column, the z term once per wave;
+//   * the two divisions of the projection share one refined reciprocal, and so do the four of a de-integration: the quotient is
+//     formed by the instruction sequence the compiler emits for an IEEE f32 division (rcp, 2 FMA Newton step, q = n*r, two
+//     residual corrections) minus its v_div_scale / v_div_fmas / v_div_fixup range handling — identical bits whenever that range
+//     handling is the identity.  That is guaranteed per block by a wave-uniform bound on the camera-space coordinates (projection)
+//     and checked per value where the result is stored (TSDF quotients); anything else takes the literal `/`;
+//   * independent operations of the two voxels of a pair are packed.
+// A wave whose block fails the bound runs voxelSample / voxelApply for its 512 voxels (colExact).
+// ---------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+BF_DEV v2f sp2(float a) { v2f r; r.x = a; r.y = a; return r; }
+BF_DEV v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct UpdCam {            // the pose-independent part of Frame the voxel update reads (kernarg => SGPRs)
+    float fx, fy, mx, my;
+    float voxelSize, maxDist, truncScale, truncation, weightMax;
+    uint32_t W, H;
+};
+struct UpdPose {           // rows 0..2 of the world -> camera transform, plus host-computed bounds for the fast path
+    float R[9], t[3];
+    float rmax;            // max |R_ij|
+    uint32_t fastOk;       // pose and camera finite and moderate (see makeUpdPose)
+};
+
+// reciprocal refined by one Newton step: the first three operations of the f32 division expansion
+BF_DEV v2f rcpRefined(v2f d) {
+    v2f r; r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    const v2f e = pkfma(-d, r, sp2(1.0f));
+    return pkfma(e, r, r);
+}
+// n / d given r = rcpRefined(d): q = n*r and two residual corrections (the rest of the expansion).  Equals the IEEE quotient when
+// the hardware's operand scaling would be the identity (d, n and n/d normal and far from the ends of the exponent range).
+BF_DEV v2f divRefined(v2f n, v2f d, v2f r) {
+    v2f q = n * r;
+    v2f e = pkfma(-d, q, n);
+    q = pkfma(e, r, q);
+    e = pkfma(-d, q, n);
+    return pkfma(e, r, q);
+}
+// the same for a quotient whose bits are stored: values outside the proven range (zero included: the sign of a zero quotient) take `/`
+BF_DEV float divStored(float n, float d, float q) {
+    if (!(fabsf(n) >= 0x1p-60f && fabsf(n) <= 0x1p60f)) q = n / d;
+    return q;
+}
+
+struct ColPose { float t0, t1, t2; };      // (R_r0 * x + R_r1 * y) of this lane's column, r = 0..2
+
+BF_DEV ColPose colPose(const UpdPose& f, float xw, float yw) {
+    ColPose p;
+    p.t0 = f.R[0] * xw + f.R[1] * yw;
+    p.t1 = f.R[3] * xw + f.R[4] * yw;
+    p.t2 = f.R[6] * xw + f.R[7] * yw;
+    return p;
+}
+
+// wave-uniform: may every voxel of block e be projected with divRefined?  Camera-space z in [0.01, 4096], |x|, |y| <= 4096, all the
+// terms of the transform bounded by 4096 (so that rounding cannot eat the margins), intrinsics moderate (fastOk).
+BF_DEV bool blockFast(const UpdCam& c, const UpdPose& f, int4 e) {
+    const float s = 8.0f * c.voxelSize;
+    const float bx = (float)e.x * s, by = (float)e.y * s, bz = (float)e.z * s;
+    const float bmax = fmaxf(fmaxf(fabsf(bx), fabsf(by)), fabsf(bz)) + s;
+    const float x0 = f.R[0] * bx + f.R[1] * by + f.R[2] * bz + f.t[0];
+    const float y0 = f.R[3] * bx + f.R[4] * by + f.R[5] * bz + f.t[1];
+    const float z0 = f.R[6] * bx + f.R[7] * by + f.R[8] * bz + f.t[2];
+    const float spr = 3.0f * f.rmax * s;       // |pc(voxel) - pc(corner)| <= (|R_r0| + |R_r1| + |R_r2|) * 7 voxels
+    return f.fastOk && bmax * f.rmax <= 4096.0f && z0 - spr >= 0.01f && z0 + spr <= 4096.0f && fabsf(x0) + spr <= 4096.0f && fabsf(y0) + spr <= 4096.0f;
+}
+
+struct PairSample { v2f sdf; uint32_t cA, cB; bool okA, okB; };      // truncated signed distances, colour pixels, "voxel is updated"
+struct PairAddr { v2f pcz; uint32_t pixA, pixB; bool inA, inB; };       // camera-space z, pixel index, "projects into the image"
+
+// voxelSample for the two voxels (z, z + 1) of this lane's column, first half: projection.  pz = their world z coordinates
+BF_DEV PairAddr projectPair(const UpdCam& c, const UpdPose& f, const ColPose& p, v2f pz) {
+    const v2f pcx = (sp2(p.t0) + sp2(f.R[2]) * pz) + sp2(f.t[0]);
+    const v2f pcy = (sp2(p.t1) + sp2(f.R[5]) * pz) + sp2(f.t[1]);
+    PairAddr o;
+    o.pcz = (sp2(p.t2) + sp2(f.R[8]) * pz) + sp2(f.t[2]);
+    const v2f r = rcpRefined(o.pcz);
+    const v2f sx = divRefined(pcx * sp2(c.fx), o.pcz, r) + sp2(c.mx);
+    const v2f sy = divRefined(pcy * sp2(c.fy), o.pcz, r) + sp2(c.my);
+    const v2f hx = sx + sp2(0.5f), hy = sy + sp2(0.5f);
+    const uint32_t pxA = (uint32_t)f2i(hx.x), pyA = (uint32_t)f2i(hy.x), pxB = (uint32_t)f2i(hx.y), pyB = (uint32_t)f2i(hy.y);
+    o.inA = pxA < c.W && pyA < c.H; o.inB = pxB < c.W && pyB < c.H;
+    o.pixA = pyA * c.W + pxA; o.pixB = pyB * c.W + pxB;
+    return o;
+}
+// second half, after the depth (and, fetched alongside it, the colour) of the two pixels arrived
+BF_DEV PairSample finishPair(const UpdCam& c, const PairAddr& a, v2f dep, uint32_t cA, uint32_t cB) {
+    PairSample o;
+    o.cA = cA; o.cB = cB;
+    o.sdf = dep - a.pcz;
+    const v2f trunc = sp2(c.truncation) + sp2(c.truncScale) * dep;
+    o.okA = a.inA && dep.x != BF_MINF && dep.x < c.maxDist && fabsf(o.sdf.x) < trunc.x;
+    o.okB = a.inB && dep.y != BF_MINF && dep.y < c.maxDist && fabsf(o.sdf.y) < trunc.y;
+    return o;          // |sdf| < trunc already: the reference's clamp to [-trunc, trunc] is the identity
+}
+
+// fmaxf(0, fminf(x, 254.5)) as one v_med3_f32.  Equal for every non-NaN x; a NaN (de-integration of a voxel of weight <= 1, whose result
+// is reset afterwards) gives 254.5 there and an unspecified member of {0, 254.5} here - both in [0, 254.5], both thrown away.
+BF_DEV float clampByte(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 254.5f); }
+BF_DEV float byteF(uint32_t c, int k) { return (float)((c >> (8 * k)) & 0xFFu); }
+BF_DEV uint32_t packRGB(float r0, float r1, float r2) {       // r in [0, 254.5] after the clamps, never NaN
+    return (uint32_t)(int)r0 | ((uint32_t)(int)r1 << 8) | ((uint32_t)(int)r2 << 16) | 0xFF000000u;
+}
+
+// voxelApply<true> on the pair (lanes / halves where on* is false keep their voxel)
+BF_DEV void deintPair(v2f sdf, uint32_t cA, uint32_t cB, bool onA, bool onB, v2f& vS, v2f& vW, uint32_t& vCA, uint32_t& vCB) {
+    const v2f d = vW - sp2(1.0f);
+    const v2f r = rcpRefined(d);
+    float ra[3], rb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v2f o, c; o.x = byteF(vCA, k); o.y = byteF(vCB, k); c.x = byteF(cA, k); c.y = byteF(cB, k);
+        const v2f q = divRefined(o * vW - c, d, r);           // a zero or out-of-range quotient here dies in the clamp / the reset below
+        ra[k] = clampByte(roundf(q.x));
+        rb[k] = clampByte(roundf(q.y));
+    }
+    const v2f n = vS * vW - sdf;
+    const v2f q = divRefined(n, d, r);
+    float sA = divStored(n.x, d.x, q.x), sB = divStored(n.y, d.y, q.y);
+    float wA = fmaxf(0.0f, d.x), wB = fmaxf(0.0f, d.y);
+    uint32_t nA = packRGB(ra[0], ra[1], ra[2]), nB = packRGB(rb[0], rb[1], rb[2]);
+    if (wA <= 0.001f) { sA = 0.0f; nA = 0u; wA = 0.0f; }      // weights <= 1 (d <= 0: rcp gave inf / NaN) end here
+    if (wB <= 0.001f) { sB = 0.0f; nB = 0u; wB = 0.0f; }
+    if (onA) { vS.x = sA; vW.x = wA; vCA = nA; }
+    if (onB) { vS.y = sB; vW.y = wB; vCB = nB; }
+}
+
+// voxelApply<false> on the pair
+BF_DEV void intPair(float weightMax, v2f sdf, uint32_t cA, uint32_t cB, bool onA, bool onB, v2f& vS, v2f& vW, uint32_t& vCA, uint32_t& vCB) {
+    const v2f d = sp2(1.0f) + vW;                               // >= 1
+    const v2f r = rcpRefined(d);
+    float ra[3], rb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v2f o, c; o.x = byteF(vCA, k); o.y = byteF(vCB, k); c.x = byteF(cA, k); c.y = byteF(cB, k);
+        const v2f m = sp2(0.2f) * c + sp2(0.8f) * o;
+        const float a = vW.x == 0.0f ? c.x : m.x, b = vW.y == 0.0f ? c.y : m.y;
+        ra[k] = clampByte(__builtin_rintf(a));
+        rb[k] = clampByte(__builtin_rintf(b));
+    }
+    const v2f n = sdf + vS * vW;
+    const v2f q = divRefined(n, d, r);
+    const float sA = divStored(n.x, d.x, q.x), sB = divStored(n.y, d.y, q.y);
+    if (onA) { vS.x = sA; vW.x = fminf(weightMax, d.x); vCA = packRGB(ra[0], ra[1], ra[2]); }
+    if (onB) { vS.y = sB; vW.y = fminf(weightMax, d.y); vCB = packRGB(rb[0], rb[1], rb[2]); }
+}
+
+// voxelSample on (UpdCam, UpdPose): the literal operation sequence for one voxel — the path of blocks outside the proven range
+BF_DEV bool voxelSampleU(const UpdCam& c, const UpdPose& f, int4 e, int lx, int ly, int lz, const float* __restrict__ depth, float& sdf, uint32_t& pix) {
+    const float x = (float)(e.x * BS + lx) * c.voxelSize, y = (float)(e.y * BS + ly) * c.voxelSize, z = (float)(e.z * BS + lz) * c.voxelSize;
+    const float cx = f.R[0] * x + f.R[1] * y + f.R[2] * z + f.t[0] * 1.0f;
+    const float cy = f.R[3] * x + f.R[4] * y + f.R[5] * z + f.t[1] * 1.0f;
+    const float cz = f.R[6] * x + f.R[7] * y + f.R[8] * z + f.t[2] * 1.0f;
+    const float sx = cx * c.fx / cz + c.mx;
+    const float sy = cy * c.fy / cz + c.my;
+    const uint32_t px = (uint32_t)f2i(sx + 0.5f), py = (uint32_t)f2i(sy + 0.5f);
+    if (!(px < c.W && py < c.H)) return false;
+    pix = py * c.W + px;
+    const float dep = depth[pix];
+    if (dep == BF_MINF) return false;
+    if (!(dep < c.maxDist)) return false;
+    sdf = dep - cz;
+    const float trunc = c.truncation + c.truncScale * dep;
+    if (!(fabsf(sdf) < trunc)) return false;
+    if (sdf >= 0.0f) sdf = fminf(trunc, sdf); else sdf = fmaxf(-trunc, sdf);
+    return true;
+}
+
+// the literal per-voxel path for one block (512 voxels, 8 per lane)
+template <bool DE, bool IN>
+BF_DEV void colExact(const Dev& d, const UpdCam& c, const UpdPose& fIn, const UpdPose& fDe, int4 e, uint32_t flags, uint32_t lane, const float* __restrict__ depth,
+                     const uchar4* __restrict__ color) {
+    const int lx = (int)(lane & 7), ly = (int)(lane >> 3);
+#pragma unroll 1
+    for (int lz = 0; lz < 8; ++lz) {
+        float sdfDe = 0.0f, sdfIn = 0.0f; uint32_t pixDe = 0, pixIn = 0;
+        const bool doDe = DE && (flags & 2u) && voxelSampleU(c, fDe, e, lx, ly, lz, depth, sdfDe, pixDe);
+        const bool doIn = IN && (flags & 1u) && voxelSampleU(c, fIn, e, lx, ly, lz, depth, sdfIn, pixIn);
+        if (!doDe && !doIn) continue;
+        uint32_t* vp = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + (uint32_t)lz * 64u + lane));
+        float vSdf = __uint_as_float(vp[0]), vW = __uint_as_float(vp[1]);
+        uint32_t vC = vp[2];
+        if (doDe) voxelApply<true>(c, sdfDe, color[pixDe], vSdf, vW, vC);
+        if (doIn) voxelApply<false>(c, sdfIn, color[pixIn], vSdf, vW, vC);
+        vp[0] = __float_as_uint(vSdf); vp[1] = __float_as_uint(vW); vp[2] = vC;
+    }
+}
+
+template <bool DE, bool IN>
+BF_DEV void colFast(const Dev& d, const UpdCam& c, const UpdPose& fIn, const UpdPose& fDe, int4 e, uint32_t flags, uint32_t lane, const float* __restrict__ depth,
+                    const uint32_t* __restrict__ color) {
+    const float xw = (float)(e.x * BS + (int)(lane & 7)) * c.voxelSize, yw = (float)(e.y * BS + (int)(lane >> 3)) * c.voxelSize;
+    const bool useDe = DE && (flags & 2u), useIn = IN && (flags & 1u);       // wave-uniform
+    ColPose pDe = {0.0f, 0.0f, 0.0f}, pIn = {0.0f, 0.0f, 0.0f};
+    if (useDe) pDe = colPose(fDe, xw, yw);
+    if (useIn) pIn = colPose(fIn, xw, yw);
+    uint32_t* base = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + lane));
+#pragma unroll 1
+    for (int z = 0; z < 8; z += 2) {
+        // every load of the pair is issued before the first use: the two voxels (speculatively: ~1 in 4 is not touched), then depth AND
+        // colour of the projected pixels of both poses — one memory round trip per pair instead of five
+        uint32_t* vpA = base + (size_t)z * 64u * 3u; uint32_t* vpB = vpA + 64u * 3u;
+        v2f vS, vW; uint32_t vCA, vCB;
+        vS.x = __uint_as_float(vpA[0]); vW.x = __uint_as_float(vpA[1]); vCA = vpA[2];
+        vS.y = __uint_as_float(vpB[0]); vW.y = __uint_as_float(vpB[1]); vCB = vpB[2];
+        v2f pz; pz.x = (float)(e.z * BS + z) * c.voxelSize; pz.y = (float)(e.z * BS + z + 1) * c.voxelSize;
+        PairAddr aDe, aIn;
+        aDe.inA = aDe.inB = aIn.inA = aIn.inB = false; aDe.pixA = aDe.pixB = aIn.pixA = aIn.pixB = 0u; aDe.pcz = aIn.pcz = sp2(0.0f);
+        if (useDe) aDe = projectPair(c, fDe, pDe, pz);
+        if (useIn) aIn = projectPair(c, fIn, pIn, pz);
+        v2f dDe = sp2(BF_MINF), dIn = sp2(BF_MINF); uint32_t cDeA = 0u, cDeB = 0u, cInA = 0u, cInB = 0u;
+        if (aDe.inA) { dDe.x = depth[aDe.pixA]; cDeA = color[aDe.pixA]; }
+        if (aDe.inB) { dDe.y = depth[aDe.pixB]; cDeB = color[aDe.pixB]; }
+        if (aIn.inA) { dIn.x = depth[aIn.pixA]; cInA = color[aIn.pixA]; }
+        if (aIn.inB) { dIn.y = depth[aIn.pixB]; cInB = color[aIn.pixB]; }
+        const PairSample sDe = finishPair(c, aDe, dDe, cDeA, cDeB), sIn = finishPair(c, aIn, dIn, cInA, cInB);
+        const bool anyA = sDe.okA || sIn.okA, anyB = sDe.okB || sIn.okB;
+        if (!anyA && !anyB) continue;
+        if (DE && (sDe.okA || sDe.okB)) deintPair(sDe.sdf, sDe.cA, sDe.cB, sDe.okA, sDe.okB, vS, vW, vCA, vCB);
+        if (IN && (sIn.okA || sIn.okB)) intPair(c.weightMax, sIn.sdf, sIn.cA, sIn.cB, sIn.okA, sIn.okB, vS, vW, vCA, vCB);
+        if (anyA) { vpA[0] = __float_as_uint(vS.x); vpA[1] = __float_as_uint(vW.x); vpA[2] = vCA; }
+        if (anyB) { vpB[0] = __float_as_uint(vS.y); vpB[1] = __float_as_uint(vW.y); vpB[2] = vCB; }
+    }
+}
+
+// MODE 0 integrate (pose `in`), 1 de-integrate (pose `de`), 2 fused: de-integrate at `de`, then integrate at `in`, over the union
+// list with membership flags
+template <int MODE>
+__global__ __launch_bounds__(256) void k_update_col(Dev d, UpdCam c, UpdPose in, UpdPose de, const float* __restrict__ depth, const uchar4* __restrict__ color,
+                                                    int accumulate, int forceExact) {
+    if (color == nullptr) return;   // .cu:441-448: without colour data `color.x != MINF` never holds
+    constexpr bool DE = MODE != 0, IN = MODE != 1;
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), nWaves = gridDim.x * 4u;
+    if (accumulate && wave == 0 && lane == 0) {          // block accounting of the timed launches (bench.py); no atomics in the update itself
+        if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
+        else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
+    }
+    for (uint32_t blk = wave; blk < n; blk += nWaves) {
+        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];                                    // wave-uniform
+        const uint32_t flags = MODE == 2 ? reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4] : 3u;
+        bool fast = !forceExact;
+        if (DE && (flags & 2u)) fast = fast && blockFast(c, de, e);
+        if (IN && (flags & 1u)) fast = fast && blockFast(c, in, e);
+        if (fast) colFast<DE, IN>(d, c, in, de, e, flags, lane, depth, reinterpret_cast<const uint32_t*>(color));
+        else colExact<DE, IN>(d, c, in, de, e, flags, lane, depth, color);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -831,7 +1095,9 @@ struct bf_scene {
     hipStream_t stream = nullptr;
     uint32_t numIntegrated = 0;
     uint32_t dedupeSize = 0;
-    uint32_t gridCompact = 0, gridUpdate = 0;
+    uint32_t gridCompact = 0, gridUpdate = 0, gridUpdateCol = 0;
+    bool columnUpdate = true;       // k_update_col (one wave per block); false: the one-voxel-per-lane kernels (BF_TSDF_UPDATE=voxel)
+    bool forceExactDiv = false;     // k_update_col takes the literal `/` path for every block (BF_TSDF_EXACT_DIV=1; tests)
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
@@ -882,6 +1148,29 @@ Frame makeFrame(const bf_scene* s) {
     f.weightMax = (float)s->params.m_integrationWeightMax;
     f.shardLo = s->shardLo; f.shardHi = s->shardHi;
     return f;
+}
+
+UpdCam makeUpdCam(const Frame& f) {
+    UpdCam u;
+    u.fx = f.cam.fx; u.fy = f.cam.fy; u.mx = f.cam.mx; u.my = f.cam.my;
+    u.voxelSize = f.voxelSize; u.maxDist = f.maxIntegrationDistance; u.truncScale = f.truncScale; u.truncation = f.truncation; u.weightMax = f.weightMax;
+    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight;
+    return u;
+}
+UpdPose makeUpdPose(const Frame& f) {
+    UpdPose u;
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) u.R[r * 3 + c] = f.Tinv.e[r * 4 + c]; u.t[r] = f.Tinv.e[r * 4 + 3]; }
+    float rmax = 0.0f; bool ok = true;
+    for (int i = 0; i < 9; ++i) { ok = ok && std::isfinite(u.R[i]); rmax = std::max(rmax, std::fabs(u.R[i])); }
+    for (int i = 0; i < 3; ++i) ok = ok && std::isfinite(u.t[i]) && std::fabs(u.t[i]) <= 4096.0f;
+    u.rmax = rmax;
+    // the ranges under which the shared-reciprocal quotients of colFast are the IEEE quotients (see the kernel's header comment)
+    const UpdCam c = makeUpdCam(f);
+    ok = ok && rmax <= 16.0f && c.fx >= 0x1p-10f && c.fx <= 0x1p20f && c.fy >= 0x1p-10f && c.fy <= 0x1p20f && std::isfinite(c.mx) && std::isfinite(c.my) &&
+         c.voxelSize >= 1e-6f && c.voxelSize <= 16.0f && c.weightMax >= 1.0f && c.weightMax <= 0x1p39f && std::isfinite(c.truncation) && std::isfinite(c.truncScale) &&
+         std::isfinite(c.maxDist);
+    u.fastOk = ok ? 1u : 0u;
+    return u;
 }
 
 void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepHashSDF.h:128-134
@@ -977,7 +1266,14 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     }
     const uchar4* color = reinterpret_cast<const uchar4*>(data->d_colorData);
     const int acc = s->timing ? 1 : 0;
-    if (kind == 0) hipLaunchKernelGGL(k_update<false>, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, data->d_depthData, color, acc);
+    if (s->columnUpdate) {
+        const UpdCam uc = makeUpdCam(f);
+        const UpdPose pin = makeUpdPose(f), pde = makeUpdPose(kind == 2 ? fo : f);
+        const int fe = s->forceExactDiv ? 1 : 0;
+        if (kind == 0) hipLaunchKernelGGL(k_update_col<0>, dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, uc, pin, pde, data->d_depthData, color, acc, fe);
+        else if (kind == 1) hipLaunchKernelGGL(k_update_col<1>, dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, uc, pin, pde, data->d_depthData, color, acc, fe);
+        else hipLaunchKernelGGL(k_update_col<2>, dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, uc, pin, pde, data->d_depthData, color, acc, fe);
+    } else if (kind == 0) hipLaunchKernelGGL(k_update<false>, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, data->d_depthData, color, acc);
     else if (kind == 1) hipLaunchKernelGGL(k_update<true>, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, data->d_depthData, color, acc);
     else hipLaunchKernelGGL(k_reupdate, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, fo, data->d_depthData, color, acc);
     if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
@@ -1025,7 +1321,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     A(s->d.vox, N * VOX);
     A(s->cbuf[0], N); A(s->cbuf[1], N);
     A(s->csrc[0], N); A(s->csrc[1], N);
-    A(s->ccnt[0], 1); A(s->ccnt[1], 1);
+    A(s->ccnt[0], 4); A(s->ccnt[1], 4);      // [0] list length, [1] operator blocks of a union list (entries in the new frustum + entries in the old one)
     A(s->d.occSum, 3);
     A(s->d.allocList, N);
     A(s->d.allocListAlt, N);
@@ -1053,6 +1349,10 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
     s->gridUpdate = 256 * 16;    // persistent 512-thread workgroups, 16 per CU: measured optimum with the feature pipeline running concurrently (2048: -4 %, 8192: -2 %, 16384: -25 %)
     if (const char* e = getenv("BF_GRID_UPDATE")) s->gridUpdate = (uint32_t)atoi(e);      // tuning knob (experiments)
+    s->gridUpdateCol = 256 * 16;  // persistent 256-thread workgroups (4 waves = 4 blocks in flight each)
+    if (const char* e = getenv("BF_GRID_UPDATE_COL")) s->gridUpdateCol = (uint32_t)atoi(e);
+    if (const char* e = getenv("BF_TSDF_UPDATE")) s->columnUpdate = strcmp(e, "voxel") != 0;
+    if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     *out = s;
     return bf_scene_reset(s);
 }
@@ -1098,8 +1398,8 @@ int bf_scene_reset(bf_scene* s) {                                  // CUDASceneR
     s->params.m_numOccupiedBlocks = 0;
     BF_TRY_RC(syncAll(s));
     s->compactStale = false; s->updRecorded[0] = s->updRecorded[1] = false; s->barrierPending = false; s->pendingEv = nullptr;
-    BF_HIP_TRY(hipMemsetAsync(s->ccnt[0], 0, 4, s->stream));
-    BF_HIP_TRY(hipMemsetAsync(s->ccnt[1], 0, 4, s->stream));
+    BF_HIP_TRY(hipMemsetAsync(s->ccnt[0], 0, 16, s->stream));
+    BF_HIP_TRY(hipMemsetAsync(s->ccnt[1], 0, 16, s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
     BF_HIP_TRY(hipMemsetAsync(s->d.vox, 0, (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel), s->stream));
     hipLaunchKernelGGL(k_reset, dim3(2048), dim3(256), 0, s->stream, s->d, s->params.m_numSDFBlocks, (uint32_t)numEntries,

@@ -6,7 +6,95 @@
   bit-deterministic bundling redundantly (replicated solve, 8e-3) and integrates only its hash-bucket shard of ONE volume
   (bf_scene_set_shard).  Poses need no exchange because they are bit-identical on every rank; `same_over_ranks` verifies
   exactly that with one MIN/MAX all-reduce of the trajectory after the run.
+
+* "chunks" (strong scaling of ONE stream, SURVEY.md 8e-1 + 8e-2 + 8e-3; bench.py --gpus N default): local chunks are dealt
+  round-robin to the ranks (`chunk_owner`); each rank runs the chunk-local half (SIFT, matching inside the chunk, local solve,
+  key-frame fusion: capi.ChunkWorker) for its chunks; one all-gather per round of `world` chunks hands every package to every rank
+  (`gather_packages`: RCCL over xGMI, ~0.4 MB per chunk); then every rank runs the global half on all packages in stream order and
+  integrates into its hash-bucket shard of the one volume (`run_chunked`).  The global solve is replicated (it is deterministic, so
+  the pose update needs no further exchange; `same_over_ranks` checks it).
 """
+
+
+def chunk_owner(chunk, world, first_chunk=0):
+    """Rank that runs the chunk-local half of local chunk `chunk`: round robin inside rounds of `world` consecutive chunks."""
+    return (chunk - first_chunk) % world
+
+
+def chunk_frames(chunk, submap):
+    """Stream frames [first, last] of local chunk `chunk`: submap + 1 frames, the first shared with the previous chunk."""
+    return chunk * submap, chunk * submap + submap
+
+
+def gather_packages(mine, world, rank, device=None):
+    """All-gather of one round of chunk packages: `mine` (uint8 numpy array, zeros when this rank had no chunk in the round) ->
+    list of `world` arrays indexed by owner rank.  One collective per round; identity for world == 1."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return [mine]
+    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.from_numpy(mine).to(dev)
+    out = torch.empty((world, t.numel()), dtype=torch.uint8, device=dev)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, t)                 # one RCCL all-gather (ring over xGMI)
+    else:
+        dist.all_gather(list(out.unbind(0)), t)             # gloo (CPU tests)
+    host = out.cpu().numpy()
+    return [np.ascontiguousarray(host[r]) for r in range(world)]
+
+
+class ChunkedRunner:
+    """Drives one rank of the chunk-parallel mode.  `pipe` has its volume sharded with set_volume_shard(rank, world); `feed` is the whole
+    stream as (depth, colour) cuda tensors.  advance(n) pushes the next n frames of the stream through the global half; whenever a frame
+    of a local chunk without a package is reached, the round of `world` chunks containing it is produced: local half of this rank's
+    chunk of the round (capi.ChunkWorker), then ONE all-gather.  Every rank must call advance() with the same arguments."""
+
+    def __init__(self, pipe, worker, feed, submap, rank=0, world=1, device=None):
+        self.pipe, self.worker, self.feed, self.S = pipe, worker, feed, submap
+        self.rank, self.world, self.device = rank, world, device
+        self.next_frame = 0
+        self.pkgs = {}
+        self.rounds = 0
+        self.local_chunks = 0
+
+    def frames_needed(self, upto_frame):
+        """Stream length needed to advance to `upto_frame` frames: the last round's chunks must be complete."""
+        last_chunk = 0 if upto_frame <= 1 else (upto_frame - 2) // self.S
+        round_end = (last_chunk // self.world + 1) * self.world
+        return round_end * self.S + 1
+
+    def _ensure(self, chunk):
+        import numpy as np
+        if chunk in self.pkgs:
+            return
+        r0 = chunk - chunk % self.world
+        mine = np.zeros(self.worker.package_bytes, np.uint8)
+        c_mine = r0 + self.rank
+        a, b = chunk_frames(c_mine, self.S)
+        if b < len(self.feed):
+            self.worker.run(c_mine, self.feed[a:b + 1], out=mine)
+            self.local_chunks += 1
+        got = gather_packages(mine, self.world, self.rank, self.device)
+        self.rounds += 1
+        for i, p in enumerate(got):
+            self.pkgs[r0 + i] = p
+
+    def advance(self, n):
+        for f in range(self.next_frame, self.next_frame + n):
+            c = 0 if f == 0 else (f - 1) // self.S
+            self._ensure(c)
+            assert self.pipe.process_frame_chunked(self.feed[f][0], self.feed[f][1], self.pkgs[c], f - c * self.S)
+            for old in [k for k in self.pkgs if k < c - self.world]:
+                del self.pkgs[old]
+        self.next_frame += n
+        return n
+
+
+def run_chunked(pipe, worker, feed, submap, rank=0, world=1, device=None):
+    """The whole stream `feed` (1 + k * submap frames) through ChunkedRunner; returns the number of frames processed."""
+    return ChunkedRunner(pipe, worker, feed, submap, rank, world, device).advance(len(feed))
 
 
 def segment(rank, world, frames_per_rank):

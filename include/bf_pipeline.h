@@ -263,6 +263,57 @@ BF_API int bf_pipeline_get_host_profile(bf_pipeline* p, double out[8], int reset
 BF_API int bf_pipeline_enable_timings(bf_pipeline* p, int enable);
 BF_API int bf_pipeline_get_last_timing(bf_pipeline* p, bf_frame_timing* out);
 
+/* ------------------------------------------------------------------------- */
+/* Chunk-parallel bundling (multi-GPU partition of ONE stream) */
+/*                                                                             */
+/* Everything OnlineBundler does for a frame BEFORE the global step reads only */
+/* the frames of its own local chunk: ingest, SIFT, cache frame, matching and   */
+/* filtering against the chunk (Bundler::matchAndFilter on m_local,             */
+/* OnlineBundler.cpp:118-127), the local solve (:242-271) and the fusion into   */
+/* one key frame (SIFTImageManager::fuseToGlobal, .cpp:414-476).  A             */
+/* bf_chunk_worker runs exactly that for one chunk and returns the result as a  */
+/* flat host package; local chunks are dealt round-robin to the ranks, the       */
+/* packages are all-gathered (RCCL), and every rank then runs the global half    */
+/* (pose chaining, global match + solve, TrajectoryManager, re-integration       */
+/* scheduling) on all packages in stream order with                              */
+/* bf_pipeline_process_frame_chunked, integrating into its hash-bucket shard of  */
+/* the volume.  Results are those of the serial loop, bit for bit.               */
+/* ------------------------------------------------------------------------- */
+#define BF_CHUNK_MAX_FRAMES 32u          /* s_submapSize + 1 must not exceed this */
+#define BF_CHUNK_MAGIC 0x4B434642u       /* "BFCK" */
+
+typedef struct bf_chunk_frame_record {   /* what processInput learns about one frame from its chunk (OnlineBundler.cpp:118-132, OnlineBundler.cu:5-52) */
+    int32_t valid;                       /* matchAndFilter returned a previous frame of the chunk (lastMatchedFrame != -1) */
+    int32_t prevLocal;                   /* local index of the previous frame the SIFT pose chains from: the largest i with filtered matches; -1 if none */
+    float relInv[16];                    /* d_currFilteredTransformsInv[prevLocal] */
+} bf_chunk_frame_record;
+
+typedef struct bf_chunk_header {
+    uint32_t magic, chunkIndex, numFrames /* frames of the chunk, the one shared with the previous chunk included */, submapSize;
+    int32_t chunkValid;                  /* Bundler::isValid() of the chunk before its solve (OnlineBundler.cpp:147) */
+    int32_t solveValid;                  /* Bundler::optimize() verdict (.cpp:255); 0 when the chunk was not solved */
+    uint32_t numKeys, maxKeys, cacheWidth, cacheHeight;
+    int32_t validImages[BF_CHUNK_MAX_FRAMES];                 /* getValidImages() of the chunk after the solve */
+    float localTrajectory[BF_CHUNK_MAX_FRAMES * 16];          /* the chunk's optimised poses (getTrajectoryGPU) */
+    bf_chunk_frame_record frames[BF_CHUNK_MAX_FRAMES];
+    uint64_t offKeys, offDescs;          /* fused key frame: numKeys x 16 B key points, numKeys x 128 B descriptors (byte offsets from the package start) */
+    uint64_t offCache[6];                /* cache frame of the chunk's first image: depth, camera positions, intensity, derivatives, normals u8x4, normals f32x4 */
+    uint64_t totalBytes;
+} bf_chunk_header;
+
+typedef struct bf_chunk_worker bf_chunk_worker;
+BF_API int bf_chunk_worker_create(const bf_global_app_state* gas, const bf_global_bundling_state* gbs, const bf_rgbd_sensor_desc* sensor, bf_chunk_worker** out);
+BF_API int bf_chunk_worker_destroy(bf_chunk_worker* w);
+BF_API int bf_chunk_worker_set_stream(bf_chunk_worker* w, void* hip_stream);
+BF_API int bf_chunk_worker_package_bytes(bf_chunk_worker* w, uint64_t* bytes);        /* size of one package (fixed for a configuration) */
+/* the chunk-local half of the loop for chunk `chunkIndex`: numFrames device frames in stream order (frames chunkIndex*S .. chunkIndex*S + numFrames-1) */
+BF_API int bf_chunk_worker_run(bf_chunk_worker* w, uint32_t chunkIndex, uint32_t numFrames, const float* const* d_depth, const uint8_t* const* d_colorRGBX,
+                               void* h_package);
+/* one iteration of the frame loop for the next frame of the stream, whose chunk-local half is in `h_package` (localIdx = index of the frame in that
+ * package's chunk; 0 only for the very first frame).  Ingest for integration, pose chaining, integration / re-integration into this pipeline's volume
+ * (shard), and — at the chunk's last frame — the global step.  The stream must hold 1 + k * s_submapSize frames. */
+BF_API int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, const uint8_t* d_colorRGBX, const void* h_package, uint32_t localIdx, int* gotFrame);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,78 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert all(r[5] == "1" and r[6] == "0" for r in rows)                   # bit-identical tensors pass, a 1-ulp difference is caught
 
 
+_CHUNK_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from bundlefusion_amd.shard import ChunkedRunner, chunk_owner, chunk_frames
+
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+S = 10
+
+
+class FakeWorker:                      # a package = 64 bytes tagged with (producing rank, chunk, first frame, last frame)
+    package_bytes = 64
+    def __init__(self): self.ran = []
+    def run(self, chunk, frames, out=None):
+        assert len(frames) == S + 1 and frames[0] == chunk * S and frames[-1] == chunk * S + S      # the chunk's frames, first one shared
+        out[:] = 0
+        out[:16].view(np.int32)[:] = [r, chunk, frames[0], frames[-1]]
+        self.ran.append(chunk)
+        return out
+
+
+class FakePipe:
+    def __init__(self): self.log = []
+    def process_frame_chunked(self, d, c, pkg, j):
+        tag = pkg[:16].view(np.int32)
+        self.log.append((int(d), int(tag[0]), int(tag[1]), j))
+        return True
+
+
+class Frame(int):
+    pass
+
+
+n = 1 + 5 * S                                  # 5 local chunks over 2 ranks: the last round is half empty
+runner = ChunkedRunner(FakePipe(), FakeWorker(), None, S, r, w, device="cpu")
+feed = [(Frame(i), Frame(i)) for i in range(runner.frames_needed(n))]
+runner.feed = feed
+# the worker of this test takes frame numbers: hand it the first element of each pair
+orig_run = runner.worker.run
+runner.worker.run = lambda chunk, frames, out=None: orig_run(chunk, [int(f[0]) for f in frames], out)
+runner.advance(7); runner.advance(n - 7)       # any split of the stream gives the same schedule
+log = runner.pipe.log
+ok_order = [f for f, _, _, _ in log] == list(range(n))
+ok_owner = all(prod == chunk_owner(c, w) and c == (0 if f == 0 else (f - 1) // S) and j == f - c * S for f, prod, c, j in log)
+os.write(1, ("CHUNKS {} {} {} {} {} {}\n".format(r, int(ok_order), int(ok_owner), ",".join(map(str, runner.worker.ran)), runner.rounds, len(feed))).encode())
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_chunk_parallel_schedule(tmp_path):
+    """Chunk-parallel mode across 2 processes (gloo, CPU): local chunks go round robin to the ranks, one all-gather per round of
+    `world` chunks delivers every package to every rank in owner order, and every rank then walks ALL frames in stream order with
+    the package of the frame's chunk (fake worker / pipeline objects record the schedule)."""
+    script = tmp_path / "chunk_worker.py"
+    script.write_text(_CHUNK_WORKER % ROOT)
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = sorted(l.split()[1:] for l in out.stdout.splitlines() if l.startswith("CHUNKS"))
+    assert len(rows) == 2
+    assert all(r[1] == "1" and r[2] == "1" for r in rows)                    # every frame once, in order, with the right package and local index
+    assert rows[0][3] == "0,2,4" and rows[1][3] == "1,3,5"                   # round robin (chunk 5 lies beyond the stream's 5 chunks but inside the last round)
+    assert all(r[4] == "3" and r[5] == "61" for r in rows)                   # 3 rounds = 3 collectives; the stream is extended to complete the last round
+
+
 def test_cpp_header_classes_compile_and_link(built, tmp_path):
     """include/bundlefusion/bundlefusion.hpp (reference class names over the C ABI) builds with plain g++ — no HIP headers
     needed on the integrator's side — and every forwarded symbol resolves against libbf_hip.so."""

@@ -279,3 +279,57 @@ def test_volume_shard_mode_equals_single_volume(gpu, oracle):
     assert c0 == c1 == c2 and c0["deintegrate"] > 5
     assert not (b1.keys() & b2.keys()) and (b1.keys() | b2.keys()) == b0.keys() and len(b1) > 50 and len(b2) > 50
     assert all((b1.get(k) or b2.get(k)) == v for k, v in b0.items())
+
+
+def test_chunk_parallel_mode_equals_serial_loop(gpu, oracle):
+    """The multi-GPU partition of ONE stream, emulated on one GPU: local chunks are processed by a
+    bf_chunk_worker (SIFT, matching inside the chunk, local solve, key-frame fusion) and reach the pipelines as packages; G
+    pipelines, each owning one hash-bucket shard of the volume, run the global half on the packages in stream order.  Against the
+    serial loop on the same stream: the same trajectories bit for bit, the same operation counts, and the union of the shards is
+    the serial volume bit for bit."""
+    import torch
+    from bundlefusion_amd import shard
+    from bundlefusion_amd.capi import FREE_ENTRY, VOX_PER_BLOCK
+    n = 41                                       # 4 local chunks: 1 + 4 * s_submapSize frames
+    src = synth.render_frames(range(n))
+    Kd = src[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in src]
+
+    def snapshot(p):
+        p.synchronize()
+        gh, gheap, gcnt, gvox = p.scene().download()
+        occ = gh[gh["ptr"] != FREE_ENTRY]
+        blocks = {tuple(int(v) for v in e["pos"]): gvox[int(e["ptr"]):int(e["ptr"]) + VOX_PER_BLOCK].tobytes() for e in occ}
+        return p.integrated_trajectory().copy(), p.optimized_trajectory().copy(), p.counters(), blocks
+
+    gas, gbs = _params()
+    serial = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    for d, c in dev:
+        assert serial.process_frame(d, c)
+    for _ in range(3):
+        serial.process_end_of_sequence()
+    t0, o0, c0, b0 = snapshot(serial)
+    del serial
+    assert c0["deintegrate"] > 20 and c0["global_solves"] >= 3 and np.isfinite(t0[:, 0, 0]).all()
+
+    G = 2
+    gas, gbs = _params()
+    worker = gpu.capi.ChunkWorker(gas, gbs, sensor_desc(W, H, K))
+    shards = []
+    for r in range(G):
+        gas, gbs = _params()
+        p = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+        p.set_volume_shard(r, G)
+        assert shard.run_chunked(p, worker, dev, gbs.s_submapSize) == n
+        for _ in range(3):
+            p.process_end_of_sequence()
+        shards.append(snapshot(p))
+        del p
+    for t, o, c, b in shards:
+        assert np.array_equal(t.view(np.uint32), t0.view(np.uint32)), "integrated trajectory differs from the serial loop"
+        assert np.array_equal(o.view(np.uint32), o0.view(np.uint32)), "optimised trajectory differs from the serial loop"
+        assert c == c0
+    b1, b2 = shards[0][3], shards[1][3]
+    assert not (b1.keys() & b2.keys()) and (b1.keys() | b2.keys()) == b0.keys() and len(b1) > 50 and len(b2) > 50
+    assert all((b1.get(k) or b2.get(k)) == v for k, v in b0.items())

@@ -263,3 +263,76 @@ def test_hash_bucket_shards_partition_the_volume(gpu, oracle):
     for s in scenes:
         dbg = s.debug_hash()
         assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0 and dbg["dropped"] == 0
+
+
+def _volume_bytes(gs):
+    gh, gheap, gcnt, gvox = gs.download()
+    return gh.tobytes(), gheap.tobytes(), gcnt, gvox.tobytes()
+
+
+def test_column_update_kernel_equals_voxel_kernel_and_exact_division_path(gpu, oracle, monkeypatch):
+    """The three implementations of the voxel update — one voxel per lane (k_update / k_reupdate), one wave per block with shared
+    refined reciprocals (k_update_col, the default), and k_update_col forced onto its literal-division path — produce the same
+    volume bit for bit at the bench configuration (640x480, 4 mm): integrations, fused re-integrations, a plain de-integration,
+    garbage collection; and all equal the oracle."""
+    import torch
+    W, H = 640, 480
+    frames = [synth.scene_room(k * 9, W, H) for k in range(5)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=400000, num_sdf_blocks=120000, voxel_size=0.004)
+    dev = [_to_dev(f[0], f[1]) for f in frames]
+    rng = np.random.default_rng(5)
+
+    def script(sc, integ, deint, reint):
+        poses = [f[2].copy() for f in frames]
+        for i in range(len(frames)):
+            integ(i, poses[i])
+        for i in (1, 3, 4):
+            T2 = poses[i].copy(); T2[:3, 3] += np.float32(0.004) * (i + 1); T2[0, 1] += np.float32(1e-4)
+            reint(i, poses[i], T2); poses[i] = T2
+        deint(0, poses[0])
+        sc.garbage_collect()
+
+    results = {}
+    for name, env in (("voxel", {"BF_TSDF_UPDATE": "voxel"}), ("column", {}), ("column-exact", {"BF_TSDF_EXACT_DIV": "1"})):
+        for k in ("BF_TSDF_UPDATE", "BF_TSDF_EXACT_DIV"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gs = gpu.capi.SceneRepHashSDF(p)
+        script(gs, lambda i, T: gs.integrate(T, dev[i][0], dev[i][1], cam), lambda i, T: gs.deintegrate(T, dev[i][0], dev[i][1], cam),
+               lambda i, T0, T1: gs.reintegrate(T0, T1, dev[i][0], dev[i][1], cam))
+        results[name] = _volume_bytes(gs)
+        assert gs.num_allocated_blocks() > 20000
+        del gs
+    assert results["voxel"] == results["column"], "column kernel differs from the one-voxel-per-lane kernel"
+    assert results["column"] == results["column-exact"], "shared-reciprocal quotients differ from the literal division"
+    osc = oracle.OracleScene(p)
+
+    def o_re(i, T0, T1):
+        osc.deintegrate(T0, frames[i][0], frames[i][1], cam, threads=64); osc.integrate(T1, frames[i][0], frames[i][1], cam, threads=64)
+    script(osc, lambda i, T: osc.integrate(T, frames[i][0], frames[i][1], cam, threads=64), lambda i, T: osc.deintegrate(T, frames[i][0], frames[i][1], cam, threads=64), o_re)
+    assert results["column"][0] == osc.hash().tobytes() and results["column"][3] == osc.voxels().tobytes()
+
+
+def test_column_update_blocks_outside_the_fast_range(gpu, oracle, monkeypatch):
+    """Blocks whose camera-space z comes closer than 1 cm (a surface 3 cm in front of a sensor whose near plane is 0) fail the
+    wave-uniform range test of k_update_col and take the literal path, next to blocks that pass it: same bits as the oracle."""
+    for k in ("BF_TSDF_UPDATE", "BF_TSDF_EXACT_DIV"):
+        monkeypatch.delenv(k, raising=False)
+    W, H = 160, 120
+    depth, color, T, K = synth.scene_wall(W, H)
+    near = np.where(np.isfinite(depth), np.float32(0.012) + (depth - np.float32(2.0)) * np.float32(0.05), depth).astype(np.float32)
+    near[:, W // 2:] = np.where(np.isfinite(depth[:, W // 2:]), depth[:, W // 2:] * np.float32(0.5), depth[:, W // 2:])      # right half: 1 m away (fast range)
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"], dmin=0.0, dmax=4.0)
+    p = default_hash_params(num_buckets=100000, num_sdf_blocks=40000, voxel_size=0.004, truncation=0.01, trunc_scale=0.01)
+    gs = gpu.capi.SceneRepHashSDF(p)
+    osc = oracle.OracleScene(p)
+    d, c = _to_dev(near, color)
+    T2 = T.copy(); T2[2, 3] += np.float32(0.002)
+    gs.integrate(T, d, c, cam); osc.integrate(T, near, color, cam)
+    gs.reintegrate(T, T2, d, c, cam); osc.deintegrate(T, near, color, cam); osc.integrate(T2, near, color, cam)
+    assert_same_state(gs, osc, "near-plane blocks:")
+    vox = gs.download()[3]
+    assert (vox["weight"] > 0).sum() > 10000
