@@ -1131,6 +1131,23 @@ int bf_solver_get_var_to_corr_num_entries_per_row(bf_solver* s, const int32_t** 
     return BF_OK;
 }
 
+// The reference's per-image correspondence table holds m_maxCorrPerImage slots per image (CUDASolverBundling.cpp:39); correspondences
+// beyond that are invalidated in atomic arrival order ("AT RANDOM", .cpp:195-199, SolverBundling.cu:1226-1248).  The block-sparse
+// system here has no such limit and uses every correspondence; this call tells an integrator whether the reference would have
+// dropped some in the last solve: the number of images whose correspondence count exceeds the limit, and the limit.
+int bf_solver_get_corr_overflow(bf_solver* s, uint32_t* numImagesOverLimit, uint32_t* limit) {
+    BF_REQUIRE(s && numImagesOverLimit, "null argument");
+    if (limit) *limit = s->maxCorrPerImage;
+    *numImagesOverLimit = 0;
+    const uint32_t N = s->lastN;
+    if (N == 0) return BF_OK;
+    std::vector<int> rows(N);                 // the table of the last solve's start (k_row_entries)
+    BF_HIP_TRY(hipMemcpyAsync(rows.data(), s->d.numEntriesPerRow, sizeof(int) * N, hipMemcpyDeviceToHost, s->stream));
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int r : rows) if ((uint32_t)std::max(r, 0) > s->maxCorrPerImage) (*numImagesOverLimit)++;
+    return BF_OK;
+}
+
 int bf_solver_get_max_residual(bf_solver* s, float* mx, int32_t* idx) {
     BF_REQUIRE(s && mx && idx, "null argument");
     *mx = s->hMaxRes; *idx = s->hMaxIdx;

@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
         const bool useFile = gas.s_sensorIdx == 8;
         if (useFile) reader.createFirstConnected();
         RGBDSensor& sensor = useFile ? static_cast<RGBDSensor&>(reader) : static_cast<RGBDSensor&>(dummy);
-        CUDAImageManager imageManager(gas.s_integrationWidth, gas.s_integrationHeight, gbs.s_widthSIFT, gbs.s_heightSIFT, &sensor);
+        CUDAImageManager imageManager(gas.s_integrationWidth, gas.s_integrationHeight, gbs.s_widthSIFT, gbs.s_heightSIFT, &sensor, /*storeFramesOnGPU=*/true);
         OnlineBundler bundler(&sensor, &imageManager);
         CUDASceneRepHashSDF sceneRep(CUDASceneRepHashSDF::parametersFromGlobalAppState(gas));
         DepthCameraParams cam;                                  // DepthSensing.cpp:636-643

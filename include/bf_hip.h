@@ -281,6 +281,9 @@ BF_API int bf_solver_solve(bf_solver* s, bf_entry_j* d_correspondences, uint32_t
 /* getVarToCorrNumEntriesPerRow(): device int[numberOfImages], #valid correspondences touching each image at the
  * last solve                                                    CUDASolverBundling.h:48 */
 BF_API int bf_solver_get_var_to_corr_num_entries_per_row(bf_solver* s, const int32_t** d_out);
+/* m_maxCorrPerImage (CUDASolverBundling.cpp:39): the reference invalidates correspondences beyond this many per image in atomic arrival
+ * order (.cpp:195-199); this solver uses all of them.  *numImagesOverLimit = images of the last solve whose count exceeds the limit. */
+BF_API int bf_solver_get_corr_overflow(bf_solver* s, uint32_t* numImagesOverLimit, uint32_t* limit);
 /* getMaxResidual(max, index)                                   CUDASolverBundling.h:37-40 */
 BF_API int bf_solver_get_max_residual(bf_solver* s, float* max, int32_t* index);
 /* getMaxResidual(curFrame, d_corr, imageIndices, maxRes) -> remove?   .cpp:429-452 */

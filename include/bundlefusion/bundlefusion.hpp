@@ -451,7 +451,7 @@ public:
         std::vector<float> m_depthCPU; std::vector<unsigned char> m_colorCPU;
     };
     CUDAImageManager(unsigned int widthIntegration, unsigned int heightIntegration, unsigned int widthSIFT, unsigned int heightSIFT, RGBDSensor* sensor,
-                     bool storeFramesOnGPU = true) : m_sensor(sensor) {
+                     bool storeFramesOnGPU = false) : m_sensor(sensor) {      // default as CUDAImageManager.h:140; pass true to keep every frame resident in HBM (what bf_pipeline does)
         check(bf_image_manager_create(widthIntegration, heightIntegration, widthSIFT, heightSIFT, &sensor->desc(), &GlobalBundlingState::get(), storeFramesOnGPU, &m_h));
     }
     ~CUDAImageManager() { bf_image_manager_destroy(m_h); }

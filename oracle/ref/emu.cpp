@@ -10,38 +10,77 @@ thread_local uint3 threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 
 namespace {
-struct Fiber { ucontext_t ctx; std::vector<char> stack; bool done = false; uint3 tid; };
+enum State { READY, AT_BARRIER, AT_SHFL, DONE };
+struct Fiber {
+    ucontext_t ctx; std::vector<char> stack; State state = READY; uint3 tid;
+    unsigned shflCount = 0;        // shuffles this fiber has deposited
+};
 struct Block {
     std::vector<Fiber> fibers;
+    std::vector<unsigned> xchg;    // [warp][generation & 1][lane]: the values a warp's lanes deposited for a shuffle
     ucontext_t main;
     int cur = -1;
     const std::function<void()>* body = nullptr;
 };
 thread_local Block* g_block = nullptr;
 const size_t STACK = 256 * 1024;
+const unsigned WARP = 32;
 
 void trampoline() {
     Block* b = g_block;
     Fiber& f = b->fibers[b->cur];
     (*b->body)();
-    f.done = true;
+    f.state = DONE;
     swapcontext(&f.ctx, &b->main);
 }
+
+// all live lanes of fiber i's warp have deposited the shuffle generation fiber i waits for
+bool warpReady(const Block& b, size_t i) {
+    const unsigned need = b.fibers[i].shflCount;                    // = generation + 1
+    const size_t w0 = i / WARP * WARP, w1 = std::min(w0 + WARP, b.fibers.size());
+    for (size_t j = w0; j < w1; ++j)
+        if (b.fibers[j].state != DONE && b.fibers[j].shflCount < need) return false;
+    return true;
+}
+
+// lock-step exchange inside a warp: deposit, wait for the warp, read lane `src` (own value when src is outside the segment / has exited)
+unsigned shflExchange(unsigned val, int src, int width) {
+    Block* b = g_block;
+    if (!b || b->cur < 0) return val;
+    const size_t i = (size_t)b->cur;
+    Fiber& f = b->fibers[i];
+    const unsigned lane = (unsigned)(i % WARP), warp = (unsigned)(i / WARP), buf = f.shflCount & 1u;
+    b->xchg[(warp * 2 + buf) * WARP + lane] = val;
+    f.shflCount++;
+    f.state = AT_SHFL;
+    swapcontext(&f.ctx, &b->main);
+    threadIdx = f.tid;
+    if (width <= 0 || width > (int)WARP) width = WARP;
+    const int seg = (int)lane / width * width;
+    if (src < seg || src >= seg + width) return val;
+    const size_t j = (size_t)warp * WARP + (size_t)src;
+    if (j >= b->fibers.size() || (b->fibers[j].state == DONE && b->fibers[j].shflCount < f.shflCount)) return val;
+    return b->xchg[(warp * 2 + buf) * WARP + (unsigned)src];
+}
+unsigned f2u(float v) { unsigned u; memcpy(&u, &v, 4); return u; }
+float u2f(unsigned u) { float v; memcpy(&v, &u, 4); return v; }
+int laneId() { return g_block && g_block->cur >= 0 ? (int)(g_block->cur % WARP) : 0; }
 }  // namespace
 
 void __syncthreads() {
     Block* b = g_block;
     if (!b || b->cur < 0) return;
     Fiber& f = b->fibers[b->cur];
+    f.state = AT_BARRIER;
     swapcontext(&f.ctx, &b->main);            // resumed when every live fiber of the block has arrived
     threadIdx = f.tid;
 }
 
-float __shfl_down(float, int, int) { throw std::runtime_error("warp shuffles are not emulated"); }
-float __shfl_xor(float, int, int) { throw std::runtime_error("warp shuffles are not emulated"); }
-float __shfl(float, int, int) { throw std::runtime_error("warp shuffles are not emulated"); }
-int __shfl_down(int, int, int) { throw std::runtime_error("warp shuffles are not emulated"); }
-int __shfl_xor(int, int, int) { throw std::runtime_error("warp shuffles are not emulated"); }
+float __shfl_down(float v, int d, int w) { return u2f(shflExchange(f2u(v), laneId() + d, w)); }
+float __shfl_xor(float v, int m, int w) { return u2f(shflExchange(f2u(v), laneId() ^ m, w)); }
+float __shfl(float v, int s, int w) { const int ww = (w <= 0 || w > (int)WARP) ? (int)WARP : w; return u2f(shflExchange(f2u(v), laneId() / ww * ww + s % ww, w)); }
+int __shfl_down(int v, int d, int w) { return (int)shflExchange((unsigned)v, laneId() + d, w); }
+int __shfl_xor(int v, int m, int w) { return (int)shflExchange((unsigned)v, laneId() ^ m, w); }
 
 namespace emu {
 
@@ -50,7 +89,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     Block b;
     b.body = &body;
     b.fibers.resize(T);
+    b.xchg.assign(((T + WARP - 1) / WARP) * 2 * WARP, 0u);
     for (auto& f : b.fibers) f.stack.resize(STACK);
+    const dim3 gridSave = gridDim, blockSave = blockDim;
     gridDim = grid; blockDim = block;
     Block* outer = g_block;
     g_block = &b;
@@ -63,25 +104,37 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                     for (unsigned ty = 0; ty < block.y; ++ty)
                         for (unsigned tx = 0; tx < block.x; ++tx, ++t) {
                             Fiber& f = b.fibers[t];
-                            f.done = false; f.tid = make_uint3(tx, ty, tz);
+                            f.state = READY; f.shflCount = 0; f.tid = make_uint3(tx, ty, tz);
                             getcontext(&f.ctx);
                             f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = nullptr;
                             makecontext(&f.ctx, trampoline, 0);
                         }
-                size_t live = T;
-                while (live) {              // one pass = run every live fiber up to its next barrier (or to its end)
-                    live = 0;
+                for (;;) {                  // run every runnable fiber up to its next barrier / shuffle (or to its end), in thread-index order
+                    bool progress = false;
+                    size_t live = 0, atBarrier = 0;
                     for (size_t i = 0; i < T; ++i) {
                         Fiber& f = b.fibers[i];
-                        if (f.done) continue;
+                        if (f.state == DONE) continue;
+                        ++live;
+                        if (f.state == AT_BARRIER) { ++atBarrier; continue; }
+                        if (f.state == AT_SHFL && !warpReady(b, i)) continue;
+                        f.state = READY;
                         b.cur = (int)i; threadIdx = f.tid;
                         swapcontext(&b.main, &f.ctx);
-                        if (!f.done) ++live;
+                        progress = true;
+                        if (f.state == AT_BARRIER) ++atBarrier;
                     }
+                    if (live == 0) break;
+                    size_t stillLive = 0, stillBarrier = 0;
+                    for (auto& f : b.fibers) { if (f.state != DONE) ++stillLive; if (f.state == AT_BARRIER) ++stillBarrier; }
+                    if (stillLive == 0) break;
+                    if (stillBarrier == stillLive) { for (auto& f : b.fibers) if (f.state == AT_BARRIER) f.state = READY; progress = true; }
+                    if (!progress) throw std::runtime_error("emu: block cannot make progress (divergent barrier / shuffle)");
                 }
                 b.cur = -1;
             }
     g_block = outer;
+    gridDim = gridSave; blockDim = blockSave;
 }
 
 }  // namespace emu

@@ -3,7 +3,7 @@
 // g++ through shim/cuda_runtime.h) as the parity pin of the CPU oracle.  Blocks run one after the other; the threads of a
 // block are fibers (ucontext) executed in thread-index order, and __syncthreads() suspends a fiber until every live fiber of
 // the block has reached a barrier — so kernels with __shared__ data and barriers keep their semantics, while atomics and
-// "first thread wins" races resolve in a fixed (thread-index) order.  Warp shuffles are not emulated.
+// "first thread wins" races resolve in a fixed (thread-index) order.
 #ifndef BF_REF_EMU_H
 #define BF_REF_EMU_H
 #include <functional>

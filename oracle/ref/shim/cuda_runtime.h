@@ -114,13 +114,14 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; *p = v < o ? v : o; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; *p = v > o ? v : o; return o; }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+static inline float atomicAdd(float* p, int v) { float o = *p; *p = o + (float)v; return o; }
 static inline int atomicAdd(int* p, unsigned int v) { int o = *p; *p = o + (int)v; return o; }
 static inline unsigned int atomicAdd(unsigned int* p, int v) { unsigned int o = *p; *p = o + (unsigned int)v; return o; }
 static inline unsigned int atomicSub(unsigned int* p, int v) { unsigned int o = *p; *p = o - (unsigned int)v; return o; }
 static inline int atomicExch(int* p, unsigned int v) { int o = *p; *p = (int)v; return o; }
 static inline unsigned int atomicExch(unsigned int* p, int v) { unsigned int o = *p; *p = (unsigned int)v; return o; }
 
-// warp intrinsics are not emulated (kernels that need lock-step lanes are not part of the pinned set)
+// warp shuffles: lock-step exchange between the fibers of a warp (../emu.cpp)
 float __shfl_down(float, int, int = 32);
 float __shfl_xor(float, int, int = 32);
 float __shfl(float, int, int = 32);

@@ -238,3 +238,45 @@ def cache_store_frame(depth, color, W, H, input_intrinsics_inv, sigma_intensity=
                                 C.c_float(sigma_d), C.c_float(sigma_r), _fp(out["depth"]), _fp(out["campos"]), _fp(out["intensity"]), _fp(out["derivs"]),
                                 _fp(out["normals_u"]), _fp(out["normals"]))
     return out
+
+
+# ---- bundling solver (Solver/SolverBundling.cu) ----
+class _RefSolverParams(C.Structure):
+    _fields_ = [("denseDistThresh", C.c_float), ("denseNormalThresh", C.c_float), ("denseColorThresh", C.c_float), ("denseColorGradientMin", C.c_float),
+                ("denseDepthMin", C.c_float), ("denseDepthMax", C.c_float), ("denseOverlapCheckSubsampleFactor", C.c_uint32)]
+
+
+class _RefCacheFrame(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("campos", C.c_void_p), ("intensity", C.c_void_p), ("derivs", C.c_void_p), ("normalsU", C.c_void_p), ("normals", C.c_void_p)]
+
+
+def solver_solve(corr, valid, n_images, n_nonlin, n_lin, weights_sparse, weights_dense_depth, weights_dense_color, rot, trans,
+                 cache_frames=None, cache_geom=None, cfg=None, use_pairwise=True, max_images=None, max_residuals=None):
+    """solveBundlingStub of the reference (serial emulation).  corr (ENTRYJ, may be modified), rot / trans [N,3] float32 are updated in place."""
+    from bundlefusion_amd.capi import default_solver_config
+    cfg = cfg or default_solver_config()
+    gp = _RefSolverParams(*[getattr(cfg, f) for f in ("denseDistThresh", "denseNormalThresh", "denseColorThresh", "denseColorGradientMin", "denseDepthMin",
+                                                      "denseDepthMax", "denseOverlapCheckSubsampleFactor")])
+    max_images = max_images or max(n_images, 2)
+    max_residuals = max_residuals or max(len(corr), 1)
+    valid = np.ascontiguousarray(valid, np.int32)
+    ws, wd, wc = (np.asarray(w, np.float32) for w in (weights_sparse, weights_dense_depth, weights_dense_color))
+    keep, frames, geom = [], None, None
+    W = H = 0
+    if cache_frames is not None:
+        arr = (_RefCacheFrame * n_images)()
+        for i in range(n_images):
+            f = {k: np.ascontiguousarray(v) for k, v in cache_frames[i].items()}
+            keep.append(f)
+            arr[i].depth, arr[i].campos, arr[i].intensity = f["depth"].ctypes.data, f["campos"].ctypes.data, f["intensity"].ctypes.data
+            arr[i].derivs, arr[i].normalsU, arr[i].normals = f["derivs"].ctypes.data, f["normals_u"].ctypes.data, f["normals"].ctypes.data
+        frames = arr
+        W, H, k4 = cache_geom
+        geom = np.asarray(k4, np.float32)
+    conv = np.full(n_nonlin + 1, -1.0, np.float32)
+    mx = C.c_float(-1.0); mi = C.c_int(-1); ver = C.c_int(0)
+    rows = np.zeros(n_images, np.int32)
+    lib().ref_solver_solve(C.c_void_p(corr.ctypes.data if len(corr) else 0), len(corr), _fp(valid), n_images, max_images, max_residuals, n_nonlin, n_lin,
+                           _fp(ws), _fp(wd), _fp(wc), len(ws), frames, W, H, _fp(geom) if geom is not None else None, int(use_pairwise), C.byref(gp),
+                           _fp(rot), _fp(trans), _fp(conv), C.byref(mx) if len(corr) else None, C.byref(mi), _fp(rows), C.byref(ver) if len(corr) else None)
+    return dict(convergence=conv, max_residual=mx.value, max_residual_index=mi.value, rows=rows, use_verification=bool(ver.value))

@@ -141,18 +141,18 @@ def test_resample_branch_sensor_640_integration_320(gpu, oracle):
     assert gp.scene().num_allocated_blocks() > 1500
 
 
-@pytest.mark.skipif(os.environ.get("BF_SKIP_LONG") == "1", reason="BF_SKIP_LONG=1")
-def test_config1_200_frames_vs_oracle_loop(gpu, oracle):
-    """BASELINE configs[1]: 200 frames of the stream at 4 mm through the whole loop (20 local chunks, 19 global solves,
-    ~10 re-integrations per frame) against the oracle frame loop."""
-    n = 200
+@pytest.mark.parametrize("n", [71] + ([201] if os.environ.get("BF_LONG_TESTS") == "1" else []))
+def test_config1_stream_vs_oracle_loop(gpu, oracle, n):
+    """BASELINE configs[1] at 4 mm through the whole loop against the oracle frame loop: 71 frames by default (7 local chunks, 6 global
+    solves, the re-integration queue saturated from frame ~25 on), the full 201 frames (20 chunks, 19 global solves) with BF_LONG_TESTS=1
+    — the oracle needs ~9 minutes of host time for those (profiles/r02_gpu_tests_full.txt holds that run)."""
     frames = synth.render_frames(range(n))
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     gp, op = _run_both(gpu, frames, K, tail=0, blocks=400000, max_images=28)
     c = gp.counters()
-    assert (c["integrate"], c["deintegrate"]) == _counts(op)
-    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves and c["global_solves"] == op.glob.num_solves >= 18
+    assert (c["integrate"], c["deintegrate"]) == _counts(op) and c["deintegrate"] > 3 * n
+    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves and c["global_solves"] == op.glob.num_solves >= (n - 1) // 10 - 1
     gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
     assert np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).all()
     assert np.abs(gt - ot).max() < 5e-4

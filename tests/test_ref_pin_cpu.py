@@ -142,6 +142,74 @@ def test_greedy_kabsch_filter_exact(oracle):
     assert kept_total > 150          # the comparison is not vacuous
 
 
+# ------------------------------------------------------------------------------------------------ Gauss-Newton / PCG solver
+def test_solver_vs_reference_kernels(oracle):
+    """solveBundlingStub of the reference (its own kernels: Initialization, PCGIteration, EvalResidual, BuildDenseSystem ..., float
+    atomics summed in thread-index order) against the oracle solver on the same problems.  Both evaluate the same energy with
+    different summation orders, so: energies per Gauss-Newton iteration rel 1e-3, poses 1e-4 — the tolerances the HIP solver is held
+    to against the oracle (tests/test_solver_gpu.py) — and the per-image row counts of the correspondence table exactly."""
+    from tests import bundle_synth as bs
+    for n, seed, nl, lin in ((11, 0, 4, 100), (30, 1, 3, 150)):
+        corr, T_gt, T_init = bs.sparse_problem(n_images=n, pair_prob=0.6, seed=seed)
+        valid = np.ones(n, np.int32)
+        ro, to = oracle.matrices_to_poses(T_init); rr, tr = ro.copy(), to.copy()
+        w1, w0 = [1.0] * nl, [0.0] * nl
+        o = oracle.solver_solve(corr.copy(), valid, n, nl, lin, w1, w0, w0, ro, to)
+        r = ref_api.solver_solve(corr.copy(), valid, n, nl, lin, w1, w0, w0, rr, tr)
+        assert np.array_equal(r["rows"], np.bincount(np.r_[corr["imgIdx_i"], corr["imgIdx_j"]], minlength=n))
+        k = o["gn_iterations"]
+        assert k >= 2
+        co, cr = o["convergence"][:k + 1], r["convergence"][:k + 1]
+        assert (cr >= 0).all() and np.abs(co - cr).max() <= 1e-3 * max(co.max(), 1e-6), (co, cr)
+        assert np.abs(ro - rr).max() < 1e-4 and np.abs(to - tr).max() < 1e-4
+        gt_r, gt_t = oracle.matrices_to_poses(T_gt.astype(np.float32))
+        assert np.abs(rr - gt_r).max() < 0.01 and np.abs(tr - gt_t).max() < 0.01            # and it is the right answer
+        assert abs(o["max_residual"] - r["max_residual"]) <= 1e-3 * max(r["max_residual"], 1e-6) and o["max_residual_index"] == r["max_residual_index"]
+
+
+def test_solver_dense_terms_vs_reference_kernels(oracle):
+    """The dense depth + colour terms (BuildDenseSystem: FindImageImageCorr / FindDenseCorrespondences / BuildDenseSystem kernels and the
+    dense PCG branch) on a local chunk of 4 synthetic frames with cache frames, sparse + dense weights as the local solve uses them."""
+    from tests import bundle_synth as bs
+    from bundlefusion_amd.capi import intrinsics_matrix
+    W, H = 80, 60
+    n = 4
+    src = [synth.scene_room(3 * k, 320, 240) for k in range(n)]
+    Kd = src[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    frames = [oracle.cache_store_frame(d, c, W, H, K) for d, c, _, _ in src]
+    k4 = [K[0, 0] * W / 320, K[1, 1] * H / 240, K[0, 2] * (W - 1) / 319, K[1, 2] * (H - 1) / 239]
+    T0inv = np.linalg.inv(src[0][2].astype(np.float64))
+    T_gt = np.stack([(T0inv @ f[2].astype(np.float64)) for f in src]).astype(np.float32)
+    rng = np.random.default_rng(3)
+    T_init = T_gt.copy()
+    for i in range(1, n):
+        T_init[i] = (T_gt[i].astype(np.float64) @ bs.random_pose(rng, 0.004, 0.004)).astype(np.float32)
+    from bundlefusion_amd.capi import ENTRYJ_DTYPE
+    rows = []
+    for i in range(n):                                         # sparse correspondences consistent with the rendered poses (they anchor the sliding directions)
+        for j in range(i + 1, n):
+            pw = rng.uniform(-1, 1, (12, 3)) + np.array([0, 0, 2.2])
+            pi = (np.linalg.inv(T_gt[i].astype(np.float64)) @ np.c_[pw, np.ones(12)].T).T[:, :3] + rng.normal(0, 0.001, (12, 3))
+            pj = (np.linalg.inv(T_gt[j].astype(np.float64)) @ np.c_[pw, np.ones(12)].T).T[:, :3] + rng.normal(0, 0.001, (12, 3))
+            for a, b in zip(pi, pj):
+                e = np.zeros(1, ENTRYJ_DTYPE); e["imgIdx_i"], e["imgIdx_j"], e["pos_i"], e["pos_j"] = i, j, a, b
+                rows.append(e)
+    corr = np.concatenate(rows)
+    valid = np.ones(n, np.int32)
+    nl = 3
+    ws, wd, wc = [1.0] * nl, [1.0, 2.0, 3.0], [0.0] * nl       # SBA.cpp:28-38: local solve = sparse 1, dense depth i + 1, colour 0
+    ro, to = oracle.matrices_to_poses(T_init); rr, tr = ro.copy(), to.copy()
+    o = oracle.solver_solve(corr.copy(), valid, n, nl, 100, ws, wd, wc, ro, to, cache_frames=frames, cache_geom=(W, H, k4))
+    r = ref_api.solver_solve(corr.copy(), valid, n, nl, 100, ws, wd, wc, rr, tr, cache_frames=frames, cache_geom=(W, H, k4))
+    assert o["num_dense_pairs"] >= 3
+    assert np.abs(ro - rr).max() < 1e-4 and np.abs(to - tr).max() < 1e-4
+    gt_r, gt_t = oracle.matrices_to_poses(T_gt)
+    assert np.abs(rr - gt_r).max() < 2e-3 and np.abs(tr - gt_t).max() < 2e-3
+    k = o["gn_iterations"]
+    assert np.abs(o["convergence"][:k + 1] - r["convergence"][:k + 1]).max() <= 1e-3 * max(o["convergence"][:k + 1].max(), 1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ image kernels
 def _same(a, b):
     a = np.asarray(a); b = np.asarray(b)

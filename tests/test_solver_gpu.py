@@ -199,3 +199,70 @@ def test_solver_argument_errors(gpu):
         solver.solve(None, 0, v, 1, 2, 10, None, [1.0, 1.0], [0.0, 0.0], [0.0, 0.0], z, z)       # numberOfImages > 1 (MLIB_ASSERT .cpp:194)
     with pytest.raises(BFError):
         solver.solve(None, 0, v, 9, 2, 10, None, [1.0, 1.0], [0.0, 0.0], [0.0, 0.0], z, z)       # exceeds capacity
+
+
+def test_two_host_threads_on_separate_streams_give_the_serial_results(gpu, oracle):
+    """the reference drives m_local from the processInput thread and m_optLocal / m_global from the optimiser thread
+    (OnlineBundler.h:85-86).  Two host threads issue work to ONE device through different handles on their own HIP streams — SIFT
+    detection (what processInput does) and Gauss-Newton / PCG solves (what the optimiser thread does), 12 rounds each, concurrently —
+    and every result equals the result of the same call made serially (per-object state only; the error string is thread-local)."""
+    import threading
+    import torch
+    from bundlefusion_amd import synth
+    from bundlefusion_amd.capi import rgbx_to_intensity, KEYPOINT_DTYPE
+    W, H = 640, 480
+    frames = [synth.scene_room(7 * k, W, H) for k in range(3)]
+    inten = [_dev(rgbx_to_intensity(f[1])) for f in frames]
+    depth = [_dev(f[0]) for f in frames]
+    corr, T_gt, T_init = bs.sparse_problem(n_images=30, pair_prob=0.5, seed=5)
+    rot0, tr0 = oracle.matrices_to_poses(T_init)
+    valid = np.ones(30, np.int32)
+    ws = [1.0] * 4; wz = [0.0] * 4
+    s_sift, s_solve = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def sift_job(sift, out):
+        for r in range(12):
+            k = r % 3
+            keys = torch.zeros(1024 * 4, device="cuda"); descs = torch.zeros(1024 * 128, dtype=torch.uint8, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            sift.run(inten[k], depth[k], keys, descs, cnt)
+            s_sift.synchronize()
+            n = int(cnt.item())
+            out.append((n, keys.cpu().numpy()[:4 * n].tobytes(), descs.cpu().numpy()[:128 * n].tobytes()))
+
+    def solve_job(solver, out):
+        gcorr, gvalid = _dev(corr.view(np.uint8)), _dev(valid)
+        for r in range(12):
+            grot, gtr = _dev(rot0.copy()), _dev(tr0.copy())
+            solver.solve(gcorr, len(corr), gvalid, 30, 4, 100, None, ws, wz, wz, grot, gtr, find_max_residual=False)
+            s_solve.synchronize()
+            out.append((grot.cpu().numpy().tobytes(), gtr.cpu().numpy().tobytes()))
+
+    def make():
+        return (gpu.capi.Sift(W, H, W, H, stream=s_sift.cuda_stream),
+                gpu.capi.Solver(30, len(corr), default_solver_config(record_convergence=False), stream=s_solve.cuda_stream))
+
+    sift, solver = make()
+    ser_a, ser_b = [], []
+    sift_job(sift, ser_a); solve_job(solver, ser_b)
+    sift2, solver2 = make()
+    par_a, par_b = [], []
+    ta = threading.Thread(target=sift_job, args=(sift2, par_a)); tb = threading.Thread(target=solve_job, args=(solver2, par_b))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert len(par_a) == len(par_b) == 12 and ser_a[0][0] > 50
+    assert par_a == ser_a, "SIFT results changed when a second host thread was solving on another stream"
+    assert par_b == ser_b, "solver results changed when a second host thread was detecting on another stream"
+
+
+def test_corr_overflow_is_reported_not_dropped(gpu, oracle):
+    """m_maxCorrPerImage (CUDASolverBundling.cpp:39,195-199): the reference invalidates correspondences beyond 1000 per image in atomic
+    arrival order; this solver keeps all of them (deterministic) and reports the condition through bf_solver_get_corr_overflow."""
+    import ctypes as C
+    from bundlefusion_amd.capi import lib, check
+    corr, T_gt, T_init = bs.sparse_problem(n_images=6, pair_prob=1.0, seed=9)
+    big = np.concatenate([corr[(corr["imgIdx_i"] == 0) | (corr["imgIdx_j"] == 0)]] * 60 + [corr])        # image 0 gets > 1000 correspondences
+    solver, gcorr, ores, (orot, otr), (grot, gtr) = _solve_both(gpu, oracle, big, T_init, 3, 60, [1.0] * 3, [0.0] * 3, [0.0] * 3, find_max=False, record=False)
+    n_over, limit = C.c_uint32(), C.c_uint32()
+    check(lib.bf_solver_get_corr_overflow(solver._h, C.byref(n_over), C.byref(limit)))
+    per_image = np.bincount(np.r_[big["imgIdx_i"], big["imgIdx_j"]], minlength=6)
+    assert limit.value == 1000 and per_image[0] > 1000 and n_over.value == int((per_image > 1000).sum()) >= 1
+    assert np.abs(grot - orot).max() < 1e-4 and np.abs(gtr - otr).max() < 1e-4          # every correspondence took part, like in the oracle

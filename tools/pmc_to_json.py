@@ -15,7 +15,9 @@ def totals(db, counter):
     c = sqlite3.connect(db)
     out = {}
     for name, n, tot in c.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
-        key = "k_reupdate" if "k_reupdate" in name else ("k_update" if "k_update" in name else None)
+        fused = "k_reupdate" in name or "k_update_col<2>" in name          # fused re-integration: the per-voxel or the column kernel
+        plain = not fused and ("k_update<" in name or "k_update_col<" in name)
+        key = "k_reupdate" if fused else ("k_update" if plain else None)
         if key:
             a = out.setdefault(key, [0, 0.0]); a[0] += n; a[1] += tot
     return out
