@@ -449,118 +449,11 @@ __device__ __noinline__ bool computeReprojection(uint32_t lane, f3* src, f3* tgt
     return true;
 }
 
-// ---- the same arithmetic with the moment sums of
-// kabsch() / covarianceEig() spread over lanes.  Every sum is still accumulated sequentially in index order by ONE lane (lane c owns
-// component / matrix entry c), so each value is the value the scalar code computes; only independent sums run side by side.
-struct ReprojMoments { float mean[6]; float V[9]; float cmean[6]; float cV[18]; };
-BF_DEV float comp3(const f3& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
-
-BF_DEV m44 kabschTail(const float* mean, const float* Vin, f3& evs) {       // kabsch() from the SVD on (cuda_kabsch.h:105-211)
-    const f3 p0 = mk3(mean[0], mean[1], mean[2]), q0 = mk3(mean[3], mean[4], mean[5]);
-    float V[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) V[i] = Vin[i];
-    float U[9], S[9], W[9];
-    svd3(V, U, S, W);
-    float s[3] = {S[0], S[4], S[8]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) if (s[i] < 0.0f) { s[i] *= -1.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) U[j * 3 + i] *= -1.0f; }
-    evs = mk3(s[0], s[1], s[2]);
-    if (evs.x < evs.y) { const float t = evs.x; evs.x = evs.y; evs.y = t; }
-    if (evs.y < evs.z) { const float t = evs.y; evs.y = evs.z; evs.z = t; }
-    if (evs.x < evs.y) { const float t = evs.x; evs.x = evs.y; evs.y = t; }
-    const float Wt[9] = {W[0], W[3], W[6], W[1], W[4], W[7], W[2], W[5], W[8]};
-    float UWt[9];
-    mm3(U, Wt, UWt);
-    float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (det3(UWt) < 0) I[8] = -1;
-    const float Ut[9] = {U[0], U[3], U[6], U[1], U[4], U[7], U[2], U[5], U[8]};
-    float WI[9], R[9];
-    mm3(W, I, WI);
-    mm3(WI, Ut, R);
-    m44 ret = identity44();
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ret.e[i * 4 + j] = R[i * 3 + j];
-    ret.e[3] = q0.x - (R[0] * p0.x + R[1] * p0.y + R[2] * p0.z);
-    ret.e[7] = q0.y - (R[3] * p0.x + R[4] * p0.y + R[5] * p0.z);
-    ret.e[11] = q0.z - (R[6] * p0.x + R[7] * p0.y + R[8] * p0.z);
-    return ret;
-}
-
-__device__ __noinline__ bool computeReprojectionLanes(uint32_t lane, f3* src, f3* tgt, unsigned n, float* res, Sel* sel, ReprojShared* sh, ReprojMoments* mom) {
-    if (lane < 6) {                                                       // p0 (lanes 0-2) and q0 (lanes 3-5): sum in index order, then / n
-        const f3* a = lane < 3 ? src : tgt; const int c = (int)(lane % 3);
-        float acc = 0.0f;
-        for (unsigned i = 0; i < n; ++i) acc = acc + comp3(a[i], c);
-        mom->mean[lane] = acc / (float)n;
-    }
-    __syncthreads();
-    if (lane < 9) {                                                       // V[r][c] = sum (p - p0)[r] * (q - q0)[c] / n
-        const int r = (int)(lane / 3), c = (int)(lane % 3);
-        const float pm = mom->mean[r], qm = mom->mean[3 + c];
-        float acc = 0.0f;
-        for (unsigned i = 0; i < n; ++i) { const float pv = comp3(src[i], r) - pm, qv = comp3(tgt[i], c) - qm; acc += pv * qv; }
-        mom->V[lane] = acc / (float)n;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        f3 ev;
-        sh->T = kabschTail(mom->mean, mom->V, ev);
-        sh->ev[0] = ev.x; sh->ev[1] = ev.y; sh->ev[2] = ev.z;
-    }
-    __syncthreads();
-    float my = 0.0f;
-    if (lane < n) { const f3 d = xform(sh->T, src[lane]) - tgt[lane]; my = dot3(d, d); res[lane] = my; }
-    __syncthreads();
-    unsigned rank = 0;
-    bool odd = false;
-    if (lane < n) {
-        odd = my != my;
-        for (unsigned j = 0; j < n; ++j) { const float rj = res[j]; rank += rj < my ? 1u : 0u; odd = odd || (j != lane && rj == my); }
-    }
-    if (__ballot(odd) == 0ull) {
-        f3 s_ = mk3(0, 0, 0), t_ = mk3(0, 0, 0); Sel e_ = {0u, 0u, 0.0f, 0u};
-        if (lane < n) { s_ = src[lane]; t_ = tgt[lane]; e_ = sel[lane]; }
-        __syncthreads();
-        if (lane < n) { src[rank] = s_; tgt[rank] = t_; sel[rank] = e_; res[rank] = my; }
-    } else if (lane == 0) {
-        for (unsigned i = 0; i < n; ++i)
-            for (unsigned j = i; j < n; ++j)
-                if (res[i] > res[j]) { swp(res[i], res[j]); swp(src[i], src[j]); swp(tgt[i], tgt[j]); swp(sel[i], sel[j]); }
-    }
-    __syncthreads();
-    if (lane < 6) {                                                       // covarianceEig(src) on lanes 0-2, covarianceEig(tgt) on lanes 3-5: means
-        const f3* a = lane < 3 ? src : tgt; const int c = (int)(lane % 3);
-        float acc = 0.0f;
-        for (unsigned i = 0; i < n; ++i) acc = acc + comp3(a[i], c);
-        mom->cmean[lane] = acc / (float)n;
-    }
-    __syncthreads();
-    if (lane < 18) {                                                      // ... and the two 3x3 covariances
-        const int set = (int)(lane / 9), e = (int)(lane % 9), r = e / 3, c = e % 3;
-        const f3* a = set ? tgt : src;
-        const float mr = mom->cmean[set * 3 + r], mc = mom->cmean[set * 3 + c];
-        float acc = 0.0f;
-        for (unsigned i = 0; i < n; ++i) { const float pr = comp3(a[i], r) - mr, pc = comp3(a[i], c) - mc; acc += pr * pc; }
-        mom->cV[lane] = acc / (float)n;
-    }
-    __syncthreads();
-    if (lane < 2) { const f3 e = eigenValues3(mom->cV + 9 * lane); sh->cond[lane] = e.x / e.y; }
-    __syncthreads();
-    const float c1 = sh->ev[0] / sh->ev[1], cp = sh->cond[0], cq = sh->cond[1];
-    if (c1 != c1 || cp != cp || cq != cq || fabsf(c1) > 100.0f || fabsf(cp) > 100.0f || fabsf(cq) > 100.0f) return false;
-    return true;
-}
-
 struct FilterArgs {
     const Key* keys; uint32_t curFrame, startFrame;
     const int* numMatches; const float* dist; const uint2* idx;
     int* numFilt; float* fdist; uint2* fidx; m44* T; m44* Tinv;
-    m44 Kinv; int minNumMatches; float maxKabschRes2; int laneMoments;
+    m44 Kinv; int minNumMatches; float maxKabschRes2;
 };
 
 // One wave per previous image.  The greedy filter is inherently sequential (every accepted match changes the Kabsch fit
@@ -579,7 +472,6 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
     __shared__ f3 src[MAX_FILT], tgt[MAX_FILT];
     __shared__ float res[MAX_FILT];
     __shared__ ReprojShared sh;
-    __shared__ ReprojMoments mom;
     __shared__ m44 prevT;
     for (int i = (int)tid; i < numRaw; i += 64) {
         const uint2 k = a.idx[prev * MAX_RAW + i];
@@ -615,7 +507,7 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
             if (cur >= 3) {
                 if (tid < cur) { src[tid] = ptI[sel[tid].r]; tgt[tid] = ptJ[sel[tid].r]; }
                 __syncthreads();
-                validT = a.laneMoments ? computeReprojectionLanes(tid, src, tgt, cur, res, sel, &sh, &mom) : computeReprojection(tid, src, tgt, cur, res, sel, &sh);
+                validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
                 const bool b = validT;
                 if (tid < 16) prevT.e[tid] = sh.T.e[tid];
                 curMaxRes = res[cur - 1];
@@ -626,7 +518,7 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
                         lastRes = res[k];
                         cur--;
                         __syncthreads();
-                        validT = a.laneMoments ? computeReprojectionLanes(tid, src, tgt, cur, res, sel, &sh, &mom) : computeReprojection(tid, src, tgt, cur, res, sel, &sh);
+                        validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
                         curMaxRes = res[cur - 1];
                         if (cur == 3 && (curMaxRes > a.maxKabschRes2 || (b && !validT))) {
                             cur++; curMaxRes = lastRes; validT = b;
@@ -971,7 +863,6 @@ struct bf_siftmgr {
     uint32_t numImages = 0, currentImage = 0, globNumResiduals = 0;
     bool finalized = true;
     bool resPrefetched = false;
-    int kabschLanes = 1;                 // lane-parallel moment sums in the Kabsch filter (BF_KABSCH_LANES=0: all sums on lane 0; same bits)
     bool validDirty = false;          // host copy of the valid flags changed since the last upload
     std::deque<uint32_t> retry;
 };
@@ -982,7 +873,6 @@ int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_sift
     BF_REQUIRE(out && maxImages >= 1 && maxKeyPointsPerImage >= 16 && maxKeyPointsPerImage <= 1024, "maxKeyPointsPerImage must be in [16, 1024]");
     bf_siftmgr* m = new bf_siftmgr;
     m->maxImages = maxImages; m->maxKeys = maxKeyPointsPerImage;
-    if (const char* e = getenv("BF_KABSCH_LANES")) m->kabschLanes = atoi(e) != 0;
     m->maxResiduals = MAX_FILT * (maxImages * (maxImages - 1)) / 2;
     int rc;
     const size_t nk = (size_t)maxImages * maxKeyPointsPerImage;
@@ -1085,7 +975,7 @@ int bf_siftmgr_filter_keypoint_matches(bf_siftmgr* m, uint32_t curFrame, uint32_
                                        uint32_t minNumMatches, float maxKabschRes2) {
     BF_REQUIRE(m && siftIntrinsicsInv && numFrames <= m->numImages && startFrame < numFrames, "frame range out of bounds");
     FilterArgs a = {m->d_keys, curFrame, startFrame, m->d_numMatches, m->d_dist, m->d_idx, m->d_numFilt, m->d_fdist, m->d_fidx, m->d_T, m->d_Tinv,
-                    toM44(siftIntrinsicsInv), (int)minNumMatches, maxKabschRes2, m->kabschLanes};
+                    toM44(siftIntrinsicsInv), (int)minNumMatches, maxKabschRes2};
     k_filter_kabsch<<<numFrames - startFrame, 64, 0, m->stream>>>(a);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;

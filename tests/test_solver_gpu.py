@@ -264,5 +264,6 @@ def test_corr_overflow_is_reported_not_dropped(gpu, oracle):
     n_over, limit = C.c_uint32(), C.c_uint32()
     check(lib.bf_solver_get_corr_overflow(solver._h, C.byref(n_over), C.byref(limit)))
     per_image = np.bincount(np.r_[big["imgIdx_i"], big["imgIdx_j"]], minlength=6)
-    assert limit.value == 1000 and per_image[0] > 1000 and n_over.value == int((per_image > 1000).sum()) >= 1
+    lim = min(max(len(big) // 6, 1000), 4000)                              # clamp(maxNumResiduals / maxNumberOfImages, 1000, 4000)
+    assert limit.value == lim and per_image[0] > lim and n_over.value == int((per_image > lim).sum()) >= 1
     assert np.abs(grot - orot).max() < 1e-4 and np.abs(gtr - otr).max() < 1e-4          # every correspondence took part, like in the oracle
