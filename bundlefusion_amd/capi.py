@@ -920,3 +920,55 @@ class ChunkWorker:
         pkg = out if out is not None else np.zeros(self.package_bytes, np.uint8)
         check(lib.bf_chunk_worker_run(self._h, int(chunk_index), n, dp, cp, pkg.ctypes.data_as(C.c_void_p)))
         return pkg
+
+
+# --------------------------------------------------------------------------- marching cubes
+class MarchingCubesParams(C.Structure):
+    _fields_ = [("m_maxNumTriangles", C.c_uint32), ("m_sdfBlockSize", C.c_uint32), ("m_hashNumBuckets", C.c_uint32), ("m_hashBucketSize", C.c_uint32),
+                ("m_threshMarchingCubes", C.c_float), ("m_threshMarchingCubes2", C.c_float)]
+
+
+def marching_cubes_tables():
+    """The generated case tables: (edgeTable[256] uint16, triTable[256,16] int8).  Host-only."""
+    e = np.zeros(256, np.uint16); t = np.zeros(256 * 16, np.int8)
+    check(lib.bf_marching_cubes_tables(e.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)))
+    return e, t.reshape(256, 16)
+
+
+class MarchingCubesHashSDF:
+    """Python view of `bf_marching_cubes` (== the reference's CUDAMarchingCubesHashSDF)."""
+
+    def __init__(self, max_triangles, num_buckets, voxel_size, thresh_factor=10.0):
+        p = MarchingCubesParams(max_triangles, SDF_BLOCK_SIZE, num_buckets, HASH_BUCKET_SIZE, thresh_factor * voxel_size, thresh_factor * voxel_size)
+        self.params = p
+        self._h = C.c_void_p()
+        check(lib.bf_marching_cubes_create(C.byref(p), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.bf_marching_cubes_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extract(self, scene, box=None):
+        """extractIsoSurface over `scene` (a SceneRepHashSDF): returns (triangles [n,3,6] float32 = position + colour per vertex, number found)"""
+        hd = scene.hash_data(); hp = scene.hash_params()
+        mn = (C.c_float * 3)(*(box[0] if box else (0, 0, 0))); mx = (C.c_float * 3)(*(box[1] if box else (0, 0, 0)))
+        check(lib.bf_marching_cubes_clear_mesh_buffer(self._h))
+        check(lib.bf_marching_cubes_extract(self._h, C.byref(hd), C.byref(hp), mn, mx, int(box is not None)))
+        n = C.c_uint32(); found = C.c_uint32()
+        check(lib.bf_marching_cubes_get_triangles_gpu(self._h, None, C.byref(n), C.byref(found)))
+        out = np.zeros((n.value, 3, 6), np.float32); cnt = C.c_uint32()
+        check(lib.bf_marching_cubes_get_mesh(self._h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(cnt)))
+        return out, found.value
+
+    def save_mesh(self, filename, transform=None):
+        nv = C.c_uint32(); nf = C.c_uint32()
+        T = mat16(transform) if transform is not None else None
+        check(lib.bf_marching_cubes_save_mesh(self._h, str(filename).encode(), T, C.byref(nv), C.byref(nf)))
+        return nv.value, nf.value

@@ -464,6 +464,38 @@ BF_API int bf_image_resample_uchar4(uint8_t* d_output, uint32_t outputWidth, uin
 BF_API int bf_image_resample_to_intensity(float* d_output, uint32_t outputWidth, uint32_t outputHeight, const uint8_t* d_input,
                                           uint32_t inputWidth, uint32_t inputHeight, void* hip_stream);
 
+/* ------------------------------------------------------------------------- */
+/* Marching cubes over the voxel hash:                                         */
+/* DepthSensing/CUDAMarchingCubesHashSDF.h:8-58, .cpp, CUDAMarchingCubesSDF.cu, */
+/* MarchingCubesSDFUtil.h:9-287 (a consumer of getHashData(): it reads the raw  */
+/* arrays in the reference layout)                                             */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_mc_vertex { float p[3]; float c[3]; } bf_mc_vertex;              /* MarchingCubesData::Vertex  :28-32 */
+typedef struct bf_mc_triangle { bf_mc_vertex v[3]; } bf_mc_triangle;               /* MarchingCubesData::Triangle :34-39 (72 bytes) */
+typedef struct bf_marching_cubes_params {                                          /* MarchingCubesParams :9-22, parametersFromGlobalAppState (.h:20-29) */
+    uint32_t m_maxNumTriangles;          /* s_marchingCubesMaxNumTriangles */
+    uint32_t m_sdfBlockSize, m_hashNumBuckets, m_hashBucketSize;
+    float m_threshMarchingCubes;         /* s_SDFMarchingCubeThreshFactor * s_SDFVoxelSize */
+    float m_threshMarchingCubes2;
+} bf_marching_cubes_params;
+typedef struct bf_marching_cubes bf_marching_cubes;   /* == class CUDAMarchingCubesHashSDF */
+
+BF_API int bf_marching_cubes_create(const bf_marching_cubes_params* p, bf_marching_cubes** out);
+BF_API int bf_marching_cubes_destroy(bf_marching_cubes* m);
+BF_API int bf_marching_cubes_set_stream(bf_marching_cubes* m, void* hip_stream);
+/* extractIsoSurface(hashData, hashParams, rayCastData, minCorner, maxCorner, boxEnabled)  .cpp:107-119; the triangles are also appended
+ * to the host mesh buffer (copyTrianglesToCPU :27-46).  Triangle order is deterministic: (hash slot, voxel index, table order). */
+BF_API int bf_marching_cubes_extract(bf_marching_cubes* m, const bf_hash_data* hashData, const bf_hash_params* hashParams,
+                                     const float minCorner[3], const float maxCorner[3], int boxEnabled);
+/* device buffer of the last extraction: *numTriangles <= m_maxNumTriangles were written, *numFound is the number the volume holds */
+BF_API int bf_marching_cubes_get_triangles_gpu(bf_marching_cubes* m, const bf_mc_triangle** d_triangles, uint32_t* numTriangles, uint32_t* numFound);
+BF_API int bf_marching_cubes_get_mesh(bf_marching_cubes* m, bf_mc_triangle* h_out, uint32_t capacity, uint32_t* count);   /* m_meshData */
+BF_API int bf_marching_cubes_clear_mesh_buffer(bf_marching_cubes* m);                                                     /* clearMeshBuffer */
+/* saveMesh(filename, transform)  .cpp:48-105: merge vertices closer than 1e-5, drop duplicate / degenerate faces, binary PLY */
+BF_API int bf_marching_cubes_save_mesh(bf_marching_cubes* m, const char* filename, const float transform[16], uint32_t* numVertices, uint32_t* numFaces);
+/* the generated case tables (edge mask per case, up to 5 triangles of edge indices, -1 terminated), for inspection / tests */
+BF_API int bf_marching_cubes_tables(uint16_t edgeTable[256], int8_t triTable[256 * 16]);
+
 #ifdef __cplusplus
 }
 #endif

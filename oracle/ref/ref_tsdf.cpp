@@ -21,11 +21,7 @@ extern "C" void updateConstantDepthCameraParams(const DepthCameraParams& p) { c_
 static_assert(sizeof(HashParams) == 224, "HashParams layout");
 static_assert(sizeof(HashEntry) == 32 && sizeof(Voxel) == 12, "HashEntry / Voxel layout");
 
-struct ref_scene {
-    HashParams params;
-    HashDataStruct data;
-    unsigned int numIntegrated = 0;
-};
+#include "ref_scene.h"
 
 static unsigned int heapFree(ref_scene* s) { return s->data.d_heapCounter[0] + 1; }
 

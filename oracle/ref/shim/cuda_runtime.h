@@ -63,6 +63,12 @@ BF_REF_VEC(double, double) BF_REF_VEC24(double, double, 16, 16)
 #undef BF_REF_VEC
 #undef BF_REF_VEC24
 
+// cutil_math.h declares unary minus on NON-const lvalue references (accepted for temporaries by MSVC / nvcc); temporaries bind here
+static inline float2 operator-(const float2& a) { return make_float2(-a.x, -a.y); }
+static inline float3 operator-(const float3& a) { return make_float3(-a.x, -a.y, -a.z); }
+static inline float4 operator-(const float4& a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+struct cudaArray;
+
 struct dim3 {
     unsigned int x, y, z;
     dim3(unsigned int x_ = 1, unsigned int y_ = 1, unsigned int z_ = 1) : x(x_), y(y_), z(z_) {}

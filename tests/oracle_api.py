@@ -376,3 +376,18 @@ def make_entry(keys, ix, iy, img_i, img_j, Kinv):
     olib.or_make_entry(_fp(np.ascontiguousarray(keys, np.float32)), int(ix), int(iy), int(img_i), int(img_j),
                        _fp(np.ascontiguousarray(Kinv, np.float32)), _fp(e))
     return e[0]
+
+
+# --------------------------------------------------------------------------- marching cubes oracle
+def mc_extract(scene, thresh, thresh2, edge_table, tri_table, max_triangles=2000000, box=None):
+    """or_mc_extract on an OracleScene with the given case tables -> (triangles [n,3,6], number found)"""
+    from bundlefusion_amd.capi import HashParams
+    olib.or_mc_extract.restype = C.c_uint32
+    out = np.zeros((max_triangles, 3, 6), np.float32)
+    e = np.ascontiguousarray(edge_table, np.uint16); t = np.ascontiguousarray(tri_table, np.int8).reshape(-1)
+    mn = np.ascontiguousarray(box[0], np.float32) if box else np.zeros(3, np.float32)
+    mx = np.ascontiguousarray(box[1], np.float32) if box else np.zeros(3, np.float32)
+    hp = scene.hash_params()
+    n = olib.or_mc_extract(C.c_void_p(olib.or_scene_hash(scene._h)), C.c_void_p(olib.or_scene_voxels(scene._h)), C.byref(hp), C.c_float(thresh), C.c_float(thresh2),
+                           int(box is not None), _fp(mn), _fp(mx), _fp(e), _fp(t), _fp(out), max_triangles)
+    return out[:min(n, max_triangles)].copy(), n

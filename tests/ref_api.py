@@ -280,3 +280,21 @@ def solver_solve(corr, valid, n_images, n_nonlin, n_lin, weights_sparse, weights
                            _fp(ws), _fp(wd), _fp(wc), len(ws), frames, W, H, _fp(geom) if geom is not None else None, int(use_pairwise), C.byref(gp),
                            _fp(rot), _fp(trans), _fp(conv), C.byref(mx) if len(corr) else None, C.byref(mi), _fp(rows), C.byref(ver) if len(corr) else None)
     return dict(convergence=conv, max_residual=mx.value, max_residual_index=mi.value, rows=rows, use_verification=bool(ver.value))
+
+
+# ---- marching cubes (CUDAMarchingCubesSDF.cu, MarchingCubesSDFUtil.h, Tables.h) ----
+def mc_tables():
+    """(edgeTable[256] uint16, triTable[256,16] int8) of the reference's Tables.h"""
+    e = np.zeros(256, np.uint16); t = np.zeros(256 * 16, np.int8)
+    lib().ref_mc_tables(_fp(e), _fp(t))
+    return e, t.reshape(256, 16)
+
+
+def mc_extract(scene, thresh, thresh2, max_triangles=2000000, box=None):
+    """extractIsoSurface on a RefScene -> triangles [n, 3, 6] (position, colour), in the (atomic) append order of the serial emulation"""
+    out = np.zeros((max_triangles, 3, 6), np.float32)
+    lib().ref_mc_extract.restype = C.c_uint32
+    mn = _f32(box[0]) if box else None; mx = _f32(box[1]) if box else None
+    n = lib().ref_mc_extract(scene._h, C.c_float(thresh), C.c_float(thresh2), int(box is not None), _fp(mn) if box else None, _fp(mx) if box else None,
+                             _fp(out), max_triangles)
+    return out[:min(n, max_triangles)].copy(), n

@@ -1,0 +1,74 @@
+"""GPU parity tests (-m gpu): marching cubes over the voxel hash through the C ABI vs the CPU oracle.
+
+The HIP extraction reads the volume only through bf_scene_get_hash_data() / bf_scene_get_hash_params() — the reference layout — so
+these tests are also the consumer-side check of that layout.  Bar: with the same case tables the triangle list is bit-exact INCLUDING
+its order (hash slot, voxel index, table order); tol = 0.  The oracle itself is pinned to the reference's own kernel and Tables.h in
+tests/test_ref_pin_cpu.py."""
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_hash_params, camera_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(gpu, oracle, W, H, voxel, buckets, blocks, ks):
+    import torch
+    frames = [synth.scene_room(k, W, H) for k in ks]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=buckets, num_sdf_blocks=blocks, voxel_size=voxel)
+    gs = gpu.capi.SceneRepHashSDF(p); osc = oracle.OracleScene(p)
+    for d, c, T, _ in frames:
+        gs.integrate(T, torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), cam)
+        osc.integrate(T, d, c, cam, threads=64)
+    return gs, osc, p
+
+
+def test_marching_cubes_bit_exact_and_ordered(gpu, oracle, tmp_path):
+    gs, osc, p = _build(gpu, oracle, 160, 120, 0.02, 20011, 20000, (0, 20, 40))
+    e, t = gpu.capi.marching_cubes_tables()
+    mc = gpu.capi.MarchingCubesHashSDF(600000, p.m_hashNumBuckets, 0.02)
+    tris, found = mc.extract(gs)
+    otris, on = oracle.mc_extract(osc, 0.2, 0.2, e, t, 600000)
+    assert found == on == len(tris) > 20000
+    assert np.array_equal(tris.view(np.uint32), otris.view(np.uint32))            # same triangles in the same order
+    # determinism: a second extraction gives the same bytes
+    tris2, _ = mc.extract(gs)
+    assert np.array_equal(tris.view(np.uint32), tris2.view(np.uint32))
+    # a box
+    pts = tris[:, :, :3].reshape(-1, 3)
+    box = ([float(v) for v in np.percentile(pts, 30, axis=0)], [float(v) for v in np.percentile(pts, 70, axis=0)])
+    tb, fb = mc.extract(gs, box=box)
+    ob, onb = oracle.mc_extract(osc, 0.2, 0.2, e, t, 600000, box=box)
+    assert 0 < fb == onb < found and np.array_equal(tb.view(np.uint32), ob.view(np.uint32))
+    # capacity: the buffer bounds the mesh, the count of what the volume holds is still reported
+    small = gpu.capi.MarchingCubesHashSDF(1000, p.m_hashNumBuckets, 0.02)
+    ts, fs = small.extract(gs)
+    assert fs == found and len(ts) == 1000 and np.array_equal(ts.view(np.uint32), tris[:1000].view(np.uint32))
+    # the mesh: a closed-enough surface patch — merged vertices are shared by ~6 triangles, the file parses
+    mc.extract(gs)
+    nv, nf = mc.save_mesh(tmp_path / "scan.ply")
+    assert nf <= found and nf > 0.98 * found and 0.4 * nf < nv < 0.7 * nf
+    raw = open(tmp_path / "scan.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"element vertex %d" % nv in head and b"element face %d" % nf in head and len(body) == nv * 16 + nf * 13
+
+
+def test_marching_cubes_at_4mm_and_after_reintegration(gpu, oracle):
+    """The bench resolution (640x480, 4 mm) with overflow chains in the hash, after a fused re-integration and a garbage collection."""
+    import torch
+    gs, osc, p = _build(gpu, oracle, 640, 480, 0.004, 100003, 120000, (0, 12))
+    d, c, T, K = synth.scene_room(12, 640, 480)
+    cam = camera_params(640, 480, K["fx"], K["fy"], K["mx"], K["my"])
+    T2 = T.copy(); T2[:3, 3] += np.float32(0.003)
+    gs.reintegrate(T, T2, torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), cam)
+    osc.deintegrate(T, d, c, cam, threads=64); osc.integrate(T2, d, c, cam, threads=64)
+    gs.garbage_collect(); osc.garbage_collect()
+    e, t = gpu.capi.marching_cubes_tables()
+    mc = gpu.capi.MarchingCubesHashSDF(3000000, p.m_hashNumBuckets, 0.004)
+    tris, found = mc.extract(gs)
+    otris, on = oracle.mc_extract(osc, 0.04, 0.04, e, t, 3000000)
+    assert found == on == len(tris) > 300000
+    assert np.array_equal(tris.view(np.uint32), otris.view(np.uint32))

@@ -349,3 +349,86 @@ def test_tsdf_operators_vs_reference_kernels(oracle, cfg):
         osc.compactify(T, cam); rsc.compactify(T, cam)
         _assert_same_volume(osc, rsc, nb, "tear-down %d" % i)
     assert len(_by_key(osc.hash(), osc.voxels())) == 0 and osc.heap_counter() + 1 == cfg["blocks"]
+
+
+# ------------------------------------------------------------------------------------------------ marching cubes
+def _loops(tri_row):
+    """directed boundary loops of one case's triangles, each rotated to start at its lowest edge"""
+    t = [int(x) for x in tri_row if x >= 0]
+    tris = [tuple(t[i:i + 3]) for i in range(0, len(t), 3)]
+    d = {}
+    for a, b, c in tris:
+        for u, v in ((a, b), (b, c), (c, a)):
+            d[(u, v)] = d.get((u, v), 0) + 1
+    nxt = {u: v for (u, v) in d if (v, u) not in d}
+    loops, seen = [], set()
+    for s0 in sorted(nxt):
+        if s0 in seen:
+            continue
+        loop, cur = [], s0
+        while cur not in seen:
+            seen.add(cur); loop.append(cur); cur = nxt[cur]
+        i = loop.index(min(loop))
+        loops.append(tuple(loop[i:] + loop[:i]))
+    return sorted(loops), len(tris)
+
+
+def test_marching_cubes_tables_vs_reference():
+    """The product GENERATES its case tables (mesh.hip: makeTables).  Against the reference's Tables.h: the edge table is identical;
+    for every one of the 256 cases the triangles bound the same oriented polygon loops (same cut edges, same connectivity on ambiguous
+    faces, same winding) and there are equally many of them; cases made of triangles only are identical as triangle sets."""
+    import ctypes as C
+    from bundlefusion_amd.capi import lib
+    e = np.zeros(256, np.uint16); t = np.zeros(256 * 16, np.int8)
+    assert lib.bf_marching_cubes_tables(e.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)) == 0
+    t = t.reshape(256, 16)
+    re_, rt = ref_api.mc_tables()
+    assert np.array_equal(e, re_)
+    same_triangles = 0
+    for cs in range(256):
+        lp, n = _loops(t[cs]); lr, nr = _loops(rt[cs])
+        assert lp == lr and n == nr, cs
+        canon = lambda row: sorted(tuple(sorted(int(x) for x in row[i:i + 3])) for i in range(0, 15, 3) if row[i] >= 0)
+        if all(len(l) == 3 for l in lr):
+            assert canon(t[cs]) == canon(rt[cs]), cs
+        same_triangles += canon(t[cs]) == canon(rt[cs])
+    assert same_triangles >= 90           # (larger polygons may be split along other diagonals: same vertices, same patch)
+
+
+def test_marching_cubes_oracle_vs_reference_kernels(oracle):
+    """extractIsoSurface of the reference (its own kernel, trilinear sampling and Tables.h) against the oracle restatement fed the SAME
+    tables, on a volume built from three frames: the same triangles — positions and colours bit for bit — as a multiset (the reference
+    appends in atomic order).  With the product's generated tables the oracle yields the same vertices and equally many triangles."""
+    import ctypes as C
+    from bundlefusion_amd.capi import lib
+    W, H = 96, 72
+    frames = [synth.scene_room(20 * k, W, H) for k in range(3)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=3001, num_sdf_blocks=6000, voxel_size=0.02)
+    osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p)
+    for d, c, T, _ in frames:
+        osc.integrate(T, d, c, cam); rsc.integrate(T, d, c, cam)
+    thresh = 10.0 * 0.02
+    re_, rt = ref_api.mc_tables()
+    rt_tris, rn = ref_api.mc_extract(rsc, thresh, thresh, 400000)
+    ot_tris, on = oracle.mc_extract(osc, thresh, thresh, re_, rt, 400000)
+    assert rn == on > 5000
+    key = lambda a: sorted(map(bytes, np.ascontiguousarray(a).reshape(len(a), -1)))
+    assert key(rt_tris) == key(ot_tris)
+    # a box restricts the extraction identically
+    pts = rt_tris[:, :, :3].reshape(-1, 3)
+    lo, hi = np.percentile(pts, 25, axis=0), np.percentile(pts, 75, axis=0)
+    box = ([float(v) for v in lo], [float(v) for v in hi])
+    rb, rbn = ref_api.mc_extract(rsc, thresh, thresh, 400000, box=box)
+    ob, obn = oracle.mc_extract(osc, thresh, thresh, re_, rt, 400000, box=box)
+    assert 0 < rbn == obn < rn and key(rb) == key(ob)
+    # the product's tables: same vertices (positions + colours), same triangle count
+    e = np.zeros(256, np.uint16); t = np.zeros(256 * 16, np.int8)
+    assert lib.bf_marching_cubes_tables(e.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)) == 0
+    pt_tris, pn = oracle.mc_extract(osc, thresh, thresh, e, t.reshape(256, 16), 400000)
+    assert pn == rn
+    verts = lambda a: set(map(bytes, np.ascontiguousarray(a).reshape(-1, 6)))
+    assert verts(pt_tris) == verts(rt_tris)
+    area = lambda a: float(np.linalg.norm(np.cross(a[:, 1, :3] - a[:, 0, :3], a[:, 2, :3] - a[:, 0, :3]), axis=1).sum() / 2)
+    assert abs(area(pt_tris) - area(rt_tris)) <= 2e-3 * area(rt_tris)
