@@ -888,6 +888,23 @@ class Pipeline:
         check(lib.bf_online_bundler_get_bundler(ob, {"local": 0, "optLocal": 1, "global": 2}[which], C.byref(b)))
         return b
 
+    def initialize_correspondence_evaluator(self, complete_trajectory, log_prefix=None):
+        """OnlineBundler.cpp:81-90: evaluate the global key-frame matches against a reference trajectory (one 4x4 per INPUT frame)."""
+        ob = C.c_void_p()
+        check(lib.bf_pipeline_get_online_bundler(self._h, C.byref(ob)))
+        t = np.ascontiguousarray(complete_trajectory, np.float32).reshape(-1, 16)
+        check(lib.bf_online_bundler_initialize_correspondence_evaluator(ob, t.ctypes.data_as(C.POINTER(C.c_float)), len(t), (log_prefix or "").encode()))
+
+    def finish_correspondence_evaluator_logging(self):
+        ob = C.c_void_p()
+        check(lib.bf_pipeline_get_online_bundler(self._h, C.byref(ob)))
+        check(lib.bf_online_bundler_finish_correspondence_evaluator_logging(ob))
+
+    def correspondence_evaluator(self):
+        h = C.c_void_p()
+        check(lib.bf_bundler_get_correspondence_evaluator(self.bundler("global"), C.byref(h)))
+        return CorrespondenceEvaluator(handle=h) if h else None
+
 
 class ChunkWorker:
     """Python view of `bf_chunk_worker`: the chunk-local half of the frame loop (SIFT, matching + filters inside the chunk, local
@@ -972,3 +989,68 @@ class MarchingCubesHashSDF:
         T = mat16(transform) if transform is not None else None
         check(lib.bf_marching_cubes_save_mesh(self._h, str(filename).encode(), T, C.byref(nv), C.byref(nf)))
         return nv.value, nf.value
+
+
+# --------------------------------------------------------------------------- CorrespondenceEvaluator
+class CorrEvaluation(C.Structure):
+    _fields_ = [("numCorrect", C.c_uint32), ("numDetected", C.c_uint32), ("numTotal", C.c_uint32)]
+
+    def precision(self):
+        lib.bf_corr_evaluation_get_precision.restype = C.c_float
+        return float(lib.bf_corr_evaluation_get_precision(C.byref(self)))
+
+    def recall(self):
+        lib.bf_corr_evaluation_get_recall.restype = C.c_float
+        return float(lib.bf_corr_evaluation_get_recall(C.byref(self)))
+
+    def as_tuple(self):
+        return (self.numCorrect, self.numDetected, self.numTotal)
+
+
+class CorrEvalParams(C.Structure):
+    _fields_ = [("depthMin", C.c_float), ("depthMax", C.c_float), ("distThresh", C.c_float), ("normalThresh", C.c_float), ("colorThresh", C.c_float)]
+
+
+class CorrespondenceEvaluator:
+    """Python view of `bf_correspondence_evaluator` (== class CorrespondenceEvaluator, CorrespondenceEvaluator.h:39): precision / recall
+    of the current frame's image-to-image matches against a reference trajectory."""
+
+    def __init__(self, trajectory=None, log_prefix=None, handle=None):
+        self._borrowed = handle is not None
+        if handle is not None:
+            self._h = handle
+            return
+        t = np.ascontiguousarray(trajectory, np.float32).reshape(-1, 16)
+        self._h = C.c_void_p()
+        check(lib.bf_correspondence_evaluator_create(t.ctypes.data_as(C.POINTER(C.c_float)), len(t), (log_prefix or "").encode(), C.byref(self._h)))
+
+    def close(self):
+        if self._h and not self._borrowed:
+            lib.bf_correspondence_evaluator_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def evaluate(self, mgr, cache, sift_intrinsics_inv, filtered, recompute_cache, clear_cache, corr_type, params=None, stream=0):
+        p = params or CorrEvalParams(0.5, 4.0, 0.15, 0.97, 0.1)          # zParametersBundlingDefault.txt:26-27,55-57
+        out = CorrEvaluation()
+        check(lib.bf_correspondence_evaluator_evaluate(self._h, mgr._h, cache._h, _f16(sift_intrinsics_inv), C.byref(p), int(filtered), int(recompute_cache),
+                                                       int(clear_cache), corr_type.encode(), C.c_void_p(stream), C.byref(out)))
+        return out
+
+    def finish_logging(self):
+        check(lib.bf_correspondence_evaluator_finish_logging_to_file(self._h))
+
+    def total(self, corr_type):
+        out = CorrEvaluation()
+        check(lib.bf_correspondence_evaluator_get_total(self._h, corr_type.encode(), C.byref(out)))
+        return out
+
+    def overlap_counts(self, num_frames, with_flags=True):
+        c = np.zeros((num_frames, 4), np.uint32); f = np.zeros(num_frames, np.uint8)
+        check(lib.bf_correspondence_evaluator_get_overlap_counts(self._h, c.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if with_flags else None, num_frames))
+        return c, f

@@ -388,6 +388,7 @@ struct bf_bundler {
     float maxResidual = -1.0f;
     uint32_t numSolves = 0;
     std::vector<int> validScratch;
+    bf_correspondence_evaluator* corrEvaluator = nullptr;       // Bundler.h:101-103
 };
 
 namespace {
@@ -405,6 +406,12 @@ int cacheK(bf_bundler* b, uint32_t& w, uint32_t& h, float k4[4], m44& K) {
 }
 
 // the asynchronous half of Bundler::matchAndFilter (:103-221): everything up to the read-back of the frame result
+int evaluateStage(bf_bundler* b, bool filtered, bool recompute, bool clear, const char* type) {      // Bundler.cpp:145-147,164-166,181-183,202-204
+    if (!b->corrEvaluator) return BF_OK;
+    const bf_corr_eval_params p = {b->gbs.s_denseDepthMin, b->gbs.s_denseDepthMax, b->gbs.s_projCorrDistThres, b->gbs.s_projCorrNormalThres, b->gbs.s_projCorrColorThresh};
+    return bf_correspondence_evaluator_evaluate(b->corrEvaluator, b->mgr, b->cache, b->siftIntrinsicsInv.e, &p, filtered, recompute, clear, type, b->stream, nullptr);
+}
+
 int matchAndFilterEnqueue(bf_bundler* b, uint32_t& curFrame, uint32_t& startFrame, uint32_t& numFrames) {
     BF_TRY(bf_siftmgr_get_num_images(b->mgr, &numFrames));
     BF_REQUIRE(numFrames > 1, "matchAndFilter needs more than one frame");
@@ -415,8 +422,11 @@ int matchAndFilterEnqueue(bf_bundler* b, uint32_t& curFrame, uint32_t& startFram
     BF_TRY(bf_siftmgr_match(b->mgr, curFrame, startFrame, numFrames, b->gbs.s_siftMatchThresh, ratioMax));
     if (curFrame > 0) {
         const uint32_t minNumMatches = b->isLocal ? b->gbs.s_minNumMatchesLocal : b->gbs.s_minNumMatchesGlobal;
+        BF_TRY(evaluateStage(b, false, true, false, "raw"));
         BF_TRY(bf_siftmgr_filter_keypoint_matches(b->mgr, curFrame, startFrame, numFrames, b->siftIntrinsicsInv.e, minNumMatches, b->gbs.s_maxKabschResidual2));
+        BF_TRY(evaluateStage(b, true, false, false, "kabsch"));
         BF_TRY(bf_siftmgr_filter_matches_by_surface_area(b->mgr, curFrame, startFrame, numFrames, b->siftIntrinsicsInv.e, b->gbs.s_surfAreaPcaThresh));
+        BF_TRY(evaluateStage(b, true, false, false, "sa"));
         uint32_t cw, ch; float k4[4]; m44 K;
         BF_TRY(cacheK(b, cw, ch, k4, K));
         const bf_cached_frame* d_frames = nullptr;
@@ -424,6 +434,7 @@ int matchAndFilterEnqueue(bf_bundler* b, uint32_t& curFrame, uint32_t& startFram
         BF_TRY(bf_siftmgr_filter_matches_by_dense_verify(b->mgr, curFrame, startFrame, numFrames, cw, ch, K.e, d_frames, b->gbs.s_projCorrDistThres,
                                                          b->gbs.s_projCorrNormalThres, b->gbs.s_projCorrColorThresh, b->gbs.s_verifySiftErrThresh,
                                                          b->gbs.s_verifySiftCorrThresh, b->gas.s_sensorDepthMin, b->gas.s_sensorDepthMax));
+        BF_TRY(evaluateStage(b, true, false, true, "dense"));
         BF_TRY(bf_siftmgr_filter_frames_async(b->mgr, curFrame, startFrame, numFrames));
         BF_TRY(bf_siftmgr_add_curr_to_residuals(b->mgr, curFrame, startFrame, numFrames, b->siftIntrinsicsInv.e));
     }
@@ -589,6 +600,7 @@ int bf_bundler_create(uint32_t maxNumImages, uint32_t maxNumKeysPerImage, const 
 int bf_bundler_destroy(bf_bundler* b) {
     if (!b) return BF_OK;
     bf_sift_destroy(b->sift); bf_solver_destroy(b->solver); bf_cache_destroy(b->cache); bf_siftmgr_destroy(b->mgr);
+    bf_correspondence_evaluator_destroy(b->corrEvaluator);
     (void)hipFree(b->d_trajectory); (void)hipFree(b->d_xRot); (void)hipFree(b->d_xTrans);
     delete b;
     return BF_OK;
@@ -744,6 +756,17 @@ int bf_bundler_save_sparse_corrs_to_file(bf_bundler* b, const char* filename) { 
     return BF_OK;
 }
 
+int bf_bundler_initialize_correspondence_evaluator(bf_bundler* b, const float* h_trajectory, uint32_t numTransforms, const char* logFilePrefix) {
+    BF_REQUIRE(b, "null bundler");
+    bf_correspondence_evaluator_destroy(b->corrEvaluator);
+    b->corrEvaluator = nullptr;
+    return bf_correspondence_evaluator_create(h_trajectory, numTransforms, logFilePrefix, &b->corrEvaluator);
+}
+int bf_bundler_finish_correspondence_evaluator_logging(bf_bundler* b) {
+    BF_REQUIRE(b, "null bundler");
+    return b->corrEvaluator ? bf_correspondence_evaluator_finish_logging_to_file(b->corrEvaluator) : BF_OK;
+}
+int bf_bundler_get_correspondence_evaluator(bf_bundler* b, bf_correspondence_evaluator** out) { BF_REQUIRE(b && out, "null argument"); *out = b->corrEvaluator; return BF_OK; }
 int bf_bundler_get_sift_manager(bf_bundler* b, bf_siftmgr** out) { BF_REQUIRE(b && out, "null argument"); *out = b->mgr; return BF_OK; }
 int bf_bundler_get_cache(bf_bundler* b, bf_cache** out) { BF_REQUIRE(b && out, "null argument"); *out = b->cache; return BF_OK; }
 int bf_bundler_get_solver(bf_bundler* b, bf_solver** out) { BF_REQUIRE(b && out, "null argument"); *out = b->solver; return BF_OK; }
@@ -1446,6 +1469,18 @@ int bf_online_bundler_get_complete_trajectory(bf_online_bundler* ob, float* h_ou
     return BF_OK;
 }
 int bf_online_bundler_save_global_sparse_corrs_to_file(bf_online_bundler* ob, const char* filename) { BF_REQUIRE(ob, "null bundler"); return bf_bundler_save_sparse_corrs_to_file(ob->global, filename); }
+int bf_online_bundler_initialize_correspondence_evaluator(bf_online_bundler* ob, const float* h_completeTrajectory, uint32_t numFrames, const char* logFilePrefix) {
+    BF_REQUIRE(ob && h_completeTrajectory, "null argument");                                  // OnlineBundler.cpp:81-90: "only want global trajectory"
+    std::vector<float> keyPoses;
+    for (uint32_t i = 0; i < numFrames; i += ob->submapSize) keyPoses.insert(keyPoses.end(), h_completeTrajectory + 16 * (size_t)i, h_completeTrajectory + 16 * (size_t)i + 16);
+    return bf_bundler_initialize_correspondence_evaluator(ob->global, keyPoses.data(), (uint32_t)(keyPoses.size() / 16), logFilePrefix);
+}
+int bf_online_bundler_finish_correspondence_evaluator_logging(bf_online_bundler* ob) {       // :480-487
+    BF_REQUIRE(ob, "null bundler");
+    BF_TRY(bf_bundler_finish_correspondence_evaluator_logging(ob->global));
+    BF_TRY(bf_bundler_finish_correspondence_evaluator_logging(ob->local));
+    return bf_bundler_finish_correspondence_evaluator_logging(ob->optLocal);
+}
 
 }  // extern "C"
 

@@ -1156,6 +1156,12 @@ int bf_siftmgr_get_keys_gpu(bf_siftmgr* m, const bf_sift_keypoint** d_keys, cons
     return BF_OK;
 }
 
+int bf_siftmgr_get_curr_matches_gpu(bf_siftmgr* m, int filtered, const uint32_t** d_keyPointIndices, const int32_t** d_numMatches) {
+    BF_REQUIRE(m && d_keyPointIndices && d_numMatches, "null argument");
+    *d_keyPointIndices = (const uint32_t*)(filtered ? m->d_fidx : m->d_idx);
+    *d_numMatches = filtered ? m->d_numFilt : m->d_numMatches;
+    return BF_OK;
+}
 int bf_siftmgr_get_raw_matches(bf_siftmgr* m, uint32_t imagePairIndex, int32_t* numMatches, uint32_t* h_keyPointIndices, float* h_distances) {
     BF_REQUIRE(m && numMatches && imagePairIndex < m->maxImages, "bad argument");
     BF_HIP_TRY(hipMemcpyAsync(numMatches, m->d_numMatches + imagePairIndex, sizeof(int), hipMemcpyDeviceToHost, m->stream));

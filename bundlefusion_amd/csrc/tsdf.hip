@@ -43,7 +43,7 @@ constexpr int KEYLIM = 1 << 20;
 struct AllocRec { uint64_t key; int32_t ptr; uint32_t pad; };          // 16 B
 struct BinRec { uint64_t key; uint32_t bucket; uint32_t aux; };        // 16 B
 
-enum Stat { ST_DROPPED = 0, ST_ERROR = 1, ST_STUCK = 2, ST_COUNT = 4 };      // ST_STUCK: de-dup slots of keys that found their bin full (released by k_alloc_finish)
+enum Stat { ST_DROPPED = 0, ST_ERROR = 1, ST_STUCK = 2, ST_TICKET = 3, ST_COUNT = 4 };      // ST_STUCK: de-dup slots of keys that found their bin full (released by k_alloc_finish)
 enum ErrBits { ERR_BIN_OVERFLOW = 1, ERR_DEDUPE_FULL = 2, ERR_OV_OVERFLOW = 4, ERR_GC_MISSING = 8, ERR_LIST_FULL = 16 };
 
 struct Dev {
@@ -222,15 +222,50 @@ BF_DEV void emitCandidate(const Dev& d, const Frame& f, i3 b) {
     atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
 }
 
-// Neighbouring pixels of the 8x8 tile walk through the same 8^3 block at the same DDA step most of the time (a block is ~9
-// pixels wide at 2 m); a lane whose left or upper neighbour holds the same block this step leaves the frustum test and the
-// hash-bucket look-up (320 bytes of random traffic) to that neighbour.  Queuing a block is idempotent, so the set of
-// candidates is unchanged.  All 64 lanes stay in the loop (alive flag) so that the lane exchange is well defined.
+// One wave = one 8x8 pixel tile.  The DDA itself touches no global memory: every block a ray steps through goes into a small LDS set
+// of the wave (neighbouring pixels walk through the same 8^3 block most of the time - a block is ~9 pixels wide at 2 m - so a tile
+// sees ~30 distinct blocks in ~600 lane-steps; a lane whose left or upper neighbour holds the same block this step does not even try).
+// Only the distinct blocks are then tested against the frustum and looked up in the hash table, one lane per block, all look-ups of a
+// wave in flight together.  (The first version looked every block up inside the DDA loop: one dependent ~2 us global round trip per
+// step made the kernel a 15-deep latency chain, 40-75 us per launch.)  Queuing a block is idempotent and the bins are sorted before
+// they are placed, so the hash table does not depend on the order in which candidates are found.
+constexpr uint32_t WSET = 256;        // slots of a wave's block set (open addressing, load <= 0.5)
+constexpr uint32_t WLIST = 128;       // distinct blocks buffered per wave before they are looked up
+
+BF_DEV bool waveSetInsert(unsigned long long* set, uint64_t key) {
+    uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (WSET - 1);
+    for (uint32_t probe = 0; probe < WSET; ++probe) {
+        const unsigned long long old = atomicCAS(&set[slot], (unsigned long long)EMPTY64, (unsigned long long)key);
+        if (old == EMPTY64) return true;
+        if (old == key) return false;
+        slot = (slot + 1) & (WSET - 1);
+    }
+    return false;       // cannot happen: the set is flushed at half load
+}
+
+BF_DEV void waveSetFlush(const Dev& d, const Frame& f, unsigned long long* set, const unsigned long long* list, uint32_t n, uint32_t lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the list entries were written by other lanes of this wave
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const i3 b = unpackKey(list[i]);
+            if (blockInFrustum(f, b)) emitCandidate(d, f, b);
+        }
+    }
+    for (uint32_t i = lane; i < WSET; i += 64) set[i] = EMPTY64;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth) {
+    __shared__ unsigned long long setAll[4][WSET];
+    __shared__ unsigned long long listAll[4][WLIST];
+    unsigned long long* set = setAll[threadIdx.x >> 6];
+    unsigned long long* list = listAll[threadIdx.x >> 6];
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
     const uint32_t tilesX = (W + 7) / 8;
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t i = lane; i < WSET; i += 64) set[i] = EMPTY64;
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7);
     const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
     bool alive = x < W && y < H;
@@ -270,6 +305,7 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
     if (boundary.y - rayMin.y == 0.0f) { tMax.y = BF_PINF; tDelta.y = BF_PINF; }
     if (rayDir.z == 0.0f) { tMax.z = BF_PINF; tDelta.z = BF_PINF; }
     if (boundary.z - rayMin.z == 0.0f) { tMax.z = BF_PINF; tDelta.z = BF_PINF; }
+    uint32_t uniq = 0;                      // wave-uniform: blocks buffered in `list`
     for (unsigned iter = 0; iter < 1024; ++iter) {
         if (!__any((int)alive)) break;
         const int live = alive ? 1 : 0;
@@ -277,8 +313,14 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
         const int ux = __shfl_up(cur.x, 8, 64), uy = __shfl_up(cur.y, 8, 64), uz = __shfl_up(cur.z, 8, 64), ul = __shfl_up(live, 8, 64);
         const bool sameLeft = (lane & 7) != 0 && ll && lx == cur.x && ly == cur.y && lz == cur.z;
         const bool sameUp = lane >= 8 && ul && ux == cur.x && uy == cur.y && uz == cur.z;
+        bool fresh = false;
+        uint64_t key = 0;
+        if (alive && !sameLeft && !sameUp && keyable(cur)) { key = packKey(cur); fresh = waveSetInsert(set, key); }
+        const unsigned long long mask = __ballot((int)fresh);
+        if (fresh) list[uniq + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = key;
+        uniq += (uint32_t)__popcll(mask);
+        if (uniq > WLIST - 64) { waveSetFlush(d, f, set, list, uniq, lane); uniq = 0; }
         if (alive) {
-            if (!sameLeft && !sameUp && blockInFrustum(f, cur)) emitCandidate(d, f, cur);
             if (tMax.x < tMax.y && tMax.x < tMax.z) {
                 cur.x = f2i((float)cur.x + step.x);
                 if (cur.x == bound.x) alive = false;
@@ -294,6 +336,7 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
             }
         }
     }
+    if (uniq) waveSetFlush(d, f, set, list, uniq, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -360,15 +403,15 @@ BF_DEV uint32_t binPrefix(const uint32_t* binCount, uint32_t limit, uint32_t* sc
 // alloc, pass B: one workgroup per bin — sort, rank, place into home buckets
 //   (serial-equivalent of allocBlock's in-bucket branch, VoxelUtilHashSDF.h:553-612)
 // ---------------------------------------------------------------------------------------
-// 256 threads: the usual bin holds a handful of new keys, and four waves find a free CU next to the voxel kernels much sooner
-// than sixteen; a full bin (4096 records, first frames of a scan) sorts in ~10 us either way.
-__global__ __launch_bounds__(256) void k_alloc_insert(Dev d, Frame f) {
-    __shared__ SortLds s;
-    __shared__ uint32_t scratch[16];
-    __shared__ int8_t sel[BINCAP];
-    const uint32_t bin = blockIdx.x;
+// One launch for passes B and C: PLACE_WGS workgroups walk the bins (the usual bin holds a handful of new keys; a full bin - 4096 records,
+// first frames of a scan - sorts in ~10 us), and the workgroup that finishes last runs the single-workgroup tail.  (As two kernels of
+// 256 and 1 workgroups the passes cost two more dependent launches per operator, each of which queued behind the voxel kernels of the
+// other stream for 10-30 us: the allocation chain, not the voxel update, paced the re-integration loop.)
+constexpr uint32_t PLACE_WGS = 64;
+
+BF_DEV void placeBin(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch, int8_t* sel, uint32_t bin) {
     const uint32_t n = min(d.binCount[bin], BINCAP);
-    if (n == 0) return;
+    if (n == 0) return;                       // block-uniform
     loadBinSorted(s, d.bins + (size_t)bin * BINCAP, n);
     const uint32_t base = binPrefix(d.binCount, bin, scratch);
     const uint32_t heapC = d.heapCounter[0];
@@ -416,15 +459,14 @@ __global__ __launch_bounds__(256) void k_alloc_insert(Dev d, Frame f) {
             else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
         }
     }
+    __syncthreads();                          // s and sel are reused for the next bin
 }
 
 // ---------------------------------------------------------------------------------------
 // alloc, pass C: single workgroup tail — bucket-full keys walk the collision window in
 // sorted order (VoxelUtilHashSDF.h:614-654), counters are committed, bins are recycled.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
-    __shared__ SortLds s;
-    __shared__ uint32_t scratch[16];
+BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch) {
     const uint32_t M = binPrefix(d.binCount, NBINS, scratch);
     const uint32_t nov = min(d.overflowCount[0], OVCAP);
     if (nov > 0) loadBinSorted(s, d.overflow, nov);
@@ -432,7 +474,7 @@ __global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
         const uint32_t heapC = d.heapCounter[0];
         const uint32_t allocBase = d.allocCount[0];
         const uint32_t listRoom = f.numSDFBlocks - min(allocBase, f.numSDFBlocks);
-        const uint32_t heapFree = min(heapC + 1u, listRoom);          // the same limit k_alloc_insert applied
+        const uint32_t heapFree = min(heapC + 1u, listRoom);          // the same limit placeBin applied
         if (M > listRoom && listRoom < heapC + 1u) atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_LIST_FULL);
         const uint32_t Mp = min(M, heapFree);
         const uint32_t total = BF_HASH_BUCKET_SIZE * f.numBuckets;
@@ -481,6 +523,28 @@ __global__ __launch_bounds__(1024) void k_alloc_finish(Dev d, Frame f) {
         if (threadIdx.x == 0) d.stats[ST_STUCK] = 0;
     }
     for (uint32_t b = threadIdx.x; b < NBINS; b += blockDim.x) d.binCount[b] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
+    __shared__ SortLds s;
+    __shared__ uint32_t scratch[16];
+    __shared__ int8_t sel[BINCAP];
+    __shared__ uint32_t lastFlag;
+    for (uint32_t bin = blockIdx.x; bin < NBINS; bin += gridDim.x) placeBin(d, f, s, scratch, sel, bin);
+    // hand-off to the workgroup that arrives last: drain this wave's stores, publish (agent-scope release by one lane), take a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t ticket = atomicAdd(&d.stats[ST_TICKET], 1u);
+        lastFlag = ticket == gridDim.x - 1 ? 1u : 0u;
+        if (lastFlag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // same CU as every other wave of this workgroup: its L1 is clean from here on
+    }
+    __syncthreads();
+    if (!lastFlag) return;
+    placeTail(d, f, s, scratch);
+    if (threadIdx.x == 0) d.stats[ST_TICKET] = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1225,8 +1289,7 @@ int refreshStaleList(bf_scene* s) {                              // a fused re-i
 void launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_depth) {      // alloc :328-352
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
     hipLaunchKernelGGL(k_alloc_candidates, dim3(div_up(tiles, 4)), dim3(256), 0, st, s->d, f, d_depth);
-    hipLaunchKernelGGL(k_alloc_insert, dim3(NBINS), dim3(256), 0, st, s->d, f);
-    hipLaunchKernelGGL(k_alloc_finish, dim3(1), dim3(1024), 0, st, s->d, f);
+    hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
 }
 
 // One operator = [allocation] -> frustum list -> voxel update.  kind 0 integrate(f), 1 de-integrate(f), 2 fused: de-integrate(fo) +

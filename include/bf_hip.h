@@ -429,6 +429,12 @@ BF_API int bf_siftmgr_get_filt_transforms_gpu(bf_siftmgr* m, const float** d_tra
 BF_API int bf_siftmgr_get_num_filt_matches_gpu(bf_siftmgr* m, const int32_t** d_out);
 BF_API int bf_siftmgr_get_keys_gpu(bf_siftmgr* m, const bf_sift_keypoint** d_keys, const bf_sift_keypoint_desc** d_descs,
                                    const int32_t** d_numKeys);
+#define BF_MAX_MATCHES_PER_IMAGE_PAIR_RAW 128u        /* GlobalDefines.h:8 */
+#define BF_MAX_MATCHES_PER_IMAGE_PAIR_FILTERED 25u    /* GlobalDefines.h:9 */
+/* getCurrMatchKeyPointIndicesDEBUG without the copy (SIFTImageManager.h:236-243): device views of the current frame's match lists -
+ * uint2 key indices [maxImages][128] (raw) or [maxImages][25] (filtered) and the match count per previous image.  A key index is
+ * image * maxNumKeyPointsPerImage + key (fixed stride; the reference packs the key points of all images). */
+BF_API int bf_siftmgr_get_curr_matches_gpu(bf_siftmgr* m, int filtered, const uint32_t** d_keyPointIndices, const int32_t** d_numMatches);
 /* get{Raw,Filt}KeyPointIndicesAndMatchDistancesDEBUG           .h:212-235 (128 / 25 slots are copied) */
 BF_API int bf_siftmgr_get_raw_matches(bf_siftmgr* m, uint32_t imagePairIndex, int32_t* numMatches,
                                       uint32_t* h_keyPointIndices, float* h_distances);

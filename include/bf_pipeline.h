@@ -158,6 +158,48 @@ BF_API int bf_bundler_get_cache(bf_bundler* b, bf_cache** out);
 BF_API int bf_bundler_get_solver(bf_bundler* b, bf_solver** out);
 
 /* ------------------------------------------------------------------------- */
+/* CorrespondenceEvaluator:  CorrespondenceEvaluator.h:39-141, .cpp           */
+/* (compiled in the reference under EVALUATE_SPARSE_CORRESPONDENCES,          */
+/*  GlobalBundlingState.h:11; always available here, active once attached)    */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_corr_evaluation {       /* struct CorrEvaluation  .h:10-37 */
+    uint32_t numCorrect;                  /* image pairs with matches whose largest world-space error is below the threshold AND that overlap */
+    uint32_t numDetected;                 /* overlapping image pairs for which matches were found */
+    uint32_t numTotal;                    /* overlapping image pairs (by the reference trajectory) */
+} bf_corr_evaluation;
+BF_API float bf_corr_evaluation_get_precision(const bf_corr_evaluation* e);     /* numCorrect / numDetected, -inf without detections */
+BF_API float bf_corr_evaluation_get_recall(const bf_corr_evaluation* e);        /* numDetected / numTotal,   -inf without overlaps   */
+
+typedef struct bf_corr_eval_params {      /* what computeCachedData reads from GlobalBundlingState  .cpp:15-19 */
+    float depthMin, depthMax;             /* s_denseDepthMin / s_denseDepthMax */
+    float distThresh, normalThresh, colorThresh;   /* s_projCorrDistThres / s_projCorrNormalThres / s_projCorrColorThresh (colour is unused, .cpp:198) */
+} bf_corr_eval_params;
+
+typedef struct bf_correspondence_evaluator bf_correspondence_evaluator;
+/* CorrespondenceEvaluator(referenceTrajectory, logFilePrefix)  .h:42-57: one 4x4 per image of the manager that will be evaluated;
+ * logFilePrefix NULL or "" = no files, otherwise <prefix>_frame.csv and <prefix>_wrong.csv are written in the reference's format. */
+BF_API int bf_correspondence_evaluator_create(const float* h_referenceTrajectory, uint32_t numTransforms, const char* logFilePrefix,
+                                              bf_correspondence_evaluator** out);
+BF_API int bf_correspondence_evaluator_destroy(bf_correspondence_evaluator* ev);
+/* evaluate(siftManager, cudaCache, siftIntrinsicsInv, filtered, recomputeCache, clearCache, corrType)  .cpp:47-96.
+ * Synchronises hip_stream (the stream the manager's matching was enqueued on).  out may be NULL. */
+BF_API int bf_correspondence_evaluator_evaluate(bf_correspondence_evaluator* ev, bf_siftmgr* siftManager, bf_cache* cache,
+                                                const float siftIntrinsicsInv[16], const bf_corr_eval_params* params, int filtered,
+                                                int recomputeCache, int clearCache, const char* corrType, void* hip_stream,
+                                                bf_corr_evaluation* out);
+BF_API int bf_correspondence_evaluator_finish_logging_to_file(bf_correspondence_evaluator* ev);       /* .h:64-69 */
+/* sum of all evaluate() results for one corrType ("raw", "kabsch", "sa", "dense") since creation */
+BF_API int bf_correspondence_evaluator_get_total(bf_correspondence_evaluator* ev, const char* corrType, bf_corr_evaluation* out);
+/* the counters of the last computeCachedData: per image {numCorr, numValid} cur->prev and prev->cur, and the overlap flags */
+BF_API int bf_correspondence_evaluator_get_overlap_counts(bf_correspondence_evaluator* ev, uint32_t* h_counts4, uint8_t* h_hasGTCorr,
+                                                          uint32_t numFrames);
+/* Bundler::initializeCorrespondenceEvaluator / finishCorrespondenceEvaluatorLogging  Bundler.h:61-67; with an evaluator attached,
+ * matchAndFilter evaluates after each stage (Bundler.cpp:145-204), which synchronises the stream four times per frame. */
+BF_API int bf_bundler_initialize_correspondence_evaluator(bf_bundler* b, const float* h_trajectory, uint32_t numTransforms, const char* logFilePrefix);
+BF_API int bf_bundler_finish_correspondence_evaluator_logging(bf_bundler* b);
+BF_API int bf_bundler_get_correspondence_evaluator(bf_bundler* b, bf_correspondence_evaluator** out);   /* NULL when none is attached */
+
+/* ------------------------------------------------------------------------- */
 /* TrajectoryManager:  TrajectoryManager.h:6-116, .cpp                        */
 /* ------------------------------------------------------------------------- */
 typedef struct bf_trajectory_manager bf_trajectory_manager;
@@ -213,6 +255,11 @@ BF_API int bf_online_bundler_get_curr_processed_frame(bf_online_bundler* ob, int
 BF_API int bf_online_bundler_get_bundler(bf_online_bundler* ob, int which /* 0 local, 1 optLocal, 2 global */, bf_bundler** out);
 BF_API int bf_online_bundler_get_complete_trajectory(bf_online_bundler* ob, float* h_out, uint32_t capacity, uint32_t* count);
 BF_API int bf_online_bundler_save_global_sparse_corrs_to_file(bf_online_bundler* ob, const char* filename);
+/* OnlineBundler.cpp:81-90: attach a CorrespondenceEvaluator to the GLOBAL bundler; h_completeTrajectory holds one reference pose per
+ * input frame, every s_submapSize-th is used.  finishCorrespondenceEvaluatorLogging  .cpp:480-487. */
+BF_API int bf_online_bundler_initialize_correspondence_evaluator(bf_online_bundler* ob, const float* h_completeTrajectory, uint32_t numFrames,
+                                                                 const char* logFilePrefix);
+BF_API int bf_online_bundler_finish_correspondence_evaluator_logging(bf_online_bundler* ob);
 /* the three trajectory kernels of OnlineBundler.cu (computeSiftTransformCU / updateTrajectoryCU / initNextGlobalTransformCU) */
 BF_API int bf_compute_sift_transform(const float* d_currFilteredTransformsInv, const int32_t* d_currNumFilteredMatchesPerImagePair,
                                      const float* d_completeTrajectory, uint32_t lastValidCompleteTransform, float* d_siftTrajectory,
