@@ -708,6 +708,9 @@ class GlobalAppState(C.Structure):
         ("s_streamingVoxelExtents", C.c_float * 3), ("s_streamingGridDimensions", C.c_int32 * 3), ("s_streamingMinGridPos", C.c_int32 * 3),
         ("s_streamingInitialChunkListSize", C.c_uint32), ("s_numSolveFramesBeforeExit", C.c_uint32),
         ("s_binaryDumpSensorFile", C.c_char * 512),
+        ("s_rayCastWidth", C.c_uint32), ("s_rayCastHeight", C.c_uint32),
+        ("s_SDFRayIncrementFactor", C.c_float), ("s_SDFRayThresSampleDistFactor", C.c_float), ("s_SDFRayThresDistFactor", C.c_float),
+        ("s_SDFUseGradients", C.c_int32),
     ]
 
 
@@ -1054,3 +1057,77 @@ class CorrespondenceEvaluator:
         c = np.zeros((num_frames, 4), np.uint32); f = np.zeros(num_frames, np.uint8)
         check(lib.bf_correspondence_evaluator_get_overlap_counts(self._h, c.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if with_flags else None, num_frames))
         return c, f
+
+
+# --------------------------------------------------------------------------- ray cast
+class RayCastParams(C.Structure):
+    _fields_ = [("m_viewMatrix", C.c_float * 16), ("m_viewMatrixInverse", C.c_float * 16),
+                ("mx", C.c_float), ("my", C.c_float), ("fx", C.c_float), ("fy", C.c_float),
+                ("m_width", C.c_uint32), ("m_height", C.c_uint32), ("m_numOccupiedSDFBlocks", C.c_uint32), ("m_maxNumVertices", C.c_uint32),
+                ("m_splatMinimum", C.c_int32), ("m_minDepth", C.c_float), ("m_maxDepth", C.c_float),
+                ("m_rayIncrement", C.c_float), ("m_thresSampleDist", C.c_float), ("m_thresDist", C.c_float),
+                ("m_useGradients", C.c_int32), ("dummy0", C.c_uint32)]
+
+
+class RayCastData(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("d_depth", "d_depth4", "d_normals", "d_colors", "d_rayIntervalSplatMin", "d_rayIntervalSplatMax")]
+
+
+def ray_cast_params_from_global_app_state(gas, intrinsics):
+    """CUDARayCastSDF::parametersFromGlobalAppState (CUDARayCastSDF.h:24-52)"""
+    p = RayCastParams()
+    check(lib.bf_ray_cast_params_from_global_app_state(C.byref(gas), _f16(intrinsics), C.byref(p)))
+    return p
+
+
+class RayCastSDF:
+    """Python view of `bf_ray_cast` (== class CUDARayCastSDF)."""
+
+    def __init__(self, params, stream=None):
+        self._h = C.c_void_p()
+        check(lib.bf_ray_cast_create(C.byref(params), C.byref(self._h)))
+        if stream is not None:
+            check(lib.bf_ray_cast_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            lib.bf_ray_cast_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def params(self):
+        p = RayCastParams()
+        check(lib.bf_ray_cast_get_params(self._h, C.byref(p)))
+        return p
+
+    def update_min_max(self, dmin, dmax):
+        check(lib.bf_ray_cast_update_min_max(self._h, C.c_float(dmin), C.c_float(dmax)))
+
+    def set_intrinsics(self, width, height, K):
+        check(lib.bf_ray_cast_set_intrinsics(self._h, width, height, _f16(K)))
+
+    def render(self, scene, cam, last_rigid_transform):
+        """render(hashData, hashParams, lastRigidTransform) on a SceneRepHashSDF whose frustum list was made for `cam` (after an
+        integrate, or scene.compactify(T, cam))."""
+        hd = scene.hash_data(); hp = scene.hash_params()
+        check(lib.bf_ray_cast_render(self._h, C.byref(hd), C.byref(hp), C.byref(cam), _f16(last_rigid_transform)))
+
+    def convert_to_camera_space(self, cam):
+        check(lib.bf_ray_cast_convert_to_camera_space(self._h, C.byref(cam)))
+
+    def download(self):
+        """dict of host images: depth (H,W), depth4 / normals / colors (H,W,4), ray_min / ray_max (H,W)"""
+        import torch
+        torch.cuda.synchronize()
+        p = self.params(); d = RayCastData()
+        check(lib.bf_ray_cast_get_data(self._h, C.byref(d)))
+        n = p.m_width * p.m_height
+        f1 = lambda ptr: _d2h(ptr, n * 4).view("<f4").reshape(p.m_height, p.m_width).copy()
+        f4 = lambda ptr: _d2h(ptr, n * 16).view("<f4").reshape(p.m_height, p.m_width, 4).copy()
+        return dict(depth=f1(d.d_depth), depth4=f4(d.d_depth4), normals=f4(d.d_normals), colors=f4(d.d_colors),
+                    ray_min=f1(d.d_rayIntervalSplatMin), ray_max=f1(d.d_rayIntervalSplatMax))

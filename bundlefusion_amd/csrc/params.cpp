@@ -84,6 +84,9 @@ void readApp(Reader& r, bf_global_app_state& g) {
     r.u("s_garbageCollectionStarve", g.s_garbageCollectionStarve);
     r.fv("s_streamingVoxelExtents", g.s_streamingVoxelExtents, 3); r.iv("s_streamingGridDimensions", g.s_streamingGridDimensions, 3);
     r.iv("s_streamingMinGridPos", g.s_streamingMinGridPos, 3); r.u("s_streamingInitialChunkListSize", g.s_streamingInitialChunkListSize);
+    r.u("s_rayCastWidth", g.s_rayCastWidth); r.u("s_rayCastHeight", g.s_rayCastHeight);
+    r.f("s_SDFRayIncrementFactor", g.s_SDFRayIncrementFactor); r.f("s_SDFRayThresSampleDistFactor", g.s_SDFRayThresSampleDistFactor);
+    r.f("s_SDFRayThresDistFactor", g.s_SDFRayThresDistFactor); r.b("s_SDFUseGradients", g.s_SDFUseGradients);
     if (auto* s = r.find("s_numSolveFramesBeforeExit")) g.s_numSolveFramesBeforeExit = (uint32_t)strtol(s->c_str(), nullptr, 10);   // may be -1
     if (auto* s = r.find("s_binaryDumpSensorFile")) {                                    // a quoted string
         std::string v = *s;
@@ -141,6 +144,8 @@ int bf_global_app_state_default(bf_global_app_state* g) {           // zParamete
     g->s_streamingMinGridPos[0] = g->s_streamingMinGridPos[1] = g->s_streamingMinGridPos[2] = -128;
     g->s_streamingInitialChunkListSize = 2000;
     g->s_numSolveFramesBeforeExit = 30;
+    g->s_rayCastWidth = 320; g->s_rayCastHeight = 240;
+    g->s_SDFRayIncrementFactor = 0.8f; g->s_SDFRayThresSampleDistFactor = 50.5f; g->s_SDFRayThresDistFactor = 50.0f; g->s_SDFUseGradients = 0;
     snprintf(g->s_binaryDumpSensorFile, sizeof g->s_binaryDumpSensorFile, "%s", "../data/sequence.sens");
     return BF_OK;
 }
@@ -186,6 +191,28 @@ int bf_global_bundling_state_read(const char* filename, bf_global_bundling_state
     Reader r(kv);
     readBundling(r, *out);
     if (numMissing) *numMissing = r.missing;
+    return BF_OK;
+}
+
+int bf_ray_cast_params_from_global_app_state(const bf_global_app_state* gas, const float K[16], bf_ray_cast_params* p) {   // CUDARayCastSDF.h:24-52
+    BF_REQUIRE(gas && K && p, "null argument");
+    memset(p, 0, sizeof *p);
+    float fx = K[0], fy = K[5], mx = K[2], my = K[6];
+    if (gas->s_rayCastWidth != gas->s_integrationWidth || gas->s_rayCastHeight != gas->s_integrationHeight) {
+        fx *= (float)gas->s_rayCastWidth / (float)gas->s_integrationWidth;
+        fy *= (float)gas->s_rayCastHeight / (float)gas->s_integrationHeight;
+        mx *= (float)(gas->s_rayCastWidth - 1) / (float)(gas->s_integrationWidth - 1);
+        my *= (float)(gas->s_rayCastHeight - 1) / (float)(gas->s_integrationHeight - 1);
+    }
+    p->m_width = gas->s_rayCastWidth; p->m_height = gas->s_rayCastHeight;
+    p->fx = fx; p->fy = fy; p->mx = mx; p->my = my;
+    p->m_minDepth = gas->s_renderDepthMin; p->m_maxDepth = gas->s_renderDepthMax;
+    p->m_rayIncrement = gas->s_SDFRayIncrementFactor * gas->s_SDFTruncation;
+    p->m_thresSampleDist = gas->s_SDFRayThresSampleDistFactor * p->m_rayIncrement;
+    p->m_thresDist = gas->s_SDFRayThresDistFactor * p->m_rayIncrement;
+    p->m_useGradients = gas->s_SDFUseGradients;
+    p->m_maxNumVertices = gas->s_hashNumSDFBlocks * 6;
+    for (int i = 0; i < 16; ++i) p->m_viewMatrix[i] = p->m_viewMatrixInverse[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     return BF_OK;
 }
 

@@ -138,25 +138,27 @@ BF_HD bool blockInFrustum(const Frame& f, i3 b) {              // :322-326, Dept
     return !(px < -1.0f || px > 1.0f || py < -1.0f || py > 1.0f || pz < 0.0f || pz > 1.0f);
 }
 
-// read-only lookup, VoxelUtilHashSDF.h:441-485
+// read-only lookup, VoxelUtilHashSDF.h:441-485.  The four entries of the home bucket and its chain head are loaded unconditionally
+// (one memory round trip instead of up to five dependent ones: next to the voxel kernel of the other stream a round trip costs 2-3 us).
 BF_DEV bool blockPresent(const Dev& d, const Frame& f, i3 b, uint32_t h) {
     const uint32_t hp = h * BF_HASH_BUCKET_SIZE;
     const int4* e4 = reinterpret_cast<const int4*>(d.hash);
-    uint32_t lastOffset = 0;
+    int4 a[BF_HASH_BUCKET_SIZE];
 #pragma unroll
-    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) {
-        const int4 a = e4[(size_t)(hp + j) * 2];                 // pos.xyz, ptr
-        if (a.x == b.x && a.y == b.y && a.z == b.z && a.w != BF_FREE_ENTRY) return true;
-        if (j == BF_HASH_BUCKET_SIZE - 1) lastOffset = d.hash[hp + j].offset;
-    }
+    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) a[j] = e4[(size_t)(hp + j) * 2];                 // pos.xyz, ptr
+    const uint32_t lastOffset = d.hash[hp + BF_HASH_BUCKET_SIZE - 1].offset;
+    bool hit = false;
+#pragma unroll
+    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) hit = hit || (a[j].x == b.x && a[j].y == b.y && a[j].z == b.z && a[j].w != BF_FREE_ENTRY);
+    if (hit) return true;
     if (lastOffset == 0) return false;
     const uint32_t last = hp + BF_HASH_BUCKET_SIZE - 1;
     const uint32_t total = BF_HASH_BUCKET_SIZE * f.numBuckets;
     uint32_t i = (last + lastOffset) % total;
     for (uint32_t it = 1; it < f.maxChain; ++it) {
-        const int4 a = e4[(size_t)i * 2];
-        if (a.x == b.x && a.y == b.y && a.z == b.z && a.w != BF_FREE_ENTRY) return true;
+        const int4 c = e4[(size_t)i * 2];
         const uint32_t off = d.hash[i].offset;
+        if (c.x == b.x && c.y == b.y && c.z == b.z && c.w != BF_FREE_ENTRY) return true;
         if (off == 0) break;
         i = (last + off) % total;
     }
@@ -229,6 +231,9 @@ BF_DEV void emitCandidate(const Dev& d, const Frame& f, i3 b) {
 // wave in flight together.  (The first version looked every block up inside the DDA loop: one dependent ~2 us global round trip per
 // step made the kernel a 15-deep latency chain, 40-75 us per launch.)  Queuing a block is idempotent and the bins are sorted before
 // they are placed, so the hash table does not depend on the order in which candidates are found.
+// PREP_PRIO: the allocation / list kernels are a few thousand short, latency-bound waves that share each SIMD with up to seven waves of
+// the voxel update of the previous operator (other stream), which saturates VALU issue; at equal wave priority they ran 2-4x slower
+// than alone (23 -> 51 us, 22 -> 54 us) and the allocation chain paced the loop.  s_setprio 3 lets them issue first.
 constexpr uint32_t WSET = 256;        // slots of a wave's block set (open addressing, load <= 0.5)
 constexpr uint32_t WLIST = 128;       // distinct blocks buffered per wave before they are looked up
 
@@ -257,6 +262,7 @@ BF_DEV void waveSetFlush(const Dev& d, const Frame& f, unsigned long long* set, 
 }
 
 __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth) {
+    __builtin_amdgcn_s_setprio(3);          // see PREP_PRIO
     __shared__ unsigned long long setAll[4][WSET];
     __shared__ unsigned long long listAll[4][WLIST];
     unsigned long long* set = setAll[threadIdx.x >> 6];
@@ -409,6 +415,12 @@ BF_DEV uint32_t binPrefix(const uint32_t* binCount, uint32_t limit, uint32_t* sc
 // other stream for 10-30 us: the allocation chain, not the voxel update, paced the re-integration loop.)
 constexpr uint32_t PLACE_WGS = 64;
 
+// write-through (agent scope) 8-byte stores: what the tail workgroup reads of the other workgroups' output goes straight to memory, so
+// the hand-off needs no L2 write-back (a release fence writes back the XCD's whole L2, which the voxel kernel of the other stream keeps
+// full of dirty lines: measured 30-50 us per launch)
+BF_DEV void storeThrough(void* p, uint64_t v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BF_DEV uint64_t pack2(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+
 BF_DEV void placeBin(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch, int8_t* sel, uint32_t bin) {
     const uint32_t n = min(d.binCount[bin], BINCAP);
     if (n == 0) return;                       // block-uniform
@@ -445,21 +457,77 @@ BF_DEV void placeBin(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch
         d.dedupe[s.aux[idx]] = EMPTY64;
         if (gi >= heapFree) { atomicAdd(&d.stats[ST_DROPPED], 1u); continue; }     // heap exhausted
         const int32_t ptr = (int32_t)(d.heap[heapC - gi] * (uint32_t)VOX);          // consumeHeap :536-540
-        AllocRec ar; ar.key = key; ar.ptr = ptr; ar.pad = 0;
-        d.allocList[allocBase + gi] = ar;
+        uint64_t* ar = reinterpret_cast<uint64_t*>(d.allocList + allocBase + gi);      // AllocRec {key, ptr, pad}
+        storeThrough(ar, key); storeThrough(ar + 1, pack2((uint32_t)ptr, 0u));
         const int slot = sel[idx];
         if (slot >= 0) {
             const i3 b = unpackKey(key);
-            const size_t e = (size_t)h * BF_HASH_BUCKET_SIZE + (uint32_t)slot;
-            h4[e * 2] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)ptr);
-            h4[e * 2 + 1] = make_uint4(0u, 0u, 0u, 0u);                              // NO_OFFSET :608
+            uint64_t* e = reinterpret_cast<uint64_t*>(d.hash + ((size_t)h * BF_HASH_BUCKET_SIZE + (uint32_t)slot));   // {pos.xyz, ptr, offset = NO_OFFSET :608, pad}
+            storeThrough(e, pack2((uint32_t)b.x, (uint32_t)b.y)); storeThrough(e + 1, pack2((uint32_t)b.z, (uint32_t)ptr));
+            storeThrough(e + 2, 0ull); storeThrough(e + 3, 0ull);
         } else {
             const uint32_t ov = atomicAdd(d.overflowCount, 1u);
-            if (ov < OVCAP) { BinRec r; r.key = key; r.bucket = h; r.aux = gi; d.overflow[ov] = r; }
+            if (ov < OVCAP) { uint64_t* r = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(r, key); storeThrough(r + 1, pack2(h, gi)); }      // BinRec {key, bucket, aux}
             else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
         }
     }
     __syncthreads();                          // s and sel are reused for the next bin
+}
+
+// A bin of at most 64 records (every bin once the scan is under way) is placed by ONE wave: bitonic sort in registers (lane
+// exchanges, no LDS, no barriers), rank by lane exchange, and two memory round trips in all - {bin records, bin counts, counters} and
+// {the four slots of the home bucket, the heap block}.  Same order and same decisions as placeBin.
+BF_DEV void placeBinWave(const Dev& d, const Frame& f, uint32_t n, BinRec r, uint32_t base, uint32_t heapC, uint32_t allocBase, uint32_t lane) {
+    uint32_t bucket = lane < n ? r.bucket : 0xFFFFFFFFu;
+    uint64_t key = lane < n ? r.key : EMPTY64;
+    uint32_t aux = lane < n ? r.aux : 0u;
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t ob = (uint32_t)__shfl_xor((int)bucket, (int)j, 64), oa = (uint32_t)__shfl_xor((int)aux, (int)j, 64);
+            const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j, 64), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j, 64);
+            const uint64_t ok = (uint64_t)olo | ((uint64_t)ohi << 32);
+            const bool wantMin = ((lane & j) == 0) == ((lane & k) == 0);
+            const bool ownGreater = bucket != ob ? bucket > ob : key > ok;
+            const bool otherGreater = bucket != ob ? ob > bucket : ok > key;
+            if (wantMin ? ownGreater : otherGreater) { bucket = ob; key = ok; aux = oa; }
+        }
+    }
+    const uint32_t idx = lane;
+    const uint32_t b1 = (uint32_t)__shfl_up((int)bucket, 1, 64), b2 = (uint32_t)__shfl_up((int)bucket, 2, 64);
+    const uint32_t b3 = (uint32_t)__shfl_up((int)bucket, 3, 64), b4 = (uint32_t)__shfl_up((int)bucket, 4, 64);
+    if (idx >= n) return;
+    uint32_t rank = 0;
+    if (idx >= 1 && b1 == bucket) { rank = 1; if (idx >= 2 && b2 == bucket) { rank = 2; if (idx >= 3 && b3 == bucket) { rank = 3; if (idx >= 4 && b4 == bucket) rank = 4; } } }
+    const uint32_t heapFree = min(heapC + 1u, f.numSDFBlocks - min(allocBase, f.numSDFBlocks));
+    const uint32_t gi = base + idx;
+    int32_t p[BF_HASH_BUCKET_SIZE];
+#pragma unroll
+    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) p[j] = d.hash[bucket * BF_HASH_BUCKET_SIZE + j].ptr;
+    const uint32_t heapBlock = gi < heapFree ? d.heap[heapC - gi] : 0u;                                // consumeHeap :536-540
+    int slot = -1;
+    if (rank < BF_HASH_BUCKET_SIZE) {
+        uint32_t seen = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j)
+            if (p[j] == BF_FREE_ENTRY) { if (seen == rank && slot < 0) slot = (int)j; ++seen; }
+    }
+    d.dedupe[aux] = EMPTY64;
+    if (gi >= heapFree) { atomicAdd(&d.stats[ST_DROPPED], 1u); return; }                               // heap exhausted
+    const int32_t ptr = (int32_t)(heapBlock * (uint32_t)VOX);
+    uint64_t* ar = reinterpret_cast<uint64_t*>(d.allocList + allocBase + gi);
+    storeThrough(ar, key); storeThrough(ar + 1, pack2((uint32_t)ptr, 0u));
+    if (slot >= 0) {
+        const i3 b = unpackKey(key);
+        uint64_t* e = reinterpret_cast<uint64_t*>(d.hash + ((size_t)bucket * BF_HASH_BUCKET_SIZE + (uint32_t)slot));
+        storeThrough(e, pack2((uint32_t)b.x, (uint32_t)b.y)); storeThrough(e + 1, pack2((uint32_t)b.z, (uint32_t)ptr));
+        storeThrough(e + 2, 0ull); storeThrough(e + 3, 0ull);
+    } else {
+        const uint32_t ov = atomicAdd(d.overflowCount, 1u);
+        if (ov < OVCAP) { uint64_t* o = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(o, key); storeThrough(o + 1, pack2(bucket, gi)); }
+        else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -530,13 +598,33 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
     __shared__ uint32_t scratch[16];
     __shared__ int8_t sel[BINCAP];
     __shared__ uint32_t lastFlag;
-    for (uint32_t bin = blockIdx.x; bin < NBINS; bin += gridDim.x) placeBin(d, f, s, scratch, sel, bin);
-    // hand-off to the workgroup that arrives last: drain this wave's stores, publish (agent-scope release by one lane), take a ticket
+    __shared__ uint32_t bigBin[4];
+    __builtin_amdgcn_s_setprio(3);
+    static_assert(PLACE_WGS * 4 == NBINS && NBINS == 256, "one wave per bin");
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t bin = blockIdx.x * 4 + wave;
+    {   // first round trip: this bin's count and first 64 records, the counts of all bins, the two counters
+        const uint32_t nRaw = d.binCount[bin];
+        const uint4 c4 = reinterpret_cast<const uint4*>(d.binCount)[lane];
+        const BinRec r = d.bins[(size_t)bin * BINCAP + lane];
+        const uint32_t heapC = d.heapCounter[0], allocBase = d.allocCount[0];
+        const uint32_t n = min(nRaw, BINCAP);
+        uint32_t pre = 0;
+        if (lane * 4 + 0 < bin) pre += min(c4.x, BINCAP);
+        if (lane * 4 + 1 < bin) pre += min(c4.y, BINCAP);
+        if (lane * 4 + 2 < bin) pre += min(c4.z, BINCAP);
+        if (lane * 4 + 3 < bin) pre += min(c4.w, BINCAP);
+        const uint32_t base = (uint32_t)wave_sum_i((int)pre);
+        if (lane == 0) bigBin[wave] = n > 64 ? 1u : 0u;
+        if (n > 0 && n <= 64) placeBinWave(d, f, n, r, base, heapC, allocBase, lane);
+    }
+    __syncthreads();
+    for (uint32_t w = 0; w < 4; ++w)
+        if (bigBin[w]) placeBin(d, f, s, scratch, sel, blockIdx.x * 4 + w);          // block-uniform: first frames of a scan, fast motion
+    // hand-off to the workgroup that arrives last: every wave drains its (write-through) stores, then one lane takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t ticket = atomicAdd(&d.stats[ST_TICKET], 1u);
         lastFlag = ticket == gridDim.x - 1 ? 1u : 0u;
         if (lastFlag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // same CU as every other wave of this workgroup: its L1 is clean from here on
@@ -566,6 +654,7 @@ BF_DEV uint32_t keepRec(const Frame& f, const Frame& fo, const AllocRec& r) {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f, Frame fo) {
     __shared__ uint32_t wsum[4];
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
     if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) d.compactCount[1] = 0;      // the scatter pass (next launch) accumulates the operator blocks here
@@ -587,6 +676,7 @@ __global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f, Frame fo)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame fo) {
     __shared__ uint32_t wsum[4];
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t wscan[4];
     const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;

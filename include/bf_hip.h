@@ -502,6 +502,48 @@ BF_API int bf_marching_cubes_save_mesh(bf_marching_cubes* m, const char* filenam
 /* the generated case tables (edge mask per case, up to 5 triangles of edge indices, -1 terminated), for inspection / tests */
 BF_API int bf_marching_cubes_tables(uint16_t edgeTable[256], int8_t triTable[256 * 16]);
 
+/* ------------------------------------------------------------------------- */
+/* Ray cast of the volume: class CUDARayCastSDF (DepthSensing/CUDARayCastSDF.h:14-101, .cpp, .cu),        */
+/* RayCastSDFUtil.h, DX11RayIntervalSplatting (the rasterised interval splat is a compute pass here)      */
+/* ------------------------------------------------------------------------- */
+typedef struct bf_ray_cast_params {        /* struct RayCastParams, CUDARayCastParams.h:7-27 (same field order) */
+    float m_viewMatrix[16];
+    float m_viewMatrixInverse[16];
+    float mx, my, fx, fy;                  /* ray cast intrinsics */
+    uint32_t m_width, m_height;
+    uint32_t m_numOccupiedSDFBlocks;
+    uint32_t m_maxNumVertices;             /* kept for the capacity check of rayIntervalSplatting (6 vertices per block) */
+    int32_t m_splatMinimum;                /* unused: both intervals are splatted in one pass */
+    float m_minDepth, m_maxDepth;
+    float m_rayIncrement, m_thresSampleDist, m_thresDist;
+    int32_t m_useGradients;
+    uint32_t dummy0;
+} bf_ray_cast_params;
+
+typedef struct bf_ray_cast_data {          /* struct RayCastData, RayCastSDFUtil.h:33-303: device images of m_width x m_height */
+    float* d_depth;                        /* depth along the camera z axis, -inf where no surface was hit */
+    float* d_depth4;                       /* float4 camera-space point (x, y, z, 1) or -inf */
+    float* d_normals;                      /* float4 camera-space normal (w = 1) or -inf */
+    float* d_colors;                       /* float4 rgb in [0,1] (w = 1) or -inf */
+    float* d_rayIntervalSplatMin;          /* per-pixel entry / exit depth of the allocated blocks (the two D3D11 render targets), -inf = no block */
+    float* d_rayIntervalSplatMax;
+} bf_ray_cast_data;
+
+typedef struct bf_ray_cast bf_ray_cast;    /* == class CUDARayCastSDF */
+BF_API int bf_ray_cast_create(const bf_ray_cast_params* params, bf_ray_cast** out);          /* CUDARayCastSDF(params) */
+BF_API int bf_ray_cast_destroy(bf_ray_cast* rc);
+BF_API int bf_ray_cast_set_stream(bf_ray_cast* rc, void* hip_stream);
+/* render(hashData, hashParams, lastRigidTransform)  .cpp:42-72: hashData / hashParams as bf_scene_get_hash_data / _get_hash_params
+ * return them after an integrate or setLastRigidTransformAndCompactify (frustum list + m_numOccupiedBlocks + m_rigidTransformInverse);
+ * depthCamera = the DepthCameraParams the volume was compactified with (c_depthCameraParams of the splat's frustum test).  */
+BF_API int bf_ray_cast_render(bf_ray_cast* rc, const bf_hash_data* hashData, const bf_hash_params* hashParams,
+                              const bf_depth_camera_params* depthCamera, const float lastRigidTransform[16]);
+BF_API int bf_ray_cast_get_data(bf_ray_cast* rc, bf_ray_cast_data* out);                      /* getRayCastData */
+BF_API int bf_ray_cast_get_params(bf_ray_cast* rc, bf_ray_cast_params* out);                  /* getRayCastParams */
+BF_API int bf_ray_cast_update_min_max(bf_ray_cast* rc, float depthMin, float depthMax);       /* updateRayCastMinMax */
+BF_API int bf_ray_cast_set_intrinsics(bf_ray_cast* rc, uint32_t width, uint32_t height, const float intrinsics[16]);   /* setRayCastIntrinsics */
+BF_API int bf_ray_cast_convert_to_camera_space(bf_ray_cast* rc, const bf_depth_camera_params* depthCamera);            /* convertToCameraSpace */
+
 #ifdef __cplusplus
 }
 #endif

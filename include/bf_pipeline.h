@@ -44,6 +44,10 @@ typedef struct bf_global_app_state {
     uint32_t s_streamingInitialChunkListSize;
     uint32_t s_numSolveFramesBeforeExit;
     char s_binaryDumpSensorFile[512];      /* the .sens file played when s_sensorIdx == 8 (SensorDataReader.cpp:44) */
+    /* ray cast (CUDARayCastSDF::parametersFromGlobalAppState, CUDARayCastSDF.h:24-52) */
+    uint32_t s_rayCastWidth, s_rayCastHeight;
+    float s_SDFRayIncrementFactor, s_SDFRayThresSampleDistFactor, s_SDFRayThresDistFactor;
+    int32_t s_SDFUseGradients;
 } bf_global_app_state;
 
 typedef struct bf_global_bundling_state {
@@ -72,6 +76,9 @@ typedef struct bf_global_bundling_state {
 /* defaults = the values of zParametersDefault.txt / zParametersBundlingDefault.txt as shipped */
 BF_API int bf_global_app_state_default(bf_global_app_state* out);
 BF_API int bf_global_bundling_state_default(bf_global_bundling_state* out);
+/* CUDARayCastSDF::parametersFromGlobalAppState(gas, intrinsics, intrinsicsInv)  CUDARayCastSDF.h:24-52: intrinsics = those of the
+ * integration images; they are rescaled when the ray cast size differs (same rule as the image manager). */
+BF_API int bf_ray_cast_params_from_global_app_state(const bf_global_app_state* gas, const float intrinsics[16], bf_ray_cast_params* out);
 /* GlobalAppState::readMembers(ParameterFile) GlobalAppState.h:128-136 / GlobalBundlingState.h:90-98.  Starts from
  * the defaults; *numMissing (optional) counts fields that the file did not set (the reference warns per field). */
 BF_API int bf_global_app_state_read(const char* filename, bf_global_app_state* out, uint32_t* numMissing);

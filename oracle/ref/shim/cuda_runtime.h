@@ -67,7 +67,7 @@ BF_REF_VEC(double, double) BF_REF_VEC24(double, double, 16, 16)
 static inline float2 operator-(const float2& a) { return make_float2(-a.x, -a.y); }
 static inline float3 operator-(const float3& a) { return make_float3(-a.x, -a.y, -a.z); }
 static inline float4 operator-(const float4& a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
-struct cudaArray;
+struct cudaArray { const void* ptr; size_t width, height, pitch; };      // a 2-D array is a pitched host image here
 
 struct dim3 {
     unsigned int x, y, z;
@@ -187,6 +187,12 @@ static inline cudaError_t cudaBindTexture(size_t* off, texture<T, DIM, M>& t, co
     if (off) *off = 0; t.ptr = (const T*)p; t.width = n / sizeof(T); t.height = 1; t.pitch = n; return cudaSuccess;
 }
 template <class T, int DIM, cudaTextureReadMode M> static inline cudaError_t cudaUnbindTexture(texture<T, DIM, M>&) { return cudaSuccess; }
+enum cudaChannelFormatKind { cudaChannelFormatKindSigned, cudaChannelFormatKindUnsigned, cudaChannelFormatKindFloat };
+static inline cudaChannelFormatDesc cudaCreateChannelDesc(int x, int y, int z, int w, cudaChannelFormatKind f) { cudaChannelFormatDesc d = {x, y, z, w, (int)f}; return d; }
+template <class T, int DIM, cudaTextureReadMode M>
+static inline cudaError_t cudaBindTextureToArray(texture<T, DIM, M>& t, const cudaArray* a, const cudaChannelFormatDesc&) {
+    t.ptr = (const T*)a->ptr; t.width = a->width; t.height = a->height; t.pitch = a->pitch; return cudaSuccess;
+}
 template <class T, int DIM, cudaTextureReadMode M>
 static inline T tex2D(const texture<T, DIM, M>& t, float x, float y) {      // unnormalised coordinates, point filter: texel floor(x), floor(y)
     long ix = (long)floorf(x), iy = (long)floorf(y);

@@ -391,3 +391,24 @@ def mc_extract(scene, thresh, thresh2, edge_table, tri_table, max_triangles=2000
     n = olib.or_mc_extract(C.c_void_p(olib.or_scene_hash(scene._h)), C.c_void_p(olib.or_scene_voxels(scene._h)), C.byref(hp), C.c_float(thresh), C.c_float(thresh2),
                            int(box is not None), _fp(mn), _fp(mx), _fp(e), _fp(t), _fp(out), max_triangles)
     return out[:min(n, max_triangles)].copy(), n
+
+
+# --------------------------------------------------------------------------- ray cast oracle
+def rc_splat(scene, cam, params):
+    """or_rc_splat over the scene's frustum list -> (ray_min, ray_max) float32 (H, W), -inf where no block projects"""
+    W, H = params.m_width, params.m_height
+    mn = np.zeros((H, W), np.float32); mx = np.zeros((H, W), np.float32)
+    hp = scene.hash_params()
+    olib.or_rc_splat(C.c_void_p(olib.or_scene_compactified(scene._h)), C.c_uint32(scene.num_occupied()), C.byref(hp), C.byref(cam), C.byref(params), _fp(mn), _fp(mx))
+    return mn, mx
+
+
+def rc_render(scene, params, ray_min, ray_max):
+    """or_rc_render from given interval images -> dict depth (H,W), depth4 / normals / colors (H,W,4)"""
+    W, H = params.m_width, params.m_height
+    out = dict(depth=np.zeros((H, W), np.float32), depth4=np.zeros((H, W, 4), np.float32), normals=np.zeros((H, W, 4), np.float32), colors=np.zeros((H, W, 4), np.float32))
+    hp = scene.hash_params()
+    mn = np.ascontiguousarray(ray_min, np.float32); mx = np.ascontiguousarray(ray_max, np.float32)
+    olib.or_rc_render(C.c_void_p(olib.or_scene_hash(scene._h)), C.c_void_p(olib.or_scene_voxels(scene._h)), C.byref(hp), C.byref(params), _fp(mn), _fp(mx),
+                      _fp(out["depth"]), _fp(out["depth4"]), _fp(out["normals"]), _fp(out["colors"]))
+    return out

@@ -298,3 +298,15 @@ def mc_extract(scene, thresh, thresh2, max_triangles=2000000, box=None):
     n = lib().ref_mc_extract(scene._h, C.c_float(thresh), C.c_float(thresh2), int(box is not None), _fp(mn) if box else None, _fp(mx) if box else None,
                              _fp(out), max_triangles)
     return out[:min(n, max_triangles)].copy(), n
+
+
+def rc_render(scene, params, ray_min, ray_max):
+    """The reference's renderCS on a RefScene from given ray-interval images -> dict depth (H,W), depth4 / normals / colors (H,W,4).
+    (computeNormals, which CUDARayCastSDF::render runs afterwards when gradients are off, is NOT applied: normals stay -inf then.)"""
+    W, H = params.m_width, params.m_height
+    out = dict(depth=np.zeros((H, W), np.float32), depth4=np.zeros((H, W, 4), np.float32), normals=np.zeros((H, W, 4), np.float32), colors=np.zeros((H, W, 4), np.float32))
+    intr = _f32([params.mx, params.my, params.fx, params.fy])
+    f5 = _f32([params.m_minDepth, params.m_maxDepth, params.m_rayIncrement, params.m_thresSampleDist, params.m_thresDist])
+    lib().ref_rc_render(scene._h, _fp(_f32(list(params.m_viewMatrix))), _fp(_f32(list(params.m_viewMatrixInverse))), _fp(intr), C.c_uint32(W), C.c_uint32(H), _fp(f5),
+                        int(params.m_useGradients), _fp(_f32(ray_min)), _fp(_f32(ray_max)), _fp(out["depth"]), _fp(out["depth4"]), _fp(out["normals"]), _fp(out["colors"]))
+    return out

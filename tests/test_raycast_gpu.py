@@ -1,0 +1,109 @@
+"""GPU parity tests (-m gpu): ray cast of the voxel hash through the C ABI vs the CPU oracle.
+
+bf_ray_cast_render reads the volume only through bf_scene_get_hash_data() / _get_hash_params() (reference layout + frustum list).  Bar:
+the two ray-interval images and all four output images (depth, camera-space point, normal, colour) bit-exact, tol = 0, with analytic
+gradients and with image-space normals.  The oracle's render kernel is pinned to the reference's own renderKernel in
+tests/test_ref_pin_cpu.py; the interval splat (a D3D11 rasteriser pass in the reference) is defined by this repository."""
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_hash_params, camera_params, default_app_state, intrinsics_matrix, ray_cast_params_from_global_app_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(gpu, oracle, W, H, voxel, buckets, blocks, ks):
+    import torch
+    frames = [synth.scene_room(k, W, H) for k in ks]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=buckets, num_sdf_blocks=blocks, voxel_size=voxel)
+    gs = gpu.capi.SceneRepHashSDF(p); osc = oracle.OracleScene(p)
+    for d, c, T, _ in frames:
+        gs.integrate(T, torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), cam)
+        osc.integrate(T, d, c, cam, threads=64)
+    return frames, cam, gs, osc, p
+
+
+def _same(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def _check(gpu, oracle, gs, osc, cam, rp, T):
+    gs.compactify(T, cam); osc.compactify(T, cam)
+    rc = gpu.capi.RayCastSDF(rp)
+    rc.render(gs, cam, T)
+    g = rc.download()
+    rp2 = rc.params()
+    assert rp2.m_numOccupiedSDFBlocks == osc.num_occupied() > 0
+    assert np.allclose(np.array(list(rp2.m_viewMatrixInverse), np.float32).reshape(4, 4), T)
+    omin, omax = oracle.rc_splat(osc, cam, rp2)
+    assert _same(g["ray_min"], omin) and _same(g["ray_max"], omax)
+    o = oracle.rc_render(osc, rp2, omin, omax)
+    for k in ("depth", "depth4", "colors", "normals"):
+        assert _same(g[k], o[k]), k
+    return rc, g
+
+
+def test_ray_cast_bit_exact_small_volume(gpu, oracle):
+    frames, cam, gs, osc, p = _build(gpu, oracle, 160, 120, 0.02, 20011, 20000, (0, 20, 40))
+    gas = default_app_state()
+    gas.s_integrationWidth, gas.s_integrationHeight, gas.s_rayCastWidth, gas.s_rayCastHeight = 160, 120, 160, 120
+    gas.s_hashNumSDFBlocks = 20000
+    K = frames[0][3]
+    Kmat = intrinsics_matrix(K["fx"], K["fy"], K["mx"], K["my"])
+    for use_grad in (0, 1):
+        gas.s_SDFUseGradients = use_grad
+        rp = ray_cast_params_from_global_app_state(gas, Kmat)
+        assert (rp.m_width, rp.m_height, rp.m_useGradients, rp.m_maxNumVertices) == (160, 120, use_grad, 120000)
+        assert abs(rp.m_rayIncrement - 0.8 * 0.06) < 1e-7 and abs(rp.m_thresDist - 50.0 * rp.m_rayIncrement) < 1e-6 and rp.fx == np.float32(K["fx"])
+        T = frames[1][2].astype(np.float32)
+        rc, g = _check(gpu, oracle, gs, osc, cam, rp, T)
+        hit = g["depth"] != -np.inf
+        assert hit.mean() > 0.8
+        d_in = frames[1][0]
+        ok = hit & (d_in != -np.inf) & (d_in < 3.0)
+        assert np.median(np.abs(g["depth"][ok] - d_in[ok])) < 0.01                     # the surface that was integrated from this pose
+        n = g["normals"][hit & (g["normals"][..., 0] != -np.inf)]
+        assert len(n) > 0.7 * hit.sum() and np.abs(np.linalg.norm(n[:, :3], axis=1) - 1.0).max() < 1e-3 and (n[:, 3] == 1.0).all()
+        c = g["colors"][hit]
+        assert c[:, :3].min() >= 0.0 and c[:, :3].max() <= 1.0
+    # a ray cast size different from the integration size rescales the intrinsics (CUDARayCastSDF.h:26-31); a novel view
+    gas.s_rayCastWidth, gas.s_rayCastHeight, gas.s_SDFUseGradients = 320, 240, 0
+    rp = ray_cast_params_from_global_app_state(gas, Kmat)
+    assert rp.fx == np.float32(np.float32(K["fx"]) * np.float32(2.0)) and abs(rp.mx - K["mx"] * 319 / 159) < 1e-3
+    T = (frames[0][2].astype(np.float64) @ np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.03], [0, 0, 1, 0.1], [0, 0, 0, 1.0]])).astype(np.float32)
+    rc, g = _check(gpu, oracle, gs, osc, cam, rp, T)
+    assert (g["depth"] != -np.inf).mean() > 0.6
+    # convertToCameraSpace: depth -> camera-space points with the DEPTH camera's intrinsics, normals recomputed
+    rc.convert_to_camera_space(cam)
+    g2 = rc.download()
+    hit = g2["depth"] != -np.inf
+    ys, xs = np.nonzero(hit)
+    d = g2["depth"][hit]
+    exp = np.stack([d * ((xs.astype(np.float32) - np.float32(cam.mx)) / np.float32(cam.fx)), d * ((ys.astype(np.float32) - np.float32(cam.my)) / np.float32(cam.fy)), d,
+                    np.ones_like(d)], 1).astype(np.float32)
+    assert _same(g2["depth4"][hit], exp) and (g2["depth4"][~hit] == -np.inf).all()
+    # an empty frustum list leaves the previous view and renders nothing new... a volume without blocks renders nothing
+    empty = gpu.capi.SceneRepHashSDF(p)
+    empty.compactify(T, cam)
+    rc.render(empty, cam, T)
+    assert (rc.download()["depth"] == -np.inf).all()
+
+
+def test_ray_cast_at_4mm_640x480(gpu, oracle):
+    """The bench resolution: 640x480, 4 mm voxels, one million buckets; bit-exact with the oracle, and the rendered depth reproduces the
+    integrated depth images to a fraction of a voxel."""
+    frames, cam, gs, osc, p = _build(gpu, oracle, 640, 480, 0.004, 1000000, 250000, (0, 10, 20))
+    gas = default_app_state()
+    gas.s_integrationWidth, gas.s_integrationHeight, gas.s_rayCastWidth, gas.s_rayCastHeight = 640, 480, 640, 480
+    gas.s_hashNumSDFBlocks = 250000
+    K = frames[0][3]
+    rp = ray_cast_params_from_global_app_state(gas, intrinsics_matrix(K["fx"], K["fy"], K["mx"], K["my"]))
+    T = frames[2][2].astype(np.float32)
+    rc, g = _check(gpu, oracle, gs, osc, cam, rp, T)
+    hit = g["depth"] != -np.inf
+    d_in = frames[2][0]
+    ok = hit & (d_in != -np.inf) & (d_in < 3.0)
+    assert ok.mean() > 0.7 and np.median(np.abs(g["depth"][ok] - d_in[ok])) < 0.002

@@ -432,3 +432,54 @@ def test_marching_cubes_oracle_vs_reference_kernels(oracle):
     assert verts(pt_tris) == verts(rt_tris)
     area = lambda a: float(np.linalg.norm(np.cross(a[:, 1, :3] - a[:, 0, :3], a[:, 2, :3] - a[:, 0, :3]), axis=1).sum() / 2)
     assert abs(area(pt_tris) - area(rt_tris)) <= 2e-3 * area(rt_tris)
+
+
+def test_ray_cast_oracle_vs_reference_kernel(oracle):
+    """renderKernel of the reference (its own traverseCoarseGridSimpleSampleAll / bisection / trilinear sampling / gradient) against the
+    oracle restatement on a volume built from three frames, from the same ray-interval images: depth, camera-space points, colours and
+    (with analytic gradients) normals bit for bit.  The interval images come from the oracle's compute splat (the reference fills them
+    with a D3D11 rasteriser pass that cannot run here); every block's rectangle must bracket the surface the rays then find."""
+    from bundlefusion_amd.capi import RayCastParams
+    W, H = 96, 72
+    frames = [synth.scene_room(20 * k, W, H) for k in range(3)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=3001, num_sdf_blocks=6000, voxel_size=0.02)
+    osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p)
+    for d, c, T, _ in frames:
+        osc.integrate(T, d, c, cam); rsc.integrate(T, d, c, cam)
+    T = frames[1][2].astype(np.float32)
+    osc.compactify(T, cam); rsc.compactify(T, cam)
+    assert osc.num_occupied() == rsc.num_occupied() > 200
+    for use_grad, (w, h) in ((1, (96, 72)), (0, (64, 48))):
+        rp = RayCastParams()
+        rp.m_width, rp.m_height = w, h
+        rp.fx, rp.fy = K["fx"] * w / W, K["fy"] * h / H
+        rp.mx, rp.my = K["mx"] * (w - 1) / (W - 1), K["my"] * (h - 1) / (H - 1)
+        rp.m_minDepth, rp.m_maxDepth = 0.1, 4.0
+        rp.m_rayIncrement = 0.8 * 0.06
+        rp.m_thresSampleDist = 50.5 * rp.m_rayIncrement; rp.m_thresDist = 50.0 * rp.m_rayIncrement
+        rp.m_useGradients = use_grad
+        rp.m_maxNumVertices = 6 * 6000
+        Tinv = oracle.inverse44(T)
+        rp.m_viewMatrix[:] = [float(v) for v in Tinv.reshape(16)]; rp.m_viewMatrixInverse[:] = [float(v) for v in T.reshape(16)]
+        rmin, rmax = oracle.rc_splat(osc, cam, rp)
+        covered = rmin != -np.inf
+        assert covered.mean() > 0.7 and np.array_equal(covered, rmax != -np.inf) and (rmin[covered] < rmax[covered]).all()
+        o = oracle.rc_render(osc, rp, rmin, rmax)
+        r = ref_api.rc_render(rsc, rp, rmin, rmax)
+        hit = o["depth"] != -np.inf
+        assert hit.mean() > 0.6
+        for k in ("depth", "depth4", "colors") + (("normals",) if use_grad else ()):
+            assert np.array_equal(o[k].view(np.uint32), r[k].view(np.uint32)), k
+        # the intervals bracket the surface; without them (whole depth range) the same surface is found
+        assert (o["depth"][hit] >= rmin[hit] - 1e-6).all() and (o["depth"][hit] <= rmax[hit] + 1e-6).all()
+        full_min = np.where(covered, np.float32(rp.m_minDepth), np.float32(-np.inf)); full_max = np.where(covered, np.float32(rp.m_maxDepth), np.float32(-np.inf))
+        o2 = oracle.rc_render(osc, rp, full_min, full_max)
+        both = hit & (o2["depth"] != -np.inf)
+        assert both.sum() > 0.9 * hit.sum() and np.abs(o["depth"][both] - o2["depth"][both]).max() < 0.02
+        # the rendered depth agrees with the depth image that was integrated from this pose (truncated SDF of three frames at 20 mm voxels)
+        if (w, h) == (W, H):
+            d_in = frames[1][0]
+            ok = hit & (d_in != -np.inf) & (d_in < 3.0)
+            assert ok.sum() > 3000 and np.median(np.abs(o["depth"][ok] - d_in[ok])) < 0.01
