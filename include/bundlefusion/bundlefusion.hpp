@@ -604,6 +604,12 @@ public:
     bool getExitBundlingThread() const { return m_bExitBundlingThread; }
     unsigned int getCurrProcessedFrame() const { int32_t f; check(bf_online_bundler_get_curr_processed_frame(m_h, &f)); return (unsigned int)f; }
     void saveGlobalSparseCorrsToFile(const std::string& filename) const { check(bf_online_bundler_save_global_sparse_corrs_to_file(m_h, filename.c_str())); }
+    // EVALUATE_SPARSE_CORRESPONDENCES (OnlineBundler.cpp:81-90, :480-487): the reference builds the evaluator in the constructor from the
+    // .sens trajectory; here the caller hands the per-frame reference trajectory over once (e.g. SensorDataReader::getTrajectory)
+    void initializeCorrespondenceEvaluator(const std::vector<mat4f>& completeTrajectory, const std::string& logFilePrefix = "debug/_corr-evaluation") {
+        check(bf_online_bundler_initialize_correspondence_evaluator(m_h, completeTrajectory.empty() ? nullptr : completeTrajectory[0].m, (uint32_t)completeTrajectory.size(), logFilePrefix.c_str()));
+    }
+    void finishCorrespondenceEvaluatorLogging() { check(bf_online_bundler_finish_correspondence_evaluator_logging(m_h)); }
     bf_online_bundler* handle() const { return m_h; }
 private:
     bf_online_bundler* m_h = nullptr;
@@ -665,6 +671,77 @@ public:
     bf_scene* handle() const { return m_h; }
 private:
     bf_scene* m_h = nullptr;
+};
+
+// ---- consumers of the volume: CUDAMarchingCubesHashSDF (DepthSensing/CUDAMarchingCubesHashSDF.h:8-82) and CUDARayCastSDF (CUDARayCastSDF.h:14-101)
+typedef bf_marching_cubes_params MarchingCubesParams;
+typedef bf_ray_cast_params RayCastParams;
+typedef bf_ray_cast_data RayCastData;
+struct vec3f { float x, y, z; vec3f(float a = 0.0f, float b = 0.0f, float c = 0.0f) : x(a), y(b), z(c) {} };
+
+class CUDAMarchingCubesHashSDF {
+public:
+    explicit CUDAMarchingCubesHashSDF(const MarchingCubesParams& params) : m_params(params) { check(bf_marching_cubes_create(&params, &m_h)); }
+    ~CUDAMarchingCubesHashSDF() { bf_marching_cubes_destroy(m_h); }
+    CUDAMarchingCubesHashSDF(const CUDAMarchingCubesHashSDF&) = delete;
+    // .h:20-29; s_marchingCubesMaxNumTriangles / s_SDFMarchingCubeThreshFactor are not members of bf_global_app_state: pass them
+    static MarchingCubesParams parametersFromGlobalAppState(const GlobalAppState& gas, unsigned int marchingCubesMaxNumTriangles = 3000000, float SDFMarchingCubeThreshFactor = 10.0f) {
+        MarchingCubesParams p;
+        p.m_maxNumTriangles = marchingCubesMaxNumTriangles;
+        p.m_threshMarchingCubes = SDFMarchingCubeThreshFactor * gas.s_SDFVoxelSize;
+        p.m_threshMarchingCubes2 = SDFMarchingCubeThreshFactor * gas.s_SDFVoxelSize;
+        p.m_sdfBlockSize = 8; p.m_hashBucketSize = 4; p.m_hashNumBuckets = gas.s_hashNumBuckets;
+        return p;
+    }
+    void clearMeshBuffer() { check(bf_marching_cubes_clear_mesh_buffer(m_h)); }
+    // the RayCastData argument of the reference only carries the sampling helpers (RayCastSDFUtil.h); it is not needed here
+    void extractIsoSurface(const HashDataStruct& hashData, const HashParams& hashParams, const RayCastData& /*rayCastData*/,
+                           const vec3f& minCorner = vec3f(0.0f, 0.0f, 0.0f), const vec3f& maxCorner = vec3f(0.0f, 0.0f, 0.0f), bool boxEnabled = false) {
+        const float mn[3] = {minCorner.x, minCorner.y, minCorner.z}, mx[3] = {maxCorner.x, maxCorner.y, maxCorner.z};
+        check(bf_marching_cubes_extract(m_h, &hashData, &hashParams, mn, mx, boxEnabled ? 1 : 0));
+    }
+    void saveMesh(const std::string& filename, const mat4f* transform = nullptr, bool /*overwriteExistingFile*/ = false) {
+        uint32_t nv, nf;
+        check(bf_marching_cubes_save_mesh(m_h, filename.c_str(), transform ? transform->m : nullptr, &nv, &nf));
+    }
+    bf_marching_cubes* handle() const { return m_h; }
+private:
+    MarchingCubesParams m_params;
+    bf_marching_cubes* m_h = nullptr;
+};
+
+class CUDARayCastSDF {
+public:
+    explicit CUDARayCastSDF(const RayCastParams& params) { check(bf_ray_cast_create(&params, &m_h)); }
+    ~CUDARayCastSDF() { bf_ray_cast_destroy(m_h); }
+    CUDARayCastSDF(const CUDARayCastSDF&) = delete;
+    static RayCastParams parametersFromGlobalAppState(const GlobalAppState& gas, const mat4f& intrinsics, const mat4f& /*intrinsicsInv*/) {      // .h:24-52
+        RayCastParams p; check(bf_ray_cast_params_from_global_app_state(&gas, intrinsics.m, &p)); return p;
+    }
+    // render(hashData, hashParams, lastRigidTransform) .cpp:42-72; the depth camera parameters the reference keeps in constant memory travel with the call
+    void render(const HashDataStruct& hashData, const HashParams& hashParams, const DepthCameraParams& depthCamera, const mat4f& lastRigidTransform) {
+        check(bf_ray_cast_render(m_h, &hashData, &hashParams, &depthCamera, lastRigidTransform.m));
+    }
+    const RayCastData& getRayCastData() { check(bf_ray_cast_get_data(m_h, &m_data)); return m_data; }
+    const RayCastParams& getRayCastParams() { check(bf_ray_cast_get_params(m_h, &m_params)); return m_params; }
+    void updateRayCastMinMax(float depthMin, float depthMax) { check(bf_ray_cast_update_min_max(m_h, depthMin, depthMax)); }
+    void setRayCastIntrinsics(unsigned int width, unsigned int height, const mat4f& intrinsics, const mat4f& /*intrinsicsInverse*/) {
+        check(bf_ray_cast_set_intrinsics(m_h, width, height, intrinsics.m));
+    }
+    void convertToCameraSpace(const DepthCameraParams& depthCamera) { check(bf_ray_cast_convert_to_camera_space(m_h, &depthCamera)); }
+    bf_ray_cast* handle() const { return m_h; }
+private:
+    bf_ray_cast* m_h = nullptr;
+    RayCastData m_data;
+    RayCastParams m_params;
+};
+
+// ---- CorrespondenceEvaluator (CorrespondenceEvaluator.h:10-141)
+struct CorrEvaluation : public bf_corr_evaluation {
+    CorrEvaluation() { numCorrect = numDetected = numTotal = 0; }
+    float getPrecision() const { return bf_corr_evaluation_get_precision(this); }
+    float getRecall() const { return bf_corr_evaluation_get_recall(this); }
+    CorrEvaluation& operator+=(const CorrEvaluation& r) { numCorrect += r.numCorrect; numDetected += r.numDetected; numTotal += r.numTotal; return *this; }
 };
 
 }  // namespace bundlefusion

@@ -60,6 +60,8 @@ for step in $STEPS; do
         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_sw -o run -- python "$ROOT/tools/tsdf_sweep.py" $SWEEP_ARGS > /dev/null 2>&1)
         python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_sw)" "${PMC_FILTER:-update}" | grep '^|' > "$OUT/sweep_pmc_pass$i.txt"; tail -3 "$OUT/sweep_pmc_pass$i.txt" | cut -c1-200
       done ;;
+    clocks)
+      (rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|Temp" | head -12 | tee -a "$OUT/clocks.txt") ;;
     sweep_trace)
       rm -rf /tmp/r_swt
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/r_swt -o run -- python "$ROOT/tools/tsdf_sweep.py" $SWEEP_ARGS > /dev/null 2>&1)
