@@ -135,6 +135,7 @@ def main():
         del wa, wb
     if chunked:
         runner.advance(pre)
+        runner.wait()                                        # the local half running ahead belongs to the pre-roll
     else:
         for k in range(pre):
             assert pipe.process_frame(*feed[k])
@@ -152,6 +153,7 @@ def main():
     if chunked:
         rounds0 = runner.rounds
         runner.advance(args.steps)
+        runner.wait()                                        # ... and the one started inside the timed window is paid for inside it
     else:
         for k in range(pre, total):
             ok = pipe.process_frame(*feed[k])

@@ -51,13 +51,17 @@ class ChunkedRunner:
     of a local chunk without a package is reached, the round of `world` chunks containing it is produced: local half of this rank's
     chunk of the round (capi.ChunkWorker), then ONE all-gather.  Every rank must call advance() with the same arguments."""
 
-    def __init__(self, pipe, worker, feed, submap, rank=0, world=1, device=None):
+    def __init__(self, pipe, worker, feed, submap, rank=0, world=1, device=None, prefetch=True):
         self.pipe, self.worker, self.feed, self.S = pipe, worker, feed, submap
         self.rank, self.world, self.device = rank, world, device
         self.next_frame = 0
         self.pkgs = {}
         self.rounds = 0
         self.local_chunks = 0
+        # the local half of this rank's chunk of the NEXT round runs on a second host thread (own handles, own stream) while the main
+        # thread pushes the current round through the global half; collectives stay on the main thread
+        self.prefetch = prefetch
+        self._pending = None            # (round_start, thread, package, produced)
 
     def frames_needed(self, upto_frame):
         """Stream length needed to advance to `upto_frame` frames: the last round's chunks must be complete."""
@@ -65,21 +69,58 @@ class ChunkedRunner:
         round_end = (last_chunk // self.world + 1) * self.world
         return round_end * self.S + 1
 
-    def _ensure(self, chunk):
-        import numpy as np
-        if chunk in self.pkgs:
-            return
-        r0 = chunk - chunk % self.world
-        mine = np.zeros(self.worker.package_bytes, np.uint8)
+    def _local_half(self, r0, out, produced):
         c_mine = r0 + self.rank
         a, b = chunk_frames(c_mine, self.S)
         if b < len(self.feed):
-            self.worker.run(c_mine, self.feed[a:b + 1], out=mine)
-            self.local_chunks += 1
+            self.worker.run(c_mine, self.feed[a:b + 1], out=out)
+            produced.append(c_mine)
+
+    def _start(self, r0):
+        import threading
+        import numpy as np
+        pkg = np.zeros(self.worker.package_bytes, np.uint8)
+        produced = []
+        if self.prefetch:
+            t = threading.Thread(target=self._local_half, args=(r0, pkg, produced))
+            t.start()
+        else:
+            t = None
+        self._pending = (r0, t, pkg, produced)
+
+    def _ensure(self, chunk):
+        if chunk in self.pkgs:
+            return
+        r0 = chunk - chunk % self.world
+        if self._pending is None or self._pending[0] != r0:
+            if self._pending is not None and self._pending[1] is not None:
+                self._pending[1].join()
+            self._start(r0)
+        _, t, mine, produced = self._pending
+        if t is not None:
+            t.join()
+        else:
+            self._local_half(r0, mine, produced)
+        self._pending = None
+        self.local_chunks += len(produced)
         got = gather_packages(mine, self.world, self.rank, self.device)
         self.rounds += 1
         for i, p in enumerate(got):
             self.pkgs[r0 + i] = p
+        if self.prefetch:
+            nxt = r0 + self.world
+            a, b = chunk_frames(nxt + self.rank, self.S)
+            if b < len(self.feed):
+                self._start(nxt)
+
+    def wait(self):
+        """Block until the local half running ahead (if any) has finished; its package is kept for the round that needs it."""
+        if self._pending is not None and self._pending[1] is not None:
+            self._pending[1].join()
+
+    def close(self):
+        self.wait()
+        self._pending = None
 
     def advance(self, n):
         for f in range(self.next_frame, self.next_frame + n):
@@ -92,9 +133,12 @@ class ChunkedRunner:
         return n
 
 
-def run_chunked(pipe, worker, feed, submap, rank=0, world=1, device=None):
+def run_chunked(pipe, worker, feed, submap, rank=0, world=1, device=None, prefetch=True):
     """The whole stream `feed` (1 + k * submap frames) through ChunkedRunner; returns the number of frames processed."""
-    return ChunkedRunner(pipe, worker, feed, submap, rank, world, device).advance(len(feed))
+    r = ChunkedRunner(pipe, worker, feed, submap, rank, world, device, prefetch)
+    n = r.advance(len(feed))
+    r.close()
+    return n
 
 
 def segment(rank, world, frames_per_rank):

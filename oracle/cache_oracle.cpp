@@ -4,7 +4,8 @@
 //   :260-300 (computeIntensityDerivatives), :367-385 (convertDepthFloatToCameraSpaceFloat4),
 //   :404-433 (computeNormals), :497-514 (convertNormalsFloat4ToUCHAR4), :701-742 (erodeDepthMap),
 //   :759-796 (gaussFilterDepthMap), :811-846 (gaussFilterIntensity);  CUDACache.cpp:14-86.
-// PARITY UNPINNED.  The Gaussian taps exp(-(dx^2+dy^2)/(2 sigma^2)) are evaluated once on the
+// PINNED to the reference's kernels of CUDAImageUtil.cu through oracle/_ref, bit for bit (tests/test_ref_pin_cpu.py::
+// test_ingest_and_resample_kernels, ::test_cache_store_frame_vs_reference_kernels).  The Gaussian taps exp(-(dx^2+dy^2)/(2 sigma^2)) are evaluated once on the
 // host with expf (the reference evaluates __expf per tap in the kernel, fast-math).
 #include <cstdlib>
 #include <vector>

@@ -5,7 +5,8 @@
 //   :318-389 (surface area), :418-585 (dense verify), :610-658 (add residuals), :692-774, :1036-1127;
 //   SiftGPU/cuda_kabsch.h:73-211,278-502; SiftGPU/cuda_svd3.h (McAdams et al. 3x3 SVD);
 //   SiftGPU/cuda_SVD.h:69-208 (cyclic Jacobi); SiftGPU/cuda_EigenValue.h:9-89; SiftGPU/cuda_surfaceArea.h.
-// PARITY UNPINNED.  Canonical choices: matches of a pair are emitted in ascending column (current-frame
+// PINNED through oracle/_ref: 3x3 SVD, eigen solver, Kabsch and the whole greedy Kabsch filter, bit for bit (tests/test_ref_pin_cpu.py).
+// PARITY UNPINNED for the descriptor matcher and the surface-area / dense-verify filters.  Canonical choices: matches of a pair are emitted in ascending column (current-frame
 // key) order before the distance sort (the reference appends with atomicAdd); small sums (<= 25 terms)
 // run in index order; the dense-verify sums use 256 strided partials + 64-lane butterflies + 4 wave
 // totals added in order; rsqrt is 1/sqrt; acos comes from include/bf_detmath.h.

@@ -3,11 +3,17 @@
 // anything in oracle/.  Only tests/, __graft_entry__.smoke() and bench.py's
 // cpu_baseline leg use it, and only as the checker.
 //
-// PARITY UNPINNED: the reference (niessner/BundleFusion, /root/reference) ships no
-// golden vectors, no tests and cannot be compiled here (CUDA 7 + Windows/DirectX +
-// un-vendored mLib).  This oracle is a from-scratch restatement of the reference
-// algorithm text; each function cites the file:line it follows (paths relative to
-// /root/reference/FriedLiver/Source).  The reference itself is not bit-reproducible
+// This oracle is a from-scratch restatement of the reference algorithm text; each
+// function cites the file:line it follows (paths relative to /root/reference/FriedLiver/Source).
+// PINNING: the reference (niessner/BundleFusion) ships no golden vectors and no tests, and its
+// application cannot be built here (CUDA 7 + Windows/DirectX + un-vendored mLib) - but its
+// DEVICE code can: oracle/ref/Makefile compiles it for the host into oracle/_ref/libbfref.so and
+// tests/test_ref_pin_cpu.py compares this oracle with it on the same inputs.  Pinned that way:
+// the integer maps, SE(3), SVD / Kabsch / greedy Kabsch filter, TSDF operators, image operators
+// and the cache frame, the GN/PCG solver, marching cubes, the ray-cast kernel.  Each oracle file
+// states whether its stage is pinned; the files that still say PARITY UNPINNED (SIFT detection,
+// matcher, two match filters, the evaluator) have no reference-built counterpart yet.
+// The reference itself is not bit-reproducible
 // (atomic append order, bucket try-locks, -use_fast_math), so wherever it is
 // order-dependent the oracle fixes ONE canonical order, documented at the site.
 //

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY (see or_common.h) — SE(3)/so(3) exp & log and small fixed-size
 // matrices, restating Solver/LieDerivUtil.h:19-307 (device) == PoseHelper.h:215-426 (host twin).
-// PARITY UNPINNED.
+// PINNED to LieDerivUtil.h through oracle/_ref (tests/test_ref_pin_cpu.py::test_lie_maps_within_detmath_bound: the reference calls libm,
+// this restatement the fixed sequences of include/bf_detmath.h; the difference is bounded, not zero).
 #pragma once
 #include "or_common.h"
 

@@ -4,7 +4,7 @@
 //   :550-582 (DoG + gradient), :616-750 (keypoints), :905-1142 (orientation), :1178-1257 (descriptor),
 //   :1339-1370 (normalise), :1994-2107 (reshape, key list, uchar);  SiftGPU/SiftPyramid.cpp:82-145,
 //   148-255, 297-314, 351-394, 426-450, 730-768;  SiftGPU/SiftGPU.cpp:105-174, 224-253.
-// PARITY UNPINNED.  Canonical choices where the reference is order-dependent:
+// PARITY UNPINNED (ProgramCU.cu binds CUDA arrays / layered textures the host emulator of oracle/ref does not model).  Canonical choices where the reference is order-dependent:
 //   * keypoints of a level are kept in (row, col) order (the reference appends with atomicAdd);
 //   * the orientation histogram and the descriptor bins are accumulated as 64 strided partial sums
 //     (sample s goes to partial s mod 64) combined by a xor-butterfly 32,16,...,1 — the summation tree

@@ -7,7 +7,8 @@
 //   Solver/SolverBundlingEquationsLie.h:27-277; Solver/SolverBundlingDenseUtil.h:22-113,229-298,
 //   371-424; Solver/ICPUtil.h:14-111; Solver/LieDerivUtil.h; SBA.cu:75-108; CUDACameraUtil.h.
 // Sums that the reference forms with float atomics / warp shuffles are formed here in index
-// order (the reference's order is non-deterministic).  PARITY UNPINNED.
+// order (the reference's order is non-deterministic).  PINNED to Solver/SolverBundling.cu through oracle/_ref (sparse and sparse+dense problems, poses 1e-4 / 1e-3:
+// tests/test_ref_pin_cpu.py::test_solver_vs_reference_kernels, ::test_solver_dense_terms_vs_reference_kernels).
 #include <algorithm>
 #include <cstdio>
 #include <vector>

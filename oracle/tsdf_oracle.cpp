@@ -5,7 +5,8 @@
 //          DepthSensing/CUDASceneRepHashSDF.cu:27-684,
 //          DepthSensing/CUDASceneRepHashSDF.h:65-155,328-391,
 //          DepthSensing/DepthCameraUtil.h:70-144.
-// PARITY UNPINNED (no golden vectors exist in the reference; see or_common.h).
+// PINNED to the reference's CUDASceneRepHashSDF.cu / VoxelUtilHashSDF.h through oracle/_ref: voxel bytes, key sets, per-bucket occupancy,
+// free-block count and frustum-list sets on three configurations (tests/test_ref_pin_cpu.py::test_tsdf_operators_vs_reference_kernels).
 //
 // Canonical order (the reference is racy here, VoxelUtilHashSDF.h:604 try-lock,
 // CUDASceneRepHashSDF.cu:348 atomic append):

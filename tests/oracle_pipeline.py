@@ -6,7 +6,8 @@ kernels of oracle/*.cpp (the checker, never the product):
   filterFrames (SIFTImageManager.cpp:367-476, :551-575), TrajectoryManager (TrajectoryManager.cpp), and the serial frame
   loop with integrate / deIntegrate / reintegrate (DepthSensing.cpp:723-762, :854-902, :966-1095).
 
-PARITY UNPINNED (see oracle/or_common.h).  Plain Python loops: orchestration is a few hundred scalar decisions per frame.
+The stage kernels it calls are pinned to the reference's device code where oracle/or_common.h says so; this orchestration itself is
+PARITY UNPINNED (the reference's host classes need mLib / DirectX headers).  Plain Python loops: orchestration is a few hundred scalar decisions per frame.
 """
 from collections import deque
 

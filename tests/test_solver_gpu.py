@@ -268,3 +268,63 @@ def test_corr_overflow_is_reported_not_dropped(gpu, oracle):
     assert limit.value == lim and per_image[0] > lim and n_over.value == int((per_image > lim).sum()) >= 1
     # every correspondence took part, like in the oracle (60 PCG iterations over ~60x duplicated rows: summation-order noise ~1e-4)
     assert np.abs(grot - orot).max() < 3e-4 and np.abs(gtr - otr).max() < 5e-4
+
+
+def test_cooperative_pcg_next_to_a_saturated_volume(gpu, oracle):
+    """Residency argument of k_pcg_coop, exercised: its G workgroups pass one hand-rolled grid barrier per PCG iteration on a plain
+    launch.  No other kernel of the library spins (k_alloc_place hands off by ticket, the voxel kernels are plain grids), so
+    workgroups that are not resident yet become resident as those retire.  Here a second host thread keeps the volume's two streams
+    saturated with fused re-integrations (8192-workgroup voxel updates + the allocation chain) while 19-workgroup solves run on a
+    third stream: every solve must finish and give the bits of the undisturbed solve."""
+    import threading
+    import torch
+    from bundlefusion_amd import synth
+    from bundlefusion_amd.capi import default_hash_params, camera_params
+    n = 150
+    corr, T_gt, T_init = bs.sparse_problem(n_images=n, pair_prob=0.3, seed=4)
+    rot0, tr0 = oracle.matrices_to_poses(T_init)
+    valid = np.ones(n, np.int32)
+    s_solve = torch.cuda.Stream()
+    solver = gpu.capi.Solver(n, len(corr), default_solver_config(record_convergence=False), stream=s_solve.cuda_stream)
+    gcorr, gvalid = _dev(corr.view(np.uint8)), _dev(valid)
+
+    def solve_once():
+        grot, gtr = _dev(rot0.copy()), _dev(tr0.copy())
+        solver.solve(gcorr, len(corr), gvalid, n, 3, 150, None, [1.0] * 3, [0.0] * 3, [0.0] * 3, grot, gtr, find_max_residual=True)
+        s_solve.synchronize()
+        return grot.cpu().numpy().tobytes(), gtr.cpu().numpy().tobytes(), solver.iteration_counts()
+
+    quiet = solve_once()
+    W, H = 640, 480
+    frames = [synth.scene_room(10 * k, W, H) for k in range(4)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    sc = gpu.capi.SceneRepHashSDF(default_hash_params(num_buckets=1000000, num_sdf_blocks=300000, voxel_size=0.004))
+    sc.set_overlap(True)
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    for (d, c), f in zip(dev, frames):
+        sc.integrate(f[2], d, c, cam)
+    stop = threading.Event()
+    ops = [0]
+
+    def volume_job():
+        k = 0
+        while not stop.is_set():
+            d, c = dev[k % 4]
+            T = frames[k % 4][2]
+            sc.reintegrate(T, T, d, c, cam)              # same pose: the volume is unchanged, the launches are the real ones
+            ops[0] += 1
+            k += 1
+            if k % 64 == 0:
+                sc.hash_params()                         # bounded queue depth
+
+    t = threading.Thread(target=volume_job)
+    t.start()
+    try:
+        busy = [solve_once() for _ in range(6)]
+    finally:
+        stop.set(); t.join()
+    sc.hash_params()
+    assert ops[0] > 50, "the volume thread did not run next to the solves"
+    for r in busy:
+        assert r == quiet
