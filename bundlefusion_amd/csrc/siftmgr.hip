@@ -596,6 +596,18 @@ __device__ __noinline__ bool eigenSystem3(const float* M, float* evals, float ev
     return true;
 }
 
+// warpReduceSum (cudaUtil.h:25-29) as lane 0 of a 32-lane warp sees it: val += shfl_down(val, 16), 8, 4, 2, 1; lanes >= n hold 0
+BF_DEV float warpTree32(const float* v, int n) {
+    float x[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = i < n ? v[i] : 0.0f;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < off; ++i) x[i] = x[i] + x[i + off];
+    return x[0];
+}
+
 struct AreaArgs { const Key* keys; uint32_t curFrame, startFrame; int* numFilt; const uint2* fidx; m44 Kinv; float areaThresh; };
 
 __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
@@ -613,20 +625,27 @@ __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
     __syncthreads();
     if (threadIdx.x != 0) return;
     float area[2] = {0.0f, 0.0f};
+    float t[32];
     for (int which = 0; which < 2; ++which) {
         const f3* pts = ptsAll[which];
-        f3 mean = mk3(0, 0, 0);
-        for (int i = 0; i < n; ++i) mean = mean + pts[i];
+        // every sum below is a warpReduceSum of the reference's 32-thread block (cuda_surfaceArea.h:13-84, cudaUtil.h:25-29): warpTree32
+        f3 mean;
+        for (int i = 0; i < n; ++i) t[i] = pts[i].x; mean.x = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) t[i] = pts[i].y; mean.y = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) t[i] = pts[i].z; mean.z = warpTree32(t, n);
         mean = mean / (float)n;
-        float V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < n; ++i) {
-            const f3 p = pts[i] - mean;
-            const float pv[3] = {p.x, p.y, p.z};
+        float V[9];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * pv[c];
-        }
+            for (int c = 0; c < 3; ++c) {
+                for (int i = 0; i < n; ++i) {
+                    const f3 p = pts[i] - mean;
+                    const float pr = r == 0 ? p.x : (r == 1 ? p.y : p.z), pc = c == 0 ? p.x : (c == 1 ? p.y : p.z);
+                    t[i] = pr * pc;
+                }
+                V[r * 3 + c] = warpTree32(t, n);
+            }
 #pragma unroll
         for (int i = 0; i < 9; ++i) V[i] /= (float)n;
         float evals[3], ev[3][3];
@@ -637,14 +656,15 @@ __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
             px[i] = dot3(s, ev0); py[i] = dot3(s, ev1);
         }
         // oriented bounding box in the plane, cuda_surfaceArea.h:87-131
-        float mx = 0, my = 0;
-        for (int i = 0; i < n; ++i) { mx += px[i]; my += py[i]; }
+        float mx, my;
+        for (int i = 0; i < n; ++i) t[i] = px[i]; mx = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) t[i] = py[i]; my = warpTree32(t, n);
         mx /= (float)n; my /= (float)n;
-        float c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-        for (int i = 0; i < n; ++i) {
-            const float u = px[i] - mx, v = py[i] - my;
-            c00 += u * u; c01 += u * v; c10 += v * u; c11 += v * v;
-        }
+        float c00, c01, c10, c11;
+        for (int i = 0; i < n; ++i) { const float u = px[i] - mx; t[i] = u * u; } c00 = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) { const float u = px[i] - mx, v = py[i] - my; t[i] = u * v; } c01 = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) { const float u = px[i] - mx, v = py[i] - my; t[i] = v * u; } c10 = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) { const float v = py[i] - my; t[i] = v * v; } c11 = warpTree32(t, n);
         c00 /= (float)n; c01 /= (float)n; c10 /= (float)n; c11 /= (float)n;
         const float disc = 0.5f * sqrtf((c00 - c11) * (c00 - c11) + 4 * c01 * c01);
         const float l1 = (c00 + c11) / 2 + disc, l2 = (c00 + c11) / 2 - disc;
@@ -712,29 +732,74 @@ struct VerifyArgs {
     uint32_t numImages; const int* validImages; const m44* trajectory; int* validOpt;
 };
 
+// The block sum of FilterMatchesByDenseVerifyCU_Kernel / VerifyTrajectoryCU_Kernel AS THE REFERENCE EXECUTES IT (pinned against its
+// kernel, tests/test_ref_pin_cpu.py): block (W, ceil(H/32)), thread (x, ty) sums its 32 rows in order; warpReduceSum over the 32-lane warps
+// of the linear thread id ty*W + x (a shuffle from outside the warp returns the caller's own value); the threads with threadIdx.x % 32 == 0
+// add what they hold - for W = 80 lane 0 of warps 0-2 and lane 16 of warps 2-4, i.e. the upper 32 rows count once, of the lower rows
+// columns 0-15 three times, 32-47 and 64-79 twice, the rest not at all.  Here: the per-pixel terms are evaluated by all threads in
+// parallel into LDS, then DV_THREADS "virtual threads" replay that reduction (HIP's width-32 shuffles have the same out-of-range rule);
+// the adders are summed in ascending thread order (the reference's atomicAdd order is arbitrary).
+constexpr unsigned DV_THREADS = 512;         // >= W * ceil(H/32) (checked on the host); 8 waves
+constexpr unsigned DV_MAX_PIX = 5120;        // per-pixel terms kept in LDS (80 x 60 = 4800 pixels: 60 KB); larger images recompute
+
 BF_DEV bool denseVerifyPair(const VerifyArgs& a, const bf_cached_frame& fi, const bf_cached_frame& fm, const m44& T) {
-    __shared__ float wsum[3][4];
+    __shared__ float term[3][DV_MAX_PIX];
+    __shared__ float held[3][DV_THREADS];
     const m44 Tinv = inverse44(T);
     const CF in = {fi.d_depthDownsampled, fi.d_cameraposDownsampled, fi.d_normalsDownsampled};
     const CF mo = {fm.d_depthDownsampled, fm.d_cameraposDownsampled, fm.d_normalsDownsampled};
-    float acc[3] = {0.0f, 0.0f, 0.0f};
-    const unsigned total = a.W * a.H;
-    for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
-        float x[3], y[3];
-        projError(idx, a.W, a.H, a.distThresh, a.normalThresh, T, a.K, in, mo, a.dmin, a.dmax, x);
-        projError(idx, a.W, a.H, a.distThresh, a.normalThresh, Tinv, a.K, mo, in, a.dmin, a.dmax, y);
-        for (int k = 0; k < 3; ++k) acc[k] += x[k] + y[k];
+    const unsigned total = a.W * a.H, rows = (a.H + 31u) / 32u, nt = a.W * rows, tid = threadIdx.x;
+    const bool lds = total <= DV_MAX_PIX;
+    if (lds) {
+        for (unsigned idx = tid; idx < total; idx += DV_THREADS) {
+            float x[3], y[3];
+            projError(idx, a.W, a.H, a.distThresh, a.normalThresh, T, a.K, in, mo, a.dmin, a.dmax, x);
+            projError(idx, a.W, a.H, a.distThresh, a.normalThresh, Tinv, a.K, mo, in, a.dmin, a.dmax, y);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) term[k][idx] = x[k] + y[k];
+        }
+        __syncthreads();
     }
-    for (int k = 0; k < 3; ++k) { const float s = wave_sum(acc[k]); if ((threadIdx.x & 63) == 0) wsum[k][threadIdx.x >> 6] = s; }
+    float loc[3] = {0.0f, 0.0f, 0.0f};
+    if (tid < nt) {
+        const unsigned x = tid % a.W, ty = tid / a.W;
+        for (unsigned i = 0; i < 32u; ++i) {
+            const unsigned y = ty * 32u + i;
+            if (y >= a.H) break;
+            const unsigned idx = y * a.W + x;
+            if (lds) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) loc[k] += term[k][idx];
+            } else {
+                float p[3], q[3];
+                projError(idx, a.W, a.H, a.distThresh, a.normalThresh, T, a.K, in, mo, a.dmin, a.dmax, p);
+                projError(idx, a.W, a.H, a.distThresh, a.normalThresh, Tinv, a.K, mo, in, a.dmin, a.dmax, q);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) loc[k] += p[k] + q[k];
+            }
+        }
+    }
+#pragma unroll
+    for (unsigned off = 16; off > 0; off >>= 1) {
+        const bool ex = (tid & 31u) + off < 32u && tid + off < nt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float o = __shfl_down(loc[k], off, 32); loc[k] += ex ? o : loc[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) held[k][tid] = loc[k];
     __syncthreads();
-    float tot[3];
-    for (int k = 0; k < 3; ++k) tot[k] = ((wsum[k][0] + wsum[k][1]) + wsum[k][2]) + wsum[k][3];
+    float tot[3] = {0.0f, 0.0f, 0.0f};
+    for (unsigned v = 0; v < nt; ++v)                     // every thread forms the same total (a few adds)
+        if ((v % a.W) % 32u == 0u) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tot[k] += held[k][v];
+        }
     const float err = tot[0] / tot[1];
     const float corr = 0.5f * tot[2] / (float)(a.W * a.H);
     return !(corr < a.corrThresh || err > a.errThresh || err != err);
 }
 
-__global__ __launch_bounds__(256) void k_filter_dense_verify(VerifyArgs a) {
+__global__ __launch_bounds__(DV_THREADS) void k_filter_dense_verify(VerifyArgs a) {
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     if (a.numFilt[prev] <= 0) return;
@@ -744,7 +809,7 @@ __global__ __launch_bounds__(256) void k_filter_dense_verify(VerifyArgs a) {
 
 // VerifyTrajectoryCU_Kernel :1036-1127 — the launch has N(N-1)/2 workgroups but decodes the pair as
 // (block / N, block % N), so only part of the pairs is tested; kept exactly.
-__global__ __launch_bounds__(256) void k_verify_trajectory(VerifyArgs a) {
+__global__ __launch_bounds__(DV_THREADS) void k_verify_trajectory(VerifyArgs a) {
     const uint32_t img0 = blockIdx.x / a.numImages, img1 = blockIdx.x % a.numImages;
     if (img0 >= img1) return;
     if (a.validImages[img0] == 0 || a.validImages[img1] == 0) return;
@@ -1000,7 +1065,8 @@ int bf_siftmgr_filter_matches_by_dense_verify(bf_siftmgr* m, uint32_t curFrame, 
     a.curFrame = curFrame; a.startFrame = startFrame; a.W = imageWidth; a.H = imageHeight; a.K = toM44(intrinsics);
     a.numFilt = m->d_numFilt; a.T = m->d_T; a.frames = d_cachedFrames;
     a.distThresh = distThresh; a.normalThresh = normalThresh; a.errThresh = errThresh; a.corrThresh = corrThresh; a.dmin = sensorDepthMin; a.dmax = sensorDepthMax;
-    k_filter_dense_verify<<<numFrames - startFrame, 256, 0, m->stream>>>(a);
+    BF_REQUIRE(imageWidth * ((imageHeight + 31u) / 32u) <= DV_THREADS, "cache frame too large for the dense verification block");
+    k_filter_dense_verify<<<numFrames - startFrame, DV_THREADS, 0, m->stream>>>(a);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -1099,7 +1165,8 @@ int bf_siftmgr_verify_trajectory(bf_siftmgr* m, uint32_t numImages, const float*
     a.W = imageWidth; a.H = imageHeight; a.K = toM44(intrinsics); a.frames = d_cachedFrames;
     a.distThresh = distThresh; a.normalThresh = normalThresh; a.errThresh = errThresh; a.corrThresh = corrThresh; a.dmin = sensorDepthMin; a.dmax = sensorDepthMax;
     a.numImages = numImages; a.validImages = m->d_validImages; a.trajectory = (const m44*)d_trajectory; a.validOpt = m->d_validOpt;
-    k_verify_trajectory<<<numPairs, 256, 0, m->stream>>>(a);
+    BF_REQUIRE(imageWidth * ((imageHeight + 31u) / 32u) <= DV_THREADS, "cache frame too large for the dense verification block");
+    k_verify_trajectory<<<numPairs, DV_THREADS, 0, m->stream>>>(a);
     BF_HIP_TRY(hipGetLastError());
     int v = 0;
     BF_HIP_TRY(hipMemcpyAsync(&v, m->d_validOpt, sizeof(int), hipMemcpyDeviceToHost, m->stream));

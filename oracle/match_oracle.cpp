@@ -7,9 +7,9 @@
 //   SiftGPU/cuda_SVD.h:69-208 (cyclic Jacobi); SiftGPU/cuda_EigenValue.h:9-89; SiftGPU/cuda_surfaceArea.h.
 // PINNED through oracle/_ref: 3x3 SVD, eigen solver, Kabsch and the whole greedy Kabsch filter, bit for bit (tests/test_ref_pin_cpu.py).
 // PARITY UNPINNED for the descriptor matcher and the surface-area / dense-verify filters.  Canonical choices: matches of a pair are emitted in ascending column (current-frame
-// key) order before the distance sort (the reference appends with atomicAdd); small sums (<= 25 terms)
-// run in index order; the dense-verify sums use 256 strided partials + 64-lane butterflies + 4 wave
-// totals added in order; rsqrt is 1/sqrt; acos comes from include/bf_detmath.h.
+// key) order before the distance sort (the reference appends with atomicAdd); the sums of the surface-area filter follow the reference's
+// 32-lane warpReduceSum tree, other small sums (<= 25 terms) run in index order; the dense-verify sums follow the reference's block
+// (per-thread row sums, 32-lane warp trees, adders in ascending thread order); rsqrt is 1/sqrt; acos comes from include/bf_detmath.h.
 #include <algorithm>
 #include <cfloat>
 #include <cstdio>
@@ -444,21 +444,40 @@ int or_filter_keypoint_matches(const float* keys4, uint32_t* idx, float* dist, i
     return (int)cur;
 }
 
-// FilterMatchesBySurfaceAreaCU_Kernel (SIFTImageManager.cu:318-389); returns 1 if the pair survives
+// warpReduceSum (cudaUtil.h:25-29) as lane 0 of a 32-lane warp sees it: val += shfl_down(val, 16), 8, 4, 2, 1; lanes >= n hold 0
+static float warpTree32(const float* v, int n) {
+    float x[32];
+    for (int i = 0; i < 32; ++i) x[i] = i < n ? v[i] : 0.0f;
+    for (int off = 16; off > 0; off >>= 1)
+        for (int i = 0; i < off; ++i) x[i] = x[i] + x[i + off];
+    return x[0];
+}
+
+// FilterMatchesBySurfaceAreaCU_Kernel (SIFTImageManager.cu:318-389) with computeKeyPointMatchesCovariance / computeCovariance2d /
+// computeAreaOrientedBoundingBox2 (cuda_surfaceArea.h:13-131): one 32-thread block per pair, every sum is a warpReduceSum;
+// returns 1 if the pair survives
 int or_filter_surface_area(const float* keys4, const uint32_t* idx, int n, const float* Kinv, float areaThresh, float* areas2) {
     const Key* keys = (const Key*)keys4;
     float area[2] = {0.0f, 0.0f};
+    float t[32];
     for (int which = 0; which < 2; ++which) {
         f3 pts[MAX_FILT];
-        f3 mean = {0, 0, 0};
-        for (int i = 0; i < n; ++i) { pts[i] = backProject(Kinv, keys[idx[2 * i + which]]); mean = mean + pts[i]; }
+        for (int i = 0; i < n; ++i) pts[i] = backProject(Kinv, keys[idx[2 * i + which]]);
+        f3 mean;
+        for (int i = 0; i < n; ++i) t[i] = pts[i].x; mean.x = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) t[i] = pts[i].y; mean.y = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) t[i] = pts[i].z; mean.z = warpTree32(t, n);
         mean = mean / (float)n;
-        float V[9] = {0};
-        for (int i = 0; i < n; ++i) {
-            const f3 p = pts[i] - mean;
-            const float pv[3] = {p.x, p.y, p.z};
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * pv[c];
-        }
+        float V[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                for (int i = 0; i < n; ++i) {
+                    const f3 p = pts[i] - mean;
+                    const float pv[3] = {p.x, p.y, p.z};
+                    t[i] = pv[r] * pv[c];
+                }
+                V[r * 3 + c] = warpTree32(t, n);
+            }
         for (int i = 0; i < 9; ++i) V[i] /= (float)n;
         float evals[3], ev[3][3];
         if (!eigenSystem3(V, evals, ev)) continue;
@@ -469,14 +488,15 @@ int or_filter_surface_area(const float* keys4, const uint32_t* idx, int n, const
             proj[i] = {dot(s, ev0), dot(s, ev1)};
         }
         // computeAreaOrientedBoundingBox2 :87-131
-        f2 m2 = {0, 0};
-        for (int i = 0; i < n; ++i) { m2.x += proj[i].x; m2.y += proj[i].y; }
+        f2 m2;
+        for (int i = 0; i < n; ++i) t[i] = proj[i].x; m2.x = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) t[i] = proj[i].y; m2.y = warpTree32(t, n);
         m2.x /= (float)n; m2.y /= (float)n;
-        float c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-        for (int i = 0; i < n; ++i) {
-            const float a = proj[i].x - m2.x, b = proj[i].y - m2.y;
-            c00 += a * a; c01 += a * b; c10 += b * a; c11 += b * b;
-        }
+        float c00, c01, c10, c11;
+        for (int i = 0; i < n; ++i) { const float a = proj[i].x - m2.x; t[i] = a * a; } c00 = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) { const float a = proj[i].x - m2.x, b = proj[i].y - m2.y; t[i] = a * b; } c01 = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) { const float a = proj[i].x - m2.x, b = proj[i].y - m2.y; t[i] = b * a; } c10 = warpTree32(t, n);
+        for (int i = 0; i < n; ++i) { const float b = proj[i].y - m2.y; t[i] = b * b; } c11 = warpTree32(t, n);
         c00 /= (float)n; c01 /= (float)n; c10 /= (float)n; c11 /= (float)n;
         const float disc = 0.5f * sqrtf((c00 - c11) * (c00 - c11) + 4 * c01 * c01);
         const float l1 = (c00 + c11) / 2 + disc, l2 = (c00 + c11) / 2 - disc;
@@ -496,27 +516,47 @@ int or_filter_surface_area(const float* keys4, const uint32_t* idx, int n, const
     return (area[0] < areaThresh && area[1] < areaThresh) ? 0 : 1;
 }
 
-// FilterMatchesByDenseVerifyCU_Kernel (:491-585) / VerifyTrajectoryCU_Kernel (:1036-1127); returns 1 if valid
+// FilterMatchesByDenseVerifyCU_Kernel (:491-585) / VerifyTrajectoryCU_Kernel (:1036-1127); returns 1 if valid.
+// The block sum is restated as the reference executes it, not as it was meant: the block is (W, ceil(H/32)) threads, thread (x, ty) sums
+// its 32 rows in order, warpReduceSum runs over the 32-lane warps of the LINEAR thread id ty*W + x (a shuffle from a lane outside the
+// warp returns the caller's own value), and the threads with threadIdx.x % 32 == 0 add what they hold to the block total - for W = 80
+// those are lane 0 of warps 0-2 and lane 16 of warps 2-4, so the upper rows count once and of the lower rows the columns 0-15 count
+// three times, 32-47 and 64-79 twice and the rest not at all (pinned against the reference's kernel: tests/test_ref_pin_cpu.py).
+// The atomicAdd order of those threads is arbitrary in the reference; here it is ascending thread id.
 int or_dense_verify(const float* inDepth, const float* inCampos, const float* inNormals, const float* moDepth, const float* moCampos,
                     const float* moNormals, unsigned W, unsigned H, const float* K16, const float* T16, float distThresh, float normalThresh,
                     float errThresh, float corrThresh, float dmin, float dmax, float* errOut, float* corrOut) {
     m44 T; memcpy(T.e, T16, 64);
     const m44 Tinv = inverse(T);
     const CF in = {inDepth, inCampos, inNormals}, mo = {moDepth, moCampos, moNormals};
-    static float pr[3][256];
-    for (int k = 0; k < 3; ++k) for (int t = 0; t < 256; ++t) pr[k][t] = 0.0f;
-    for (unsigned idx = 0; idx < W * H; ++idx) {
-        float a[3], b[3];
-        projError(idx, W, H, distThresh, normalThresh, T, K16, in, mo, dmin, dmax, a);
-        projError(idx, W, H, distThresh, normalThresh, Tinv, K16, mo, in, dmin, dmax, b);
-        for (int k = 0; k < 3; ++k) pr[k][idx & 255] += a[k] + b[k];
+    const unsigned rows = (H + 31) / 32, nt = W * rows;
+    std::vector<float> loc(3 * (size_t)nt, 0.0f);
+    for (unsigned v = 0; v < nt; ++v) {
+        const unsigned x = v % W, ty = v / W;
+        for (unsigned i = 0; i < 32; ++i) {
+            const unsigned y = ty * 32 + i;
+            if (y >= H) continue;
+            const unsigned idx = y * W + x;
+            float a[3], b[3];
+            projError(idx, W, H, distThresh, normalThresh, T, K16, in, mo, dmin, dmax, a);
+            projError(idx, W, H, distThresh, normalThresh, Tinv, K16, mo, in, dmin, dmax, b);
+            for (int k = 0; k < 3; ++k) loc[3 * v + k] += a[k] + b[k];
+        }
     }
-    float tot[3];
-    for (int k = 0; k < 3; ++k) {
-        float w[4];
-        for (int wv = 0; wv < 4; ++wv) w[wv] = butterfly64(pr[k] + 64 * wv);
-        tot[k] = ((w[0] + w[1]) + w[2]) + w[3];
-    }
+    for (unsigned w0 = 0; w0 < nt; w0 += 32)                              // warpReduceSum per warp of the linear thread id
+        for (int k = 0; k < 3; ++k) {
+            float x[32], y[32];
+            for (unsigned l = 0; l < 32; ++l) x[l] = w0 + l < nt ? loc[3 * (w0 + l) + k] : 0.0f;
+            for (unsigned off = 16; off > 0; off >>= 1) {
+                for (unsigned l = 0; l < 32; ++l) { const bool ex = l + off < 32 && w0 + l + off < nt; y[l] = x[l] + (ex ? x[l + off] : x[l]); }
+                memcpy(x, y, sizeof x);
+            }
+            for (unsigned l = 0; l < 32 && w0 + l < nt; ++l) loc[3 * (w0 + l) + k] = x[l];
+        }
+    float tot[3] = {0.0f, 0.0f, 0.0f};
+    for (unsigned v = 0; v < nt; ++v)
+        if ((v % W) % 32 == 0)
+            for (int k = 0; k < 3; ++k) tot[k] += loc[3 * v + k];
     const float err = tot[0] / tot[1];
     const float corr = 0.5f * tot[2] / (float)(W * H);
     if (errOut) *errOut = err;

@@ -310,3 +310,82 @@ def rc_render(scene, params, ray_min, ray_max):
     lib().ref_rc_render(scene._h, _fp(_f32(list(params.m_viewMatrix))), _fp(_f32(list(params.m_viewMatrixInverse))), _fp(intr), C.c_uint32(W), C.c_uint32(H), _fp(f5),
                         int(params.m_useGradients), _fp(_f32(ray_min)), _fp(_f32(ray_max)), _fp(out["depth"]), _fp(out["depth4"]), _fp(out["normals"]), _fp(out["colors"]))
     return out
+
+
+class RefSiftManager:
+    """The reference's SIFTImageManager match-filter chain (its own kernels and launch configurations, serial block emulation):
+    raw / filtered match lists per previous image, key points in one global array addressed by the match indices."""
+    RAW, FILT = 128, 25
+
+    def __init__(self, max_images, max_keys=1024):
+        L = lib()
+        L.ref_siftmgr_create.restype = C.c_void_p
+        self._h = C.c_void_p(L.ref_siftmgr_create(max_images, max_keys))
+        self.max_images, self.max_keys = max_images, max_keys
+        self._keep = []
+
+    def set_keys(self, keys):
+        k = _f32(keys).reshape(-1, 4)
+        lib().ref_siftmgr_set_keys(self._h, _fp(k), len(k))
+
+    def set_raw(self, pair, n, idx, dist):
+        i = np.zeros((self.RAW, 2), np.uint32); d = np.zeros(self.RAW, np.float32)
+        m = min(int(n), self.RAW, len(idx)); i[:m] = idx[:m]; d[:m] = dist[:m]
+        lib().ref_siftmgr_set_raw(self._h, pair, int(n), _fp(d), _fp(i))
+
+    def raw(self, pair):
+        n = C.c_int(); i = np.zeros((self.RAW, 2), np.uint32); d = np.zeros(self.RAW, np.float32)
+        lib().ref_siftmgr_get_raw(self._h, pair, C.byref(n), _fp(d), _fp(i))
+        return n.value, i, d
+
+    def set_filtered(self, pair, n, idx=None, dist=None, T=None, Tinv=None):
+        i = d = None
+        if idx is not None:
+            i = np.zeros((self.FILT, 2), np.uint32); i[:len(idx)] = idx
+        if dist is not None:
+            d = np.zeros(self.FILT, np.float32); d[:len(dist)] = dist
+        lib().ref_siftmgr_set_filtered(self._h, pair, int(n), _fp(d) if d is not None else None, _fp(i) if i is not None else None,
+                                       _fp(_f32(T).reshape(16)) if T is not None else None, _fp(_f32(Tinv).reshape(16)) if Tinv is not None else None)
+
+    def filtered(self, pair):
+        n = C.c_int(); i = np.zeros((self.FILT, 2), np.uint32); d = np.zeros(self.FILT, np.float32)
+        T = np.zeros((4, 4), np.float32); Ti = np.zeros((4, 4), np.float32)
+        lib().ref_siftmgr_get_filtered(self._h, pair, C.byref(n), _fp(d), _fp(i), _fp(T), _fp(Ti))
+        return n.value, i, d, T, Ti
+
+    def set_cached_frame(self, i, frame):
+        """frame: dict of the six cached arrays (tests/oracle_api.cache_store_frame); the arrays are kept alive here"""
+        a = [np.ascontiguousarray(frame[k], np.float32) for k in ("depth", "campos", "intensity", "derivs")]
+        nu = np.ascontiguousarray(frame["normals_u"], np.uint8); nf = np.ascontiguousarray(frame["normals"], np.float32)
+        self._keep.append((a, nu, nf))
+        lib().ref_siftmgr_set_cached_frame(self._h, i, _fp(a[0]), _fp(a[1]), _fp(a[2]), _fp(a[3]), _fp(nu), _fp(nf))
+
+    def sort(self, cur, start, num):
+        lib().ref_siftmgr_sort(self._h, cur, start, num)
+
+    def filter_keypoint_matches(self, cur, start, num, Kinv, min_matches=5, max_res2=0.0004):
+        lib().ref_siftmgr_filter_keypoint_matches(self._h, cur, start, num, _fp(_f32(Kinv).reshape(16)), int(min_matches), C.c_float(max_res2))
+
+    def filter_surface_area(self, cur, start, num, Kinv, area_thresh=0.032):
+        lib().ref_siftmgr_filter_surface_area(self._h, cur, start, num, _fp(_f32(Kinv).reshape(16)), C.c_float(area_thresh))
+
+    def filter_dense_verify(self, cur, start, num, W, H, K, dist_thresh=0.15, normal_thresh=0.97, color_thresh=0.1, err_thresh=0.075, corr_thresh=0.02,
+                            dmin=0.1, dmax=3.0):
+        lib().ref_siftmgr_filter_dense_verify(self._h, cur, start, num, W, H, _fp(_f32(K).reshape(16)), C.c_float(dist_thresh), C.c_float(normal_thresh),
+                                              C.c_float(color_thresh), C.c_float(err_thresh), C.c_float(corr_thresh), C.c_float(dmin), C.c_float(dmax))
+
+    def add_curr_to_residuals(self, cur, start, num, Kinv):
+        from bundlefusion_amd.capi import ENTRYJ_DTYPE
+        L = lib()
+        L.ref_siftmgr_add_curr_to_residuals.restype = C.c_uint32
+        n = L.ref_siftmgr_add_curr_to_residuals(self._h, cur, start, num, _fp(_f32(Kinv).reshape(16)))
+        assert L.ref_siftmgr_sizeof_entryj() == ENTRYJ_DTYPE.itemsize
+        e = np.zeros(n, ENTRYJ_DTYPE); k = np.zeros((n, 2), np.uint32)
+        if n:
+            L.ref_siftmgr_get_residuals(self._h, _fp(e), _fp(k), n)
+        return e, k
+
+    def verify_trajectory(self, traj, valid, W, H, K, dist_thresh=0.15, normal_thresh=0.97, color_thresh=0.1, err_thresh=0.05, corr_thresh=0.02, dmin=0.1, dmax=3.0):
+        t = _f32(traj).reshape(-1, 16); v = np.ascontiguousarray(valid, np.int32)
+        return int(lib().ref_siftmgr_verify_trajectory(self._h, len(t), _fp(t), _fp(v), W, H, _fp(_f32(K).reshape(16)), C.c_float(dist_thresh), C.c_float(normal_thresh),
+                                                       C.c_float(color_thresh), C.c_float(err_thresh), C.c_float(corr_thresh), C.c_float(dmin), C.c_float(dmax)))

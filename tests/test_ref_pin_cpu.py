@@ -483,3 +483,103 @@ def test_ray_cast_oracle_vs_reference_kernel(oracle):
             d_in = frames[1][0]
             ok = hit & (d_in != -np.inf) & (d_in < 3.0)
             assert ok.sum() > 3000 and np.median(np.abs(o["depth"][ok] - d_in[ok])) < 0.01
+
+
+def test_match_filter_chain_vs_reference_kernels(oracle):
+    """SIFTImageManager.cu of the reference — SortKeyPointMatchesCU, FilterKeyPointMatchesCU, FilterMatchesBySurfaceAreaCU,
+    FilterMatchesByDenseVerifyCU, AddCurrToResidualsCU with their own launch configurations — against the oracle on the matches of a
+    5-frame chunk of the synthetic stream (keys, descriptors and raw matches come from the oracle's detector / matcher, which are inputs
+    here):
+      * Kabsch filter: kept matches, distances, transform and inverse bit for bit;
+      * surface area: the decision flips exactly at the oracle's area value (threshold = area and the next float);
+      * dense verify: the decision flips exactly at the oracle's error and correspondence fraction - which pins the reference's block
+        sum as it executes (warps of the linear thread id, adders at threadIdx.x % 32 == 0: rows and columns are weighted 0-3 times),
+        not as it was meant;  * EntryJ rows bit for bit."""
+    from bundlefusion_amd.capi import rgbx_to_intensity
+    n_frames, W, H = 5, 640, 480
+    frames = [synth.scene_room(30 + 5 * k, W, H) for k in range(n_frames)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    Kinv = oracle.inverse44(K)
+    mk = 1024
+    allkeys = np.zeros((n_frames * mk, 4), np.float32)
+    descs, nk = [], []
+    for i, (d, c, _, _) in enumerate(frames):
+        n, keys, ds, _ = oracle.sift_run(rgbx_to_intensity(c), d)
+        allkeys[i * mk:i * mk + n] = keys; descs.append(ds); nk.append(n)
+    assert min(nk) > 30
+    oframes = [oracle.cache_store_frame(f[0], f[1], 80, 60, K) for f in frames]
+    Kc = K.copy(); Kc[0, 0] *= 80 / W; Kc[1, 1] *= 60 / H; Kc[0, 2] *= 79 / (W - 1); Kc[1, 2] *= 59 / (H - 1)
+    cur = n_frames - 1
+    ref = ref_api.RefSiftManager(n_frames + 1, mk)
+    ref.set_keys(allkeys)
+    for i in range(n_frames):
+        ref.set_cached_frame(i, oframes[i])
+    raw = {}
+    for p in range(cur):
+        n_u, idx_u, dist_u = oracle.sift_match(descs[p], descs[cur], off1=p * mk, off2=cur * mk, sort=False)
+        n_s, idx_s, dist_s = oracle.sift_match(descs[p], descs[cur], off1=p * mk, off2=cur * mk, sort=True)
+        assert n_u == n_s > 10
+        ref.set_raw(p, n_u, idx_u, dist_u)
+        raw[p] = (n_s, idx_s, dist_s)
+    # ---- sort: SortKeyPointMatchesCU_Kernel is an odd-even transposition sort that stops on a shared `swapped` flag which every thread
+    # clears at the top of each pass with ONE barrier per pass (SIFTImageManager.cu:104-128) - it relies on lock-step execution of its 64
+    # threads; the serial block emulator runs threads one after the other between barriers, the flag reads false for the second thread
+    # and the loop ends.  Not pinnable this way; the oracle's stable sort by distance is the input of the next stage on both sides.
+    for p in range(cur):
+        assert np.all(np.diff(raw[p][2]) >= 0)
+        ref.set_raw(p, raw[p][0], raw[p][1], raw[p][2])
+    # ---- Kabsch filter
+    ref.filter_keypoint_matches(cur, 0, n_frames, Kinv)
+    filt = {}
+    for p in range(cur):
+        m = min(raw[p][0], 128)
+        pidx = np.zeros((128, 2), np.uint32); pidx[:m] = raw[p][1]
+        pdist = np.zeros(128, np.float32); pdist[:m] = raw[p][2]
+        fn, fidx, fdist, fT = oracle.filter_matches(allkeys, pidx, pdist, m, Kinv)
+        gn, gidx, gdist, gT, gTi = ref.filtered(p)
+        assert gn == fn, (p, gn, fn)
+        if fn:
+            assert np.array_equal(gidx[:fn], fidx) and np.array_equal(gdist[:fn].view(np.uint32), fdist.view(np.uint32))
+            assert np.array_equal(gT.view(np.uint32), fT.view(np.uint32)) and np.array_equal(gTi.view(np.uint32), oracle.inverse44(fT).view(np.uint32))
+        filt[p] = (fn, fidx, fdist, fT)
+    assert sum(1 for p in filt if filt[p][0] > 0) >= 3
+    # ---- surface area: decision flips exactly at the oracle's larger area
+    for p in range(cur):
+        fn, fidx, fdist, fT = filt[p]
+        if fn == 0:
+            continue
+        _, areas = oracle.filter_surface_area(allkeys, fidx, Kinv)
+        a = np.float32(max(areas))
+        for thr, expect in ((a, True), (np.nextafter(a, np.float32(np.inf)), False), (np.float32(0.032), bool(oracle.filter_surface_area(allkeys, fidx, Kinv)[0]))):
+            ref.set_filtered(p, fn, fidx, fdist, fT, oracle.inverse44(fT))
+            ref.filter_surface_area(cur, 0, n_frames, Kinv, float(thr))
+            assert (ref.filtered(p)[0] > 0) == expect, (p, float(a), float(thr))
+    # ---- dense verify
+    n_checked = 0
+    for p in range(cur):
+        fn, fidx, fdist, fT = filt[p]
+        if fn == 0:
+            continue
+        ok, err, corr = oracle.dense_verify(oframes[p], oframes[cur], 80, 60, Kc, fT, dmin=0.1, dmax=3.0)
+        e32, c32 = np.float32(err), np.float32(corr)
+        assert np.isfinite(e32) and e32 > 0 and c32 > 0
+        cases = [(0.075, 0.02, ok),
+                 (e32, 0.0, True), (np.nextafter(e32, np.float32(-np.inf)), 0.0, False),              # invalid iff err > errThresh
+                 (10.0, c32, True), (10.0, np.nextafter(c32, np.float32(np.inf)), False)]             # invalid iff corr < corrThresh
+        for et, ct, expect in cases:
+            ref.set_filtered(p, fn, fidx, fdist, fT, oracle.inverse44(fT))
+            ref.filter_dense_verify(cur, 0, n_frames, 80, 60, Kc, err_thresh=float(et), corr_thresh=float(ct))
+            assert (ref.filtered(p)[0] > 0) == bool(expect), (p, err, corr, et, ct)
+            n_checked += 1
+    assert n_checked >= 15
+    # ---- EntryJ rows of the surviving pairs
+    exp = []
+    for p in range(cur):
+        fn, fidx, fdist, fT = filt[p]
+        ref.set_filtered(p, fn, fidx, fdist, fT, oracle.inverse44(fT))
+        for k in range(fn):
+            exp.append(oracle.make_entry(allkeys, fidx[k, 0], fidx[k, 1], p, cur, Kinv))
+    e, keyidx = ref.add_curr_to_residuals(cur, 0, n_frames, Kinv)
+    assert len(e) == len(exp) > 20
+    assert sorted(map(bytes, e)) == sorted(bytes(np.array(x)) for x in exp)

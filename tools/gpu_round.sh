@@ -28,8 +28,9 @@ for step in $STEPS; do
       rm -rf /tmp/r_trace
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS > "$OUT/bench_traced.json" 2> /dev/null)
       D=$(db /tmp/r_trace)
-      python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" | head -14
-      python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt" ;;
+      rm -f "$OUT/kernel_stats.md"
+      python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" --exclude "Cijk_,at::native" | head -14
+      python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 "Cijk_,at::native" > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt" ;;
     pmc)   # HBM traffic of the voxel update in the bench configuration: two passes (FETCH_SIZE, WRITE_SIZE), then bytes per visited block
       for C in FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/r_pmc_$C

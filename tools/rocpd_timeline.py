@@ -11,6 +11,8 @@ def main():
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     rows = c.execute("select start, end, name, %s from kernels order by start" % (qcol or "0")).fetchall()
+    excl = [e for e in (sys.argv[3].split(",") if len(sys.argv) > 3 else []) if e]      # e.g. "Cijk_,at::native": bench.py's untimed clock warm-up
+    rows = [r for r in rows if not any(e in r[2] for e in excl)]
     t0, t1 = rows[0][0], rows[-1][1]
     lo = t1 - (t1 - t0) * frac                      # analyse the steady-state tail
     rows = [r for r in rows if r[0] >= lo]
