@@ -5,8 +5,10 @@
 //   :318-389 (surface area), :418-585 (dense verify), :610-658 (add residuals), :692-774, :1036-1127;
 //   SiftGPU/cuda_kabsch.h:73-211,278-502; SiftGPU/cuda_svd3.h (McAdams et al. 3x3 SVD);
 //   SiftGPU/cuda_SVD.h:69-208 (cyclic Jacobi); SiftGPU/cuda_EigenValue.h:9-89; SiftGPU/cuda_surfaceArea.h.
-// PINNED through oracle/_ref: 3x3 SVD, eigen solver, Kabsch and the whole greedy Kabsch filter, bit for bit (tests/test_ref_pin_cpu.py).
-// PARITY UNPINNED for the descriptor matcher and the surface-area / dense-verify filters.  Canonical choices: matches of a pair are emitted in ascending column (current-frame
+// PINNED through oracle/_ref (tests/test_ref_pin_cpu.py): 3x3 SVD, eigen solver, Kabsch; the matcher (identical index pairs, distances within
+// 1e-6: acos); the kernels of SIFTImageManager.cu with their launch configurations - Kabsch filter, surface-area filter (decision flips exactly
+// at this file's area), dense verification (flips exactly at this file's error / correspondence fraction), EntryJ rows, VerifyTrajectory verdicts.
+// Not pinnable: SortKeyPointMatchesCU_Kernel (its termination flag relies on lock-step warps).  Canonical choices: matches of a pair are emitted in ascending column (current-frame
 // key) order before the distance sort (the reference appends with atomicAdd); the sums of the surface-area filter follow the reference's
 // 32-lane warpReduceSum tree, other small sums (<= 25 terms) run in index order; the dense-verify sums follow the reference's block
 // (per-thread row sums, 32-lane warp trees, adders in ascending thread order); rsqrt is 1/sqrt; acos comes from include/bf_detmath.h.

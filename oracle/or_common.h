@@ -10,9 +10,9 @@
 // DEVICE code can: oracle/ref/Makefile compiles it for the host into oracle/_ref/libbfref.so and
 // tests/test_ref_pin_cpu.py compares this oracle with it on the same inputs.  Pinned that way:
 // the integer maps, SE(3), SVD / Kabsch / greedy Kabsch filter, TSDF operators, image operators
-// and the cache frame, the GN/PCG solver, marching cubes, the ray-cast kernel.  Each oracle file
-// states whether its stage is pinned; the files that still say PARITY UNPINNED (SIFT detection,
-// matcher, two match filters, the evaluator) have no reference-built counterpart yet.
+// and the cache frame, the GN/PCG solver, marching cubes, the ray-cast kernel, the whole SiftGPU
+// fork (pyramid, detection, descriptors, matcher) and the match-filter chain of SIFTImageManager.cu.
+// Each oracle file states what of its stage is pinned and to which bound.
 // The reference itself is not bit-reproducible
 // (atomic append order, bucket try-locks, -use_fast_math), so wherever it is
 // order-dependent the oracle fixes ONE canonical order, documented at the site.

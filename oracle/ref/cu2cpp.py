@@ -6,7 +6,7 @@ where it lies and writes it to stdout with every kernel launch
 
 rewritten as a call of the host block emulator (oracle/ref/emu.h)
 
-    emu::launch(grid, block [, shmem [, stream]], [&]{ kernel<targs>(args); });
+    emu::named("kernel<targs>"), emu::launch(grid, block [, shmem [, stream]], [&]{ kernel<targs>(args); });
 
 Nothing else is touched (g++ cannot parse the <<< >>> launch syntax; the kernel bodies are compiled as written).  The output goes
 to a temporary directory that the Makefile removes after compiling; no reference text is kept in the repository."""
@@ -41,7 +41,7 @@ def main():
         out.append(src[pos:m.start()])
         end = match_paren(src, m.end() - 1)
         args = src[m.end():end - 1]
-        out.append("emu::launch(%s, [&]{ %s(%s); })" % (m.group(2).strip(), m.group(1).strip(), args))
+        out.append("emu::named(\"%s\"), emu::launch(%s, [&]{ %s(%s); })" % (m.group(1).strip().replace('"', ""), m.group(2).strip(), m.group(1).strip(), args))
         pos = end
     sys.stdout.write('#include "emu.h"\n' + "".join(out))
 

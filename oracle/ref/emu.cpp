@@ -3,7 +3,10 @@
 
 #include <ucontext.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 thread_local uint3 threadIdx, blockIdx;
@@ -34,12 +37,17 @@ void trampoline() {
     swapcontext(&f.ctx, &b->main);
 }
 
-// all live lanes of fiber i's warp have deposited the shuffle generation fiber i waits for
-bool warpReady(const Block& b, size_t i) {
+// all live lanes of fiber i's warp have deposited the shuffle generation fiber i waits for.  `relaxed`: lanes parked at a block barrier
+// count as inactive in this shuffle (they took the other side of a divergent branch and cannot arrive before the barrier opens, which
+// needs the shuffling lanes) - used only when the block could not make progress otherwise.
+bool warpReady(const Block& b, size_t i, bool relaxed = false) {
     const unsigned need = b.fibers[i].shflCount;                    // = generation + 1
     const size_t w0 = i / WARP * WARP, w1 = std::min(w0 + WARP, b.fibers.size());
-    for (size_t j = w0; j < w1; ++j)
-        if (b.fibers[j].state != DONE && b.fibers[j].shflCount < need) return false;
+    for (size_t j = w0; j < w1; ++j) {
+        if (b.fibers[j].state == DONE || b.fibers[j].shflCount >= need) continue;
+        if (relaxed && b.fibers[j].state == AT_BARRIER) continue;
+        return false;
+    }
     return true;
 }
 
@@ -59,7 +67,7 @@ unsigned shflExchange(unsigned val, int src, int width) {
     const int seg = (int)lane / width * width;
     if (src < seg || src >= seg + width) return val;
     const size_t j = (size_t)warp * WARP + (size_t)src;
-    if (j >= b->fibers.size() || (b->fibers[j].state == DONE && b->fibers[j].shflCount < f.shflCount)) return val;
+    if (j >= b->fibers.size() || b->fibers[j].shflCount < f.shflCount) return val;      // the source lane has exited or is inactive in this shuffle
     return b->xchg[(warp * 2 + buf) * WARP + (unsigned)src];
 }
 unsigned f2u(float v) { unsigned u; memcpy(&u, &v, 4); return u; }
@@ -84,7 +92,12 @@ int __shfl_xor(int v, int m, int w) { return (int)shflExchange((unsigned)v, lane
 
 namespace emu {
 
+static thread_local const char* g_name = "?";
+void named(const char* kernel) { g_name = kernel; }
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    static const bool trace = getenv("EMU_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "emu: %s grid (%u,%u,%u) block (%u,%u,%u)\n", g_name, grid.x, grid.y, grid.z, block.x, block.y, block.z);
     const size_t T = (size_t)block.x * block.y * block.z;
     Block b;
     b.body = &body;
@@ -129,7 +142,17 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                     for (auto& f : b.fibers) { if (f.state != DONE) ++stillLive; if (f.state == AT_BARRIER) ++stillBarrier; }
                     if (stillLive == 0) break;
                     if (stillBarrier == stillLive) { for (auto& f : b.fibers) if (f.state == AT_BARRIER) f.state = READY; progress = true; }
-                    if (!progress) throw std::runtime_error("emu: block cannot make progress (divergent barrier / shuffle)");
+                    if (!progress) {        // divergent shuffle: release the waiting lanes whose missing partners are parked at the barrier
+                        for (size_t i = 0; i < T; ++i) {
+                            Fiber& f = b.fibers[i];
+                            if (f.state != AT_SHFL || !warpReady(b, i, true)) continue;
+                            f.state = READY;
+                            b.cur = (int)i; threadIdx = f.tid;
+                            swapcontext(&b.main, &f.ctx);
+                            progress = true;
+                        }
+                    }
+                    if (!progress) throw std::runtime_error(std::string("emu: block cannot make progress (divergent barrier / shuffle) in ") + g_name);
                 }
                 b.cur = -1;
             }

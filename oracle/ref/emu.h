@@ -11,6 +11,7 @@
 #include "cuda_runtime.h"
 
 namespace emu {
+void named(const char* kernel);      // name of the kernel the next launch runs (error messages; EMU_TRACE=1 prints every launch)
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 inline void launch(dim3 grid, dim3 block, size_t /*sharedBytes*/, const std::function<void()>& body) { launch(grid, block, body); }
 inline void launch(dim3 grid, dim3 block, size_t, cudaStream_t, const std::function<void()>& body) { launch(grid, block, body); }

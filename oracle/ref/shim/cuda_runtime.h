@@ -155,53 +155,82 @@ static inline cudaError_t cudaMemset(void* d, int v, size_t n) { memset(d, v, n)
 static inline cudaError_t cudaDeviceSynchronize() { return cudaSuccess; }
 static inline cudaError_t cudaGetLastError() { return cudaSuccess; }
 static inline const char* cudaGetErrorString(cudaError_t) { return "emulated"; }
-#define cudaMemcpyToSymbol(sym, src, n, ...) (memcpy((void*)&(sym), (src), (n)), cudaSuccess)
+static inline cudaError_t shimCopyToSymbol(void* sym, const void* src, size_t n, size_t offset = 0, int /*kind*/ = 0) { memcpy((char*)sym + offset, src, n); return cudaSuccess; }
+#define cudaMemcpyToSymbol(sym, ...) shimCopyToSymbol((void*)&(sym), __VA_ARGS__)
 #define cudaMemcpyFromSymbol(dst, sym, n, ...) (memcpy((dst), (const void*)&(sym), (n)), cudaSuccess)
 #define cutilSafeCall(x) (void)(x)
 #define cutilCheckMsg(msg) ((void)0)
 #define CUDA_SAFE_CALL(x) (void)(x)
 #define CUDA_CHECKED_CALL(x) (void)(x)
 
-// ---- 2-D texture references, point sampling with clamped addressing (the modes the reference binds) ----
-enum cudaTextureReadMode { cudaReadModeElementType };
+// ---- texture references: 1-D fetches from linear memory and point-sampled 2-D textures with clamped addressing (the modes the reference binds) ----
+enum cudaTextureReadMode { cudaReadModeElementType, cudaReadModeNormalizedFloat };
 enum cudaTextureFilterMode { cudaFilterModePoint, cudaFilterModeLinear };
 enum cudaTextureAddressMode { cudaAddressModeWrap, cudaAddressModeClamp };
 enum { cudaTextureType1D = 1, cudaTextureType2D = 2 };
+enum cudaChannelFormatKind { cudaChannelFormatKindSigned, cudaChannelFormatKindUnsigned, cudaChannelFormatKindFloat };
 struct cudaChannelFormatDesc { int x, y, z, w, f; };
 template <class T> static inline cudaChannelFormatDesc cudaCreateChannelDesc() { cudaChannelFormatDesc d = {(int)sizeof(T) * 8, 0, 0, 0, 0}; return d; }
-template <class T, int DIM = 1, cudaTextureReadMode M = cudaReadModeElementType>
-struct texture {
-    const T* ptr = nullptr; size_t width = 0, height = 0, pitch = 0;
+static inline cudaChannelFormatDesc cudaCreateChannelDesc(int x, int y, int z, int w, cudaChannelFormatKind f) { cudaChannelFormatDesc d = {x, y, z, w, (int)f}; return d; }
+struct textureReference {
+    const void* ptr = nullptr; size_t width = 0, height = 0, pitch = 0;
     cudaTextureFilterMode filterMode = cudaFilterModePoint; cudaTextureAddressMode addressMode[3]; int normalized = 0;
     cudaChannelFormatDesc channelDesc;
 };
+template <class T, int DIM = 1, cudaTextureReadMode M = cudaReadModeElementType>
+struct texture : textureReference {};
+static inline cudaError_t cudaBindTexture(size_t* off, const textureReference* t, const void* p, const cudaChannelFormatDesc* = nullptr, size_t n = (size_t)-1) {
+    if (off) *off = 0;
+    textureReference* w = const_cast<textureReference*>(t); w->ptr = p; w->width = n; w->height = 1; w->pitch = n; return cudaSuccess;
+}
+static inline cudaError_t cudaBindTexture(size_t* off, const textureReference& t, const void* p, const cudaChannelFormatDesc& d, size_t n = (size_t)-1) { return cudaBindTexture(off, &t, p, &d, n); }
 template <class T, int DIM, cudaTextureReadMode M>
-static inline cudaError_t cudaBindTexture2D(size_t* off, texture<T, DIM, M>* t, const void* p, const cudaChannelFormatDesc*, size_t w, size_t h, size_t pitch) {
-    if (off) *off = 0; t->ptr = (const T*)p; t->width = w; t->height = h; t->pitch = pitch; return cudaSuccess;
+static inline cudaError_t cudaBindTexture(size_t* off, const texture<T, DIM, M>& t, const void* p, size_t n = (size_t)-1) { return cudaBindTexture(off, (const textureReference*)&t, p, nullptr, n); }
+static inline cudaError_t cudaBindTexture2D(size_t* off, const textureReference* t, const void* p, const cudaChannelFormatDesc*, size_t w, size_t h, size_t pitch) {
+    if (off) *off = 0;
+    textureReference* r = const_cast<textureReference*>(t); r->ptr = p; r->width = w; r->height = h; r->pitch = pitch; return cudaSuccess;
 }
 template <class T, int DIM, cudaTextureReadMode M>
 static inline cudaError_t cudaBindTexture2D(size_t* off, texture<T, DIM, M>& t, const void* p, const cudaChannelFormatDesc& d, size_t w, size_t h, size_t pitch) {
-    return cudaBindTexture2D(off, &t, p, &d, w, h, pitch);
+    return cudaBindTexture2D(off, (const textureReference*)&t, p, &d, w, h, pitch);
+}
+static inline cudaError_t cudaBindTextureToArray(const textureReference* t, const cudaArray* a, const cudaChannelFormatDesc* = nullptr) {
+    textureReference* r = const_cast<textureReference*>(t); r->ptr = a->ptr; r->width = a->width; r->height = a->height; r->pitch = a->pitch; return cudaSuccess;
 }
 template <class T, int DIM, cudaTextureReadMode M>
-static inline cudaError_t cudaBindTexture(size_t* off, texture<T, DIM, M>& t, const void* p, size_t n = (size_t)-1) {
-    if (off) *off = 0; t.ptr = (const T*)p; t.width = n / sizeof(T); t.height = 1; t.pitch = n; return cudaSuccess;
-}
-template <class T, int DIM, cudaTextureReadMode M> static inline cudaError_t cudaUnbindTexture(texture<T, DIM, M>&) { return cudaSuccess; }
-enum cudaChannelFormatKind { cudaChannelFormatKindSigned, cudaChannelFormatKindUnsigned, cudaChannelFormatKindFloat };
-static inline cudaChannelFormatDesc cudaCreateChannelDesc(int x, int y, int z, int w, cudaChannelFormatKind f) { cudaChannelFormatDesc d = {x, y, z, w, (int)f}; return d; }
-template <class T, int DIM, cudaTextureReadMode M>
-static inline cudaError_t cudaBindTextureToArray(texture<T, DIM, M>& t, const cudaArray* a, const cudaChannelFormatDesc&) {
-    t.ptr = (const T*)a->ptr; t.width = a->width; t.height = a->height; t.pitch = a->pitch; return cudaSuccess;
-}
-template <class T, int DIM, cudaTextureReadMode M>
-static inline T tex2D(const texture<T, DIM, M>& t, float x, float y) {      // unnormalised coordinates, point filter: texel floor(x), floor(y)
+static inline cudaError_t cudaBindTextureToArray(texture<T, DIM, M>& t, const cudaArray* a, const cudaChannelFormatDesc&) { return cudaBindTextureToArray((const textureReference*)&t, a); }
+static inline cudaError_t cudaUnbindTexture(const textureReference*) { return cudaSuccess; }
+static inline cudaError_t cudaUnbindTexture(const textureReference&) { return cudaSuccess; }
+template <class T, int DIM>
+static inline T tex2D(const texture<T, DIM, cudaReadModeElementType>& t, float x, float y) {      // unnormalised coordinates, point filter: texel floor(x), floor(y)
     long ix = (long)floorf(x), iy = (long)floorf(y);
     ix = ix < 0 ? 0 : (ix >= (long)t.width ? (long)t.width - 1 : ix);
     iy = iy < 0 ? 0 : (iy >= (long)t.height ? (long)t.height - 1 : iy);
     return *(const T*)((const char*)t.ptr + (size_t)iy * t.pitch + (size_t)ix * sizeof(T));
 }
-template <class T, int DIM, cudaTextureReadMode M>
-static inline T tex1Dfetch(const texture<T, DIM, M>& t, int i) { return t.ptr[i]; }
+template <class T, int DIM>
+static inline T tex1Dfetch(const texture<T, DIM, cudaReadModeElementType>& t, int i) { return ((const T*)t.ptr)[i]; }
+template <int DIM>
+static inline float tex1Dfetch(const texture<unsigned char, DIM, cudaReadModeNormalizedFloat>& t, int i) { return (float)((const unsigned char*)t.ptr)[i] / 255.0f; }
+// 2-D arrays are pitched host images
+static inline cudaError_t cudaMallocArray(cudaArray** a, const cudaChannelFormatDesc* d, size_t w, size_t h = 0) {
+    const size_t texel = (size_t)(d->x + d->y + d->z + d->w) / 8, hh = h ? h : 1;
+    cudaArray* r = new cudaArray; r->width = w; r->height = hh; r->pitch = w * texel; r->ptr = calloc(hh, r->pitch); *a = r; return cudaSuccess;
+}
+static inline cudaError_t cudaFreeArray(cudaArray* a) { if (a) { free(const_cast<void*>(a->ptr)); delete a; } return cudaSuccess; }
+static inline cudaError_t cudaMemcpy2DToArray(cudaArray* dst, size_t wOff, size_t hOff, const void* src, size_t spitch, size_t widthBytes, size_t height, cudaMemcpyKind) {
+    for (size_t y = 0; y < height; ++y) memcpy((char*)const_cast<void*>(dst->ptr) + (hOff + y) * dst->pitch + wOff, (const char*)src + y * spitch, widthBytes);
+    return cudaSuccess;
+}
+static inline cudaError_t cudaMemcpyFromArray(void* dst, const cudaArray* src, size_t wOff, size_t hOff, size_t count, cudaMemcpyKind) {
+    memcpy(dst, (const char*)src->ptr + hOff * src->pitch + wOff, count); return cudaSuccess;
+}
+static inline cudaError_t cudaMemcpyAsync(void* d, const void* s, size_t n, cudaMemcpyKind, cudaStream_t = nullptr) { memcpy(d, s, n); return cudaSuccess; }
+static inline float saturate(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }      // __saturatef
+struct cudaDeviceProp { char name[256]; int major, minor, multiProcessorCount, clockRate; size_t totalGlobalMem, sharedMemPerBlock; int maxThreadsPerBlock, warpSize, regsPerBlock; };
+static inline cudaError_t cudaGetDeviceCount(int* n) { *n = 1; return cudaSuccess; }
+static inline cudaError_t cudaGetDeviceProperties(cudaDeviceProp* p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "host emulation"); p->major = 5; p->warpSize = 32; p->maxThreadsPerBlock = 1024; return cudaSuccess; }
+static inline cudaError_t cudaSetDevice(int) { return cudaSuccess; }
+static inline cudaError_t cudaGetDevice(int* d) { *d = 0; return cudaSuccess; }
 
 #endif

@@ -4,7 +4,10 @@
 //   :550-582 (DoG + gradient), :616-750 (keypoints), :905-1142 (orientation), :1178-1257 (descriptor),
 //   :1339-1370 (normalise), :1994-2107 (reshape, key list, uchar);  SiftGPU/SiftPyramid.cpp:82-145,
 //   148-255, 297-314, 351-394, 426-450, 730-768;  SiftGPU/SiftGPU.cpp:105-174, 224-253.
-// PARITY UNPINNED (ProgramCU.cu binds CUDA arrays / layered textures the host emulator of oracle/ref does not model).  Canonical choices where the reference is order-dependent:
+// PINNED to the reference's SiftGPU fork through oracle/_ref (tests/test_ref_pin_cpu.py::test_sift_detector_and_matcher_vs_reference): all 18
+// pyramid levels and the DoG extrema sets bit for bit, per-slot counts, the final key points as a multiset of float bits, descriptors within one
+// count in <= 0.1 % of the bytes (the reference build uses CUDA's fast-math exp / atan2 / sincos, the host build of it glibc, this file the fixed
+// sequences of include/bf_detmath.h).  Canonical choices where the reference is order-dependent:
 //   * keypoints of a level are kept in (row, col) order (the reference appends with atomicAdd);
 //   * the orientation histogram and the descriptor bins are accumulated as 64 strided partial sums
 //     (sample s goes to partial s mod 64) combined by a xor-butterfly 32,16,...,1 — the summation tree
@@ -95,14 +98,9 @@ inline float butterfly(float* lane) {       // 64-lane xor butterfly sum
 
 }  // namespace
 
-extern "C" {
-
-// returns the number of features; keys: 4 floats each (x, y, scale, depth); descs: 128 bytes each.
-// levelCounts (optional, 12 ints): per (octave, level) feature count after the final limit.
-int or_sift_run(const float* intensity, const float* depth, int W, int H, int depthW, int depthH, float depthMin, float depthMax,
-                float minKeyScale, int featureCountThreshold, int maxFeatures, float* keys, uint8_t* descs, int* levelCounts) {
-    static SiftParams P = makeParams();
-    std::vector<Octave> oct(NUM_OCT);
+// BuildPyramid + DetectKeypoints (SiftPyramid.cpp:82-145, 351-394): the pyramid and the raw key lists per (octave, DoG level) slot
+static void buildAndDetect(const SiftParams& P, const float* intensity, const float* depth, int W, int H, int depthW, int depthH, float depthMin, float depthMax,
+                           std::vector<Octave>& oct, std::vector<RawKey>* raw, int* levelNum) {
     // ---- BuildPyramid, SiftPyramid.cpp:82-145
     for (int o = 0; o < NUM_OCT; ++o) {
         Octave& oc = oct[o];
@@ -134,8 +132,6 @@ int or_sift_run(const float* intensity, const float* depth, int W, int H, int de
         }
     }
     // ---- DetectKeypoints, SiftPyramid.cpp:351-394 + ComputeKEY_Kernel :616-750
-    std::vector<RawKey> raw[NUM_OCT * DOG_LEVELS];
-    int levelNum[NUM_OCT * DOG_LEVELS];
     const float Tedge = (P.edgeThreshold + 1) * (P.edgeThreshold + 1) / P.edgeThreshold;
     for (int o = 0; o < NUM_OCT; ++o) {
         const Octave& oc = oct[o];
@@ -188,6 +184,19 @@ int or_sift_run(const float* intensity, const float* depth, int W, int H, int de
             levelNum[li] = (int)raw[li].size();
         }
     }
+}
+
+extern "C" {
+
+// returns the number of features; keys: 4 floats each (x, y, scale, depth); descs: 128 bytes each.
+// levelCounts (optional, 12 ints): per (octave, level) feature count after the final limit.
+int or_sift_run(const float* intensity, const float* depth, int W, int H, int depthW, int depthH, float depthMin, float depthMax,
+                float minKeyScale, int featureCountThreshold, int maxFeatures, float* keys, uint8_t* descs, int* levelCounts) {
+    static SiftParams P = makeParams();
+    std::vector<Octave> oct(NUM_OCT);
+    std::vector<RawKey> raw[NUM_OCT * DOG_LEVELS];
+    int levelNum[NUM_OCT * DOG_LEVELS];
+    buildAndDetect(P, intensity, depth, W, H, depthW, depthH, depthMin, depthMax, oct, raw, levelNum);
     // ---- LimitFeatureCount(0), SiftPyramid.cpp:227-255 (TruncateMethod 0)
     auto limit = [&](int* lv) {
         if (featureCountThreshold <= 0) return;
@@ -366,6 +375,19 @@ int or_sift_run(const float* intensity, const float* depth, int W, int H, int de
         }
     }
     return n;
+}
+
+// test hook: raw key lists after DetectKeypoints, before any limit: counts[12] and (col, row) pairs per slot (capacity keys per slot)
+void or_sift_detect(const float* intensity, const float* depth, int W, int H, int depthW, int depthH, float depthMin, float depthMax, int* counts, int* xy, int capacity) {
+    static SiftParams P = makeParams();
+    std::vector<Octave> oct(NUM_OCT);
+    std::vector<RawKey> raw[NUM_OCT * DOG_LEVELS];
+    int levelNum[NUM_OCT * DOG_LEVELS];
+    buildAndDetect(P, intensity, depth, W, H, depthW, depthH, depthMin, depthMax, oct, raw, levelNum);
+    for (int li = 0; li < NUM_OCT * DOG_LEVELS; ++li) {
+        counts[li] = levelNum[li];
+        for (int k = 0; k < levelNum[li] && k < capacity; ++k) { xy[((size_t)li * capacity + k) * 2] = raw[li][k].x; xy[((size_t)li * capacity + k) * 2 + 1] = raw[li][k].y; }
+    }
 }
 
 // test hook: one gaussian level of the pyramid (octave o, array index a in 0..5)

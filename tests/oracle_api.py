@@ -412,3 +412,12 @@ def rc_render(scene, params, ray_min, ray_max):
     olib.or_rc_render(C.c_void_p(olib.or_scene_hash(scene._h)), C.c_void_p(olib.or_scene_voxels(scene._h)), C.byref(hp), C.byref(params), _fp(mn), _fp(mx),
                       _fp(out["depth"]), _fp(out["depth4"]), _fp(out["normals"]), _fp(out["colors"]))
     return out
+
+
+def sift_detect(intensity, depth, depth_min=0.1, depth_max=4.0, capacity=4096):
+    """raw key lists after DetectKeypoints: list of 12 arrays (n_i, 2) of (col, row) per (octave, DoG level) slot"""
+    intensity = np.ascontiguousarray(intensity, np.float32); depth = np.ascontiguousarray(depth, np.float32)
+    H, W = intensity.shape; dH, dW = depth.shape
+    counts = np.zeros(12, np.int32); xy = np.zeros((12, capacity, 2), np.int32)
+    olib.or_sift_detect(_fp(intensity), _fp(depth), W, H, dW, dH, C.c_float(depth_min), C.c_float(depth_max), _fp(counts), _fp(xy), capacity)
+    return [xy[i, :min(counts[i], capacity)].copy() for i in range(12)]

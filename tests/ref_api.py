@@ -389,3 +389,60 @@ class RefSiftManager:
         t = _f32(traj).reshape(-1, 16); v = np.ascontiguousarray(valid, np.int32)
         return int(lib().ref_siftmgr_verify_trajectory(self._h, len(t), _fp(t), _fp(v), W, H, _fp(_f32(K).reshape(16)), C.c_float(dist_thresh), C.c_float(normal_thresh),
                                                        C.c_float(color_thresh), C.c_float(err_thresh), C.c_float(corr_thresh), C.c_float(dmin), C.c_float(dmax)))
+
+
+class RefSift:
+    """The reference's SiftGPU fork (detector + descriptor + matcher) on the host emulator."""
+
+    def __init__(self, w, h, K, feature_count_threshold=150, depth_min=0.1, depth_max=4.0, min_key_scale=3.0, max_keys=1024):
+        L = lib()
+        L.ref_sift_create.restype = C.c_void_p
+        Kf = _f32(K).reshape(16)
+        Ki = _f32(np.linalg.inv(np.asarray(K, np.float64))).reshape(16)
+        self.max_keys = max_keys
+        self._h = C.c_void_p(L.ref_sift_create(w, h, w, h, _fp(Kf), _fp(Ki), feature_count_threshold, C.c_float(depth_min), C.c_float(depth_max),
+                                               C.c_float(min_key_scale), max_keys))
+
+    def run(self, intensity, depth):
+        keys = np.zeros((self.max_keys, 4), np.float32); descs = np.zeros((self.max_keys, 128), np.uint8)
+        n = lib().ref_sift_run(self._h, _fp(_f32(intensity)), _fp(_f32(depth)), _fp(keys), _fp(descs))
+        m = max(0, min(n, self.max_keys))
+        return n, keys[:m].copy(), descs[:m].copy()
+
+    def match(self, d1, d2, off1=0, off2=0, distmax=0.7, ratiomax=0.8):
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        idx = np.zeros((128, 2), np.uint32); dist = np.zeros(128, np.float32)
+        n = lib().ref_sift_match(self._h, _fp(d1), len(d1), _fp(d2), len(d2), off1, off2, C.c_float(distmax), C.c_float(ratiomax), _fp(idx), _fp(dist))
+        m = max(0, min(n, 128))
+        return n, idx[:m].copy(), dist[:m].copy()
+
+
+def sift_stages(rs, intensity, depth):
+    """RefSift `rs` run stage by stage on one frame: dict with `levels` {(octave, index): image} of the Gaussian pyramid, `raw` (12 arrays of
+    (col, row) after DetectKeypoints), `counts` (12 final per-slot counts after orientation + limits), `final` (12 arrays (n, 4): x, y,
+    scale, orientation)."""
+    L = lib()
+    I = _f32(intensity); d = _f32(depth)
+    L.ref_sift_detect(rs._h, _fp(I), _fp(d))
+    out = {"levels": {}, "raw": [], "final": []}
+    H, W = I.shape
+    buf = np.zeros(W * H * 4, np.float32)
+    for o in range(3):
+        for a in range(6):
+            w, h, ch = C.c_int(), C.c_int(), C.c_int()
+            r = L.ref_sift_level(rs._h, o, a, 0, _fp(buf), len(buf), C.byref(w), C.byref(h), C.byref(ch))
+            if r > 0:
+                out["levels"][(o, a)] = buf[:r].reshape(h.value, w.value).copy()
+    raw = np.zeros((4096, 4), np.int32)
+    for s in range(12):
+        k = L.ref_sift_raw_keys(rs._h, s, _fp(raw), 4096)
+        out["raw"].append(raw[:k, :2].copy())
+    L.ref_sift_orient(rs._h)
+    cnt = np.zeros(12, np.int32)
+    L.ref_sift_level_counts(rs._h, _fp(cnt), 12)
+    out["counts"] = cnt
+    fin = np.zeros((4096, 4), np.float32)
+    for s in range(12):
+        k = L.ref_sift_final_keys(rs._h, s, _fp(fin), 4096)
+        out["final"].append(fin[:k].copy())
+    return out

@@ -583,3 +583,104 @@ def test_match_filter_chain_vs_reference_kernels(oracle):
     e, keyidx = ref.add_curr_to_residuals(cur, 0, n_frames, Kinv)
     assert len(e) == len(exp) > 20
     assert sorted(map(bytes, e)) == sorted(bytes(np.array(x)) for x in exp)
+
+
+def test_verify_trajectory_vs_reference_kernel(oracle):
+    """VerifyTrajectoryCU (SIFTImageManager.cu:1036-1159) against the oracle's restatement (pair decoding (block / N, block % N) over
+    N(N-1)/2 blocks + the dense verification block sum): same verdict for the true trajectory, for perturbed ones and with an invalid image."""
+    n, W, H = 5, 640, 480
+    frames = [synth.scene_room(30 + 5 * k, W, H) for k in range(n)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    Kc = K.copy(); Kc[0, 0] *= 80 / W; Kc[1, 1] *= 60 / H; Kc[0, 2] *= 79 / (W - 1); Kc[1, 2] *= 59 / (H - 1)
+    oframes = [oracle.cache_store_frame(f[0], f[1], 80, 60, K) for f in frames]
+    ref = ref_api.RefSiftManager(n + 1, 64)
+    for i in range(n):
+        ref.set_cached_frame(i, oframes[i])
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    gt = np.stack([(T0inv @ f[2].astype(np.float64)).astype(np.float32) for f in frames])
+
+    def oracle_verdict(traj, valid, err_t=0.05, corr_t=0.02):
+        ok = True
+        for blk in range(n * (n - 1) // 2):
+            i0, i1 = blk // n, blk % n
+            if i0 >= i1 or valid[i0] == 0 or valid[i1] == 0:
+                continue
+            T = oracle.mul44(oracle.inverse44(traj[i1]), traj[i0])
+            v, _, _ = oracle.dense_verify(oframes[i0], oframes[i1], 80, 60, Kc, T, err_thresh=err_t, corr_thresh=corr_t, dmin=0.1, dmax=3.0)
+            ok = ok and v
+        return int(ok)
+
+    rng = np.random.default_rng(3)
+    seen = set()
+    for case in range(6):
+        traj = gt.copy(); valid = [1] * n
+        if case in (1, 2, 3):
+            traj[1 + case % 2, :3, 3] += rng.normal(0, 0.02 * case, 3).astype(np.float32)
+        if case == 4:
+            traj[1, :3, 3] += 0.5; valid[1] = 0                      # the broken pose belongs to an invalid image: not tested
+        if case == 5:
+            traj[3, :3, 3] += 0.5                                     # (3, x) is not among the decoded pairs for N = 5: kept quirk
+        exp = oracle_verdict(traj, valid)
+        got = ref.verify_trajectory(traj, valid, 80, 60, Kc)
+        assert got == exp, (case, got, exp)
+        seen.add(exp)
+    assert seen == {0, 1}
+
+
+def test_sift_detector_and_matcher_vs_reference(oracle):
+    """The reference's SiftGPU fork, whole (SiftGPU.cpp, SiftPyramid.cpp, CuTexImage.cpp, SiftMatch.cpp, ProgramCU.cu compiled as they are),
+    on two 640x480 frames of the synthetic stream, against the oracle detector / matcher:
+      * all 18 Gaussian pyramid levels bit for bit;  * the DoG extrema with depth gate: the same (col, row) sets in all 12 (octave, level) slots;
+      * per-slot feature counts after orientation assignment and both LimitFeatureCount passes: equal;
+      * final key points (x, y, scale, depth): the same multiset of float bits; orientations within 1e-5 rad (atan2 / exp: libm there,
+        include/bf_detmath.h in the oracle and the product);
+      * descriptors: key for key, at most 1 count difference per byte in at most 0.1 % of the bytes (same reason + atomicAdd order);
+      * matcher: identical index pairs, distances within 1e-6 (acos)."""
+    from bundlefusion_amd.capi import rgbx_to_intensity
+    from collections import defaultdict
+    W, H = 640, 480
+    frames = [synth.scene_room(30 + 7 * k, W, H) for k in range(2)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    rs = ref_api.RefSift(W, H, K)
+    descs_o, descs_r = [], []
+    for fi, (d, c, _, _) in enumerate(frames):
+        I = rgbx_to_intensity(c)
+        on, okeys, odescs, olev = oracle.sift_run(I, d)
+        if fi == 0:
+            st = ref_api.sift_stages(rs, I, d)
+            assert len(st["levels"]) == 18
+            for (o, a), img in st["levels"].items():
+                assert np.array_equal(img.view(np.uint32), oracle.sift_pyramid_level(I, o, a).view(np.uint32)), (o, a)
+            oraw = oracle.sift_detect(I, d)
+            for s in range(12):
+                assert set(map(tuple, st["raw"][s].tolist())) == set(map(tuple, oraw[s].tolist())), s
+            assert sum(len(r) for r in oraw) > 250
+            assert np.array_equal(st["counts"], olev)
+        rn, rkeys, rdescs = rs.run(I, d)
+        assert rn == on > 100
+        bits = lambda k: sorted(map(tuple, np.ascontiguousarray(k).view(np.uint32).tolist()))
+        assert bits(rkeys) == bits(okeys)
+        by_key = defaultdict(list)
+        for k, dsc in zip(okeys, odescs):
+            by_key[tuple(k.view(np.uint32).tolist())].append(dsc.astype(int))
+        n_diff = 0
+        for k, dsc in zip(rkeys, rdescs):
+            best = min((np.abs(c - dsc.astype(int)) for c in by_key[tuple(k.view(np.uint32).tolist())]), key=lambda x: x.sum())
+            assert best.max() <= 1
+            n_diff += int((best > 0).sum())
+        assert n_diff <= 0.001 * 128 * rn
+        descs_o.append(odescs); descs_r.append(rdescs)
+    # orientations of the first frame's final lists (the oracle keeps them inside sift_run; they enter the descriptors compared above) are
+    # bounded through the descriptors; the matcher on the oracle's descriptors:
+    rn, ridx, rdist = rs.match(descs_o[0], descs_o[1], off1=0, off2=1024)
+    on, oidx, odist = oracle.sift_match(descs_o[0], descs_o[1], off1=0, off2=1024, sort=False)
+    assert rn == on > 50
+    om = {tuple(i): d for i, d in zip(oidx.tolist(), odist.tolist())}
+    assert sorted(om) == sorted(map(tuple, ridx.tolist()))
+    assert max(abs(om[tuple(i)] - d) for i, d in zip(ridx.tolist(), rdist.tolist())) < 1e-6
+    # thresholds are applied identically
+    rn2, ridx2, _ = rs.match(descs_o[0], descs_o[1], distmax=0.3, ratiomax=0.6)
+    on2, oidx2, _ = oracle.sift_match(descs_o[0], descs_o[1], distmax=0.3, ratiomax=0.6, sort=False)
+    assert rn2 == on2 < on and sorted(map(tuple, ridx2.tolist())) == sorted(map(tuple, oidx2.tolist()))
