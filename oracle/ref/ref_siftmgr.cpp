@@ -3,9 +3,10 @@
 // The REFERENCE's match-filter chain: SiftGPU/SIFTImageManager.cu compiled from where it lies — SortKeyPointMatchesCU,
 // FilterKeyPointMatchesCU (cuda_kabsch.h), FilterMatchesBySurfaceAreaCU (cuda_surfaceArea.h, cuda_EigenValue.h),
 // FilterMatchesByDenseVerifyCU, AddCurrToResidualsCU, VerifyTrajectoryCU — kernels AND their launch configurations (the member
-// functions of class SIFTImageManager are called as they are).  The class's constructor lives in SIFTImageManager.cpp, which needs
-// mLib / DirectX headers; this file therefore builds the object from zeroed storage and fills in the device pointers the member
-// functions read (private members are opened for that with a #define — test glue, not product code).
+// functions of class SIFTImageManager are called as they are) - and the host half of the class, SIFTImageManager.cpp (constructor / alloc,
+// createSIFTImageGPU / finalizeSIFTImageGPU, computeTracks + fuseToGlobal, filterFrames), compiled by the Makefile from a temporary copy
+// whose two includes of GlobalBundlingState.h / GlobalAppState.h (unused by the file; they pull the application's precompiled header) are
+// deleted.  Private members are opened with a #define where this glue has to reach state the class keeps to itself - test glue, not product code.
 #define private public
 #define protected public
 #include "SIFTImageManager.cu.cpp"      // = cu2cpp.py < reference file (generated into the build's temporary directory)
@@ -27,28 +28,41 @@ extern "C" {
 ref_siftmgr* ref_siftmgr_create(unsigned int maxImages, unsigned int maxKeysPerImage) {
     ref_siftmgr* h = new ref_siftmgr;
     h->maxImages = maxImages; h->maxKeys = maxKeysPerImage;
-    SIFTImageManager* m = (SIFTImageManager*)calloc(1, sizeof(SIFTImageManager));      // no constructor: see the header comment
-    new (&m->m_validImages) std::vector<int>(maxImages, 1);
-    m->m_maxNumImages = maxImages; m->m_maxKeyPointsPerImage = maxKeysPerImage; m->m_timer = NULL;
-    const size_t nk = (size_t)maxImages * maxKeysPerImage;
-    m->d_keyPoints = (SIFTKeyPoint*)calloc(nk, sizeof(SIFTKeyPoint));
-    m->d_currNumMatchesPerImagePair = (int*)calloc(maxImages, sizeof(int));
-    m->d_currMatchDistances = (float*)calloc((size_t)maxImages * MAX_MATCHES_PER_IMAGE_PAIR_RAW, sizeof(float));
-    m->d_currMatchKeyPointIndices = (uint2*)calloc((size_t)maxImages * MAX_MATCHES_PER_IMAGE_PAIR_RAW, sizeof(uint2));
-    m->d_currNumFilteredMatchesPerImagePair = (int*)calloc(maxImages, sizeof(int));
-    m->d_currFilteredMatchDistances = (float*)calloc((size_t)maxImages * MAX_MATCHES_PER_IMAGE_PAIR_FILTERED, sizeof(float));
-    m->d_currFilteredMatchKeyPointIndices = (uint2*)calloc((size_t)maxImages * MAX_MATCHES_PER_IMAGE_PAIR_FILTERED, sizeof(uint2));
-    m->d_currFilteredTransforms = (float4x4*)calloc(maxImages, sizeof(float4x4));
-    m->d_currFilteredTransformsInv = (float4x4*)calloc(maxImages, sizeof(float4x4));
-    const size_t maxRes = (size_t)MAX_MATCHES_PER_IMAGE_PAIR_FILTERED * maxImages * (maxImages - 1) / 2 + 64;
-    m->d_globMatches = (EntryJ*)calloc(maxRes, sizeof(EntryJ));
-    m->d_globMatchesKeyPointIndices = (uint2*)calloc(maxRes, sizeof(uint2));
-    m->d_globNumResiduals = (int*)calloc(1, sizeof(int));
-    m->d_validImages = (int*)calloc(maxImages, sizeof(int));
-    m->d_validOpt = (int*)calloc(1, sizeof(int));
-    h->m = m;
+    h->m = new SIFTImageManager(maxImages, maxKeysPerImage);             // SIFTImageManager.cpp:7-15, alloc :274-313
+    for (unsigned int i = 0; i < maxImages; ++i) h->m->m_validImages[i] = 1;
     h->frames = (CUDACachedFrame*)calloc(maxImages, sizeof(CUDACachedFrame));
     return h;
+}
+
+// an image through createSIFTImageGPU / finalizeSIFTImageGPU (keys are PACKED in the reference: image i starts at the prefix sum)
+unsigned int ref_siftmgr_add_image(ref_siftmgr* h, const float* keys4, const unsigned char* descs128, unsigned int n) {
+    SIFTImageGPU& img = h->m->createSIFTImageGPU();
+    memcpy(img.d_keyPoints, keys4, sizeof(SIFTKeyPoint) * (size_t)n);
+    memcpy(img.d_keyPointDescs, descs128, sizeof(SIFTKeyPointDesc) * (size_t)n);
+    h->m->finalizeSIFTImageGPU(n);
+    return h->m->m_numKeyPointsPerImagePrefixSum.back();
+}
+void ref_siftmgr_set_residuals(ref_siftmgr* h, const void* entryJ, const unsigned int* keyIdx2, unsigned int n) {
+    memcpy(h->m->d_globMatches, entryJ, sizeof(EntryJ) * (size_t)n);
+    memcpy(h->m->d_globMatchesKeyPointIndices, keyIdx2, sizeof(uint2) * (size_t)n);
+    h->m->m_globNumResiduals = n; *h->m->d_globNumResiduals = (int)n;
+}
+// fuseToGlobal (SIFTImageManager.cpp:411-468) into a fresh global manager; returns the number of fused keys
+unsigned int ref_siftmgr_fuse_to_global(ref_siftmgr* h, const float* K16, const float* Kinv16, const float* transforms16, unsigned int maxKeysGlobal, float* outKeys4,
+                                        unsigned char* outDescs128) {
+    SIFTImageManager global(4, maxKeysGlobal);
+    h->m->fuseToGlobal(&global, float4x4(K16), (const float4x4*)transforms16, float4x4(Kinv16));
+    const unsigned int n = global.m_numKeyPointsPerImage[0];
+    memcpy(outKeys4, global.d_keyPoints, sizeof(SIFTKeyPoint) * (size_t)n);
+    memcpy(outDescs128, global.d_keyPointDescs, sizeof(SIFTKeyPointDesc) * (size_t)n);
+    return n;
+}
+// filterFrames (SIFTImageManager.cpp:551-575): returns the last matched frame, *valid receives m_validImages[curFrame]
+unsigned int ref_siftmgr_filter_frames(ref_siftmgr* h, unsigned int cur, unsigned int start, unsigned int num, const int* validIn, int* validOut) {
+    for (unsigned int i = 0; i < num; ++i) h->m->m_validImages[i] = validIn[i];
+    const unsigned int last = h->m->filterFrames(cur, start, num);
+    *validOut = h->m->m_validImages[cur];
+    return last;
 }
 
 void ref_siftmgr_set_keys(ref_siftmgr* h, const float* keys, unsigned int count) { memcpy(h->m->d_keyPoints, keys, sizeof(SIFTKeyPoint) * (size_t)count); }
@@ -114,6 +128,14 @@ int ref_siftmgr_verify_trajectory(ref_siftmgr* h, unsigned int numImages, const 
     memcpy(T.data(), traj16, 64 * (size_t)numImages);
     return h->m->VerifyTrajectoryCU(numImages, T.data(), W, H, float4x4(K16), h->frames, distThresh, normalThresh, colorThresh, errThresh, corrThresh, dmin, dmax);
 }
+// CheckForInvalidFramesCU / CheckForInvalidFramesSimpleCU (:746-797) and InvalidateImageToImageCU (:706-720); valid flags in and out
+void ref_siftmgr_check_invalid_frames(ref_siftmgr* h, const int* rows, unsigned int numVars, int* valid, int simple) {
+    for (unsigned int i = 0; i < numVars; ++i) h->m->m_validImages[i] = valid[i];
+    if (simple) h->m->CheckForInvalidFramesSimpleCU(rows, numVars);
+    else h->m->CheckForInvalidFramesCU(rows, numVars);
+    for (unsigned int i = 0; i < numVars; ++i) valid[i] = h->m->m_validImages[i];
+}
+void ref_siftmgr_invalidate_image_to_image(ref_siftmgr* h, unsigned int i, unsigned int j) { h->m->InvalidateImageToImageCU(make_uint2(i, j)); }
 unsigned int ref_siftmgr_sizeof_entryj() { return (unsigned int)sizeof(EntryJ); }
 
 }  // extern "C"

@@ -13,4 +13,14 @@ typedef unsigned char BYTE;
 #define MLIB_WARNING(s) ((void)0)
 #define SAFE_DELETE(p) do { delete (p); (p) = nullptr; } while (0)
 #define SAFE_DELETE_ARRAY(p) do { delete[] (p); (p) = nullptr; } while (0)
+// ml::DepthImage32 as SIFTImageManager::fuseLocalKeyDepths uses it (allocate / getData / getNumPixels / operator()(x, y))
+#include <fstream>
+#include <vector>
+struct DepthImage32 {
+    std::vector<float> d; unsigned int w = 0, h = 0;
+    void allocate(unsigned int width, unsigned int height) { w = width; h = height; d.assign((size_t)w * h, 0.0f); }
+    float* getData() { return d.data(); }
+    size_t getNumPixels() const { return d.size(); }
+    float& operator()(unsigned int x, unsigned int y) { return d[(size_t)y * w + x]; }
+};
 #endif

@@ -284,63 +284,10 @@ class OBundler:
     # ---- SIFTImageManager::fuseToGlobal (.cpp:367-476)
     def fuse_to_global(self, glob):
         assert len(self.corr) > 0
-        mk = self.max_keys
-        T = self.trajectory
-        corr_per_key = {}
-        def xf(M, p):          # float4x4 * float3 with w = 1, same operation order as the device code
-            f = np.float32
-            return np.array([f(f(f(f(M[r, 0] * p[0]) + f(M[r, 1] * p[1])) + f(M[r, 2] * p[2])) + f(M[r, 3] * f(1.0))) for r in range(3)], np.float32)
-        for c, k in zip(self.corr, self.corr_keys):
-            if c["imgIdx_i"] == INVALID:
-                continue
-            i, j = int(c["imgIdx_i"]), int(c["imgIdx_j"])
-            pi, pj = c["pos_i"].astype(np.float32), c["pos_j"].astype(np.float32)
-            d = xf(T[i], pi) - xf(T[j], pj)
-            err = np.sqrt(np.float32(np.float32(np.float32(d[0] * d[0]) + np.float32(d[1] * d[1])) + np.float32(d[2] * d[2])))
-            if err < np.float32(0.03):
-                corr_per_key.setdefault(int(k[0]), []).append(((j, int(k[1])), pj))
-                corr_per_key.setdefault(int(k[1]), []).append(((i, int(k[0])), pi))
-            else:
-                corr_per_key.setdefault(int(k[0]), []).append(((j, int(k[1])), None))
-                corr_per_key.setdefault(int(k[1]), []).append(((i, int(k[0])), None))
-        marker = set()
-        tracks = []
-        def find_track(track, key):
-            stack = [(key, 0)]
-            while stack:
-                kk, pos = stack.pop()
-                lst = corr_per_key.get(kk, [])
-                if pos >= len(lst):
-                    continue
-                stack.append((kk, pos + 1))
-                (img, ky), p = lst[pos]
-                if ky not in marker:
-                    track.append(((img, ky), p))
-                    marker.add(ky)
-                    stack.append((ky, 0))
-        for i in range(self.num_images):
-            for k in range(len(self.keys[i])):
-                if not tracks or tracks[-1]:
-                    tracks.append([])
-                find_track(tracks[-1], i * mk + k)
-        cur_keys, cur_desc = [], []
-        for tr in tracks:
-            if not tr:
-                continue
-            rep = tr[0]
-            pos = np.zeros(3, np.float32); num = 0
-            for (img, ky), p in tr:
-                if p is not None:
-                    pos = (pos + xf(T[img], p)).astype(np.float32); num += 1
-            if num > 0:
-                pos = (pos / np.float32(num)).astype(np.float32)
-                pos = xf(self.K, pos)
-                cur_keys.append([np.float32(pos[0] / pos[2]), np.float32(pos[1] / pos[2]), self.allkeys[rep[0][1], 2], pos[2]])
-                cur_desc.append(self.descs[rep[0][1] // mk][rep[0][1] % mk])
-        n = min(len(cur_keys), glob.max_keys)
-        keys = np.array(cur_keys, np.float32).reshape(-1, 4)
-        if len(cur_keys) > glob.max_keys:
-            keys = keys[np.argsort(keys[:, 3], kind="stable")]
+        keys, descs = fuse_tracks(self.corr, self.corr_keys, self.trajectory, [len(k) for k in self.keys][:self.num_images], self.descs, self.allkeys,
+                                  self.K, self.max_keys, glob.max_keys)
+        n = len(keys)
+        cur_desc = descs
         glob._add_image(keys[:n].copy(), np.array(cur_desc, np.uint8).reshape(-1, 128)[:n].copy())
         glob.cache.append(self.cache[0])
 
@@ -732,3 +679,64 @@ class OraclePipeline:
             f = self.tm.frames[i]
             out.append(f["integrated"] if f["type"] in (0, 4) else _minf())
         return np.stack(out) if out else np.zeros((0, 4, 4), np.float32)
+
+
+def fuse_tracks(corr, corr_keys, T, num_keys_per_image, descs, allkeys, K, mk, glob_max_keys):
+    """computeTracks + fuseToGlobal (SIFTImageManager.cpp:367-468): correspondences (EntryJ rows + key index pairs, image * mk + key) and the chunk's
+    trajectory -> fused key points (n, 4) and their descriptors (n, 128) of the chunk's key frame."""
+    corr_per_key = {}
+    def xf(M, p):          # float4x4 * float3 with w = 1, same operation order as the device code
+        f = np.float32
+        return np.array([f(f(f(f(M[r, 0] * p[0]) + f(M[r, 1] * p[1])) + f(M[r, 2] * p[2])) + f(M[r, 3] * f(1.0))) for r in range(3)], np.float32)
+    for c, k in zip(corr, corr_keys):
+        if c["imgIdx_i"] == INVALID:
+            continue
+        i, j = int(c["imgIdx_i"]), int(c["imgIdx_j"])
+        pi, pj = c["pos_i"].astype(np.float32), c["pos_j"].astype(np.float32)
+        d = xf(T[i], pi) - xf(T[j], pj)
+        err = np.sqrt(np.float32(np.float32(np.float32(d[0] * d[0]) + np.float32(d[1] * d[1])) + np.float32(d[2] * d[2])))
+        if err < np.float32(0.03):
+            corr_per_key.setdefault(int(k[0]), []).append(((j, int(k[1])), pj))
+            corr_per_key.setdefault(int(k[1]), []).append(((i, int(k[0])), pi))
+        else:
+            corr_per_key.setdefault(int(k[0]), []).append(((j, int(k[1])), None))
+            corr_per_key.setdefault(int(k[1]), []).append(((i, int(k[0])), None))
+    marker = set()
+    tracks = []
+    def find_track(track, key):
+        stack = [(key, 0)]
+        while stack:
+            kk, pos = stack.pop()
+            lst = corr_per_key.get(kk, [])
+            if pos >= len(lst):
+                continue
+            stack.append((kk, pos + 1))
+            (img, ky), p = lst[pos]
+            if ky not in marker:
+                track.append(((img, ky), p))
+                marker.add(ky)
+                stack.append((ky, 0))
+    for i in range(len(num_keys_per_image)):
+        for k in range(num_keys_per_image[i]):
+            if not tracks or tracks[-1]:
+                tracks.append([])
+            find_track(tracks[-1], i * mk + k)
+    cur_keys, cur_desc = [], []
+    for tr in tracks:
+        if not tr:
+            continue
+        rep = tr[0]
+        pos = np.zeros(3, np.float32); num = 0
+        for (img, ky), p in tr:
+            if p is not None:
+                pos = (pos + xf(T[img], p)).astype(np.float32); num += 1
+        if num > 0:
+            pos = (pos / np.float32(num)).astype(np.float32)
+            pos = xf(K, pos)
+            cur_keys.append([np.float32(pos[0] / pos[2]), np.float32(pos[1] / pos[2]), allkeys[rep[0][1], 2], pos[2]])
+            cur_desc.append(descs[rep[0][1] // mk][rep[0][1] % mk])
+    n = min(len(cur_keys), glob_max_keys)
+    keys = np.array(cur_keys, np.float32).reshape(-1, 4)
+    if len(cur_keys) > glob_max_keys:
+        keys = keys[np.argsort(keys[:, 3], kind="stable")]
+    return keys[:n].copy(), np.array(cur_desc, np.uint8).reshape(-1, 128)[:n].copy()

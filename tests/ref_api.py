@@ -446,3 +446,34 @@ def sift_stages(rs, intensity, depth):
         k = L.ref_sift_final_keys(rs._h, s, _fp(fin), 4096)
         out["final"].append(fin[:k].copy())
     return out
+
+
+def siftmgr_fuse(keys_per_image, descs_per_image, corr, corr_keys_packed, transforms, K, max_keys_global=1024):
+    """SIFTImageManager::fuseToGlobal of the reference on a chunk given by its images (key points / descriptors per image), its correspondences
+    (EntryJ rows + PACKED key index pairs) and its trajectory -> (keys (n, 4), descs (n, 128)) of the fused key frame."""
+    L = lib()
+    L.ref_siftmgr_create.restype = C.c_void_p
+    h = C.c_void_p(L.ref_siftmgr_create(len(keys_per_image) + 1, 1024))
+    for k, d in zip(keys_per_image, descs_per_image):
+        L.ref_siftmgr_add_image(h, _fp(_f32(k).reshape(-1, 4)), _fp(np.ascontiguousarray(d, np.uint8)), len(k))
+    e = np.ascontiguousarray(corr); ck = np.ascontiguousarray(corr_keys_packed, np.uint32)
+    L.ref_siftmgr_set_residuals(h, _fp(e), _fp(ck), len(e))
+    T = _f32(transforms).reshape(-1, 16)
+    Kf = _f32(K).reshape(16); Ki = _f32(np.linalg.inv(np.asarray(K, np.float64))).reshape(16)
+    ok = np.zeros((max_keys_global, 4), np.float32); od = np.zeros((max_keys_global, 128), np.uint8)
+    L.ref_siftmgr_fuse_to_global.restype = C.c_uint32
+    n = L.ref_siftmgr_fuse_to_global(h, _fp(Kf), _fp(Ki), _fp(T), max_keys_global, _fp(ok), _fp(od))
+    return ok[:n].copy(), od[:n].copy()
+
+
+def siftmgr_filter_frames(num_filt, valid, cur, start, num):
+    """SIFTImageManager::filterFrames -> (lastMatchedFrame or -1, valid flag of the current frame)"""
+    L = lib()
+    L.ref_siftmgr_create.restype = C.c_void_p
+    h = C.c_void_p(L.ref_siftmgr_create(max(num, 2) + 1, 64))
+    for p, n in enumerate(num_filt):
+        L.ref_siftmgr_set_filtered(h, p, int(n), None, None, None, None)
+    v = np.ascontiguousarray(valid, np.int32); out = C.c_int()
+    L.ref_siftmgr_filter_frames.restype = C.c_uint32
+    last = L.ref_siftmgr_filter_frames(h, cur, start, num, _fp(v), C.byref(out))
+    return (-1 if last == 0xFFFFFFFF else int(last)), out.value

@@ -684,3 +684,108 @@ def test_sift_detector_and_matcher_vs_reference(oracle):
     rn2, ridx2, _ = rs.match(descs_o[0], descs_o[1], distmax=0.3, ratiomax=0.6)
     on2, oidx2, _ = oracle.sift_match(descs_o[0], descs_o[1], distmax=0.3, ratiomax=0.6, sort=False)
     assert rn2 == on2 < on and sorted(map(tuple, ridx2.tolist())) == sorted(map(tuple, oidx2.tolist()))
+
+
+def test_fuse_to_global_and_filter_frames_vs_reference(oracle):
+    """The host half of the reference's SIFTImageManager (SIFTImageManager.cpp compiled as it is): computeTracks + fuseToGlobal on the
+    correspondences of a 5-frame chunk with its ground-truth trajectory - fused key points (position, scale, depth) and descriptors bit for
+    bit, in the same order; filterFrames on random match-count / validity
+    patterns."""
+    from bundlefusion_amd.capi import rgbx_to_intensity, ENTRYJ_DTYPE
+    from tests.oracle_pipeline import fuse_tracks
+    n, W, H = 5, 640, 480
+    frames = [synth.scene_room(30 + 4 * k, W, H) for k in range(n)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    Kinv = oracle.inverse44(K)
+    mk = 1024
+    keys, descs, nk = [], [], []
+    allkeys = np.zeros((n * mk, 4), np.float32)
+    for i, (d, c, _, _) in enumerate(frames):
+        m, k, ds, _ = oracle.sift_run(rgbx_to_intensity(c), d)
+        keys.append(k); descs.append(ds); nk.append(m); allkeys[i * mk:i * mk + m] = k
+    prefix = np.concatenate([[0], np.cumsum(nk)[:-1]])
+    corr, ckeys = [], []
+    for cur in range(1, n):
+        for p in range(cur):
+            cnt, idx, dist = oracle.sift_match(descs[p], descs[cur], off1=p * mk, off2=cur * mk, sort=True)
+            m = min(cnt, 128)
+            pidx = np.zeros((128, 2), np.uint32); pidx[:m] = idx; pdist = np.zeros(128, np.float32); pdist[:m] = dist
+            fn, fidx, fdist, fT = oracle.filter_matches(allkeys, pidx, pdist, m, Kinv)
+            for q in range(fn):
+                corr.append(oracle.make_entry(allkeys, fidx[q, 0], fidx[q, 1], p, cur, Kinv)); ckeys.append((int(fidx[q, 0]), int(fidx[q, 1])))
+    corr = np.array(corr, ENTRYJ_DTYPE); ckeys = np.array(ckeys, np.uint32)
+    assert len(corr) > 100
+    corr["imgIdx_i"][3] = 0xFFFFFFFF; corr["imgIdx_j"][3] = 0xFFFFFFFF          # an invalidated correspondence is skipped
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    traj = np.stack([(T0inv @ f[2].astype(np.float64)).astype(np.float32) for f in frames])
+    traj[2, 0, 3] += 0.05                                                      # one pose off by 5 cm: its correspondences exceed MAX_TRACK_CORR_ERROR
+    packed = np.stack([prefix[ckeys[:, 0] // mk] + ckeys[:, 0] % mk, prefix[ckeys[:, 1] // mk] + ckeys[:, 1] % mk], 1).astype(np.uint32)
+    ok, od = fuse_tracks(corr, ckeys, traj, nk, descs, allkeys, K, mk, 1024)
+    rk, rd = ref_api.siftmgr_fuse(keys, descs, corr, packed, traj, K, max_keys_global=1024)
+    assert len(rk) == len(ok) > 60
+    assert np.array_equal(rk.view(np.uint32), ok.view(np.uint32)) and np.array_equal(rd, od)
+    # (the over-capacity branch - more fused keys than s_maxNumKeysPerImage, :459-464 - needs > 1024 tracks and is not exercised here)
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        num = int(rng.integers(2, 9)); cur = int(rng.integers(0, num)); start = 0 if cur + 1 == num else cur + 1
+        nf = rng.integers(0, 3, num); valid = rng.integers(0, 2, num)
+        last, v = ref_api.siftmgr_filter_frames(nf, valid, cur, start, num)
+        exp_last, exp_v = -1, 0
+        for i in range(num - 1, start - 1, -1):
+            if valid[i] != 0 and nf[i] > 0 and i != cur:
+                exp_last, exp_v = i, 1; break
+        assert (last, v) == (exp_last, exp_v)
+
+
+def test_check_for_invalid_frames_launch_arithmetic_vs_reference():
+    """CheckForInvalidFramesCU (SIFTImageManager.cu:725-760): the reference launches grid (ceil(R/128), 128) x block (ceil(N/16), 16) and
+    indexes residuals with blockDim.x * blockIdx.x + blockIdx.y and variables with gridDim.x * threadIdx.x + threadIdx.y, so only a subset of
+    (residual, variable) pairs is visited.  The product restates that subset in closed form (csrc/siftmgr.hip: k_check_invalid); the same closed
+    form here against the reference's own launch, on random problems: valid flags and invalidated residuals identical.  Also the simple
+    variant and InvalidateImageToImageCU."""
+    import ctypes as C
+    from bundlefusion_amd.capi import ENTRYJ_DTYPE
+    L = ref_api.lib()
+    L.ref_siftmgr_create.restype = C.c_void_p
+    rng = np.random.default_rng(11)
+    INV = 0xFFFFFFFF
+    for trial in range(25):
+        N = int(rng.integers(2, 40)); R = int(rng.integers(1, 700))
+        h = C.c_void_p(L.ref_siftmgr_create(max(N + 1, 9), 32))          # capacity 25 * M (M - 1) / 2 >= 700 residuals
+        e = np.zeros(R, ENTRYJ_DTYPE)
+        e["imgIdx_i"] = rng.integers(0, N, R); e["imgIdx_j"] = rng.integers(0, N, R)
+        dead = rng.random(R) < 0.1
+        e["imgIdx_i"][dead] = INV; e["imgIdx_j"][dead] = INV
+        rows = (rng.random(N) < 0.7).astype(np.int32) * rng.integers(1, 5, N).astype(np.int32)
+        rows[0] = max(int(rows[0]), 1)                     # (the reference prints a warning when the first frame loses its rows)
+        valid = (rng.random(N) < 0.8).astype(np.int32)
+        simple = trial % 5 == 4
+        L.ref_siftmgr_set_residuals(h, e.ctypes.data_as(C.c_void_p), np.zeros((R, 2), np.uint32).ctypes.data_as(C.c_void_p), R)
+        v = valid.copy()
+        L.ref_siftmgr_check_invalid_frames(h, rows.ctypes.data_as(C.c_void_p), N, v.ctypes.data_as(C.c_void_p), int(simple))
+        got = np.zeros(R, ENTRYJ_DTYPE); gk = np.zeros((R, 2), np.uint32)
+        L.ref_siftmgr_get_residuals(h, got.ctypes.data_as(C.c_void_p), gk.ctypes.data_as(C.c_void_p), R)
+        # closed form
+        exp_v = valid.copy(); exp_e = e.copy()
+        if simple:
+            exp_v[rows == 0] = 0
+        else:
+            gx, bx = (R + 127) // 128, (N + 15) // 16
+            in_var = lambda x: any((x - d) % gx == 0 and (x - d) // gx < bx for d in range(min(16, x + 1)))
+            in_res = lambda r: any((r - b) % bx == 0 and (r - b) // bx < gx for b in range(min(128, r + 1)))
+            zero = [x for x in range(N) if rows[x] == 0 and in_var(x)]
+            for x in zero:
+                exp_v[x] = 0
+            for r in range(R):
+                if in_res(r) and exp_e["imgIdx_i"][r] != INV and (int(exp_e["imgIdx_i"][r]) in zero or int(exp_e["imgIdx_j"][r]) in zero):
+                    exp_e["imgIdx_i"][r] = INV; exp_e["imgIdx_j"][r] = INV
+        assert np.array_equal(v, exp_v), (trial, N, R)
+        assert np.array_equal(got["imgIdx_i"], exp_e["imgIdx_i"]) and np.array_equal(got["imgIdx_j"], exp_e["imgIdx_j"]), (trial, N, R)
+        # InvalidateImageToImageCU
+        i, j = int(rng.integers(0, N)), int(rng.integers(0, N))
+        L.ref_siftmgr_invalidate_image_to_image(h, i, j)
+        L.ref_siftmgr_get_residuals(h, got.ctypes.data_as(C.c_void_p), gk.ctypes.data_as(C.c_void_p), R)
+        hit = (exp_e["imgIdx_i"] == i) & (exp_e["imgIdx_j"] == j)
+        exp_e["imgIdx_i"][hit] = INV; exp_e["imgIdx_j"][hit] = INV
+        assert np.array_equal(got["imgIdx_i"], exp_e["imgIdx_i"]) and np.array_equal(got["imgIdx_j"], exp_e["imgIdx_j"])
