@@ -70,11 +70,14 @@ class ChunkedRunner:
         return round_end * self.S + 1
 
     def _local_half(self, r0, out, produced):
-        c_mine = r0 + self.rank
-        a, b = chunk_frames(c_mine, self.S)
-        if b < len(self.feed):
-            self.worker.run(c_mine, self.feed[a:b + 1], out=out)
-            produced.append(c_mine)
+        try:
+            c_mine = r0 + self.rank
+            a, b = chunk_frames(c_mine, self.S)
+            if b < len(self.feed):
+                self.worker.run(c_mine, self.feed[a:b + 1], out=out)
+                produced.append(c_mine)
+        except BaseException as e:           # raised again on the main thread when the package is needed (wait / _ensure)
+            produced.append(e)
 
     def _start(self, r0):
         import threading
@@ -102,6 +105,9 @@ class ChunkedRunner:
         else:
             self._local_half(r0, mine, produced)
         self._pending = None
+        for p in produced:
+            if isinstance(p, BaseException):
+                raise p
         self.local_chunks += len(produced)
         got = gather_packages(mine, self.world, self.rank, self.device)
         self.rounds += 1
@@ -117,6 +123,9 @@ class ChunkedRunner:
         """Block until the local half running ahead (if any) has finished; its package is kept for the round that needs it."""
         if self._pending is not None and self._pending[1] is not None:
             self._pending[1].join()
+            for p in self._pending[3]:
+                if isinstance(p, BaseException):
+                    raise p
 
     def close(self):
         self.wait()

@@ -443,3 +443,40 @@ def test_pose_helper_functions(built, tmp_path):
     ang = 2 * np.arctan2(q[:, 2], q[:, 3])
     assert np.allclose(ang, 0.7 + 0.1 * np.array([0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11]), atol=1e-4)
     assert abs(float(rows[0][1]) - 1.0) < 1e-6 and abs(float(rows[0][2]) + 2.0) < 1e-6 and abs(float(rows[0][3]) - 0.5) < 1e-6
+
+
+def test_chunked_runner_local_half_runs_ahead_and_fails_loudly():
+    """ChunkedRunner (world 1): the local half of the next chunk is produced on a second thread while the current one is consumed - same
+    schedule with and without the run-ahead; an error inside the local half surfaces on the main thread, never as a silent empty package."""
+    import numpy as np
+    import pytest
+    from bundlefusion_amd.shard import ChunkedRunner
+    S = 10
+
+    class Worker:
+        package_bytes = 16
+        def __init__(self, fail_at=None): self.ran, self.fail_at = [], fail_at
+        def run(self, chunk, frames, out=None):
+            if chunk == self.fail_at:
+                raise RuntimeError("local half failed for chunk %d" % chunk)
+            out[:4].view(np.int32)[0] = chunk
+            self.ran.append(chunk)
+
+    class Pipe:
+        def __init__(self): self.log = []
+        def process_frame_chunked(self, d, c, pkg, j):
+            self.log.append((d, int(pkg[:4].view(np.int32)[0]), j)); return True
+
+    feed = [(i, i) for i in range(1 + 4 * S)]
+    logs = []
+    for prefetch in (True, False):
+        r = ChunkedRunner(Pipe(), Worker(), feed, S, prefetch=prefetch)
+        r.advance(13); r.wait(); r.advance(len(feed) - 13); r.close()
+        assert r.worker.ran == [0, 1, 2, 3] and r.local_chunks == 4 and r.rounds == 4
+        logs.append(r.pipe.log)
+    assert logs[0] == logs[1] and [f for f, _, _ in logs[0]] == list(range(len(feed)))
+    assert all(c == (0 if f == 0 else (f - 1) // S) for f, c, _ in logs[0])
+    r = ChunkedRunner(Pipe(), Worker(fail_at=2), feed, S)
+    with pytest.raises(RuntimeError, match="chunk 2"):
+        r.advance(len(feed))
+    assert max(f for f, _, _ in r.pipe.log) <= 2 * S         # nothing of chunk 2 was consumed
