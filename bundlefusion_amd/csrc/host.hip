@@ -793,6 +793,9 @@ void tmInvalidate(bf_trajectory_manager* tm, uint32_t idx) {                    
     const int before = f.type;
     f.type = BF_TF_INVALID;
     if (before == BF_TF_INTEGRATED) tm->toDeIntegrate.push_back(&f);
+    // never integrated and no pose any more: nothing to integrate.  (The reference leaves the frame in m_toIntegrateList, and its
+    // getTopFromIntegrateList then stops at "ERROR NEED TO CHECK FOR INVALIDATE INTEGRATE LIST ELEMENTS" + assert, :142-146.)
+    else if (before == BF_TF_NOT_INTEGRATED_WITH_TRANSFORM) tm->toIntegrate.remove(&f);
 }
 }  // namespace
 
@@ -854,9 +857,13 @@ int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm) {    
             f3 ro, to, ri, ti;
             matrixToPose(T, ro, to);
             matrixToPose(f.integratedTransform, ri, ti);
+            // PoseHelper::MatrixToPose (USE_LIE_SPACE, PoseHelper.h:332-363) returns (translation part, rotation vector), and the
+            // reference rescales elements 0..2 (:70-77): it is the TRANSLATION part that is doubled, whatever the member's name says.
+            // Pinned against TrajectoryManager.cpp itself (tests/test_ref_pin_cpu.py).
             const float s = tm->featureRescaleRotToTrans;
-            const float d[6] = {ri.x * s - ro.x * s, ri.y * s - ro.y * s, ri.z * s - ro.z * s, ti.x - to.x, ti.y - to.y, ti.z - to.z};
-            f.dist = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+            const float d[6] = {ti.x * s - to.x * s, ti.y * s - to.y * s, ti.z * s - to.z * s, ri.x - ro.x, ri.y - ro.y, ri.z - ro.z};
+            f.dist = 0.0f;
+            for (int k = 0; k < 6; ++k) f.dist += d[k] * d[k];
         }
     }
     // std::sort in the reference; a stable sort makes the order of equal distances reproducible
@@ -905,14 +912,21 @@ int bf_trajectory_manager_get_top_from_integrate_list(bf_trajectory_manager* tm,
     BF_REQUIRE(tm && trans && frameIdx && found, "null argument");
     *found = 0;
     if (tm->toIntegrate.empty()) return BF_OK;
-    auto* f = tm->toIntegrate.front();
-    BF_REQUIRE(f->type == BF_TF_NOT_INTEGRATED_WITH_TRANSFORM, "integrate list holds an invalidated frame");
-    const m44 T = tm->opt(*f);
-    memcpy(trans, T.e, 64);
-    *frameIdx = f->frameIdx;
-    f->integratedTransform = T;
-    tm->toIntegrate.pop_front();
-    *found = 1;
+    while (!tm->toIntegrate.empty()) {
+        auto* f = tm->toIntegrate.front();
+        BF_REQUIRE(f->type == BF_TF_NOT_INTEGRATED_WITH_TRANSFORM, "integrate list holds an invalidated frame");
+        const m44 T = tm->opt(*f);
+        tm->toIntegrate.pop_front();
+        // the optimisation result that arrived after the list was made took the pose away again: not integrated, Invalid until a
+        // pose comes back.  (The reference hands the -inf pose to its consumer, which asserts: DepthSensing.cpp:881.  Integrating it
+        // would also leave a NaN in the ranking distance of an Integrated frame, i.e. an unspecified sort order.)
+        if (T.e[0] == NINF) { f->type = BF_TF_INVALID; continue; }
+        memcpy(trans, T.e, 64);
+        *frameIdx = f->frameIdx;
+        f->integratedTransform = T;
+        *found = 1;
+        break;
+    }
     return BF_OK;
 }
 

@@ -6,8 +6,10 @@ kernels of oracle/*.cpp (the checker, never the product):
   filterFrames (SIFTImageManager.cpp:367-476, :551-575), TrajectoryManager (TrajectoryManager.cpp), and the serial frame
   loop with integrate / deIntegrate / reintegrate (DepthSensing.cpp:723-762, :854-902, :966-1095).
 
-The stage kernels it calls are pinned to the reference's device code where oracle/or_common.h says so; this orchestration itself is
-PARITY UNPINNED (the reference's host classes need mLib / DirectX headers).  Plain Python loops: orchestration is a few hundred scalar decisions per frame.
+The stage kernels it calls are pinned to the reference's device code where oracle/or_common.h says so.  Of the orchestration,
+OTrajectoryManager is pinned to the reference's TrajectoryManager.cpp compiled as it is (tests/test_ref_pin_cpu.py), fuse_tracks / filter_frames
+to SIFTImageManager.cpp; the Bundler / OnlineBundler / SBA / frame-loop control flow is PARITY UNPINNED (those classes need mLib, DirectX
+and the sensor headers).  Plain Python loops: orchestration is a few hundred scalar decisions per frame.
 """
 from collections import deque
 
@@ -316,23 +318,69 @@ class OTrajectoryManager:
     def num_active(self):
         return len(self.to_de) + len(self.to_in) + len(self.to_re)
 
+    # ---- the list consumers (getTopFrom*List + confirmIntegration, TrajectoryManager.cpp:113-175), with the return convention of the
+    #      C ABI: (found, frame, T[, newT]).  Two situations the reference does not survive are defined here as in host.hip: a frame that
+    #      loses its pose while it waits in the integrate list is dropped from it (the reference's consumer asserts on the -inf pose,
+    #      DepthSensing.cpp:881), one that loses it while waiting for re-integration stays integrated at its old pose and is de-integrated
+    #      by the next list update (the reference leaves it typed ReIntegration for good).
+    def top_de(self):
+        if not self.to_de:
+            return False, 0, None
+        f = self.to_de.popleft()
+        return True, f["idx"], f["integrated"].copy()
+
+    def top_in(self):
+        while self.to_in:
+            f = self.to_in.popleft()
+            assert f["type"] == 2
+            T = self.opt[f["idx"]].copy()
+            if T[0, 0] == NINF:
+                f["type"] = 3
+                continue
+            f["integrated"] = T
+            return True, f["idx"], T.copy()
+        return False, 0, None
+
+    def top_re(self):
+        if not self.to_re:
+            return False, 0, None, None
+        f = old = new = None
+        while self.to_re:
+            f = self.to_re.popleft()
+            new = self.opt[f["idx"]].copy(); old = f["integrated"].copy()
+            if new[0, 0] != NINF:
+                f["integrated"] = new
+                break
+            f["type"] = 0
+        return True, f["idx"], old, new
+
+    def confirm(self, idx):
+        self.frames[idx]["type"] = 0
+
+    def _invalidate(self, f):
+        if f["type"] == 3:
+            return
+        before = f["type"]; f["type"] = 3
+        if before == 0:
+            self.to_de.append(f)
+        elif before == 2:
+            self.to_in = deque(g for g in self.to_in if g is not f)
+
     def generate_update_lists(self):
         n = min(self.num_optimized, self.num_added)
         for i in range(n):
             f = self.frames[i]
             T = self.opt[i]
             if T[0, 0] == NINF:
-                if f["type"] != 3:
-                    before = f["type"]; f["type"] = 3
-                    if before == 0:
-                        self.to_de.append(f)
+                self._invalidate(f)
             else:
                 if f["type"] in (1, 3):
                     f["type"] = 2
                     self.to_in.append(f)
                 ro, to = o.matrices_to_poses(T[None]); ri, ti = o.matrices_to_poses(f["integrated"][None])
                 s = np.float32(2.0)
-                d = np.concatenate([ri[0] * s - ro[0] * s, ti[0] - to[0]]).astype(np.float32)
+                # (translation part, rotation vector) with the translation part doubled: PoseHelper.h:358-361, TrajectoryManager.cpp:70-77
+                d = np.concatenate([ti[0] * s - to[0] * s, ri[0] - ro[0]]).astype(np.float32)
                 acc = np.float32(0)
                 for x in d:
                     acc = np.float32(acc + np.float32(x * x))
@@ -624,30 +672,21 @@ class OraclePipeline:
         if tm.num_active() < mx:
             tm.generate_update_lists()
         for _ in range(mx):
-            if tm.to_de:
-                f = tm.to_de.popleft()
-                self._integrate(f["idx"], f["integrated"], True)
+            found, idx, T = tm.top_de()
+            if found:
+                self._integrate(idx, T, True)
                 continue
-            if tm.to_in:
-                f = tm.to_in.popleft()
-                assert f["type"] == 2
-                T = tm.opt[f["idx"]].copy(); f["integrated"] = T
-                self._integrate(f["idx"], T, False); f["type"] = 0
+            found, idx, T = tm.top_in()
+            if found:
+                self._integrate(idx, T, False); tm.confirm(idx)
                 continue
-            if tm.to_re:
-                old = new = None; f = None
-                while tm.to_re:
-                    f = tm.to_re.popleft()
-                    new = tm.opt[f["idx"]].copy(); old = f["integrated"].copy()
-                    if new[0, 0] != NINF:
-                        f["integrated"] = new
-                        break
-                    f["type"] = 0      # invalidated while queued: still integrated at its old pose -> de-integrated by the next list update (see host.hip, deviation)
+            found, idx, old, new = tm.top_re()
+            if found:
                 if new[0, 0] == NINF:
                     continue
-                self._integrate(f["idx"], old, True)
-                self._integrate(f["idx"], new, False)
-                f["type"] = 0
+                self._integrate(idx, old, True)
+                self._integrate(idx, new, False)
+                tm.confirm(idx)
                 continue
             break
         if self.gas.s_garbageCollectionEnabled:

@@ -477,3 +477,67 @@ def siftmgr_filter_frames(num_filt, valid, cur, start, num):
     L.ref_siftmgr_filter_frames.restype = C.c_uint32
     last = L.ref_siftmgr_filter_frames(h, cur, start, num, _fp(v), C.byref(out))
     return (-1 if last == 0xFFFFFFFF else int(last)), out.value
+
+
+class RefTrajectoryManager:
+    """The reference's TrajectoryManager (TrajectoryManager.cpp compiled as it is, with PoseHelper.h's se(3) logarithm)."""
+
+    def __init__(self, n_max, top_n, min_dist):
+        L = lib()
+        L.ref_tm_create.restype = C.c_void_p
+        L.ref_tm_num_active.restype = C.c_uint32
+        self._h = C.c_void_p(L.ref_tm_create(C.c_uint32(n_max), C.c_uint32(top_n), C.c_float(min_dist)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ref_tm_destroy(self._h)
+
+    def add(self, typ, T, idx):
+        lib().ref_tm_add_frame(self._h, C.c_int(typ), _fp(_f32(T)), C.c_uint32(idx))
+
+    def update(self, traj):
+        a = _f32(traj)
+        lib().ref_tm_update_optimized_transform(self._h, _fp(a), C.c_uint32(len(a)))
+
+    def generate(self):
+        lib().ref_tm_generate_update_lists(self._h)
+
+    def confirm(self, idx):
+        lib().ref_tm_confirm_integration(self._h, C.c_uint32(idx))
+
+    def active(self):
+        return int(lib().ref_tm_num_active(self._h))
+
+    def _top(self, fn, two):
+        a, b = np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32)
+        idx = C.c_uint32()
+        found = fn(self._h, _fp(a), _fp(b), C.byref(idx)) if two else fn(self._h, _fp(a), C.byref(idx))
+        return bool(found), idx.value, a, b
+
+    def top_de(self):
+        return self._top(lib().ref_tm_top_deintegrate, False)
+
+    def top_in(self):
+        return self._top(lib().ref_tm_top_integrate, False)
+
+    def top_re(self):
+        return self._top(lib().ref_tm_top_reintegrate, True)
+
+    def frame(self, idx):
+        t, d = C.c_int(), C.c_float()
+        a, b = np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32)
+        lib().ref_tm_frame(self._h, C.c_uint32(idx), C.byref(t), _fp(a), _fp(b), C.byref(d))
+        return t.value, a, d.value
+
+
+def host_matrix_to_pose(T):
+    """PoseHelper::MatrixToPose (PoseHelper.h:332-363, USE_LIE_SPACE): 6 floats, the translation part first, then the rotation vector."""
+    p = np.zeros(6, np.float32)
+    lib().ref_pose_matrix_to_pose(_fp(_f32(T)), _fp(p))
+    return p
+
+
+def host_pose_to_matrix(p):
+    T = np.zeros((4, 4), np.float32)
+    lib().ref_pose_pose_to_matrix(_fp(_f32(p)), _fp(T))
+    return T

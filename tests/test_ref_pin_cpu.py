@@ -789,3 +789,101 @@ def test_check_for_invalid_frames_launch_arithmetic_vs_reference():
         hit = (exp_e["imgIdx_i"] == i) & (exp_e["imgIdx_j"] == j)
         exp_e["imgIdx_i"][hit] = INV; exp_e["imgIdx_j"][hit] = INV
         assert np.array_equal(got["imgIdx_i"], exp_e["imgIdx_i"]) and np.array_equal(got["imgIdx_j"], exp_e["imgIdx_j"])
+
+
+def test_trajectory_manager_vs_reference_host_code():
+    """a12: the reference's TrajectoryManager.cpp (compiled as it is, with PoseHelper.h's se(3) logarithm) against the product's
+    bf_trajectory_manager_* and the restatement the oracle frame loop uses, driven by one random script of frame-loop events
+    (DepthSensing.cpp:854-902 consumer order).  Types, integrated poses, the ranking distance (bit-exact) and every list pop agree.
+    One situation is kept out of the script: a frame that loses its pose WHILE it waits in the integration or re-integration list.  The
+    reference's consumer asserts on the -inf pose it then pops (DepthSensing.cpp:881,890), and a frame integrated at -inf leaves a NaN
+    in the ranking that makes std::sort's order unspecified; the product deviates there on purpose
+    (tests/test_trajectory_manager_cpu.py, DESIGN.md "Deviations")."""
+    from collections import deque
+    from tests.oracle_pipeline import OTrajectoryManager, NINF, _minf
+    from tests.test_trajectory_manager_cpu import _CTM, _pose, _same
+    from bundlefusion_amd.capi import lib
+    import ctypes as C
+    lib.bf_trajectory_manager_update_optimized_transform_host.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+
+    class OTM:                                # the restatement behind the interface of the other two
+        def __init__(self, *a): self.o = OTrajectoryManager(*a)
+        def add(self, typ, T, idx): self.o.add_frame(typ, T, idx)
+        def update(self, traj): self.o.update_optimized(traj, len(traj))
+        def generate(self): self.o.generate_update_lists()
+        def active(self): return self.o.num_active()
+        def confirm(self, idx): self.o.confirm(idx)
+        def top_de(self): return self.o.top_de() + (None,)
+        def top_in(self): return self.o.top_in() + (None,)
+        def top_re(self): return self.o.top_re()
+        def frame(self, i):
+            g = self.o.frames[i]; return g["type"], g["integrated"], g["dist"]
+
+    total_ops = {"de": 0, "in": 0, "re": 0}
+    for seed, top_n, min_dist, max_fixes in ((0, 30, 0.0, 10), (1, 5, 0.0004, 3), (2, 8, 0.0, 1), (3, 30, 0.001, 10)):
+        rng = np.random.default_rng(100 + seed)
+        n_max = 150
+        impls = [ref_api.RefTrajectoryManager(n_max, top_n, min_dist), _CTM(n_max, top_n, min_dist), OTM(n_max, top_n, min_dist)]
+        ref = impls[0]
+        gt = [_pose(rng, 0.5) for _ in range(n_max)]
+        for frame in range(n_max):
+            for m in impls:
+                if m.active() < max_fixes:
+                    m.generate()
+            assert len({m.active() for m in impls}) == 1
+            for _ in range(max_fixes):
+                got = [m.top_de() for m in impls]
+                if got[0][0]:
+                    assert all(g[0] and g[1] == got[0][1] and _same(g[2], got[0][2]) for g in got)
+                    total_ops["de"] += 1; continue
+                assert not any(g[0] for g in got)
+                got = [m.top_in() for m in impls]
+                if got[0][0]:
+                    assert all(g[0] and g[1] == got[0][1] and _same(g[2], got[0][2]) for g in got)
+                    for m in impls: m.confirm(got[0][1])
+                    total_ops["in"] += 1; continue
+                assert not any(g[0] for g in got)
+                got = [m.top_re() for m in impls]
+                if got[0][0]:
+                    assert all(g[0] and g[1] == got[0][1] and _same(g[2], got[0][2]) and _same(g[3], got[0][3]) for g in got), (seed, frame)
+                    for m in impls: m.confirm(got[0][1])
+                    total_ops["re"] += 1; continue
+                assert not any(g[0] for g in got)
+                break
+            if rng.random() < 0.85:
+                T = (gt[frame].astype(np.float64) @ _pose(rng, 0.01).astype(np.float64)).astype(np.float32)
+                for m in impls: m.add(0, T, frame)
+            else:
+                for m in impls: m.add(1, _minf(), frame)
+            if frame % 10 == 9:
+                n = frame + 1 - int(rng.integers(0, 3))
+                traj = np.stack([(gt[i].astype(np.float64) @ _pose(rng, 0.002 + 0.02 * rng.random()).astype(np.float64)).astype(np.float32) for i in range(n)])
+                bad = rng.random(n) < 0.08
+                for i in range(n):
+                    if ref.frame(i)[0] in (2, 4):
+                        bad[i] = False                        # queued for (re-)integration: see the docstring
+                traj[bad] = -np.inf
+                for m in impls: m.update(traj)
+            for i in range(frame + 1):
+                st = [m.frame(i) for m in impls]
+                assert len({s[0] for s in st}) == 1, (seed, frame, i, [s[0] for s in st])
+                assert all(_same(s[1], st[0][1]) for s in st)
+                if st[0][0] != 1 and ref.frame(i)[2] == ref.frame(i)[2]:
+                    d = [np.float32(s[2]).view(np.uint32) for s in st]
+                    assert d[0] == d[1] == d[2], (seed, frame, i, [s[2] for s in st])
+        impls[1].close()
+    assert min(total_ops.values()) > 10, total_ops
+
+
+def test_host_pose_helper_equals_device_lie_maps():
+    """PoseHelper::MatrixToPose / PoseToMatrix (host, PoseHelper.h:332-426) order a pose as (translation part, rotation vector) and
+    agree with the device-side LieDerivUtil.h maps the solver uses - which is what lets one restatement (or_se3.h / bf_se3.h) serve both."""
+    rng = np.random.default_rng(5)
+    from tests.test_trajectory_manager_cpu import _pose
+    for _ in range(200):
+        T = _pose(rng, float(rng.choice([1e-4, 0.05, 1.0, 3.0])))
+        p = ref_api.host_matrix_to_pose(T)
+        rot, trans = ref_api.matrix_to_pose(T)
+        assert np.allclose(p[:3], trans, rtol=2e-6, atol=2e-6) and np.allclose(p[3:], rot, rtol=0, atol=2e-6)
+        assert np.allclose(ref_api.host_pose_to_matrix(p), ref_api.pose_to_matrix(rot, trans), rtol=2e-6, atol=2e-6)
+        assert np.allclose(ref_api.host_pose_to_matrix(p), T, rtol=1e-5, atol=1e-5)

@@ -1,6 +1,8 @@
 """CPU test of the TrajectoryManager host logic (TrajectoryManager.cpp:24-200) through the C ABI,
 against the Python restatement the oracle frame loop uses (tests/oracle_pipeline.py::OTrajectoryManager +
-OraclePipeline._reintegrate's list consumers).  Both are driven by the same random script of frame-loop events."""
+its list consumers).  Both are driven by the same random script of frame-loop events, which includes the two situations the reference
+does not survive (a frame losing its pose while it waits in the integrate / re-integrate list); against the reference's own
+TrajectoryManager.cpp, without those: tests/test_ref_pin_cpu.py::test_trajectory_manager_vs_reference_host_code."""
 import ctypes as C
 
 import numpy as np
@@ -91,34 +93,27 @@ def test_trajectory_manager_matches_restatement():
             assert c.active() == o.num_active()
             for _ in range(max_fixes):
                 f, idx, T, _ = c.top_de()
+                g = o.top_de()
+                assert f == g[0]
                 if f:
-                    g = o.to_de.popleft()
-                    assert idx == g["idx"] and _same(T, g["integrated"])
+                    assert idx == g[1] and _same(T, g[2])
                     ops.append(("de", idx)); continue
                 f, idx, T, _ = c.top_in()
+                g = o.top_in()
+                assert f == g[0]
                 if f:
-                    g = o.to_in.popleft()
-                    assert g["type"] == 2 and idx == g["idx"] and _same(T, o.opt[g["idx"]])
-                    g["integrated"] = o.opt[g["idx"]].copy(); g["type"] = 0
-                    c.confirm(idx)
+                    assert idx == g[1] and _same(T, g[2])
+                    c.confirm(idx); o.confirm(idx)
                     ops.append(("in", idx)); continue
                 f, idx, oldT, newT = c.top_re()
+                g = o.top_re()
+                assert f == g[0]
                 if f:
-                    old = new = g = None
-                    while o.to_re:
-                        g = o.to_re.popleft()
-                        new = o.opt[g["idx"]].copy(); old = g["integrated"].copy()
-                        if new[0, 0] != NINF:
-                            g["integrated"] = new
-                            break
-                        g["type"] = 0      # invalidated while queued: re-typed Integrated, de-integrated by the next list update
-                    assert g is not None and idx == g["idx"] and _same(oldT, old) and _same(newT, new)
+                    assert idx == g[1] and _same(oldT, g[2]) and _same(newT, g[3])
                     if newT[0, 0] == NINF:
                         continue
-                    g["type"] = 0
-                    c.confirm(idx)
+                    c.confirm(idx); o.confirm(idx)
                     ops.append(("re", idx)); continue
-                assert not (o.to_de or o.to_in or o.to_re)
                 break
             # ---- the new frame: tracked (integrated at a slightly wrong pose) or not
             if rng.random() < 0.85:
@@ -199,3 +194,36 @@ def test_frame_invalidated_while_queued_for_reintegration_is_deintegrated_once()
         c.confirm(i4); ins.append(i4); assert _same(T, T1[i4])
     assert sorted(ins) == sorted(victims)
     c.close()
+
+
+def test_frame_losing_its_pose_while_queued_for_integration_is_not_integrated():
+    """A never-integrated frame gets a pose (-> integrate list) and loses it again before the list is consumed.  Whether the loss is seen
+    by the next list update or only at the pop, nothing is integrated, the list is left clean and the frame is integrated exactly once
+    when a pose comes back.  (The reference keeps the frame in m_toIntegrateList and stops at an assert when it is popped,
+    TrajectoryManager.cpp:142-146 / DepthSensing.cpp:881.)"""
+    lib.bf_trajectory_manager_update_optimized_transform_host.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+    rng = np.random.default_rng(11)
+    for seen_by_update in (True, False):
+        c, o = _CTM(8, 30, 0.0), OTrajectoryManager(8, 30, 0.0)
+        T = np.stack([_pose(rng, 0.5) for _ in range(3)])
+        for m_add in (lambda *a: c.add(*a), lambda *a: o.add_frame(*a)):
+            m_add(0, T[0], 0); m_add(1, _minf(), 1); m_add(1, _minf(), 2)
+        c.update(T); o.update_optimized(T, 3); c.generate(); o.generate_update_lists()
+        assert c.active() == o.num_active() == 2 and c.frame(1)[0] == c.frame(2)[0] == 2
+        T2 = T.copy(); T2[1] = -np.inf
+        c.update(T2); o.update_optimized(T2, 3)
+        if seen_by_update:
+            c.generate(); o.generate_update_lists()
+            assert c.active() == o.num_active() == 1
+        f, idx, Tin, _ = c.top_in(); g = o.top_in()
+        assert f and g[0] and idx == g[1] == 2 and _same(Tin, T[2]) and _same(g[2], T[2])       # frame 1 was skipped
+        c.confirm(2); o.confirm(2)
+        assert not c.top_in()[0] and not o.top_in()[0] and c.active() == o.num_active() == 0
+        assert c.frame(1)[0] == o.frames[1]["type"] == 3
+        c.update(T); o.update_optimized(T, 3); c.generate(); o.generate_update_lists()
+        f, idx, Tin, _ = c.top_in(); g = o.top_in()
+        assert f and g[0] and idx == g[1] == 1 and _same(Tin, T[1])
+        c.confirm(1); o.confirm(1)
+        c.generate(); o.generate_update_lists()
+        assert c.active() == o.num_active() == 0 and all(c.frame(i)[0] == 0 and np.isfinite(c.frame(i)[2]) for i in range(3))
+        c.close()
