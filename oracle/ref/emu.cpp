@@ -15,7 +15,7 @@ thread_local dim3 blockDim, gridDim;
 namespace {
 enum State { READY, AT_BARRIER, AT_SHFL, DONE };
 struct Fiber {
-    ucontext_t ctx; std::vector<char> stack; State state = READY; uint3 tid;
+    ucontext_t ctx; char* stack = nullptr; State state = READY; uint3 tid;
     unsigned shflCount = 0;        // shuffles this fiber has deposited
 };
 struct Block {
@@ -27,6 +27,13 @@ struct Block {
 };
 thread_local Block* g_block = nullptr;
 const size_t STACK = 256 * 1024;
+// fiber stacks are recycled across launches (a 512-thread block needs 128 MB of them; allocating and clearing that per launch was most
+// of the run time of the solver pins); a nested launch takes other stacks from the same pool
+thread_local std::vector<char*> g_freeStacks;
+char* takeStack() {
+    if (g_freeStacks.empty()) return (char*)malloc(STACK);
+    char* p = g_freeStacks.back(); g_freeStacks.pop_back(); return p;
+}
 const unsigned WARP = 32;
 
 void trampoline() {
@@ -103,7 +110,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     b.body = &body;
     b.fibers.resize(T);
     b.xchg.assign(((T + WARP - 1) / WARP) * 2 * WARP, 0u);
-    for (auto& f : b.fibers) f.stack.resize(STACK);
+    for (auto& f : b.fibers) f.stack = takeStack();
+    struct Release { Block& b; ~Release() { for (auto& f : b.fibers) g_freeStacks.push_back(f.stack); } } release{b};
     const dim3 gridSave = gridDim, blockSave = blockDim;
     gridDim = grid; blockDim = block;
     Block* outer = g_block;
@@ -119,7 +127,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                             Fiber& f = b.fibers[t];
                             f.state = READY; f.shflCount = 0; f.tid = make_uint3(tx, ty, tz);
                             getcontext(&f.ctx);
-                            f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = nullptr;
+                            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
                             makecontext(&f.ctx, trampoline, 0);
                         }
                 for (;;) {                  // run every runnable fiber up to its next barrier / shuffle (or to its end), in thread-index order

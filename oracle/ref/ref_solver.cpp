@@ -6,7 +6,8 @@
 // SolverBundlingUtil.h, LieDerivUtil.h, ICPUtil.h, compiled from where they lie and run through the serial block emulator (warp
 // reductions are lock-step fibers; float atomics add in thread-index order).  This file allocates and fills SolverInput /
 // SolverState / SolverParameters the way CUDASolverBundling does (CUDASolverBundling.cpp:20-110 constructor, :187-284 solve,
-// :286-292 buildVariablesToCorrespondencesTable, :454-476 useVerification) — that host class needs mLib and cannot be compiled.
+// :286-292 buildVariablesToCorrespondencesTable, :454-476 useVerification).  The host class itself is compiled too since (ref_sba.cpp, over an mLib stand-in): on the same problems it
+// produces bit-identical poses and energies to this driver (tests/test_ref_pin_cpu.py).
 #include "SolverBundling.cu.cpp"      // = cu2cpp.py < reference file (generated into the build's temporary directory)
 
 #include <limits>

@@ -12,6 +12,9 @@
 #include <cassert>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <functional>
+#include <unordered_map>
 #include <algorithm>
 #include <fstream>
 #include <iostream>
@@ -45,6 +48,7 @@ template <class T> struct point2d {
 typedef point2d<unsigned int> vec2ui;
 typedef point2d<int> vec2i;
 typedef point2d<float> vec2f;
+template <class T> inline std::ostream& operator<<(std::ostream& s, const point2d<T>& v) { return s << v.x << " " << v.y; }
 
 struct vec3f {
     union { struct { float x, y, z; }; float array[3]; };
@@ -117,6 +121,7 @@ struct mat3f {
 struct mat4f {
     float matrix[16];
     mat4f() { for (float& v : matrix) v = 0.0f; }
+    explicit mat4f(const float* p) { memcpy(matrix, p, sizeof matrix); }
     float& operator()(unsigned int r, unsigned int c) { return matrix[r * 4 + c]; }
     const float& operator()(unsigned int r, unsigned int c) const { return matrix[r * 4 + c]; }
     float& operator[](unsigned int i) { return matrix[i]; }
@@ -167,6 +172,32 @@ struct mat4f {
         for (int i = 0; i < 16; ++i) r.matrix[i] = inv[i] * id;
         return r;
     }
+};
+
+// host utilities the bundling classes name: a wall-clock timer, directory helpers, the binary stream of debug dumps (inline methods
+// that no pinned test calls: declared so that the headers compile), the parameter-file reader of the application singletons
+struct Timer {
+    double t0 = 0.0, t1 = 0.0;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    void start() { t0 = now(); }
+    void stop() { t1 = now(); }
+    double getElapsedTime() const { return t1 - t0; }
+    double getElapsedTimeMS() const { return 1e3 * (t1 - t0); }
+};
+namespace util {
+inline bool directoryExists(const std::string&) { return true; }
+inline void makeDirectory(const std::string&) {}
+}  // namespace util
+struct BinaryDataStreamFile {
+    BinaryDataStreamFile(const std::string&, bool) { throw std::runtime_error("mlib_standin: BinaryDataStreamFile is not provided"); }
+    template <class T> BinaryDataStreamFile& operator<<(const T&) { return *this; }
+    template <class T> BinaryDataStreamFile& operator>>(T&) { return *this; }
+    void writeData(const BYTE*, size_t) {}
+    void readData(BYTE*, size_t) {}
+    void close() {}
+};
+struct ParameterFile {
+    template <class T> bool readParameter(const std::string&, T&) const { return false; }
 };
 
 // the two mLib classes PoseHelper.h names in helpers that no pinned test calls (ATE evaluation, pose files): declared so that the

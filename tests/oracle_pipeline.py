@@ -247,6 +247,7 @@ class OBundler:
         for i in range(N):
             if valid[i]:
                 self.trajectory[i] = T[i]
+        self.last_align = dict(removed=removed, use_verification=verify, max_residual=res["max_residual"], convergence=res["convergence"], gn_iterations=res["gn_iterations"])
         ok = True
         if verify:
             ok = self._verify_trajectory(N)

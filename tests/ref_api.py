@@ -541,3 +541,70 @@ def host_pose_to_matrix(p):
     T = np.zeros((4, 4), np.float32)
     lib().ref_pose_pose_to_matrix(_fp(_f32(p)), _fp(T))
     return T
+
+
+class _RefBundlingParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("numLocalNonLinIterations", "numGlobalNonLinIterations", "submapSize", "denseOverlapCheckSubsampleFactor")] + \
+               [(n, C.c_float) for n in ("optMaxResThresh", "denseDistThresh", "denseNormalThresh", "denseColorThresh", "denseColorGradientMin", "denseDepthMin",
+                                         "denseDepthMax")] + \
+               [(n, C.c_int) for n in ("useComprehensiveFrameInvalidation", "useLocalDense", "recordSolverConvergence")]
+
+
+class RefSBA:
+    """The reference's SBA + CUDASolverBundling host classes (SBA.cpp / CUDASolverBundling.cpp compiled as they are) over a RefSiftManager
+    that holds the images, the global correspondences and, for the dense terms, the cached frames."""
+
+    def __init__(self, max_images, max_residuals, gbs):
+        L = lib()
+        L.ref_sba_create.restype = C.c_void_p
+        p = _RefBundlingParams(gbs.s_numLocalNonLinIterations, gbs.s_numGlobalNonLinIterations, gbs.s_submapSize, gbs.s_denseOverlapCheckSubsampleFactor,
+                               gbs.s_optMaxResThresh, gbs.s_denseDistThresh, gbs.s_denseNormalThresh, gbs.s_denseColorThresh, gbs.s_denseColorGradientMin,
+                               gbs.s_denseDepthMin, gbs.s_denseDepthMax, int(gbs.s_useComprehensiveFrameInvalidation), int(gbs.s_useLocalDense), 1)
+        self._h = C.c_void_p(L.ref_sba_create(max_images, max_residuals, C.byref(p)))
+        self.n_its = max(gbs.s_numLocalNonLinIterations, gbs.s_numGlobalNonLinIterations)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().ref_sba_destroy(self._h)
+
+    def weights(self, which):
+        ws, wd, wc = (np.zeros(self.n_its, np.float32) for _ in range(3))
+        n = lib().ref_sba_get_weights(self._h, int(which), _fp(ws), _fp(wd), _fp(wc))
+        return ws[:n], wd[:n], wc[:n]
+
+    def set_global_weights(self, ws, wd, wc, use_global_dense):
+        a, b, c = _f32(ws), _f32(wd), _f32(wc)
+        lib().ref_sba_set_global_weights(self._h, _fp(a), _fp(b), _fp(c), len(a), int(use_global_dense))
+
+    def align(self, mgr, valid, current_frame, transforms, max_iters, pcg_its, use_verify, is_local, is_start=True, is_end=True, revalidate_idx=0xFFFFFFFF,
+              cache_geom=None):
+        """-> dict(removed, valid, transforms, max_residual, use_verification, convergence); cache_geom = (W, H, K 4x4 of the cached frames) or None"""
+        v = np.ascontiguousarray(valid, np.int32).copy()
+        T = _f32(transforms).reshape(-1, 16).copy()
+        mr, uv = C.c_float(), C.c_int()
+        conv = np.full(max_iters + 1, -1.0, np.float32)
+        W, H, K = cache_geom if cache_geom else (0, 0, np.eye(4))
+        Kf = _f32(K).reshape(16)
+        removed = lib().ref_sba_align(self._h, mgr._h, _fp(v), C.c_uint32(current_frame), C.c_uint32(W), C.c_uint32(H), _fp(Kf), _fp(T), C.c_uint32(max_iters),
+                                      C.c_uint32(pcg_its), int(use_verify), int(is_local), int(is_start), int(is_end), C.c_uint32(revalidate_idx),
+                                      C.byref(mr), C.byref(uv), _fp(conv))
+        return dict(removed=bool(removed), valid=v, transforms=T.reshape(-1, 4, 4), max_residual=mr.value, use_verification=bool(uv.value), convergence=conv)
+
+
+def siftmgr_with_images(n_images, corr, max_keys=64):
+    """A RefSiftManager holding n_images (one dummy key each) and the global correspondences `corr` (EntryJ rows)."""
+    m = RefSiftManager(n_images + 1, max_keys)
+    L = lib()
+    for _ in range(n_images):
+        L.ref_siftmgr_add_image(m._h, _fp(np.zeros((1, 4), np.float32)), _fp(np.zeros((1, 128), np.uint8)), 1)
+    e = np.ascontiguousarray(corr)
+    L.ref_siftmgr_set_residuals(m._h, _fp(e), _fp(np.zeros((max(len(e), 1), 2), np.uint32)), len(e))
+    return m
+
+
+def siftmgr_residuals(mgr, n):
+    from bundlefusion_amd.capi import ENTRYJ_DTYPE
+    e = np.zeros(n, ENTRYJ_DTYPE); k = np.zeros((max(n, 1), 2), np.uint32)
+    if n:
+        lib().ref_siftmgr_get_residuals(mgr._h, _fp(e), _fp(k), n)
+    return e
