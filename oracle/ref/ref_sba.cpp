@@ -4,10 +4,9 @@
 // align :54-118, alignCUDA :120-139, removeMaxResidualCUDA :167-203) and Solver/CUDASolverBundling.cpp (constructor :24-136, solve
 // :186-283, buildVariablesToCorrespondencesTable, computeMaxResidual :312-419, getMaxResidual :421-446, useVerification :448-476) on top
 // of the kernels of Solver/SolverBundling.cu and SBA.cu and of the real SIFTImageManager (InvalidateImageToImageCU,
-// CheckForInvalidFrames[Simple]CU).  Stand-ins (shim/): mLib's element arithmetic, Timer and ParameterFile; a CUDACache that only
-// holds the frames the solver reads; empty SiftVisualization.h / cuda_d3d11_interop.h.  The Makefile compiles temporary copies of
-// SBA.h / SBA.cpp / CUDASolverBundling.cpp / GlobalBundlingState.h so that their quoted includes resolve to those stand-ins instead of
-// the application's precompiled header; "../" prefixes of includes are dropped in the copies.  Nothing else changes.
+// CheckForInvalidFrames[Simple]CU) and the real CUDACache.  Stand-ins (shim/): mLib's element arithmetic, Timer and ParameterFile; empty
+// SiftVisualization.h / cuda_d3d11_interop.h.  The Makefile compiles verbatim temporary copies of the application files so that their
+// quoted includes resolve to those stand-ins instead of the application's precompiled header (see its header comment).
 #define private public
 #define protected public
 #include "SBA.h"
@@ -65,8 +64,9 @@ int ref_sba_align(void* s, ref_siftmgr* h, int* valid, unsigned int currentFrame
     m->setCurrentFrame(currentFrame);
     CUDACache* cache = nullptr;
     if (cacheW) {
-        cache = new CUDACache(cacheW, cacheH, mat4f(cacheIntrinsics16));
-        cache->frames().assign(h->frames, h->frames + n);
+        cache = new CUDACache(cacheW, cacheH, cacheW, cacheH, n, mat4f(cacheIntrinsics16));      // input size = cached size: intrinsics unchanged
+        cache->setCachedFrames(std::vector<CUDACachedFrame>(h->frames, h->frames + n));             // copies the frame data into its own buffers
+        cache->setCurrentFrame(n);
     }
     const bool removed = a->align(m, cache, (float4x4*)transforms16, maxNumIters, numPCGits, useVerify != 0, isLocal != 0, false, isStart != 0, isEnd != 0, false, revalidateIdx);
     for (unsigned int i = 0; i < n; ++i) valid[i] = m->d_validImages[i];

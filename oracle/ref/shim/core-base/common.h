@@ -18,6 +18,9 @@ typedef unsigned char BYTE;
 #include <vector>
 struct DepthImage32 {
     std::vector<float> d; unsigned int w = 0, h = 0;
+    DepthImage32() {}
+    DepthImage32(unsigned int width, unsigned int height) { allocate(width, height); }
+    const float* getData() const { return d.data(); }
     void allocate(unsigned int width, unsigned int height) { w = width; h = height; d.assign((size_t)w * h, 0.0f); }
     float* getData() { return d.data(); }
     size_t getNumPixels() const { return d.size(); }

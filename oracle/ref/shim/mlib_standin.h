@@ -48,6 +48,7 @@ template <class T> struct point2d {
 typedef point2d<unsigned int> vec2ui;
 typedef point2d<int> vec2i;
 typedef point2d<float> vec2f;
+typedef unsigned long long UINT64;
 template <class T> inline std::ostream& operator<<(std::ostream& s, const point2d<T>& v) { return s << v.x << " " << v.y; }
 
 struct vec3f {
@@ -75,9 +76,12 @@ struct vec3f {
 };
 inline vec3f operator*(float s, const vec3f& v) { return v * s; }
 
+struct vec3i { int x = 0, y = 0, z = 0; vec3i() {} vec3i(int a, int b, int c) : x(a), y(b), z(c) {} };
+struct vec4i { int x = 0, y = 0, z = 0, w = 0; vec4i() {} vec4i(int a, int b, int c, int d) : x(a), y(b), z(c), w(d) {} };
 struct vec4f {
     union { struct { float x, y, z, w; }; float array[4]; };
     vec4f() : x(0), y(0), z(0), w(0) {}
+    explicit vec4f(float v) : x(v), y(v), z(v), w(v) {}
     vec4f(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
     float& operator[](unsigned int i) { return array[i]; }
     const float& operator[](unsigned int i) const { return array[i]; }
@@ -119,9 +123,13 @@ struct mat3f {
 };
 
 struct mat4f {
-    float matrix[16];
+    union {
+        float matrix[16];
+        struct { float _m00, _m01, _m02, _m03, _m10, _m11, _m12, _m13, _m20, _m21, _m22, _m23, _m30, _m31, _m32, _m33; };
+    };
     mat4f() { for (float& v : matrix) v = 0.0f; }
     explicit mat4f(const float* p) { memcpy(matrix, p, sizeof matrix); }
+    mat4f getTranspose() const { mat4f r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.matrix[i * 4 + j] = matrix[j * 4 + i]; return r; }
     float& operator()(unsigned int r, unsigned int c) { return matrix[r * 4 + c]; }
     const float& operator()(unsigned int r, unsigned int c) const { return matrix[r * 4 + c]; }
     float& operator[](unsigned int i) { return matrix[i]; }
@@ -187,7 +195,31 @@ struct Timer {
 namespace util {
 inline bool directoryExists(const std::string&) { return true; }
 inline void makeDirectory(const std::string&) {}
+inline std::string directoryFromPath(const std::string& p) { const size_t k = p.find_last_of("/\\"); return k == std::string::npos ? std::string() : p.substr(0, k + 1); }
 }  // namespace util
+// images of the debug writers (CUDACache::saveToFile / printCacheImages, ...): shape only, never executed by a pinned test
+template <class T> struct BaseImage {
+    struct Pixel { unsigned int x, y; T value; };
+    std::vector<T> d; unsigned int w = 0, h = 0;
+    BaseImage() {}
+    BaseImage(unsigned int width, unsigned int height) : d((size_t)width * height), w(width), h(height) {}
+    template <class I> explicit BaseImage(const I&) {}
+    T* getData() { return d.data(); }
+    const T* getData() const { return d.data(); }
+    size_t getNumPixels() const { return d.size(); }
+    unsigned int getWidth() const { return w; }
+    unsigned int getHeight() const { return h; }
+    T& operator()(unsigned int x, unsigned int y) { return d[(size_t)y * w + x]; }
+    void setInvalidValue(const T&) {}
+    Pixel* begin() { return nullptr; }
+    Pixel* end() { return nullptr; }
+};
+struct vec4uc { unsigned char x = 0, y = 0, z = 0, w = 0; };
+typedef BaseImage<float> ColorImageR32;
+typedef BaseImage<vec3f> ColorImageR32G32B32;
+typedef BaseImage<vec4f> ColorImageR32G32B32A32;
+typedef BaseImage<vec4uc> ColorImageR8G8B8A8;
+struct FreeImageWrapper { template <class I> static void saveImage(const std::string&, const I&) { throw std::runtime_error("mlib_standin: FreeImageWrapper is not provided"); } };
 struct BinaryDataStreamFile {
     BinaryDataStreamFile(const std::string&, bool) { throw std::runtime_error("mlib_standin: BinaryDataStreamFile is not provided"); }
     template <class T> BinaryDataStreamFile& operator<<(const T&) { return *this; }
@@ -211,6 +243,10 @@ struct EigenWrapperf {
     static mat4f kabsch(const std::vector<vec3f>&, const std::vector<vec3f>&, vec3f&) { throw std::runtime_error("mlib_standin: EigenWrapperf::kabsch is not provided"); }
 };
 
+inline std::ostream& operator<<(std::ostream& s, const vec3f& v) { return s << v.x << " " << v.y << " " << v.z; }
+inline std::ostream& operator<<(std::ostream& s, const vec4f& v) { return s << v.x << " " << v.y << " " << v.z << " " << v.w; }
+inline std::ostream& operator<<(std::ostream& s, const vec3i& v) { return s << v.x << " " << v.y << " " << v.z; }
+inline std::ostream& operator<<(std::ostream& s, const mat4f& m) { for (int i = 0; i < 16; ++i) s << m.matrix[i] << (i % 4 == 3 ? "\n" : " "); return s; }
 }  // namespace ml
 using namespace ml;        // as the reference's mLib.h does
 #endif

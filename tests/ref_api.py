@@ -608,3 +608,149 @@ def siftmgr_residuals(mgr, n):
     if n:
         lib().ref_siftmgr_get_residuals(mgr._h, _fp(e), _fp(k), n)
     return e
+
+
+class _RefBundlingState(C.Structure):
+    _U = ("maxNumImages", "submapSize", "widthSIFT", "heightSIFT", "maxNumKeysPerImage", "numLocalNonLinIterations", "numLocalLinIterations",
+          "numGlobalNonLinIterations", "numGlobalLinIterations", "downsampledWidth", "downsampledHeight", "minNumMatchesLocal", "minNumMatchesGlobal",
+          "denseOverlapCheckSubsampleFactor", "numOptPerResidualRemoval")
+    _F = ("verifySiftErrThresh", "verifySiftCorrThresh", "projCorrDistThres", "projCorrNormalThres", "projCorrColorThresh", "surfAreaPcaThresh", "verifyOptErrThresh",
+          "verifyOptCorrThresh", "maxKabschResidual2", "minKeyScale", "siftMatchThresh", "siftMatchRatioMaxLocal", "siftMatchRatioMaxGlobal", "colorDownSigma",
+          "depthDownSigmaD", "depthDownSigmaR", "optMaxResThresh", "denseDistThresh", "denseNormalThresh", "denseColorThresh", "denseColorGradientMin", "denseDepthMin",
+          "denseDepthMax")
+    _I = ("useComprehensiveFrameInvalidation", "useLocalVerify", "useLocalDense", "erodeSIFTdepth")
+    _fields_ = [(n, C.c_uint32) for n in _U] + [(n, C.c_float) for n in _F] + [("sensorDepthMin", C.c_float), ("sensorDepthMax", C.c_float)] + [(n, C.c_int) for n in _I]
+
+
+class _RefAppState(C.Structure):
+    _fields_ = [("topNActive", C.c_uint32), ("numSolveFramesBeforeExit", C.c_uint32), ("minPoseDistSqrt", C.c_float), ("colorSigmaD", C.c_float),
+                ("colorSigmaR", C.c_float), ("colorFilter", C.c_int)]
+
+
+def set_reference_state(gas, gbs):
+    """GlobalAppState / GlobalBundlingState singletons of the reference build <- the ctypes parameter structs of bundlefusion_amd.capi."""
+    p = _RefBundlingState()
+    for n in _RefBundlingState._U + _RefBundlingState._F:
+        setattr(p, n, getattr(gbs, "s_" + n))
+    for n in _RefBundlingState._I:
+        setattr(p, n, int(getattr(gbs, "s_" + n)))
+    p.sensorDepthMin, p.sensorDepthMax = gas.s_sensorDepthMin, gas.s_sensorDepthMax
+    lib().ref_set_bundling_state(C.byref(p))
+    a = _RefAppState(gas.s_topNActive, gas.s_numSolveFramesBeforeExit, gas.s_minPoseDistSqrt, gas.s_colorSigmaD, gas.s_colorSigmaR, int(gas.s_colorFilter))
+    lib().ref_set_app_state(C.byref(a))
+
+
+class _RefBundlerHandle(C.Structure):
+    _fields_ = [("b", C.c_void_p), ("im", C.c_void_p)]
+
+
+class RefBundlerView:
+    """Accessors on one of the reference OnlineBundler's three Bundlers."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def num_frames(self):
+        return int(lib().ref_bundler_num_frames(C.byref(self._h)))
+
+    def trajectory(self, n):
+        T = np.zeros((n, 4, 4), np.float32)
+        lib().ref_bundler_get_trajectory(C.byref(self._h), _fp(T), n)
+        return T
+
+    def valid(self, n):
+        v = np.zeros(n, np.int32)
+        lib().ref_bundler_get_valid(C.byref(self._h), _fp(v), n)
+        return v
+
+    def num_keys(self, image):
+        return int(lib().ref_bundler_num_keys(C.byref(self._h), image))
+
+    def keys(self, image):
+        n = self.num_keys(image)
+        k = np.zeros((max(n, 1), 4), np.float32); d = np.zeros((max(n, 1), 128), np.uint8)
+        lib().ref_bundler_get_keys(C.byref(self._h), image, _fp(k), _fp(d))
+        return k[:n], d[:n]
+
+    def correspondences(self):
+        from bundlefusion_amd.capi import ENTRYJ_DTYPE
+        n = int(lib().ref_bundler_num_correspondences(C.byref(self._h)))
+        e = np.zeros(max(n, 1), ENTRYJ_DTYPE)
+        if n:
+            lib().ref_bundler_get_correspondences(C.byref(self._h), _fp(e), n)
+        return e[:n]
+
+
+class RefOnlineBundler:
+    """The reference's OnlineBundler (OnlineBundler.cpp compiled as it is, with its Bundler / SBA / CUDASolverBundling / TrajectoryManager /
+    SIFTImageManager / CUDACache / SiftGPU fork).  One frame: set_frame -> process_input -> (frame loop work) -> process."""
+    STATE = ("last_processed", "last_valid", "local_to_solve", "last_local_solved", "past_end", "num_complete", "last_valid_complete", "tracking_lost",
+             "process_state", "use_solve", "total_opt_local")
+
+    def __init__(self, gas, gbs, width, height, K):
+        set_reference_state(gas, gbs)
+        L = lib()
+        L.ref_ob_create.restype = C.c_void_p
+        L.ref_ob_trajectory_manager.restype = C.c_void_p
+        Kf = _f32(K).reshape(16)
+        self.gbs = gbs
+        self._h = C.c_void_p(L.ref_ob_create(width, height, width, height, _fp(Kf), _fp(Kf)))
+        self.tm = RefTrajectoryManager.__new__(RefTrajectoryManager)
+        self.tm._h = None
+        self.tm_handle = C.c_void_p(L.ref_ob_trajectory_manager(self._h))
+
+    def set_frame(self, raw, filt, color):
+        lib().ref_ob_set_frame(self._h, _fp(_f32(raw)), _fp(_f32(filt)), _fp(np.ascontiguousarray(color, np.uint8)))
+
+    def process_input(self):
+        lib().ref_ob_process_input(self._h)
+
+    def process(self):
+        g = self.gbs
+        lib().ref_ob_process(self._h, g.s_numLocalNonLinIterations, g.s_numLocalLinIterations, g.s_numGlobalNonLinIterations, g.s_numGlobalLinIterations)
+
+    def current_integration_frame(self):
+        T = np.zeros((4, 4), np.float32); idx, lost = C.c_uint32(), C.c_int()
+        ok = lib().ref_ob_current_integration_frame(self._h, _fp(T), C.byref(idx), C.byref(lost))
+        return bool(ok), T, idx.value, bool(lost.value)
+
+    def state(self):
+        s = np.zeros(11, np.int32)
+        lib().ref_ob_state(self._h, _fp(s))
+        return dict(zip(self.STATE, (int(v) for v in s)))
+
+    def _traj(self, fn, n):
+        T = np.zeros((n, 4, 4), np.float32)
+        fn(self._h, _fp(T), n)
+        return T
+
+    def complete_trajectory(self, n):
+        return self._traj(lib().ref_ob_complete_trajectory, n)
+
+    def sift_trajectory(self, n):
+        return self._traj(lib().ref_ob_sift_trajectory, n)
+
+    def local_trajectories(self, n):
+        return self._traj(lib().ref_ob_local_trajectories, n)
+
+    def invalid_images_list(self, n):
+        v = np.zeros(n, np.uint32)
+        lib().ref_ob_invalid_images_list(self._h, _fp(v), n)
+        return v
+
+    def bundler(self, which):
+        h = _RefBundlerHandle()
+        lib().ref_ob_bundler(self._h, int(which), C.byref(h))
+        return RefBundlerView(h)
+
+    def trajectory_manager(self):
+        """The OnlineBundler's TrajectoryManager behind the RefTrajectoryManager interface (not owned)."""
+        t = RefTrajectoryManager.__new__(RefTrajectoryManager)
+        t._h = self.tm_handle
+        t.__class__ = _BorrowedTM
+        return t
+
+
+class _BorrowedTM(RefTrajectoryManager):
+    def __del__(self):
+        pass

@@ -15,6 +15,8 @@ Order-dependent quantities (which of a bucket's four slots a key sits in, heap p
 (the CUDA reference itself varies from run to run); they are compared through their order-independent content.
 The tests skip (not fail) only when neither /root/reference nor a prebuilt library is present.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1036,3 +1038,123 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
     b2.optimize(nl, lin, False, False)
     assert np.abs(b2.trajectory[:n] - r2["transforms"]).max() < 1e-4
     assert np.abs(r2["transforms"] - r["transforms"]).max() > 1e-5          # the dense term did something in the first run
+
+
+# ------------------------------------------------------------------------------------------------ the bundling half of the frame loop
+@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=pytest.mark.skipif(
+    os.environ.get("BF_LONG_TESTS") != "1", reason="3 more minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)"))])
+def test_online_bundler_vs_reference_host_code(oracle, scenario):
+    """Rows a3-a12 end to end: the reference's OnlineBundler.cpp / Bundler.cpp / SBA.cpp / CUDASolverBundling.cpp / CUDACache.cpp /
+    TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
+    oracle frame loop (tests/oracle_pipeline.py - the restatement every GPU pipeline test holds the product to) on a 10-frame stream of
+    three local chunks plus the end-of-sequence iterations.  Per frame: the state machine (11 fields of BundlerState) exactly; the pose
+    handed to the integration bit for bit until the first global solve and to 5e-4 after it; complete / local / global trajectories 5e-4 (the dense local solve sums in another order; measured 2.6e-4)
+    with the same -inf pattern; key-frame counts, key counts, correspondence counts, valid flags exactly; and the operations the
+    TrajectoryManager schedules (kind and frame exactly).
+    Scenario "tracking_loss": 16 frames of which 4-8 carry no depth - untracked frames, two local chunks without a tracked frame (the
+    INVALIDATE branches of OnlineBundler.cpp:134-165, :263-266, :351-360, :399-405, Bundler::addInvalidFrame, -inf rows of
+    updateTrajectoryCU), then recovery through the global matching; poses after the gap 1e-2 (both sides re-anchor across the gap from a
+    poor initial guess and stop their three Gauss-Newton steps at slightly different iterates), everything discrete exactly."""
+    from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix
+    from tests.oracle_pipeline import OraclePipeline, NINF, _minf
+    W, H, S = 320, 240, 3
+    NF, dark, TOL = (10, range(0), 5e-4) if scenario == "three_chunks" else (16, range(4, 9), 1e-2)
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
+    gas.s_garbageCollectionEnabled = False
+    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 8, S
+    frames = [synth.scene_room(3 * k, W, H) for k in range(NF)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    frames = [((np.full_like(f[0], -np.inf) if k in dark else f[0]), f[1]) for k, f in enumerate(frames)]
+    op = OraclePipeline(gas, gbs, W, H, K)
+    op._integrate = lambda frame, T, de: op.integrate_ops.append(("de" if de else "in", frame, np.array(T, np.float32)))     # no volume in this test
+    rb = ref_api.RefOnlineBundler(gas, gbs, W, H, K)
+    rtm = rb.trajectory_manager()
+    ref_ops = []
+    STATES = {"NONE": 0, "PROCESS": 1, "INVALIDATE": 2}
+
+    def ref_reintegrate():                       # DepthSensing.cpp:854-902 on the reference's TrajectoryManager
+        if rtm.active() < gas.s_maxFrameFixes:
+            rtm.generate()
+        for _ in range(gas.s_maxFrameFixes):
+            f, idx, T, _ = rtm.top_de()
+            if f:
+                ref_ops.append(("de", idx, T)); continue
+            f, idx, T, _ = rtm.top_in()
+            if f:
+                ref_ops.append(("in", idx, T)); rtm.confirm(idx); continue
+            f, idx, old, new = rtm.top_re()
+            if f:
+                ref_ops.append(("de", idx, old)); ref_ops.append(("in", idx, new)); rtm.confirm(idx); continue
+            break
+
+    def close(a, b, tol=None):
+        tol = TOL if tol is None else tol
+        a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+        inf_a, inf_b = a == NINF, b == NINF
+        return np.array_equal(inf_a, inf_b) and (np.abs(np.where(inf_a, 0, a) - np.where(inf_b, 0, b)).max() <= tol if a.size else True)
+
+    def compare(step):
+        st = rb.state()
+        mine = dict(last_processed=op.last_processed, last_valid=int(op.last_valid), local_to_solve=op.local_to_solve, last_local_solved=op.last_local_solved,
+                    past_end=op.past_end, num_complete=op.num_complete, last_valid_complete=op.last_valid_complete, tracking_lost=int(op.tracking_lost),
+                    process_state=STATES[op.state], use_solve=int(op.use_solve), total_opt_local=op.total_opt_local)
+        assert st == mine, (step, st, mine)
+        n = op.num_complete
+        if n:
+            assert close(rb.complete_trajectory(n), op.complete[:n]), step
+        assert np.array_equal(rb.invalid_images_list(NF + S), np.array(op.invalid_list[:NF + S], np.uint32)), step
+        g = rb.bundler(2)
+        ng = g.num_frames()
+        assert ng == op.glob.num_images, step
+        if ng:
+            assert list(g.valid(ng)) == op.glob.valid[:ng], step
+            assert close(g.trajectory(ng), op.glob.trajectory[:ng]), step
+            assert [g.num_keys(i) for i in range(ng)] == [len(k) for k in op.glob.keys[:ng]], step
+            rc, oc = g.correspondences(), op.glob.corr
+            assert len(rc) == len(oc) and np.array_equal(rc["imgIdx_i"], oc["imgIdx_i"]) and np.array_equal(rc["imgIdx_j"], oc["imgIdx_j"]), step
+        nl = (op.last_local_solved + 1) * (S + 1) if op.last_local_solved >= 0 else 0
+        if nl:
+            assert close(rb.local_trajectories(nl), op.local_traj[:nl]), step
+
+    solved = False
+    n_ops = [0, 0]
+    for i in range(NF + 5):
+        if i < NF:
+            d, c = frames[i][0], frames[i][1]
+            raw, filt = op._ingest(d, c)
+            rb.set_frame(raw, filt, c)
+            rb.process_input(); op.process_input(raw, filt, c)
+            ok, T, idx, lost = rb.current_integration_frame()
+            assert ok == op.last_valid and lost == op.tracking_lost, i
+            if ok:
+                assert idx == op.last_processed
+                To = op.cur_T[op.last_processed]
+                if not solved:
+                    assert np.array_equal(T.view(np.uint32), np.asarray(To, np.float32).view(np.uint32)), (i, T, To)     # SIFT tracking: bit for bit
+                else:
+                    assert close(T, To), i
+            ref_reintegrate(); op._reintegrate()
+            if ok:
+                rtm.add(0, T, i); op.tm.add_frame(0, op.cur_T[op.last_processed], i)
+            else:
+                rtm.add(1, _minf(), i); op.tm.add_frame(1, _minf(), i)
+        else:                                        # the sequence has ended: FriedLiver.cpp keeps calling the bundler without new frames
+            rb.process_input(); op.process_input()
+            ref_reintegrate(); op._reintegrate()
+        rb.process(); op._bundler_process()
+        solved = solved or op.num_complete > 0
+        compare(i)
+        # the operations scheduled in this frame: same kinds and frames.  (Inside one frame they are ordered by the pose distance, which the
+        # two solvers' 1e-4 differences may permute: compared as sorted lists.)
+        new_r, new_o = ref_ops[n_ops[0]:], op.integrate_ops[n_ops[1]:]
+        assert sorted((k, f) for k, f, _ in new_r) == sorted((k, f) for k, f, _ in new_o), (i, [(k, f) for k, f, _ in new_r], [(k, f) for k, f, _ in new_o])
+        by_r = {(k, f): T for k, f, T in new_r}
+        assert all(close(by_r[(k, f)], T) for k, f, T in new_o), i
+        n_ops[:] = [len(ref_ops), len(op.integrate_ops)]
+    assert op.glob.num_images >= 3 and op.num_complete >= 2 * S and op.past_end >= 4
+    if scenario == "tracking_loss":
+        assert 0 in op.glob.valid[1:op.glob.num_images] and not np.isfinite(op.complete[5, 0, 0]) and np.isfinite(op.complete[NF - 2, 0, 0])
+    assert len(ref_ops) > 10 and {k for k, _, _ in ref_ops} == {"de", "in"}
