@@ -8,7 +8,8 @@
 //   DepthSensing/DepthCameraUtil.h, CUDAHashParams.h, CUDADepthCameraParams.h
 // through shim/cuda_runtime.h and the serial block emulator emu.h.  This file only sequences the launch wrappers the way
 // CUDASceneRepHashSDF.h does (integrate :65-83, deIntegrate :85-107, garbageCollect :110-126, setLastRigidTransform :128-134,
-// reset :147-155, alloc :328-352, compactifyHashEntries :355-391) — that host class itself needs mLib and cannot be compiled.
+// reset :147-155, alloc :328-352, compactifyHashEntries :355-391).  The host class itself is compiled as well (ref_scene_host.cpp, over the
+// mLib stand-in) and produces the same volume byte for byte (tests/test_ref_pin_cpu.py).
 // Threads of the emulated launches run in index order, so the physical slot / heap order of the result is ONE of the orders the
 // CUDA reference can produce; parity targets are the order-independent quantities.
 #include "CUDASceneRepHashSDF.cu.cpp"      // = cu2cpp.py < reference file (generated into the build's temporary directory)

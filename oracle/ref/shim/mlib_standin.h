@@ -15,6 +15,7 @@
 #include <ctime>
 #include <functional>
 #include <unordered_map>
+#include <unordered_set>
 #include <algorithm>
 #include <fstream>
 #include <iostream>
@@ -55,6 +56,7 @@ struct vec3f {
     union { struct { float x, y, z; }; float array[3]; };
     vec3f() : x(0), y(0), z(0) {}
     explicit vec3f(float v) : x(v), y(v), z(v) {}
+    explicit vec3f(const struct vec3i& v);
     vec3f(float a, float b, float c) : x(a), y(b), z(c) {}
     float& operator[](unsigned int i) { return array[i]; }
     const float& operator[](unsigned int i) const { return array[i]; }
@@ -76,7 +78,12 @@ struct vec3f {
 };
 inline vec3f operator*(float s, const vec3f& v) { return v * s; }
 
-struct vec3i { int x = 0, y = 0, z = 0; vec3i() {} vec3i(int a, int b, int c) : x(a), y(b), z(c) {} };
+struct vec3i {
+    int x = 0, y = 0, z = 0; vec3i() {} vec3i(int a, int b, int c) : x(a), y(b), z(c) {}
+    vec3i operator*(int s) const { return vec3i(x * s, y * s, z * s); }
+    vec3i operator+(const vec3i& o) const { return vec3i(x + o.x, y + o.y, z + o.z); }
+};
+inline vec3f::vec3f(const vec3i& v) : x((float)v.x), y((float)v.y), z((float)v.z) {}
 struct vec4i { int x = 0, y = 0, z = 0, w = 0; vec4i() {} vec4i(int a, int b, int c, int d) : x(a), y(b), z(c), w(d) {} };
 struct vec4f {
     union { struct { float x, y, z, w; }; float array[4]; };
@@ -219,6 +226,14 @@ typedef BaseImage<float> ColorImageR32;
 typedef BaseImage<vec3f> ColorImageR32G32B32;
 typedef BaseImage<vec4f> ColorImageR32G32B32A32;
 typedef BaseImage<vec4uc> ColorImageR8G8B8A8;
+struct PointCloudf { std::vector<vec3f> m_points, m_normals; std::vector<vec4f> m_colors; };        // debug dumps (shape only)
+struct PointCloudIOf { static void saveToFile(const std::string&, const PointCloudf&) { throw std::runtime_error("mlib_standin: PointCloudIOf is not provided"); } };
+template <class T> struct BoundingBox3 {
+    void include(const vec3i&) {}
+    T getExtentX() const { return 0; } T getExtentY() const { return 0; } T getExtentZ() const { return 0; }
+    vec3i getMin() const { return vec3i(); } vec3i getMax() const { return vec3i(); }
+};
+template <class T> inline std::ostream& operator<<(std::ostream& s, const BoundingBox3<T>&) { return s; }
 struct FreeImageWrapper { template <class I> static void saveImage(const std::string&, const I&) { throw std::runtime_error("mlib_standin: FreeImageWrapper is not provided"); } };
 struct BinaryDataStreamFile {
     BinaryDataStreamFile(const std::string&, bool) { throw std::runtime_error("mlib_standin: BinaryDataStreamFile is not provided"); }

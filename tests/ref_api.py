@@ -49,49 +49,70 @@ def _view(ptr, nbytes, dtype):
 
 
 class RefScene:
-    """The reference's CUDASceneRepHashSDF operators (serial block emulation of its own kernels)."""
+    """The reference's CUDASceneRepHashSDF operators (serial block emulation of its own kernels).  host_class=False: the launch wrappers
+    sequenced by oracle/ref/ref_tsdf.cpp; host_class=True: the reference's own host class (CUDASceneRepHashSDF.h compiled as it is)."""
 
-    def __init__(self, params):
+    def __init__(self, params, host_class=False):
         self.params = params
-        self._h = C.c_void_p(lib().ref_scene_create(C.byref(params)))
+        self._p = "ref_hscene_" if host_class else "ref_scene_"
+        L = lib()
+        for f in ("create", "hash", "heap", "voxels", "compactified"):
+            getattr(L, self._p + f).restype = C.c_void_p
+        for f in ("heap_counter", "num_occupied"):
+            getattr(L, self._p + f).restype = C.c_uint32
+        self._h = C.c_void_p(self._f("create")(C.byref(params)))
+
+    def _f(self, name):
+        return getattr(lib(), self._p + name)
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().ref_scene_destroy(self._h)
+            self._f("destroy")(self._h)
             self._h = None
 
     def integrate(self, T, depth, color, cam):
         d = _f32(depth); c = np.ascontiguousarray(color, np.uint8)
-        lib().ref_scene_integrate(self._h, _fp(_f32(T).reshape(16)), _fp(d), _fp(c), C.byref(cam))
+        self._f("integrate")(self._h, _fp(_f32(T).reshape(16)), _fp(d), _fp(c), C.byref(cam))
 
     def deintegrate(self, T, depth, color, cam):
         d = _f32(depth); c = np.ascontiguousarray(color, np.uint8)
-        lib().ref_scene_deintegrate(self._h, _fp(_f32(T).reshape(16)), _fp(d), _fp(c), C.byref(cam))
+        self._f("deintegrate")(self._h, _fp(_f32(T).reshape(16)), _fp(d), _fp(c), C.byref(cam))
 
     def compactify(self, T, cam):
-        lib().ref_scene_compactify(self._h, _fp(_f32(T).reshape(16)), C.byref(cam))
+        self._f("compactify")(self._h, _fp(_f32(T).reshape(16)), C.byref(cam))
 
     def garbage_collect(self):
-        lib().ref_scene_garbage_collect(self._h)
+        self._f("garbage_collect")(self._h)
 
     def hash(self):
-        return _view(lib().ref_scene_hash(self._h), self.params.m_hashNumBuckets * HASH_BUCKET_SIZE * 32, HASH_ENTRY_DTYPE)
+        return _view(self._f("hash")(self._h), self.params.m_hashNumBuckets * HASH_BUCKET_SIZE * 32, HASH_ENTRY_DTYPE)
 
     def heap(self):
-        return _view(lib().ref_scene_heap(self._h), self.params.m_numSDFBlocks * 4, "<u4")
+        return _view(self._f("heap")(self._h), self.params.m_numSDFBlocks * 4, "<u4")
 
     def heap_counter(self):
-        return lib().ref_scene_heap_counter(self._h)
+        return self._f("heap_counter")(self._h)
 
     def voxels(self):
-        return _view(lib().ref_scene_voxels(self._h), self.params.m_numSDFBlocks * VOX_PER_BLOCK * 12, VOXEL_DTYPE)
+        return _view(self._f("voxels")(self._h), self.params.m_numSDFBlocks * VOX_PER_BLOCK * 12, VOXEL_DTYPE)
 
     def num_occupied(self):
-        return lib().ref_scene_num_occupied(self._h)
+        return self._f("num_occupied")(self._h)
 
     def compactified(self):
         n = self.num_occupied()
-        return _view(lib().ref_scene_compactified(self._h), n * 32, HASH_ENTRY_DTYPE) if n else np.zeros(0, HASH_ENTRY_DTYPE)
+        return _view(self._f("compactified")(self._h), n * 32, HASH_ENTRY_DTYPE) if n else np.zeros(0, HASH_ENTRY_DTYPE)
+
+
+def hash_params_from_global_app_state(gas):
+    """CUDASceneRepHashSDF::parametersFromGlobalAppState (CUDASceneRepHashSDF.h:39-59) of the reference on the values of a capi.GlobalAppState"""
+    from bundlefusion_amd.capi import HashParams
+    p = HashParams()
+    lib().ref_hash_params_from_global_app_state(C.c_uint32(gas.s_hashNumBuckets), C.c_uint32(gas.s_hashMaxCollisionLinkedListSize), C.c_uint32(gas.s_hashNumSDFBlocks),
+                                                C.c_float(gas.s_SDFVoxelSize), C.c_float(gas.s_SDFMaxIntegrationDistance), C.c_float(gas.s_SDFTruncation),
+                                                C.c_float(gas.s_SDFTruncationScale), C.c_uint32(gas.s_SDFIntegrationWeightSample),
+                                                C.c_uint32(gas.s_SDFIntegrationWeightMax), C.byref(p))
+    return p
 
 
 def hash_pos(num_buckets, x, y, z):

@@ -313,7 +313,9 @@ def osc_hash(nb, k):
 def test_tsdf_operators_vs_reference_kernels(oracle, cfg):
     """integrate x3 (moving camera) -> de-integrate the middle frame -> re-integrate it at a perturbed pose -> garbage collection
     -> de-integrate everything + GC: after every step the oracle volume equals the volume produced by the reference's own
-    allocKernel / compactifyHashAllInOneKernel / integrateDepthMapKernel<deIntegrate> / garbageCollect kernels."""
+    allocKernel / compactifyHashAllInOneKernel / integrateDepthMapKernel<deIntegrate> / garbageCollect kernels, sequenced by the
+    reference's own host class (DepthSensing/CUDASceneRepHashSDF.h compiled as it is: integrate / deIntegrate / garbageCollect /
+    setLastRigidTransformAndCompactify with its allocation loop)."""
     global _hash_fn
     _hash_fn = oracle.hash_pos
     W, H = cfg["W"], cfg["H"]
@@ -329,7 +331,7 @@ def test_tsdf_operators_vs_reference_kernels(oracle, cfg):
     K = frames[0][3]
     cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
     p = default_hash_params(num_buckets=cfg["buckets"], num_sdf_blocks=cfg["blocks"], voxel_size=cfg["voxel"])
-    osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p)
+    osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p, host_class=True)      # the reference's own host class drives its kernels
     nb = cfg["buckets"]
     for i, (d, c, T, _) in enumerate(frames):
         osc.integrate(T, d, c, cam); rsc.integrate(T, d, c, cam)
@@ -351,6 +353,37 @@ def test_tsdf_operators_vs_reference_kernels(oracle, cfg):
         osc.compactify(T, cam); rsc.compactify(T, cam)
         _assert_same_volume(osc, rsc, nb, "tear-down %d" % i)
     assert len(_by_key(osc.hash(), osc.voxels())) == 0 and osc.heap_counter() + 1 == cfg["blocks"]
+
+
+def test_scene_host_class_equals_hand_sequenced_kernels_and_hash_params(oracle):
+    """The other pins (marching cubes, ray cast) fill their volumes through oracle/ref/ref_tsdf.cpp, which sequences the launch wrappers by
+    hand: same bytes as the reference's host class.  And HashParams as CUDASceneRepHashSDF::parametersFromGlobalAppState derives them
+    from the application state = what the C ABI's default_hash_params / the oracle frame loop use."""
+    import ctypes as C
+    from bundlefusion_amd.capi import default_app_state, HashParams
+    W, H = 64, 48
+    frames = [synth.scene_room(20 * k, W, H) for k in range(2)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=2003, num_sdf_blocks=4000, voxel_size=0.02)
+    a, b = ref_api.RefScene(p, host_class=True), ref_api.RefScene(p, host_class=False)
+    for d, c, T, _ in frames:
+        a.integrate(T, d, c, cam); b.integrate(T, d, c, cam)
+    d, c, T, _ = frames[0]
+    a.deintegrate(T, d, c, cam); b.deintegrate(T, d, c, cam)
+    a.garbage_collect(); b.garbage_collect()
+    a.compactify(T, cam); b.compactify(T, cam)
+    assert a.heap_counter() == b.heap_counter() and a.num_occupied() == b.num_occupied() > 50
+    assert np.array_equal(a.hash().view(np.uint8), b.hash().view(np.uint8)) and np.array_equal(a.heap(), b.heap())
+    assert np.array_equal(a.voxels().view(np.uint8), b.voxels().view(np.uint8))
+    assert np.array_equal(a.compactified().view(np.uint8), b.compactified().view(np.uint8))
+    gas = default_app_state()
+    gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks, gas.s_SDFVoxelSize = 123457, 54321, 0.004
+    r = ref_api.hash_params_from_global_app_state(gas)
+    mine = default_hash_params(num_buckets=gas.s_hashNumBuckets, num_sdf_blocks=gas.s_hashNumSDFBlocks, voxel_size=gas.s_SDFVoxelSize,
+                               max_integration_distance=gas.s_SDFMaxIntegrationDistance, truncation=gas.s_SDFTruncation, trunc_scale=gas.s_SDFTruncationScale,
+                               weight_sample=gas.s_SDFIntegrationWeightSample, weight_max=gas.s_SDFIntegrationWeightMax, max_chain=gas.s_hashMaxCollisionLinkedListSize)
+    assert C.sizeof(HashParams) == 224 and bytes(r) == bytes(mine)
 
 
 # ------------------------------------------------------------------------------------------------ marching cubes
