@@ -57,3 +57,21 @@ unsigned int ref_hscene_num_occupied(void* s) { return ((CUDASceneRepHashSDF*)s)
 unsigned int ref_hscene_num_integrated(void* s) { return ((CUDASceneRepHashSDF*)s)->getNumIntegratedFrames(); }
 
 }
+
+// CUDARayCastSDF::parametersFromGlobalAppState (CUDARayCastSDF.h:24-52): the static function only - the class's render() drives Direct3D
+#include "CUDARayCastSDF.h"
+extern "C" void ref_ray_cast_params_from_global_app_state(unsigned int rayCastWidth, unsigned int rayCastHeight, unsigned int integrationWidth, unsigned int integrationHeight,
+                                                          float renderDepthMin, float renderDepthMax, float SDFRayIncrementFactor, float SDFTruncation,
+                                                          float SDFRayThresSampleDistFactor, float SDFRayThresDistFactor, int SDFUseGradients, unsigned int hashNumSDFBlocks,
+                                                          const float* intrinsics16, void* outRayCastParams) {
+    GlobalAppState& g = GlobalAppState::get();
+    g.s_rayCastWidth = rayCastWidth; g.s_rayCastHeight = rayCastHeight; g.s_integrationWidth = integrationWidth; g.s_integrationHeight = integrationHeight;
+    g.s_renderDepthMin = renderDepthMin; g.s_renderDepthMax = renderDepthMax; g.s_SDFRayIncrementFactor = SDFRayIncrementFactor; g.s_SDFTruncation = SDFTruncation;
+    g.s_SDFRayThresSampleDistFactor = SDFRayThresSampleDistFactor; g.s_SDFRayThresDistFactor = SDFRayThresDistFactor; g.s_SDFUseGradients = SDFUseGradients != 0;
+    g.s_hashNumSDFBlocks = hashNumSDFBlocks;
+    const mat4f K(intrinsics16);
+    RayCastParams p; memset(&p, 0, sizeof p);
+    p = CUDARayCastSDF::parametersFromGlobalAppState(g, K, K.getInverse());
+    memcpy(outRayCastParams, &p, sizeof p);
+}
+extern "C" unsigned int ref_sizeof_ray_cast_params() { return (unsigned int)sizeof(RayCastParams); }

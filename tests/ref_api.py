@@ -775,3 +775,16 @@ class RefOnlineBundler:
 class _BorrowedTM(RefTrajectoryManager):
     def __del__(self):
         pass
+
+
+def ray_cast_params_from_global_app_state(gas, intrinsics):
+    """CUDARayCastSDF::parametersFromGlobalAppState (CUDARayCastSDF.h:24-52) of the reference -> capi.RayCastParams"""
+    from bundlefusion_amd.capi import RayCastParams
+    assert lib().ref_sizeof_ray_cast_params() == C.sizeof(RayCastParams)
+    p = RayCastParams()
+    lib().ref_ray_cast_params_from_global_app_state(C.c_uint32(gas.s_rayCastWidth), C.c_uint32(gas.s_rayCastHeight), C.c_uint32(gas.s_integrationWidth),
+                                                    C.c_uint32(gas.s_integrationHeight), C.c_float(gas.s_renderDepthMin), C.c_float(gas.s_renderDepthMax),
+                                                    C.c_float(gas.s_SDFRayIncrementFactor), C.c_float(gas.s_SDFTruncation), C.c_float(gas.s_SDFRayThresSampleDistFactor),
+                                                    C.c_float(gas.s_SDFRayThresDistFactor), C.c_int(int(gas.s_SDFUseGradients)), C.c_uint32(gas.s_hashNumSDFBlocks),
+                                                    _fp(_f32(intrinsics).reshape(16)), C.byref(p))
+    return p

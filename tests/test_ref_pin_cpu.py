@@ -384,6 +384,20 @@ def test_scene_host_class_equals_hand_sequenced_kernels_and_hash_params(oracle):
                                max_integration_distance=gas.s_SDFMaxIntegrationDistance, truncation=gas.s_SDFTruncation, trunc_scale=gas.s_SDFTruncationScale,
                                weight_sample=gas.s_SDFIntegrationWeightSample, weight_max=gas.s_SDFIntegrationWeightMax, max_chain=gas.s_hashMaxCollisionLinkedListSize)
     assert C.sizeof(HashParams) == 224 and bytes(r) == bytes(mine)
+    # ... and RayCastParams as CUDARayCastSDF::parametersFromGlobalAppState derives them = bf_ray_cast_params_from_global_app_state (host
+    # function of the product), with and without the intrinsics rescaling branch (ray-cast size != integration size)
+    from bundlefusion_amd.capi import ray_cast_params_from_global_app_state
+    Km = intrinsics_matrix(583.0, 580.5, 319.5, 241.25)
+    for rw, rh in ((640, 480), (320, 240), (512, 424)):
+        gas = default_app_state()
+        gas.s_integrationWidth, gas.s_integrationHeight, gas.s_rayCastWidth, gas.s_rayCastHeight = 640, 480, rw, rh
+        gas.s_SDFUseGradients = rw == 320
+        a_, b_ = ref_api.ray_cast_params_from_global_app_state(gas, Km), ray_cast_params_from_global_app_state(gas, Km)
+        for name, _ in a_._fields_:
+            if name in ("m_viewMatrix", "m_viewMatrixInverse", "m_numOccupiedSDFBlocks", "m_splatMinimum", "dummy0"):
+                continue                          # not set by the function (uninitialised members in the reference)
+            va, vb = getattr(a_, name), getattr(b_, name)
+            assert np.float32(va).tobytes() == np.float32(vb).tobytes() if isinstance(va, float) else va == vb, (rw, name, va, vb)
 
 
 # ------------------------------------------------------------------------------------------------ marching cubes
