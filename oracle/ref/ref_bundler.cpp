@@ -2,9 +2,9 @@
 //
 // The REFERENCE's Bundler (Bundler.cpp compiled as it is: constructor :18-53, detectFeatures :91-101, matchAndFilter :103-249,
 // optimize :251-280, storeCachedFrame, copyFrame, isValid, tryRevalidation :309-357, reset, addInvalidFrame, invalidateLastFrame,
-// fuseToGlobal) on top of the reference's own SiftGPU fork, SIFTImageManager, CUDACache (CUDACache.cpp, also compiled as it is), SBA and
-// CUDASolverBundling.  Stand-ins: mLib's element arithmetic (shim/mlib_standin.h) and a CUDAImageManager that only carries the SIFT-side
-// depth size and intrinsics the constructor reads (shim/app/CUDAImageManager.h).
+// fuseToGlobal) on top of the reference's own SiftGPU fork, SIFTImageManager, CUDACache (CUDACache.cpp, also compiled as it is), SBA,
+// CUDASolverBundling and CUDAImageManager.  Stand-ins: mLib's element arithmetic (shim/mlib_standin.h) and an RGBDSensor that carries sizes,
+// intrinsics and the frame the test supplies (shim/app/RGBDSensor.h).
 #define private public
 #define protected public
 #include "Bundler.h"
@@ -24,7 +24,8 @@ struct ref_bundling_state {            // GlobalBundlingState / GlobalAppState v
         verifyOptCorrThresh, maxKabschResidual2, minKeyScale, siftMatchThresh, siftMatchRatioMaxLocal, siftMatchRatioMaxGlobal, colorDownSigma, depthDownSigmaD,
         depthDownSigmaR, optMaxResThresh, denseDistThresh, denseNormalThresh, denseColorThresh, denseColorGradientMin, denseDepthMin, denseDepthMax, sensorDepthMin,
         sensorDepthMax;
-    int useComprehensiveFrameInvalidation, useLocalVerify, useLocalDense, erodeSIFTdepth;
+    int useComprehensiveFrameInvalidation, useLocalVerify, useLocalDense, erodeSIFTdepth, depthFilter;
+    float depthSigmaD, depthSigmaR;
 };
 
 extern "C" {
@@ -47,6 +48,7 @@ void ref_set_bundling_state(const ref_bundling_state* p) {
     g.s_denseDepthMin = p->denseDepthMin; g.s_denseDepthMax = p->denseDepthMax;
     g.s_useComprehensiveFrameInvalidation = p->useComprehensiveFrameInvalidation != 0; g.s_useLocalVerify = p->useLocalVerify != 0;
     g.s_useLocalDense = p->useLocalDense != 0; g.s_erodeSIFTdepth = p->erodeSIFTdepth != 0;
+    g.s_depthFilter = p->depthFilter != 0; g.s_depthSigmaD = p->depthSigmaD; g.s_depthSigmaR = p->depthSigmaR;
     g.s_enableGlobalTimings = false; g.s_enablePerFrameTimings = false; g.s_verbose = false; g.s_recordSolverConvergence = false;
     GlobalAppState::get().s_sensorDepthMin = p->sensorDepthMin; GlobalAppState::get().s_sensorDepthMax = p->sensorDepthMax;
 }
@@ -60,16 +62,17 @@ void ref_set_sift_camera(unsigned int depthW, unsigned int depthH, unsigned int 
     updateConstantSiftCameraParams(c);
 }
 
-struct ref_bundler { Bundler* b; CUDAImageManager* im; };
+struct ref_bundler { Bundler* b; CUDAImageManager* im; RGBDSensor* sensor; };
 
 ref_bundler* ref_bundler_create(unsigned int maxNumImages, unsigned int maxNumKeysPerImage, const float* siftIntrinsicsInv16, unsigned int depthW, unsigned int depthH,
                                 const float* depthIntrinsics16, int isLocal) {
     ref_bundler* h = new ref_bundler;
-    h->im = new CUDAImageManager(depthW, depthH, depthW, depthH, mat4f(depthIntrinsics16));
+    h->sensor = new RGBDSensor(depthW, depthH, depthW, depthH, mat4f(depthIntrinsics16), mat4f(depthIntrinsics16));
+    h->im = new CUDAImageManager(depthW, depthH, GlobalBundlingState::get().s_widthSIFT, GlobalBundlingState::get().s_heightSIFT, h->sensor, false);
     h->b = new Bundler(maxNumImages, maxNumKeysPerImage, mat4f(siftIntrinsicsInv16), h->im, isLocal != 0);
     return h;
 }
-void ref_bundler_destroy(ref_bundler* h) { delete h->b; delete h->im; delete h; }
+void ref_bundler_destroy(ref_bundler* h) { delete h->b; delete h->im; delete h->sensor; delete h; }
 void ref_bundler_detect_features(ref_bundler* h, float* intensitySift, const float* depthFilt) { h->b->detectFeatures(intensitySift, depthFilt); }
 void ref_bundler_store_cached_frame(ref_bundler* h, unsigned int depthW, unsigned int depthH, const unsigned char* colorRGBX, unsigned int colorW, unsigned int colorH,
                                     const float* depthRaw) {

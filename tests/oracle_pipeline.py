@@ -7,10 +7,10 @@ kernels of oracle/*.cpp (the checker, never the product):
   loop with integrate / deIntegrate / reintegrate (DepthSensing.cpp:723-762, :854-902, :966-1095).
 
 The stage kernels it calls are pinned to the reference's device code where oracle/or_common.h says so, and this orchestration is pinned
-END TO END to the reference's own host classes - OnlineBundler.cpp, Bundler.cpp, SBA.cpp, CUDASolverBundling.cpp, CUDACache.cpp,
+END TO END to the reference's own host classes - CUDAImageManager.cpp, OnlineBundler.cpp, Bundler.cpp, SBA.cpp, CUDASolverBundling.cpp, CUDACache.cpp,
 TrajectoryManager.cpp, SIFTImageManager.cpp compiled as they are into oracle/_ref - frame by frame on a three-chunk stream and on a stream
 with a tracking loss (tests/test_ref_pin_cpu.py::test_online_bundler_vs_reference_host_code).  Not pinned: the DirectX frame loop of
-DepthSensing.cpp around those classes (_integrate / process_frame here) and CUDAImageManager::process as a class (_ingest; its kernels are pinned).
+DepthSensing.cpp around those classes (_integrate / process_frame here).
 Plain Python loops: orchestration is a few hundred scalar decisions per frame.
 """
 from collections import deque

@@ -639,8 +639,10 @@ class _RefBundlingState(C.Structure):
           "verifyOptCorrThresh", "maxKabschResidual2", "minKeyScale", "siftMatchThresh", "siftMatchRatioMaxLocal", "siftMatchRatioMaxGlobal", "colorDownSigma",
           "depthDownSigmaD", "depthDownSigmaR", "optMaxResThresh", "denseDistThresh", "denseNormalThresh", "denseColorThresh", "denseColorGradientMin", "denseDepthMin",
           "denseDepthMax")
-    _I = ("useComprehensiveFrameInvalidation", "useLocalVerify", "useLocalDense", "erodeSIFTdepth")
-    _fields_ = [(n, C.c_uint32) for n in _U] + [(n, C.c_float) for n in _F] + [("sensorDepthMin", C.c_float), ("sensorDepthMax", C.c_float)] + [(n, C.c_int) for n in _I]
+    _I = ("useComprehensiveFrameInvalidation", "useLocalVerify", "useLocalDense", "erodeSIFTdepth", "depthFilter")
+    _F2 = ("depthSigmaD", "depthSigmaR")
+    _fields_ = [(n, C.c_uint32) for n in _U] + [(n, C.c_float) for n in _F] + [("sensorDepthMin", C.c_float), ("sensorDepthMax", C.c_float)] + \
+               [(n, C.c_int) for n in _I] + [(n, C.c_float) for n in _F2]
 
 
 class _RefAppState(C.Structure):
@@ -651,7 +653,7 @@ class _RefAppState(C.Structure):
 def set_reference_state(gas, gbs):
     """GlobalAppState / GlobalBundlingState singletons of the reference build <- the ctypes parameter structs of bundlefusion_amd.capi."""
     p = _RefBundlingState()
-    for n in _RefBundlingState._U + _RefBundlingState._F:
+    for n in _RefBundlingState._U + _RefBundlingState._F + _RefBundlingState._F2:
         setattr(p, n, getattr(gbs, "s_" + n))
     for n in _RefBundlingState._I:
         setattr(p, n, int(getattr(gbs, "s_" + n)))
@@ -662,7 +664,7 @@ def set_reference_state(gas, gbs):
 
 
 class _RefBundlerHandle(C.Structure):
-    _fields_ = [("b", C.c_void_p), ("im", C.c_void_p)]
+    _fields_ = [("b", C.c_void_p), ("im", C.c_void_p), ("sensor", C.c_void_p)]
 
 
 class RefBundlerView:
@@ -715,13 +717,34 @@ class RefOnlineBundler:
         L.ref_ob_trajectory_manager.restype = C.c_void_p
         Kf = _f32(K).reshape(16)
         self.gbs = gbs
-        self._h = C.c_void_p(L.ref_ob_create(width, height, width, height, _fp(Kf), _fp(Kf)))
+        self.W, self.H, self.WI, self.HI = width, height, gas.s_integrationWidth, gas.s_integrationHeight
+        self.num_frames = 0
+        self._h = C.c_void_p(L.ref_ob_create(width, height, width, height, self.WI, self.HI, _fp(Kf), _fp(Kf)))
         self.tm = RefTrajectoryManager.__new__(RefTrajectoryManager)
         self.tm._h = None
         self.tm_handle = C.c_void_p(L.ref_ob_trajectory_manager(self._h))
 
-    def set_frame(self, raw, filt, color):
-        lib().ref_ob_set_frame(self._h, _fp(_f32(raw)), _fp(_f32(filt)), _fp(np.ascontiguousarray(color, np.uint8)))
+    def set_frame(self, depth, color):
+        """A new sensor frame through the reference's own ingest (CUDAImageManager::process)."""
+        ok = lib().ref_ob_set_frame(self._h, _fp(_f32(depth)), _fp(np.ascontiguousarray(color, np.uint8)))
+        assert ok
+        self.num_frames += 1
+
+    def ingest_outputs(self, frame=None):
+        """(raw depth, filtered depth) at sensor resolution of the CURRENT frame, (depth, colour) stored for integration of frame `frame`"""
+        frame = self.num_frames - 1 if frame is None else frame
+        raw, filt = np.zeros((self.H, self.W), np.float32), np.zeros((self.H, self.W), np.float32)
+        di, ci = np.zeros((self.HI, self.WI), np.float32), np.zeros((self.HI, self.WI, 4), np.uint8)
+        lib().ref_ob_ingest_outputs(self._h, _fp(raw), _fp(filt), C.c_uint32(frame), _fp(di), _fp(ci))
+        return raw, filt, di, ci
+
+    def override_filtered_depth(self, filt):
+        lib().ref_ob_override_filtered_depth(self._h, _fp(_f32(filt)))
+
+    def integration_intrinsics(self):
+        K = np.zeros((4, 4), np.float32)
+        lib().ref_ob_integration_intrinsics(self._h, _fp(K))
+        return K
 
     def process_input(self):
         lib().ref_ob_process_input(self._h)

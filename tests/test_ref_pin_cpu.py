@@ -1091,10 +1091,11 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
 @pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=pytest.mark.skipif(
     os.environ.get("BF_LONG_TESTS") != "1", reason="3 more minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)"))])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
-    """Rows a3-a12 end to end: the reference's OnlineBundler.cpp / Bundler.cpp / SBA.cpp / CUDASolverBundling.cpp / CUDACache.cpp /
-    TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
+    """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
+    CUDASolverBundling.cpp / CUDACache.cpp / TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
     oracle frame loop (tests/oracle_pipeline.py - the restatement every GPU pipeline test holds the product to) on a 10-frame stream of
-    three local chunks plus the end-of-sequence iterations.  Per frame: the state machine (11 fields of BundlerState) exactly; the pose
+    three local chunks plus the end-of-sequence iterations.  Per frame: the ingest's outputs (SIFT-side raw depth and the colour frame bit for bit, filtered depth and the
+    depth frame stored for integration to the 3e-6 of the exp() difference); the state machine (11 fields of BundlerState) exactly; the pose
     handed to the integration bit for bit until the first global solve and to 5e-4 after it; complete / local / global trajectories 5e-4 (the dense local solve sums in another order; measured 2.6e-4)
     with the same -inf pattern; key-frame counts, key counts, correspondence counts, valid flags exactly; and the operations the
     TrajectoryManager schedules (kind and frame exactly).
@@ -1172,7 +1173,16 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         if i < NF:
             d, c = frames[i][0], frames[i][1]
             raw, filt = op._ingest(d, c)
-            rb.set_frame(raw, filt, c)
+            rb.set_frame(d, c)                                 # the reference's own ingest, CUDAImageManager::process
+            r_raw, r_filt, r_di, r_ci = rb.ingest_outputs()
+            assert _same(r_raw, raw), i
+
+            def near(a, b):                              # the depth Gauss filter: glibc exp() there, bf_detmath here (3e-6, test_ingest_and_resample_kernels)
+                v = np.isfinite(b)
+                return np.array_equal(np.isfinite(a), v) and (not v.any() or np.abs(a[v] - b[v]).max() <= 3e-6 * np.abs(b[v]).max())
+            assert near(r_filt, filt), i
+            assert near(r_di, op.frames[i][0]) and _same(r_ci.reshape(op.frames[i][1].shape), op.frames[i][1]), i     # what the integration will read
+            rb.override_filtered_depth(filt)             # from here on bit for bit
             rb.process_input(); op.process_input(raw, filt, c)
             ok, T, idx, lost = rb.current_integration_frame()
             assert ok == op.last_valid and lost == op.tracking_lost, i
@@ -1205,3 +1215,37 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     if scenario == "tracking_loss":
         assert 0 in op.glob.valid[1:op.glob.num_images] and not np.isfinite(op.complete[5, 0, 0]) and np.isfinite(op.complete[NF - 2, 0, 0])
     assert len(ref_ops) > 10 and {k for k, _, _ in ref_ops} == {"de", "in"}
+
+
+def test_image_manager_resample_branch_vs_reference_class(oracle):
+    """a1, the reference's default configuration (integration resolution below the sensor's): CUDAImageManager's constructor and process()
+    (CUDAImageManager.h:141-193, CUDAImageManager.cpp:22-158, compiled as they are) against the oracle's _ingest - the depth / colour frame
+    stored for integration through resampleFloat / resampleUCHAR4 of the FILTERED depth, and the integration intrinsics adapted with
+    (w' / w, h' / h, (w' - 1) / (w - 1), (h' - 1) / (h - 1))."""
+    from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix
+    from tests.oracle_pipeline import OraclePipeline, scale_intrinsics
+    W, H, WI, HI = 320, 240, 160, 120
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = WI, HI
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
+    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 4, 3
+    frames = [synth.scene_room(5 * k, W, H) for k in range(2)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    op = OraclePipeline(gas, gbs, W, H, K)
+    rb = ref_api.RefOnlineBundler(gas, gbs, W, H, K)
+    Ki = rb.integration_intrinsics()
+    assert _same(Ki, scale_intrinsics(K, WI, HI, W, H))
+    for i, (d, c, _, _) in enumerate(frames):
+        raw, filt = op._ingest(d, c)
+        rb.set_frame(d, c)
+        r_raw, r_filt, r_di, r_ci = rb.ingest_outputs()
+        assert _same(r_raw, raw)
+        v = np.isfinite(filt)
+        assert np.array_equal(np.isfinite(r_filt), v) and np.abs(r_filt[v] - filt[v]).max() <= 3e-6 * np.abs(filt[v]).max()
+        od, oc = op.frames[i]
+        assert r_di.shape == od.shape == (HI, WI)
+        assert _same(r_di, oracle.resample_float(r_filt, WI, HI))                    # the class resamples ITS filtered depth with the pinned kernel ...
+        vi = np.isfinite(od)
+        assert np.array_equal(np.isfinite(r_di), vi) and np.abs(r_di[vi] - od[vi]).max() <= 3e-6 * np.abs(od[vi]).max()      # ... = the oracle's frame up to exp()
+        assert _same(r_ci.reshape(oc.shape), oc)
