@@ -1098,7 +1098,10 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     depth frame stored for integration to the 3e-6 of the exp() difference); the state machine (11 fields of BundlerState) exactly; the pose
     handed to the integration bit for bit until the first global solve and to 5e-4 after it; complete / local / global trajectories 5e-4 (the dense local solve sums in another order; measured 2.6e-4)
     with the same -inf pattern; key-frame counts, key counts, correspondence counts, valid flags exactly; and the operations the
-    TrajectoryManager schedules (kind and frame exactly).
+    TrajectoryManager schedules (kind and frame exactly).  In the "three_chunks" scenario those operations also drive the VOLUME on both
+    sides - the reference's CUDASceneRepHashSDF host class over its own kernels against the oracle volume: allocated keys, bucket occupancy,
+    free list and every voxel byte identical while the poses are identical bit for bit (up to the first re-integration), the same blocks up
+    to a 3 % fringe afterwards.
     Scenario "tracking_loss": 16 frames of which 4-8 carry no depth - untracked frames, two local chunks without a tracked frame (the
     INVALIDATE branches of OnlineBundler.cpp:134-165, :263-266, :351-360, :399-405, Bundler::addInvalidFrame, -inf rows of
     updateTrajectoryCU), then recovery through the global matching; poses after the gap 1e-2 (both sides re-anchor across the gap from a
@@ -1110,15 +1113,25 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     gas = default_app_state(); gbs = default_bundling_state()
     gas.s_integrationWidth, gas.s_integrationHeight = W, H
     gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
-    gas.s_garbageCollectionEnabled = False
+    with_volume = scenario == "three_chunks"
+    gas.s_garbageCollectionEnabled = with_volume
     gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 8, S
     frames = [synth.scene_room(3 * k, W, H) for k in range(NF)]
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     frames = [((np.full_like(f[0], -np.inf) if k in dark else f[0]), f[1]) for k, f in enumerate(frames)]
     op = OraclePipeline(gas, gbs, W, H, K)
-    op._integrate = lambda frame, T, de: op.integrate_ops.append(("de" if de else "in", frame, np.array(T, np.float32)))     # no volume in this test
+    if not with_volume:
+        op._integrate = lambda frame, T, de: op.integrate_ops.append(("de" if de else "in", frame, np.array(T, np.float32)))
     rb = ref_api.RefOnlineBundler(gas, gbs, W, H, K)
+    # the volume: the reference's CUDASceneRepHashSDF host class with the HashParams its parametersFromGlobalAppState derives, driven by
+    # the operations its TrajectoryManager hands out - DepthSensing.cpp:854-902 (reintegrate) and :723-762 (integrate) are these few lines
+    rsc = ref_api.RefScene(ref_api.hash_params_from_global_app_state(gas), host_class=True) if with_volume else None
+
+    def ref_volume(kind, idx, T):
+        if rsc is not None:
+            (rsc.deintegrate if kind == "de" else rsc.integrate)(T, op.frames[idx][0], op.frames[idx][1], op.cam)
+
     rtm = rb.trajectory_manager()
     ref_ops = []
     STATES = {"NONE": 0, "PROCESS": 1, "INVALIDATE": 2}
@@ -1129,14 +1142,16 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         for _ in range(gas.s_maxFrameFixes):
             f, idx, T, _ = rtm.top_de()
             if f:
-                ref_ops.append(("de", idx, T)); continue
+                ref_ops.append(("de", idx, T)); ref_volume("de", idx, T); continue
             f, idx, T, _ = rtm.top_in()
             if f:
-                ref_ops.append(("in", idx, T)); rtm.confirm(idx); continue
+                ref_ops.append(("in", idx, T)); ref_volume("in", idx, T); rtm.confirm(idx); continue
             f, idx, old, new = rtm.top_re()
             if f:
-                ref_ops.append(("de", idx, old)); ref_ops.append(("in", idx, new)); rtm.confirm(idx); continue
+                ref_ops.append(("de", idx, old)); ref_ops.append(("in", idx, new)); ref_volume("de", idx, old); ref_volume("in", idx, new); rtm.confirm(idx); continue
             break
+        if rsc is not None:
+            rsc.garbage_collect()
 
     def close(a, b, tol=None):
         tol = TOL if tol is None else tol
@@ -1167,7 +1182,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         if nl:
             assert close(rb.local_trajectories(nl), op.local_traj[:nl]), step
 
-    solved = False
+    solved = reintegrated = False
+    volume_checks = [0, 0]
     n_ops = [0, 0]
     for i in range(NF + 5):
         if i < NF:
@@ -1195,6 +1211,9 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
                     assert close(T, To), i
             ref_reintegrate(); op._reintegrate()
             if ok:
+                if with_volume:                  # integrate() of the current frame, DepthSensing.cpp:723-762
+                    ref_ops.append(("in", i, T)); ref_volume("in", i, T)
+                    op._integrate(op.last_processed, op.cur_T[op.last_processed], False)
                 rtm.add(0, T, i); op.tm.add_frame(0, op.cur_T[op.last_processed], i)
             else:
                 rtm.add(1, _minf(), i); op.tm.add_frame(1, _minf(), i)
@@ -1211,10 +1230,24 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         by_r = {(k, f): T for k, f, T in new_r}
         assert all(close(by_r[(k, f)], T) for k, f, T in new_o), i
         n_ops[:] = [len(ref_ops), len(op.integrate_ops)]
+        if with_volume:
+            if not reintegrated and not any(k == "de" for k, _, _ in new_o):
+                # every pose so far was identical bit for bit: so is the volume (north_star: bit-exact hash-bucket occupancy and voxel indices)
+                global _hash_fn
+                _hash_fn = oracle.hash_pos
+                _assert_same_volume(op.scene, rsc, gas.s_hashNumBuckets, "frame %d" % i)
+                volume_checks[0] += 1
+            else:                                # re-integration at poses that differ by 1e-4: the same blocks up to the surface fringe
+                reintegrated = True
+                ko, kr = set(_by_key(op.scene.hash(), op.scene.voxels())), set(_by_key(rsc.hash(), rsc.voxels()))
+                assert len(ko & kr) >= 0.97 * len(ko | kr) and abs(op.scene.heap_counter() - rsc.heap_counter()) <= 0.03 * len(ko), i
+                volume_checks[1] += 1
     assert op.glob.num_images >= 3 and op.num_complete >= 2 * S and op.past_end >= 4
     if scenario == "tracking_loss":
         assert 0 in op.glob.valid[1:op.glob.num_images] and not np.isfinite(op.complete[5, 0, 0]) and np.isfinite(op.complete[NF - 2, 0, 0])
     assert len(ref_ops) > 10 and {k for k, _, _ in ref_ops} == {"de", "in"}
+    if with_volume:
+        assert volume_checks[0] >= 2 * S and volume_checks[1] >= 3, volume_checks
 
 
 def test_image_manager_resample_branch_vs_reference_class(oracle):
