@@ -1088,8 +1088,10 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ the bundling half of the frame loop
-@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=pytest.mark.skipif(
-    os.environ.get("BF_LONG_TESTS") != "1", reason="3 more minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)"))])
+_LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)")
+
+
+@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=_LONG), pytest.param("default_submap", marks=_LONG)])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
     CUDASolverBundling.cpp / CUDACache.cpp / TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
@@ -1102,7 +1104,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     sides - the reference's CUDASceneRepHashSDF host class over its own kernels against the oracle volume: allocated keys, bucket occupancy,
     free list and every voxel byte identical while the poses are identical bit for bit (up to the first re-integration), the same blocks up
     to a 3 % fringe afterwards.
-    Scenario "tracking_loss": 16 frames of which 4-8 carry no depth - untracked frames, two local chunks without a tracked frame (the
+    Scenario "default_submap": the same with the reference's chunk size of 10 (31 frames, three chunks of 11 frames, local solves over 55 dense
+    pairs).  Scenario "tracking_loss": 16 frames of which 4-8 carry no depth - untracked frames, two local chunks without a tracked frame (the
     INVALIDATE branches of OnlineBundler.cpp:134-165, :263-266, :351-360, :399-405, Bundler::addInvalidFrame, -inf rows of
     updateTrajectoryCU), then recovery through the global matching; poses after the gap 1e-2 (both sides re-anchor across the gap from a
     poor initial guess and stop their three Gauss-Newton steps at slightly different iterates), everything discrete exactly."""
@@ -1110,6 +1113,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     from tests.oracle_pipeline import OraclePipeline, NINF, _minf
     W, H, S = 320, 240, 3
     NF, dark, TOL = (10, range(0), 5e-4) if scenario == "three_chunks" else (16, range(4, 9), 1e-2)
+    if scenario == "default_submap":             # the reference's chunk size (zParametersBundlingDefault.txt: s_submapSize = 10): 31 frames, three chunks of 11
+        S, NF, TOL = 10, 31, 5e-4
     gas = default_app_state(); gbs = default_bundling_state()
     gas.s_integrationWidth, gas.s_integrationHeight = W, H
     gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
