@@ -62,6 +62,12 @@ class ChunkedRunner:
         # thread pushes the current round through the global half; collectives stay on the main thread
         self.prefetch = prefetch
         self._pending = None            # (round_start, thread, package, produced)
+        # the current HIP device is per host thread: the thread running ahead has to select this rank's GPU itself (on a node where every
+        # process sees all GPUs it would otherwise work on device 0 with handles that live on device `rank`)
+        self._device_index = None
+        if device is not None and str(device).startswith("cuda"):
+            import torch
+            self._device_index = torch.cuda.current_device()
 
     def frames_needed(self, upto_frame):
         """Stream length needed to advance to `upto_frame` frames: the last round's chunks must be complete."""
@@ -71,6 +77,9 @@ class ChunkedRunner:
 
     def _local_half(self, r0, out, produced):
         try:
+            if self._device_index is not None:
+                import torch
+                torch.cuda.set_device(self._device_index)
             c_mine = r0 + self.rank
             a, b = chunk_frames(c_mine, self.S)
             if b < len(self.feed):

@@ -1091,7 +1091,8 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
 _LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)")
 
 
-@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=_LONG), pytest.param("default_submap", marks=_LONG)])
+@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=_LONG), pytest.param("default_submap", marks=_LONG),
+                                      pytest.param("alt_flags", marks=_LONG)])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
     CUDASolverBundling.cpp / CUDACache.cpp / TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
@@ -1104,6 +1105,9 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     sides - the reference's CUDASceneRepHashSDF host class over its own kernels against the oracle volume: allocated keys, bucket occupancy,
     free list and every voxel byte identical while the poses are identical bit for bit (up to the first re-integration), the same blocks up
     to a 3 % fringe afterwards.
+    Scenario "alt_flags": no erosion / depth filter (the integration frame is then the raw sensor depth), intensity filter on, no local
+    verification, simple frame invalidation, residual removal every second solve, and s_numSolveFramesBeforeExit = 2 so that the run reaches
+    the end-of-scan switch to the dense global solve (setSolveWeights: sparse 1, dense depth 15) and the stop of the solver.
     Scenario "default_submap": the same with the reference's chunk size of 10 (31 frames, three chunks of 11 frames, local solves over 55 dense
     pairs).  Scenario "tracking_loss": 16 frames of which 4-8 carry no depth - untracked frames, two local chunks without a tracked frame (the
     INVALIDATE branches of OnlineBundler.cpp:134-165, :263-266, :351-360, :399-405, Bundler::addInvalidFrame, -inf rows of
@@ -1113,6 +1117,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     from tests.oracle_pipeline import OraclePipeline, NINF, _minf
     W, H, S = 320, 240, 3
     NF, dark, TOL = (10, range(0), 5e-4) if scenario == "three_chunks" else (16, range(4, 9), 1e-2)
+    if scenario == "alt_flags":                  # the other side of the switches, and the end-of-scan global dense solve (OnlineBundler.cpp:175-196)
+        NF = 7
     if scenario == "default_submap":             # the reference's chunk size (zParametersBundlingDefault.txt: s_submapSize = 10): 31 frames, three chunks of 11
         S, NF, TOL = 10, 31, 5e-4
     gas = default_app_state(); gbs = default_bundling_state()
@@ -1121,6 +1127,10 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     with_volume = scenario == "three_chunks"
     gas.s_garbageCollectionEnabled = with_volume
     gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 8, S
+    if scenario == "alt_flags":
+        gbs.s_erodeSIFTdepth = gbs.s_depthFilter = gbs.s_useLocalVerify = gbs.s_useComprehensiveFrameInvalidation = False
+        gbs.s_numOptPerResidualRemoval = 2
+        gas.s_colorFilter, gas.s_numSolveFramesBeforeExit = True, 2
     frames = [synth.scene_room(3 * k, W, H) for k in range(NF)]
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
@@ -1189,6 +1199,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
 
     solved = reintegrated = False
     volume_checks = [0, 0]
+    capped = [0]
     n_ops = [0, 0]
     for i in range(NF + 5):
         if i < NF:
@@ -1231,9 +1242,15 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         # the operations scheduled in this frame: same kinds and frames.  (Inside one frame they are ordered by the pose distance, which the
         # two solvers' 1e-4 differences may permute: compared as sorted lists.)
         new_r, new_o = ref_ops[n_ops[0]:], op.integrate_ops[n_ops[1]:]
-        assert sorted((k, f) for k, f, _ in new_r) == sorted((k, f) for k, f, _ in new_o), (i, [(k, f) for k, f, _ in new_r], [(k, f) for k, f, _ in new_o])
-        by_r = {(k, f): T for k, f, T in new_r}
-        assert all(close(by_r[(k, f)], T) for k, f, T in new_o), i
+        assert sorted(k for k, _, _ in new_r) == sorted(k for k, _, _ in new_o), i                 # as many operations of each kind
+        if sorted((k, f) for k, f, _ in new_r) == sorted((k, f) for k, f, _ in new_o):
+            by_r = {(k, f): T for k, f, T in new_r}
+            assert all(close(by_r[(k, f)], T) for k, f, T in new_o), i
+        else:
+            # more candidates than s_maxFrameFixes: WHICH of two frames with nearly the same pose distance makes the cut may differ; they
+            # are served in the next frames (checked over the whole run below)
+            assert len(new_o) >= 2 * gas.s_maxFrameFixes, (i, [(k, f) for k, f, _ in new_r], [(k, f) for k, f, _ in new_o])
+            capped[0] += 1
         n_ops[:] = [len(ref_ops), len(op.integrate_ops)]
         if with_volume:
             if not reintegrated and not any(k == "de" for k, _, _ in new_o):
@@ -1247,10 +1264,15 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
                 ko, kr = set(_by_key(op.scene.hash(), op.scene.voxels())), set(_by_key(rsc.hash(), rsc.voxels()))
                 assert len(ko & kr) >= 0.97 * len(ko | kr) and abs(op.scene.heap_counter() - rsc.heap_counter()) <= 0.03 * len(ko), i
                 volume_checks[1] += 1
-    assert op.glob.num_images >= 3 and op.num_complete >= 2 * S and op.past_end >= 4
+    assert op.glob.num_images >= (2 if scenario == "alt_flags" else 3) and op.num_complete >= 2 * S and op.past_end >= 4
+    if scenario == "alt_flags":
+        assert not op.use_solve and op.glob.use_global_dense          # reached the dense end-of-scan solve and the stop
     if scenario == "tracking_loss":
         assert 0 in op.glob.valid[1:op.glob.num_images] and not np.isfinite(op.complete[5, 0, 0]) and np.isfinite(op.complete[NF - 2, 0, 0])
     assert len(ref_ops) > 10 and {k for k, _, _ in ref_ops} == {"de", "in"}
+    from collections import Counter
+    cr, co = Counter((k, f) for k, f, _ in ref_ops), Counter((k, f) for k, f, _ in op.integrate_ops)
+    assert all(abs(cr[key] - co[key]) <= 1 for key in set(cr) | set(co)) and capped[0] <= 3, (capped, cr - co, co - cr)
     if with_volume:
         assert volume_checks[0] >= 2 * S and volume_checks[1] >= 3, volume_checks
 
