@@ -197,8 +197,9 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_chunk_parallel_schedule(tmp_path):
-    """Chunk-parallel mode across 2 processes (gloo, CPU): local chunks go round robin to the ranks, one all-gather per round of
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_chunk_parallel_schedule(tmp_path, world):
+    """Chunk-parallel mode across 2 and 4 processes (gloo, CPU): local chunks go round robin to the ranks, one all-gather per round of
     `world` chunks delivers every package to every rank in owner order, and every rank then walks ALL frames in stream order with
     the package of the frame's chunk (fake worker / pipeline objects record the schedule)."""
     script = tmp_path / "chunk_worker.py"
@@ -208,14 +209,16 @@ def test_two_rank_gloo_chunk_parallel_schedule(tmp_path):
         sock.bind(("127.0.0.1", 0))
         port = str(sock.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                           "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = sorted(l.split()[1:] for l in out.stdout.splitlines() if l.startswith("CHUNKS"))
-    assert len(rows) == 2
+    assert len(rows) == world
     assert all(r[1] == "1" and r[2] == "1" for r in rows)                    # every frame once, in order, with the right package and local index
-    assert rows[0][3] == "0,2,4" and rows[1][3] == "1,3,5"                   # round robin (chunk 5 lies beyond the stream's 5 chunks but inside the last round)
-    assert all(r[4] == "3" and r[5] == "61" for r in rows)                   # 3 rounds = 3 collectives; the stream is extended to complete the last round
+    rounds = -(-5 // world)                                                  # 5 local chunks of the stream; the last round may reach beyond them
+    for rank, r in enumerate(rows):
+        assert r[3] == ",".join(str(rank + k * world) for k in range(rounds))      # round robin inside rounds of `world` chunks
+        assert r[4] == str(rounds) and r[5] == str(rounds * world * 10 + 1)  # one collective per round; the stream is extended to complete the last round
 
 
 def test_cpp_header_classes_compile_and_link(built, tmp_path):
