@@ -1092,7 +1092,7 @@ _LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="minut
 
 
 @pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=_LONG), pytest.param("default_submap", marks=_LONG),
-                                      pytest.param("alt_flags", marks=_LONG)])
+                                      "alt_flags"])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
     CUDASolverBundling.cpp / CUDACache.cpp / TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
@@ -1269,7 +1269,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         assert not op.use_solve and op.glob.use_global_dense          # reached the dense end-of-scan solve and the stop
     if scenario == "tracking_loss":
         assert 0 in op.glob.valid[1:op.glob.num_images] and not np.isfinite(op.complete[5, 0, 0]) and np.isfinite(op.complete[NF - 2, 0, 0])
-    assert len(ref_ops) > 10 and {k for k, _, _ in ref_ops} == {"de", "in"}
+    assert len(ref_ops) > (3 if scenario == "alt_flags" else 10) and {k for k, _, _ in ref_ops} == {"de", "in"}
     from collections import Counter
     cr, co = Counter((k, f) for k, f, _ in ref_ops), Counter((k, f) for k, f, _ in op.integrate_ops)
     assert all(abs(cr[key] - co[key]) <= 1 for key in set(cr) | set(co)) and capped[0] <= 3, (capped, cr - co, co - cr)
