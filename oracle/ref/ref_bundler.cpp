@@ -115,6 +115,18 @@ void ref_bundler_get_cache_frame(ref_bundler* h, unsigned int i, float* depth, f
     memcpy(depth, f.d_depthDownsampled, 4 * n); memcpy(campos4, f.d_cameraposDownsampled, 16 * n); memcpy(intensity, f.d_intensityDownsampled, 4 * n);
     memcpy(derivs2, f.d_intensityDerivsDownsampled, 8 * n); memcpy(normals4, f.d_normalsDownsampled, 16 * n);
 }
+void* ref_bundler_sift_manager(ref_bundler* h) { return h->b->m_siftManager; }
+void* ref_bundler_cuda_cache(ref_bundler* h) { return h->b->m_cudaCache; }
+// all key points of the manager as the evaluator sees them (getSIFTKeyPointsDEBUG: the packed array)
+unsigned int ref_bundler_get_all_keys(ref_bundler* h, float* keys4, unsigned int capacity) {
+    unsigned int n = 0;
+    for (unsigned int k : h->b->m_siftManager->m_numKeyPointsPerImage) n += k;
+    memcpy(keys4, h->b->m_siftManager->d_keyPoints, sizeof(SIFTKeyPoint) * (size_t)std::min(n, capacity));
+    return n;
+}
+// a ref_siftmgr view (ref_siftmgr.cpp) of the bundler's manager, for the raw / filtered match accessors; free() it
+struct ref_siftmgr { SIFTImageManager* m; unsigned int maxImages, maxKeys; CUDACachedFrame* frames; };
+ref_siftmgr* ref_bundler_siftmgr_view(ref_bundler* h) { ref_siftmgr* v = (ref_siftmgr*)calloc(1, sizeof(ref_siftmgr)); v->m = h->b->m_siftManager; return v; }
 void ref_bundler_cache_intrinsics(ref_bundler* h, float* K16) { memcpy(K16, h->b->m_cudaCache->getIntrinsics().matrix, 64); }
 
 }

@@ -25,5 +25,9 @@ struct DepthImage32 {
     float* getData() { return d.data(); }
     size_t getNumPixels() const { return d.size(); }
     float& operator()(unsigned int x, unsigned int y) { return d[(size_t)y * w + x]; }
+    const float& operator()(unsigned int x, unsigned int y) const { return d[(size_t)y * w + x]; }
+    unsigned int getWidth() const { return w; }
+    unsigned int getHeight() const { return h; }
+    void setPixels(float v) { for (float& e : d) e = v; }
 };
 #endif

@@ -33,6 +33,7 @@ static const float PIf = 3.14159265358979323846f;
 template <class T> inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 template <class T> inline T clamp(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline int round(float f) { return f > 0.0f ? (int)floorf(f + 0.5f) : (int)ceilf(f - 0.5f); }
 inline float radiansToDegrees(float r) { return r * (180.0f / PIf); }
 inline float degreesToRadians(float d) { return d * (PIf / 180.0f); }
 }  // namespace math
@@ -50,6 +51,7 @@ typedef point2d<unsigned int> vec2ui;
 typedef point2d<int> vec2i;
 typedef point2d<float> vec2f;
 typedef unsigned long long UINT64;
+namespace math { inline int round(float f); inline vec2i round(const vec2f& v); }
 template <class T> inline std::ostream& operator<<(std::ostream& s, const point2d<T>& v) { return s << v.x << " " << v.y; }
 
 struct vec3f {
@@ -65,6 +67,7 @@ struct vec3f {
     vec3f operator-() const { return vec3f(-x, -y, -z); }
     vec3f operator*(float s) const { return vec3f(x * s, y * s, z * s); }
     vec3f operator/(float s) const { return vec3f(x / s, y / s, z / s); }
+    vec3f operator-(float s) const { return vec3f(x - s, y - s, z - s); }
     vec3f& operator+=(const vec3f& o) { x += o.x; y += o.y; z += o.z; return *this; }
     vec3f& operator-=(const vec3f& o) { x -= o.x; y -= o.y; z -= o.z; return *this; }
     vec3f& operator*=(float s) { x *= s; y *= s; z *= s; return *this; }
@@ -89,6 +92,12 @@ struct vec4f {
     union { struct { float x, y, z, w; }; float array[4]; };
     vec4f() : x(0), y(0), z(0), w(0) {}
     explicit vec4f(float v) : x(v), y(v), z(v), w(v) {}
+    vec4f(const vec3f& v, float ww) : x(v.x), y(v.y), z(v.z), w(ww) {}
+    vec3f getVec3() const { return vec3f(x, y, z); }
+    vec4f operator-(const vec4f& o) const { return vec4f(x - o.x, y - o.y, z - o.z, w - o.w); }
+    float operator|(const vec4f& o) const { return x * o.x + y * o.y + z * o.z + w * o.w; }
+    float lengthSq() const { return x * x + y * y + z * z + w * w; }
+    float length() const { return sqrt(lengthSq()); }
     vec4f(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
     float& operator[](unsigned int i) { return array[i]; }
     const float& operator[](unsigned int i) const { return array[i]; }
@@ -159,6 +168,10 @@ struct mat4f {
             r(i, j) = (*this)(i, 0) * o(0, j) + (*this)(i, 1) * o(1, j) + (*this)(i, 2) * o(2, j) + (*this)(i, 3) * o(3, j);
         return r;
     }
+    vec4f operator*(const vec4f& v) const {
+        return vec4f(matrix[0] * v.x + matrix[1] * v.y + matrix[2] * v.z + matrix[3] * v.w, matrix[4] * v.x + matrix[5] * v.y + matrix[6] * v.z + matrix[7] * v.w,
+                     matrix[8] * v.x + matrix[9] * v.y + matrix[10] * v.z + matrix[11] * v.w, matrix[12] * v.x + matrix[13] * v.y + matrix[14] * v.z + matrix[15] * v.w);
+    }
     vec3f operator*(const vec3f& p) const {      // affine transform of a point
         return vec3f(matrix[0] * p.x + matrix[1] * p.y + matrix[2] * p.z + matrix[3], matrix[4] * p.x + matrix[5] * p.y + matrix[6] * p.z + matrix[7],
                      matrix[8] * p.x + matrix[9] * p.y + matrix[10] * p.z + matrix[11]);
@@ -217,6 +230,9 @@ template <class T> struct BaseImage {
     unsigned int getWidth() const { return w; }
     unsigned int getHeight() const { return h; }
     T& operator()(unsigned int x, unsigned int y) { return d[(size_t)y * w + x]; }
+    const T& operator()(unsigned int x, unsigned int y) const { return d[(size_t)y * w + x]; }
+    void allocate(unsigned int width, unsigned int height) { w = width; h = height; d.assign((size_t)w * h, T()); }
+    void setPixels(const T& v) { for (T& e : d) e = v; }
     void setInvalidValue(const T&) {}
     Pixel* begin() { return nullptr; }
     Pixel* end() { return nullptr; }
@@ -224,6 +240,7 @@ template <class T> struct BaseImage {
 struct vec4uc { unsigned char x = 0, y = 0, z = 0, w = 0; };
 typedef BaseImage<float> ColorImageR32;
 typedef BaseImage<vec3f> ColorImageR32G32B32;
+typedef BaseImage<vec3f> PointImage;
 typedef BaseImage<vec4f> ColorImageR32G32B32A32;
 typedef BaseImage<vec4uc> ColorImageR8G8B8A8;
 struct PointCloudf { std::vector<vec3f> m_points, m_normals; std::vector<vec4f> m_colors; };        // debug dumps (shape only)
@@ -262,6 +279,7 @@ inline std::ostream& operator<<(std::ostream& s, const vec3f& v) { return s << v
 inline std::ostream& operator<<(std::ostream& s, const vec4f& v) { return s << v.x << " " << v.y << " " << v.z << " " << v.w; }
 inline std::ostream& operator<<(std::ostream& s, const vec3i& v) { return s << v.x << " " << v.y << " " << v.z; }
 inline std::ostream& operator<<(std::ostream& s, const mat4f& m) { for (int i = 0; i < 16; ++i) s << m.matrix[i] << (i % 4 == 3 ? "\n" : " "); return s; }
+namespace math { inline vec2i round(const vec2f& v) { return vec2i(round(v.x), round(v.y)); } }
 }  // namespace ml
 using namespace ml;        // as the reference's mLib.h does
 #endif

@@ -5,9 +5,11 @@ only (used by tests/test_evaluator_gpu.py).  Paths relative to /root/reference/F
   has_gt_overlap      computeOverlap (.cpp:226-250) + the threshold of computeCachedData (.cpp:39-43)
   evaluate            evaluate (.cpp:47-96)
 
-parity unpinned: CorrespondenceEvaluator.cpp needs mLib (DepthImage32, mat4f, PointCloudIOf; the submodule is absent from the
-reference tree), so it cannot be compiled into oracle/_ref; mat4f * vec4f is taken as the row sums in index order, vec3f's default
-constructor as (0,0,0), math::round as floor(x + 0.5).
+Pinned to the reference's CorrespondenceEvaluator.cpp compiled as it is (oracle/ref/ref_evaluator.cpp, tests/test_ref_pin_cpu.py::
+test_correspondence_evaluator_vs_reference_class): overlap flags and (numCorrect, numDetected, numTotal) equal.  The class works on mLib
+types (the submodule is absent from the reference tree) which oracle/ref/shim/mlib_standin.h supplies as plain containers; three mLib
+conventions remain assumptions on both sides: mat4f * vec4f is taken as the row sums in index order, vec3f's default constructor as
+(0,0,0), math::round as round-half-away-from-zero (floor(x + 0.5) here: the two differ only for negative exact halves, which are outside the image anyway).
 """
 import numpy as np
 

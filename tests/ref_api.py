@@ -811,3 +811,82 @@ def ray_cast_params_from_global_app_state(gas, intrinsics):
                                                     C.c_float(gas.s_SDFRayThresDistFactor), C.c_int(int(gas.s_SDFUseGradients)), C.c_uint32(gas.s_hashNumSDFBlocks),
                                                     _fp(_f32(intrinsics).reshape(16)), C.byref(p))
     return p
+
+
+class RefBundler:
+    """A reference Bundler of its own (Bundler.cpp compiled as it is): detect / cache / match-and-filter one image set.  set_reference_state first."""
+
+    def __init__(self, max_images, max_keys, sift_intrinsics, width, height, depth_intrinsics, is_local, min_key_scale):
+        L = lib()
+        L.ref_bundler_create.restype = C.c_void_p
+        Ks = _f32(sift_intrinsics).reshape(16)
+        Ki = _f32(np.linalg.inv(np.asarray(sift_intrinsics, np.float64))).reshape(16)
+        L.ref_set_sift_camera(width, height, width, height, _fp(Ks), C.c_float(min_key_scale))
+        self._h = C.c_void_p(L.ref_bundler_create(max_images, max_keys, _fp(Ki), width, height, _fp(_f32(depth_intrinsics).reshape(16)), int(is_local)))
+        self.W, self.H = width, height
+
+    def add_frame(self, intensity, depth_filt, depth_raw, color):
+        L = lib()
+        i = _f32(intensity).copy(); f = _f32(depth_filt); r = _f32(depth_raw); c = np.ascontiguousarray(color, np.uint8)
+        L.ref_bundler_detect_features(self._h, _fp(i), _fp(f))
+        L.ref_bundler_store_cached_frame(self._h, self.W, self.H, _fp(c), self.W, self.H, _fp(r))
+
+    def match_and_filter(self):
+        L = lib()
+        L.ref_bundler_match_and_filter.restype = C.c_uint32
+        return int(L.ref_bundler_match_and_filter(self._h))
+
+    def num_frames(self):
+        return int(lib().ref_bundler_num_frames(self._h))
+
+    def all_keys(self, capacity=65536):
+        k = np.zeros((capacity, 4), np.float32)
+        L = lib(); L.ref_bundler_get_all_keys.restype = C.c_uint32
+        n = L.ref_bundler_get_all_keys(self._h, _fp(k), capacity)
+        return k[:n].copy()
+
+    def matches_view(self):
+        L = lib(); L.ref_bundler_siftmgr_view.restype = C.c_void_p
+        m = RefSiftManager.__new__(RefSiftManager)
+        m._h = C.c_void_p(L.ref_bundler_siftmgr_view(self._h)); m._keep = []
+        return m
+
+    def cache_frame_depth(self, i, w, h):
+        d = np.zeros((h, w), np.float32); p4 = np.zeros((h, w, 4), np.float32); it = np.zeros((h, w), np.float32); dv = np.zeros((h, w, 2), np.float32)
+        n4 = np.zeros((h, w, 4), np.float32); wh = np.zeros(2, np.uint32)
+        lib().ref_bundler_get_cache_frame(self._h, i, _fp(d), _fp(p4), _fp(it), _fp(dv), _fp(n4), _fp(wh))
+        assert (int(wh[0]), int(wh[1])) == (w, h)
+        return d
+
+    def cache_intrinsics(self):
+        K = np.zeros((4, 4), np.float32)
+        lib().ref_bundler_cache_intrinsics(self._h, _fp(K))
+        return K
+
+    def handles(self):
+        L = lib()
+        L.ref_bundler_sift_manager.restype = C.c_void_p; L.ref_bundler_cuda_cache.restype = C.c_void_p
+        return C.c_void_p(L.ref_bundler_sift_manager(self._h)), C.c_void_p(L.ref_bundler_cuda_cache(self._h))
+
+
+class RefCorrespondenceEvaluator:
+    """The reference's CorrespondenceEvaluator (CorrespondenceEvaluator.cpp compiled as it is) on a RefBundler's manager and cache."""
+
+    def __init__(self, trajectory, log_prefix=""):
+        L = lib(); L.ref_evaluator_create.restype = C.c_void_p
+        T = _f32(trajectory).reshape(-1, 16)
+        self._h = C.c_void_p(L.ref_evaluator_create(_fp(T), len(T), log_prefix.encode()))
+
+    def evaluate(self, bundler, sift_intrinsics_inv, filtered, recompute, clear, corr_type):
+        mgr, cache = bundler.handles()
+        out = np.zeros(3, np.uint32)
+        lib().ref_evaluator_evaluate(self._h, mgr, cache, _fp(_f32(sift_intrinsics_inv).reshape(16)), int(filtered), int(recompute), int(clear), corr_type.encode(), _fp(out))
+        return tuple(int(x) for x in out)
+
+    def has_gt_overlap(self, n):
+        v = np.zeros(n, np.uint8)
+        lib().ref_evaluator_has_gt_overlap(self._h, _fp(v), n)
+        return v.astype(bool)
+
+    def finish(self):
+        lib().ref_evaluator_finish_logging(self._h)

@@ -1309,3 +1309,65 @@ def test_image_manager_resample_branch_vs_reference_class(oracle):
         vi = np.isfinite(od)
         assert np.array_equal(np.isfinite(r_di), vi) and np.abs(r_di[vi] - od[vi]).max() <= 3e-6 * np.abs(od[vi]).max()      # ... = the oracle's frame up to exp()
         assert _same(r_ci.reshape(oc.shape), oc)
+
+
+def test_correspondence_evaluator_vs_reference_class(oracle, tmp_path):
+    """f4: the reference's CorrespondenceEvaluator.cpp (compiled as it is) on the key points, the current raw / filtered matches and the
+    cached frames of a reference Bundler after its matchAndFilter, against tests/oracle_eval.py - the restatement the product's evaluator is
+    held to on the GPU: ground-truth overlap per previous frame, and (numCorrect, numDetected, numTotal) for the raw and the filtered
+    matches, with one reference pose falsified so that correct, incorrect and undetected pairs all occur."""
+    from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, rgbx_to_intensity
+    from tests.oracle_pipeline import OraclePipeline
+    from tests import oracle_eval as oe
+    W, H, n = 320, 240, 4
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
+    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 4, 10
+    frames = [synth.scene_room(4 * k, W, H) for k in range(n)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    op = OraclePipeline(gas, gbs, W, H, K)                                   # for its ingest only
+    ref_api.set_reference_state(gas, gbs)
+    rb = ref_api.RefBundler(11, gbs.s_maxNumKeysPerImage, K, W, H, K, True, gbs.s_minKeyScale)
+    for i, (d, c, _, _) in enumerate(frames):
+        raw, filt = op._ingest(d, c)
+        rb.add_frame(rgbx_to_intensity(c), filt, raw, c)
+        if i > 0:
+            assert rb.match_and_filter() != 0xFFFFFFFF
+    cur = n - 1
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    traj = np.stack([(T0inv @ f[2].astype(np.float64)).astype(np.float32) for f in frames])
+    Ry = np.array([[0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 0, 1]], np.float32)
+    traj[1] = Ry @ traj[1]; traj[1, 1, 3] += 0.7                             # a wrong reference pose for image 1 (turned by 90 degrees and lifted)
+    ev = ref_api.RefCorrespondenceEvaluator(traj, str(tmp_path / "corr"))
+    Kinv = oracle.inverse44(K)
+    r_raw = ev.evaluate(rb, Kinv, False, True, False, "raw")
+    r_gt = ev.has_gt_overlap(n)
+    r_filt = ev.evaluate(rb, Kinv, True, False, True, "dense")
+    ev.finish()
+    # the same through the restatement, on the reference bundler's data
+    gw, gh = gbs.s_downsampledWidth, gbs.s_downsampledHeight
+    Kc = rb.cache_intrinsics(); Kci = oracle.inverse44(Kc)
+    depths = [rb.cache_frame_depth(i, gw, gh) for i in range(n)]
+    has_gt = np.zeros(n, bool)
+    for p in range(cur):
+        Tcp = oracle.mul44(oracle.inverse44(traj[p]), traj[cur])
+        c = oe.overlap_counts(depths[cur], depths[p], Tcp, oracle.inverse44(Tcp), Kc, Kci, gbs.s_denseDepthMin, gbs.s_denseDepthMax, gbs.s_projCorrDistThres,
+                              gbs.s_projCorrNormalThres)
+        has_gt[p] = oe.has_gt_overlap(c)
+    assert np.array_equal(has_gt, r_gt), (has_gt, r_gt)
+    assert has_gt[0] and has_gt[2] and not has_gt[1]
+    keys = rb.all_keys()
+    view = rb.matches_view()
+    for filtered, expect in ((False, r_raw), (True, r_filt)):
+        slots = 25 if filtered else 128
+        idx = np.zeros((n, slots, 2), np.uint32); num = np.zeros(n, np.int64)
+        for p in range(cur):
+            r = view.filtered(p) if filtered else view.raw(p)
+            num[p] = r[0]; idx[p] = r[1]
+        (correct, detected, total), worst = oe.evaluate(keys, idx, num, has_gt, traj, cur, Kinv)
+        assert (correct, detected, total) == expect, (filtered, (correct, detected, total), expect)
+    assert r_raw[2] == 2 and r_raw[1] >= 1 and r_filt[0] >= 1
+    rows = open(str(tmp_path / "corr") + "_frame.csv").read().splitlines()
+    assert rows[0] == "numFrames,curFrame,type,precision,recall,numCorrect,numDetected,numTotal" and len(rows) == 3
