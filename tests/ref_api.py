@@ -510,7 +510,7 @@ class RefTrajectoryManager:
         self._h = C.c_void_p(L.ref_tm_create(C.c_uint32(n_max), C.c_uint32(top_n), C.c_float(min_dist)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().ref_tm_destroy(self._h)
 
     def add(self, typ, T, idx):
