@@ -1,8 +1,8 @@
 """Writes tests/golden/oracle_snapshot.json: digests of what the CPU oracle frame loop produces on the 13-frame synthetic sequence
 of tests/test_pipeline_oracle.py (poses, hash table, voxels, operation log).
 
-This pins the ORACLE against accidental change between rounds.  It is NOT output of the reference (which cannot be built or run
-here): parity with the reference remains unpinned.
+This pins the ORACLE against accidental change between rounds.  It is NOT output of the reference: for that see reference_first_chunk.npz /
+make_reference_golden.py next to this file and tests/test_ref_pin_cpu.py.
 
 usage:  python tests/golden/make_oracle_snapshot.py        (from the repository root, after build())
 """

@@ -1,6 +1,6 @@
 """CPU tests (-m "not gpu"): descriptor matching + match filters of the oracle.
 
-PARITY UNPINNED (the reference holds no fixtures).  Pinned here against independent numpy / float64
+Independent sanity of the oracle (its pin against the reference's own kernels is tests/test_ref_pin_cpu.py).  Checked here against independent numpy / float64
 evaluations: the McAdams SVD reconstructs its input, Kabsch recovers a known rigid motion, the matcher
 finds a planted permutation and applies distance / ratio / mutual tests, the greedy Kabsch filter keeps
 inliers and rejects a planted outlier, and the SIFT -> match -> filter chain on two synthetic frames

@@ -38,7 +38,7 @@ def run_oracle_sequence():
 
 def snapshot(op):
     """Digest of what the oracle frame loop produced (tests/golden/oracle_snapshot.json is written from this by
-    tests/golden/make_oracle_snapshot.py).  It is a regression pin of the ORACLE, not reference output: parity stays unpinned."""
+    tests/golden/make_oracle_snapshot.py).  It is a regression pin of the ORACLE, not reference output (for that: tests/test_ref_pin_cpu.py, tests/test_golden_ref_cpu.py)."""
     traj = op.integrated_trajectory()
     h = op.scene.hash()
     return {

@@ -1,6 +1,6 @@
 """CPU tests (-m "not gpu"): SIFT oracle sanity + the deterministic elementary functions.
 
-PARITY UNPINNED (no golden vectors in the reference).  Pinned here: the pyramid against a direct numpy
+Independent sanity of the oracle (its pin against the reference's own SiftGPU fork is tests/test_ref_pin_cpu.py).  Checked here: the pyramid against a direct numpy
 convolution with the same taps, descriptor normalisation (|d| = 512 +- rounding), detection gated by
 valid depth, keypoints invariant under an integer image shift (structure-level repeatability).
 """

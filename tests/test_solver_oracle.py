@@ -1,6 +1,6 @@
 """CPU tests (-m "not gpu"): SE(3) maps, image operators and the bundling-solver oracle.
 
-No golden vectors exist in the reference (PARITY UNPINNED); the oracle is pinned here against independent
+Independent sanity of the oracle (its pin against the reference's own code is tests/test_ref_pin_cpu.py); the oracle is checked here against independent
 maths: scipy rotations for exp/log, numpy.linalg for the Gauss-Newton optimum (the sparse energy is a
 sum of squared 3-vectors, so the solver must drive it to the noise floor and recover the ground-truth
 poses), a finite-difference check of the dense Jacobians through the energy decrease.

@@ -1,6 +1,6 @@
 """CPU tests (-m "not gpu"): the TSDF oracle against independent restatements and invariants.
 
-The reference ships no golden vectors — parity is UNPINNED; what can be pinned
+The reference ships no golden vectors; the oracle's pin against the reference's own code is tests/test_ref_pin_cpu.py.  What can be checked
 on the CPU is (a) the integer maps against a pure-Python big-int restatement of
 VoxelUtilHashSDF.h:226-299, (b) debugHash()'s heap/hash invariants (CUDASceneRepHashSDF.h:179-314),
 (c) size-independent properties: integrate -> de-integrate restores an empty volume, GC returns
