@@ -7,8 +7,11 @@
 // function cites the file:line it follows (paths relative to /root/reference/FriedLiver/Source).
 // PINNING: the reference (niessner/BundleFusion) ships no golden vectors and no tests, and its
 // application cannot be built here (CUDA 7 + Windows/DirectX + un-vendored mLib) - but its
-// DEVICE code can: oracle/ref/Makefile compiles it for the host into oracle/_ref/libbfref.so and
-// tests/test_ref_pin_cpu.py compares this oracle with it on the same inputs.  Pinned that way:
+// DEVICE code and the HOST classes of this path can: oracle/ref/Makefile compiles them for the host into
+// oracle/_ref/libbfref.so and tests/test_ref_pin_cpu.py compares this oracle with it on the same inputs (the host
+// classes - CUDAImageManager, OnlineBundler, Bundler, SBA, CUDASolverBundling, CUDACache, TrajectoryManager,
+// CUDASceneRepHashSDF, CorrespondenceEvaluator - end to end against tests/oracle_pipeline.py; golden vectors written by
+// that build are in tests/golden/).  Pinned per stage:
 // the integer maps, SE(3), SVD / Kabsch / greedy Kabsch filter, TSDF operators, image operators
 // and the cache frame, the GN/PCG solver, marching cubes, the ray-cast kernel, the whole SiftGPU
 // fork (pyramid, detection, descriptors, matcher) and the match-filter chain of SIFTImageManager.cu.
