@@ -1073,6 +1073,14 @@ class RayCastData(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("d_depth", "d_depth4", "d_normals", "d_colors", "d_rayIntervalSplatMin", "d_rayIntervalSplatMax")]
 
 
+def write_processed_summary(path, heap_free_count, optimized_trajectory, aborted=False):
+    """processed.txt of StopScanningAndExit (DepthSensing.cpp:921-957) -> the `valid` verdict"""
+    T = np.ascontiguousarray(optimized_trajectory, np.float32).reshape(-1, 16)
+    v = C.c_int()
+    check(lib.bf_write_processed_summary(str(path).encode(), C.c_uint32(int(heap_free_count)), T.ctypes.data_as(C.c_void_p), C.c_uint32(len(T)), int(aborted), C.byref(v)))
+    return bool(v.value)
+
+
 def ray_cast_params_from_global_app_state(gas, intrinsics):
     """CUDARayCastSDF::parametersFromGlobalAppState (CUDARayCastSDF.h:24-52)"""
     p = RayCastParams()

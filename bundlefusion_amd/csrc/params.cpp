@@ -3,6 +3,9 @@
 // X-macro readers GlobalAppState.h:128-136 / GlobalBundlingState.h:90-98): one `name = value;` per line, `//` starts a
 // comment, values are booleans (true/false), numbers with an optional f suffix, quoted strings, or space separated
 // vectors.  Unknown names are ignored; names that never appear keep the default and are counted as missing.
+#include <cstdio>
+#include <limits>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -191,6 +194,24 @@ int bf_global_bundling_state_read(const char* filename, bf_global_bundling_state
     Reader r(kv);
     readBundling(r, *out);
     if (numMissing) *numMissing = r.missing;
+    return BF_OK;
+}
+
+int bf_write_processed_summary(const char* path, uint32_t heapFreeCount, const float* T, uint32_t numTransforms, int aborted, int* validOut) {      // DepthSensing.cpp:921-957
+    BF_REQUIRE(path && (T || numTransforms == 0 || aborted), "null argument");
+    FILE* f = fopen(path, "w");
+    if (!f) { bf::set_error("cannot write %s", path); return BF_ERR_INVALID_ARG; }
+    bool valid = false;
+    if (aborted) fprintf(f, "valid = false\nABORTED\n");
+    else {
+        valid = heapFreeCount >= 800;                                        // "probably a messed up reconstruction (used up all the heap...)"
+        uint32_t numValid = 0;
+        for (uint32_t i = 0; i < numTransforms; ++i) if (T[16 * (size_t)i] != -std::numeric_limits<float>::infinity()) ++numValid;      // PoseHelper::countNumValidTransforms
+        if (numValid < (uint32_t)std::lround(0.5f * (float)numTransforms)) valid = false;
+        fprintf(f, "valid = %s\nheapFreeCount = %u\nnumValidOptTransforms = %u\nnumTransforms = %u\n", valid ? "true" : "false", heapFreeCount, numValid, numTransforms);
+    }
+    fclose(f);
+    if (validOut) *validOut = valid ? 1 : 0;
     return BF_OK;
 }
 

@@ -78,6 +78,11 @@ BF_API int bf_global_app_state_default(bf_global_app_state* out);
 BF_API int bf_global_bundling_state_default(bf_global_bundling_state* out);
 /* CUDARayCastSDF::parametersFromGlobalAppState(gas, intrinsics, intrinsicsInv)  CUDARayCastSDF.h:24-52: intrinsics = those of the
  * integration images; they are rescaled when the ray cast size differs (same rule as the image manager). */
+/* The confirmation file the application writes when a scan ends (StopScanningAndExit, DepthSensing.cpp:921-957): `valid = true|false`
+ * (false when fewer than 800 SDF blocks are left on the heap, or fewer than round(0.5 n) of the n optimised transforms are valid, i.e. not
+ * -inf), heapFreeCount, numValidOptTransforms, numTransforms; with `aborted`: `valid = false` + `ABORTED` (invalid first chunk).  Host only.
+ * h_optimizedTrajectory = TrajectoryManager::getOptimizedTransforms (n x 16 floats). */
+BF_API int bf_write_processed_summary(const char* path, uint32_t heapFreeCount, const float* h_optimizedTrajectory, uint32_t numTransforms, int aborted, int* validOut);
 BF_API int bf_ray_cast_params_from_global_app_state(const bf_global_app_state* gas, const float intrinsics[16], bf_ray_cast_params* out);
 /* GlobalAppState::readMembers(ParameterFile) GlobalAppState.h:128-136 / GlobalBundlingState.h:90-98.  Starts from
  * the defaults; *numMissing (optional) counts fields that the file did not set (the reference warns per field). */

@@ -174,6 +174,14 @@ private:
     unsigned int m_numRecorded = 0;
 };
 
+// ---- the confirmation file of StopScanningAndExit (DepthSensing.cpp:921-957): processed.txt next to the processed sequence; returns `valid`
+inline bool writeProcessedSummary(const std::string& path, unsigned int heapFreeCount, const std::vector<mat4f>& optimizedTrajectory, bool aborted = false) {
+    int valid = 0;
+    check(bf_write_processed_summary(path.c_str(), heapFreeCount, optimizedTrajectory.empty() ? nullptr : optimizedTrajectory[0].m,
+                                             (uint32_t)optimizedTrajectory.size(), aborted ? 1 : 0, &valid));
+    return valid != 0;
+}
+
 // ---- PoseHelper (PoseHelper.h:8-166): trajectory bookkeeping and evaluation on the host
 namespace PoseHelper {
 inline unsigned int countNumValidTransforms(const std::vector<mat4f>& trajectory) {

@@ -483,3 +483,19 @@ def test_chunked_runner_local_half_runs_ahead_and_fails_loudly():
     with pytest.raises(RuntimeError, match="chunk 2"):
         r.advance(len(feed))
     assert max(f for f, _, _ in r.pipe.log) <= 2 * S         # nothing of chunk 2 was consumed
+
+
+def test_processed_summary_file(built, tmp_path):
+    """processed.txt as StopScanningAndExit writes it (DepthSensing.cpp:921-957): the validity rule and the four lines."""
+    from bundlefusion_amd.capi import write_processed_summary
+    T = np.tile(np.eye(4, dtype=np.float32), (7, 1, 1))
+    T[4:] = -np.inf                                                      # 4 of 7 valid: 4 >= round(3.5) = 4
+    p = tmp_path / "processed.txt"
+    assert write_processed_summary(p, 12345, T) is True
+    assert p.read_text() == "valid = true\nheapFreeCount = 12345\nnumValidOptTransforms = 4\nnumTransforms = 7\n"
+    T[3] = -np.inf                                                       # 3 of 7: not enough valid transforms
+    assert write_processed_summary(p, 12345, T) is False and p.read_text().startswith("valid = false\nheapFreeCount = 12345\nnumValidOptTransforms = 3\n")
+    T[3] = np.eye(4)
+    assert write_processed_summary(p, 799, T) is False                   # the heap is (almost) used up
+    assert write_processed_summary(p, 800, T) is True
+    assert write_processed_summary(p, 5000, T, aborted=True) is False and p.read_text() == "valid = false\nABORTED\n"
