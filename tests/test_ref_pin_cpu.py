@@ -1091,7 +1091,7 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
 _LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)")
 
 
-@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=_LONG), pytest.param("default_submap", marks=_LONG),
+@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=_LONG), pytest.param("default_submap", marks=_LONG), pytest.param("revisit", marks=_LONG),
                                       "alt_flags"])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
@@ -1105,6 +1105,9 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     sides - the reference's CUDASceneRepHashSDF host class over its own kernels against the oracle volume: allocated keys, bucket occupancy,
     free list and every voxel byte identical while the poses are identical bit for bit (up to the first re-integration), the same blocks up
     to a 3 % fringe afterwards.
+    Scenario "revisit": 16 frames over the same seven views twice (the jump back after view 6 is one large step): the global key frames of the
+    second pass match key frames of the first pass that are not their predecessors - loop-closure correspondences in the global problem and the
+    re-initialisation of the global pose from the last MATCHED key frame (Bundler.cpp:205-210).
     Scenario "alt_flags": no erosion / depth filter (the integration frame is then the raw sensor depth), intensity filter on, no local
     verification, simple frame invalidation, residual removal every second solve, and s_numSolveFramesBeforeExit = 2 so that the run reaches
     the end-of-scan switch to the dense global solve (setSolveWeights: sparse 1, dense depth 15) and the stop of the solver.
@@ -1117,6 +1120,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     from tests.oracle_pipeline import OraclePipeline, NINF, _minf
     W, H, S = 320, 240, 3
     NF, dark, TOL = (10, range(0), 5e-4) if scenario == "three_chunks" else (16, range(4, 9), 1e-2)
+    if scenario == "revisit":                    # the camera goes over the same seven views twice: key frames of the second pass match those of the first
+        NF = 16
     if scenario == "alt_flags":                  # the other side of the switches, and the end-of-scan global dense solve (OnlineBundler.cpp:175-196)
         NF = 7
     if scenario == "default_submap":             # the reference's chunk size (zParametersBundlingDefault.txt: s_submapSize = 10): 31 frames, three chunks of 11
@@ -1131,7 +1136,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         gbs.s_erodeSIFTdepth = gbs.s_depthFilter = gbs.s_useLocalVerify = gbs.s_useComprehensiveFrameInvalidation = False
         gbs.s_numOptPerResidualRemoval = 2
         gas.s_colorFilter, gas.s_numSolveFramesBeforeExit = True, 2
-    frames = [synth.scene_room(3 * k, W, H) for k in range(NF)]
+    frames = [synth.scene_room(3 * (k % 7 if scenario == "revisit" else k), W, H) for k in range(NF)]
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     frames = [((np.full_like(f[0], -np.inf) if k in dark else f[0]), f[1]) for k, f in enumerate(frames)]
@@ -1267,6 +1272,9 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     assert op.glob.num_images >= (2 if scenario == "alt_flags" else 3) and op.num_complete >= 2 * S and op.past_end >= 4
     if scenario == "alt_flags":
         assert not op.use_solve and op.glob.use_global_dense          # reached the dense end-of-scan solve and the stop
+    if scenario == "revisit":
+        gc = op.glob.corr[op.glob.corr["imgIdx_i"] != 0xFFFFFFFF]
+        assert (gc["imgIdx_j"].astype(np.int64) - gc["imgIdx_i"].astype(np.int64)).max() >= 2          # a key frame matched one that is not its predecessor
     if scenario == "tracking_loss":
         assert 0 in op.glob.valid[1:op.glob.num_images] and not np.isfinite(op.complete[5, 0, 0]) and np.isfinite(op.complete[NF - 2, 0, 0])
     assert len(ref_ops) > (3 if scenario == "alt_flags" else 10) and {k for k, _, _ in ref_ops} == {"de", "in"}
