@@ -1,8 +1,8 @@
 // oracle/ref/emu.cpp — see emu.h (test infrastructure only)
 #include "emu.h"
 
-#include <ucontext.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -14,14 +14,40 @@ thread_local dim3 blockDim, gridDim;
 
 namespace {
 enum State { READY, AT_BARRIER, AT_SHFL, DONE };
+// Fiber switch: callee-saved registers + stack pointer (x86-64 System V).  ucontext's swapcontext saves and restores the signal mask with a
+// system call on every switch, which made the switches - one or more per emulated thread - most of the emulator's run time.
+extern "C" void emu_switch(void** saveSp, void* loadSp);
+asm(R"(
+    .text
+    .globl emu_switch
+    .type emu_switch, @function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emu_switch, .-emu_switch
+)");
+
 struct Fiber {
-    ucontext_t ctx; char* stack = nullptr; State state = READY; uint3 tid;
+    void* sp = nullptr; char* stack = nullptr; State state = READY; uint3 tid;
     unsigned shflCount = 0;        // shuffles this fiber has deposited
 };
 struct Block {
     std::vector<Fiber> fibers;
     std::vector<unsigned> xchg;    // [warp][generation & 1][lane]: the values a warp's lanes deposited for a shuffle
-    ucontext_t main;
+    void* mainSp = nullptr;
     int cur = -1;
     const std::function<void()>* body = nullptr;
 };
@@ -41,7 +67,15 @@ void trampoline() {
     Fiber& f = b->fibers[b->cur];
     (*b->body)();
     f.state = DONE;
-    swapcontext(&f.ctx, &b->main);
+    emu_switch(&f.sp, b->mainSp);
+    abort();                                   // a finished fiber is never resumed
+}
+void prepare(Fiber& f) {                       // the first switch into the fiber "returns" into trampoline() with a call-aligned stack
+    void** sp = (void**)(((uintptr_t)(f.stack + STACK)) & ~(uintptr_t)15);
+    *--sp = nullptr;                           // the slot of trampoline's return address (it never returns)
+    *--sp = (void*)&trampoline;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;      // rbp, rbx, r12-r15
+    f.sp = sp;
 }
 
 // all live lanes of fiber i's warp have deposited the shuffle generation fiber i waits for.  `relaxed`: lanes parked at a block barrier
@@ -68,7 +102,7 @@ unsigned shflExchange(unsigned val, int src, int width) {
     b->xchg[(warp * 2 + buf) * WARP + lane] = val;
     f.shflCount++;
     f.state = AT_SHFL;
-    swapcontext(&f.ctx, &b->main);
+    emu_switch(&f.sp, b->mainSp);
     threadIdx = f.tid;
     if (width <= 0 || width > (int)WARP) width = WARP;
     const int seg = (int)lane / width * width;
@@ -87,7 +121,7 @@ void __syncthreads() {
     if (!b || b->cur < 0) return;
     Fiber& f = b->fibers[b->cur];
     f.state = AT_BARRIER;
-    swapcontext(&f.ctx, &b->main);            // resumed when every live fiber of the block has arrived
+    emu_switch(&f.sp, b->mainSp);             // resumed when every live fiber of the block has arrived
     threadIdx = f.tid;
 }
 
@@ -126,9 +160,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                         for (unsigned tx = 0; tx < block.x; ++tx, ++t) {
                             Fiber& f = b.fibers[t];
                             f.state = READY; f.shflCount = 0; f.tid = make_uint3(tx, ty, tz);
-                            getcontext(&f.ctx);
-                            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
-                            makecontext(&f.ctx, trampoline, 0);
+                            prepare(f);
                         }
                 for (;;) {                  // run every runnable fiber up to its next barrier / shuffle (or to its end), in thread-index order
                     bool progress = false;
@@ -141,7 +173,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                         if (f.state == AT_SHFL && !warpReady(b, i)) continue;
                         f.state = READY;
                         b.cur = (int)i; threadIdx = f.tid;
-                        swapcontext(&b.main, &f.ctx);
+                        emu_switch(&b.mainSp, f.sp);
                         progress = true;
                         if (f.state == AT_BARRIER) ++atBarrier;
                     }
@@ -156,7 +188,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                             if (f.state != AT_SHFL || !warpReady(b, i, true)) continue;
                             f.state = READY;
                             b.cur = (int)i; threadIdx = f.tid;
-                            swapcontext(&b.main, &f.ctx);
+                            emu_switch(&b.mainSp, f.sp);
                             progress = true;
                         }
                     }

@@ -270,7 +270,7 @@ def _by_key(hash_np, vox_np):
     return {tuple(int(c) for c in e["pos"]): v[e["ptr"] // VOX_PER_BLOCK] for e in occ}
 
 
-def _assert_same_volume(osc, rsc, nb, what):
+def _assert_same_volume(osc, rsc, nb, what, frustum_list=True):
     oh, rh = osc.hash(), rsc.hash()
     ob, rb = _by_key(oh, osc.voxels()), _by_key(rh, rsc.voxels())
     assert set(ob) == set(rb), what + ": allocated block keys"
@@ -296,6 +296,8 @@ def _assert_same_volume(osc, rsc, nb, what):
         assert not (free & used) and len(free) + len(used) == len(sc.heap())
     # frustum list (compactified hash) as a set of keys
     co, cr = osc.compactified(), rsc.compactified()
+    if not frustum_list:
+        return            # after a garbage collection that no integration follows the reference keeps the (stale) frustum list of the last operator, the oracle refreshes it
     assert osc.num_occupied() == rsc.num_occupied(), what + ": numOccupiedBlocks"
     assert set(map(tuple, co["pos"].tolist())) == set(map(tuple, cr["pos"].tolist())), what + ": frustum list"
 
@@ -1088,11 +1090,7 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ the bundling half of the frame loop
-_LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)")
-
-
-@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=_LONG), pytest.param("default_submap", marks=_LONG), pytest.param("revisit", marks=_LONG),
-                                      "alt_flags"])
+@pytest.mark.parametrize("scenario", ["three_chunks", "tracking_loss", "default_submap", "revisit", "alt_flags"])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
     CUDASolverBundling.cpp / CUDACache.cpp / TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
@@ -1101,7 +1099,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     depth frame stored for integration to the 3e-6 of the exp() difference); the state machine (11 fields of BundlerState) exactly; the pose
     handed to the integration bit for bit until the first global solve and to 5e-4 after it; complete / local / global trajectories 5e-4 (the dense local solve sums in another order; measured 2.6e-4)
     with the same -inf pattern; key-frame counts, key counts, correspondence counts, valid flags exactly; and the operations the
-    TrajectoryManager schedules (kind and frame exactly).  In the "three_chunks" scenario those operations also drive the VOLUME on both
+    TrajectoryManager schedules (kind and frame exactly).  In the "three_chunks", "tracking_loss" and "revisit" scenarios those operations also drive the VOLUME on both
     sides - the reference's CUDASceneRepHashSDF host class over its own kernels against the oracle volume: allocated keys, bucket occupancy,
     free list and every voxel byte identical while the poses are identical bit for bit (up to the first re-integration), the same blocks up
     to a 3 % fringe afterwards.
@@ -1129,7 +1127,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     gas = default_app_state(); gbs = default_bundling_state()
     gas.s_integrationWidth, gas.s_integrationHeight = W, H
     gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
-    with_volume = scenario == "three_chunks"
+    with_volume = scenario in ("three_chunks", "tracking_loss", "revisit")
     gas.s_garbageCollectionEnabled = with_volume
     gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 8, S
     if scenario == "alt_flags":
@@ -1207,6 +1205,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     capped = [0]
     n_ops = [0, 0]
     for i in range(NF + 5):
+        integrated_now = False
         if i < NF:
             d, c = frames[i][0], frames[i][1]
             raw, filt = op._ingest(d, c)
@@ -1233,6 +1232,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
             ref_reintegrate(); op._reintegrate()
             if ok:
                 if with_volume:                  # integrate() of the current frame, DepthSensing.cpp:723-762
+                    integrated_now = True
                     ref_ops.append(("in", i, T)); ref_volume("in", i, T)
                     op._integrate(op.last_processed, op.cur_T[op.last_processed], False)
                 rtm.add(0, T, i); op.tm.add_frame(0, op.cur_T[op.last_processed], i)
@@ -1262,7 +1262,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
                 # every pose so far was identical bit for bit: so is the volume (north_star: bit-exact hash-bucket occupancy and voxel indices)
                 global _hash_fn
                 _hash_fn = oracle.hash_pos
-                _assert_same_volume(op.scene, rsc, gas.s_hashNumBuckets, "frame %d" % i)
+                _assert_same_volume(op.scene, rsc, gas.s_hashNumBuckets, "frame %d" % i, frustum_list=integrated_now)
                 volume_checks[0] += 1
             else:                                # re-integration at poses that differ by 1e-4: the same blocks up to the surface fringe
                 reintegrated = True
