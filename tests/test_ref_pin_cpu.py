@@ -1090,7 +1090,10 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ the bundling half of the frame loop
-@pytest.mark.parametrize("scenario", ["three_chunks", "tracking_loss", "default_submap", "revisit", "alt_flags"])
+_LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="1-2 more minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)")
+
+
+@pytest.mark.parametrize("scenario", ["three_chunks", "tracking_loss", pytest.param("default_submap", marks=_LONG), "revisit", "alt_flags"])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
     CUDASolverBundling.cpp / CUDACache.cpp / TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
