@@ -1093,7 +1093,11 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
 _LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="1-2 more minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)")
 
 
-@pytest.mark.parametrize("scenario", ["three_chunks", "tracking_loss", pytest.param("default_submap", marks=_LONG), "revisit", "alt_flags"])
+_LOOP = pytest.mark.skipif(os.environ.get("BF_LOOP_TEST") != "1", reason="the full 360 degree loop through the emulated reference: about half an hour, BF_LOOP_TEST=1 (log: profiles/r02_ref_pin_loop.txt)")
+
+
+@pytest.mark.parametrize("scenario", ["three_chunks", "tracking_loss", pytest.param("default_submap", marks=_LONG), "revisit", "alt_flags",
+                                      pytest.param("full_loop", marks=_LOOP)])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
     CUDASolverBundling.cpp / CUDACache.cpp / TrajectoryManager.cpp / SIFTImageManager.cpp / SiftGPU fork, all compiled as they are and run on the block emulator, against the
@@ -1106,6 +1110,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     sides - the reference's CUDASceneRepHashSDF host class over its own kernels against the oracle volume: allocated keys, bucket occupancy,
     free list and every voxel byte identical while the poses are identical bit for bit (up to the first re-integration), the same blocks up
     to a 3 % fringe afterwards.
+    Scenario "full_loop" (BF_LOOP_TEST=1): BASELINE configs[2] in small - 212 frames once around the room and into the second lap, chunk size 10,
+    21 key frames, the loop closed by global matches between the last and the first key frames; poses 2e-2 (21 global solves deep).
     Scenario "revisit": 16 frames over the same seven views twice (the jump back after view 6 is one large step): the global key frames of the
     second pass match key frames of the first pass that are not their predecessors - loop-closure correspondences in the global problem and the
     re-initialisation of the global pose from the last MATCHED key frame (Bundler.cpp:205-210).
@@ -1121,6 +1127,9 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     from tests.oracle_pipeline import OraclePipeline, NINF, _minf
     W, H, S = 320, 240, 3
     NF, dark, TOL = (10, range(0), 5e-4) if scenario == "three_chunks" else (16, range(4, 9), 1e-2)
+    stride = 3
+    if scenario == "full_loop":                  # BASELINE configs[2] in small: once around the room (1800 / 9 = 200 frames) and 12 frames into the second lap
+        S, NF, TOL, stride = 10, 212, 2e-2, 9
     if scenario == "revisit":                    # the camera goes over the same seven views twice: key frames of the second pass match those of the first
         NF = 16
     if scenario == "alt_flags":                  # the other side of the switches, and the end-of-scan global dense solve (OnlineBundler.cpp:175-196)
@@ -1132,12 +1141,12 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
     with_volume = scenario in ("three_chunks", "tracking_loss", "revisit")
     gas.s_garbageCollectionEnabled = with_volume
-    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 8, S
+    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, (30 if scenario == "full_loop" else 8), S
     if scenario == "alt_flags":
         gbs.s_erodeSIFTdepth = gbs.s_depthFilter = gbs.s_useLocalVerify = gbs.s_useComprehensiveFrameInvalidation = False
         gbs.s_numOptPerResidualRemoval = 2
         gas.s_colorFilter, gas.s_numSolveFramesBeforeExit = True, 2
-    frames = [synth.scene_room(3 * (k % 7 if scenario == "revisit" else k), W, H) for k in range(NF)]
+    frames = [synth.scene_room(stride * (k % 7 if scenario == "revisit" else k), W, H) for k in range(NF)]
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     frames = [((np.full_like(f[0], -np.inf) if k in dark else f[0]), f[1]) for k, f in enumerate(frames)]
@@ -1174,11 +1183,15 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         if rsc is not None:
             rsc.garbage_collect()
 
+    max_dev = [0.0]
+
     def close(a, b, tol=None):
         tol = TOL if tol is None else tol
         a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
         inf_a, inf_b = a == NINF, b == NINF
-        return np.array_equal(inf_a, inf_b) and (np.abs(np.where(inf_a, 0, a) - np.where(inf_b, 0, b)).max() <= tol if a.size else True)
+        dev = float(np.abs(np.where(inf_a, 0, a) - np.where(inf_b, 0, b)).max()) if a.size else 0.0
+        max_dev[0] = max(max_dev[0], dev)
+        return np.array_equal(inf_a, inf_b) and dev <= tol
 
     def compare(step):
         st = rb.state()
@@ -1196,9 +1209,17 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         if ng:
             assert list(g.valid(ng)) == op.glob.valid[:ng], step
             assert close(g.trajectory(ng), op.glob.trajectory[:ng]), step
-            assert [g.num_keys(i) for i in range(ng)] == [len(k) for k in op.glob.keys[:ng]], step
+            rk, ok_ = [g.num_keys(i) for i in range(ng)], [len(k) for k in op.glob.keys[:ng]]
             rc, oc = g.correspondences(), op.glob.corr
-            assert len(rc) == len(oc) and np.array_equal(rc["imgIdx_i"], oc["imgIdx_i"]) and np.array_equal(rc["imgIdx_j"], oc["imgIdx_j"]), step
+            if scenario != "full_loop":
+                assert rk == ok_, step
+                assert len(rc) == len(oc) and np.array_equal(rc["imgIdx_i"], oc["imgIdx_i"]) and np.array_equal(rc["imgIdx_j"], oc["imgIdx_j"]), step
+            else:
+                # 20 chunks deep a fused key point next to the image border, or a match next to a filter threshold, falls on the other side for one
+                # of the two solvers now and then (their local poses differ by 1e-4): counts within a few, the same image pairs up to a few
+                assert max(abs(a - b) for a, b in zip(rk, ok_)) <= 3, (step, rk, ok_)
+                pr = set(zip(rc["imgIdx_i"].tolist(), rc["imgIdx_j"].tolist())); po = set(zip(oc["imgIdx_i"].tolist(), oc["imgIdx_j"].tolist()))
+                assert len(pr & po) >= 0.9 * len(pr | po) and abs(len(rc) - len(oc)) <= 0.05 * max(len(oc), 1) + 25, (step, len(rc), len(oc), pr ^ po)
         nl = (op.last_local_solved + 1) * (S + 1) if op.last_local_solved >= 0 else 0
         if nl:
             assert close(rb.local_trajectories(nl), op.local_traj[:nl]), step
@@ -1275,6 +1296,12 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     assert op.glob.num_images >= (2 if scenario == "alt_flags" else 3) and op.num_complete >= 2 * S and op.past_end >= 4
     if scenario == "alt_flags":
         assert not op.use_solve and op.glob.use_global_dense          # reached the dense end-of-scan solve and the stop
+    if scenario == "full_loop":                 # the loop is closed: the last key frames match the first ones
+        gc = op.glob.corr[op.glob.corr["imgIdx_i"] != 0xFFFFFFFF]
+        span = gc["imgIdx_j"].astype(np.int64) - gc["imgIdx_i"].astype(np.int64)
+        print("full_loop: %d key frames, %d global correspondences, widest image pair %d key frames apart, max deviation of any compared pose %.2e"
+              % (op.glob.num_images, len(gc), span.max(), max_dev[0]))
+        assert span.max() >= 18
     if scenario == "revisit":
         gc = op.glob.corr[op.glob.corr["imgIdx_i"] != 0xFFFFFFFF]
         assert (gc["imgIdx_j"].astype(np.int64) - gc["imgIdx_i"].astype(np.int64)).max() >= 2          # a key frame matched one that is not its predecessor
@@ -1283,7 +1310,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     assert len(ref_ops) > (3 if scenario == "alt_flags" else 10) and {k for k, _, _ in ref_ops} == {"de", "in"}
     from collections import Counter
     cr, co = Counter((k, f) for k, f, _ in ref_ops), Counter((k, f) for k, f, _ in op.integrate_ops)
-    assert all(abs(cr[key] - co[key]) <= 1 for key in set(cr) | set(co)) and capped[0] <= 3, (capped, cr - co, co - cr)
+    slack = 1 if scenario != "full_loop" else 3           # the long run re-integrates every frame several times; the cut at s_maxFrameFixes falls differently more often
+    assert all(abs(cr[key] - co[key]) <= slack for key in set(cr) | set(co)) and (capped[0] <= 3 or scenario == "full_loop"), (capped, cr - co, co - cr)
     if with_volume:
         assert volume_checks[0] >= 2 * S and volume_checks[1] >= 3, volume_checks
 
