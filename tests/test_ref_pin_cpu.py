@@ -311,7 +311,11 @@ def osc_hash(nb, k):
 
 @pytest.mark.parametrize("cfg", [dict(W=96, H=72, voxel=0.02, buckets=3001, blocks=6000, scene="wall"),
                                  dict(W=96, H=72, voxel=0.02, buckets=500, blocks=6000, scene="room"),     # load factor > 1: overflow chains
-                                 dict(W=64, H=48, voxel=0.01, buckets=20011, blocks=12000, scene="room")])
+                                 dict(W=64, H=48, voxel=0.01, buckets=20011, blocks=12000, scene="room"),
+                                 # the other corner of the parameter space: weights that saturate (de-integration is then not the inverse of
+                                 # integration), 3 samples per frame, narrow truncation, short integration range
+                                 dict(W=80, H=60, voxel=0.02, buckets=4001, blocks=8000, scene="room",
+                                      extra=dict(weight_sample=3, weight_max=5, truncation=0.03, trunc_scale=0.04, max_integration_distance=2.5))])
 def test_tsdf_operators_vs_reference_kernels(oracle, cfg):
     """integrate x3 (moving camera) -> de-integrate the middle frame -> re-integrate it at a perturbed pose -> garbage collection
     -> de-integrate everything + GC: after every step the oracle volume equals the volume produced by the reference's own
@@ -332,7 +336,7 @@ def test_tsdf_operators_vs_reference_kernels(oracle, cfg):
         frames = [synth.scene_room(20 * k, W, H) for k in range(3)]
     K = frames[0][3]
     cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
-    p = default_hash_params(num_buckets=cfg["buckets"], num_sdf_blocks=cfg["blocks"], voxel_size=cfg["voxel"])
+    p = default_hash_params(num_buckets=cfg["buckets"], num_sdf_blocks=cfg["blocks"], voxel_size=cfg["voxel"], **cfg.get("extra", {}))
     osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p, host_class=True)      # the reference's own host class drives its kernels
     nb = cfg["buckets"]
     for i, (d, c, T, _) in enumerate(frames):
@@ -681,7 +685,7 @@ def test_verify_trajectory_vs_reference_kernel(oracle):
 
 def test_sift_detector_and_matcher_vs_reference(oracle):
     """The reference's SiftGPU fork, whole (SiftGPU.cpp, SiftPyramid.cpp, CuTexImage.cpp, SiftMatch.cpp, ProgramCU.cu compiled as they are),
-    on two 640x480 frames of the synthetic stream, against the oracle detector / matcher:
+    on four 640x480 frames of the synthetic stream, against the oracle detector / matcher:
       * all 18 Gaussian pyramid levels bit for bit;  * the DoG extrema with depth gate: the same (col, row) sets in all 12 (octave, level) slots;
       * per-slot feature counts after orientation assignment and both LimitFeatureCount passes: equal;
       * final key points (x, y, scale, depth): the same multiset of float bits; orientations within 1e-5 rad (atan2 / exp: libm there,
@@ -691,7 +695,7 @@ def test_sift_detector_and_matcher_vs_reference(oracle):
     from bundlefusion_amd.capi import rgbx_to_intensity
     from collections import defaultdict
     W, H = 640, 480
-    frames = [synth.scene_room(30 + 7 * k, W, H) for k in range(2)]
+    frames = [synth.scene_room(k, W, H) for k in (30, 37, 640, 1250)]          # two neighbours (for the matcher) and two other parts of the room
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     rs = ref_api.RefSift(W, H, K)
