@@ -1,7 +1,7 @@
 // oracle/ref/emu.h — TEST INFRASTRUCTURE ONLY.
 // Serial emulation of a CUDA kernel launch on the host, for running the reference's own __global__ functions (compiled by
 // g++ through shim/cuda_runtime.h) as the parity pin of the CPU oracle.  Blocks run one after the other; the threads of a
-// block are fibers (ucontext) executed in thread-index order, and __syncthreads() suspends a fiber until every live fiber of
+// block are fibers (own stacks, a register / stack-pointer switch in emu.cpp; x86-64) executed in thread-index order, and __syncthreads() suspends a fiber until every live fiber of
 // the block has reached a barrier — so kernels with __shared__ data and barriers keep their semantics, while atomics and
 // "first thread wins" races resolve in a fixed (thread-index) order.
 #ifndef BF_REF_EMU_H
