@@ -1414,3 +1414,42 @@ def test_correspondence_evaluator_vs_reference_class(oracle, tmp_path):
     assert r_raw[2] == 2 and r_raw[1] >= 1 and r_filt[0] >= 1
     rows = open(str(tmp_path / "corr") + "_frame.csv").read().splitlines()
     assert rows[0] == "numFrames,curFrame,type,precision,recall,numCorrect,numDetected,numTotal" and len(rows) == 3
+
+
+def test_raw_match_cap_is_a_function_of_the_key_order(oracle):
+    """More than MAX_MATCHES_PER_IMAGE_PAIR_RAW = 128 raw matches between two frames: the reference keeps the first 128 that arrive at
+    `atomicAdd(d_numMatches, 1)` (ProgramCU.cu:1909), i.e. its result depends on the order of its key lists, which its detector fills in thread
+    arrival order.  The restatement keeps the first 128 in key order.  Fed the reference's key order, it reproduces the reference's filtered
+    correspondences bit for bit - the cap itself is pinned, the order is the reference's own non-determinism (golden vectors)."""
+    from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix
+    from tests.oracle_pipeline import OraclePipeline, OBundler
+    W, H, S = 320, 240, 3
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
+    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 8, S
+    rng = np.random.default_rng(1)
+    frames = [synth.scene_room(200 + 3 * k, W, H) for k in range(2)]
+    frames = [(f[0] + rng.normal(0, 0.004, f[0].shape).astype(np.float32), f[1]) for f in frames]            # 4 mm depth noise: more key points survive
+    Kd = synth.intrinsics(W, H)
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    op = OraclePipeline(gas, gbs, W, H, K); op._integrate = lambda *a: None
+    rb = ref_api.RefOnlineBundler(gas, gbs, W, H, K)
+    for d, c in frames:
+        raw, filt = op._ingest(d, c)
+        rb.set_frame(d, c); rb.override_filtered_depth(filt)
+        rb.process_input(); op.process_input(raw, filt, c)
+    b = op.local
+    n_raw, _, _ = oracle.sift_match(b.descs[0], b.descs[1], gbs.s_siftMatchThresh, gbs.s_siftMatchRatioMaxLocal, 0, b.max_keys)
+    assert n_raw > 128                                                                   # the cap is active
+    loc = rb.bundler(0)
+    rc = loc.correspondences()
+    assert len(rc) == len(b.corr) == 25 and rc.tobytes() != b.corr.tobytes()            # same count, other matches: the two key orders differ
+    b2 = OBundler(S + 1, b.max_keys, b.Kinv, b.depthK, True, gas, gbs)
+    for im in range(2):
+        rk, rd = loc.keys(im)
+        assert sorted(map(tuple, rk.view(np.uint32).tolist())) == sorted(map(tuple, np.asarray(b.keys[im], np.float32).view(np.uint32).tolist()))   # same key points
+        b2._add_image(rk.copy(), rd.copy())                                              # ... in the reference's order
+    b2.cache = list(b.cache[:2]); b2.valid = [1, 1] + [0] * (S - 1); b2.current = 1
+    assert b2.match_and_filter() == 0
+    assert b2.corr.tobytes() == rc.tobytes()
