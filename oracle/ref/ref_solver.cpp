@@ -19,7 +19,13 @@ struct ref_solver_params {             // GlobalBundlingState values the constru
 };
 struct ref_cache_frame { float* depth; float* campos; float* intensity; float* derivs; unsigned char* normalsU; float* normals; };
 
+static int g_lastNumDensePairs = -1, g_lastCorrCount = -1; static float g_lastSumResidual = 0.0f;
+
 extern "C" {
+
+// diagnostics of the last ref_solver_solve: overlapping image pairs of the last dense build (d_numDenseOverlappingImages), dense depth correspondences and their
+// residual sum (d_corrCount, d_sumResidual)
+void ref_solver_last_dense_stats(int* numPairs, int* corrCount, float* sumResidual) { *numPairs = g_lastNumDensePairs; *corrCount = g_lastCorrCount; *sumResidual = g_lastSumResidual; }
 
 // returns the number of Gauss-Newton iterations recorded in convergence[] (nNonLin + 1 entries, -1 where an early out skipped them)
 int ref_solver_solve(void* corrEntryJ, unsigned int numCorr, const int* validImages, unsigned int numImages, unsigned int maxImages, unsigned int maxResiduals,
@@ -85,6 +91,7 @@ int ref_solver_solve(void* corrEntryJ, unsigned int numCorr, const int* validIma
     if (numEntriesPerRowOut) memcpy(numEntriesPerRowOut, numEntriesPerRow.data(), sizeof(int) * numImages);
     if (convergence) for (unsigned int i = 0; i <= nNonLin; ++i) convergence[i] = -1.0f;
     solveBundlingStub(in, st, par, an, convergence, NULL);
+    g_lastNumDensePairs = numDense[0]; g_lastCorrCount = corrCount[0]; g_lastSumResidual = sumResidual[0];
     if (maxResidualOut) {                                                    // computeMaxResidual, .cpp:313-349 (weights = 1, 0, 0)
         SolverParameters p2 = par; p2.highResidualThresh = std::numeric_limits<float>::infinity();
         p2.weightSparse = 1.0f; p2.weightDenseDepth = 0.0f; p2.weightDenseColor = 0.0f;
