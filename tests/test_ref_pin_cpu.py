@@ -1453,3 +1453,48 @@ def test_raw_match_cap_is_a_function_of_the_key_order(oracle):
     b2.cache = list(b.cache[:2]); b2.valid = [1, 1] + [0] * (S - 1); b2.current = 1
     assert b2.match_and_filter() == 0
     assert b2.corr.tobytes() == rc.tobytes()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_tsdf_random_operator_sequences_vs_reference(oracle, seed):
+    """Random sequences of integrate / de-integrate / garbage collection over noisy frames with holes, random voxel size, bucket count (chained to roomy),
+    truncation and weight cap: after every operator the oracle volume equals the one the reference's host class and kernels produce."""
+    global _hash_fn
+    _hash_fn = oracle.hash_pos
+    rng = np.random.default_rng(1000 + seed)
+    W, H = 80, 60
+    voxel = float(rng.choice([0.01, 0.02, 0.04]))
+    # from chained to roomy; a table so overloaded that chains hit their length limit drops blocks by arrival order - the reference's own non-determinism
+    nb = int(rng.choice([4001, 20011] if voxel == 0.01 else [1009, 4001, 20011]))
+    p = default_hash_params(num_buckets=nb, num_sdf_blocks=20000, voxel_size=voxel, truncation=float(rng.choice([0.03, 0.06])), trunc_scale=float(rng.choice([0.01, 0.03])),
+                            weight_sample=int(rng.choice([1, 2, 10])), weight_max=int(rng.choice([4, 255, 99999999])), max_integration_distance=float(rng.choice([2.0, 3.0, 4.0])))
+    Kd = synth.intrinsics(W, H)
+    cam = camera_params(W, H, Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    frames = []
+    for k in rng.choice(1800, size=4, replace=False):
+        d, c, T, _ = synth.scene_room(int(k), W, H)
+        d = d + rng.normal(0, 0.003, d.shape).astype(np.float32)
+        d[rng.random(d.shape) < 0.02] = -np.inf
+        y, x = int(rng.integers(0, H - 12)), int(rng.integers(0, W - 16))
+        d[y:y + 12, x:x + 16] = -np.inf
+        frames.append((d, c, T))
+    osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p, host_class=True)
+    inside = []
+    for step in range(10):
+        if inside and rng.random() < 0.4:
+            j = inside.pop(int(rng.integers(len(inside))))
+            d, c, T = frames[j]
+            osc.deintegrate(T, d, c, cam); rsc.deintegrate(T, d, c, cam)
+        else:
+            j = int(rng.integers(len(frames)))
+            d, c, T = frames[j]
+            T = T.copy(); T[:3, 3] += rng.normal(0, 0.01, 3).astype(np.float32)
+            frames[j] = (d, c, T)
+            if j in inside:
+                continue                                   # a frame is integrated once at a time (the TrajectoryManager guarantees it)
+            osc.integrate(T, d, c, cam); rsc.integrate(T, d, c, cam)
+            inside.append(j)
+        if rng.random() < 0.5:
+            osc.garbage_collect(); rsc.garbage_collect()
+            osc.compactify(T, cam); rsc.compactify(T, cam)
+        _assert_same_volume(osc, rsc, nb, "seed %d step %d" % (seed, step))
