@@ -1100,7 +1100,7 @@ _LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="1-2 m
 _LOOP = pytest.mark.skipif(os.environ.get("BF_LOOP_TEST") != "1", reason="the full 360 degree loop through the emulated reference: about half an hour, BF_LOOP_TEST=1 (log: profiles/r02_ref_pin_loop.txt)")
 
 
-@pytest.mark.parametrize("scenario", ["three_chunks", "tracking_loss", pytest.param("default_submap", marks=_LONG), "revisit", "alt_flags",
+@pytest.mark.parametrize("scenario", ["three_chunks", "tracking_loss", pytest.param("default_submap", marks=_LONG), "revisit", "alt_flags", "noisy",
                                       pytest.param("full_loop", marks=_LOOP)])
 def test_online_bundler_vs_reference_host_code(oracle, scenario):
     """Rows a1-a12 end to end: the reference's CUDAImageManager.cpp (ingest) / OnlineBundler.cpp / Bundler.cpp / SBA.cpp /
@@ -1116,6 +1116,7 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     to a 3 % fringe afterwards.
     Scenario "full_loop" (BF_LOOP_TEST=1): BASELINE configs[2] in small - 212 frames once around the room and into the second lap, chunk size 10,
     21 key frames, the loop closed by global matches between the last and the first key frames; poses 2e-2 (21 global solves deep).
+    Scenario "noisy": ten frames of another part of the room, 1.8 degrees apart, with 4 mm of Gaussian depth noise.
     Scenario "revisit": 16 frames over the same seven views twice (the jump back after view 6 is one large step): the global key frames of the
     second pass match key frames of the first pass that are not their predecessors - loop-closure correspondences in the global problem and the
     re-initialisation of the global pose from the last MATCHED key frame (Bundler.cpp:205-210).
@@ -1134,6 +1135,8 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
     stride = 3
     if scenario == "full_loop":                  # BASELINE configs[2] in small: once around the room (1800 / 9 = 200 frames) and 12 frames into the second lap
         S, NF, TOL, stride = 10, 212, 2e-2, 9
+    if scenario == "noisy":
+        stride = 9
     if scenario == "revisit":                    # the camera goes over the same seven views twice: key frames of the second pass match those of the first
         NF = 16
     if scenario == "alt_flags":                  # the other side of the switches, and the end-of-scan global dense solve (OnlineBundler.cpp:175-196)
@@ -1150,7 +1153,11 @@ def test_online_bundler_vs_reference_host_code(oracle, scenario):
         gbs.s_erodeSIFTdepth = gbs.s_depthFilter = gbs.s_useLocalVerify = gbs.s_useComprehensiveFrameInvalidation = False
         gbs.s_numOptPerResidualRemoval = 2
         gas.s_colorFilter, gas.s_numSolveFramesBeforeExit = True, 2
-    frames = [synth.scene_room(stride * (k % 7 if scenario == "revisit" else k), W, H) for k in range(NF)]
+    start = 900 if scenario == "noisy" else 0
+    frames = [synth.scene_room(start + stride * (k % 7 if scenario == "revisit" else k), W, H) for k in range(NF)]
+    if scenario == "noisy":                     # another part of the room, 1.8 degrees per frame, 4 mm of depth noise
+        nrng = np.random.default_rng(2)
+        frames = [(f[0] + nrng.normal(0, 0.004, f[0].shape).astype(np.float32),) + tuple(f[1:]) for f in frames]
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     frames = [((np.full_like(f[0], -np.inf) if k in dark else f[0]), f[1]) for k, f in enumerate(frames)]
