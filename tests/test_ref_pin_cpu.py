@@ -247,19 +247,24 @@ def test_ingest_and_resample_kernels(oracle):
 
 
 def test_cache_store_frame_vs_reference_kernels(oracle):
-    """CUDACache::storeFrame: the six arrays of one 80x60 cache frame from a 320x240 input."""
-    d, c, _, Kd = synth.scene_room(12, 320, 240)
-    d = d.copy(); d[100:110, 150:180] = -np.inf
-    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
-    fo = oracle.cache_store_frame(d, c, 80, 60, K)
-    fr = ref_api.cache_store_frame(d, c, 80, 60, oracle.mat4_inverse(K))
-    for k in ("depth", "campos", "normals", "intensity", "derivs"):
-        fin_o, fin_r = np.isfinite(fo[k]), np.isfinite(fr[k])
-        assert np.array_equal(fin_o, fin_r), k
-        tol = 3e-6 if k in ("depth", "campos", "intensity", "derivs") else 2e-5      # normals: a normalised cross product of differences of filtered positions
-        assert np.abs(fo[k][fin_o] - fr[k][fin_r]).max() <= tol * max(1.0, np.abs(fr[k][fin_r]).max()), k
-        assert fin_o.sum() > 0.5 * fin_o.size
-    assert np.abs(fo["normals_u"].astype(int) - fr["normals_u"].astype(int)).max() <= 1      # bytes of the float normals above
+    """CUDACache::storeFrame: the six arrays of one 80x60 cache frame from a 320x240 input and from a 640x480 one, clean and with depth noise + holes."""
+    rng = np.random.default_rng(4)
+    for k, (w, h), noisy in ((12, (320, 240), False), (500, (640, 480), True), (1300, (320, 240), True)):
+        d, c, _, Kd = synth.scene_room(k, w, h)
+        d = d.copy(); d[h // 2 - 5:h // 2 + 5, w // 2:w // 2 + 30] = -np.inf
+        if noisy:
+            d = d + rng.normal(0, 0.004, d.shape).astype(np.float32)
+            d[rng.random(d.shape) < 0.01] = -np.inf
+        K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+        fo = oracle.cache_store_frame(d, c, 80, 60, K)
+        fr = ref_api.cache_store_frame(d, c, 80, 60, oracle.mat4_inverse(K))
+        for name in ("depth", "campos", "normals", "intensity", "derivs"):
+            fin_o, fin_r = np.isfinite(fo[name]), np.isfinite(fr[name])
+            assert np.array_equal(fin_o, fin_r), (k, name)
+            tol = 3e-6 if name in ("depth", "campos", "intensity", "derivs") else 2e-5      # normals: a normalised cross product of differences of filtered positions
+            assert np.abs(fo[name][fin_o] - fr[name][fin_r]).max() <= tol * max(1.0, np.abs(fr[name][fin_r]).max()), (k, name)
+            assert fin_o.sum() > 0.4 * fin_o.size
+        assert np.abs(fo["normals_u"].astype(int) - fr["normals_u"].astype(int)).max() <= 1      # bytes of the float normals above
 
 
 # ------------------------------------------------------------------------------------------------ voxel hash
