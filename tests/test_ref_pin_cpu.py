@@ -455,8 +455,9 @@ def test_marching_cubes_tables_vs_reference():
     assert same_triangles >= 90           # (larger polygons may be split along other diagonals: same vertices, same patch)
 
 
-def test_marching_cubes_oracle_vs_reference_kernels(oracle):
-    """extractIsoSurface of the reference (its own kernel, trilinear sampling and Tables.h) against the oracle restatement fed the SAME
+@pytest.mark.parametrize("noisy", [False, True])
+def test_marching_cubes_oracle_vs_reference_kernels(oracle, noisy):
+    """(Also on a volume built from frames with 4 mm of depth noise and holes: far more of the 256 cube cases occur.)  extractIsoSurface of the reference (its own kernel, trilinear sampling and Tables.h) against the oracle restatement fed the SAME
     tables, on a volume built from three frames: the same triangles — positions and colours bit for bit — as a multiset (the reference
     appends in atomic order).  With the product's generated tables the oracle yields the same vertices and equally many triangles."""
     import ctypes as C
@@ -464,6 +465,9 @@ def test_marching_cubes_oracle_vs_reference_kernels(oracle):
     W, H = 96, 72
     frames = [synth.scene_room(20 * k, W, H) for k in range(3)]
     K = frames[0][3]
+    if noisy:
+        nrng = np.random.default_rng(10)
+        frames = [(d + nrng.normal(0, 0.004, d.shape).astype(np.float32) + np.where(nrng.random(d.shape) < 0.02, -np.inf, 0).astype(np.float32), c, T, None) for d, c, T, _ in frames]
     cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
     p = default_hash_params(num_buckets=3001, num_sdf_blocks=6000, voxel_size=0.02)
     osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p)
@@ -494,8 +498,9 @@ def test_marching_cubes_oracle_vs_reference_kernels(oracle):
     assert abs(area(pt_tris) - area(rt_tris)) <= 2e-3 * area(rt_tris)
 
 
-def test_ray_cast_oracle_vs_reference_kernel(oracle):
-    """renderKernel of the reference (its own traverseCoarseGridSimpleSampleAll / bisection / trilinear sampling / gradient) against the
+@pytest.mark.parametrize("noisy", [False, True])
+def test_ray_cast_oracle_vs_reference_kernel(oracle, noisy):
+    """(Also on a volume built from frames with 4 mm of depth noise and holes.)  renderKernel of the reference (its own traverseCoarseGridSimpleSampleAll / bisection / trilinear sampling / gradient) against the
     oracle restatement on a volume built from three frames, from the same ray-interval images: depth, camera-space points, colours and
     (with analytic gradients) normals bit for bit.  The interval images come from the oracle's compute splat (the reference fills them
     with a D3D11 rasteriser pass that cannot run here); every block's rectangle must bracket the surface the rays then find."""
@@ -503,6 +508,14 @@ def test_ray_cast_oracle_vs_reference_kernel(oracle):
     W, H = 96, 72
     frames = [synth.scene_room(20 * k, W, H) for k in range(3)]
     K = frames[0][3]
+    if noisy:
+        nrng = np.random.default_rng(9)
+        noisy_frames = []
+        for d, c, T, _ in frames:
+            d = d + nrng.normal(0, 0.004, d.shape).astype(np.float32)
+            d[nrng.random(d.shape) < 0.02] = -np.inf
+            noisy_frames.append((d, c, T, None))
+        frames = noisy_frames
     cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
     p = default_hash_params(num_buckets=3001, num_sdf_blocks=6000, voxel_size=0.02)
     osc, rsc = oracle.OracleScene(p), ref_api.RefScene(p)
