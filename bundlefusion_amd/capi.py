@@ -175,6 +175,15 @@ class SceneRepHashSDF:
     def set_shard(self, rank, world):
         check(lib.bf_scene_set_shard(self._h, rank, world))
 
+    def set_arith(self, mode):
+        """'exact' (IEEE op by op, default) or 'fast' (the reference GPU build's -use_fast_math contract): bf_scene_set_arith"""
+        check(lib.bf_scene_set_arith(self._h, {"exact": 0, "fast": 1}[mode]))
+
+    def arith(self):
+        m = C.c_int()
+        check(lib.bf_scene_get_arith(self._h, C.byref(m)))
+        return ("exact", "fast")[m.value]
+
     def reintegrate(self, old_cam_to_world, new_cam_to_world, depth, color, cam):
         """fused deintegrate(old) + integrate(new) of the same frame"""
         data = self._data(depth, color)

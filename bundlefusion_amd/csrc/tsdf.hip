@@ -882,6 +882,10 @@ __global__ __launch_bounds__(512) void k_reupdate(Dev d, Frame f, Frame fo, cons
 //   * independent operations of the two voxels of a pair are packed.
 // A wave whose block fails the bound runs voxelSample / voxelApply for its 512 voxels (colExact).
 // ---------------------------------------------------------------------------------------
+// f2i as the one instruction it describes (v_cvt_i32_f32: toward zero, saturating, NaN -> 0).  The portable spelling in bf_device.h
+// costs three compares and three exec-mask branches per conversion in the voxel kernels' inner loop.
+BF_DEV int f2iHw(float v) { int r; asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 BF_DEV v2f sp2(float a) { v2f r; r.x = a; r.y = a; return r; }
 BF_DEV v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -954,7 +958,7 @@ BF_DEV PairAddr projectPair(const UpdCam& c, const UpdPose& f, const ColPose& p,
     const v2f sx = divRefined(pcx * sp2(c.fx), o.pcz, r) + sp2(c.mx);
     const v2f sy = divRefined(pcy * sp2(c.fy), o.pcz, r) + sp2(c.my);
     const v2f hx = sx + sp2(0.5f), hy = sy + sp2(0.5f);
-    const uint32_t pxA = (uint32_t)f2i(hx.x), pyA = (uint32_t)f2i(hy.x), pxB = (uint32_t)f2i(hx.y), pyB = (uint32_t)f2i(hy.y);
+    const uint32_t pxA = (uint32_t)f2iHw(hx.x), pyA = (uint32_t)f2iHw(hy.x), pxB = (uint32_t)f2iHw(hx.y), pyB = (uint32_t)f2iHw(hy.y);
     o.inA = pxA < c.W && pyA < c.H; o.inB = pxB < c.W && pyB < c.H;
     o.pixA = pyA * c.W + pxA; o.pixB = pyB * c.W + pxB;
     return o;
@@ -1129,6 +1133,178 @@ __global__ __launch_bounds__(256) void k_update_col(Dev d, UpdCam c, UpdPose in,
 }
 
 // ---------------------------------------------------------------------------------------
+// voxel update, arithmetic contract "fast" (bf_scene_set_arith(1) / BF_TSDF_ARITH=fast).
+//
+// The reference's Release build compiles its CUDA code with -use_fast_math (FriedLiver.vcxproj:124 <FastMath>true</FastMath>): `a / b`
+// is the approximate __fdividef, products and sums are contracted to FMAs, denormals flush.  The column kernel above instead evaluates
+// every operation of CUDASceneRepHashSDF.cu:425-516 as written, IEEE op by op (that is what makes it bit-comparable with a host build
+// of the reference, and VALU-issue bound: profiles/r02_sq_tsdf_update.md, 1696 vector instructions per block of a fused launch).
+// This kernel is the same update under the contract the reference's GPU build actually has:
+//   * a quotient is numerator * v_rcp_f32(denominator) (1 ulp reciprocal), no refinement, no range handling;
+//   * the image coordinates are one FMA chain over the voxel's integer coordinates with the intrinsics folded into the rows of the
+//     world -> camera transform on the host (in double, rounded once);
+//   * camera-space z keeps the exact kernel's operation order, so the signed distance SAMPLE of a voxel (depth - z) has the same bits
+//     in both contracts whenever both pick the same pixel;
+//   * colour bytes: v_cvt_f32_ubyteN in, one FMA per channel, v_cvt_pk_u8_f32 out.
+// What can differ from the exact contract, and how the tests bound it (tests/test_tsdf_gpu.py, arith = fast): the set of allocated
+// blocks, bucket occupancy, heap and every weight are decided by integer / comparison logic on identical samples and stay EXACT;
+// sdf within 1e-5 x truncation and colour within 1 LSB; a voxel whose projection lies within ~1e-4 pixel of a pixel
+// boundary may sample the neighbouring pixel (as it may between the reference's own fast-math build and a host build of it) - the
+// tests recompute the projection in double, exclude exactly those voxels, and bound their share.
+// Depth and colour are fetched through buffer descriptors (32-bit offsets, out-of-image lanes read 0 and are masked) - no 64-bit
+// address arithmetic, no divergent branches around the loads.
+// ---------------------------------------------------------------------------------------
+struct ApxCam {
+    float mxh, myh;            // principal point + 0.5 (the rounding offset of the pixel index)
+    float voxelSize, maxDist, truncScale, truncation, weightMax;
+    uint32_t W, H, bytes;      // image size, bytes of one image plane (W * H * 4)
+};
+struct ApxPose {
+    float ax, bx, cx, dx;      // fx * voxelSize * (R00, R01, R02), fx * t0: numerator of the image x coordinate over the integer voxel coordinates
+    float ay, by, cy, dy;      // fy * voxelSize * (R10, R11, R12), fy * t1
+    float r6, r7, r8, t2;      // third row of the world -> camera transform (camera-space z in the exact kernel's operation order)
+};
+
+// v_cvt_pk_u8_f32 saturates to [0, 255]; whether it rounds to nearest-even or truncates is probed once per scene (k_probe_cvt) and
+// selects the kernel instantiation: RNE converts the value itself, RTZ the value + 0.5 (folded into the FMA that produces it).
+// roundf-then-truncate of the exact contract == nearest, ties away from zero: differs from RNE on exact .5 ties only (1 LSB, inside
+// the contract).  Both contracts clamp at 254 ((uint)254.5).
+template <bool RNE>
+BF_DEV uint32_t packByte(float v, uint32_t sel, uint32_t old) { return __builtin_amdgcn_cvt_pk_u8_f32(fminf(v, RNE ? 254.4f : 254.9f), sel, old); }
+
+struct ApxCol { float nx0, ny0, zc; };       // per lane (column x, y) and pose: image-coordinate numerators at z = 0, R6 * xw + R7 * yw
+
+BF_DEV ApxCol apxCol(const ApxPose& p, float ix, float iy, float xw, float yw) {
+    ApxCol c;
+    c.nx0 = __builtin_fmaf(p.ax, ix, __builtin_fmaf(p.bx, iy, p.dx));
+    c.ny0 = __builtin_fmaf(p.ay, ix, __builtin_fmaf(p.by, iy, p.dy));
+    c.zc = p.r6 * xw + p.r7 * yw;
+    return c;
+}
+
+struct ApxSample { v2f pcz; uint32_t offA, offB; bool inA, inB; };
+
+BF_DEV ApxSample apxProject(const ApxCam& c, const ApxPose& p, const ApxCol& col, v2f iz, v2f pz) {
+    ApxSample o;
+    o.pcz = (sp2(col.zc) + sp2(p.r8) * pz) + sp2(p.t2);
+    const v2f nx = pkfma(sp2(p.cx), iz, sp2(col.nx0)), ny = pkfma(sp2(p.cy), iz, sp2(col.ny0));
+    v2f r; r.x = __builtin_amdgcn_rcpf(o.pcz.x); r.y = __builtin_amdgcn_rcpf(o.pcz.y);
+    const v2f hx = pkfma(nx, r, sp2(c.mxh)), hy = pkfma(ny, r, sp2(c.myh));
+    const uint32_t pxA = (uint32_t)f2iHw(hx.x), pyA = (uint32_t)f2iHw(hy.x), pxB = (uint32_t)f2iHw(hx.y), pyB = (uint32_t)f2iHw(hy.y);
+    o.inA = pxA < c.W && pyA < c.H; o.inB = pxB < c.W && pyB < c.H;
+    o.offA = o.inA ? (__umul24(pyA, c.W) + pxA) << 2 : 0xFFFFFFFFu;      // beyond the descriptor's range: the load returns 0
+    o.offB = o.inB ? (__umul24(pyB, c.W) + pxB) << 2 : 0xFFFFFFFFu;
+    return o;
+}
+
+template <bool DE, bool IN, bool RNE>
+BF_DEV void colApprox(const Dev& d, const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, int4 e, uint32_t flags, uint32_t lane,
+                      __amdgpu_buffer_rsrc_t depthRes, __amdgpu_buffer_rsrc_t colorRes) {
+    const int vx = e.x * BS + (int)(lane & 7), vy = e.y * BS + (int)(lane >> 3);
+    const float ix = (float)vx, iy = (float)vy;
+    const float xw = ix * c.voxelSize, yw = iy * c.voxelSize;
+    const bool useDe = DE && (flags & 2u), useIn = IN && (flags & 1u);       // wave-uniform
+    ApxCol cDe = {0.0f, 0.0f, 0.0f}, cIn = {0.0f, 0.0f, 0.0f};
+    if (useDe) cDe = apxCol(pDe, ix, iy, xw, yw);
+    if (useIn) cIn = apxCol(pIn, ix, iy, xw, yw);
+    uint32_t* base = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + lane));
+    const float kz = (float)(e.z * BS);
+#pragma unroll 1
+    for (int z = 0; z < 8; z += 2) {
+        uint32_t* vpA = base + (size_t)z * 64u * 3u; uint32_t* vpB = vpA + 64u * 3u;
+        v2f vS, vW; uint32_t vCA, vCB;
+        vS.x = __uint_as_float(vpA[0]); vW.x = __uint_as_float(vpA[1]); vCA = vpA[2];
+        vS.y = __uint_as_float(vpB[0]); vW.y = __uint_as_float(vpB[1]); vCB = vpB[2];
+        v2f iz; iz.x = kz + (float)z; iz.y = kz + (float)(z + 1);                 // exact small integers
+        const v2f pz = iz * sp2(c.voxelSize);
+        ApxSample aDe, aIn;
+        aDe.inA = aDe.inB = aIn.inA = aIn.inB = false; aDe.offA = aDe.offB = aIn.offA = aIn.offB = 0xFFFFFFFFu; aDe.pcz = aIn.pcz = sp2(0.0f);
+        if (useDe) aDe = apxProject(c, pDe, cDe, iz, pz);
+        if (useIn) aIn = apxProject(c, pIn, cIn, iz, pz);
+        v2f dDe = sp2(0.0f), dIn = sp2(0.0f); uint32_t kDeA = 0u, kDeB = 0u, kInA = 0u, kInB = 0u;
+        if (useDe) {
+            dDe.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aDe.offA, 0, 0)); kDeA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aDe.offA, 0, 0);
+            dDe.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aDe.offB, 0, 0)); kDeB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aDe.offB, 0, 0);
+        }
+        if (useIn) {
+            dIn.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aIn.offA, 0, 0)); kInA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aIn.offA, 0, 0);
+            dIn.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aIn.offB, 0, 0)); kInB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aIn.offB, 0, 0);
+        }
+        // sample validity (voxelSample): the depth -inf of an invalid pixel fails |sdf| < trunc by itself; |sdf| < trunc makes the
+        // reference's clamp to [-trunc, trunc] the identity
+        const v2f sDe = dDe - aDe.pcz, sIn = dIn - aIn.pcz;
+        const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * dIn;       // the exact contract's operations: the validity of a sample (hence every weight) does not depend on the contract
+        const bool okDeA = aDe.inA && dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = aDe.inB && dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
+        const bool okInA = aIn.inA && dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = aIn.inB && dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
+        const bool anyA = okDeA || okInA, anyB = okDeB || okInB;
+        if (!anyA && !anyB) continue;
+        if (DE && (okDeA || okDeB)) {           // voxelApply<true>
+            const v2f dd = vW - sp2(1.0f);
+            v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
+            uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(kDeA, k); cc.y = byteF(kDeB, k);
+                const v2f q = RNE ? pkfma(o, vW, -cc) * r : pkfma(pkfma(o, vW, -cc), r, sp2(0.5f));
+                nA = packByte<RNE>(q.x, (uint32_t)k, nA); nB = packByte<RNE>(q.y, (uint32_t)k, nB);
+            }
+            const v2f s = pkfma(vS, vW, -sDe) * r;
+            float sA = s.x, sB = s.y, wA = fmaxf(0.0f, dd.x), wB = fmaxf(0.0f, dd.y);
+            if (wA <= 0.001f) { sA = 0.0f; nA = 0u; wA = 0.0f; }
+            if (wB <= 0.001f) { sB = 0.0f; nB = 0u; wB = 0.0f; }
+            if (okDeA) { vS.x = sA; vW.x = wA; vCA = nA; }
+            if (okDeB) { vS.y = sB; vW.y = wB; vCB = nB; }
+        }
+        if (IN && (okInA || okInB)) {           // voxelApply<false>
+            const v2f dd = sp2(1.0f) + vW;
+            v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
+            v2f ca, cb;                         // colour blend 0.2 new + 0.8 old; a voxel without weight takes the new colour
+            ca.x = vW.x == 0.0f ? 1.0f : 0.2f; cb.x = vW.x == 0.0f ? 0.0f : 0.8f;
+            ca.y = vW.y == 0.0f ? 1.0f : 0.2f; cb.y = vW.y == 0.0f ? 0.0f : 0.8f;
+            uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(kInA, k); cc.y = byteF(kInB, k);
+                const v2f m = pkfma(o, cb, RNE ? cc * ca : pkfma(cc, ca, sp2(0.5f)));
+                nA = packByte<RNE>(m.x, (uint32_t)k, nA); nB = packByte<RNE>(m.y, (uint32_t)k, nB);
+            }
+            const v2f s = pkfma(vS, vW, sIn) * r;
+            if (okInA) { vS.x = s.x; vW.x = fminf(c.weightMax, dd.x); vCA = nA; }
+            if (okInB) { vS.y = s.y; vW.y = fminf(c.weightMax, dd.y); vCB = nB; }
+        }
+        if (anyA) { vpA[0] = __float_as_uint(vS.x); vpA[1] = __float_as_uint(vW.x); vpA[2] = vCA; }
+        if (anyB) { vpB[0] = __float_as_uint(vS.y); vpB[1] = __float_as_uint(vW.y); vpB[2] = vCB; }
+    }
+}
+
+template <int MODE, bool RNE>
+__global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in, ApxPose de, const float* __restrict__ depth, const uchar4* __restrict__ color,
+                                                    int accumulate) {
+    if (color == nullptr) return;
+    constexpr bool DE = MODE != 0, IN = MODE != 1;
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), nWaves = gridDim.x * 4u;
+    if (accumulate && wave == 0 && lane == 0) {
+        if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
+        else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
+    }
+    const __amdgpu_buffer_rsrc_t depthRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(depth), 0, (int)c.bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t colorRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uchar4*>(color), 0, (int)c.bytes, 0x00020000);
+    for (uint32_t blk = wave; blk < n; blk += nWaves) {
+        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];                                    // wave-uniform
+        const uint32_t flags = MODE == 2 ? reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4] : 3u;
+        colApprox<DE, IN, RNE>(d, c, in, de, e, flags, lane, depthRes, colorRes);
+    }
+}
+
+// what v_cvt_pk_u8_f32 does on this device (see packByte)
+__global__ void k_probe_cvt(uint32_t* out) {
+    const float v[8] = {0.5f, 1.5f, 2.5f, 2.7f, 254.4f, 300.0f, -3.0f, 3.49f};
+    if (threadIdx.x < 8) out[threadIdx.x] = __builtin_amdgcn_cvt_pk_u8_f32(v[threadIdx.x], 1u, 0xAABBCCDDu);
+}
+
+// ---------------------------------------------------------------------------------------
 // garbage collection (CUDASceneRepHashSDF.cu:584-668, VoxelUtilHashSDF.h:740-826)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gc_identify(Dev d, Frame f) {
@@ -1256,6 +1432,8 @@ struct bf_scene {
     uint32_t gridCompact = 0, gridUpdate = 0, gridUpdateCol = 0, gridUpdateColPlain = 0;
     bool columnUpdate = true;       // k_update_col (one wave per block); false: the one-voxel-per-lane kernels (BF_TSDF_UPDATE=voxel)
     bool forceExactDiv = false;     // k_update_col takes the literal `/` path for every block (BF_TSDF_EXACT_DIV=1; tests)
+    int arith = BF_TSDF_ARITH_EXACT; // bf_scene_set_arith / BF_TSDF_ARITH: exact (IEEE op by op, default) or fast (k_update_apx)
+    int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
@@ -1329,6 +1507,53 @@ UpdPose makeUpdPose(const Frame& f) {
          std::isfinite(c.maxDist);
     u.fastOk = ok ? 1u : 0u;
     return u;
+}
+
+ApxCam makeApxCam(const Frame& f) {
+    ApxCam u;
+    u.mxh = f.cam.mx + 0.5f; u.myh = f.cam.my + 0.5f;
+    u.voxelSize = f.voxelSize; u.maxDist = f.maxIntegrationDistance; u.truncScale = f.truncScale; u.truncation = f.truncation; u.weightMax = f.weightMax;
+    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight; u.bytes = u.W * u.H * 4u;
+    return u;
+}
+ApxPose makeApxPose(const Frame& f) {
+    ApxPose u;
+    const double fx = f.cam.fx, fy = f.cam.fy, vs = f.voxelSize;
+    const float* M = f.Tinv.e;
+    u.ax = (float)(fx * vs * M[0]); u.bx = (float)(fx * vs * M[1]); u.cx = (float)(fx * vs * M[2]); u.dx = (float)(fx * M[3]);
+    u.ay = (float)(fy * vs * M[4]); u.by = (float)(fy * vs * M[5]); u.cy = (float)(fy * vs * M[6]); u.dy = (float)(fy * M[7]);
+    u.r6 = M[8]; u.r7 = M[9]; u.r8 = M[10]; u.t2 = M[11];
+    return u;
+}
+
+// one-time probe of v_cvt_pk_u8_f32 (rounding mode and saturation) on the scene's device
+int probeCvt(bf_scene* s) {
+    if (s->cvtRne >= 0) return BF_OK;
+    uint32_t* d_out = nullptr;
+    BF_HIP_TRY(hipMalloc((void**)&d_out, 8 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_probe_cvt, dim3(1), dim3(64), 0, s->stream, d_out);
+    uint32_t h[8];
+    hipError_t e = hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(d_out);
+    if (e != hipSuccess) { set_error("cvt probe failed: %s", hipGetErrorString(e)); return BF_ERR_HIP; }
+    uint32_t b[8];
+    for (int i = 0; i < 8; ++i) {
+        if ((h[i] & 0xFFFF00FFu) != 0xAABB00DDu) { set_error("v_cvt_pk_u8_f32 probe: unexpected packing 0x%08x", h[i]); return BF_ERR_HIP; }
+        b[i] = (h[i] >> 8) & 0xFFu;
+    }
+    // inputs 0.5 1.5 2.5 2.7 254.4 300 -3 3.49
+    const uint32_t rne[8] = {0, 2, 2, 3, 254, 255, 0, 3}, rtz[8] = {0, 1, 2, 2, 254, 255, 0, 3};
+    if (memcmp(b, rne, sizeof b) == 0) s->cvtRne = 1;
+    else if (memcmp(b, rtz, sizeof b) == 0) s->cvtRne = 0;
+    else { set_error("v_cvt_pk_u8_f32 probe: neither nearest-even nor truncation (%u %u %u %u %u %u %u %u)", b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7]); return BF_ERR_HIP; }
+    return BF_OK;
+}
+
+template <int MODE>
+void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* depth, const uchar4* color, int acc) {
+    if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
+    else hipLaunchKernelGGL((k_update_apx<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
 }
 
 void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepHashSDF.h:128-134
@@ -1423,7 +1648,13 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     }
     const uchar4* color = reinterpret_cast<const uchar4*>(data->d_colorData);
     const int acc = s->timing ? 1 : 0;
-    if (s->columnUpdate) {
+    if (s->arith == BF_TSDF_ARITH_FAST) {
+        const ApxCam ac = makeApxCam(f);
+        const ApxPose pin = makeApxPose(f), pde = makeApxPose(kind == 2 ? fo : f);
+        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, acc);
+        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, acc);
+        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, data->d_depthData, color, acc);
+    } else if (s->columnUpdate) {
         const UpdCam uc = makeUpdCam(f);
         const UpdPose pin = makeUpdPose(f), pde = makeUpdPose(kind == 2 ? fo : f);
         const int fe = s->forceExactDiv ? 1 : 0;
@@ -1512,7 +1743,28 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_TSDF_UPDATE")) s->columnUpdate = strcmp(e, "voxel") != 0;
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     *out = s;
-    return bf_scene_reset(s);
+    int rcReset = bf_scene_reset(s);
+    if (rcReset != BF_OK) return rcReset;
+    if (const char* e = getenv("BF_TSDF_ARITH")) return bf_scene_set_arith(s, strcmp(e, "fast") == 0 ? BF_TSDF_ARITH_FAST : BF_TSDF_ARITH_EXACT);
+    return BF_OK;
+}
+
+// Arithmetic contract of the voxel update (see k_update_apx): BF_TSDF_ARITH_EXACT evaluates CUDASceneRepHashSDF.cu:425-516 IEEE
+// operation by operation (bit-comparable with a host build of the reference); BF_TSDF_ARITH_FAST is the contract of the reference's
+// own GPU build (-use_fast_math, FriedLiver.vcxproj:124): approximate division, FMA contraction.  Allocation, lists, weights and
+// garbage collection are unaffected.
+int bf_scene_set_arith(bf_scene* s, int mode) {
+    BF_REQUIRE(s, "null scene");
+    BF_REQUIRE(mode == BF_TSDF_ARITH_EXACT || mode == BF_TSDF_ARITH_FAST, "unknown arithmetic contract");
+    if (mode == BF_TSDF_ARITH_FAST) BF_TRY_RC(probeCvt(s));
+    s->arith = mode;
+    return BF_OK;
+}
+
+int bf_scene_get_arith(bf_scene* s, int* mode) {
+    BF_REQUIRE(s && mode, "null argument");
+    *mode = s->arith;
+    return BF_OK;
 }
 
 int bf_scene_destroy(bf_scene* s) {

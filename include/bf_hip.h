@@ -153,6 +153,18 @@ BF_API int bf_scene_wait_event(bf_scene* s, void* hip_event);
  * [rank*numBuckets/world, (rank+1)*numBuckets/world) and allocates / integrates / collects only blocks hashing there.
  * Call before the first integrate; every shard is fed every frame and pose, there is no exchange between shards. */
 BF_API int bf_scene_set_shard(bf_scene* s, uint32_t rank, uint32_t world);
+/* Arithmetic contract of the voxel update, CUDASceneRepHashSDF.cu:425-516 (integrateDepthMapKernel / deIntegrateDepthMapKernel):
+ *   BF_TSDF_ARITH_EXACT (default)  every operation as written, IEEE binary32, no contraction - bit-comparable with a host build of the
+ *                                  reference (and with oracle/);
+ *   BF_TSDF_ARITH_FAST             the contract of the reference's own Release GPU build (FriedLiver.vcxproj:124 <FastMath>true</FastMath>):
+ *                                  approximate division (v_rcp_f32), FMA contraction.  Block set, bucket occupancy, heap and voxel
+ *                                  weights are the same as in exact mode; sdf within 1e-5 x truncation, colour within 1 LSB, except
+ *                                  voxels projecting within ~1e-4 pixel of a pixel boundary (they may sample the neighbouring pixel).
+ * Environment: BF_TSDF_ARITH=fast|exact selects the mode of every scene created afterwards.  May be switched at any time. */
+#define BF_TSDF_ARITH_EXACT 0
+#define BF_TSDF_ARITH_FAST 1
+BF_API int bf_scene_set_arith(bf_scene* s, int mode);
+BF_API int bf_scene_get_arith(bf_scene* s, int* mode);
 /* MI355X addition: deIntegrate(oldT) + integrate(newT) of the same frame (DepthSensing.cpp:882-889) as ONE pass over
  * the union of the two frustum lists — each touched voxel is read and written once.  Bit-identical to the two calls. */
 BF_API int bf_scene_reintegrate(bf_scene* s, const float old_cam_to_world[16], const float new_cam_to_world[16],
