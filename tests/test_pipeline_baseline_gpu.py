@@ -163,3 +163,93 @@ def test_config1_stream_vs_oracle_loop(gpu, oracle, n):
     assert abs(ate - ate_o) < 1e-3          # north_star: ATE within 1 mm of the reference
     dbg = gp.scene().debug_hash()
     assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["dropped"] == 0
+
+
+def test_loop_closure_stream_vs_oracle_loop(gpu, oracle):
+    """BASELINE configs[2] in small at 640x480: 212 frames, 1.8 degrees apart - once around the room and 12 frames into the second lap -
+    chunk size 10: 22 key frames, the loop closed by global matches between the last key frames and the first ones (Bundler.cpp:205-210:
+    a key frame matched against ALL previous key frames), then the end of the scan: process_end_of_sequence until the solver switches
+    to the dense global solve (OnlineBundler.cpp:181-186: sparse 1 / dense depth 15, 3 non-linear iterations) and stops.  Product
+    (C ABI, GPU) vs the oracle frame loop: scheduled operation counts exact, every pose within 5e-4, |ATE difference| < 1 mm
+    (north_star).  The volume is coarse (20 mm) on the product side and switched off in the oracle - it does not feed back into the
+    poses; the 4 mm volume parity is the replay tests' job."""
+    import torch
+    from tests.oracle_pipeline import OraclePipeline
+    NF, stride, tail = 212, 9, 4
+    frames = synth.render_frames([stride * k for k in range(NF)])
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+
+    def params():
+        gas, gbs = _params(voxel=0.02, buckets=400000, blocks=150000, max_images=NF // 10 + 8)
+        gas.s_numSolveFramesBeforeExit = 2
+        return gas, gbs
+    gp = gpu.capi.Pipeline(*params(), sensor_desc(W, H, K))
+    op = OraclePipeline(*params(), W, H, K)
+    op._integrate = lambda frame, T, de: op.integrate_ops.append(("de" if de else "in", frame, np.array(T, np.float32)))
+    for d, c, _, _ in frames:
+        assert gp.process_frame(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda())
+        op.process_frame(d, c)
+    for _ in range(tail):
+        gp.process_end_of_sequence(); op.process_end_of_sequence()
+    gp.synchronize()
+    # the loop was closed and the end-of-scan dense solve ran
+    gc = op.glob.corr[op.glob.corr["imgIdx_i"] != 0xFFFFFFFF]
+    span = int((gc["imgIdx_j"].astype(np.int64) - gc["imgIdx_i"].astype(np.int64)).max())
+    assert op.glob.num_images >= 20 and span >= 15, (op.glob.num_images, span)
+    assert op.glob.use_global_dense and not op.use_solve
+    c = gp.counters()
+    assert (c["integrate"], c["deintegrate"]) == _counts(op) and c["deintegrate"] > 2 * NF
+    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves and c["global_solves"] == op.glob.num_solves >= 20
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert len(gt) == len(ot) == NF and np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).all()
+    gopt = gp.optimized_trajectory()
+    oopt = np.stack([op.tm.opt[i] for i in range(len(gopt))])
+    dev_int, dev_opt = float(np.abs(gt - ot).max()), float(np.abs(gopt - oopt).max())
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    ref = np.stack([T0inv @ f[2].astype(np.float64) for f in frames])
+
+    def ate(t):
+        return float(np.sqrt(np.mean(np.sum((t[:, :3, 3] - ref[:len(t), :3, 3]) ** 2, axis=1))))
+    print("loop closure stream: %d key frames, widest matched pair %d key frames apart, %d global solves; max pose deviation integrated %.2e optimised %.2e; "
+          "ATE product %.3f mm oracle %.3f mm (optimised: %.3f / %.3f)" % (op.glob.num_images, span, c["global_solves"], dev_int, dev_opt, 1e3 * ate(gt), 1e3 * ate(ot),
+                                                                          1e3 * ate(gopt), 1e3 * ate(oopt)))
+    assert dev_int < 5e-4 and dev_opt < 5e-4
+    assert abs(ate(gt) - ate(ot)) < 1e-3 and abs(ate(gopt) - ate(oopt)) < 1e-3
+
+
+def test_replay_1280x960_2mm_reintegration_sweep(gpu, oracle):
+    """BASELINE configs[4] in small: 1280x960 depth, 2 mm voxels.  24 frames integrated at their poses, then one re-integration sweep
+    (every frame de-integrated at P_k and integrated at P_k * exp(xi_k), xi ~ N(0, diag(0.01 rad, 0.01 m)), seed 777),
+    garbage collection every 8 operators - the same operator log through the oracle volume and through bf_scene_* (fused
+    re-integration operator, operators software-pipelined): hash table, heap and every voxel byte identical."""
+    import torch
+    from tools.tsdf_sweep import se3_exp
+    W2, H2, NF = 1280, 960, 24
+    frames = synth.render_frames([3 * k for k in range(NF)], W2, H2)
+    Kd = frames[0][3]
+    cam = camera_params(W2, H2, Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    p = default_hash_params(num_buckets=2000000, num_sdf_blocks=700000, voxel_size=0.002)
+    gs = gpu.capi.SceneRepHashSDF(p); gs.set_overlap(True)
+    osc = oracle.OracleScene(p)
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    poses = [f[2].astype(np.float32) for f in frames]
+    rng = np.random.RandomState(777)
+    nops = 0
+    for k in range(NF):
+        gs.integrate(poses[k], dev[k][0], dev[k][1], cam); osc.integrate(poses[k], frames[k][0], frames[k][1], cam, threads=64)
+        nops += 1
+        if nops % 8 == 0:
+            gs.garbage_collect(); osc.garbage_collect()
+    nblocks = gs.num_allocated_blocks()
+    assert nblocks > 160000 and osc.num_dropped() == 0
+    for k in range(NF):
+        xi = rng.normal(0.0, 0.01, 6)
+        T2 = (poses[k].astype(np.float64) @ se3_exp(xi[:3], xi[3:])).astype(np.float32)
+        gs.reintegrate(poses[k], T2, dev[k][0], dev[k][1], cam)
+        osc.deintegrate(poses[k], frames[k][0], frames[k][1], cam, threads=64); osc.integrate(T2, frames[k][0], frames[k][1], cam, threads=64)
+        nops += 1
+        if nops % 8 == 0:
+            gs.garbage_collect(); osc.garbage_collect()
+    _assert_volume_bit_equal(gs, osc, "1280x960 @2 mm sweep")
+    print("1280x960 @2 mm: %d blocks after the integrations, %d after the sweep: bit-equal" % (nblocks, gs.num_allocated_blocks()))
