@@ -138,7 +138,8 @@ def main():
         runner.wait()                                        # the local half running ahead belongs to the pre-roll
     else:
         for k in range(pre):
-            assert pipe.process_frame(*feed[k])
+            if not pipe.process_frame(*feed[k]):
+                raise RuntimeError("pre-roll frame %d not accepted" % k)
     pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -156,8 +157,8 @@ def main():
         runner.wait()                                        # ... and the one started inside the timed window is paid for inside it
     else:
         for k in range(pre, total):
-            ok = pipe.process_frame(*feed[k])
-            assert ok
+            if not pipe.process_frame(*feed[k]):
+                raise RuntimeError("frame %d not accepted" % k)
     pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:

@@ -882,7 +882,7 @@ class Pipeline:
         possibly of another rank): depth / colour are torch cuda tensors, package a contiguous uint8 numpy array."""
         got = C.c_int()
         check(lib.bf_pipeline_process_frame_chunked(self._h, C.c_void_p(depth.data_ptr()), C.c_void_p(color.data_ptr()),
-                                                    package.ctypes.data_as(C.c_void_p), int(local_idx), C.byref(got)))
+                                                    package.ctypes.data_as(C.c_void_p), C.c_uint64(package.nbytes), int(local_idx), C.byref(got)))
         return bool(got.value)
 
     def integrate_frame_cpu(self, frame):

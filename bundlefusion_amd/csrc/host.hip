@@ -1019,6 +1019,25 @@ const int ID_MARK_OFFSET = 2;
 
 // chunk-parallel mode: what Bundler::fuseToGlobal (:388-394) leaves in the global bundler — one more image (the fused key points and
 // descriptors) and one more cache frame (the chunk's first) — taken from a chunk package instead of m_optLocal
+// A package arrives by all-gather from another rank: before anything in it is used as an offset or an index, every field that is
+// one is checked against the buffer it came in (`bytes`) and against this bundler's configuration.
+int chunkPackageCheck(const bf_chunk_header* h, uint64_t bytes, uint32_t maxKeys, uint32_t cacheW, uint32_t cacheH, uint32_t submapSize) {
+    BF_REQUIRE(h && bytes >= sizeof(bf_chunk_header), "chunk package: shorter than its header");
+    BF_REQUIRE(h->magic == BF_CHUNK_MAGIC, "chunk package: bad magic (a rank without a chunk in this round sends zeros)");
+    BF_REQUIRE(h->totalBytes <= bytes && h->totalBytes >= sizeof(bf_chunk_header), "chunk package: totalBytes exceeds the buffer");
+    BF_REQUIRE(h->submapSize == submapSize && h->numFrames >= 1 && h->numFrames <= submapSize + 1 && h->numFrames <= BF_CHUNK_MAX_FRAMES, "chunk package: chunk size differs");
+    BF_REQUIRE(h->maxKeys == maxKeys && h->numKeys <= maxKeys, "chunk package: key capacity differs");
+    BF_REQUIRE(h->cacheWidth == cacheW && h->cacheHeight == cacheH, "chunk package: cache geometry differs");
+    const uint64_t n = (uint64_t)cacheW * cacheH;
+    const uint64_t need[8] = {(uint64_t)sizeof(bf_sift_keypoint) * h->numKeys, (uint64_t)128 * h->numKeys, n * 4, n * 16, n * 4, n * 8, n * 4, n * 16};
+    const uint64_t off[8] = {h->offKeys, h->offDescs, h->offCache[0], h->offCache[1], h->offCache[2], h->offCache[3], h->offCache[4], h->offCache[5]};
+    for (int k = 0; k < 8; ++k)
+        BF_REQUIRE(off[k] >= sizeof(bf_chunk_header) && off[k] <= h->totalBytes && need[k] <= h->totalBytes - off[k], "chunk package: a payload section lies outside the package");
+    for (uint32_t j = 0; j < h->numFrames; ++j)
+        BF_REQUIRE(h->frames[j].prevLocal < (int32_t)j, "chunk package: a frame is chained to a later frame");       // -1 = none; k_sift_transform_ext indexes curFrame - (localIdx - prevLocal)
+    return BF_OK;
+}
+
 int obAppendKeyFrame(bf_bundler* glob, const bf_chunk_header* h) {
     BF_REQUIRE(h->magic == BF_CHUNK_MAGIC && h->numKeys <= glob->maxKeys, "bad chunk package");
     const uint8_t* base = reinterpret_cast<const uint8_t*>(h);
@@ -2072,9 +2091,14 @@ int obProcessInputChunked(bf_online_bundler* ob, uint32_t curFrame, const bf_chu
 
 extern "C" {
 
-int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, const uint8_t* d_color, const void* h_package, uint32_t localIdx, int* gotFrame) {
+int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, const uint8_t* d_color, const void* h_package, uint64_t packageBytes, uint32_t localIdx, int* gotFrame) {
     BF_REQUIRE(p && d_depth && d_color && h_package, "null argument");
     BF_REQUIRE(!p->timings, "per-stage timings are not available in chunked mode");
+    {
+        uint32_t cw = 0, ch = 0; float k4[4];
+        BF_TRY(bf_cache_get_geometry(p->ob->global->cache, &cw, &ch, k4));
+        BF_TRY(chunkPackageCheck(reinterpret_cast<const bf_chunk_header*>(h_package), packageBytes, p->ob->global->maxKeys, cw, ch, p->ob->submapSize));
+    }
     BF_TRY(plFlush(p));                                         // (a pipeline is driven either serially or chunked; nothing is deferred in chunked mode)
     const bf_chunk_header* pkg = reinterpret_cast<const bf_chunk_header*>(h_package);
     hipStream_t sd = p->sDetect;

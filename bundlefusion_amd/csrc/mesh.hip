@@ -26,6 +26,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "bf_device.h"
@@ -431,12 +432,16 @@ int bf_marching_cubes_save_mesh(bf_marching_cubes* m, const char* filename, cons
         return id;
     };
     struct Face { uint32_t a, b, c; };
-    auto canon = [](Face f) { uint32_t v[3] = {f.a, f.b, f.c}; std::sort(v, v + 3); return ((uint64_t)v[0] << 42) ^ ((uint64_t)v[1] << 21) ^ (uint64_t)v[2]; };
-    std::unordered_map<uint64_t, char> seen;
+    // duplicate faces are keyed on the full sorted vertex triple (96 bits): a packed 64-bit key with 21-bit fields would let distinct
+    // faces of a mesh with more than 2^21 vertices collide, and the later one would be dropped as a "duplicate" (a hole)
+    struct Tri { uint32_t v[3]; bool operator==(const Tri& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; } };
+    struct TriHash { size_t operator()(const Tri& t) const { uint64_t h = t.v[0] * 0x9E3779B97F4A7C15ull; h = (h ^ t.v[1]) * 0xC2B2AE3D27D4EB4Full; h = (h ^ t.v[2]) * 0x165667B19E3779F9ull; return (size_t)(h ^ (h >> 29)); } };
+    auto canon = [](Face f) { Tri t = {{f.a, f.b, f.c}}; std::sort(t.v, t.v + 3); return t; };
+    std::unordered_set<Tri, TriHash> seen;
     for (const bf_mc_triangle& t : m->mesh) {
         const Face f = {vertex(t.v[0]), vertex(t.v[1]), vertex(t.v[2])};
         if (f.a == f.b || f.b == f.c || f.a == f.c) continue;
-        if (!seen.emplace(canon(f), 1).second) continue;
+        if (!seen.insert(canon(f)).second) continue;
         faces.push_back(f.a); faces.push_back(f.b); faces.push_back(f.c);
     }
     if (transform) {

@@ -584,15 +584,26 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratc
         d.overflowCount[0] = 0;
     }
     __syncthreads();
-    {   // keys that found their bin full: release their de-dup slots now that nobody probes any more
-        const uint32_t stuck = min(d.stats[ST_STUCK], OVCAP);
+    {   // keys that found their bin full: release their de-dup slots now that nobody probes any more.  Only the first OVCAP of them
+        // were recorded; beyond that (ERR_BIN_OVERFLOW is set anyway) the whole set is cleared - at this point every slot of the set
+        // belongs to a key that has been placed or dropped, so "empty everywhere" is its correct state.
+        const uint32_t stuckAll = d.stats[ST_STUCK];
+        const uint32_t stuck = min(stuckAll, OVCAP);
         for (uint32_t q = threadIdx.x; q < stuck; q += blockDim.x) d.dedupe[d.stuckSlots[q]] = EMPTY64;
+        if (stuckAll > OVCAP)
+            for (uint32_t i = threadIdx.x; i <= d.dedupeMask; i += blockDim.x) d.dedupe[i] = EMPTY64;
         __syncthreads();
         if (threadIdx.x == 0) d.stats[ST_STUCK] = 0;
     }
     for (uint32_t b = threadIdx.x; b < NBINS; b += blockDim.x) d.binCount[b] = 0;
 }
 
+// The hand-off to the last workgroup below relies on gfx94x / gfx950 memory-model details: vmcnt counts stores (s_waitcnt vmcnt(0) drains
+// them), agent-scope relaxed atomic stores are write-through (sc1) and a single-lane agent acquire invalidates the CU's L1 for the whole
+// workgroup.  There is no portable fallback; the library is built for gfx950 only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_alloc_place: the workgroup hand-off is written for gfx942 / gfx950"
+#endif
 __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
     __shared__ SortLds s;
     __shared__ uint32_t scratch[16];
@@ -1184,100 +1195,138 @@ BF_DEV ApxCol apxCol(const ApxPose& p, float ix, float iy, float xw, float yw) {
 
 struct ApxSample { v2f pcz; uint32_t offA, offB; bool inA, inB; };
 
-BF_DEV ApxSample apxProject(const ApxCam& c, const ApxPose& p, const ApxCol& col, v2f iz, v2f pz) {
+BF_DEV ApxSample apxProject(const ApxCam& c, const ApxPose& p, const ApxCol& col, v2f iz, v2f pz, bool use) {
     ApxSample o;
     o.pcz = (sp2(col.zc) + sp2(p.r8) * pz) + sp2(p.t2);
     const v2f nx = pkfma(sp2(p.cx), iz, sp2(col.nx0)), ny = pkfma(sp2(p.cy), iz, sp2(col.ny0));
     v2f r; r.x = __builtin_amdgcn_rcpf(o.pcz.x); r.y = __builtin_amdgcn_rcpf(o.pcz.y);
     const v2f hx = pkfma(nx, r, sp2(c.mxh)), hy = pkfma(ny, r, sp2(c.myh));
     const uint32_t pxA = (uint32_t)f2iHw(hx.x), pyA = (uint32_t)f2iHw(hy.x), pxB = (uint32_t)f2iHw(hx.y), pyB = (uint32_t)f2iHw(hy.y);
-    o.inA = pxA < c.W && pyA < c.H; o.inB = pxB < c.W && pyB < c.H;
+    o.inA = use && pxA < c.W && pyA < c.H; o.inB = use && pxB < c.W && pyB < c.H;
     o.offA = o.inA ? (__umul24(pyA, c.W) + pxA) << 2 : 0xFFFFFFFFu;      // beyond the descriptor's range: the load returns 0
     o.offB = o.inB ? (__umul24(pyB, c.W) + pxB) << 2 : 0xFFFFFFFFu;
     return o;
 }
 
-template <bool DE, bool IN, bool RNE>
-BF_DEV void colApprox(const Dev& d, const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, int4 e, uint32_t flags, uint32_t lane,
-                      __amdgpu_buffer_rsrc_t depthRes, __amdgpu_buffer_rsrc_t colorRes) {
-    const int vx = e.x * BS + (int)(lane & 7), vy = e.y * BS + (int)(lane >> 3);
-    const float ix = (float)vx, iy = (float)vy;
+// Per block: what the lanes of the wave need of the list entry (wave-uniform) and of their column (x, y)
+struct ApxBlock {
+    uint32_t* base;            // voxel (x, y, 0) of this lane
+    float kz;                  // (float)(8 * block z)
+    ApxCol cDe, cIn;
+    bool useDe, useIn;         // wave-uniform: the block lies in the frustum of the old / new pose
+};
+// Stage A of one voxel pair (z, z + 1): every load it needs, issued without waiting for any of them - the two voxels (speculatively:
+// about one in four is not touched), and depth + colour of the pixels both poses project them to.  No load depends on another load,
+// so stage A of the NEXT pair (or of the next block's first pair) is issued before stage B of the current one: the wave always has
+// two pairs' worth of loads in flight and its arithmetic runs in the shadow of the round trip.
+struct ApxPair {
+    v2f vS, vW; uint32_t vCA, vCB;
+    v2f pczDe, pczIn, dDe, dIn;
+    uint32_t kDeA, kDeB, kInA, kInB;
+    bool inDeA, inDeB, inInA, inInB;
+};
+
+template <bool DE, bool IN>
+BF_DEV ApxBlock apxBlock(const Dev& d, const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, int4 e, uint32_t flags, uint32_t lane) {
+    ApxBlock b;
+    const float ix = (float)(e.x * BS + (int)(lane & 7)), iy = (float)(e.y * BS + (int)(lane >> 3));
     const float xw = ix * c.voxelSize, yw = iy * c.voxelSize;
-    const bool useDe = DE && (flags & 2u), useIn = IN && (flags & 1u);       // wave-uniform
-    ApxCol cDe = {0.0f, 0.0f, 0.0f}, cIn = {0.0f, 0.0f, 0.0f};
-    if (useDe) cDe = apxCol(pDe, ix, iy, xw, yw);
-    if (useIn) cIn = apxCol(pIn, ix, iy, xw, yw);
-    uint32_t* base = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + lane));
-    const float kz = (float)(e.z * BS);
-#pragma unroll 1
-    for (int z = 0; z < 8; z += 2) {
-        uint32_t* vpA = base + (size_t)z * 64u * 3u; uint32_t* vpB = vpA + 64u * 3u;
-        v2f vS, vW; uint32_t vCA, vCB;
-        vS.x = __uint_as_float(vpA[0]); vW.x = __uint_as_float(vpA[1]); vCA = vpA[2];
-        vS.y = __uint_as_float(vpB[0]); vW.y = __uint_as_float(vpB[1]); vCB = vpB[2];
-        v2f iz; iz.x = kz + (float)z; iz.y = kz + (float)(z + 1);                 // exact small integers
-        const v2f pz = iz * sp2(c.voxelSize);
-        ApxSample aDe, aIn;
-        aDe.inA = aDe.inB = aIn.inA = aIn.inB = false; aDe.offA = aDe.offB = aIn.offA = aIn.offB = 0xFFFFFFFFu; aDe.pcz = aIn.pcz = sp2(0.0f);
-        if (useDe) aDe = apxProject(c, pDe, cDe, iz, pz);
-        if (useIn) aIn = apxProject(c, pIn, cIn, iz, pz);
-        v2f dDe = sp2(0.0f), dIn = sp2(0.0f); uint32_t kDeA = 0u, kDeB = 0u, kInA = 0u, kInB = 0u;
-        if (useDe) {
-            dDe.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aDe.offA, 0, 0)); kDeA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aDe.offA, 0, 0);
-            dDe.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aDe.offB, 0, 0)); kDeB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aDe.offB, 0, 0);
-        }
-        if (useIn) {
-            dIn.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aIn.offA, 0, 0)); kInA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aIn.offA, 0, 0);
-            dIn.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)aIn.offB, 0, 0)); kInB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)aIn.offB, 0, 0);
-        }
-        // sample validity (voxelSample): the depth -inf of an invalid pixel fails |sdf| < trunc by itself; |sdf| < trunc makes the
-        // reference's clamp to [-trunc, trunc] the identity
-        const v2f sDe = dDe - aDe.pcz, sIn = dIn - aIn.pcz;
-        const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * dIn;       // the exact contract's operations: the validity of a sample (hence every weight) does not depend on the contract
-        const bool okDeA = aDe.inA && dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = aDe.inB && dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
-        const bool okInA = aIn.inA && dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = aIn.inB && dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
-        const bool anyA = okDeA || okInA, anyB = okDeB || okInB;
-        if (!anyA && !anyB) continue;
-        if (DE && (okDeA || okDeB)) {           // voxelApply<true>
-            const v2f dd = vW - sp2(1.0f);
-            v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
-            uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(kDeA, k); cc.y = byteF(kDeB, k);
-                const v2f q = RNE ? pkfma(o, vW, -cc) * r : pkfma(pkfma(o, vW, -cc), r, sp2(0.5f));
-                nA = packByte<RNE>(q.x, (uint32_t)k, nA); nB = packByte<RNE>(q.y, (uint32_t)k, nB);
-            }
-            const v2f s = pkfma(vS, vW, -sDe) * r;
-            float sA = s.x, sB = s.y, wA = fmaxf(0.0f, dd.x), wB = fmaxf(0.0f, dd.y);
-            if (wA <= 0.001f) { sA = 0.0f; nA = 0u; wA = 0.0f; }
-            if (wB <= 0.001f) { sB = 0.0f; nB = 0u; wB = 0.0f; }
-            if (okDeA) { vS.x = sA; vW.x = wA; vCA = nA; }
-            if (okDeB) { vS.y = sB; vW.y = wB; vCB = nB; }
-        }
-        if (IN && (okInA || okInB)) {           // voxelApply<false>
-            const v2f dd = sp2(1.0f) + vW;
-            v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
-            v2f ca, cb;                         // colour blend 0.2 new + 0.8 old; a voxel without weight takes the new colour
-            ca.x = vW.x == 0.0f ? 1.0f : 0.2f; cb.x = vW.x == 0.0f ? 0.0f : 0.8f;
-            ca.y = vW.y == 0.0f ? 1.0f : 0.2f; cb.y = vW.y == 0.0f ? 0.0f : 0.8f;
-            uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(kInA, k); cc.y = byteF(kInB, k);
-                const v2f m = pkfma(o, cb, RNE ? cc * ca : pkfma(cc, ca, sp2(0.5f)));
-                nA = packByte<RNE>(m.x, (uint32_t)k, nA); nB = packByte<RNE>(m.y, (uint32_t)k, nB);
-            }
-            const v2f s = pkfma(vS, vW, sIn) * r;
-            if (okInA) { vS.x = s.x; vW.x = fminf(c.weightMax, dd.x); vCA = nA; }
-            if (okInB) { vS.y = s.y; vW.y = fminf(c.weightMax, dd.y); vCB = nB; }
-        }
-        if (anyA) { vpA[0] = __float_as_uint(vS.x); vpA[1] = __float_as_uint(vW.x); vpA[2] = vCA; }
-        if (anyB) { vpB[0] = __float_as_uint(vS.y); vpB[1] = __float_as_uint(vW.y); vpB[2] = vCB; }
-    }
+    b.useDe = DE && (flags & 2u); b.useIn = IN && (flags & 1u);
+    b.cDe = apxCol(pDe, ix, iy, xw, yw);
+    b.cIn = apxCol(pIn, ix, iy, xw, yw);
+    b.base = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + lane));
+    b.kz = (float)(e.z * BS);
+    return b;
 }
 
-template <int MODE, bool RNE>
+template <bool DE, bool IN>
+BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, __amdgpu_buffer_rsrc_t depthRes,
+                         __amdgpu_buffer_rsrc_t colorRes) {
+    ApxPair o;
+    const uint32_t* vpA = b.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
+    o.vS.x = __uint_as_float(vpA[0]); o.vW.x = __uint_as_float(vpA[1]); o.vCA = vpA[2];
+    o.vS.y = __uint_as_float(vpB[0]); o.vW.y = __uint_as_float(vpB[1]); o.vCB = vpB[2];
+    v2f iz; iz.x = b.kz + (float)z; iz.y = b.kz + (float)(z + 1);                 // exact small integers
+    const v2f pz = iz * sp2(c.voxelSize);
+    o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
+    o.inDeA = o.inDeB = o.inInA = o.inInB = false;
+    if (DE) {
+        const ApxSample a = apxProject(c, pDe, b.cDe, iz, pz, b.useDe);
+        o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
+        o.dDe.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offA, 0, 0)); o.kDeA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offA, 0, 0);
+        o.dDe.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offB, 0, 0)); o.kDeB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offB, 0, 0);
+    }
+    if (IN) {
+        const ApxSample a = apxProject(c, pIn, b.cIn, iz, pz, b.useIn);
+        o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
+        o.dIn.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offA, 0, 0)); o.kInA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offA, 0, 0);
+        o.dIn.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offB, 0, 0)); o.kInB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offB, 0, 0);
+    }
+    return o;
+}
+
+// Stage B: sample validity, voxelApply<true> and / or voxelApply<false>, store.
+template <bool DE, bool IN, bool RNE>
+BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& a) {
+    uint32_t* vpA = b.base + (size_t)z * 64u * 3u; uint32_t* vpB = vpA + 64u * 3u;
+    v2f vS = a.vS, vW = a.vW; uint32_t vCA = a.vCA, vCB = a.vCB;
+    // sample validity (voxelSample): the depth -inf of an invalid pixel fails |sdf| < trunc by itself; |sdf| < trunc makes the reference's
+    // clamp to [-trunc, trunc] the identity.  Truncation in the exact contract's operations: the validity of a sample (hence every
+    // weight) does not depend on the contract.
+    const v2f sDe = a.dDe - a.pczDe, sIn = a.dIn - a.pczIn;
+    const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * a.dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * a.dIn;
+    const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
+    const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
+    const bool anyA = okDeA || okInA, anyB = okDeB || okInB;
+    if (!anyA && !anyB) return;
+    if (DE && (okDeA || okDeB)) {           // voxelApply<true>
+        const v2f dd = vW - sp2(1.0f);
+        v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
+        uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(a.kDeA, k); cc.y = byteF(a.kDeB, k);
+            const v2f q = RNE ? pkfma(o, vW, -cc) * r : pkfma(pkfma(o, vW, -cc), r, sp2(0.5f));
+            nA = packByte<RNE>(q.x, (uint32_t)k, nA); nB = packByte<RNE>(q.y, (uint32_t)k, nB);
+        }
+        const v2f s = pkfma(vS, vW, -sDe) * r;
+        float sA = s.x, sB = s.y, wA = fmaxf(0.0f, dd.x), wB = fmaxf(0.0f, dd.y);
+        if (wA <= 0.001f) { sA = 0.0f; nA = 0u; wA = 0.0f; }
+        if (wB <= 0.001f) { sB = 0.0f; nB = 0u; wB = 0.0f; }
+        if (okDeA) { vS.x = sA; vW.x = wA; vCA = nA; }
+        if (okDeB) { vS.y = sB; vW.y = wB; vCB = nB; }
+    }
+    if (IN && (okInA || okInB)) {           // voxelApply<false>
+        const v2f dd = sp2(1.0f) + vW;
+        v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
+        v2f ca, cb;                         // colour blend 0.2 new + 0.8 old; a voxel without weight takes the new colour
+        ca.x = vW.x == 0.0f ? 1.0f : 0.2f; cb.x = vW.x == 0.0f ? 0.0f : 0.8f;
+        ca.y = vW.y == 0.0f ? 1.0f : 0.2f; cb.y = vW.y == 0.0f ? 0.0f : 0.8f;
+        uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(a.kInA, k); cc.y = byteF(a.kInB, k);
+            const v2f m = pkfma(o, cb, RNE ? cc * ca : pkfma(cc, ca, sp2(0.5f)));
+            nA = packByte<RNE>(m.x, (uint32_t)k, nA); nB = packByte<RNE>(m.y, (uint32_t)k, nB);
+        }
+        const v2f s = pkfma(vS, vW, sIn) * r;
+        if (okInA) { vS.x = s.x; vW.x = fminf(c.weightMax, dd.x); vCA = nA; }
+        if (okInB) { vS.y = s.y; vW.y = fminf(c.weightMax, dd.y); vCB = nB; }
+    }
+    if (anyA) { vpA[0] = __float_as_uint(vS.x); vpA[1] = __float_as_uint(vW.x); vpA[2] = vCA; }
+    if (anyB) { vpB[0] = __float_as_uint(vS.y); vpB[1] = __float_as_uint(vW.y); vpB[2] = vCB; }
+}
+
+struct ApxEntry { int4 e; uint32_t flags; };
+template <int MODE>
+BF_DEV ApxEntry apxEntry(const Dev& d, uint32_t blk) {
+    ApxEntry r;
+    r.e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];                                              // wave-uniform
+    r.flags = MODE == 2 ? reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4] : 3u;
+    return r;
+}
+
+template <int MODE, bool RNE, bool PIPE>
 __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in, ApxPose de, const float* __restrict__ depth, const uchar4* __restrict__ color,
                                                     int accumulate) {
     if (color == nullptr) return;
@@ -1289,12 +1338,47 @@ __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in,
         if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
         else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
     }
+    if (wave >= n) return;
     const __amdgpu_buffer_rsrc_t depthRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(depth), 0, (int)c.bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t colorRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uchar4*>(color), 0, (int)c.bytes, 0x00020000);
-    for (uint32_t blk = wave; blk < n; blk += nWaves) {
-        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];                                    // wave-uniform
-        const uint32_t flags = MODE == 2 ? reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4] : 3u;
-        colApprox<DE, IN, RNE>(d, c, in, de, e, flags, lane, depthRes, colorRes);
+    if (!PIPE) {           // one pair at a time: one memory round trip per pair, hidden by the other waves of the SIMD only
+        for (uint32_t blk = wave; blk < n; blk += nWaves) {
+            const ApxEntry en = apxEntry<MODE>(d, blk);
+            const ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
+#pragma unroll 1
+            for (int z = 0; z < 8; z += 2) {
+                const ApxPair pa = apxStageA<DE, IN>(c, in, de, cur, z, depthRes, colorRes);
+                apxStageB<DE, IN, RNE>(c, cur, z, pa);
+            }
+        }
+        return;
+    }
+    // The wave's stream of work is (block, pair) for its blocks wave, wave + nWaves, ...; stage A runs one pair ahead of stage B, across
+    // block boundaries, and the list entry of the next block is fetched one block ahead.
+    uint32_t nextBlk = wave + nWaves;
+    ApxEntry en = apxEntry<MODE>(d, wave);
+    ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
+    if (nextBlk < n) en = apxEntry<MODE>(d, nextBlk);
+    ApxPair pa = apxStageA<DE, IN>(c, in, de, cur, 0, depthRes, colorRes);
+    int z = 0;
+    for (;;) {
+        ApxBlock nb = cur;
+        int nz = z + 2;
+        bool more = true;
+        if (z == 6) {                                   // wave-uniform
+            nz = 0;
+            more = nextBlk < n;
+            if (more) {
+                nb = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
+                nextBlk += nWaves;
+                if (nextBlk < n) en = apxEntry<MODE>(d, nextBlk);
+            }
+        }
+        ApxPair pn = pa;
+        if (more) pn = apxStageA<DE, IN>(c, in, de, nb, nz, depthRes, colorRes);
+        apxStageB<DE, IN, RNE>(c, cur, z, pa);
+        if (!more) break;
+        cur = nb; z = nz; pa = pn;
     }
 }
 
@@ -1434,6 +1518,7 @@ struct bf_scene {
     bool forceExactDiv = false;     // k_update_col takes the literal `/` path for every block (BF_TSDF_EXACT_DIV=1; tests)
     int arith = BF_TSDF_ARITH_EXACT; // bf_scene_set_arith / BF_TSDF_ARITH: exact (IEEE op by op, default) or fast (k_update_apx)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
+    bool apxPipe = true;            // k_update_apx: stage A of the next voxel pair issued before stage B of the current one (BF_APX_PIPE=0: off)
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
@@ -1552,8 +1637,13 @@ int probeCvt(bf_scene* s) {
 
 template <int MODE>
 void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* depth, const uchar4* color, int acc) {
-    if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
-    else hipLaunchKernelGGL((k_update_apx<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
+    if (s->apxPipe) {
+        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
+        else hipLaunchKernelGGL((k_update_apx<MODE, false, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
+    } else {
+        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
+        else hipLaunchKernelGGL((k_update_apx<MODE, false, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
+    }
 }
 
 void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepHashSDF.h:128-134
@@ -1742,6 +1832,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_GRID_UPDATE_COL_PLAIN")) s->gridUpdateColPlain = (uint32_t)atoi(e);
     if (const char* e = getenv("BF_TSDF_UPDATE")) s->columnUpdate = strcmp(e, "voxel") != 0;
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
+    if (const char* e = getenv("BF_APX_PIPE")) s->apxPipe = atoi(e) != 0;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
@@ -1913,6 +2004,16 @@ int bf_scene_get_hash_data(bf_scene* s, bf_hash_data* out) {
     return BF_OK;
 }
 
+// Scratch-capacity conditions of the allocation (bin / de-dup set / overflow list full, allocated-block list full) are recorded on the
+// device by the asynchronous operators; every accessor that synchronises anyway reports them (bf_scene_integrate itself never waits).
+static int checkDeviceErrors(bf_scene* s) {
+    uint32_t stats[ST_COUNT];
+    BF_HIP_TRY(hipMemcpyAsync(stats, s->d.stats, sizeof stats, hipMemcpyDeviceToHost, s->stream));
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    if (stats[ST_ERROR]) { set_error("TSDF scratch capacity exceeded during an earlier operator (error bits 0x%x: 1 bin, 2 de-dup set, 4 overflow list, 8 GC, 16 block list)", stats[ST_ERROR]); return BF_ERR_CAPACITY; }
+    return BF_OK;
+}
+
 int bf_scene_get_hash_params(bf_scene* s, bf_hash_params* out) {
     BF_REQUIRE(s && out, "null argument");
     BF_TRY_RC(refreshStaleList(s));
@@ -1922,7 +2023,7 @@ int bf_scene_get_hash_params(bf_scene* s, bf_hash_params* out) {
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
     s->params.m_numOccupiedBlocks = (uint32_t)n;
     *out = s->params;
-    return BF_OK;
+    return checkDeviceErrors(s);
 }
 
 int bf_scene_get_heap_free_count(bf_scene* s, uint32_t* out) {       // :168-172

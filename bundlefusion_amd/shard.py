@@ -144,7 +144,9 @@ class ChunkedRunner:
         for f in range(self.next_frame, self.next_frame + n):
             c = 0 if f == 0 else (f - 1) // self.S
             self._ensure(c)
-            assert self.pipe.process_frame_chunked(self.feed[f][0], self.feed[f][1], self.pkgs[c], f - c * self.S)
+            ok = self.pipe.process_frame_chunked(self.feed[f][0], self.feed[f][1], self.pkgs[c], f - c * self.S)      # not inside an assert: python -O strips those
+            if not ok:
+                raise RuntimeError("frame %d of the stream was not accepted by the global half" % f)
             for old in [k for k in self.pkgs if k < c - self.world]:
                 del self.pkgs[old]
         self.next_frame += n

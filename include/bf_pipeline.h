@@ -370,8 +370,11 @@ BF_API int bf_chunk_worker_run(bf_chunk_worker* w, uint32_t chunkIndex, uint32_t
                                void* h_package);
 /* one iteration of the frame loop for the next frame of the stream, whose chunk-local half is in `h_package` (localIdx = index of the frame in that
  * package's chunk; 0 only for the very first frame).  Ingest for integration, pose chaining, integration / re-integration into this pipeline's volume
- * (shard), and — at the chunk's last frame — the global step.  The stream must hold 1 + k * s_submapSize frames. */
-BF_API int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, const uint8_t* d_colorRGBX, const void* h_package, uint32_t localIdx, int* gotFrame);
+ * (shard), and — at the chunk's last frame — the global step.  The stream must hold 1 + k * s_submapSize frames.
+ * `packageBytes` is the size of the buffer the package arrived in: every offset, count and index of the header is checked against it and against this
+ * pipeline's configuration before it is used (BF_ERR_INVALID_ARG otherwise). */
+BF_API int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, const uint8_t* d_colorRGBX, const void* h_package, uint64_t packageBytes, uint32_t localIdx,
+                                             int* gotFrame);
 
 #ifdef __cplusplus
 }

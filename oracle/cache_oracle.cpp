@@ -31,9 +31,15 @@ void resampleIdx(unsigned x, unsigned y, unsigned ow, unsigned oh, unsigned iw, 
 
 }  // namespace
 
+namespace orc { int g_threads = 1; }
+
 extern "C" {
 
+void or_set_threads(int n) { orc::g_threads = n < 1 ? 1 : n; }
+int or_get_threads() { return orc::g_threads; }
+
 void or_erode_depth(float* out, const float* in, int structureSize, int w, int h, float dThresh, float fracReq) {
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             unsigned count = 0;
@@ -51,6 +57,7 @@ void or_erode_depth(float* out, const float* in, int structureSize, int w, int h
 
 void or_gauss_filter_depth(float* out, const float* in, float sigmaD, float sigmaR, unsigned w, unsigned h) {
     const int r = (int)ceil(2.0 * sigmaD);
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (int y = 0; y < (int)h; ++y)
         for (int x = 0; x < (int)w; ++x) {
             float sum = 0.0f, sumW = 0.0f;
@@ -73,6 +80,7 @@ void or_gauss_filter_depth(float* out, const float* in, float sigmaD, float sigm
 
 void or_gauss_filter_intensity(float* out, const float* in, float sigmaD, unsigned w, unsigned h) {
     const int r = (int)ceil(2.0 * sigmaD);
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (int y = 0; y < (int)h; ++y)
         for (int x = 0; x < (int)w; ++x) {
             float sum = 0.0f, sumW = 0.0f;
@@ -88,6 +96,7 @@ void or_gauss_filter_intensity(float* out, const float* in, float sigmaD, unsign
 }
 
 void or_resample_float(float* out, unsigned ow, unsigned oh, const float* in, unsigned iw, unsigned ih) {
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < oh; ++y)
         for (unsigned x = 0; x < ow; ++x) {
             unsigned xi, yi;
@@ -98,6 +107,7 @@ void or_resample_float(float* out, unsigned ow, unsigned oh, const float* in, un
 
 // resampleUCHAR4_Kernel, CUDAImageUtil.cu:160-177 (colour to the integration resolution, CUDAImageManager.cpp:72-78)
 void or_resample_uchar4(uint8_t* out, unsigned ow, unsigned oh, const uint8_t* in, unsigned iw, unsigned ih) {
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < oh; ++y)
         for (unsigned x = 0; x < ow; ++x) {
             unsigned xi, yi;
@@ -109,6 +119,7 @@ void or_resample_uchar4(uint8_t* out, unsigned ow, unsigned oh, const uint8_t* i
 float or_intensity(const uint8_t* c) { return (0.299f * (float)c[0] + 0.587f * (float)c[1] + 0.114f * (float)c[2]) / 255.0f; }
 
 void or_resample_to_intensity(float* out, unsigned ow, unsigned oh, const uint8_t* in, unsigned iw, unsigned ih) {
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < oh; ++y)
         for (unsigned x = 0; x < ow; ++x) {
             unsigned xi, yi;
@@ -118,6 +129,7 @@ void or_resample_to_intensity(float* out, unsigned ow, unsigned oh, const uint8_
 }
 
 void or_intensity_derivatives(float* out2, const float* in, unsigned w, unsigned h) {
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < h; ++y)
         for (unsigned x = 0; x < w; ++x) {
             float* o = out2 + 2 * (y * w + x);
@@ -138,6 +150,7 @@ void or_intensity_derivatives(float* out2, const float* in, unsigned w, unsigned
 
 void or_depth_to_campos(float* out4, const float* in, const float* intrinsicsInv, unsigned w, unsigned h) {
     const float* M = intrinsicsInv;
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < h; ++y)
         for (unsigned x = 0; x < w; ++x) {
             float* o = out4 + 4 * (y * w + x);
@@ -154,6 +167,7 @@ void or_depth_to_campos(float* out4, const float* in, const float* intrinsicsInv
 }
 
 void or_compute_normals(float* out4, const float* in4, unsigned w, unsigned h) {
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < h; ++y)
         for (unsigned x = 0; x < w; ++x) {
             float* o = out4 + 4 * (y * w + x);
@@ -194,6 +208,7 @@ void or_cache_store_frame(const float* depth, unsigned dw, unsigned dh, const ui
     const float* din = depth;
     if (sigmaD > 0.0f) { or_gauss_filter_depth(filt.data(), depth, sigmaD, sigmaR, dw, dh); din = filt.data(); }
     or_depth_to_campos(campos.data(), din, inputIntrinsicsInv, dw, dh);
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < H; ++y)
         for (unsigned x = 0; x < W; ++x) {
             unsigned xi, yi;
@@ -201,6 +216,7 @@ void or_cache_store_frame(const float* depth, unsigned dw, unsigned dh, const ui
             if (xi < dw && yi < dh) memcpy(camposDown4 + 4 * (y * W + x), campos.data() + 4 * ((size_t)yi * dw + xi), 16);
         }
     or_compute_normals(normals.data(), campos.data(), dw, dh);
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (unsigned y = 0; y < H; ++y)
         for (unsigned x = 0; x < W; ++x) {
             unsigned xi, yi;

@@ -30,6 +30,10 @@
 
 namespace orc {
 
+// Host threads of the image-space loops (every output pixel is computed independently, so the results do not depend on it).
+// Set by or_set_threads (cpu_baseline: 1 thread and all cores); the voxel update takes its thread count per call.
+extern int g_threads;
+
 static const float MINF = -std::numeric_limits<float>::infinity();
 static const float PINF = std::numeric_limits<float>::infinity();
 

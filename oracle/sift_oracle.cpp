@@ -65,6 +65,7 @@ SiftParams makeParams() {       // SiftParam::ParseSiftParam, SiftGPU.cpp:126-17
 void blur(const std::vector<float>& src, std::vector<float>& dst, int w, int h, const std::vector<float>& k) {
     const int fw = (int)k.size(), half = fw >> 1;
     std::vector<float> tmp((size_t)w * h);
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (int y = 0; y < h; ++y)          // FilterH :159-196 (clamp to edge)
         for (int x = 0; x < w; ++x) {
             float v = 0;
@@ -72,6 +73,7 @@ void blur(const std::vector<float>& src, std::vector<float>& dst, int w, int h, 
             tmp[(size_t)y * w + x] = v;
         }
     dst.resize((size_t)w * h);
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
     for (int y = 0; y < h; ++y)          // FilterV :198-264
         for (int x = 0; x < w; ++x) {
             float v = 0;
@@ -120,6 +122,7 @@ static void buildAndDetect(const SiftParams& P, const float* intensity, const fl
         for (int a = 1; a <= 3; ++a) {
             Level& L = oc.lev[a];
             L.mag.resize(L.g.size()); L.ang.resize(L.g.size());
+#pragma omp parallel for num_threads(orc::g_threads) schedule(static)
             for (int y = 0; y < oc.h; ++y)
                 for (int x = 0; x < oc.w; ++x) {
                     const long idx = (long)y * oc.w + x;

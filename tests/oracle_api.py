@@ -15,6 +15,13 @@ from bundlefusion_amd.capi import (HashParams, DepthCameraParams, HASH_ENTRY_DTY
                                    HASH_BUCKET_SIZE, VOX_PER_BLOCK, mat16)
 
 olib.or_scene_create.restype = C.c_void_p
+
+
+def set_threads(n):
+    """Host threads of the oracle's image-space loops (ingest filters, cache frame, SIFT pyramid); results do not depend on it."""
+    olib.or_set_threads(int(n))
+
+
 olib.or_scene_hash.restype = C.c_void_p
 olib.or_scene_heap.restype = C.c_void_p
 olib.or_scene_voxels.restype = C.c_void_p

@@ -457,7 +457,8 @@ class OraclePipeline:
         self.cam = camera_params(gas.s_integrationWidth, gas.s_integrationHeight, float(Ki[0, 0]), float(Ki[1, 1]), float(Ki[0, 2]), float(Ki[1, 2]),
                                  gas.s_renderDepthMin, gas.s_renderDepthMax)
         import os
-        self.threads = os.cpu_count() or 1
+        self.threads = os.cpu_count() or 1          # voxel update (per call) and, through set_threads(), the image-space loops
+        o.set_threads(self.threads)
 
     # ---- CUDAImageManager::process
     def _ingest(self, depth, color):

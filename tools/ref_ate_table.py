@@ -31,6 +31,8 @@ def params(a):
     gas.s_integrationWidth, gas.s_integrationHeight = a.width, a.height
     gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = a.voxel, a.buckets, a.blocks
     gas.s_garbageCollectionEnabled = False
+    if a.exit_frames >= 0:
+        gas.s_numSolveFramesBeforeExit = a.exit_frames          # the end-of-scan switch to the dense global solve after that many iterations past the end
     gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = a.width, a.height, a.frames // a.submap + 8, a.submap
     return gas, gbs
 
@@ -204,6 +206,7 @@ def main():
     p.add_argument("--submap", type=int, default=10); p.add_argument("--tail", type=int, default=5)
     p.add_argument("--voxel", type=float, default=0.05); p.add_argument("--buckets", type=int, default=5000); p.add_argument("--blocks", type=int, default=2000)
     p.add_argument("--perturb", type=int, default=0)
+    p.add_argument("--exit-frames", type=int, default=-1, help="s_numSolveFramesBeforeExit (default: the parameter file's 30, i.e. no end-of-scan dense solve within --tail)")
     p.add_argument("--out"); p.add_argument("--table", nargs="*")
     a = p.parse_args()
     if a.table:

@@ -47,7 +47,8 @@ def main():
     for k in range(n):
         depth = sd.depth(k)                                 # metres, -inf invalid
         color = sd.color_rgbx(k)
-        assert p.process_frame(depth, color)
+        if not p.process_frame(depth, color):
+            raise RuntimeError("frame not accepted")
         keep = (keep + [(depth, color)])[-4:]
     for _ in range(a.tail):
         p.process_end_of_sequence()
