@@ -54,8 +54,14 @@ def main():
                     help="auto = 'serial' on one GPU, 'chunks' on N>1: one stream, local chunks round-robin over the ranks + all-gather of key-frame "
                          "packages + replicated global half + volume sharded by hash bucket (strong scaling).  'segments' = each rank its own stream "
                          "segment and volume (weak scaling); 'volume-shard' = one stream, bundling replicated, volume sharded")
+    ap.add_argument("--arith", choices=["fast", "exact"], default=os.environ.get("BF_TSDF_ARITH", "fast"),
+                    help="arithmetic contract of the voxel update in the measured leg (bf_scene_set_arith): 'fast' = the reference GPU build's own contract "
+                         "(-use_fast_math), 'exact' = IEEE op by op, bit-identical with the oracle")
+    ap.add_argument("--both-contracts", action="store_true", default=True, help="(1 GPU) also measure the other contract, reported as other_contract")
+    ap.add_argument("--one-contract", dest="both_contracts", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=21, help="frames of the stream the CPU baseline processes (two local chunks)")
+    ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the stream the CPU baseline processes (three local chunks: the last ten frames "
+                    "run with the re-integration queue saturated, like the timed window of the GPU leg)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,6 +69,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     W, H = 640, 480
     pre = args.preroll + args.warmup
+    if world > 1 and args.mode in ("auto", "chunks"):
+        # chunk-parallel mode: a round is world * 10 frames (frames r*world*10 + 1 .. (r+1)*world*10).  The timed window starts at a round
+        # boundary, so that it contains this round's all-gather and - running ahead on the second host thread - the whole local half of
+        # the next round (SIFT, local matching, local solve, key-frame fusion of one chunk per rank), not only the replicated global half.
+        rnd = world * 10
+        pre = ((pre - 1 + rnd - 1) // rnd) * rnd + 1
     total = pre + args.steps
 
     # synthetic stream, rendered by plain-python subprocesses before HIP is initialised
@@ -106,25 +118,11 @@ def main():
         gbs.s_maxNumImages = max(n_render // 10 + 8, 16)
         return gas, gbs
 
-    gas, gbs = params()
-    pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
-    if shard_volume and world > 1:
-        pipe.set_volume_shard(rank, world)
     if args.host:
         feed = [(f[0], f[1]) for f in frames]
     else:
         feed = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
     torch.cuda.synchronize()
-
-    runner = None
-    if chunked:
-        assert not args.host, "chunks mode feeds HBM-resident frames"
-        gas_w, gbs_w = params()
-        runner = ChunkedRunner(pipe, bf.capi.ChunkWorker(gas_w, gbs_w, sensor_desc(W, H, K)), feed, gbs_w.s_submapSize, rank, world, "cuda")
-        assert runner.frames_needed(total) <= len(feed)
-    sc = pipe.scene()
-    if args.pmc_out:
-        sc.kernel_timing(True)                               # profiling run: account every launch of the run (the PMC passes see all of them)
     if args.clock_warmup > 0:                                # untimed: bring the GPU out of its idle power state (state-free: a scratch matrix product)
         wa = torch.randn(4096, 4096, device="cuda"); wb = torch.randn(4096, 4096, device="cuda")
         tw = time.perf_counter()
@@ -133,66 +131,114 @@ def main():
                 wa = torch.mm(wa, wb) * 1e-2
             torch.cuda.synchronize()
         del wa, wb
-    if chunked:
-        runner.advance(pre)
-        runner.wait()                                        # the local half running ahead belongs to the pre-roll
-    else:
-        for k in range(pre):
-            if not pipe.process_frame(*feed[k]):
-                raise RuntimeError("pre-roll frame %d not accepted" % k)
-    pipe.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    sc = pipe.scene()
-    if not args.pmc_out:
-        sc.kernel_timing(True)                               # HIP events around every voxel-update launch, on the pipeline's stream
-    c0 = pipe.counters()
-    pipe.host_profile(reset=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if chunked:
-        rounds0 = runner.rounds
-        runner.advance(args.steps)
-        runner.wait()                                        # ... and the one started inside the timed window is paid for inside it
-    else:
-        for k in range(pre, total):
-            if not pipe.process_frame(*feed[k]):
-                raise RuntimeError("frame %d not accepted" % k)
-    pipe.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    c1 = pipe.counters()
-    hp = pipe.host_profile()
-    occ_sum, vis_plain, vis_fused, n_ops = sc.kernel_timing_blocks()
-    n_launch, kernel_ms = sc.kernel_timing_read()
-    sc.kernel_timing(False)
-    elapsed = max_over_ranks(elapsed, "cuda")
-    if shard_volume and world > 1:      # the replicated global half must have produced ONE trajectory (bit-identical on every rank): RCCL MIN/MAX all-reduce
-        traj_dev = torch.from_numpy(np.nan_to_num(pipe.integrated_trajectory(), neginf=-1e30)).cuda()
-        assert same_over_ranks(traj_dev), "ranks disagree on the trajectory"
 
-    # dominant kernel: the TSDF voxel update.  Algorithmic bytes: one integrate / de-integrate operator moves
-    # N_occ*(512*24+32) + W*H*8 bytes; a FUSED re-integration launch (de-integrate old pose + integrate new pose in one pass) reads and
-    # writes every voxel of the UNION of its two frustum lists once, so it is charged N_union*(512*24+32) + W*H*8, not 2 B.
-    n_fused = n_ops - n_launch                                   # operators = plain + 2 * fused, launches = plain + fused
-    n_occ = occ_sum / max(n_ops, 1)
-    bytes_per_launch = ((vis_plain + vis_fused) * (512 * 24 + 32) + n_launch * W * H * 8) / max(n_launch, 1)
-    avg_kernel_s = (kernel_ms / 1e3) / max(n_launch, 1)
-    achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-    traffic = pmc_traffic(args, vis_plain, vis_fused, n_launch)
-    if args.pmc_out and rank == 0:
-        json.dump({"config": pmc_config(args), "launches": n_launch, "fused_launches": n_fused, "visited_blocks_plain": vis_plain,
-                   "visited_blocks_fused": vis_fused, "operator_blocks": occ_sum}, open(args.pmc_out, "w"))
-    dbg = sc.debug_hash()
-    traj = pipe.integrated_trajectory()
     T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
     gt = np.stack([T0inv @ f[2].astype(np.float64) for f in frames])
-    valid = np.isfinite(traj[:, 0, 0])
-    ate = float(np.sqrt(np.mean(np.sum((traj[valid][:, :3, 3] - gt[:len(traj)][valid][:, :3, 3]) ** 2, axis=1)))) if valid.any() else None
+
+    def run_leg(arith):
+        """The whole measurement (pre-roll, warm-up, K timed steps) with the voxel update under one arithmetic contract."""
+        gas, gbs = params()
+        pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+        pipe.scene().set_arith(arith)
+        if shard_volume and world > 1:
+            pipe.set_volume_shard(rank, world)
+        runner = None
+        if chunked:
+            assert not args.host, "chunks mode feeds HBM-resident frames"
+            gas_w, gbs_w = params()
+            runner = ChunkedRunner(pipe, bf.capi.ChunkWorker(gas_w, gbs_w, sensor_desc(W, H, K)), feed, gbs_w.s_submapSize, rank, world, "cuda")
+            assert runner.frames_needed(total) <= len(feed)
+        sc = pipe.scene()
+        if args.pmc_out:
+            sc.kernel_timing(True)                               # profiling run: account every launch of the run (the PMC passes see all of them)
+        if chunked:
+            runner.advance(pre)
+            runner.wait()                                        # the local half running ahead belongs to the pre-roll
+        else:
+            for k in range(pre):
+                if not pipe.process_frame(*feed[k]):
+                    raise RuntimeError("pre-roll frame %d not accepted" % k)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        sc = pipe.scene()
+        if not args.pmc_out:
+            sc.kernel_timing(True)                               # HIP events around every voxel-update launch, on the pipeline's stream
+        c0 = pipe.counters()
+        pipe.host_profile(reset=True)
+        torch.cuda.synchronize()
+        rounds0 = runner.rounds if chunked else 0
+        t0 = time.perf_counter()
+        if chunked:
+            runner.advance(args.steps)
+            runner.wait()                                        # ... and the one started inside the timed window is paid for inside it
+        else:
+            for k in range(pre, total):
+                if not pipe.process_frame(*feed[k]):
+                    raise RuntimeError("frame %d not accepted" % k)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        L = {"arith": arith, "c0": c0, "c1": pipe.counters(), "hp": pipe.host_profile()}
+        L["occ_sum"], L["vis_plain"], L["vis_fused"], L["n_ops"] = sc.kernel_timing_blocks()
+        L["n_launch"], L["kernel_ms"] = sc.kernel_timing_read()
+        sc.kernel_timing(False)
+        L["elapsed"] = max_over_ranks(elapsed, "cuda")
+        L["rounds"] = (runner.rounds - rounds0) if chunked else 0
+        if chunked and L["rounds"] == 0:
+            raise RuntimeError("the timed window holds no round of the chunk-parallel schedule (no local half, no all-gather): not a whole-loop measurement")
+        if shard_volume and world > 1:      # the replicated global half must have produced ONE trajectory (bit-identical on every rank): RCCL MIN/MAX all-reduce
+            traj_dev = torch.from_numpy(np.nan_to_num(pipe.integrated_trajectory(), neginf=-1e30)).cuda()
+            assert same_over_ranks(traj_dev), "ranks disagree on the trajectory"
+        L["dbg"] = sc.debug_hash()
+        traj = pipe.integrated_trajectory()
+        valid = np.isfinite(traj[:, 0, 0])
+        L["frames_valid"], L["frames_total"] = int(valid.sum()), int(len(traj))
+        L["ate"] = float(np.sqrt(np.mean(np.sum((traj[valid][:, :3, 3] - gt[:len(traj)][valid][:, :3, 3]) ** 2, axis=1)))) if valid.any() else None
+        if runner is not None:
+            runner.close()
+        del sc, pipe, runner
+        torch.cuda.synchronize()
+        return L
+
+    def roofline_of(L):
+        # dominant kernel: the TSDF voxel update.  Algorithmic bytes (SURVEY.md 8d): one integrate / de-integrate operator moves
+        # N_occ*(512*24+32) + W*H*8 bytes; a FUSED re-integration launch (de-integrate old pose + integrate new pose in one pass) reads and
+        # writes every voxel of the UNION of its two frustum lists once, so it is charged N_union*(512*24+32) + W*H*8, not 2 B.
+        n_launch, n_ops = L["n_launch"], L["n_ops"]
+        n_fused = n_ops - n_launch                                   # operators = plain + 2 * fused, launches = plain + fused
+        bytes_per_launch = ((L["vis_plain"] + L["vis_fused"]) * (512 * 24 + 32) + n_launch * W * H * 8) / max(n_launch, 1)
+        avg_kernel_s = (L["kernel_ms"] / 1e3) / max(n_launch, 1)
+        achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        traffic = pmc_traffic(args, L["arith"], L["vis_plain"], L["vis_fused"], n_launch)
+        kern = "k_update_apx<2> (fused de-integrate + integrate) + k_update_apx<0> (integrate)" if L["arith"] == "fast" else \
+               "k_update_col<2> (fused de-integrate + integrate) + k_update_col<0> (integrate)"
+        return {
+            "kernel": kern + " - TSDF voxel update, tsdf.hip",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "hbm_frac_measured": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_kernel_s > 0) else None,
+            "launches": n_launch, "fused_launches": n_fused, "avg_launch_us": 1e6 * avg_kernel_s,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": L["occ_sum"] / max(n_ops, 1),
+            "blocks_visited_per_launch": (L["vis_plain"] + L["vis_fused"]) / max(n_launch, 1),
+            "accounting": "fused launch = union list once: N_union*(512*24+32) + W*H*8 B; traffic = PMC bytes per visited block "
+                          "(profiles/r03_pmc_tsdf_update.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes, same contract) x blocks visited here",
+            "share_of_step_time": (L["kernel_ms"] / 1e3) / L["elapsed"] if L["elapsed"] > 0 else None,
+        }
+
+    main_leg = run_leg(args.arith)
+    other = None
+    if args.both_contracts and world == 1 and not args.pmc_out:
+        other = run_leg("exact" if args.arith == "fast" else "fast")
+    if args.pmc_out and rank == 0:
+        json.dump({"config": pmc_config(args), "launches": main_leg["n_launch"], "fused_launches": main_leg["n_ops"] - main_leg["n_launch"],
+                   "visited_blocks_plain": main_leg["vis_plain"], "visited_blocks_fused": main_leg["vis_fused"], "operator_blocks": main_leg["occ_sum"]}, open(args.pmc_out, "w"))
+    elapsed, c0, c1, hp, dbg = main_leg["elapsed"], main_leg["c0"], main_leg["c1"], main_leg["hp"], main_leg["dbg"]
+    ate = main_leg["ate"]
 
     if rank == 0:
         out = {
@@ -211,40 +257,37 @@ def main():
             "config": {
                 "workload": "BASELINE configs[1] stand-in: S2 room stream %dx%d @%.0f mm voxels through the full frame loop (ingest, SIFT, "
                             "match+filters, local+global GN/PCG, TSDF integrate + re-integration + GC); 1 step = 1 input frame; timed: frames "
-                            "%d..%d of the stream after an untimed pre-roll of %d + %d warm-up frames (re-integration queue saturated, %d key "
-                            "frames in the global problem)" % (W, H, args.voxel * 1e3, first + pre, first + total - 1, args.preroll, args.warmup, pre // 10),
+                            "%d..%d of the stream after an untimed pre-roll of %d frames incl. %d warm-up frames (re-integration queue saturated, %d key "
+                            "frames in the global problem)" % (W, H, args.voxel * 1e3, first + pre, first + total - 1, pre, args.warmup, pre // 10),
                 "input": "host buffers per frame (PCIe inclusive)" if args.host else "frames resident in HBM",
                 "clock_warmup_s": args.clock_warmup,
                 "params": "zParametersDefault.txt + zParametersBundlingDefault.txt values; s_integrationWidth/Height=640/480, "
                           "s_SDFVoxelSize=%.3f, s_hashNumBuckets=%d, s_hashNumSDFBlocks=%d" % (args.voxel, args.buckets, args.blocks),
                 "timed_ops": {k: c1[k] - c0[k] for k in c1},
-                "frames_valid": int(valid.sum()), "frames_total": int(len(traj)), "ate_rmse_vs_ground_truth_m": ate,
+                "frames_valid": main_leg["frames_valid"], "frames_total": main_leg["frames_total"], "ate_rmse_vs_ground_truth_m": ate,
                 "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
                 "render_seconds_untimed": round(t_gen, 1),
                 "host_thread_ms_per_frame": {k: round(1e3 * v / max(hp["frames"], 1.0), 4) for k, v in hp.items() if k != "frames"},
                 "frame_loop": "serial order, detection of frame k+1 overlapped with matching/solve of frame k (BF_PIPELINE_LOOKAHEAD=%s)"
                               % os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
                 "parallelism": ("one stream: local chunks round-robin over %d ranks, %d RCCL all-gathers of key-frame packages in the timed region, global half "
-                                "replicated, volume sharded by hash-bucket range" % (world, runner.rounds - rounds0)) if chunked
+                                "replicated, volume sharded by hash-bucket range" % (world, main_leg["rounds"])) if chunked
                                else ("one stream, bundling replicated on %d ranks, volume sharded by hash-bucket range" % world) if (shard_volume and world > 1)
                                else "one GPU, serial frame loop" if world == 1 else "stream segments sharded over %d rank(s), no data-path collective" % world,
                 "mode": mode,
             },
-            "roofline": {
-                "kernel": "k_update<integrate> + k_reupdate (fused de-integrate+integrate) — TSDF voxel update",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "hbm_frac_measured": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_kernel_s > 0) else None,
-                "launches": n_launch, "fused_launches": n_fused, "avg_launch_us": 1e6 * avg_kernel_s,
-                "algorithmic_bytes_per_launch": bytes_per_launch, "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": n_occ,
-                "blocks_visited_per_launch": (vis_plain + vis_fused) / max(n_launch, 1),
-                "accounting": "fused launch = union list once: N_union*(512*24+32) + W*H*8 B; traffic = PMC bytes per visited block "
-                              "(profiles/r02_pmc_tsdf_update.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes) x blocks visited here",
-                "share_of_step_time": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None,
-            },
+            "roofline": roofline_of(main_leg),
         }
+        out["config"]["arith"] = ("%s: the voxel update under the arithmetic contract of the reference's own GPU build (FriedLiver.vcxproj:124 FastMath: approximate "
+                                  "division, FMA contraction); same block set / occupancy / weights as the exact contract, sdf 1e-5 x truncation, colour 1 LSB per operator "
+                                  "(tests/test_tsdf_fast_gpu.py)" % main_leg["arith"]) if main_leg["arith"] == "fast" else \
+                                 "exact: every operation of the voxel update IEEE op by op, bit-identical with the oracle (tests/test_tsdf_gpu.py)"
+        if other is not None:
+            out["other_contract"] = {"arith": other["arith"], "value": args.steps / other["elapsed"], "unit": "frames/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
+                                     "roofline": roofline_of(other), "timed_ops": {k: other["c1"][k] - other["c0"][k] for k in other["c1"]},
+                                     "same_trajectory": other["ate"] == main_leg["ate"]}
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], params, K, W, H)
+            out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], feed[:args.cpu_frames], params, K, W, H, args.arith)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -254,36 +297,73 @@ def pmc_config(args):
     return {"preroll": args.preroll, "voxel": args.voxel, "buckets": args.buckets, "blocks": args.blocks, "host": bool(args.host)}
 
 
-def pmc_traffic(args, vis_plain, vis_fused, n_launch):
-    """HBM bytes per voxel-update launch of THIS run, from the committed PMC passes (profiles/r02_pmc_tsdf_update.json: rocprofv3
+def pmc_traffic(args, arith, vis_plain, vis_fused, n_launch):
+    """HBM bytes per voxel-update launch of THIS run, from the committed PMC passes (profiles/r03_pmc_tsdf_update.json: rocprofv3
     FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, each in its own run of this command with --pmc-out): bytes per visited SDF block
-    of the plain and of the fused kernel, times the blocks the timed launches of this run visited.  None when the counters were
-    collected on another configuration (pre-roll / volume parameters)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_tsdf_update.json")
+    of the plain and of the fused kernel under the same arithmetic contract, times the blocks the timed launches of this run visited.
+    None when the counters were collected on another configuration (pre-roll / volume parameters / contract)."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_tsdf_update.json")
     if not os.path.exists(path) or n_launch == 0:
         return None
-    pmc = json.load(open(path))
-    if pmc["config"] != pmc_config(args):
+    pmc = json.load(open(path)).get(arith)
+    if not pmc or pmc["config"] != pmc_config(args):
         return None
-    return (vis_fused * pmc["k_reupdate"]["hbm_bytes_per_visited_block"] + vis_plain * pmc["k_update"]["hbm_bytes_per_visited_block"]) / n_launch
+    return (vis_fused * pmc["fused"]["hbm_bytes_per_visited_block"] + vis_plain * pmc["plain"]["hbm_bytes_per_visited_block"]) / n_launch
 
 
-def cpu_baseline(frames, params, K, W, H):
-    """The oracle frame loop (kind 'port': the reference has no runnable CPU path) on this box's host cores,
-    on a bounded sample of the same stream: its first two local chunks (21 frames => SIFT, matching, filters, TSDF integration
-    at 4 mm, two local solves, the first global matching + solve and the re-integration it triggers; about 7 s on the GPU
-    box).  Orchestration is single-threaded Python; the voxel update runs on all cores (OpenMP)."""
+def cpu_baseline(frames, feed, params, K, W, H, arith):
+    """The oracle frame loop (kind 'port': the reference has no runnable CPU path) on this box's host cores, on a bounded
+    sample of the same stream: its first three local chunks from frame 0 (31 frames: SIFT, matching, filters, TSDF integration at 4 mm,
+    three local solves, two global matchings + solves; from frame 21 on every frame also carries s_maxFrameFixes = 10 re-integrations,
+    the state the GPU leg's timed window is in).  N threads: the voxel update and the image-space loops (ingest filters, cache frame,
+    SIFT pyramid) run on all cores (OpenMP over independent blocks / pixels), median of 3 runs; 1 thread: one run of the first chunk.
+    `gpu_same_sample` is the HIP path on exactly the same 31 frames from a fresh pipeline (frames resident in HBM), so that the ratio
+    compares the same work."""
+    import statistics
+    import torch
+    import bundlefusion_amd as bf
+    from bundlefusion_amd.capi import sensor_desc
+    from tests import oracle_api
     from tests.oracle_pipeline import OraclePipeline
-    gas, gbs = params(400000, 200000)      # two chunks touch < 150k blocks; a smaller heap keeps the host allocation out of the timing
-    op0 = time.perf_counter()
-    op = OraclePipeline(gas, gbs, W, H, K)
+
+    def run(n_frames, threads):
+        gas, gbs = params(400000, 250000)      # three chunks touch < 200k blocks; a smaller heap keeps the host allocation out of the timing
+        op = OraclePipeline(gas, gbs, W, H, K)
+        if threads is not None:
+            op.threads = threads
+            oracle_api.set_threads(threads)
+        t0 = time.perf_counter()
+        for d, c, _, _ in frames[:n_frames]:
+            op.process_frame(d, c)
+        dt = time.perf_counter() - t0
+        n_ops = len(op.integrate_ops)
+        th = op.threads
+        del op
+        return n_frames / dt, dt, n_ops, th
+
+    runs = [run(len(frames), None) for _ in range(3)]
+    fps_n = statistics.median(r[0] for r in runs)
+    n1 = min(11, len(frames))
+    fps_1, dt_1, _, _ = run(n1, 1)
+    # the GPU on the same sample
+    gas, gbs = params(400000, 250000)
+    pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    pipe.scene().set_arith(arith)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for d, c, _, _ in frames:
-        op.process_frame(d, c)
-    dt = time.perf_counter() - t0
-    return {"value": len(frames) / dt, "unit": "frames/s", "cores": op.threads, "kind": "port",
-            "sample": "first %d frames of the same stream (local chunks incl. their solves, global solve and re-integration), %.1f s; stage kernels in C++ "
-                      "(voxel update on %d OpenMP threads, the rest single-threaded)" % (len(frames), dt, op.threads)}
+    for d, c in feed:
+        if not pipe.process_frame(d, c):
+            raise RuntimeError("frame not accepted")
+    pipe.synchronize(); torch.cuda.synchronize()
+    gpu_fps = len(feed) / (time.perf_counter() - t0)
+    c = pipe.counters()
+    del pipe
+    return {"value": fps_n, "unit": "frames/s", "cores": runs[0][3], "kind": "port",
+            "single_thread": {"value": fps_1, "unit": "frames/s", "cores": 1, "sample": "first %d frames (one local chunk), one run, %.1f s" % (n1, dt_1)},
+            "gpu_same_sample": {"value": gpu_fps, "unit": "frames/s", "timed_ops": {k: int(v) for k, v in c.items()}},
+            "sample": "first %d frames of the same stream from frame 0 (three local chunks incl. their solves, two global solves, %d TSDF operators: the last 10 "
+                      "frames with 10 re-integrations each), median of 3 runs (%s s); stage kernels in C++, voxel update + image-space loops on %d OpenMP threads, "
+                      "matching / filters / solver / orchestration single-threaded" % (len(frames), runs[0][2], ", ".join("%.1f" % r[1] for r in runs), runs[0][3])}
 
 
 if __name__ == "__main__":

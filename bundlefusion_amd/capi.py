@@ -698,8 +698,15 @@ class SiftManager:
                                               T.ctypes.data_as(C.c_void_p), Ti.ctypes.data_as(C.c_void_p)))
         return n.value, idx, dist, T, Ti
 
-    def fuse_to_global(self, glob, K, d_transforms, Kinv):
-        check(lib.bf_siftmgr_fuse_to_global(self._h, glob._h, _f16(K), C.c_void_p(d_transforms), _f16(Kinv)))
+    def fuse_to_global(self, glob, K, d_transforms, Kinv, host=False):
+        """fuseToGlobal on the device (default) or in the reference's host form (host=True); same results bit for bit"""
+        fn = lib.bf_siftmgr_fuse_to_global_host if host else lib.bf_siftmgr_fuse_to_global
+        check(fn(self._h, glob._h, _f16(K), C.c_void_p(d_transforms), _f16(Kinv)))
+
+    def fuse_error(self):
+        e = C.c_int()
+        check(lib.bf_siftmgr_fuse_error(self._h, C.byref(e)))
+        return e.value
 
 
 # --------------------------------------------------------------------------- host-level operators (include/bf_pipeline.h)

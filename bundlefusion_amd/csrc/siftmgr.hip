@@ -915,6 +915,168 @@ m44 toM44(const float* p) { m44 m; memcpy(m.e, p, 64); return m; }
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// fuseToGlobal on the device (SIFTImageManager.cpp:367-476: computeTracks + fuseToGlobal).  The reference copies all key points,
+// descriptors and correspondences of the chunk to the host (1.6 MB), builds the tracks with a recursive depth-first search and
+// uploads the fused key frame.  Here the chunk hand-off never leaves HBM: ONE workgroup
+//   1. builds the adjacency lists of the key graph (both directions of every valid correspondence, each key's list in
+//      correspondence order - the order the reference's corrPerKey vectors have),
+//   2. labels the connected components with their smallest key index (the key the reference's search starts a track from: it
+//      visits the keys in ascending order and a search from the first key of a component exhausts it),
+//   3. runs the reference's depth-first search per component, one thread each - the SAME pre-order, because the track's first
+//      element is its representative and the averaged position is a float sum taken in track order,
+//   4. compacts the tracks in ascending start-key order into the new key frame of the global manager (key points, descriptors,
+//      count - all written on the device; the depth sort of an over-full key frame included).
+// Bit-identical with the host search (bf_siftmgr_fuse_to_global_host, kept for comparison: tests/test_match_gpu.py).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct FuseAdj { uint32_t src, dst, img, order; float px, py, pz; uint32_t pad; };      // 32 B: edge src -> dst (key indices image * maxKeys + key)
+struct FuseArgs {
+    const bf_entry_j* glob; const uint2* globKeys; uint32_t R;
+    const m44* T; const int* numKeys; const Key* keys; const uint8_t* descs; uint32_t nI, mk;
+    m44 K;
+    uint32_t* cnt; uint32_t* start; uint32_t* fill; FuseAdj* adj; uint32_t* label; uint32_t* marker; uint32_t* flag; uint32_t* rep; Key* tmpKeys; uint32_t* outPos;
+    Key* dstKeys; uint8_t* dstDescs; int* dstNum; uint32_t dstMaxKeys; int* error;
+};
+constexpr int FUSE_THREADS = 1024;
+constexpr int FUSE_MAX_DEPTH = 512;
+
+BF_DEV uint32_t fuseBlockScan(uint32_t v, uint32_t* lds, uint32_t& total) {       // exclusive scan over the block's threads
+    const uint32_t t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < (uint32_t)FUSE_THREADS; o <<= 1) {
+        const uint32_t add = t >= o ? lds[t - o] : 0u;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    total = lds[FUSE_THREADS - 1];
+    const uint32_t ex = lds[t] - v;
+    __syncthreads();
+    return ex;
+}
+
+__global__ __launch_bounds__(FUSE_THREADS) void k_fuse_to_global(FuseArgs a) {
+    __shared__ uint32_t lds[FUSE_THREADS];
+    __shared__ uint32_t changed;
+    const uint32_t t = threadIdx.x, N = a.nI * a.mk;
+    const float NINF_ = BF_MINF;
+    for (uint32_t k = t; k < N; k += FUSE_THREADS) { a.cnt[k] = 0u; a.label[k] = k; a.marker[k] = 0u; a.flag[k] = 0u; }
+    __syncthreads();
+    // 1. adjacency: count, scan, fill, per-key order
+    for (uint32_t i = t; i < a.R; i += FUSE_THREADS) {
+        if (a.glob[i].imgIdx_i == 0xFFFFFFFFu) continue;
+        const uint2 k = a.globKeys[i];
+        atomicAdd(&a.cnt[k.x], 1u); atomicAdd(&a.cnt[k.y], 1u);
+    }
+    __syncthreads();
+    const uint32_t per = (N + FUSE_THREADS - 1) / FUSE_THREADS;
+    uint32_t mine = 0;
+    for (uint32_t k = t * per; k < min(N, (t + 1) * per); ++k) mine += a.cnt[k];
+    uint32_t totalE;
+    uint32_t base = fuseBlockScan(mine, lds, totalE);
+    for (uint32_t k = t * per; k < min(N, (t + 1) * per); ++k) { a.start[k] = base; a.fill[k] = base; base += a.cnt[k]; }
+    __syncthreads();
+    for (uint32_t i = t; i < a.R; i += FUSE_THREADS) {
+        const bf_entry_j c = a.glob[i];
+        if (c.imgIdx_i == 0xFFFFFFFFu) continue;
+        const uint2 k = a.globKeys[i];
+        const f3 pi = mk3(c.pos_i[0], c.pos_i[1], c.pos_i[2]), pj = mk3(c.pos_j[0], c.pos_j[1], c.pos_j[2]);
+        const f3 d = xform(a.T[c.imgIdx_i], pi) - xform(a.T[c.imgIdx_j], pj);
+        const bool ok = sqrtf(dot3(d, d)) < 0.03f;                                   // MAX_TRACK_CORR_ERROR
+        FuseAdj e;
+        e.pad = 0u;
+        e.src = k.x; e.dst = k.y; e.img = c.imgIdx_j; e.order = i; e.px = ok ? pj.x : NINF_; e.py = ok ? pj.y : NINF_; e.pz = ok ? pj.z : NINF_;
+        a.adj[atomicAdd(&a.fill[k.x], 1u)] = e;
+        e.src = k.y; e.dst = k.x; e.img = c.imgIdx_i; e.px = ok ? pi.x : NINF_; e.py = ok ? pi.y : NINF_; e.pz = ok ? pi.z : NINF_;
+        a.adj[atomicAdd(&a.fill[k.y], 1u)] = e;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < N; k += FUSE_THREADS) {                                 // each key's list in correspondence order
+        const uint32_t n = a.cnt[k], s0 = a.start[k];
+        for (uint32_t i = 1; i < n; ++i) {
+            const FuseAdj e = a.adj[s0 + i];
+            uint32_t j = i;
+            while (j > 0 && a.adj[s0 + j - 1].order > e.order) { a.adj[s0 + j] = a.adj[s0 + j - 1]; --j; }
+            a.adj[s0 + j] = e;
+        }
+    }
+    __syncthreads();
+    // 2. connected components: label = smallest key index
+    for (int it = 0; it < 4096; ++it) {
+        if (t == 0) changed = 0u;
+        __syncthreads();
+        for (uint32_t e = t; e < totalE; e += FUSE_THREADS) {
+            const uint32_t u = a.adj[e].src, v = a.adj[e].dst;
+            const uint32_t lu = a.label[u], lv = a.label[v];
+            if (lu < lv) { atomicMin(&a.label[v], lu); changed = 1u; }
+            else if (lv < lu) { atomicMin(&a.label[u], lv); changed = 1u; }
+        }
+        __syncthreads();
+        const uint32_t ch = changed;
+        __syncthreads();
+        if (!ch) break;
+    }
+    // 3. the reference's depth-first search, one thread per component
+    for (uint32_t k = t; k < N; k += FUSE_THREADS) {
+        if (a.cnt[k] == 0u || a.label[k] != k) continue;
+        uint32_t stKey[FUSE_MAX_DEPTH]; uint16_t stPos[FUSE_MAX_DEPTH];
+        int sp = 0;
+        stKey[0] = k; stPos[0] = 0;
+        f3 pos = mk3(0, 0, 0);
+        uint32_t num = 0, rep = 0xFFFFFFFFu;
+        bool overflow = false;
+        while (sp >= 0) {
+            const uint32_t u = stKey[sp], p = stPos[sp];
+            if (p >= a.cnt[u]) { --sp; continue; }
+            stPos[sp] = (uint16_t)(p + 1);
+            const FuseAdj e = a.adj[a.start[u] + p];
+            if (a.marker[e.dst]) continue;
+            if (rep == 0xFFFFFFFFu) rep = e.dst;
+            if (e.px != NINF_) { pos = pos + xform(a.T[e.img], mk3(e.px, e.py, e.pz)); num++; }
+            a.marker[e.dst] = 1u;
+            if (sp + 1 >= FUSE_MAX_DEPTH) { overflow = true; break; }
+            ++sp; stKey[sp] = e.dst; stPos[sp] = 0;
+        }
+        if (overflow) { atomicExch(a.error, 1); continue; }
+        if (num > 0) {
+            pos = pos / (float)num;
+            pos = xform(a.K, pos);
+            Key key;
+            key.x = pos.x / pos.z; key.y = pos.y / pos.z; key.scale = a.keys[rep].scale; key.depth = pos.z;
+            a.tmpKeys[k] = key; a.rep[k] = rep; a.flag[k] = 1u;
+        }
+    }
+    __syncthreads();
+    // 4. tracks in ascending start-key order -> the new key frame
+    mine = 0;
+    for (uint32_t k = t * per; k < min(N, (t + 1) * per); ++k) mine += a.flag[k];
+    uint32_t M;
+    base = fuseBlockScan(mine, lds, M);
+    for (uint32_t k = t * per; k < min(N, (t + 1) * per); ++k) { a.outPos[k] = base; base += a.flag[k]; }
+    __syncthreads();
+    const uint32_t numOut = min(M, a.dstMaxKeys);
+    if (M <= a.dstMaxKeys) {
+        for (uint32_t k = t; k < N; k += FUSE_THREADS) if (a.flag[k]) a.dstKeys[a.outPos[k]] = a.tmpKeys[k];
+    } else {
+        // more tracks than the key frame holds: like the reference, the KEYS are sorted by depth (the descriptors keep the track order)
+        // and the first maxKeys of each are kept.  rank = keys with smaller (depth, track position)
+        for (uint32_t k = t; k < N; k += FUSE_THREADS) {
+            if (!a.flag[k]) continue;
+            const float dk = a.tmpKeys[k].depth; const uint32_t pk = a.outPos[k];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < N; ++j) if (a.flag[j]) { const float dj = a.tmpKeys[j].depth; rank += (dj < dk || (dj == dk && a.outPos[j] < pk)) ? 1u : 0u; }
+            if (rank < a.dstMaxKeys) a.dstKeys[rank] = a.tmpKeys[k];
+        }
+    }
+    // descriptors of the representatives: 128 B = 8 x 16 B each
+    for (uint32_t k = 0; k < N; ++k) {             // block-uniform loop; (a serial walk over <= 11 k flags costs a few microseconds)
+        if (!a.flag[k] || a.outPos[k] >= numOut) continue;
+        if (t < 8) reinterpret_cast<uint4*>(a.dstDescs + (size_t)a.outPos[k] * 128)[t] = reinterpret_cast<const uint4*>(a.descs + (size_t)a.rep[k] * 128)[t];
+    }
+    if (t == 0) *a.dstNum = (int)numOut;
+}
+
 struct bf_siftmgr {
     uint32_t maxImages = 0, maxKeys = 0, maxResiduals = 0;
     hipStream_t stream = nullptr;
@@ -930,6 +1092,8 @@ struct bf_siftmgr {
     bool resPrefetched = false;
     bool validDirty = false;          // host copy of the valid flags changed since the last upload
     std::deque<uint32_t> retry;
+    // scratch of the device-side fuseToGlobal (allocated at first use)
+    void* fuseScratch = nullptr; size_t fuseScratchBytes = 0; int* d_fuseError = nullptr;
 };
 
 extern "C" {
@@ -966,6 +1130,8 @@ int bf_siftmgr_destroy(bf_siftmgr* m) {
     hipFree(m->d_keys); hipFree(m->d_descs); hipFree(m->d_numKeys); hipFree(m->d_numMatches); hipFree(m->d_dist); hipFree(m->d_idx);
     hipFree(m->d_numFilt); hipFree(m->d_fdist); hipFree(m->d_fidx); hipFree(m->d_T); hipFree(m->d_Tinv); hipFree(m->d_validImages); hipFree(m->d_validOpt);
     hipFree(m->d_glob); hipFree(m->d_globKeys); hipFree(m->d_globNum); hipFree(m->d_res);
+    if (m->fuseScratch) hipFree(m->fuseScratch);
+    if (m->d_fuseError) hipFree(m->d_fuseError);
     if (m->h_res) hipHostFree(m->h_res);
     delete m;
     return BF_OK;
@@ -1279,6 +1445,54 @@ void findTrack(const std::vector<std::vector<TrackEl>>& corrPerKey, std::vector<
 
 int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16], const float* d_transforms,
                               const float colorIntrinsicsInv[16]) {
+    BF_REQUIRE(local && global && colorIntrinsics && d_transforms, "null argument");
+    BF_REQUIRE(local->globNumResiduals > 0, "no correspondences to fuse");
+    static const bool hostPath = [] { const char* e = getenv("BF_FUSE_HOST"); return e && atoi(e) != 0; }();
+    if (hostPath) return bf_siftmgr_fuse_to_global_host(local, global, colorIntrinsics, d_transforms, colorIntrinsicsInv);
+    const uint32_t R = local->globNumResiduals, nI = local->numImages, mk = local->maxKeys;
+    const size_t N = (size_t)nI * mk;
+    // scratch: 8 arrays of N words + N key points + 2R edges
+    const size_t need = N * 4 * 9 + N * sizeof(Key) + (size_t)2 * local->maxResiduals * sizeof(FuseAdj) + 256;
+    if (local->fuseScratchBytes < need) {
+        if (local->fuseScratch) BF_HIP_TRY(hipFree(local->fuseScratch));
+        local->fuseScratch = nullptr; local->fuseScratchBytes = 0;
+        const size_t cap = (size_t)local->maxImages * mk * 4 * 9 + (size_t)local->maxImages * mk * sizeof(Key) + (size_t)2 * local->maxResiduals * sizeof(FuseAdj) + 256;
+        BF_HIP_TRY(hipMalloc(&local->fuseScratch, cap));
+        local->fuseScratchBytes = cap;
+    }
+    if (!local->d_fuseError) { BF_HIP_TRY(hipMalloc((void**)&local->d_fuseError, sizeof(int))); BF_HIP_TRY(hipMemset(local->d_fuseError, 0, sizeof(int))); }
+    bf_sift_image_gpu img;
+    { const int rc = bf_siftmgr_create_image(global, &img); if (rc != BF_OK) return rc; }
+    FuseArgs a;
+    a.glob = local->d_glob; a.globKeys = local->d_globKeys; a.R = R;
+    a.T = reinterpret_cast<const m44*>(d_transforms); a.numKeys = local->d_numKeys; a.keys = local->d_keys; a.descs = local->d_descs; a.nI = nI; a.mk = mk;
+    a.K = toM44(colorIntrinsics);
+    uint8_t* q = reinterpret_cast<uint8_t*>(local->fuseScratch);
+    auto take = [&](size_t bytes) { uint8_t* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
+    a.cnt = (uint32_t*)take(N * 4); a.start = (uint32_t*)take(N * 4); a.fill = (uint32_t*)take(N * 4); a.label = (uint32_t*)take(N * 4); a.marker = (uint32_t*)take(N * 4);
+    a.flag = (uint32_t*)take(N * 4); a.rep = (uint32_t*)take(N * 4); a.outPos = (uint32_t*)take(N * 4);
+    a.tmpKeys = (Key*)take(N * sizeof(Key)); a.adj = (FuseAdj*)take((size_t)2 * R * sizeof(FuseAdj));
+    a.dstKeys = reinterpret_cast<Key*>(img.d_keyPoints); a.dstDescs = reinterpret_cast<uint8_t*>(img.d_keyPointDescs); a.dstNum = img.d_numKeyPoints; a.dstMaxKeys = global->maxKeys;
+    a.error = local->d_fuseError;
+    // the chunk's manager and the global manager share the bundling stream in the frame loop; if they do not, order them
+    if (global->stream != local->stream) BF_HIP_TRY(hipStreamSynchronize(global->stream));
+    k_fuse_to_global<<<1, FUSE_THREADS, 0, local->stream>>>(a);
+    BF_HIP_TRY(hipGetLastError());
+    if (global->stream != local->stream) BF_HIP_TRY(hipStreamSynchronize(local->stream));
+    return bf_siftmgr_finalize_image(global, -1);          // the count was written on the device
+}
+
+// A track deeper than the search stack of k_fuse_to_global (512 keys in one chain) raises this flag; bf_siftmgr_fuse_error reports it.
+int bf_siftmgr_fuse_error(bf_siftmgr* local, int* err) {
+    BF_REQUIRE(local && err, "null argument");
+    *err = 0;
+    if (local->d_fuseError) { BF_HIP_TRY(hipMemcpyAsync(err, local->d_fuseError, sizeof(int), hipMemcpyDeviceToHost, local->stream)); BF_HIP_TRY(hipStreamSynchronize(local->stream)); }
+    return BF_OK;
+}
+
+// The reference's own form: everything to the host, recursive search there, upload (kept for comparison and as BF_FUSE_HOST=1).
+int bf_siftmgr_fuse_to_global_host(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16], const float* d_transforms,
+                                   const float colorIntrinsicsInv[16]) {
     (void)colorIntrinsicsInv;
     BF_REQUIRE(local && global && colorIntrinsics && d_transforms, "null argument");
     BF_REQUIRE(local->globNumResiduals > 0, "no correspondences to fuse");

@@ -1286,7 +1286,10 @@ BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& 
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(a.kDeA, k); cc.y = byteF(a.kDeB, k);
-            const v2f q = RNE ? pkfma(o, vW, -cc) * r : pkfma(pkfma(o, vW, -cc), r, sp2(0.5f));
+            // roundf of the exact contract = nearest, ties AWAY from zero, and (o w - c) / (w - 1) is an exact tie for every second value at small
+            // weights (w = 3: half-integers): the conversion's nearest-EVEN would be 1 LSB off there, and the next operators amplify it.  The
+            // bias pushes ties up; a non-tie is at least 1 / (2 (w - 1)) away from one, the quotient's own error is < 7e-5 - exact for w < 2000.
+            const v2f q = pkfma(pkfma(o, vW, -cc), r, sp2(RNE ? 0x1p-12f : 0.5f));
             nA = packByte<RNE>(q.x, (uint32_t)k, nA); nB = packByte<RNE>(q.y, (uint32_t)k, nB);
         }
         const v2f s = pkfma(vS, vW, -sDe) * r;
@@ -1518,7 +1521,8 @@ struct bf_scene {
     bool forceExactDiv = false;     // k_update_col takes the literal `/` path for every block (BF_TSDF_EXACT_DIV=1; tests)
     int arith = BF_TSDF_ARITH_EXACT; // bf_scene_set_arith / BF_TSDF_ARITH: exact (IEEE op by op, default) or fast (k_update_apx)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
-    bool apxPipe = true;            // k_update_apx: stage A of the next voxel pair issued before stage B of the current one (BF_APX_PIPE=0: off)
+    bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
+                                    // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
@@ -1527,10 +1531,14 @@ struct bf_scene {
     // allocation never touches voxels; the only shared object is the frustum list, which is double-buffered.
     bool overlap = false;
     hipStream_t prep = nullptr;
-    bf_hash_entry* cbuf[2] = {nullptr, nullptr}; uint32_t* csrc[2] = {nullptr, nullptr}; int32_t* ccnt[2] = {nullptr, nullptr};
+    // NB list buffers: allocation + list of operator n+1 .. n+NB-1 may be prepared while operator n updates voxels.  (With two buffers the
+    // prep stream had to wait for the update two operators back, and the two cross-stream event hops of ~40 us each sat inside the
+    // steady-state cycle: period = hop + (prep + update) / 2, profiles/r03_timeline_fast_before.txt: 50 us idle between consecutive updates.)
+    static constexpr int NB = 4;
+    bf_hash_entry* cbuf[NB] = {nullptr, nullptr, nullptr, nullptr}; uint32_t* csrc[NB] = {nullptr, nullptr, nullptr, nullptr}; int32_t* ccnt[NB] = {nullptr, nullptr, nullptr, nullptr};
     int cur = 0;                    // buffer that holds the latest list (== d.compact / d.compactSrc / d.compactCount)
-    hipEvent_t evPrep[2] = {nullptr, nullptr}, evUpd[2] = {nullptr, nullptr}, evBarrier = nullptr, evTmp = nullptr;
-    bool updRecorded[2] = {false, false}, barrierPending = false;
+    hipEvent_t evPrep[NB] = {nullptr, nullptr, nullptr, nullptr}, evUpd[NB] = {nullptr, nullptr, nullptr, nullptr}, evBarrier = nullptr, evTmp = nullptr;
+    bool updRecorded[NB] = {false, false, false, false}, barrierPending = false;
     hipEvent_t pendingEv = nullptr; // bf_scene_wait_event: the next operator's first kernel waits for it
     bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
     // optional HIP-event timing of the voxel-update kernel
@@ -1704,12 +1712,12 @@ void launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_d
 // One operator = [allocation] -> frustum list -> voxel update.  kind 0 integrate(f), 1 de-integrate(f), 2 fused: de-integrate(fo) +
 // integrate(f).  With overlap enabled the first two phases go to the prep stream and only the update to the main stream.
 int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf_depth_camera_data* data) {
-    const int b = s->overlap ? 1 - s->cur : s->cur;
+    const int b = s->overlap ? (s->cur + 1) % bf_scene::NB : s->cur;
     hipStream_t ps = s->overlap ? s->prep : s->stream;
     if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->pendingEv = nullptr; }
     if (s->overlap) {
         if (s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
-        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer two operators ago
+        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
     }
     const Dev dv = devBuf(s, b);
     if (kind != 1) launchAllocOn(s, ps, f, data->d_depthData);      // de-integration neither allocates nor frees
@@ -1797,9 +1805,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     A(s->d.heap, N);
     A(s->d.heapCounter, 1);
     A(s->d.vox, N * VOX);
-    A(s->cbuf[0], N); A(s->cbuf[1], N);
-    A(s->csrc[0], N); A(s->csrc[1], N);
-    A(s->ccnt[0], 4); A(s->ccnt[1], 4);      // [0] list length, [1] operator blocks of a union list (entries in the new frustum + entries in the old one)
+    for (int b = 0; b < bf_scene::NB; ++b) { A(s->cbuf[b], N); A(s->csrc[b], N); A(s->ccnt[b], 4); }      // ccnt: [0] list length, [1] operator blocks of a union list (entries in the new frustum + entries in the old one)
     A(s->d.occSum, 3);
     A(s->d.allocList, N);
     A(s->d.allocListAlt, N);
@@ -1822,7 +1828,8 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&s->prep, hipStreamNonBlocking, greatest));
     }
-    for (hipEvent_t* e : {&s->evPrep[0], &s->evPrep[1], &s->evUpd[0], &s->evUpd[1], &s->evBarrier, &s->evTmp})
+    for (int b = 0; b < bf_scene::NB; ++b) { BF_HIP_TRY(hipEventCreateWithFlags(&s->evPrep[b], hipEventDisableTiming)); BF_HIP_TRY(hipEventCreateWithFlags(&s->evUpd[b], hipEventDisableTiming)); }
+    for (hipEvent_t* e : {&s->evBarrier, &s->evTmp})
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
     s->gridUpdate = 256 * 16;    // persistent 512-thread workgroups, 16 per CU: measured optimum with the feature pipeline running concurrently (2048: -4 %, 8192: -2 %, 16384: -25 %)
@@ -1863,7 +1870,8 @@ int bf_scene_destroy(bf_scene* s) {
     (void)syncAll(s);
     for (void* q : s->allocations) hipFree(q);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (hipEvent_t e : {s->evPrep[0], s->evPrep[1], s->evUpd[0], s->evUpd[1], s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
+    for (int b = 0; b < bf_scene::NB; ++b) { if (s->evPrep[b]) hipEventDestroy(s->evPrep[b]); if (s->evUpd[b]) hipEventDestroy(s->evUpd[b]); }
+    for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
     if (s->prep) hipStreamDestroy(s->prep);
     delete s;
     return BF_OK;
@@ -1880,7 +1888,8 @@ int bf_scene_set_overlap(bf_scene* s, int enable) {
     BF_REQUIRE(s, "null scene");
     BF_TRY_RC(syncAll(s));
     s->overlap = enable != 0;
-    s->updRecorded[0] = s->updRecorded[1] = false; s->barrierPending = false;
+    for (bool& u : s->updRecorded) u = false;
+    s->barrierPending = false;
     return BF_OK;
 }
 
@@ -1898,9 +1907,9 @@ int bf_scene_reset(bf_scene* s) {                                  // CUDASceneR
     memcpy(s->params.m_rigidTransformInverse, I.e, 64);
     s->params.m_numOccupiedBlocks = 0;
     BF_TRY_RC(syncAll(s));
-    s->compactStale = false; s->updRecorded[0] = s->updRecorded[1] = false; s->barrierPending = false; s->pendingEv = nullptr;
-    BF_HIP_TRY(hipMemsetAsync(s->ccnt[0], 0, 16, s->stream));
-    BF_HIP_TRY(hipMemsetAsync(s->ccnt[1], 0, 16, s->stream));
+    s->compactStale = false; s->barrierPending = false; s->pendingEv = nullptr;
+    for (bool& u : s->updRecorded) u = false;
+    for (int b = 0; b < bf_scene::NB; ++b) BF_HIP_TRY(hipMemsetAsync(s->ccnt[b], 0, 16, s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
     BF_HIP_TRY(hipMemsetAsync(s->d.vox, 0, (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel), s->stream));
     hipLaunchKernelGGL(k_reset, dim3(2048), dim3(256), 0, s->stream, s->d, s->params.m_numSDFBlocks, (uint32_t)numEntries,

@@ -456,9 +456,17 @@ BF_API int bf_siftmgr_get_filt_matches(bf_siftmgr* m, uint32_t imagePairIndex, i
 /* addToRetryList / getTopRetryImage                            .h:263-271 */
 BF_API int bf_siftmgr_add_to_retry_list(bf_siftmgr* m, uint32_t idx);
 BF_API int bf_siftmgr_get_top_retry_image(bf_siftmgr* m, uint32_t* idx, int* found);
-/* fuseToGlobal(global, colorIntrinsics, d_transforms, colorIntrinsicsInv)   SIFTImageManager.cpp:367-476 */
+/* fuseToGlobal(global, colorIntrinsics, d_transforms, colorIntrinsicsInv)   SIFTImageManager.cpp:367-476
+ * Runs on the device (track building by connected components + the reference's depth-first order per component; the new key frame
+ * and its key count are written in HBM, nothing is copied to the host); asynchronous on the manager's stream.
+ * bf_siftmgr_fuse_to_global_host is the reference's own form (all key points / descriptors / correspondences to the host, recursive
+ * search there, upload) - same results bit for bit; BF_FUSE_HOST=1 routes the first entry to it.
+ * bf_siftmgr_fuse_error: 1 if a track was deeper than the device search stack (512 keys in one chain) since creation. */
 BF_API int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16],
                                      const float* d_transforms, const float colorIntrinsicsInv[16]);
+BF_API int bf_siftmgr_fuse_to_global_host(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16],
+                                          const float* d_transforms, const float colorIntrinsicsInv[16]);
+BF_API int bf_siftmgr_fuse_error(bf_siftmgr* local, int* err);
 
 
 /* ------------------------------------------------------------------------- */

@@ -458,7 +458,7 @@ class OraclePipeline:
                                  gas.s_renderDepthMin, gas.s_renderDepthMax)
         import os
         self.threads = os.cpu_count() or 1          # voxel update (per call) and, through set_threads(), the image-space loops
-        o.set_threads(self.threads)
+        o.set_threads(min(self.threads, 16))        # image rows: more threads than that only add barrier traffic (and a container may grant fewer cores than it shows)
 
     # ---- CUDAImageManager::process
     def _ingest(self, depth, color):

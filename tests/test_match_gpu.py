@@ -241,3 +241,71 @@ def test_fuse_to_global_tracks(gpu, oracle):
     # representative descriptor/scale = first element of the track
     assert np.array_equal(gd[0], descs[1][0]) and gk[0][2] == 4.0
     assert np.array_equal(gd[1], descs[2][1]) and np.array_equal(gd[2], descs[2][3])
+    # the device search equals the reference's host form bit for bit
+    glob_h = gpu.capi.SiftManager(8, 64)
+    loc.fuse_to_global(glob_h, K, dT.data_ptr(), Kinv, host=True)
+    hk, hd = glob_h.download_image(0)
+    assert np.array_equal(gk.view(np.uint32), hk.view(np.uint32)) and np.array_equal(gd, hd) and loc.fuse_error() == 0
+
+
+def test_fuse_to_global_device_equals_host_on_random_graphs(gpu, oracle):
+    """Device-side fuseToGlobal (connected components + the reference's depth-first order, one thread per track) against the host
+    form on random correspondence graphs over 11 images: chains, cycles, keys matched several times, outlier correspondences (error
+    above MAX_TRACK_CORR_ERROR: the key joins the track without a position), invalidated correspondences, and a key frame with more
+    tracks than the global manager holds (keys re-sorted by depth, descriptors not: the reference's behaviour).  Keys, descriptors
+    and counts bit for bit; also against the python restatement (tests/oracle_pipeline.fuse_tracks) the pipeline tests use."""
+    import ctypes as C
+    import torch
+    from bundlefusion_amd.capi import lib, check, _h2d
+    from tests.oracle_pipeline import fuse_tracks
+    K = intrinsics_matrix(583.0, 583.0, 319.5, 239.5)
+    Kinv = oracle.inverse44(K)
+    for seed, (nI, per, mk, gmax, ncorr) in enumerate([(11, 40, 64, 1024, 300), (11, 60, 64, 1024, 900), (6, 64, 64, 32, 250), (3, 10, 16, 64, 12)]):
+        rng = np.random.default_rng(100 + seed)
+        loc = gpu.capi.SiftManager(nI + 1, mk)
+        T = []
+        for i in range(nI):
+            M = np.eye(4, dtype=np.float32); M[:3, 3] = rng.normal(0, 0.05, 3).astype(np.float32); T.append(M)
+        keys, descs = [], []
+        for i in range(nI):
+            k = np.c_[rng.uniform(5, 630, per), rng.uniform(5, 470, per), rng.uniform(3, 12, per), rng.uniform(0.8, 3.0, per)].astype(np.float32)
+            keys.append(k); descs.append(rng.integers(0, 255, (per, 128)).astype(np.uint8))
+            loc.add_image_host(k, descs[-1])
+        allkeys_packed = np.concatenate(keys)
+        corr, ck = [], []
+        for _ in range(ncorr):
+            i, j = sorted(rng.choice(nI, 2, replace=False).tolist())
+            a, b = int(rng.integers(per)), int(rng.integers(per))
+            e = oracle.make_entry(allkeys_packed, i * per + a, j * per + b, i, j, Kinv)
+            # make most correspondences consistent (pos_j at the world point of pos_i), some outliers, some invalidated
+            wi = (T[i].astype(np.float64) @ np.r_[e["pos_i"].astype(np.float64), 1.0])[:3]
+            pj = (np.linalg.inv(T[j].astype(np.float64)) @ np.r_[wi, 1.0])[:3]
+            e["pos_j"] = pj.astype(np.float32)
+            r = rng.random()
+            if r < 0.15:
+                e["pos_j"] = e["pos_j"] + np.float32(0.1)
+            elif r < 0.22:
+                e["imgIdx_i"] = 0xFFFFFFFF
+            corr.append(e); ck.append((i * mk + a, j * mk + b))
+        corr = np.array(corr, dtype=ENTRYJ_DTYPE)
+        loc.set_global_correspondences(corr)
+        p = C.c_void_p(); check(lib.bf_siftmgr_get_global_correspondence_keys_gpu(loc._h, C.byref(p)))
+        _h2d(p.value, np.array(ck, np.uint32))
+        dT = torch.from_numpy(np.stack(T)).cuda()
+        gd_, gh_ = gpu.capi.SiftManager(2, gmax), gpu.capi.SiftManager(2, gmax)
+        loc.fuse_to_global(gd_, K, dT.data_ptr(), Kinv)
+        loc.fuse_to_global(gh_, K, dT.data_ptr(), Kinv, host=True)
+        dk, dd = gd_.download_image(0); hk, hd = gh_.download_image(0)
+        assert len(dk) == len(hk) and len(dk) > (5 if nI > 3 else 0), (seed, len(dk), len(hk))
+        assert np.array_equal(dk.view(np.uint32), hk.view(np.uint32)), "seed %d: key points differ" % seed
+        assert np.array_equal(dd, hd), "seed %d: descriptors differ" % seed
+        assert loc.fuse_error() == 0
+        if gmax < 64:
+            assert len(dk) == gmax                       # the over-full branch was taken
+        # the restatement (keys as (n, 4) with the slots of the manager's key layout)
+        allk = np.zeros((nI * mk, 4), np.float32)
+        alld = [np.zeros((mk, 128), np.uint8) for _ in range(nI)]
+        for i in range(nI):
+            allk[i * mk:i * mk + per] = keys[i]; alld[i][:per] = descs[i]
+        ok_, od_ = fuse_tracks(corr, np.array(ck, np.uint32), [np.asarray(t, np.float32) for t in T], [per] * nI, alld, allk, K, mk, gmax)
+        assert np.array_equal(ok_.view(np.uint32), dk.view(np.uint32)) and np.array_equal(od_, dd), "seed %d: differs from the restatement" % seed

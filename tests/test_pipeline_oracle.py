@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from bundlefusion_amd import synth
 from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix
@@ -77,3 +78,17 @@ def test_oracle_frame_loop_tracks_the_synthetic_scene():
     want = json.load(open(GOLDEN))
     diff = [k for k in want if want[k] != snap.get(k)]
     assert not diff, "oracle output changed in: %s (regenerate with tests/golden/make_oracle_snapshot.py if intended)" % diff
+
+
+@pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="3 more minutes: BF_LONG_TESTS=1")
+def test_loop_closure_fixture_is_what_the_oracle_produces(oracle):
+    """tests/golden/loop_closure_oracle.npz (the fixture the GPU loop-closure test holds the product to) re-derived from the oracle frame loop."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_loop_closure_oracle", os.path.join(root, "tests", "golden", "make_loop_closure_oracle.py"))
+    g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+    fx = np.load(os.path.join(root, "tests", "golden", "loop_closure_oracle.npz"))
+    r = g.run()
+    for k in ("integrated", "optimized"):
+        assert np.array_equal(np.asarray(r[k], np.float32).view(np.uint32), fx[k].view(np.uint32)), k
+    assert list(r["counts"]) == list(fx["counts"]) and r["key_frames"] == int(fx["key_frames"]) and r["span"] == int(fx["span"])

@@ -1,0 +1,72 @@
+"""GPU test (-m gpu) of the multi-GPU path with REAL objects in TWO PROCESSES: each rank owns a capi.Pipeline
+with its hash-bucket shard of the volume and a capi.ChunkWorker, runs the chunk-local half of its chunks, exchanges the packages with ONE
+all-gather per round (torch.distributed, backend gloo: both ranks share the single GPU of the test box), runs the replicated global half.
+Against the serial loop in this process: both ranks' trajectories bit for bit, the same operation counts, and the union of the two
+shards is the serial volume bit for bit.  (The gloo tests of tests/test_host_cpu.py drive the same ChunkedRunner with stand-in
+worker / pipeline objects on the CPU; the collective is RCCL when bench.py runs with one GPU per rank.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, sensor_desc, FREE_ENTRY, VOX_PER_BLOCK
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_processes_real_pipeline_and_chunk_worker(gpu, tmp_path):
+    import torch
+    W, H, n, world = 320, 240, 41, 2            # 4 local chunks = 2 rounds of 2
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(tmp_path / ("rank%d.npz" % r)), str(n), str(W), str(H)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    # the serial loop, meanwhile, in this process
+    src = synth.render_frames(range(n), W, H)
+    Kd = src[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.02, 50000, 20000
+    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages = W, H, 8
+    serial = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    for f in src:
+        assert serial.process_frame(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda())
+    for _ in range(3):
+        serial.process_end_of_sequence()
+    serial.synchronize()
+    t0, o0, c0 = serial.integrated_trajectory().copy(), serial.optimized_trajectory().copy(), serial.counters()
+    gh, gheap, gcnt, gvox = serial.scene().download()
+    occ = gh[gh["ptr"] != FREE_ENTRY]
+    b0 = {tuple(int(v) for v in e["pos"]): gvox[int(e["ptr"]):int(e["ptr"]) + VOX_PER_BLOCK].tobytes() for e in occ}
+    del serial
+    assert c0["deintegrate"] > 20 and c0["global_solves"] >= 3 and np.isfinite(t0[:, 0, 0]).all() and len(b0) > 200
+    outs = []
+    for r, p in enumerate(procs):
+        log = p.communicate(timeout=600)[0].decode()
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, log[-3000:])
+        outs.append(np.load(str(tmp_path / ("rank%d.npz" % r))))
+    union = {}
+    for r, z in enumerate(outs):
+        assert int(z["same"]) == 1, "ranks disagree on the trajectory (MIN/MAX all-reduce)"
+        assert int(z["rounds"]) == 2 and int(z["local_chunks"]) == 2            # two all-gathers, two chunk-local halves per rank
+        assert np.array_equal(z["integrated"].view(np.uint32), t0.view(np.uint32)), "rank %d: integrated trajectory differs from the serial loop" % r
+        assert np.array_equal(z["optimized"].view(np.uint32), o0.view(np.uint32)), "rank %d: optimised trajectory differs from the serial loop" % r
+        assert z["counters"].tolist() == [c0["integrate"], c0["deintegrate"], c0["local_solves"], c0["global_solves"]]
+        blocks = {tuple(int(v) for v in k): v.tobytes() for k, v in zip(z["keys"], z["vox"])}
+        assert len(blocks) > 50 and not (blocks.keys() & union.keys()), "shards overlap"
+        union.update(blocks)
+    assert union.keys() == b0.keys(), "union of the shards is not the serial block set"
+    assert all(union[k] == v for k, v in b0.items()), "voxel bytes differ"

@@ -31,12 +31,14 @@ for step in $STEPS; do
       rm -f "$OUT/kernel_stats.md"
       python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" --exclude "Cijk_,at::native" | head -14
       python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 "Cijk_,at::native" > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt" ;;
-    pmc)   # HBM traffic of the voxel update in the bench configuration: two passes (FETCH_SIZE, WRITE_SIZE), then bytes per visited block
-      for C in FETCH_SIZE WRITE_SIZE; do
-        rm -rf /tmp/r_pmc_$C
-        (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
-      done
-      python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" ;;
+    pmc)   # HBM traffic of the voxel update in the bench configuration, per arithmetic contract: two passes (FETCH_SIZE, WRITE_SIZE), then bytes per visited block
+      for A in fast exact; do
+        for C in FETCH_SIZE WRITE_SIZE; do
+          rm -rf /tmp/r_pmc_$C
+          (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
+        done
+        python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A
+      done ;;
     sq)   # where do the voxel-update waves spend their cycles: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
       rm -rf /tmp/r_sq
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES \

@@ -2,7 +2,9 @@
 """Turn the two PMC passes of `bench.py --pmc-out acc.json` (rocprofv3 --kernel-trace --pmc FETCH_SIZE, and --pmc WRITE_SIZE, each its
 own run) into profiles/rNN_pmc_tsdf_update.json: HBM bytes per visited SDF block for the plain and for the fused voxel-update kernel.
 
-    python tools/pmc_to_json.py <fetch_db> <write_db> <acc.json> <out.json> [out.md]
+    python tools/pmc_to_json.py <fetch_db> <write_db> <acc.json> <out.json> [out.md] [arith]
+
+The output file holds one entry per arithmetic contract of the voxel update ("fast" / "exact", bench.py --arith); a run adds or replaces its own.
 
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes of a wide
 coalesced read stream).  The accounting file is what the profiled run itself counted over ALL its launches."""
@@ -15,9 +17,9 @@ def totals(db, counter):
     c = sqlite3.connect(db)
     out = {}
     for name, n, tot in c.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
-        fused = "k_reupdate" in name or "k_update_col<2>" in name          # fused re-integration: the per-voxel or the column kernel
-        plain = not fused and ("k_update<" in name or "k_update_col<" in name)
-        key = "k_reupdate" if fused else ("k_update" if plain else None)
+        fused = "k_reupdate" in name or "k_update_col<2>" in name or "k_update_apx<2" in name          # fused re-integration (any of the voxel-update kernels)
+        plain = not fused and ("k_update<" in name or "k_update_col<" in name or "k_update_apx<" in name)
+        key = "fused" if fused else ("plain" if plain else None)
         if key:
             a = out.setdefault(key, [0, 0.0]); a[0] += n; a[1] += tot
     return out
@@ -29,17 +31,21 @@ def main():
     F, Wr = totals(fdb, "FETCH_SIZE"), totals(wdb, "WRITE_SIZE")
     res = {"config": acc["config"], "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) around `python bench.py --no-cpu-baseline --pmc-out ...`; "
                                               "FETCH_SIZE x2 (gfx950), KiB -> bytes"}
-    vis = {"k_reupdate": acc["visited_blocks_fused"], "k_update": acc["visited_blocks_plain"]}
-    lau = {"k_reupdate": acc["fused_launches"], "k_update": acc["launches"] - acc["fused_launches"]}
+    vis = {"fused": acc["visited_blocks_fused"], "plain": acc["visited_blocks_plain"]}
+    lau = {"fused": acc["fused_launches"], "plain": acc["launches"] - acc["fused_launches"]}
+    arith = sys.argv[6] if len(sys.argv) > 6 else "fast"
     lines = ["| kernel | launches (PMC pass / run accounting) | FETCH_SIZE x2 [MB/launch] | WRITE_SIZE [MB/launch] | HBM bytes / visited block | algorithmic bytes / block |", "|---|---|---|---|---|---|"]
-    for k in ("k_reupdate", "k_update"):
+    for k in ("fused", "plain"):
         n, f = F.get(k, [0, 0.0]); n2, w = Wr.get(k, [0, 0.0])
         fb, wb = 2.0 * f * 1024.0, w * 1024.0
         res[k] = {"launches": n, "fetch_bytes_per_launch": fb / max(n, 1), "write_bytes_per_launch": wb / max(n2, 1),
                   "hbm_bytes_per_launch": fb / max(n, 1) + wb / max(n2, 1), "visited_blocks": vis[k],
                   "hbm_bytes_per_visited_block": (fb + wb) / max(vis[k], 1)}
-        lines.append("| `%s` | %d / %d | %.1f | %.1f | %.0f | %d |" % (k, n, lau[k], fb / max(n, 1) / 1e6, wb / max(n2, 1) / 1e6, res[k]["hbm_bytes_per_visited_block"], 512 * 24 + 32))
-    json.dump(res, open(outp, "w"), indent=1)
+        lines.append("| voxel update, %s contract, `%s` | %d / %d | %.1f | %.1f | %.0f | %d |" % (arith, k, n, lau[k], fb / max(n, 1) / 1e6, wb / max(n2, 1) / 1e6, res[k]["hbm_bytes_per_visited_block"], 512 * 24 + 32))
+    import os
+    allres = json.load(open(outp)) if os.path.exists(outp) else {}
+    allres[arith] = res
+    json.dump(allres, open(outp, "w"), indent=1)
     text = "\n".join(lines)
     print(text)
     if len(sys.argv) > 5:
