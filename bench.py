@@ -105,7 +105,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import bundlefusion_amd as bf
-    from bundlefusion_amd.capi import intrinsics_matrix, default_app_state, default_bundling_state, sensor_desc
+    from bundlefusion_amd.capi import intrinsics_matrix, default_app_state, default_bundling_state, sensor_desc, bind_host_threads_to_device
+    host_cpus = bind_host_threads_to_device(local_rank)       # the host threads (this one, the volume thread, the HIP runtime's) next to the GPU: DESIGN.md 4.4
 
     Kd = frames[0][3]
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
@@ -261,6 +262,7 @@ def main():
                             "frames in the global problem)" % (W, H, args.voxel * 1e3, first + pre, first + total - 1, pre, args.warmup, pre // 10),
                 "input": "host buffers per frame (PCIe inclusive)" if args.host else "frames resident in HBM",
                 "clock_warmup_s": args.clock_warmup,
+                "host_threads": ("bound to the GPU's NUMA node (CPUs %s)" % host_cpus) if host_cpus else "not bound (topology unknown or BF_BIND_NUMA=0)",
                 "params": "zParametersDefault.txt + zParametersBundlingDefault.txt values; s_integrationWidth/Height=640/480, "
                           "s_SDFVoxelSize=%.3f, s_hashNumBuckets=%d, s_hashNumSDFBlocks=%d" % (args.voxel, args.buckets, args.blocks),
                 "timed_ops": {k: c1[k] - c0[k] for k in c1},

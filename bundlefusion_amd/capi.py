@@ -80,6 +80,15 @@ VOXEL_DTYPE = np.dtype([("sdf", "<f4"), ("weight", "<f4"), ("color", "u1", 4)])
 assert HASH_ENTRY_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 12
 
 lib.bf_last_error.restype = C.c_char_p
+
+
+def bind_host_threads_to_device(device=0):
+    """bf_bind_host_threads_to_device: all threads of this process onto the CPUs of the GPU's NUMA node; returns the cpu list ('' = unchanged)."""
+    buf = C.create_string_buffer(1024)
+    lib.bf_bind_host_threads_to_device(int(device), buf, C.c_size_t(len(buf)))
+    return buf.value.decode()
+
+
 lib.bf_version.restype = C.c_char_p
 
 

@@ -775,7 +775,14 @@ int bf_bundler_get_solver(bf_bundler* b, bf_solver** out) { BF_REQUIRE(b && out,
 
 // ================================================================================================ TrajectoryManager
 struct bf_trajectory_manager {
-    struct Frame { int type; uint32_t frameIdx; m44 integratedTransform; float dist; };
+    struct Frame {
+        int type; uint32_t frameIdx; m44 integratedTransform; float dist;
+        // se(3) coordinates of integratedTransform / of the optimised pose the last time they were needed, and of which matrices
+        // (generate_update_lists ranks ALL frames every time the lists run low: at 5000 frames the two logarithms per frame were
+        // 1.5 ms per call, 0.8 ms per input frame - the term that made the long stream decay, profiles/r03_5000_frame_stream.md)
+        m44 intOf, optOf; f3 ri, ti, ro, to; bool haveInt = false, haveOpt = false;
+    };
+    std::vector<char> picked;            // scratch of generate_update_lists
     std::vector<m44> optimizedTransforms;
     std::vector<Frame> frames;
     std::vector<Frame*> framesSort;
@@ -854,9 +861,10 @@ int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm) {    
         if (T.e[0] == NINF) tmInvalidate(tm, i);
         else {
             if (f.type == BF_TF_NOT_INTEGRATED_NO_TRANSFORM || f.type == BF_TF_INVALID) { f.type = BF_TF_NOT_INTEGRATED_WITH_TRANSFORM; tm->toIntegrate.push_back(&f); }
-            f3 ro, to, ri, ti;
-            matrixToPose(T, ro, to);
-            matrixToPose(f.integratedTransform, ri, ti);
+            // the two logarithms are cached per frame, keyed by the matrix bits they were taken of: same values, computed once per pose change
+            if (!f.haveOpt || memcmp(f.optOf.e, T.e, 64) != 0) { matrixToPose(T, f.ro, f.to); f.optOf = T; f.haveOpt = true; }
+            if (!f.haveInt || memcmp(f.intOf.e, f.integratedTransform.e, 64) != 0) { matrixToPose(f.integratedTransform, f.ri, f.ti); f.intOf = f.integratedTransform; f.haveInt = true; }
+            const f3 ro = f.ro, to = f.to, ri = f.ri, ti = f.ti;
             // PoseHelper::MatrixToPose (USE_LIE_SPACE, PoseHelper.h:332-363) returns (translation part, rotation vector), and the
             // reference rescales elements 0..2 (:70-77): it is the TRANSLATION part that is doubled, whatever the member's name says.
             // Pinned against TrajectoryManager.cpp itself (tests/test_ref_pin_cpu.py).
@@ -866,12 +874,31 @@ int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm) {    
             for (int k = 0; k < 6; ++k) f.dist += d[k] * d[k];
         }
     }
-    // std::sort in the reference; a stable sort makes the order of equal distances reproducible
-    std::stable_sort(tm->framesSort.begin(), tm->framesSort.begin() + numFrames, [](const bf_trajectory_manager::Frame* l, const bf_trajectory_manager::Frame* r) {
-        if (l->type == BF_TF_INTEGRATED && r->type != BF_TF_INTEGRATED) return true;
-        if (l->type != BF_TF_INTEGRATED) return false;
-        return l->dist > r->dist;
-    });
+    // The reference std::sorts all frames (Integrated first, by descending distance) and then reads positions < topNActive only.  Here: the
+    // first topNActive positions of the STABLE sort of the current order (ties: earlier position first) by partial selection, the other
+    // frames keep their relative order - O(F log topN) instead of O(F log F) per call.  Which frames are selected is identical: a selected
+    // frame has type Integrated and a distance > m_minPoseDistSqrt >= 0, and among those the order is strict except for bit-equal
+    // distances of different frames, which the position decides like the stable sort of the full array would.
+    {
+        struct Cand { bf_trajectory_manager::Frame* f; uint32_t pos; };
+        std::vector<Cand> c(numFrames);
+        for (uint32_t i = 0; i < numFrames; ++i) c[i] = {tm->framesSort[i], i};
+        const uint32_t K = std::min<uint32_t>(tm->topNActive, numFrames);
+        auto before = [](const Cand& l, const Cand& r) {
+            const bool li = l.f->type == BF_TF_INTEGRATED, ri = r.f->type == BF_TF_INTEGRATED;
+            if (li != ri) return li;
+            if (li && l.f->dist != r.f->dist) return l.f->dist > r.f->dist;
+            return l.pos < r.pos;
+        };
+        std::partial_sort(c.begin(), c.begin() + K, c.end(), before);
+        tm->picked.assign(numFrames, 0);
+        for (uint32_t i = 0; i < K; ++i) tm->picked[c[i].pos] = 1;
+        std::vector<bf_trajectory_manager::Frame*> rest;
+        rest.reserve(numFrames - K);
+        for (uint32_t i = 0; i < numFrames; ++i) if (!tm->picked[i]) rest.push_back(tm->framesSort[i]);
+        for (uint32_t i = 0; i < K; ++i) tm->framesSort[i] = c[i].f;
+        std::copy(rest.begin(), rest.end(), tm->framesSort.begin() + K);
+    }
     for (uint32_t i = (uint32_t)tm->toReIntegrate.size(); i < tm->topNActive && i < numFrames; ++i) {
         auto* f = tm->framesSort[i];
         if (f->dist > tm->minPoseDistSqrt && f->type == BF_TF_INTEGRATED) { f->type = BF_TF_REINTEGRATION; tm->toReIntegrate.push_back(f); }
@@ -1033,7 +1060,7 @@ int chunkPackageCheck(const bf_chunk_header* h, uint64_t bytes, uint32_t maxKeys
     const uint64_t off[8] = {h->offKeys, h->offDescs, h->offCache[0], h->offCache[1], h->offCache[2], h->offCache[3], h->offCache[4], h->offCache[5]};
     for (int k = 0; k < 8; ++k)
         BF_REQUIRE(off[k] >= sizeof(bf_chunk_header) && off[k] <= h->totalBytes && need[k] <= h->totalBytes - off[k], "chunk package: a payload section lies outside the package");
-    for (uint32_t j = 0; j < h->numFrames; ++j)
+    for (uint32_t j = 1; j < h->numFrames; ++j)          // (record 0 is never read: the chunk's first frame is chained by the previous chunk)
         BF_REQUIRE(h->frames[j].prevLocal < (int32_t)j, "chunk package: a frame is chained to a later frame");       // -1 = none; k_sift_transform_ext indexes curFrame - (localIdx - prevLocal)
     return BF_OK;
 }

@@ -938,7 +938,6 @@ struct FuseArgs {
     Key* dstKeys; uint8_t* dstDescs; int* dstNum; uint32_t dstMaxKeys; int* error;
 };
 constexpr int FUSE_THREADS = 1024;
-constexpr int FUSE_MAX_DEPTH = 512;
 
 BF_DEV uint32_t fuseBlockScan(uint32_t v, uint32_t* lds, uint32_t& total) {       // exclusive scan over the block's threads
     const uint32_t t = threadIdx.x;
@@ -1000,6 +999,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_to_global(FuseArgs a) {
             while (j > 0 && a.adj[s0 + j - 1].order > e.order) { a.adj[s0 + j] = a.adj[s0 + j - 1]; --j; }
             a.adj[s0 + j] = e;
         }
+        a.fill[k] = 0u;                                                             // from here on: the search's position in this key's list
     }
     __syncthreads();
     // 2. connected components: label = smallest key index
@@ -1017,28 +1017,28 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_to_global(FuseArgs a) {
         __syncthreads();
         if (!ch) break;
     }
-    // 3. the reference's depth-first search, one thread per component
+    // 3. the reference's depth-first search, one thread per component.  No stack: every key has ONE list position (a.fill) and the key it
+    //    was entered from (a.outPos, free until step 4); `depth` counts the open calls.  The start key is entered a second time when one of
+    //    its neighbours lists it (it is not marked at the start, like in the reference): the second visit continues the SAME list position -
+    //    equivalent to the reference's nested call restarting at 0, because everything before that position is marked by then - and the
+    //    search ends when the count of open calls returns to zero, whatever a.outPos of the start key says by then.
     for (uint32_t k = t; k < N; k += FUSE_THREADS) {
         if (a.cnt[k] == 0u || a.label[k] != k) continue;
-        uint32_t stKey[FUSE_MAX_DEPTH]; uint16_t stPos[FUSE_MAX_DEPTH];
-        int sp = 0;
-        stKey[0] = k; stPos[0] = 0;
         f3 pos = mk3(0, 0, 0);
-        uint32_t num = 0, rep = 0xFFFFFFFFu;
-        bool overflow = false;
-        while (sp >= 0) {
-            const uint32_t u = stKey[sp], p = stPos[sp];
-            if (p >= a.cnt[u]) { --sp; continue; }
-            stPos[sp] = (uint16_t)(p + 1);
+        uint32_t num = 0, rep = 0xFFFFFFFFu, u = k;
+        int depth = 1;
+        while (depth > 0) {
+            const uint32_t p = a.fill[u];
+            if (p >= a.cnt[u]) { --depth; u = a.outPos[u]; continue; }
+            a.fill[u] = p + 1;
             const FuseAdj e = a.adj[a.start[u] + p];
             if (a.marker[e.dst]) continue;
             if (rep == 0xFFFFFFFFu) rep = e.dst;
             if (e.px != NINF_) { pos = pos + xform(a.T[e.img], mk3(e.px, e.py, e.pz)); num++; }
             a.marker[e.dst] = 1u;
-            if (sp + 1 >= FUSE_MAX_DEPTH) { overflow = true; break; }
-            ++sp; stKey[sp] = e.dst; stPos[sp] = 0;
+            a.outPos[e.dst] = u;
+            u = e.dst; ++depth;
         }
-        if (overflow) { atomicExch(a.error, 1); continue; }
         if (num > 0) {
             pos = pos / (float)num;
             pos = xform(a.K, pos);
@@ -1070,9 +1070,12 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_to_global(FuseArgs a) {
         }
     }
     // descriptors of the representatives: 128 B = 8 x 16 B each
-    for (uint32_t k = 0; k < N; ++k) {             // block-uniform loop; (a serial walk over <= 11 k flags costs a few microseconds)
+    for (uint32_t k = t; k < N; k += FUSE_THREADS) {
         if (!a.flag[k] || a.outPos[k] >= numOut) continue;
-        if (t < 8) reinterpret_cast<uint4*>(a.dstDescs + (size_t)a.outPos[k] * 128)[t] = reinterpret_cast<const uint4*>(a.descs + (size_t)a.rep[k] * 128)[t];
+        const uint4* src = reinterpret_cast<const uint4*>(a.descs + (size_t)a.rep[k] * 128);
+        uint4* dst = reinterpret_cast<uint4*>(a.dstDescs + (size_t)a.outPos[k] * 128);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = src[q];
     }
     if (t == 0) *a.dstNum = (int)numOut;
 }
@@ -1482,7 +1485,7 @@ int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float
     return bf_siftmgr_finalize_image(global, -1);          // the count was written on the device
 }
 
-// A track deeper than the search stack of k_fuse_to_global (512 keys in one chain) raises this flag; bf_siftmgr_fuse_error reports it.
+// reserved for capacity conditions of the device search (none at present: the search needs no stack); always 0
 int bf_siftmgr_fuse_error(bf_siftmgr* local, int* err) {
     BF_REQUIRE(local && err, "null argument");
     *err = 0;

@@ -43,6 +43,11 @@ BF_API const char* bf_version(void);
 BF_API int bf_device_count(void);
 /* Plumbing for hosts that hold raw pointers only: copies / a device-wide fence issued by this library's own HIP
  * runtime (a process may hold more than one copy of libamdhip64; work is only ordered within one of them). */
+/* Restrict every thread of the calling process to the CPUs of the NUMA node HIP device `device` is attached to (intersected with the
+ * caller's current affinity); threads created later inherit it.  cpulist_out (optional) receives the node's CPU list ("0-63,128-191"),
+ * empty if nothing was changed (unknown topology, BF_BIND_NUMA=0).  Launch latency from the remote socket costs ~20 % of the frame rate
+ * (DESIGN.md 4.4); the library never changes affinities on its own. */
+BF_API int bf_bind_host_threads_to_device(int device, char* cpulist_out, size_t cpulist_len);
 BF_API int bf_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 BF_API int bf_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 BF_API int bf_device_synchronize(void);
@@ -461,7 +466,7 @@ BF_API int bf_siftmgr_get_top_retry_image(bf_siftmgr* m, uint32_t* idx, int* fou
  * and its key count are written in HBM, nothing is copied to the host); asynchronous on the manager's stream.
  * bf_siftmgr_fuse_to_global_host is the reference's own form (all key points / descriptors / correspondences to the host, recursive
  * search there, upload) - same results bit for bit; BF_FUSE_HOST=1 routes the first entry to it.
- * bf_siftmgr_fuse_error: 1 if a track was deeper than the device search stack (512 keys in one chain) since creation. */
+ * bf_siftmgr_fuse_error: capacity conditions of the device search since creation (none at present: always 0). */
 BF_API int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16],
                                      const float* d_transforms, const float colorIntrinsicsInv[16]);
 BF_API int bf_siftmgr_fuse_to_global_host(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16],

@@ -13,6 +13,7 @@ with a tracking loss (tests/test_ref_pin_cpu.py::test_online_bundler_vs_referenc
 DepthSensing.cpp around those classes (_integrate / process_frame here).
 Plain Python loops: orchestration is a few hundred scalar decisions per frame.
 """
+import os
 from collections import deque
 
 import numpy as np
@@ -409,6 +410,19 @@ class OTrajectoryManager:
                 break
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box shows 256 logical CPUs and
+    grants 16 cores' worth of time: 256 OpenMP threads on that quota are slower than one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 class OraclePipeline:
     """The serial frame loop on the CPU.  `gas`/`gbs` are the ctypes parameter structs of bundlefusion_amd.capi."""
 
@@ -457,8 +471,8 @@ class OraclePipeline:
         self.cam = camera_params(gas.s_integrationWidth, gas.s_integrationHeight, float(Ki[0, 0]), float(Ki[1, 1]), float(Ki[0, 2]), float(Ki[1, 2]),
                                  gas.s_renderDepthMin, gas.s_renderDepthMax)
         import os
-        self.threads = os.cpu_count() or 1          # voxel update (per call) and, through set_threads(), the image-space loops
-        o.set_threads(min(self.threads, 16))        # image rows: more threads than that only add barrier traffic (and a container may grant fewer cores than it shows)
+        self.threads = effective_cpus()             # voxel update (per call) and, through set_threads(), the image-space loops
+        o.set_threads(min(self.threads, 32))        # image rows: more threads than that only add barrier traffic
 
     # ---- CUDAImageManager::process
     def _ingest(self, depth, color):

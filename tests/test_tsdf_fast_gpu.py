@@ -25,8 +25,8 @@ pytestmark = pytest.mark.gpu
 
 BAND = 5e-4            # pixels
 COLOUR_SEQ = None      # sequences: histogram bound instead of a per-byte one (see _compare)
-COLOUR_SEQ_FRAC = 2e-3 # share of colour bytes that may deviate by more than 1 LSB after a sequence of operators
-COLOUR_SEQ_MAX = 16    # LSB
+COLOUR_SEQ_FRAC = 1e-4 # share of colour bytes that may deviate by more than 1 LSB after a sequence of operators (measured: none deviates at all)
+COLOUR_SEQ_MAX = 4     # LSB
 
 
 def _to_dev(depth, color):

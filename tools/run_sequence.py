@@ -51,7 +51,10 @@ def main():
     gas.s_SDFVoxelSize = a.voxel; gas.s_hashNumBuckets = a.buckets; gas.s_hashNumSDFBlocks = a.blocks
     gbs.s_maxNumImages = a.maximages or max(8, a.frames // 10 + 4)
     gbs.s_widthSIFT, gbs.s_heightSIFT = 640, 480
+    bf.capi.bind_host_threads_to_device(0)
     p = bf.capi.Pipeline(gas, gbs, bf.capi.sensor_desc(W, H, K))
+    if os.environ.get("BF_TSDF_ARITH"):
+        print("arithmetic contract of the voxel update:", p.scene().arith())
     if a.timings:
         p.enable_timings(True)
     dev = dev_all if not a.host else None
