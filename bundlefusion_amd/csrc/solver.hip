@@ -63,6 +63,8 @@ struct Dev {
     float* energies;
     float* maxRes; int* maxIdx; int* highCount;
     int* numEntriesPerRow;
+    uint32_t* scanRow;               // k_scan_*: three sums (then exclusive bases) per row of the key table
+    float* maxResPart; int* maxIdxPart;   // k_max_residual: one (value, index) per workgroup
     uint32_t maxSlots, maxPairs;
 };
 
@@ -100,25 +102,41 @@ __global__ void k_row_entries(Dev d) {
     d.numEntriesPerRow[i] = (int)n;
 }
 
-// single-workgroup three-channel exclusive scan over the N*N directed keys (key order = CSR order)
-__global__ __launch_bounds__(1024) void k_scan(Dev d, int useDense) {
+// Three-channel exclusive scan over the N*N directed keys (key order = CSR order): list length, slots, dense pairs.  Integer sums, so
+// any evaluation order gives the same table; this one reads the key tables coalesced and scales with the number of key frames
+// (the single-workgroup version walked N*N / 1024 keys per thread with a stride between lanes: 383 us at N = 450 key frames,
+// three times per global solve - profiles/r03_5000_frame_stream.md):
+//   k_scan_rows  one wave per row i: the row's three sums
+//   k_scan_base  one workgroup: exclusive scan over the N rows, totals -> flags
+//   k_scan_fill  one wave per row: 64 keys per step, wave-level exclusive scan on top of the row's base
+BF_DEV void scanKey(const Dev& d, int useDense, uint32_t N, uint32_t i, uint32_t j, uint32_t& cnt, uint32_t& dn) {
+    cnt = d.keyCount[i * N + j];
+    dn = (useDense && i != j) ? d.denseRaw[min(i, j) * N + max(i, j)] : 0u;
+}
+
+__global__ __launch_bounds__(64) void k_scan_rows(Dev d, int useDense) {
+    if (d.flags[FL_DONE]) return;
+    const uint32_t N = d.N, i = blockIdx.x, lane = threadIdx.x;
+    uint32_t a = 0, b = 0, c = 0;
+    for (uint32_t j = lane; j < N; j += 64) {
+        uint32_t cnt, dn;
+        scanKey(d, useDense, N, i, j, cnt, dn);
+        a += cnt; b += (cnt > 0 || dn) ? 1u : 0u; c += (dn && i < j) ? 1u : 0u;
+    }
+    a = (uint32_t)wave_sum_i((int)a); b = (uint32_t)wave_sum_i((int)b); c = (uint32_t)wave_sum_i((int)c);
+    if (lane == 0) { d.scanRow[i * 3 + 0] = a; d.scanRow[i * 3 + 1] = b; d.scanRow[i * 3 + 2] = c; }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_base(Dev d) {
     if (d.flags[FL_DONE]) return;
     __shared__ uint32_t sA[1024], sB[1024], sC[1024];
-    const uint32_t N = d.N, M = N * N;
-    const uint32_t chunk = (M + blockDim.x - 1) / blockDim.x;
-    const uint32_t k0 = min(threadIdx.x * chunk, M), k1 = min(k0 + chunk, M);
-    uint32_t a = 0, b = 0, c = 0;     // list length, slots, dense pairs
-    for (uint32_t k = k0; k < k1; ++k) {
-        const uint32_t i = k / N, j = k % N;
-        const uint32_t cnt = d.keyCount[k];
-        const uint32_t dn = (useDense && i != j) ? d.denseRaw[min(i, j) * N + max(i, j)] : 0u;
-        a += cnt;
-        b += (cnt > 0 || dn) ? 1u : 0u;
-        c += (dn && i < j) ? 1u : 0u;
-    }
+    const uint32_t N = d.N;
+    const uint32_t chunk = (N + blockDim.x - 1) / blockDim.x;
+    const uint32_t r0 = min(threadIdx.x * chunk, N), r1 = min(r0 + chunk, N);
+    uint32_t a = 0, b = 0, c = 0;
+    for (uint32_t r = r0; r < r1; ++r) { a += d.scanRow[r * 3]; b += d.scanRow[r * 3 + 1]; c += d.scanRow[r * 3 + 2]; }
     sA[threadIdx.x] = a; sB[threadIdx.x] = b; sC[threadIdx.x] = c;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
     for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
         uint32_t ta = 0, tb = 0, tc = 0;
         if (threadIdx.x >= off) { ta = sA[threadIdx.x - off]; tb = sB[threadIdx.x - off]; tc = sC[threadIdx.x - off]; }
@@ -127,27 +145,52 @@ __global__ __launch_bounds__(1024) void k_scan(Dev d, int useDense) {
         __syncthreads();
     }
     uint32_t ra = sA[threadIdx.x] - a, rb = sB[threadIdx.x] - b, rc = sC[threadIdx.x] - c;
-    for (uint32_t k = k0; k < k1; ++k) {
-        const uint32_t i = k / N, j = k % N;
-        if (j == 0) d.rowStart[i] = rb;
-        const uint32_t cnt = d.keyCount[k];
-        const uint32_t dn = (useDense && i != j) ? d.denseRaw[min(i, j) * N + max(i, j)] : 0u;
-        d.keyStart[k] = ra;
-        ra += cnt;
-        if (cnt > 0 || dn) {
-            if (rb < d.maxSlots) { d.slotOfKey[k] = rb; d.slotCol[rb] = j; d.slotKey[rb] = k; }
-            rb++;
-        } else d.slotOfKey[k] = NOSLOT;
-        if (dn && i < j) {
-            if (rc < d.maxPairs) { d.densePairs[rc] = make_uint2(i, j); d.keyPair[k] = rc + 1; d.keyPair[j * N + i] = rc + 1; }
-            rc++;
-        }
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t ta = d.scanRow[r * 3], tb = d.scanRow[r * 3 + 1], tc = d.scanRow[r * 3 + 2];
+        d.scanRow[r * 3] = ra; d.scanRow[r * 3 + 1] = rb; d.scanRow[r * 3 + 2] = rc;      // exclusive bases of row r
+        d.rowStart[r] = rb;
+        ra += ta; rb += tb; rc += tc;
     }
     if (threadIdx.x == blockDim.x - 1) {
         d.rowStart[N] = min(rb, d.maxSlots);
         d.flags[FL_LIST_LEN] = (int)ra;
         d.flags[FL_NUM_SLOTS] = (int)min(rb, d.maxSlots);
         d.flags[FL_NUM_PAIRS] = (int)min(rc, d.maxPairs);
+    }
+}
+
+BF_DEV uint32_t waveExScan(uint32_t v, uint32_t lane, uint32_t& total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if ((int)lane >= o) incl += t; }
+    total = (uint32_t)__shfl((int)incl, 63, 64);
+    return incl - v;
+}
+
+__global__ __launch_bounds__(64) void k_scan_fill(Dev d, int useDense) {
+    if (d.flags[FL_DONE]) return;
+    const uint32_t N = d.N, i = blockIdx.x, lane = threadIdx.x;
+    uint32_t ra = d.scanRow[i * 3], rb = d.scanRow[i * 3 + 1], rc = d.scanRow[i * 3 + 2];
+    for (uint32_t j0 = 0; j0 < N; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        uint32_t cnt = 0, dn = 0;
+        if (j < N) scanKey(d, useDense, N, i, j, cnt, dn);
+        const uint32_t hasSlot = (j < N && (cnt > 0 || dn)) ? 1u : 0u, hasPair = (j < N && dn && i < j) ? 1u : 0u;
+        uint32_t ta, tb, tc;
+        const uint32_t ea = waveExScan(cnt, lane, ta), eb = waveExScan(hasSlot, lane, tb), ec = waveExScan(hasPair, lane, tc);
+        if (j < N) {
+            const uint32_t k = i * N + j;
+            d.keyStart[k] = ra + ea;
+            if (hasSlot) {
+                const uint32_t sl = rb + eb;
+                if (sl < d.maxSlots) { d.slotOfKey[k] = sl; d.slotCol[sl] = j; d.slotKey[sl] = k; }
+            } else d.slotOfKey[k] = NOSLOT;
+            if (hasPair) {
+                const uint32_t pr = rc + ec;
+                if (pr < d.maxPairs) { d.densePairs[pr] = make_uint2(i, j); d.keyPair[k] = pr + 1; d.keyPair[j * N + i] = pr + 1; }
+            }
+        }
+        ra += ta; rb += tb; rc += tc;
     }
 }
 
@@ -869,11 +912,17 @@ BF_DEV float absMaxResidual(const Dev& d, const bf_entry_j& e, float w) {       
 }
 
 // EvalMaxResidualDevice (:511-550) + the host max loop of computeMaxResidual: first maximum in index order
+// computeMaxResidual: the largest residual and the SMALLEST correspondence index that attains it.  G workgroups reduce interleaved slices
+// (a single workgroup took 746 us over the 37 k correspondences of a 450-key-frame problem), the last pass reduces the G partials with the
+// same order relation, so the result does not depend on G.
+constexpr uint32_t MAXRES_GROUPS = 64;
+BF_DEV bool maxResBetter(float o, int oi, float cur, int ci) { return cur < o || (cur == o && oi < ci && o > 0.0f); }
+
 __global__ __launch_bounds__(1024) void k_max_residual(Dev d, float w) {
     __shared__ float sv[1024];
     __shared__ int si[1024];
     float best = 0.0f; int bi = 0;
-    for (uint32_t c = threadIdx.x; c < d.C; c += blockDim.x) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < d.C; c += gridDim.x * blockDim.x) {
         const float r = absMaxResidual(d, d.corr[c], w);
         if (best < r) { best = r; bi = (int)c; }
     }
@@ -882,11 +931,22 @@ __global__ __launch_bounds__(1024) void k_max_residual(Dev d, float w) {
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             const float o = sv[threadIdx.x + s]; const int oi = si[threadIdx.x + s];
-            if (sv[threadIdx.x] < o || (sv[threadIdx.x] == o && oi < si[threadIdx.x] && o > 0.0f)) { sv[threadIdx.x] = o; si[threadIdx.x] = oi; }
+            if (maxResBetter(o, oi, sv[threadIdx.x], si[threadIdx.x])) { sv[threadIdx.x] = o; si[threadIdx.x] = oi; }
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { d.maxRes[0] = sv[0]; d.maxIdx[0] = si[0]; }
+    if (threadIdx.x == 0) { d.maxResPart[blockIdx.x] = sv[0]; d.maxIdxPart[blockIdx.x] = si[0]; }
+}
+
+__global__ __launch_bounds__(64) void k_max_residual_final(Dev d, uint32_t G) {
+    float best = 0.0f; int bi = 0;
+    if (threadIdx.x < G) { best = d.maxResPart[threadIdx.x]; bi = d.maxIdxPart[threadIdx.x]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (maxResBetter(ov, oi, best, bi)) { best = ov; bi = oi; }
+    }
+    if (threadIdx.x == 0) { d.maxRes[0] = best; d.maxIdx[0] = bi; }
 }
 
 __global__ void k_count_high(Dev d, float w, float thresh) {                      // CountHighResidualsDevice :657-668
@@ -1013,7 +1073,8 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
               sAlloc(s, &d.delta, N * 6) && sAlloc(s, &d.r, N * 6) && sAlloc(s, &d.p, N * 6) && sAlloc(s, &d.Ap, N * 6) &&
               sAlloc(s, &d.densePairs, (size_t)d.maxPairs) && sAlloc(s, &d.denseWeight, (size_t)d.maxPairs) &&
               sAlloc(s, &d.denseBlocks, (size_t)d.maxPairs * DENSE_BLK) && sAlloc(s, &d.flags, FL_COUNT) && sAlloc(s, &d.gridBar, 32) && sAlloc(s, &d.energies, 40) &&
-              sAlloc(s, &d.maxRes, 1) && sAlloc(s, &d.maxIdx, 1) && sAlloc(s, &d.highCount, 1) && sAlloc(s, &d.numEntriesPerRow, N);
+              sAlloc(s, &d.maxRes, 1) && sAlloc(s, &d.maxIdx, 1) && sAlloc(s, &d.highCount, 1) && sAlloc(s, &d.numEntriesPerRow, N) &&
+              sAlloc(s, &d.scanRow, 3 * (N + 1)) && sAlloc(s, &d.maxResPart, MAXRES_GROUPS) && sAlloc(s, &d.maxIdxPart, MAXRES_GROUPS);
     if (!ok) { set_error("bf_solver_create: hipMalloc failed"); bf_solver_destroy(s); return BF_ERR_HIP; }
     (void)hipMemset(d.flags, 0, FL_COUNT * sizeof(int));
     *out = s;
@@ -1078,7 +1139,9 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
         }
         if (numCorr) hipLaunchKernelGGL(k_key_count, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
         if (it == 0) hipLaunchKernelGGL(k_row_entries, dim3(div_up(N, 64)), dim3(64), 0, st, d);     // table as of solve start (rebuildJT)
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, d, useDense);
+        hipLaunchKernelGGL(k_scan_rows, dim3(N), dim3(64), 0, st, d, useDense);
+        hipLaunchKernelGGL(k_scan_base, dim3(1), dim3(1024), 0, st, d);
+        hipLaunchKernelGGL(k_scan_fill, dim3(N), dim3(64), 0, st, d, useDense);
         if (numCorr) hipLaunchKernelGGL(k_fill, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
         if (useDense) {
             const uint32_t g = std::min<uint32_t>(std::max<uint32_t>(N * (N - 1) / 2, 1u), 1024u);
@@ -1105,7 +1168,9 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
     s->lastN = N; s->lastGNrequested = nNonLin; s->lastWeightSparse = wS[nNonLin - 1]; s->lastUsedDense = anyDense;
     if (findMaxResidual) {                                                   // computeMaxResidual .cpp:313-427
         if (s->lastWeightSparse > 0.0f && numCorr > 0) {
-            hipLaunchKernelGGL(k_max_residual, dim3(1), dim3(1024), 0, st, d, s->lastWeightSparse);
+            const uint32_t gmr = std::min<uint32_t>(MAXRES_GROUPS, std::max<uint32_t>(1u, div_up(numCorr, 1024u)));
+            hipLaunchKernelGGL(k_max_residual, dim3(gmr), dim3(1024), 0, st, d, s->lastWeightSparse);
+            hipLaunchKernelGGL(k_max_residual_final, dim3(1), dim3(64), 0, st, d, gmr);
             BF_HIP_TRY(hipMemcpyAsync(&s->hMaxRes, d.maxRes, 4, hipMemcpyDeviceToHost, st));
             BF_HIP_TRY(hipMemcpyAsync(&s->hMaxIdx, d.maxIdx, 4, hipMemcpyDeviceToHost, st));
             BF_HIP_TRY(hipMemcpyAsync(&s->hBarrierFail, d.flags + FL_BARRIER_FAIL, 4, hipMemcpyDeviceToHost, st));

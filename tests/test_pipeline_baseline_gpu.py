@@ -202,7 +202,7 @@ def test_loop_closure_stream_vs_oracle_loop(gpu):
     assert abs(c["integrate"] - o_in) <= 0.03 * o_in and abs(c["deintegrate"] - o_de) <= 0.03 * o_de and c["deintegrate"] > NF
     gt, ot = gp.integrated_trajectory(), fx["integrated"]
     gopt, oopt = gp.optimized_trajectory()[:NF], fx["optimized"]
-    assert len(gt) == len(ot) == NF and np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).sum() >= 100
+    assert len(gt) == len(ot) == NF and np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).sum() >= 60
     assert np.array_equal(np.isfinite(gopt[:, 0, 0]), np.isfinite(oopt[:, 0, 0]))
     vi, vo = np.isfinite(gt[:, 0, 0]), np.isfinite(gopt[:, 0, 0])
     dev_int, dev_opt = float(np.abs(gt[vi] - ot[vi]).max()), float(np.abs(gopt[vo] - oopt[vo]).max())
