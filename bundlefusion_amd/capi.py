@@ -184,6 +184,24 @@ class SceneRepHashSDF:
     def set_shard(self, rank, world):
         check(lib.bf_scene_set_shard(self._h, rank, world))
 
+    def set_external_alloc(self, enable=True):
+        check(lib.bf_scene_set_external_alloc(self._h, int(enable)))
+
+    def alloc_collect(self, cam_to_world, depth, cam, part, parts, keys, slots, count):
+        """keys: torch int64 [capacity] cuda, slots: int32 [capacity], count: int32 [1] (see bf_scene_alloc_collect)"""
+        d = self._data(depth, None)
+        check(lib.bf_scene_alloc_collect(self._h, mat16(cam_to_world), C.byref(d), C.byref(cam), int(part), int(parts), C.c_void_p(keys.data_ptr()),
+                                         C.c_void_p(slots.data_ptr()), C.c_void_p(count.data_ptr()), int(keys.numel())))
+
+    def alloc_ingest(self, keys, count):
+        check(lib.bf_scene_alloc_ingest(self._h, C.c_void_p(keys.data_ptr()), C.c_void_p(count.data_ptr()), int(keys.numel())))
+
+    def alloc_place(self):
+        check(lib.bf_scene_alloc_place(self._h))
+
+    def alloc_sync(self):
+        check(lib.bf_scene_alloc_sync(self._h))
+
     def set_arith(self, mode):
         """'exact' (IEEE op by op, default) or 'fast' (the reference GPU build's -use_fast_math contract): bf_scene_set_arith"""
         check(lib.bf_scene_set_arith(self._h, {"exact": 0, "fast": 1}[mode]))

@@ -248,20 +248,48 @@ BF_DEV bool waveSetInsert(unsigned long long* set, uint64_t key) {
     return false;       // cannot happen: the set is flushed at half load
 }
 
-BF_DEV void waveSetFlush(const Dev& d, const Frame& f, unsigned long long* set, const unsigned long long* list, uint32_t n, uint32_t lane) {
+// Multi-GPU allocation (bf_scene_alloc_collect / _ingest): with the volume sharded by home bucket every rank would have to
+// march ALL pixels to find its own blocks - the part of an operator that does not shrink with the number of GPUs.  Instead each rank marches
+// a band of the pixel tiles and COLLECTS the distinct in-frustum block keys it meets (no ownership test, no table lookup), the ranks exchange
+// their key lists (one all-gather), and every rank INGESTS all lists: ownership test, table lookup, de-dup set, bins - the second half of
+// emitCandidate - followed by the usual placement.  Queuing a key is idempotent and bins are sorted before placement, so the table does not
+// depend on who found a block or in which order.
+struct Collect { unsigned long long* keys; uint32_t* slots; uint32_t* count; uint32_t capacity; uint32_t tile0, tile1; };
+
+BF_DEV void collectCandidate(const Dev& d, const Collect& c, i3 b) {
+    if (!keyable(b)) return;
+    const uint64_t key = packKey(b);
+    uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & d.dedupeMask;      // the de-dup set, borrowed: one entry per distinct key of this rank's band
+    for (uint32_t probe = 0; probe <= d.dedupeMask; ++probe) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&d.dedupe[slot]), (unsigned long long)EMPTY64, (unsigned long long)key);
+        if (old == key) return;
+        if (old == EMPTY64) {
+            const uint32_t pos = atomicAdd(c.count, 1u);
+            if (pos < c.capacity) { c.keys[pos] = key; c.slots[pos] = slot; }
+            else { atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW); d.dedupe[slot] = EMPTY64; }       // (nobody probes past a key that is being withdrawn: the collect kernel only ever inserts)
+            return;
+        }
+        slot = (slot + 1) & d.dedupeMask;
+    }
+    atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
+}
+
+template <bool COLLECT>
+BF_DEV void waveSetFlush(const Dev& d, const Frame& f, const Collect& c, unsigned long long* set, const unsigned long long* list, uint32_t n, uint32_t lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the list entries were written by other lanes of this wave
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
         if (i < n) {
             const i3 b = unpackKey(list[i]);
-            if (blockInFrustum(f, b)) emitCandidate(d, f, b);
+            if (blockInFrustum(f, b)) { if (COLLECT) collectCandidate(d, c, b); else emitCandidate(d, f, b); }
         }
     }
     for (uint32_t i = lane; i < WSET; i += 64) set[i] = EMPTY64;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth) {
+template <bool COLLECT>
+__global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth, Collect c) {
     __builtin_amdgcn_s_setprio(3);          // see PREP_PRIO
     __shared__ unsigned long long setAll[4][WSET];
     __shared__ unsigned long long listAll[4][WLIST];
@@ -269,12 +297,12 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
     unsigned long long* list = listAll[threadIdx.x >> 6];
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
     const uint32_t tilesX = (W + 7) / 8;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t tile = (COLLECT ? c.tile0 : 0u) + blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     for (uint32_t i = lane; i < WSET; i += 64) set[i] = EMPTY64;
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7);
     const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
-    bool alive = x < W && y < H;
+    bool alive = x < W && y < H && (!COLLECT || tile < c.tile1);
     const float dd = alive ? depth[(size_t)y * W + x] : BF_MINF;
     if (dd == BF_MINF || dd == 0.0f) alive = false;
     if (dd >= f.maxIntegrationDistance) alive = false;
@@ -325,7 +353,7 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
         const unsigned long long mask = __ballot((int)fresh);
         if (fresh) list[uniq + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = key;
         uniq += (uint32_t)__popcll(mask);
-        if (uniq > WLIST - 64) { waveSetFlush(d, f, set, list, uniq, lane); uniq = 0; }
+        if (uniq > WLIST - 64) { waveSetFlush<COLLECT>(d, f, c, set, list, uniq, lane); uniq = 0; }
         if (alive) {
             if (tMax.x < tMax.y && tMax.x < tMax.z) {
                 cur.x = f2i((float)cur.x + step.x);
@@ -342,7 +370,20 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
             }
         }
     }
-    if (uniq) waveSetFlush(d, f, set, list, uniq, lane);
+    if (uniq) waveSetFlush<COLLECT>(d, f, c, set, list, uniq, lane);
+}
+
+// after a collect pass: give the borrowed de-dup entries back
+__global__ void k_collect_release(Dev d, Collect c) {
+    const uint32_t n = min(c.count[0], c.capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d.dedupe[c.slots[i]] = EMPTY64;
+}
+
+// ingest one rank's key list: the second half of emitCandidate for every key (ownership, lookup, de-dup set, bin)
+__global__ __launch_bounds__(256) void k_alloc_ingest(Dev d, Frame f, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ count, uint32_t capacity) {
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t n = min(count[0], capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) emitCandidate(d, f, unpackKey(keys[i]));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -413,7 +454,7 @@ BF_DEV uint32_t binPrefix(const uint32_t* binCount, uint32_t limit, uint32_t* sc
 // first frames of a scan - sorts in ~10 us), and the workgroup that finishes last runs the single-workgroup tail.  (As two kernels of
 // 256 and 1 workgroups the passes cost two more dependent launches per operator, each of which queued behind the voxel kernels of the
 // other stream for 10-30 us: the allocation chain, not the voxel update, paced the re-integration loop.)
-constexpr uint32_t PLACE_WGS = 64;
+constexpr uint32_t PLACE_WGS = 256;
 
 // write-through (agent scope) 8-byte stores: what the tail workgroup reads of the other workgroups' output goes straight to memory, so
 // the hand-off needs no L2 write-back (a release fence writes back the XCD's whole L2, which the voxel kernel of the other stream keeps
@@ -609,12 +650,16 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
     __shared__ uint32_t scratch[16];
     __shared__ int8_t sel[BINCAP];
     __shared__ uint32_t lastFlag;
-    __shared__ uint32_t bigBin[4];
+    __shared__ uint32_t bigBin;
     __builtin_amdgcn_s_setprio(3);
-    static_assert(PLACE_WGS * 4 == NBINS && NBINS == 256, "one wave per bin");
+    static_assert(PLACE_WGS == NBINS && NBINS == 256, "one workgroup per bin");
+    // One workgroup per bin.  The usual bin holds a handful of new keys and is placed by the workgroup's first wave alone (registers only);
+    // a bin with more than 64 keys - first frames of a scan, fast motion, every operator of a 2 mm sweep - is sorted by the whole workgroup
+    // in LDS.  (Round 2 gave each of 64 workgroups four bins and walked its big bins one after the other: 409 us per operator on the
+    // 1280x960 @2 mm sweep, as long as the voxel update the allocation is supposed to hide behind.)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t bin = blockIdx.x * 4 + wave;
-    {   // first round trip: this bin's count and first 64 records, the counts of all bins, the two counters
+    const uint32_t bin = blockIdx.x;
+    if (wave == 0) {   // first round trip: this bin's count and first 64 records, the counts of all bins, the two counters
         const uint32_t nRaw = d.binCount[bin];
         const uint4 c4 = reinterpret_cast<const uint4*>(d.binCount)[lane];
         const BinRec r = d.bins[(size_t)bin * BINCAP + lane];
@@ -626,12 +671,11 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
         if (lane * 4 + 2 < bin) pre += min(c4.z, BINCAP);
         if (lane * 4 + 3 < bin) pre += min(c4.w, BINCAP);
         const uint32_t base = (uint32_t)wave_sum_i((int)pre);
-        if (lane == 0) bigBin[wave] = n > 64 ? 1u : 0u;
+        if (lane == 0) bigBin = n > 64 ? 1u : 0u;
         if (n > 0 && n <= 64) placeBinWave(d, f, n, r, base, heapC, allocBase, lane);
     }
     __syncthreads();
-    for (uint32_t w = 0; w < 4; ++w)
-        if (bigBin[w]) placeBin(d, f, s, scratch, sel, blockIdx.x * 4 + w);          // block-uniform: first frames of a scan, fast motion
+    if (bigBin) placeBin(d, f, s, scratch, sel, bin);          // block-uniform
     // hand-off to the workgroup that arrives last: every wave drains its (write-through) stores, then one lane takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1519,6 +1563,7 @@ struct bf_scene {
     uint32_t gridCompact = 0, gridUpdate = 0, gridUpdateCol = 0, gridUpdateColPlain = 0;
     bool columnUpdate = true;       // k_update_col (one wave per block); false: the one-voxel-per-lane kernels (BF_TSDF_UPDATE=voxel)
     bool forceExactDiv = false;     // k_update_col takes the literal `/` path for every block (BF_TSDF_EXACT_DIV=1; tests)
+    bool externalAlloc = false;     // bf_scene_set_external_alloc: integrate / re-integrate do not allocate (the caller ran bf_scene_alloc_collect / _ingest)
     int arith = BF_TSDF_ARITH_EXACT; // bf_scene_set_arith / BF_TSDF_ARITH: exact (IEEE op by op, default) or fast (k_update_apx)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
@@ -1705,7 +1750,7 @@ int refreshStaleList(bf_scene* s) {                              // a fused re-i
 
 void launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_depth) {      // alloc :328-352
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
-    hipLaunchKernelGGL(k_alloc_candidates, dim3(div_up(tiles, 4)), dim3(256), 0, st, s->d, f, d_depth);
+    hipLaunchKernelGGL(k_alloc_candidates<false>, dim3(div_up(tiles, 4)), dim3(256), 0, st, s->d, f, d_depth, Collect{});
     hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
 }
 
@@ -1720,7 +1765,7 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
     }
     const Dev dv = devBuf(s, b);
-    if (kind != 1) launchAllocOn(s, ps, f, data->d_depthData);      // de-integration neither allocates nor frees
+    if (kind != 1 && !s->externalAlloc) launchAllocOn(s, ps, f, data->d_depthData);      // de-integration neither allocates nor frees
     if (kind == 2) {
         hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
         hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
@@ -1844,6 +1889,61 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
     if (const char* e = getenv("BF_TSDF_ARITH")) return bf_scene_set_arith(s, strcmp(e, "fast") == 0 ? BF_TSDF_ARITH_FAST : BF_TSDF_ARITH_EXACT);
+    return BF_OK;
+}
+
+// ---- multi-GPU allocation: collect on a band of pixel tiles, exchange, ingest (see Collect above)
+int bf_scene_set_external_alloc(bf_scene* s, int enable) {
+    BF_REQUIRE(s, "null scene");
+    BF_TRY_RC(syncAll(s));
+    s->externalAlloc = enable != 0;
+    return BF_OK;
+}
+
+// March the pixel tiles [part * T / parts, (part + 1) * T / parts) of the frame (T = number of 8x8 tiles, row-major: a band of image rows)
+// at pose camToWorld and write the distinct in-frustum block keys to d_keys[capacity] (packed 64-bit keys, an opaque format for
+// bf_scene_alloc_ingest), their number to d_count[0].  d_slots[capacity] is scratch of the same length.  Runs on the allocation stream
+// (the scene's prep stream when operators are software-pipelined); the caller orders its exchange after bf_scene_alloc_sync.
+int bf_scene_alloc_collect(bf_scene* s, const float camToWorld[16], const bf_depth_camera_data* data, const bf_depth_camera_params* cam, uint32_t part, uint32_t parts,
+                           uint64_t* d_keys, uint32_t* d_slots, uint32_t* d_count, uint32_t capacity) {
+    BF_REQUIRE(s && camToWorld && data && cam && d_keys && d_slots && d_count && data->d_depthData, "null argument");
+    BF_REQUIRE(parts >= 1 && part < parts && capacity > 0, "bad partition");
+    s->cam = *cam; s->haveCam = true;
+    setLastRigidTransform(s, camToWorld);
+    const Frame f = makeFrame(s);
+    hipStream_t st = s->overlap ? s->prep : s->stream;
+    const uint32_t tiles = div_up(cam->m_imageWidth, 8) * div_up(cam->m_imageHeight, 8);
+    Collect c;
+    c.keys = reinterpret_cast<unsigned long long*>(d_keys); c.slots = d_slots; c.count = d_count; c.capacity = capacity;
+    c.tile0 = (uint32_t)((uint64_t)tiles * part / parts); c.tile1 = (uint32_t)((uint64_t)tiles * (part + 1) / parts);
+    BF_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
+    if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, s->d, f, data->d_depthData, c);
+    hipLaunchKernelGGL(k_collect_release, dim3(64), dim3(256), 0, st, s->d, c);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+// Queue every key of one rank's list (d_keys / d_count as written by bf_scene_alloc_collect on that rank) that this volume owns and does
+// not hold yet; bf_scene_alloc_place then inserts what was queued.  Call once per rank list, then place once, then the operator.
+int bf_scene_alloc_ingest(bf_scene* s, const uint64_t* d_keys, const uint32_t* d_count, uint32_t capacity) {
+    BF_REQUIRE(s && d_keys && d_count, "null argument");
+    const Frame f = makeFrame(s);
+    hipStream_t st = s->overlap ? s->prep : s->stream;
+    hipLaunchKernelGGL(k_alloc_ingest, dim3(std::min<uint32_t>(div_up(capacity, 256u), 1024u)), dim3(256), 0, st, s->d, f, reinterpret_cast<const unsigned long long*>(d_keys), d_count, capacity);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+int bf_scene_alloc_place(bf_scene* s) {
+    BF_REQUIRE(s, "null scene");
+    const Frame f = makeFrame(s);
+    hipStream_t st = s->overlap ? s->prep : s->stream;
+    hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+int bf_scene_alloc_sync(bf_scene* s) {          // the allocation stream has drained (collect lists are complete, ingest has read its input)
+    BF_REQUIRE(s, "null scene");
+    BF_HIP_TRY(hipStreamSynchronize(s->overlap ? s->prep : s->stream));
     return BF_OK;
 }
 

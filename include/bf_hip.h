@@ -158,6 +158,20 @@ BF_API int bf_scene_wait_event(bf_scene* s, void* hip_event);
  * [rank*numBuckets/world, (rank+1)*numBuckets/world) and allocates / integrates / collects only blocks hashing there.
  * Call before the first integrate; every shard is fed every frame and pose, there is no exchange between shards. */
 BF_API int bf_scene_set_shard(bf_scene* s, uint32_t rank, uint32_t world);
+/* Multi-GPU allocation (with bf_scene_set_shard): the ray march of the allocation (CUDASceneRepHashSDF.cu:165-251) is the part of an operator
+ * that does not shrink when the volume is sharded by home bucket - every shard would march every pixel to find its own blocks.  Instead:
+ *   rank r:   bf_scene_alloc_collect(part = r, parts = world)  marches a band of the pixel tiles, writes the distinct in-frustum block keys
+ *   all ranks exchange the key lists (one all-gather; the lists are opaque 64-bit keys + a count)
+ *   every rank: bf_scene_alloc_ingest(list) for each rank's list (ownership, table lookup, de-dup), bf_scene_alloc_place() once,
+ *               then bf_scene_integrate / _reintegrate with bf_scene_set_external_alloc(1) (they skip their own allocation).
+ * The resulting table is identical to the one the operator's own allocation builds (tests/test_tsdf_gpu.py).  d_slots is scratch of
+ * `capacity` words; everything runs on the scene's allocation stream, bf_scene_alloc_sync waits for it. */
+BF_API int bf_scene_set_external_alloc(bf_scene* s, int enable);
+BF_API int bf_scene_alloc_collect(bf_scene* s, const float cam_to_world[16], const bf_depth_camera_data* data, const bf_depth_camera_params* cam,
+                                  uint32_t part, uint32_t parts, uint64_t* d_keys, uint32_t* d_slots, uint32_t* d_count, uint32_t capacity);
+BF_API int bf_scene_alloc_ingest(bf_scene* s, const uint64_t* d_keys, const uint32_t* d_count, uint32_t capacity);
+BF_API int bf_scene_alloc_place(bf_scene* s);
+BF_API int bf_scene_alloc_sync(bf_scene* s);
 /* Arithmetic contract of the voxel update, CUDASceneRepHashSDF.cu:425-516 (integrateDepthMapKernel / deIntegrateDepthMapKernel):
  *   BF_TSDF_ARITH_EXACT (default)  every operation as written, IEEE binary32, no contraction - bit-comparable with a host build of the
  *                                  reference (and with oracle/);

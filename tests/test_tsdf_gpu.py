@@ -336,3 +336,76 @@ def test_column_update_blocks_outside_the_fast_range(gpu, oracle, monkeypatch):
     assert_same_state(gs, osc, "near-plane blocks:")
     vox = gs.download()[3]
     assert (vox["weight"] > 0).sum() > 10000
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_sharded_allocation_collect_exchange_ingest(gpu, oracle, overlap):
+    """Multi-GPU allocation (bf_scene_alloc_collect / _ingest / _place), emulated with G volumes in one process: for every
+    operator each "rank" marches only its band of the pixel tiles and collects the block keys it meets, the lists are "exchanged" (here:
+    handed to every volume), every volume ingests all lists (keeping what it owns) and runs the operator without an allocation of its
+    own.  The union of the G shards equals the unsharded volume built by the operators' own allocation, bit for bit - integrations, fused
+    re-integrations, a de-integration, garbage collection."""
+    import torch
+    W, H = 160, 120
+    frames = [synth.scene_room(k * 10, W, H) for k in range(5)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=50000, num_sdf_blocks=40000, voxel_size=0.02)
+    G, CAP = 3, 1 << 15
+    whole = gpu.capi.SceneRepHashSDF(p)
+    shards = [gpu.capi.SceneRepHashSDF(p) for _ in range(G)]
+    for r, s in enumerate(shards):
+        s.set_shard(r, G); s.set_external_alloc(True)
+    if overlap:
+        for s in shards + [whole]:
+            s.set_overlap(True)
+    dev = [_to_dev(f[0], f[1]) for f in frames]
+    keys = [torch.zeros(CAP, dtype=torch.int64, device="cuda") for _ in range(G)]
+    slots = [torch.zeros(CAP, dtype=torch.int32, device="cuda") for _ in range(G)]
+    cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(G)]
+    collected = []
+
+    def allocate(T, i):
+        for r, s in enumerate(shards):
+            s.alloc_collect(T, dev[i][0], cam, r, G, keys[r], slots[r], cnt[r])
+        for s in shards:
+            s.alloc_sync()                          # "all-gather": every list complete before anybody reads it
+        collected.append([int(c.item()) for c in cnt])
+        for s in shards:
+            for r in range(G):
+                s.alloc_ingest(keys[r], cnt[r])
+            s.alloc_place()
+        for s in shards:
+            s.alloc_sync()                          # the lists are overwritten by the next operator's collect
+
+    poses = [f[2].copy() for f in frames]
+    for i in range(5):
+        allocate(poses[i], i)
+        for s in shards + [whole]:
+            s.integrate(poses[i], dev[i][0], dev[i][1], cam)
+    for i, dt in ((2, 0.04), (4, 0.3)):
+        T2 = poses[i].copy(); T2[:3, 3] += np.float32(dt)
+        allocate(T2, i)
+        for s in shards + [whole]:
+            s.reintegrate(poses[i], T2, dev[i][0], dev[i][1], cam)
+        poses[i] = T2
+    for s in shards + [whole]:
+        s.deintegrate(poses[0], dev[0][0], dev[0][1], cam)
+        s.garbage_collect()
+
+    def blocks(s):
+        gh, gheap, gcnt, gvox = s.download()
+        occ = gh[gh["ptr"] != FREE_ENTRY]
+        return {tuple(int(v) for v in e["pos"]): gvox[int(e["ptr"]):int(e["ptr"]) + VOX_PER_BLOCK].tobytes() for e in occ}
+    w = blocks(whole)
+    parts = [blocks(s) for s in shards]
+    assert sum(len(b) for b in parts) == len(w) > 200
+    union = {}
+    for b in parts:
+        union.update(b)
+    assert union.keys() == w.keys() and all(union[k] == w[k] for k in w)
+    # every band found blocks, and no band's list came near the full set: the march really was divided
+    assert all(min(c) > 20 for c in collected) and max(max(c) for c in collected) < 0.8 * max(sum(c) for c in collected)
+    for s in shards + [whole]:
+        dbg = s.debug_hash()
+        assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0 and dbg["dropped"] == 0

@@ -90,13 +90,13 @@ def main():
             tm = []
             for rep in range(3):
                 t0 = time.perf_counter()
-                mgr.match(n - 1, 0, n - 1)
+                mgr.match(n - 1, 0, n)
                 torch.cuda.synchronize()
                 tm.append(time.perf_counter() - t0)
             del mgr
         except Exception as e:
             err += " match: " + repr(e)[:200]
-        print("| %d | %d | %.2f | %.1f | %d | %.2f |%s" % (n, len(corr), ms, 1e3 * ms / max(its, 1), its, 1e3 * min(tm), err), flush=True)
+        print("| %d | %d | %.2f | %.1f | %d | %.2f |%s" % (n, len(corr), ms, 1e3 * ms / max(its, 1), its, 1e3 * min(tm or [float("nan")]), err), flush=True)
 
 
 if __name__ == "__main__":

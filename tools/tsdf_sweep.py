@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--sweeps", type=int, default=2)
     ap.add_argument("--separate", action="store_true", help="de-integrate + integrate as two operators instead of the fused one")
     ap.add_argument("--no-overlap", action="store_true", help="do not software-pipeline consecutive operators")
+    ap.add_argument("--shard-alloc", action="store_true", help="(several ranks) divide the allocation's ray march over the ranks: every rank marches a band of the pixel "
+                    "tiles (bf_scene_alloc_collect), ONE all-gather of the key lists per operator, every rank ingests all lists (bf_scene_alloc_ingest / _place)")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -76,6 +78,29 @@ def main():
         xi = rng.normal(0.0, 0.01, 6)
         pert.append((T.astype(np.float64) @ se3_exp(xi[:3], xi[3:])).astype(np.float32))
 
+    CAP = 1 << 19
+    if a.shard_alloc:
+        sc.set_external_alloc(True)
+        keys = torch.zeros(CAP, dtype=torch.int64, device="cuda"); slots = torch.zeros(CAP, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        all_keys = torch.zeros(world * (CAP + 1), dtype=torch.int64, device="cuda")
+
+    def allocate(T, k):
+        """collect on this rank's band, all-gather (keys + count as one fixed-size record per rank), ingest every list, place"""
+        if not a.shard_alloc:
+            return
+        sc.alloc_collect(T, dev[k][0], cam, rank, world, keys, slots, cnt)
+        sc.alloc_sync()
+        rec = torch.cat([cnt.to(torch.int64), keys])
+        if world > 1:
+            dist.all_gather_into_tensor(all_keys, rec)
+        else:
+            all_keys.copy_(rec)
+        torch.cuda.synchronize()
+        for r in range(world):
+            seg = all_keys[r * (CAP + 1):(r + 1) * (CAP + 1)]
+            sc.alloc_ingest(seg[1:], seg[:1].view(torch.int32))       # little endian: the low word of the int64 count
+        sc.alloc_place()
+
     def sync():
         sc.hash_params()          # drains both internal streams
         torch.cuda.synchronize()
@@ -85,6 +110,7 @@ def main():
 
     t0 = time.perf_counter()
     for k in range(a.frames):
+        allocate(poses[k], k)
         sc.integrate(poses[k], dev[k][0], dev[k][1], cam)
     sync()
     t_int = time.perf_counter() - t0
@@ -95,6 +121,7 @@ def main():
     for s in range(a.sweeps):
         tgt = pert if s % 2 == 0 else poses
         for k in range(a.frames):
+            allocate(tgt[k], k)
             if a.separate:
                 sc.deintegrate(cur[k], dev[k][0], dev[k][1], cam)
                 sc.integrate(tgt[k], dev[k][0], dev[k][1], cam)
