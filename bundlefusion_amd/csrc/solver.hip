@@ -63,6 +63,7 @@ struct Dev {
     float* energies;
     float* maxRes; int* maxIdx; int* highCount;
     int* numEntriesPerRow;
+    float* coopVec;                  // k_pcg_coop with vecGlobal: per-workgroup vectors (problems too large for LDS)
     uint32_t* scanRow;               // k_scan_*: three sums (then exclusive bases) per row of the key table
     float* maxResPart; int* maxIdxPart;   // k_max_residual: one (value, index) per workgroup
     uint32_t maxSlots, maxPairs;
@@ -775,7 +776,10 @@ BF_DEV bool gridBarrier(uint32_t* counter, uint32_t target, int* shFail) {
     return *shFail == 0;
 }
 
-__global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t gnIter, int lastGN, uint32_t ldsFloats) {
+// vecGlobal: the workgroup's private copies of the five vectors and of the row offsets live in global memory (d.coopVec, one region per
+// workgroup, L2-resident) instead of LDS - the form for problems whose vectors do not fit (31 N floats: N > ~1300 key frames; round 2 fell
+// back to ONE workgroup there, 79 us per iteration at N = 2000).  Same arithmetic, same order.
+__global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t gnIter, int lastGN, uint32_t ldsFloats, uint32_t vecGlobal) {
     if (d.flags[FL_DONE]) return;
     extern __shared__ __align__(16) float coopLds[];
     float* const dynLds = coopLds;
@@ -783,17 +787,20 @@ __global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t
     __shared__ int shFail;
     const uint32_t N = d.N, n6 = 6 * N, G = gridDim.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = COOP_THREADS >> 6;
-    float* const P = dynLds;
-    float* const R = dynLds + n6;
-    float* const X = dynLds + 2 * n6;
-    float* const AP = dynLds + 3 * n6;
-    float* const M = dynLds + 4 * n6;
-    uint32_t* const RS = reinterpret_cast<uint32_t*>(dynLds + 5 * n6);
+    const uint32_t vecFloats = (5 * n6 + (N + 1) + 3) & ~3u;
+    float* const vec = vecGlobal ? d.coopVec + (size_t)blockIdx.x * vecFloats : dynLds;
+    float* const P = vec;
+    float* const R = vec + n6;
+    float* const X = vec + 2 * n6;
+    float* const AP = vec + 3 * n6;
+    float* const M = vec + 4 * n6;
+    uint32_t* const RS = reinterpret_cast<uint32_t*>(vec + 5 * n6);
     // rows [r0, r1) belong to this workgroup
     const uint32_t rpg = (N - 1 + G - 1) / G;
     const uint32_t r0 = min(N, 1 + blockIdx.x * rpg), r1 = min(N, r0 + rpg);
-    float* const DG = dynLds + 5 * n6 + (N + 1);                              // diagonal blocks of the own rows
-    float* const OL = dynLds + ((5 * n6 + (N + 1) + rpg * 36 + 3) & ~3u);      // off-diagonal blocks (16-byte aligned), then one column index per slot
+    const uint32_t ldsBase = vecGlobal ? 0u : 5 * n6 + (N + 1);
+    float* const DG = dynLds + ldsBase;                                        // diagonal blocks of the own rows
+    float* const OL = dynLds + ((ldsBase + rpg * 36 + 3) & ~3u);               // off-diagonal blocks (16-byte aligned), then one column index per slot
     if (threadIdx.x == 0) shFail = 0;
     for (uint32_t t = threadIdx.x; t < n6; t += COOP_THREADS) M[t] = d.prec[t];
     for (uint32_t t = threadIdx.x; t <= N; t += COOP_THREADS) RS[t] = d.rowStart[t];
@@ -1024,6 +1031,8 @@ struct bf_solver {
     float hMaxRes = 0.0f; int hMaxIdx = 0; int hBarrierFail = 0;
     int pcgGroups = -1;                  // BF_PCG_GROUPS: -1 automatic, 0 single-workgroup kernel, n forced group count
     uint32_t maxCoopGroups = COOP_MAX_GROUPS;
+    bool forceVecGlobal = false;
+    size_t coopVecFloats = 0;            // capacity of d.coopVec (k_pcg_coop with the vectors in global memory)
     uint32_t lastN = 0, lastGNrequested = 0;
     float lastWeightSparse = 1.0f;
     bool lastUsedDense = false;
@@ -1051,6 +1060,7 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
     if (const char* e = getenv("BF_PCG_GROUPS")) s->pcgGroups = atoi(e);        // 0: single-workgroup kernel, n > 0: force n groups
+    if (const char* e = getenv("BF_PCG_VEC_GLOBAL")) s->forceVecGlobal = atoi(e) != 0;      // tests: the large-N form (vectors in global memory) on a small problem
     {   // every group of the cooperative PCG must be resident at once (each may take a whole CU's LDS): never ask for more than
         // half of the CUs this device (or compute partition) has
         int dev = 0, cus = 0;
@@ -1074,7 +1084,7 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
               sAlloc(s, &d.densePairs, (size_t)d.maxPairs) && sAlloc(s, &d.denseWeight, (size_t)d.maxPairs) &&
               sAlloc(s, &d.denseBlocks, (size_t)d.maxPairs * DENSE_BLK) && sAlloc(s, &d.flags, FL_COUNT) && sAlloc(s, &d.gridBar, 32) && sAlloc(s, &d.energies, 40) &&
               sAlloc(s, &d.maxRes, 1) && sAlloc(s, &d.maxIdx, 1) && sAlloc(s, &d.highCount, 1) && sAlloc(s, &d.numEntriesPerRow, N) &&
-              sAlloc(s, &d.scanRow, 3 * (N + 1)) && sAlloc(s, &d.maxResPart, MAXRES_GROUPS) && sAlloc(s, &d.maxIdxPart, MAXRES_GROUPS);
+              sAlloc(s, &d.scanRow, 3 * (N + 1)) && sAlloc(s, &d.coopVec, s->coopVecFloats = ((31 * N + 4096 <= PCG_LDS_MAX / 4 && !s->forceVecGlobal) ? (size_t)4 : (size_t)s->maxCoopGroups * ((31 * N + 1 + 3) & ~(size_t)3))) && sAlloc(s, &d.maxResPart, MAXRES_GROUPS) && sAlloc(s, &d.maxIdxPart, MAXRES_GROUPS);
     if (!ok) { set_error("bf_solver_create: hipMalloc failed"); bf_solver_destroy(s); return BF_ERR_HIP; }
     (void)hipMemset(d.flags, 0, FL_COUNT * sizeof(int));
     *out = s;
@@ -1154,10 +1164,13 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
             uint32_t G = N <= 32 ? 1u : std::min(s->maxCoopGroups, div_up(N - 1, COOP_ROWS_PER_GROUP));
             if (s->pcgGroups > 0) G = std::min(std::min<uint32_t>((uint32_t)s->pcgGroups, N - 1), s->maxCoopGroups);
             const uint32_t rpg = div_up(N - 1, G);
-            const size_t baseFloats = ((size_t)31 * N + 1 + (size_t)rpg * 36 + 3) & ~(size_t)3;    // 5 vectors, row offsets, own diagonal blocks
+            size_t baseFloats = ((size_t)31 * N + 1 + (size_t)rpg * 36 + 3) & ~(size_t)3;    // 5 vectors, row offsets, own diagonal blocks
+            const uint32_t vecGlobal = (s->forceVecGlobal || baseFloats + 37 * 8 > PCG_LDS_MAX / 4) ? 1u : 0u;      // the vectors do not fit into LDS: keep them in global memory (d.coopVec)
+            if (vecGlobal) baseFloats = ((size_t)rpg * 36 + 3) & ~(size_t)3;
             const size_t ldsFloats = std::min<size_t>(PCG_LDS_MAX / 4, baseFloats + (size_t)rpg * std::min<uint32_t>(N - 1, 96u) * 37);
-            if (s->pcgGroups != 0 && nNonLin <= 32 && baseFloats + 37 * 8 <= PCG_LDS_MAX / 4)
-                hipLaunchKernelGGL(k_pcg_coop, dim3(G), dim3(COOP_THREADS), ldsFloats * 4, st, d, nLin, it, (int)(it == nNonLin - 1), (uint32_t)ldsFloats);
+            const bool vecFits = !vecGlobal || (size_t)G * (((size_t)31 * N + 1 + 3) & ~(size_t)3) <= s->coopVecFloats;
+            if (s->pcgGroups != 0 && nNonLin <= 32 && vecFits && baseFloats + 37 * 8 <= PCG_LDS_MAX / 4)
+                hipLaunchKernelGGL(k_pcg_coop, dim3(G), dim3(COOP_THREADS), ldsFloats * 4, st, d, nLin, it, (int)(it == nNonLin - 1), (uint32_t)ldsFloats, vecGlobal);
             else if ((size_t)N * 124 + 4 <= PCG_LDS_MAX)                              // 5 vectors of 6N floats + N+1 row offsets
                 hipLaunchKernelGGL(k_pcg<true>, dim3(1), dim3(1024), (size_t)N * 124 + 4, st, d, nLin, it, (int)(it == nNonLin - 1));
             else hipLaunchKernelGGL(k_pcg<false>, dim3(1), dim3(1024), 0, st, d, nLin, it, (int)(it == nNonLin - 1));

@@ -1918,7 +1918,7 @@ int bf_scene_alloc_collect(bf_scene* s, const float camToWorld[16], const bf_dep
     c.tile0 = (uint32_t)((uint64_t)tiles * part / parts); c.tile1 = (uint32_t)((uint64_t)tiles * (part + 1) / parts);
     BF_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
     if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, s->d, f, data->d_depthData, c);
-    hipLaunchKernelGGL(k_collect_release, dim3(64), dim3(256), 0, st, s->d, c);
+    hipLaunchKernelGGL(k_collect_release, dim3(std::min<uint32_t>(div_up(capacity, 256u), 2048u)), dim3(256), 0, st, s->d, c);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }

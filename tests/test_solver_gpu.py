@@ -131,6 +131,13 @@ def test_pcg_result_independent_of_workgroup_count(gpu, oracle, monkeypatch):
         solver.solve(_dev(corr.view(np.uint8)), len(corr), _dev(valid), n, 3, 150, None, [1.0] * 3, [0.0] * 3, [0.0] * 3, grot, gtr, find_max_residual=True)
         out[groups] = (grot.cpu().numpy(), gtr.cpu().numpy(), solver.iteration_counts())
     monkeypatch.delenv("BF_PCG_GROUPS", raising=False)
+    # the large-problem form of the cooperative kernel (the workgroups' vectors in global memory instead of LDS: N > ~1300 key frames), forced
+    monkeypatch.setenv("BF_PCG_VEC_GLOBAL", "1")
+    solver = gpu.capi.Solver(n, len(corr), default_solver_config(record_convergence=False))
+    grot, gtr = _dev(rot0.copy()), _dev(tr0.copy())
+    solver.solve(_dev(corr.view(np.uint8)), len(corr), _dev(valid), n, 3, 150, None, [1.0] * 3, [0.0] * 3, [0.0] * 3, grot, gtr, find_max_residual=True)
+    monkeypatch.delenv("BF_PCG_VEC_GLOBAL", raising=False)
+    assert np.array_equal(grot.cpu().numpy(), out[""][0]) and np.array_equal(gtr.cpu().numpy(), out[""][1]) and solver.iteration_counts() == out[""][2]
     for groups in ("1", "7", "64"):
         assert np.array_equal(out[groups][0], out[""][0]) and np.array_equal(out[groups][1], out[""][1]), groups
         assert out[groups][2] == out[""][2]
