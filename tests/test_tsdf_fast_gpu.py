@@ -205,3 +205,51 @@ def test_fast_contract_at_bench_configuration_vs_exact_contract(gpu):
         del gs
     r = _compare(out["fast"], out["exact"], used, cam, p, "bench configuration", COLOUR_SEQ, min_checked=5000000)
     print("fast vs exact contract at 640x480 / 4 mm:", r)
+
+
+def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
+    """Two pipelines over the same 33 frames at 640x480 / 4 mm (three local chunks, re-integrations, GC), one per arithmetic contract of the
+    voxel update: the volume does not feed back into the bundling, so trajectories and every counter are identical; the hash table, the heap
+    and every voxel weight are identical; sdf / colour within the contract outside the pixel-boundary voxels (here bounded statistically: the
+    operator log of a pipeline is not replayed in float64)."""
+    import torch
+    from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, sensor_desc
+    W, H, n = 640, 480, 33
+    frames = synth.render_frames(range(n))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    out = {}
+    for arith in ("exact", "fast"):
+        gas = default_app_state(); gbs = default_bundling_state()
+        gas.s_integrationWidth, gas.s_integrationHeight = W, H
+        gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.004, 1000000, 250000
+        gbs.s_maxNumImages = 8
+        p = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+        p.scene().set_arith(arith)
+        for d, c in dev:
+            assert p.process_frame(d, c)
+        for _ in range(4):
+            p.process_end_of_sequence()
+        p.synchronize()
+        assert p.scene().arith() == arith
+        out[arith] = (p.integrated_trajectory().copy(), p.optimized_trajectory().copy(), p.counters(), p.scene().download())
+        del p
+    (te, oe, ce, ve), (tf, of, cf, vf) = out["exact"], out["fast"]
+    assert np.array_equal(te.view(np.uint32), tf.view(np.uint32)) and np.array_equal(oe.view(np.uint32), of.view(np.uint32)) and ce == cf and ce["deintegrate"] > 20
+    (he, heape, cnte, voxe), (hf, heapf, cntf, voxf) = ve, vf
+    assert cnte == cntf and np.array_equal(heape, heapf)
+    for f in ("pos", "ptr", "offset"):
+        assert np.array_equal(he[f], hf[f]), f
+    live = (voxe["weight"] > 0) | (voxf["weight"] > 0)
+    dw = voxe["weight"] != voxf["weight"]
+    ds = np.abs(voxe["sdf"].astype(np.float64) - voxf["sdf"].astype(np.float64))
+    dc = np.abs(voxe["color"].astype(np.int32) - voxf["color"].astype(np.int32)).max(axis=1)
+    tol = 1e-5 * 0.06
+    nlive = int(live.sum())
+    share = lambda m: float((m & live).sum()) / nlive
+    print("frame loop, fast vs exact contract: %d live voxels; weights differ %.2e, sdf beyond 1e-5 x truncation %.2e, colour beyond 1 LSB %.2e of them"
+          % (nlive, share(dw), share(ds > tol), share(dc > 1)))
+    assert nlive > 5000000
+    # pixel-boundary voxels only: a few 1e-4 of the voxels per operator, ~60 operators
+    assert share(dw) < 5e-3 and share(ds > tol) < 2e-2 and share(dc > 1) < 2e-2
