@@ -92,10 +92,6 @@ def main():
         S0 = 10
         last_chunk = 0 if total <= 1 else (total - 2) // S0
         n_render = ((last_chunk // world + 1) * world) * S0 + 1
-    t_gen = time.perf_counter()
-    frames = synth.render_frames(range(first, first + n_render), W, H, workers=max(1, min(64, ncpu // max(world, 1))))
-    t_gen = time.perf_counter() - t_gen
-
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -103,6 +99,32 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # One stream on several ranks: every rank needs every frame, but nobody has to render all of them - rank r renders a contiguous share (the
+    # renderer's children are fresh python processes without torch / HIP, so this is safe after the device context exists) and ONE all-gather
+    # per image plane hands every rank the whole stream (untimed set-up, 2.4 MB per frame over xGMI instead of ~1 s of host rendering per frame
+    # and rank).  BF_BENCH_SHARED_RENDER=1 takes this path with one rank too (how it is exercised on a single GPU).
+    shared_render = one_stream and (world > 1 or os.environ.get("BF_BENCH_SHARED_RENDER") == "1")
+    t_gen = time.perf_counter()
+    if shared_render:
+        per = (n_render + world - 1) // world
+        mine = list(range(first + rank * per, min(first + (rank + 1) * per, first + n_render)))
+        part = synth.render_frames(mine, W, H, workers=max(1, min(64, ncpu // max(world, 1)))) if mine else []
+        d_part = torch.zeros((per, H, W), dtype=torch.float32, device="cuda"); c_part = torch.zeros((per, H, W, 4), dtype=torch.uint8, device="cuda")
+        for i, f in enumerate(part):
+            d_part[i] = torch.from_numpy(f[0]).cuda(); c_part[i] = torch.from_numpy(f[1]).cuda()
+        if world > 1:
+            d_all = torch.empty((world * per, H, W), dtype=torch.float32, device="cuda"); c_all = torch.empty((world * per, H, W, 4), dtype=torch.uint8, device="cuda")
+            dist.all_gather_into_tensor(d_all, d_part); dist.all_gather_into_tensor(c_all, c_part)
+        else:
+            d_all, c_all = d_part, c_part
+        torch.cuda.synchronize()
+        Kd_ = synth.intrinsics(W, H)
+        # (depth, colour, pose, intrinsics) like synth.scene_room returns them; depth / colour stay on the device
+        frames = [(d_all[i], c_all[i], synth.trajectory_pose(first + i), Kd_) for i in range(n_render)]
+    else:
+        frames = synth.render_frames(range(first, first + n_render), W, H, workers=max(1, min(64, ncpu // max(world, 1))))
+    t_gen = time.perf_counter() - t_gen
 
     import bundlefusion_amd as bf
     from bundlefusion_amd.capi import intrinsics_matrix, default_app_state, default_bundling_state, sensor_desc, bind_host_threads_to_device
@@ -119,7 +141,10 @@ def main():
         gbs.s_maxNumImages = max(n_render // 10 + 8, 16)
         return gas, gbs
 
-    if args.host:
+    if shared_render:
+        assert not args.host, "the shared rendering keeps the frames on the device"
+        feed = [(f[0], f[1]) for f in frames]
+    elif args.host:
         feed = [(f[0], f[1]) for f in frames]
     else:
         feed = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
@@ -327,6 +352,8 @@ def cpu_baseline(frames, feed, params, K, W, H, arith):
     from bundlefusion_amd.capi import sensor_desc
     from tests import oracle_api
     from tests.oracle_pipeline import OraclePipeline
+
+    frames = [(f[0].cpu().numpy() if hasattr(f[0], "cpu") else f[0], f[1].cpu().numpy() if hasattr(f[1], "cpu") else f[1], f[2], f[3]) for f in frames]
 
     def run(n_frames, threads):
         gas, gbs = params(400000, 250000)      # three chunks touch < 200k blocks; a smaller heap keeps the host allocation out of the timing
