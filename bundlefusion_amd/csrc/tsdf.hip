@@ -1373,21 +1373,6 @@ BF_DEV ApxEntry apxEntry(const Dev& d, uint32_t blk) {
     return r;
 }
 
-// The same list entry through the scalar cache: the address is wave-uniform, the list was written by an earlier kernel (scalar and vector L1
-// are invalidated at the launch's acquire), and a scalar load returns in a fraction of a vector round trip - the one serial round trip a
-// wave pays per block before it can address its voxels.
-template <int MODE>
-BF_DEV ApxEntry apxEntryScalar(const Dev& d, uint32_t blk) {
-    typedef int v8i __attribute__((ext_vector_type(8)));
-    const unsigned long long addr = (unsigned long long)reinterpret_cast<uintptr_t>(d.compact) + (unsigned long long)blk * 32ull;
-    v8i w;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(addr) : "memory");
-    ApxEntry r;
-    r.e.x = w[0]; r.e.y = w[1]; r.e.z = w[2]; r.e.w = w[3];
-    r.flags = MODE == 2 ? (uint32_t)w[4] : 3u;
-    return r;
-}
-
 template <int MODE, bool RNE, bool PIPE>
 BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* __restrict__ depth, const uchar4* __restrict__ color,
                           int accumulate) {
@@ -1396,7 +1381,7 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
     const uint32_t n = (uint32_t)d.compactCount[0];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), nWaves = gridDim.x * 4u;
-    if ((accumulate & 1) && wave == 0 && lane == 0) {          // bit 0: block accounting of the timed launches; bit 1: list entries through the scalar cache
+    if (accumulate && wave == 0 && lane == 0) {          // block accounting of the timed launches
         if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
         else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
     }
@@ -1405,7 +1390,7 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
     const __amdgpu_buffer_rsrc_t colorRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uchar4*>(color), 0, (int)c.bytes, 0x00020000);
     if (!PIPE) {           // one pair at a time: one memory round trip per pair, hidden by the other waves of the SIMD only
         for (uint32_t blk = wave; blk < n; blk += nWaves) {
-            const ApxEntry en = (accumulate & 2) ? apxEntryScalar<MODE>(d, blk) : apxEntry<MODE>(d, blk);
+            const ApxEntry en = apxEntry<MODE>(d, blk);
             const ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
 #pragma unroll 1
             for (int z = 0; z < 8; z += 2) {
@@ -1444,18 +1429,12 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
     }
 }
 
-// Two builds of the same body: the register allocator's own choice (85-87 SGPRs for the fused kernel: 7 workgroups of 256 threads per CU -
-// MI355X_MICROARCH.md: 82-96 SGPRs admit 7) and one held to 80 SGPRs (8 per CU; the ten values that no longer fit live in lanes of a VGPR and
-// are read back once per block, none inside the voxel-pair loop).  BF_APX_SGPR80 selects (bf_scene: apxSgpr80).
+// Measured and withdrawn (gpurun r03i): the same body held to 80 SGPRs (8 workgroups per CU instead of 7; the ten spilled values are read back
+// once per block) - 92.7 vs 93.4 us per launch, inside the run-to-run spread; list entries through the scalar cache (s_load_dwordx8) - 92.8 us.
 template <int MODE, bool RNE, bool PIPE>
 __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in, ApxPose de, const float* __restrict__ depth, const uchar4* __restrict__ color,
                                                     int accumulate) {
     updateApxBody<MODE, RNE, PIPE>(d, c, in, de, depth, color, accumulate);
-}
-template <int MODE, bool RNE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_update_apx80(Dev d, ApxCam c, ApxPose in, ApxPose de, const float* __restrict__ depth,
-                                                                                           const uchar4* __restrict__ color, int accumulate) {
-    updateApxBody<MODE, RNE, false>(d, c, in, de, depth, color, accumulate);
 }
 
 // what v_cvt_pk_u8_f32 does on this device (see packByte)
@@ -1595,8 +1574,6 @@ struct bf_scene {
     bool externalAlloc = false;     // bf_scene_set_external_alloc: integrate / re-integrate do not allocate (the caller ran bf_scene_alloc_collect / _ingest)
     int arith = BF_TSDF_ARITH_EXACT; // bf_scene_set_arith / BF_TSDF_ARITH: exact (IEEE op by op, default) or fast (k_update_apx)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
-    bool apxScalarEntry = false;    // k_update_apx: frustum-list entries through the scalar cache (BF_APX_SLOAD)
-    bool apxSgpr80 = false;         // k_update_apx80: the same kernel held to 80 SGPRs (8 workgroups per CU instead of 7); BF_APX_SGPR80
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
                                     // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
     int32_t* d_hashDecision = nullptr;
@@ -1721,10 +1698,7 @@ int probeCvt(bf_scene* s) {
 
 template <int MODE>
 void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* depth, const uchar4* color, int acc) {
-    if (s->apxSgpr80 && !s->apxPipe) {
-        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx80<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
-        else hipLaunchKernelGGL((k_update_apx80<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
-    } else if (s->apxPipe) {
+    if (s->apxPipe) {
         if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
         else hipLaunchKernelGGL((k_update_apx<MODE, false, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
     } else {
@@ -1828,10 +1802,9 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     if (s->arith == BF_TSDF_ARITH_FAST) {
         const ApxCam ac = makeApxCam(f);
         const ApxPose pin = makeApxPose(f), pde = makeApxPose(kind == 2 ? fo : f);
-        const int opt = acc | (s->apxScalarEntry ? 2 : 0);
-        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, opt);
-        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, opt);
-        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, data->d_depthData, color, opt);
+        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, acc);
+        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, acc);
+        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, data->d_depthData, color, acc);
     } else if (s->columnUpdate) {
         const UpdCam uc = makeUpdCam(f);
         const UpdPose pin = makeUpdPose(f), pde = makeUpdPose(kind == 2 ? fo : f);
@@ -1920,8 +1893,6 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_TSDF_UPDATE")) s->columnUpdate = strcmp(e, "voxel") != 0;
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_PIPE")) s->apxPipe = atoi(e) != 0;
-    if (const char* e = getenv("BF_APX_SGPR80")) s->apxSgpr80 = atoi(e) != 0;
-    if (const char* e = getenv("BF_APX_SLOAD")) s->apxScalarEntry = atoi(e) != 0;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
