@@ -1558,7 +1558,9 @@ struct bf_pipeline {
     // first call that needs its result).  The per-frame work and its order are unchanged, so are the results.
     hipStream_t sDetect = nullptr;
     bool lookahead = true;
+    bool earlyChain = true;         // BF_PIPELINE_EARLY_CHAIN=0: enqueue a frame's matching chain in the next call (round-2 behaviour)
     int deferred = -1;              // frame whose body has not run yet
+    bool deferredBegun = false;     // ... but whose matching chain is already enqueued (plBodyBegin ran in the call that delivered it)
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
@@ -1729,7 +1731,9 @@ int plBody(bf_pipeline* p, uint32_t frame, bool got) {
 int plFlush(bf_pipeline* p) {
     if (p->deferred < 0) return BF_OK;
     const uint32_t f = (uint32_t)p->deferred;
-    p->deferred = -1;
+    const bool begun = p->deferredBegun;
+    p->deferred = -1; p->deferredBegun = false;
+    if (begun) return plBodyRest(p, f, true);
     return plBody(p, f, true);
 }
 
@@ -1740,7 +1744,7 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     // ---- look-ahead: the previous frame's matching chain is enqueued first, so the GPU works on it while this thread issues
     //      the ~35 launches of the new frame's ingest and detection
     const int prev = ahead ? p->deferred : -1;
-    if (prev >= 0) BF_TRY(plBodyBegin(p, (uint32_t)prev));
+    if (prev >= 0) { if (!p->deferredBegun) BF_TRY(plBodyBegin(p, (uint32_t)prev)); }
     else BF_TRY(plFlush(p));
     // ---- read input (detect stream)
     const double tIn = plNow();
@@ -1752,8 +1756,15 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (tm) { (void)hipEventRecord(p->ev[1], sd); BF_HIP_TRY(hipStreamWaitEvent(sa, p->ev[1], 0)); (void)hipEventRecord(p->ev[8], sa); }
     if (got) BF_TRY(bf_online_bundler_detect_ahead(p->ob));
     p->hostProfile[1] += plNow() - tIn;
-    if (prev >= 0) { p->deferred = -1; BF_TRY(plBodyRest(p, (uint32_t)prev, true)); }
-    if (ahead && got) p->deferred = (int)frame;
+    if (prev >= 0) { p->deferred = -1; p->deferredBegun = false; BF_TRY(plBodyRest(p, (uint32_t)prev, true)); }
+    if (ahead && got) {
+        p->deferred = (int)frame;
+        // The new frame's matching chain goes onto the bundling stream NOW - behind the previous frame's solves, which is where it belongs in
+        // the serial order - instead of at the start of the next call: the stream used to idle for the return to the caller, the next call's
+        // set-up and the next frame's ingest / detection enqueue (340 us per frame, profiles/r03_pipeline_timeline.txt: "copyBuffer ->
+        // k_copy_segments").  Same operations in the same stream order; only the moment the host issues them moves.
+        if (p->earlyChain) { BF_TRY(plBodyBegin(p, frame)); p->deferredBegun = true; }
+    }
     else if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, got != 0));
     if (tm) {
         (void)hipEventRecord(p->ev[3], sa);
@@ -1813,6 +1824,7 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
+    if (const char* e = getenv("BF_PIPELINE_EARLY_CHAIN")) p->earlyChain = atoi(e) != 0;
     BF_TRY(bf_image_manager_set_stream(p->im, p->sDetect));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_online_bundler_set_detect_stream(p->ob, p->sDetect));
