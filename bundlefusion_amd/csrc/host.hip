@@ -1820,6 +1820,19 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         int least = 0, greatest = 0;
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sBundle, hipStreamNonBlocking, greatest));
+        // BF_VOLUME_CU_RESERVE=R (experiment, default off): the volume stream may use all but R compute units, so that the latency-bound kernels of
+        // the bundling chain always find idle CUs instead of sharing SIMDs with the voxel update's resident waves
+        uint32_t reserve = 0;
+        if (const char* e = getenv("BF_VOLUME_CU_RESERVE")) reserve = (uint32_t)atoi(e);
+        int cus = 0;
+        int devId = 0;
+        (void)hipGetDevice(&devId);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devId);
+        if (reserve > 0 && cus > 0 && reserve < (uint32_t)cus) {
+            std::vector<uint32_t> mask(((uint32_t)cus + 31) / 32, 0u);
+            for (uint32_t c = 0; c < (uint32_t)cus - reserve; ++c) mask[c / 32] |= 1u << (c % 32);
+            BF_HIP_TRY(hipExtStreamCreateWithCUMask(&p->sVolume, (uint32_t)mask.size(), mask.data()));
+        } else
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
     }
