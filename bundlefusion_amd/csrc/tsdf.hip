@@ -1294,27 +1294,17 @@ BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe
     const v2f pz = iz * sp2(c.voxelSize);
     o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
     o.inDeA = o.inDeB = o.inInA = o.inInB = false;
-    // The two voxels of a pair are neighbours along world z and mostly project to the SAME pixel (a 4 mm voxel is about one pixel wide at 2 m and the
-    // step is mostly along the viewing direction).  The kernel is bound by the rate of L1 accesses of these divergent gathers (TD busy 84 %, 0.78
-    // cache accesses per cycle and CU: profiles/r03_ta_tsdf_update.md), so the second voxel's loads go out of the descriptor's range - answered with 0 by
-    // the address unit, without a cache access - when its pixel is the first one's, and take the first one's values.
     if (DE) {
         const ApxSample a = apxProject(c, pDe, b.cDe, iz, pz, b.useDe);
         o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
-        const bool same = a.offA == a.offB;
-        const uint32_t offB = same ? 0xFFFFFFFFu : a.offB;
         o.dDe.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offA, 0, 0)); o.kDeA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offA, 0, 0);
-        const float dB = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)offB, 0, 0)); const uint32_t kB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)offB, 0, 0);
-        o.dDe.y = same ? o.dDe.x : dB; o.kDeB = same ? o.kDeA : kB;
+        o.dDe.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offB, 0, 0)); o.kDeB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offB, 0, 0);
     }
     if (IN) {
         const ApxSample a = apxProject(c, pIn, b.cIn, iz, pz, b.useIn);
         o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
-        const bool same = a.offA == a.offB;
-        const uint32_t offB = same ? 0xFFFFFFFFu : a.offB;
         o.dIn.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offA, 0, 0)); o.kInA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offA, 0, 0);
-        const float dB = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)offB, 0, 0)); const uint32_t kB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)offB, 0, 0);
-        o.dIn.y = same ? o.dIn.x : dB; o.kInB = same ? o.kInA : kB;
+        o.dIn.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offB, 0, 0)); o.kInB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offB, 0, 0);
     }
     return o;
 }
