@@ -1213,6 +1213,7 @@ struct ApxCam {
     float mxh, myh;            // principal point + 0.5 (the rounding offset of the pixel index)
     float voxelSize, maxDist, truncScale, truncation, weightMax;
     uint32_t W, H, bytes;      // image size, bytes of one image plane (W * H * 4)
+    uint32_t texel;            // 1: `depth` is an interleaved image of 8-byte texels {depth, colour} (k_interleave), `color` is only tested for null
 };
 struct ApxPose {
     float ax, bx, cx, dx;      // fx * voxelSize * (R00, R01, R02), fx * t0: numerator of the image x coordinate over the integer voxel coordinates
@@ -1283,6 +1284,26 @@ BF_DEV ApxBlock apxBlock(const Dev& d, const ApxCam& c, const ApxPose& pIn, cons
     return b;
 }
 
+// depth and colour of one pixel: two 4-byte gathers from the two planes, or ONE 8-byte gather from the interleaved image the prep stream
+// builds per operator (k_interleave) - half the vector-memory instructions of a kernel that sits on the CU's memory pipeline
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+struct ApxTexel { float dep; uint32_t col; };
+BF_DEV ApxTexel apxGather(const ApxCam& c, __amdgpu_buffer_rsrc_t depthRes, __amdgpu_buffer_rsrc_t colorRes, uint32_t off) {
+    ApxTexel r;
+    if (c.texel) {
+        const v2u t = __builtin_amdgcn_raw_buffer_load_b64(depthRes, (int)(off << 1), 0, 0);      // 0xFFFFFFFF << 1 stays beyond the range
+        r.dep = __uint_as_float(t.x); r.col = t.y;
+    } else {
+        r.dep = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)off, 0, 0));
+        r.col = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)off, 0, 0);
+    }
+    return r;
+}
+
+__global__ void k_interleave(const float* __restrict__ depth, const uint32_t* __restrict__ color, uint2* __restrict__ texel, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) texel[i] = make_uint2(__float_as_uint(depth[i]), color[i]);
+}
+
 template <bool DE, bool IN>
 BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, __amdgpu_buffer_rsrc_t depthRes,
                          __amdgpu_buffer_rsrc_t colorRes) {
@@ -1297,14 +1318,14 @@ BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe
     if (DE) {
         const ApxSample a = apxProject(c, pDe, b.cDe, iz, pz, b.useDe);
         o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
-        o.dDe.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offA, 0, 0)); o.kDeA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offA, 0, 0);
-        o.dDe.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offB, 0, 0)); o.kDeB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offB, 0, 0);
+        const ApxTexel tA = apxGather(c, depthRes, colorRes, a.offA), tB = apxGather(c, depthRes, colorRes, a.offB);
+        o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
     }
     if (IN) {
         const ApxSample a = apxProject(c, pIn, b.cIn, iz, pz, b.useIn);
         o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
-        o.dIn.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offA, 0, 0)); o.kInA = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offA, 0, 0);
-        o.dIn.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)a.offB, 0, 0)); o.kInB = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)a.offB, 0, 0);
+        const ApxTexel tA = apxGather(c, depthRes, colorRes, a.offA), tB = apxGather(c, depthRes, colorRes, a.offB);
+        o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
     }
     return o;
 }
@@ -1386,7 +1407,7 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
         else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
     }
     if (wave >= n) return;
-    const __amdgpu_buffer_rsrc_t depthRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(depth), 0, (int)c.bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t depthRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(depth), 0, (int)(c.texel ? 2u * c.bytes : c.bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t colorRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uchar4*>(color), 0, (int)c.bytes, 0x00020000);
     if (!PIPE) {           // one pair at a time: one memory round trip per pair, hidden by the other waves of the SIMD only
         for (uint32_t blk = wave; blk < n; blk += nWaves) {
@@ -1574,6 +1595,8 @@ struct bf_scene {
     bool externalAlloc = false;     // bf_scene_set_external_alloc: integrate / re-integrate do not allocate (the caller ran bf_scene_alloc_collect / _ingest)
     int arith = BF_TSDF_ARITH_EXACT; // bf_scene_set_arith / BF_TSDF_ARITH: exact (IEEE op by op, default) or fast (k_update_apx)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
+    bool apxTexel = true;           // k_update_apx gathers 8-byte {depth, colour} texels from an interleaved copy of the frame built per operator on the prep stream (BF_APX_TEXEL=0: the two planes)
+    uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // one per list buffer (NB)
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
                                     // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
     int32_t* d_hashDecision = nullptr;
@@ -1659,7 +1682,7 @@ ApxCam makeApxCam(const Frame& f) {
     ApxCam u;
     u.mxh = f.cam.mx + 0.5f; u.myh = f.cam.my + 0.5f;
     u.voxelSize = f.voxelSize; u.maxDist = f.maxIntegrationDistance; u.truncScale = f.truncScale; u.truncation = f.truncation; u.weightMax = f.weightMax;
-    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight; u.bytes = u.W * u.H * 4u;
+    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight; u.bytes = u.W * u.H * 4u; u.texel = 0u;
     return u;
 }
 ApxPose makeApxPose(const Frame& f) {
@@ -1781,6 +1804,16 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
         hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
     }
+    const bool useTexel = s->arith == BF_TSDF_ARITH_FAST && s->apxTexel && data->d_colorData != nullptr;
+    if (useTexel) {          // the frame as 8-byte texels for this operator's gathers (2 x 2.4 MB at 640x480: a few microseconds on the stream that runs ahead)
+        const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
+        if (s->texelPixels < npx) {
+            BF_TRY_RC(syncAll(s));
+            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
+            s->texelPixels = npx;
+        }
+        hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ps, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
+    }
     if (s->overlap) {
         BF_HIP_TRY(hipEventRecord(s->evPrep[b], ps));
         BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
@@ -1800,11 +1833,13 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     const uchar4* color = reinterpret_cast<const uchar4*>(data->d_colorData);
     const int acc = s->timing ? 1 : 0;
     if (s->arith == BF_TSDF_ARITH_FAST) {
-        const ApxCam ac = makeApxCam(f);
+        ApxCam ac = makeApxCam(f);
+        ac.texel = useTexel ? 1u : 0u;
+        const float* src = useTexel ? reinterpret_cast<const float*>(s->texel[b]) : data->d_depthData;
         const ApxPose pin = makeApxPose(f), pde = makeApxPose(kind == 2 ? fo : f);
-        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, acc);
-        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, data->d_depthData, color, acc);
-        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, data->d_depthData, color, acc);
+        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, src, color, acc);
+        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, src, color, acc);
+        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, src, color, acc);
     } else if (s->columnUpdate) {
         const UpdCam uc = makeUpdCam(f);
         const UpdPose pin = makeUpdPose(f), pde = makeUpdPose(kind == 2 ? fo : f);
@@ -1893,6 +1928,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_TSDF_UPDATE")) s->columnUpdate = strcmp(e, "voxel") != 0;
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_PIPE")) s->apxPipe = atoi(e) != 0;
+    if (const char* e = getenv("BF_APX_TEXEL")) s->apxTexel = atoi(e) != 0;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
@@ -1977,6 +2013,7 @@ int bf_scene_destroy(bf_scene* s) {
     if (!s) return BF_OK;
     (void)syncAll(s);
     for (void* q : s->allocations) hipFree(q);
+    for (uint2* t : s->texel) if (t) hipFree(t);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int b = 0; b < bf_scene::NB; ++b) { if (s->evPrep[b]) hipEventDestroy(s->evPrep[b]); if (s->evUpd[b]) hipEventDestroy(s->evUpd[b]); }
     for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
