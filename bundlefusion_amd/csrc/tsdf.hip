@@ -1288,9 +1288,10 @@ BF_DEV ApxBlock apxBlock(const Dev& d, const ApxCam& c, const ApxPose& pIn, cons
 // builds per operator (k_interleave) - half the vector-memory instructions of a kernel that sits on the CU's memory pipeline
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 struct ApxTexel { float dep; uint32_t col; };
-BF_DEV ApxTexel apxGather(const ApxCam& c, __amdgpu_buffer_rsrc_t depthRes, __amdgpu_buffer_rsrc_t colorRes, uint32_t off) {
+template <bool TEX>
+BF_DEV ApxTexel apxGather(__amdgpu_buffer_rsrc_t depthRes, __amdgpu_buffer_rsrc_t colorRes, uint32_t off) {
     ApxTexel r;
-    if (c.texel) {
+    if (TEX) {
         const v2u t = __builtin_amdgcn_raw_buffer_load_b64(depthRes, (int)(off << 1), 0, 0);      // 0xFFFFFFFF << 1 stays beyond the range
         r.dep = __uint_as_float(t.x); r.col = t.y;
     } else {
@@ -1304,7 +1305,7 @@ __global__ void k_interleave(const float* __restrict__ depth, const uint32_t* __
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) texel[i] = make_uint2(__float_as_uint(depth[i]), color[i]);
 }
 
-template <bool DE, bool IN>
+template <bool DE, bool IN, bool TEX>
 BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, __amdgpu_buffer_rsrc_t depthRes,
                          __amdgpu_buffer_rsrc_t colorRes) {
     ApxPair o;
@@ -1318,13 +1319,13 @@ BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe
     if (DE) {
         const ApxSample a = apxProject(c, pDe, b.cDe, iz, pz, b.useDe);
         o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
-        const ApxTexel tA = apxGather(c, depthRes, colorRes, a.offA), tB = apxGather(c, depthRes, colorRes, a.offB);
+        const ApxTexel tA = apxGather<TEX>(depthRes, colorRes, a.offA), tB = apxGather<TEX>(depthRes, colorRes, a.offB);
         o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
     }
     if (IN) {
         const ApxSample a = apxProject(c, pIn, b.cIn, iz, pz, b.useIn);
         o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
-        const ApxTexel tA = apxGather(c, depthRes, colorRes, a.offA), tB = apxGather(c, depthRes, colorRes, a.offB);
+        const ApxTexel tA = apxGather<TEX>(depthRes, colorRes, a.offA), tB = apxGather<TEX>(depthRes, colorRes, a.offB);
         o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
     }
     return o;
@@ -1394,7 +1395,7 @@ BF_DEV ApxEntry apxEntry(const Dev& d, uint32_t blk) {
     return r;
 }
 
-template <int MODE, bool RNE, bool PIPE>
+template <int MODE, bool RNE, bool PIPE, bool TEX>
 BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* __restrict__ depth, const uchar4* __restrict__ color,
                           int accumulate) {
     if (color == nullptr) return;
@@ -1407,7 +1408,7 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
         else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
     }
     if (wave >= n) return;
-    const __amdgpu_buffer_rsrc_t depthRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(depth), 0, (int)(c.texel ? 2u * c.bytes : c.bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t depthRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(depth), 0, (int)(TEX ? 2u * c.bytes : c.bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t colorRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uchar4*>(color), 0, (int)c.bytes, 0x00020000);
     if (!PIPE) {           // one pair at a time: one memory round trip per pair, hidden by the other waves of the SIMD only
         for (uint32_t blk = wave; blk < n; blk += nWaves) {
@@ -1415,7 +1416,7 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
             const ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
 #pragma unroll 1
             for (int z = 0; z < 8; z += 2) {
-                const ApxPair pa = apxStageA<DE, IN>(c, in, de, cur, z, depthRes, colorRes);
+                const ApxPair pa = apxStageA<DE, IN, TEX>(c, in, de, cur, z, depthRes, colorRes);
                 apxStageB<DE, IN, RNE>(c, cur, z, pa);
             }
         }
@@ -1427,7 +1428,7 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
     ApxEntry en = apxEntry<MODE>(d, wave);
     ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
     if (nextBlk < n) en = apxEntry<MODE>(d, nextBlk);
-    ApxPair pa = apxStageA<DE, IN>(c, in, de, cur, 0, depthRes, colorRes);
+    ApxPair pa = apxStageA<DE, IN, TEX>(c, in, de, cur, 0, depthRes, colorRes);
     int z = 0;
     for (;;) {
         ApxBlock nb = cur;
@@ -1443,7 +1444,7 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
             }
         }
         ApxPair pn = pa;
-        if (more) pn = apxStageA<DE, IN>(c, in, de, nb, nz, depthRes, colorRes);
+        if (more) pn = apxStageA<DE, IN, TEX>(c, in, de, nb, nz, depthRes, colorRes);
         apxStageB<DE, IN, RNE>(c, cur, z, pa);
         if (!more) break;
         cur = nb; z = nz; pa = pn;
@@ -1452,10 +1453,10 @@ BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, cons
 
 // Measured and withdrawn (gpurun r03i): the same body held to 80 SGPRs (8 workgroups per CU instead of 7; the ten spilled values are read back
 // once per block) - 92.7 vs 93.4 us per launch, inside the run-to-run spread; list entries through the scalar cache (s_load_dwordx8) - 92.8 us.
-template <int MODE, bool RNE, bool PIPE>
+template <int MODE, bool RNE, bool PIPE, bool TEX>
 __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in, ApxPose de, const float* __restrict__ depth, const uchar4* __restrict__ color,
                                                     int accumulate) {
-    updateApxBody<MODE, RNE, PIPE>(d, c, in, de, depth, color, accumulate);
+    updateApxBody<MODE, RNE, PIPE, TEX>(d, c, in, de, depth, color, accumulate);
 }
 
 // what v_cvt_pk_u8_f32 does on this device (see packByte)
@@ -1721,13 +1722,11 @@ int probeCvt(bf_scene* s) {
 
 template <int MODE>
 void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* depth, const uchar4* color, int acc) {
-    if (s->apxPipe) {
-        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
-        else hipLaunchKernelGGL((k_update_apx<MODE, false, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
-    } else {
-        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
-        else hipLaunchKernelGGL((k_update_apx<MODE, false, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc);
-    }
+#define BF_APX_LAUNCH(RNE, PIPE, TEX) hipLaunchKernelGGL((k_update_apx<MODE, RNE, PIPE, TEX>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc)
+    if (c.texel) { if (s->cvtRne) BF_APX_LAUNCH(true, false, true); else BF_APX_LAUNCH(false, false, true); }          // (the pipelined variant exists for the two-plane form only)
+    else if (s->apxPipe) { if (s->cvtRne) BF_APX_LAUNCH(true, true, false); else BF_APX_LAUNCH(false, true, false); }
+    else { if (s->cvtRne) BF_APX_LAUNCH(true, false, false); else BF_APX_LAUNCH(false, false, false); }
+#undef BF_APX_LAUNCH
 }
 
 void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepHashSDF.h:128-134
