@@ -32,7 +32,7 @@ for step in $STEPS; do
       python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" --exclude "Cijk_,at::native" | head -14
       python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 "Cijk_,at::native" > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt" ;;
     pmc)   # HBM traffic of the voxel update in the bench configuration, per arithmetic contract: two passes (FETCH_SIZE, WRITE_SIZE), then bytes per visited block
-      for A in fast exact; do
+      for A in ${PMC_CONTRACTS:-fast exact}; do
         for C in FETCH_SIZE WRITE_SIZE; do
           rm -rf /tmp/r_pmc_$C
           (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
