@@ -1459,6 +1459,153 @@ __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in,
     updateApxBody<MODE, RNE, PIPE, TEX>(d, c, in, de, depth, color, accumulate);
 }
 
+// ---------------------------------------------------------------------------------------
+// The fast update with the block's pixel footprint staged through LDS (BF_APX_LDS=1).
+//
+// What bounds k_update_apx is the CU's vector-memory path (profiles/r03_ta_tsdf_update.md): every gather of a voxel slice looks up ~25 cache
+// lines, and the eight slices of a block project onto nearly the same patch of the image, which each of them gathers again.  Here the wave
+// copies that patch ONCE per block and pose into LDS - up to three 1 KB pieces of LDS-DMA (global_load_lds_dwordx4: a lane fetches two
+// neighbouring texels, a piece is 8 rows of 16 or 4 rows of 32 texels, coalesced) - and the voxels fetch their samples from LDS.  The patch
+// is the bounding box of the block's eight corner voxels (a projective map is monotone along a line that does not cross the camera plane, so
+// the extreme pixel coordinates of the block are those of its corners); a sample outside the copied patch - a footprint larger than the
+// tile, a block that reaches behind the camera, a rounding difference at the rim - is gathered from memory as before, so the RESULT does not
+// depend on the patch at all: bit-identical to k_update_apx<.., TEX = true> (tests/test_tsdf_fast_gpu.py).
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t TILE_TEXELS = 384;          // per wave and pose: 16 x 24 or 32 x 12 texels of 8 bytes = three LDS-DMA pieces of 1 KB
+constexpr uint32_t TEXEL_SLACK = 64;           // texels allocated behind the interleaved image: a piece may read up to 31 texels past a row's end
+
+struct ApxTile { int x0, y0; uint32_t shift, rows; };        // wave-uniform: origin (x0 even), log2 of the row length, rows copied
+
+BF_DEV void apxCorner(const ApxCam& c, const ApxPose& p, const ApxCol& col, float iz, float& hx, float& hy) {
+    const float pcz = (col.zc + p.r8 * (iz * c.voxelSize)) + p.t2;
+    const float r = __builtin_amdgcn_rcpf(pcz);
+    hx = __builtin_fmaf(__builtin_fmaf(p.cx, iz, col.nx0), r, c.mxh);
+    hy = __builtin_fmaf(__builtin_fmaf(p.cy, iz, col.ny0), r, c.myh);
+}
+
+BF_DEV int cornerMin(int v) { return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 7)), min(__builtin_amdgcn_readlane(v, 56), __builtin_amdgcn_readlane(v, 63))); }
+BF_DEV int cornerMax(int v) { return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 7)), max(__builtin_amdgcn_readlane(v, 56), __builtin_amdgcn_readlane(v, 63))); }
+
+// Bounding box of the block under pose `p`, then the copy: piece k holds the texels [128 k, 128 k + 128) of the tile in row-major order, lane l
+// the two texels 128 k + 2 l and + 1 (LDS-DMA writes lane l's 16 bytes at base + 16 l: the LDS image is linear, the source address per lane).
+BF_DEV ApxTile apxStage(const ApxCam& c, const ApxPose& p, const ApxCol& col, float kz, const uint2* __restrict__ tex, uint2* tile, uint32_t lane) {
+    float ax, ay, bx, by;
+    apxCorner(c, p, col, kz, ax, ay);
+    apxCorner(c, p, col, kz + 7.0f, bx, by);
+    const int xlo = cornerMin(f2iHw(fminf(ax, bx))), xhi = min(cornerMax(f2iHw(fmaxf(ax, bx))), (int)c.W);      // (the conversion saturates: keep the differences below in range)
+    const int ylo = cornerMin(f2iHw(fminf(ay, by))), yhi = min(cornerMax(f2iHw(fmaxf(ay, by))), (int)c.H);
+    ApxTile t;
+    t.x0 = min(max(xlo, 0), (int)c.W - 2) & ~1;
+    t.y0 = min(max(ylo, 0), (int)c.H - 1);
+    t.shift = (xhi - t.x0 >= 16) ? 5u : 4u;
+    const uint32_t perPiece = 128u >> t.shift;                       // rows per piece
+    const int need = min(max(yhi - t.y0 + 1, 1), (int)(TILE_TEXELS >> t.shift));
+    const uint32_t pieces = ((uint32_t)need + perPiece - 1u) / perPiece;
+    t.rows = pieces * perPiece;
+    const uint32_t wmask = (1u << t.shift) - 1u;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        if (k < pieces) {                                            // wave-uniform
+            const uint32_t q = 2u * lane + 128u * k, row = q >> t.shift, cx = q & wmask;
+            const uint32_t y = min((uint32_t)t.y0 + row, c.H - 1u);
+            const uint2* src = tex + (__umul24(y, c.W) + (uint32_t)t.x0 + cx);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(tile + 128u * k), 16, 0, 0);
+        }
+    }
+    return t;
+}
+
+struct ApxSampleXY { v2f pcz; uint32_t pxA, pyA, pxB, pyB; bool inA, inB; };
+
+BF_DEV ApxSampleXY apxProjectXY(const ApxCam& c, const ApxPose& p, const ApxCol& col, v2f iz, v2f pz, bool use) {      // apxProject, pixel coordinates kept apart
+    ApxSampleXY o;
+    o.pcz = (sp2(col.zc) + sp2(p.r8) * pz) + sp2(p.t2);
+    const v2f nx = pkfma(sp2(p.cx), iz, sp2(col.nx0)), ny = pkfma(sp2(p.cy), iz, sp2(col.ny0));
+    v2f r; r.x = __builtin_amdgcn_rcpf(o.pcz.x); r.y = __builtin_amdgcn_rcpf(o.pcz.y);
+    const v2f hx = pkfma(nx, r, sp2(c.mxh)), hy = pkfma(ny, r, sp2(c.myh));
+    o.pxA = (uint32_t)f2iHw(hx.x); o.pyA = (uint32_t)f2iHw(hy.x); o.pxB = (uint32_t)f2iHw(hx.y); o.pyB = (uint32_t)f2iHw(hy.y);
+    o.inA = use && o.pxA < c.W && o.pyA < c.H; o.inB = use && o.pxB < c.W && o.pyB < c.H;
+    return o;
+}
+
+// the texel of pixel (px, py): from the wave's tile when it lies inside the copied rows, from memory otherwise (a lane outside the image reads 0)
+BF_DEV ApxTexel apxFetch(const ApxCam& c, const ApxTile& t, const uint2* tile, __amdgpu_buffer_rsrc_t texRes, uint32_t px, uint32_t py, bool in) {
+    const uint32_t cx = px - (uint32_t)t.x0, cy = py - (uint32_t)t.y0;
+    const bool inTile = in && cx < (1u << t.shift) && cy < t.rows;
+    const uint2 l = tile[inTile ? (cy << t.shift) + cx : 0u];
+    const bool direct = in && !inTile;
+    v2u g; g.x = 0u; g.y = 0u;
+    if (__builtin_amdgcn_ballot_w64(direct) != 0ull)                // wave-uniform: no vector-memory instruction at all in the usual case
+        g = __builtin_amdgcn_raw_buffer_load_b64(texRes, direct ? (int)((__umul24(py, c.W) + px) << 3) : -1, 0, 0);
+    ApxTexel r;
+    r.dep = __uint_as_float(inTile ? l.x : g.x); r.col = inTile ? l.y : g.y;
+    return r;
+}
+
+template <bool DE, bool IN>
+BF_DEV ApxPair apxStageALds(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, const ApxTile& tDe, const ApxTile& tIn,
+                            const uint2* tileDe, const uint2* tileIn, __amdgpu_buffer_rsrc_t texRes) {
+    ApxPair o;
+    const uint32_t* vpA = b.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
+    o.vS.x = __uint_as_float(vpA[0]); o.vW.x = __uint_as_float(vpA[1]); o.vCA = vpA[2];
+    o.vS.y = __uint_as_float(vpB[0]); o.vW.y = __uint_as_float(vpB[1]); o.vCB = vpB[2];
+    v2f iz; iz.x = b.kz + (float)z; iz.y = b.kz + (float)(z + 1);
+    const v2f pz = iz * sp2(c.voxelSize);
+    o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
+    o.inDeA = o.inDeB = o.inInA = o.inInB = false;
+    // The block's LDS-DMA pieces were issued just before its first pair.  Nothing but the issuing wave's vmcnt orders a ds_read behind a pending
+    // LDS-DMA write, and hipcc does not insert that wait here (checked in the ISA): wait once per block, after this pair's voxel loads went out.
+    if (z == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DE) {
+        const ApxSampleXY a = apxProjectXY(c, pDe, b.cDe, iz, pz, b.useDe);
+        o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
+        const ApxTexel tA = apxFetch(c, tDe, tileDe, texRes, a.pxA, a.pyA, a.inA), tB = apxFetch(c, tDe, tileDe, texRes, a.pxB, a.pyB, a.inB);
+        o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
+    }
+    if (IN) {
+        const ApxSampleXY a = apxProjectXY(c, pIn, b.cIn, iz, pz, b.useIn);
+        o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
+        const ApxTexel tA = apxFetch(c, tIn, tileIn, texRes, a.pxA, a.pyA, a.inA), tB = apxFetch(c, tIn, tileIn, texRes, a.pxB, a.pyB, a.inB);
+        o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
+    }
+    return o;
+}
+
+template <int MODE, bool RNE>
+__global__ __launch_bounds__(256) void k_update_apx_lds(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, const uchar4* __restrict__ color,
+                                                        int accumulate) {
+    if (color == nullptr) return;
+    constexpr bool DE = MODE != 0, IN = MODE != 1;
+    constexpr uint32_t NP = MODE == 2 ? 2u : 1u;
+    __shared__ __attribute__((aligned(16))) uint2 tiles[4u * NP * TILE_TEXELS];
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u) + wid, nWaves = gridDim.x * 4u;
+    if (accumulate && wave == 0 && lane == 0) {          // block accounting of the timed launches
+        if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
+        else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
+    }
+    if (wave >= n) return;
+    uint2* tileDe = tiles + wid * NP * TILE_TEXELS;
+    uint2* tileIn = tileDe + (NP - 1u) * TILE_TEXELS;
+    const __amdgpu_buffer_rsrc_t texRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(tex), 0, (int)(2u * c.bytes), 0x00020000);
+    for (uint32_t blk = wave; blk < n; blk += nWaves) {
+        ApxEntry en = apxEntry<MODE>(d, blk);
+        en.flags = __builtin_amdgcn_readfirstlane(en.flags);
+        const ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
+        ApxTile tDe, tIn;
+        tDe.x0 = tDe.y0 = tIn.x0 = tIn.y0 = 0; tDe.shift = tIn.shift = 4u; tDe.rows = tIn.rows = 0u;
+        if (DE && (en.flags & 2u)) tDe = apxStage(c, de, cur.cDe, cur.kz, tex, tileDe, lane);
+        if (IN && (en.flags & 1u)) tIn = apxStage(c, in, cur.cIn, cur.kz, tex, tileIn, lane);
+#pragma unroll 1
+        for (int z = 0; z < 8; z += 2) {
+            const ApxPair pa = apxStageALds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes);
+            apxStageB<DE, IN, RNE>(c, cur, z, pa);
+        }
+    }
+}
+
 // what v_cvt_pk_u8_f32 does on this device (see packByte)
 __global__ void k_probe_cvt(uint32_t* out) {
     const float v[8] = {0.5f, 1.5f, 2.5f, 2.7f, 254.4f, 300.0f, -3.0f, 3.49f};
@@ -1598,6 +1745,7 @@ struct bf_scene {
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
     bool apxTexel = true;           // k_update_apx gathers 8-byte {depth, colour} texels from an interleaved copy of the frame built per operator on the prep stream (BF_APX_TEXEL=0: the two planes)
     uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // one per list buffer (NB)
+    bool apxLds = false;            // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1); needs apxTexel
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
                                     // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
     int32_t* d_hashDecision = nullptr;
@@ -1723,7 +1871,11 @@ int probeCvt(bf_scene* s) {
 template <int MODE>
 void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* depth, const uchar4* color, int acc) {
 #define BF_APX_LAUNCH(RNE, PIPE, TEX) hipLaunchKernelGGL((k_update_apx<MODE, RNE, PIPE, TEX>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc)
-    if (c.texel) { if (s->cvtRne) BF_APX_LAUNCH(true, false, true); else BF_APX_LAUNCH(false, false, true); }          // (the pipelined variant exists for the two-plane form only)
+    if (c.texel && s->apxLds) {
+        const uint2* tex = reinterpret_cast<const uint2*>(depth);
+        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx_lds<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
+        else hipLaunchKernelGGL((k_update_apx_lds<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
+    } else if (c.texel) { if (s->cvtRne) BF_APX_LAUNCH(true, false, true); else BF_APX_LAUNCH(false, false, true); }          // (the pipelined variant exists for the two-plane form only)
     else if (s->apxPipe) { if (s->cvtRne) BF_APX_LAUNCH(true, true, false); else BF_APX_LAUNCH(false, true, false); }
     else { if (s->cvtRne) BF_APX_LAUNCH(true, false, false); else BF_APX_LAUNCH(false, false, false); }
 #undef BF_APX_LAUNCH
@@ -1808,7 +1960,7 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
         if (s->texelPixels < npx) {
             BF_TRY_RC(syncAll(s));
-            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
+            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], (npx + TEXEL_SLACK) * sizeof(uint2))); BF_HIP_TRY(hipMemsetAsync(s->texel[k] + npx, 0, TEXEL_SLACK * sizeof(uint2), ps)); }
             s->texelPixels = npx;
         }
         hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ps, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
@@ -1928,6 +2080,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_PIPE")) s->apxPipe = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_TEXEL")) s->apxTexel = atoi(e) != 0;
+    if (const char* e = getenv("BF_APX_LDS")) s->apxLds = atoi(e) != 0;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;

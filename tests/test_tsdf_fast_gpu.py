@@ -253,3 +253,39 @@ def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
     assert nlive > 5000000
     # pixel-boundary voxels only: a few 1e-4 of the voxels per operator, ~60 operators
     assert share(dw) < 5e-3 and share(ds > tol) < 2e-2 and share(dc > 1) < 2e-2
+
+
+@pytest.mark.parametrize("size", ["160x120@20mm", "640x480@4mm"])
+def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, size):
+    """BF_APX_LDS=1 (k_update_apx_lds: the block's pixel footprint copied once per block and pose into LDS, samples outside the copied patch
+    gathered from memory as before) must not change ONE bit of the result of the fast contract: integrations, fused re-integrations with
+    translated and rotated poses (patches of different shapes), a de-integration, GC."""
+    W, H = (160, 120) if size.startswith("160") else (640, 480)
+    voxel = 0.02 if W == 160 else 0.004
+    frames = [synth.scene_room(k * 9, W, H) for k in range(5)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=50000 if W == 160 else 400000, num_sdf_blocks=40000 if W == 160 else 120000, voxel_size=voxel)
+    dev = [_to_dev(f[0], f[1]) for f in frames]
+    out = {}
+    for lds in ("0", "1"):
+        monkeypatch.setenv("BF_APX_LDS", lds)                 # read when the scene is created
+        gs = gpu.capi.SceneRepHashSDF(p); gs.set_arith("fast"); gs.set_overlap(True)
+        poses = [f[2].copy() for f in frames]
+        for i in range(len(frames)):
+            gs.integrate(poses[i], dev[i][0], dev[i][1], cam)
+        for i in (1, 3, 4):
+            T2 = poses[i].copy(); T2[:3, 3] += np.float32(voxel) * (i + 1)
+            a = np.float32(0.02 * i); R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)     # roll about the optical axis
+            T2[:3, :3] = T2[:3, :3] @ R
+            gs.reintegrate(poses[i], T2, dev[i][0], dev[i][1], cam); poses[i] = T2
+        gs.deintegrate(poses[0], dev[0][0], dev[0][1], cam)
+        gs.garbage_collect()
+        out[lds] = gs.download()
+        assert gs.num_allocated_blocks() > (1000 if W == 160 else 20000)
+        del gs
+    (h0, heap0, c0, v0), (h1, heap1, c1, v1) = out["0"], out["1"]
+    assert c0 == c1 and np.array_equal(heap0, heap1)
+    for f in ("pos", "ptr", "offset"):
+        assert np.array_equal(h0[f], h1[f]), f
+    assert np.array_equal(v0.view(np.uint8), v1.view(np.uint8)), "%d voxels differ" % int((v0.view(np.uint8).reshape(len(v0), -1) != v1.view(np.uint8).reshape(len(v1), -1)).any(axis=1).sum())
