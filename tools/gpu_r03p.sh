@@ -3,7 +3,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/r03p; mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
 (timeout 100 python -m pytest tests/test_tsdf_fast_gpu.py -q -k "lds_staged" 2>&1 | tail -8 | tee "$OUT/pytest_lds.txt")
-for L in 1 0; do
+for L in ${LDS_LIST:-2 1 0}; do
   BF_APX_LDS=$L timeout 90 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract > "$OUT/bench_lds$L.json" 2> "$OUT/bench_lds$L.err" || tail -3 "$OUT/bench_lds$L.err"
   python -c "
 import json; j=json.load(open('$OUT/bench_lds$L.json')); r=j['roofline']; print('lds=$L bench fps %.1f launch_us %.1f frac %.3f share %.2f' % (j['value'], r['avg_launch_us'], r['frac'], r['share_of_step_time']))"
