@@ -1214,6 +1214,8 @@ struct ApxCam {
     float voxelSize, maxDist, truncScale, truncation, weightMax;
     uint32_t W, H, bytes;      // image size, bytes of one image plane (W * H * 4)
     uint32_t texel;            // 1: `depth` is an interleaved image of 8-byte texels {depth, colour} (k_interleave), `color` is only tested for null
+    uint32_t fullStores;       // 1: a voxel slice is written back by ALL lanes of the wave as soon as one of them changed its voxel (whole 768-byte rows instead of
+                               // byte-masked partial lines; the other lanes write what they read) - BF_APX_FULL_STORES, an experiment on the write path
 };
 struct ApxPose {
     float ax, bx, cx, dx;      // fx * voxelSize * (R00, R01, R02), fx * t0: numerator of the image x coordinate over the integer voxel coordinates
@@ -1344,7 +1346,8 @@ BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& 
     const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
     const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
     const bool anyA = okDeA || okInA, anyB = okDeB || okInB;
-    if (!anyA && !anyB) return;
+    const bool stA = c.fullStores ? __builtin_amdgcn_ballot_w64(anyA) != 0ull : anyA, stB = c.fullStores ? __builtin_amdgcn_ballot_w64(anyB) != 0ull : anyB;
+    if (!stA && !stB) return;
     if (DE && (okDeA || okDeB)) {           // voxelApply<true>
         const v2f dd = vW - sp2(1.0f);
         v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
@@ -1382,8 +1385,8 @@ BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& 
         if (okInA) { vS.x = s.x; vW.x = fminf(c.weightMax, dd.x); vCA = nA; }
         if (okInB) { vS.y = s.y; vW.y = fminf(c.weightMax, dd.y); vCB = nB; }
     }
-    if (anyA) { vpA[0] = __float_as_uint(vS.x); vpA[1] = __float_as_uint(vW.x); vpA[2] = vCA; }
-    if (anyB) { vpB[0] = __float_as_uint(vS.y); vpB[1] = __float_as_uint(vW.y); vpB[2] = vCB; }
+    if (stA) { vpA[0] = __float_as_uint(vS.x); vpA[1] = __float_as_uint(vW.x); vpA[2] = vCA; }
+    if (stB) { vpB[0] = __float_as_uint(vS.y); vpB[1] = __float_as_uint(vW.y); vpB[2] = vCB; }
 }
 
 struct ApxEntry { int4 e; uint32_t flags; };
@@ -1776,6 +1779,7 @@ struct bf_scene {
     bool apxTexel = true;           // k_update_apx gathers 8-byte {depth, colour} texels from an interleaved copy of the frame built per operator on the prep stream (BF_APX_TEXEL=0: the two planes)
     uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // one per list buffer (NB)
     int apxLds = 0;                 // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1; 2: + all voxel slices of the block loaded up front); needs apxTexel
+    bool apxFullStores = false;     // see ApxCam::fullStores (BF_APX_FULL_STORES=1)
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
                                     // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
     int32_t* d_hashDecision = nullptr;
@@ -1861,7 +1865,7 @@ ApxCam makeApxCam(const Frame& f) {
     ApxCam u;
     u.mxh = f.cam.mx + 0.5f; u.myh = f.cam.my + 0.5f;
     u.voxelSize = f.voxelSize; u.maxDist = f.maxIntegrationDistance; u.truncScale = f.truncScale; u.truncation = f.truncation; u.weightMax = f.weightMax;
-    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight; u.bytes = u.W * u.H * 4u; u.texel = 0u;
+    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight; u.bytes = u.W * u.H * 4u; u.texel = 0u; u.fullStores = 0u;
     return u;
 }
 ApxPose makeApxPose(const Frame& f) {
@@ -2018,6 +2022,7 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     if (s->arith == BF_TSDF_ARITH_FAST) {
         ApxCam ac = makeApxCam(f);
         ac.texel = useTexel ? 1u : 0u;
+        ac.fullStores = s->apxFullStores ? 1u : 0u;
         const float* src = useTexel ? reinterpret_cast<const float*>(s->texel[b]) : data->d_depthData;
         const ApxPose pin = makeApxPose(f), pde = makeApxPose(kind == 2 ? fo : f);
         if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, src, color, acc);
@@ -2113,6 +2118,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_APX_PIPE")) s->apxPipe = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_TEXEL")) s->apxTexel = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_LDS")) s->apxLds = atoi(e);
+    if (const char* e = getenv("BF_APX_FULL_STORES")) s->apxFullStores = atoi(e) != 0;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;

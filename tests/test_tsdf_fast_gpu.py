@@ -255,7 +255,7 @@ def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
     assert share(dw) < 5e-3 and share(ds > tol) < 2e-2 and share(dc > 1) < 2e-2
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "full-stores"])
 @pytest.mark.parametrize("size", ["160x120@20mm", "640x480@4mm"])
 def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, size, variant):
     """BF_APX_LDS=1 (k_update_apx_lds: the block's pixel footprint copied once per block and pose into LDS, samples outside the copied patch
@@ -270,7 +270,8 @@ def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, s
     dev = [_to_dev(f[0], f[1]) for f in frames]
     out = {}
     for lds in ("0", variant):
-        monkeypatch.setenv("BF_APX_LDS", lds)                 # read when the scene is created
+        monkeypatch.setenv("BF_APX_LDS", lds if lds.isdigit() else "0")                 # both read when the scene is created
+        monkeypatch.setenv("BF_APX_FULL_STORES", "1" if lds == "full-stores" else "0")  # (whole voxel rows written back: an experiment on the write path)
         gs = gpu.capi.SceneRepHashSDF(p); gs.set_arith("fast"); gs.set_overlap(True)
         poses = [f[2].copy() for f in frames]
         for i in range(len(frames)):
