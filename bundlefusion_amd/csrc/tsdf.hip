@@ -1289,6 +1289,7 @@ BF_DEV ApxBlock apxBlock(const Dev& d, const ApxCam& c, const ApxPose& pIn, cons
 // depth and colour of one pixel: two 4-byte gathers from the two planes, or ONE 8-byte gather from the interleaved image the prep stream
 // builds per operator (k_interleave) - half the vector-memory instructions of a kernel that sits on the CU's memory pipeline
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v3u __attribute__((ext_vector_type(3)));
 struct ApxTexel { float dep; uint32_t col; };
 template <bool TEX>
 BF_DEV ApxTexel apxGather(__amdgpu_buffer_rsrc_t depthRes, __amdgpu_buffer_rsrc_t colorRes, uint32_t off) {
@@ -1555,7 +1556,8 @@ BF_DEV ApxTexel apxFetchRest(const ApxCam& c, ApxFetch f, __amdgpu_buffer_rsrc_t
 template <bool DE, bool IN>
 BF_DEV void apxSamplesLds(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, const ApxTile& tDe, const ApxTile& tIn,
                           const uint2* tileDe, const uint2* tileIn, __amdgpu_buffer_rsrc_t texRes, ApxPair& o) {
-    v2f iz; iz.x = b.kz + (float)z; iz.y = b.kz + (float)(z + 1);
+    const int zz = z & 7;                                             // z >= 8: a second pass over the pair (z - 8), no LDS-DMA pending
+    v2f iz; iz.x = b.kz + (float)zz; iz.y = b.kz + (float)(zz + 1);
     const v2f pz = iz * sp2(c.voxelSize);
     o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
     o.inDeA = o.inDeB = o.inInA = o.inInB = false;
@@ -1581,9 +1583,23 @@ BF_DEV void apxSamplesLds(const ApxCam& c, const ApxPose& pIn, const ApxPose& pD
     }
 }
 
-// PRE: all eight voxel slices of the block are loaded together with the LDS-DMA pieces - ONE memory round trip per block instead of one per
+// which voxels of a pair have a valid sample (the conditions of apxStageB, on the same values)
+template <bool DE, bool IN>
+BF_DEV void apxTouched(const ApxCam& c, const ApxPair& a, bool& anyA, bool& anyB) {
+    const v2f sDe = a.dDe - a.pczDe, sIn = a.dIn - a.pczIn;
+    const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * a.dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * a.dIn;
+    const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
+    const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
+    anyA = okDeA || okInA; anyB = okDeB || okInB;
+}
+
+// PRE 1: all eight voxel slices of the block are loaded together with the LDS-DMA pieces - ONE memory round trip per block instead of one per
 // voxel pair (the samples come from LDS, so nothing else a pair needs is in memory); 24 more VGPRs.
-template <int MODE, bool RNE, bool PRE>
+// PRE 2: as 1, but only the slices that hold a voxel with a valid sample are loaded at all.  Whether a voxel is touched depends on its sample
+// alone, not on the voxel: a first pass over the block's pairs (projection + LDS reads, no memory) collects one bit per slice, the loads of the
+// set bits go out together, a second pass repeats the sampling and updates.  About 2.5 of a block's 8 slices are untouched by any lane
+// (5.5 store instructions per block, profiles/r03_ta_tsdf_update.md) - 30 % of the voxel bytes read by the other forms of the kernel.
+template <int MODE, bool RNE, int PRE>
 __global__ __launch_bounds__(256) void k_update_apx_lds(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, const uchar4* __restrict__ color,
                                                         int accumulate) {
     if (color == nullptr) return;
@@ -1610,7 +1626,38 @@ __global__ __launch_bounds__(256) void k_update_apx_lds(Dev d, ApxCam c, ApxPose
         tDe.x0 = tDe.y0 = tIn.x0 = tIn.y0 = 0; tDe.shift = tIn.shift = 4u; tDe.rows = tIn.rows = 0u;
         if (DE && (en.flags & 2u)) tDe = apxStage(c, de, cur.cDe, cur.kz, tex, tileDe, lane);
         if (IN && (en.flags & 1u)) tIn = apxStage(c, in, cur.cIn, cur.kz, tex, tileIn, lane);
-        if (PRE) {
+        if (PRE == 2) {
+            uint32_t need = 0u;                                     // wave-uniform: bit z = slice z holds a voxel with a valid sample
+#pragma unroll
+            for (int z = 0; z < 8; z += 2) {
+                ApxPair pa;
+                pa.vS = pa.vW = sp2(0.0f); pa.vCA = pa.vCB = 0u;
+                apxSamplesLds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes, pa);
+                bool anyA, anyB;
+                apxTouched<DE, IN>(c, pa, anyA, anyB);
+                if (__builtin_amdgcn_ballot_w64(anyA) != 0ull) need |= 1u << z;
+                if (__builtin_amdgcn_ballot_w64(anyB) != 0ull) need |= 2u << z;
+            }
+            // the slices through a descriptor of the BLOCK (6 KB): a slice that is not needed gets an offset beyond it - the load returns 0 without a
+            // memory access, and no branch (with its wait at the join) separates the eight loads
+            const bf_voxel* blockBase = d.vox + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)en.e.w);
+            const __amdgpu_buffer_rsrc_t voxRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf_voxel*>(blockBase), 0, (int)(512u * sizeof(bf_voxel)), 0x00020000);
+            uint32_t vv[8][3];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const v3u t = __builtin_amdgcn_raw_buffer_load_b96(voxRes, (need & (1u << z)) ? (int)(lane * 12u + (uint32_t)z * 768u) : -1, 0, 0);      // (the range check covers the VGPR offset only)
+                vv[z][0] = t.x; vv[z][1] = t.y; vv[z][2] = t.z;
+            }
+#pragma unroll
+            for (int z = 0; z < 8; z += 2) {
+                if ((need & (3u << z)) == 0u) continue;
+                ApxPair pa;
+                pa.vS.x = __uint_as_float(vv[z][0]); pa.vW.x = __uint_as_float(vv[z][1]); pa.vCA = vv[z][2];
+                pa.vS.y = __uint_as_float(vv[z + 1][0]); pa.vW.y = __uint_as_float(vv[z + 1][1]); pa.vCB = vv[z + 1][2];
+                apxSamplesLds<DE, IN>(c, in, de, cur, z + 8, tDe, tIn, tileDe, tileIn, texRes, pa);      // (z + 8: see apxSamplesLds - the DMA wait belongs to the first pass)
+                apxStageB<DE, IN, RNE>(c, cur, z, pa);
+            }
+        } else if (PRE == 1) {
             uint32_t vv[8][3];
 #pragma unroll
             for (int z = 0; z < 8; ++z) {
@@ -1778,7 +1825,7 @@ struct bf_scene {
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
     bool apxTexel = true;           // k_update_apx gathers 8-byte {depth, colour} texels from an interleaved copy of the frame built per operator on the prep stream (BF_APX_TEXEL=0: the two planes)
     uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // one per list buffer (NB)
-    int apxLds = 0;                 // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1; 2: + all voxel slices of the block loaded up front); needs apxTexel
+    int apxLds = 0;                 // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1; 2: + all voxel slices of the block loaded up front; 3: + only the slices some lane touches); needs apxTexel
     bool apxFullStores = false;     // see ApxCam::fullStores (BF_APX_FULL_STORES=1)
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
                                     // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
@@ -1908,8 +1955,9 @@ void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const
     if (c.texel && s->apxLds) {
         const uint2* tex = reinterpret_cast<const uint2*>(depth);
 #define BF_APX_LDS_LAUNCH(RNE, PRE) hipLaunchKernelGGL((k_update_apx_lds<MODE, RNE, PRE>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc)
-        if (s->apxLds >= 2) { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, true); else BF_APX_LDS_LAUNCH(false, true); }
-        else { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, false); else BF_APX_LDS_LAUNCH(false, false); }
+        if (s->apxLds >= 3) { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, 2); else BF_APX_LDS_LAUNCH(false, 2); }
+        else if (s->apxLds == 2) { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, 1); else BF_APX_LDS_LAUNCH(false, 1); }
+        else { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, 0); else BF_APX_LDS_LAUNCH(false, 0); }
 #undef BF_APX_LDS_LAUNCH
     } else if (c.texel) { if (s->cvtRne) BF_APX_LAUNCH(true, false, true); else BF_APX_LAUNCH(false, false, true); }          // (the pipelined variant exists for the two-plane form only)
     else if (s->apxPipe) { if (s->cvtRne) BF_APX_LAUNCH(true, true, false); else BF_APX_LAUNCH(false, true, false); }

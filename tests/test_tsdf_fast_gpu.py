@@ -255,12 +255,12 @@ def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
     assert share(dw) < 5e-3 and share(ds > tol) < 2e-2 and share(dc > 1) < 2e-2
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "full-stores"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "full-stores"])
 @pytest.mark.parametrize("size", ["160x120@20mm", "640x480@4mm"])
 def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, size, variant):
     """BF_APX_LDS=1 (k_update_apx_lds: the block's pixel footprint copied once per block and pose into LDS, samples outside the copied patch
     gathered from memory as before) must not change ONE bit of the result of the fast contract: integrations, fused re-integrations with
-    translated and rotated poses (patches of different shapes), a de-integration, GC.  Variant 2 also loads all eight voxel slices of a block up front."""
+    translated and rotated poses (patches of different shapes), a de-integration, GC.  Variant 2 also loads all eight voxel slices of a block up front, variant 3 only the slices some lane has a valid sample for."""
     W, H = (160, 120) if size.startswith("160") else (640, 480)
     voxel = 0.02 if W == 160 else 0.004
     frames = [synth.scene_room(k * 9, W, H) for k in range(5)]
