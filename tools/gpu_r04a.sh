@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # round 4, first GPU call: variants prepared at the end of round 3 WITHOUT GPU time left to run them.
-#   BF_KABSCH_LANES=1   greedy Kabsch filter with the moment sums of every fit spread over lanes (bit-identical by construction; never run)
+#   BF_KABSCH_LANES=1   greedy Kabsch filter with the moment sums of every fit spread over lanes (bit-identical by construction; the chain test
+#                       passed on the GPU in the last seconds of round 3, the kernel has not been TIMED)
 # The whole GPU suite first (the parametrised chain test covers the new path), then the driver's bench with and without the variant.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/r04a; mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
