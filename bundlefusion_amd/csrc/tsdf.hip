@@ -1463,6 +1463,77 @@ __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in,
     updateApxBody<MODE, RNE, PIPE, TEX>(d, c, in, de, depth, color, accumulate);
 }
 
+// which voxels of a pair have a valid sample (the conditions of apxStageB, on the same values)
+template <bool DE, bool IN>
+BF_DEV void apxTouched(const ApxCam& c, const ApxPair& a, bool& anyA, bool& anyB) {
+    const v2f sDe = a.dDe - a.pczDe, sIn = a.dIn - a.pczIn;
+    const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * a.dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * a.dIn;
+    const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
+    const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
+    anyA = okDeA || okInA; anyB = okDeB || okInB;
+}
+
+// ---------------------------------------------------------------------------------------
+// The fast update with the voxel loads DEFERRED behind the samples (BF_APX_DEFER=1; prepared at the end of round 3, not yet timed).
+//
+// Whether a voxel is touched depends on its sample alone (apxTouched), and about 2.5 of a block's 8 slices are touched by no lane at all
+// (5.5 store instructions per block) - yet k_update_apx reads every slice, speculatively, together with the samples: 30 % of the voxel bytes
+// it reads, on a kernel that runs at the memory system's streaming rate (profiles/r03_lds_footprint.md).  Here a pair's samples are gathered
+// first, and its two slices are loaded only when some lane of the wave has a valid sample for one of them: two dependent round trips per touched
+// pair instead of one, no memory access at all for an untouched pair.  Same values, same operations: bit-identical to k_update_apx.
+// ---------------------------------------------------------------------------------------
+template <bool DE, bool IN>
+BF_DEV void apxSamplesTex(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, __amdgpu_buffer_rsrc_t texRes, ApxPair& o) {
+    v2f iz; iz.x = b.kz + (float)z; iz.y = b.kz + (float)(z + 1);
+    const v2f pz = iz * sp2(c.voxelSize);
+    o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
+    o.inDeA = o.inDeB = o.inInA = o.inInB = false;
+    if (DE) {
+        const ApxSample a = apxProject(c, pDe, b.cDe, iz, pz, b.useDe);
+        o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
+        const ApxTexel tA = apxGather<true>(texRes, texRes, a.offA), tB = apxGather<true>(texRes, texRes, a.offB);
+        o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
+    }
+    if (IN) {
+        const ApxSample a = apxProject(c, pIn, b.cIn, iz, pz, b.useIn);
+        o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
+        const ApxTexel tA = apxGather<true>(texRes, texRes, a.offA), tB = apxGather<true>(texRes, texRes, a.offB);
+        o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
+    }
+}
+
+template <int MODE, bool RNE>
+__global__ __launch_bounds__(256) void k_update_apx_defer(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, const uchar4* __restrict__ color,
+                                                          int accumulate) {
+    if (color == nullptr) return;
+    constexpr bool DE = MODE != 0, IN = MODE != 1;
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), nWaves = gridDim.x * 4u;
+    if (accumulate && wave == 0 && lane == 0) {          // block accounting of the timed launches
+        if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
+        else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
+    }
+    if (wave >= n) return;
+    const __amdgpu_buffer_rsrc_t texRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(tex), 0, (int)(2u * c.bytes), 0x00020000);
+    for (uint32_t blk = wave; blk < n; blk += nWaves) {
+        const ApxEntry en = apxEntry<MODE>(d, blk);
+        const ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
+#pragma unroll 1
+        for (int z = 0; z < 8; z += 2) {
+            ApxPair pa;
+            apxSamplesTex<DE, IN>(c, in, de, cur, z, texRes, pa);
+            bool anyA, anyB;
+            apxTouched<DE, IN>(c, pa, anyA, anyB);
+            if (__builtin_amdgcn_ballot_w64(anyA || anyB) == 0ull) continue;          // wave-uniform: nothing of this pair is read or written
+            const uint32_t* vpA = cur.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
+            pa.vS.x = __uint_as_float(vpA[0]); pa.vW.x = __uint_as_float(vpA[1]); pa.vCA = vpA[2];
+            pa.vS.y = __uint_as_float(vpB[0]); pa.vW.y = __uint_as_float(vpB[1]); pa.vCB = vpB[2];
+            apxStageB<DE, IN, RNE>(c, cur, z, pa);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // The fast update with the block's pixel footprint staged through LDS (BF_APX_LDS=1).
 //
@@ -1581,16 +1652,6 @@ BF_DEV void apxSamplesLds(const ApxCam& c, const ApxPose& pIn, const ApxPose& pD
         const ApxTexel tA = apxFetchRest(c, fInA, texRes, aIn.pxA, aIn.pyA), tB = apxFetchRest(c, fInB, texRes, aIn.pxB, aIn.pyB);
         o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
     }
-}
-
-// which voxels of a pair have a valid sample (the conditions of apxStageB, on the same values)
-template <bool DE, bool IN>
-BF_DEV void apxTouched(const ApxCam& c, const ApxPair& a, bool& anyA, bool& anyB) {
-    const v2f sDe = a.dDe - a.pczDe, sIn = a.dIn - a.pczIn;
-    const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * a.dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * a.dIn;
-    const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
-    const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
-    anyA = okDeA || okInA; anyB = okDeB || okInB;
 }
 
 // PRE 1: all eight voxel slices of the block are loaded together with the LDS-DMA pieces - ONE memory round trip per block instead of one per
@@ -1827,6 +1888,7 @@ struct bf_scene {
     uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // one per list buffer (NB)
     int apxLds = 0;                 // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1; 2: + all voxel slices of the block loaded up front; 3: + only the slices some lane touches); needs apxTexel
     bool apxFullStores = false;     // see ApxCam::fullStores (BF_APX_FULL_STORES=1)
+    bool apxDefer = false;          // k_update_apx_defer: voxel slices loaded only behind a valid sample (BF_APX_DEFER=1); needs apxTexel
     bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
                                     // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
     int32_t* d_hashDecision = nullptr;
@@ -1952,7 +2014,11 @@ int probeCvt(bf_scene* s) {
 template <int MODE>
 void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* depth, const uchar4* color, int acc) {
 #define BF_APX_LAUNCH(RNE, PIPE, TEX) hipLaunchKernelGGL((k_update_apx<MODE, RNE, PIPE, TEX>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc)
-    if (c.texel && s->apxLds) {
+    if (c.texel && s->apxDefer) {
+        const uint2* tex = reinterpret_cast<const uint2*>(depth);
+        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx_defer<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
+        else hipLaunchKernelGGL((k_update_apx_defer<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
+    } else if (c.texel && s->apxLds) {
         const uint2* tex = reinterpret_cast<const uint2*>(depth);
 #define BF_APX_LDS_LAUNCH(RNE, PRE) hipLaunchKernelGGL((k_update_apx_lds<MODE, RNE, PRE>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc)
         if (s->apxLds >= 3) { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, 2); else BF_APX_LDS_LAUNCH(false, 2); }
@@ -2167,6 +2233,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_APX_TEXEL")) s->apxTexel = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_LDS")) s->apxLds = atoi(e);
     if (const char* e = getenv("BF_APX_FULL_STORES")) s->apxFullStores = atoi(e) != 0;
+    if (const char* e = getenv("BF_APX_DEFER")) s->apxDefer = atoi(e) != 0;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;

@@ -5,7 +5,14 @@
 # The whole GPU suite first (the parametrised chain test covers the new path), then the driver's bench with and without the variant.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/r04a; mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
+#   BF_APX_DEFER=1      fast voxel update with a pair's voxel loads issued only behind a valid sample (k_update_apx_defer; bit-identical by construction; NEVER RUN)
 (timeout 200 python -m pytest tests/test_match_gpu.py -q 2>&1 | tail -6 | tee "$OUT/pytest_match.txt")
+(BF_TEST_UNVERIFIED=1 timeout 200 python -m pytest tests/test_tsdf_fast_gpu.py -q -k "lds_staged and defer" 2>&1 | tail -6 | tee "$OUT/pytest_defer.txt")
+for L in 1 0; do
+  BF_APX_DEFER=$L timeout 120 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract > "$OUT/bench_defer$L.json" 2> "$OUT/bench_defer$L.err" || tail -3 "$OUT/bench_defer$L.err"
+  python -c "
+import json; j=json.load(open('$OUT/bench_defer$L.json')); r=j['roofline']; print('defer=$L bench fps %.1f launch_us %.1f frac %.3f share %.2f' % (j['value'], r['avg_launch_us'], r['frac'], r['share_of_step_time']))"
+done
 for L in 1 0; do
   BF_KABSCH_LANES=$L timeout 120 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract > "$OUT/bench_kabsch$L.json" 2> "$OUT/bench_kabsch$L.err" || tail -3 "$OUT/bench_kabsch$L.err"
   python -c "
