@@ -69,12 +69,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     W, H = 640, 480
     pre = args.preroll + args.warmup
-    if world > 1 and args.mode in ("auto", "chunks"):
+    if (world > 1 and args.mode == "auto") or args.mode == "chunks":
         # chunk-parallel mode: a round is world * 10 frames (frames r*world*10 + 1 .. (r+1)*world*10).  The timed window starts at a round
         # boundary, so that it contains this round's all-gather and - running ahead on the second host thread - the whole local half of
         # the next round (SIFT, local matching, local solve, key-frame fusion of one chunk per rank), not only the replicated global half.
-        rnd = world * 10
-        pre = ((pre - 1 + rnd - 1) // rnd) * rnd + 1
+        from bundlefusion_amd.shard import timed_window
+        pre = timed_window(pre, args.steps, world)[0]
     total = pre + args.steps
 
     # synthetic stream, rendered by plain-python subprocesses before HIP is initialised
@@ -88,10 +88,11 @@ def main():
     one_stream = shard_volume or mode == "serial" or world == 1
     first = 0 if one_stream else segment(rank, world, total)[0]   # segments: each rank its own contiguous part of the S2 loop
     n_render = total
-    if chunked:                     # the last round of `world` chunks must be complete (its local halves run before the all-gather)
-        S0 = 10
-        last_chunk = 0 if total <= 1 else (total - 2) // S0
-        n_render = ((last_chunk // world + 1) * world) * S0 + 1
+    if chunked:
+        # the last round of `world` chunks must be complete (its local halves run before the all-gather), and the stream continues for ONE MORE
+        # round, whose chunk-local halves (SIFT, matching inside the chunk, local solve, key-frame fusion) run inside the timed window: shard.timed_window
+        from bundlefusion_amd.shard import timed_window
+        n_render = timed_window(pre, args.steps, world)[2]
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -195,6 +196,7 @@ def main():
         pipe.host_profile(reset=True)
         torch.cuda.synchronize()
         rounds0 = runner.rounds if chunked else 0
+        chunks0 = runner.local_runs if chunked else 0
         t0 = time.perf_counter()
         if chunked:
             runner.advance(args.steps)
@@ -215,8 +217,10 @@ def main():
         sc.kernel_timing(False)
         L["elapsed"] = max_over_ranks(elapsed, "cuda")
         L["rounds"] = (runner.rounds - rounds0) if chunked else 0
-        if chunked and L["rounds"] == 0:
-            raise RuntimeError("the timed window holds no round of the chunk-parallel schedule (no local half, no all-gather): not a whole-loop measurement")
+        L["local_chunks"] = (runner.local_runs - chunks0) if chunked else 0
+        if chunked and (L["rounds"] == 0 or L["local_chunks"] == 0):
+            raise RuntimeError("the timed window holds no round of the chunk-parallel schedule (all-gathers %d, chunk-local halves run on this rank %d): not a "
+                               "whole-loop measurement" % (L["rounds"], L["local_chunks"]))
         if shard_volume and world > 1:      # the replicated global half must have produced ONE trajectory (bit-identical on every rank): RCCL MIN/MAX all-reduce
             traj_dev = torch.from_numpy(np.nan_to_num(pipe.integrated_trajectory(), neginf=-1e30)).cuda()
             assert same_over_ranks(traj_dev), "ranks disagree on the trajectory"
@@ -298,7 +302,10 @@ def main():
                 "frame_loop": "serial order, detection of frame k+1 overlapped with matching/solve of frame k (BF_PIPELINE_LOOKAHEAD=%s)"
                               % os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
                 "parallelism": ("one stream: local chunks round-robin over %d ranks, %d RCCL all-gathers of key-frame packages in the timed region, global half "
-                                "replicated, volume sharded by hash-bucket range" % (world, main_leg["rounds"])) if chunked
+                                "replicated, volume sharded by hash-bucket range; the timed window holds the global half of its %d frames and, on every rank, "
+                                "the chunk-local half of ONE whole chunk of the next round (%d of them ran here) - the steady state when steps == 10 x ranks, "
+                                "more local work per frame than the steady state when steps is smaller"
+                                % (world, main_leg["rounds"], args.steps, main_leg["local_chunks"])) if chunked
                                else ("one stream, bundling replicated on %d ranks, volume sharded by hash-bucket range" % world) if (shard_volume and world > 1)
                                else "one GPU, serial frame loop" if world == 1 else "stream segments sharded over %d rank(s), no data-path collective" % world,
                 "mode": mode,

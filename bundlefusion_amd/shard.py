@@ -26,6 +26,20 @@ def chunk_frames(chunk, submap):
     return chunk * submap, chunk * submap + submap
 
 
+def timed_window(preroll, steps, world, submap=10):
+    """Frame counts of a measurement over the chunk-parallel mode: (pre, total, stream_length).
+
+    `pre` untimed frames (>= preroll, rounded up so that the timed window starts exactly at a round boundary: frame 0 + whole rounds of
+    world * submap frames), `total` = pre + steps, and the stream length the runner needs.  The local half of round R + 1 runs while round R goes
+    through the global half, so the stream must hold one round MORE than the one the window ends in - otherwise a timed window contains the
+    replicated global half and the volume only (the local halves of its own round ran before it started)."""
+    rnd = world * submap
+    pre = ((max(preroll, 1) - 1 + rnd - 1) // rnd) * rnd + 1
+    total = pre + steps
+    last_chunk = (total - 2) // submap
+    return pre, total, ((last_chunk // world + 2) * world) * submap + 1
+
+
 def gather_packages(mine, world, rank, device=None):
     """All-gather of one round of chunk packages: `mine` (uint8 numpy array, zeros when this rank had no chunk in the round) ->
     list of `world` arrays indexed by owner rank.  One collective per round; identity for world == 1."""
@@ -57,7 +71,8 @@ class ChunkedRunner:
         self.next_frame = 0
         self.pkgs = {}
         self.rounds = 0
-        self.local_chunks = 0
+        self.local_chunks = 0           # packages of this rank handed to an all-gather
+        self.local_runs = 0             # chunk-local halves this rank has RUN (counted when the run finishes, on whichever thread ran it)
         # the local half of this rank's chunk of the NEXT round runs on a second host thread (own handles, own stream) while the main
         # thread pushes the current round through the global half; collectives stay on the main thread
         self.prefetch = prefetch
@@ -85,6 +100,7 @@ class ChunkedRunner:
             if b < len(self.feed):
                 self.worker.run(c_mine, self.feed[a:b + 1], out=out)
                 produced.append(c_mine)
+                self.local_runs += 1
         except BaseException as e:           # raised again on the main thread when the package is needed (wait / _ensure)
             produced.append(e)
 

@@ -485,6 +485,41 @@ def test_chunked_runner_local_half_runs_ahead_and_fails_loudly():
     assert max(f for f, _, _ in r.pipe.log) <= 2 * S         # nothing of chunk 2 was consumed
 
 
+def test_timed_window_of_the_chunk_parallel_mode_contains_chunk_local_work():
+    """bench.py's window over the chunk-parallel mode (shard.timed_window): it starts at a round boundary, and the stream is long enough for the
+    local halves of the NEXT round to run inside it - a window over the replicated global half alone would not be a whole-loop measurement."""
+    import numpy as np
+    from bundlefusion_amd.shard import ChunkedRunner, timed_window, chunk_frames
+    S = 10
+    for world in (1, 2, 4, 8):
+        for steps in (20, 200):
+            pre, total, n = timed_window(205, steps, world, S)
+            rnd = world * S
+            assert pre >= 205 and (pre - 1) % rnd == 0 and total == pre + steps
+            first_round = (pre - 1) // S                               # first chunk of the round the window starts with
+            last_round = ((total - 2) // S) // world * world           # ... and of the round it ends in
+            for rank in range(world):                                  # every rank's chunk of the round behind the last one is in the stream
+                assert chunk_frames(last_round + world + rank, S)[1] < n
+            assert first_round % world == 0
+
+    class Worker:
+        package_bytes = 16
+        def __init__(self): self.ran = []
+        def run(self, chunk, frames, out=None):
+            out[:4].view(np.int32)[0] = chunk; self.ran.append(chunk)
+
+    class Pipe:
+        def process_frame_chunked(self, d, c, pkg, j): return True
+
+    pre, total, n = timed_window(205, 20, 1, S)
+    r = ChunkedRunner(Pipe(), Worker(), [(i, i) for i in range(n)], S)
+    r.advance(pre); r.wait()
+    runs0, rounds0 = r.local_runs, r.rounds
+    r.advance(20); r.wait()
+    assert r.local_runs - runs0 == 2 and r.rounds - rounds0 == 2       # world 1, 20 frames = two rounds: two all-gathers, two local halves - the steady state
+    r.close()
+
+
 def test_processed_summary_file(built, tmp_path):
     """processed.txt as StopScanningAndExit writes it (DepthSensing.cpp:921-957): the validity rule and the four lines."""
     from bundlefusion_amd.capi import write_processed_summary
