@@ -712,12 +712,12 @@ __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
         for (int i = 0; i < n; ++i) t[i] = px[i]; mx = warpTree32(t, n);
         for (int i = 0; i < n; ++i) t[i] = py[i]; my = warpTree32(t, n);
         mx /= (float)n; my /= (float)n;
-        float c00, c01, c10, c11;
+        float c00, c01, c10, c11;                     // (c10 is accumulated like in the reference and, like there, never read)
         for (int i = 0; i < n; ++i) { const float u = px[i] - mx; t[i] = u * u; } c00 = warpTree32(t, n);
         for (int i = 0; i < n; ++i) { const float u = px[i] - mx, v = py[i] - my; t[i] = u * v; } c01 = warpTree32(t, n);
         for (int i = 0; i < n; ++i) { const float u = px[i] - mx, v = py[i] - my; t[i] = v * u; } c10 = warpTree32(t, n);
         for (int i = 0; i < n; ++i) { const float v = py[i] - my; t[i] = v * v; } c11 = warpTree32(t, n);
-        c00 /= (float)n; c01 /= (float)n; c10 /= (float)n; c11 /= (float)n;
+        c00 /= (float)n; c01 /= (float)n; c10 /= (float)n; c11 /= (float)n; (void)c10;
         const float disc = 0.5f * sqrtf((c00 - c11) * (c00 - c11) + 4 * c01 * c01);
         const float l1 = (c00 + c11) / 2 + disc, l2 = (c00 + c11) / 2 - disc;
         float a0x = -c01, a0y = c00 - l1, a1x = -c01, a1y = c00 - l2;

@@ -472,7 +472,6 @@ BF_DEV void placeBin(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch
     // blocks this pass may hand out: the free heap blocks, but never more than the allocated-block list can still record (holes left by
     // exhausted collision windows are compacted only by GC, so live + holes can reach the list capacity before the heap is empty)
     const uint32_t heapFree = min(heapC + 1u, f.numSDFBlocks - min(allocBase, f.numSDFBlocks));
-    uint4* h4 = reinterpret_cast<uint4*>(d.hash);
     // phase 1 (reads only): rank among the bin's new keys of the same home bucket -> free slot
     for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
         const uint32_t h = s.bucket[idx];
