@@ -62,11 +62,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the stream the CPU baseline processes (three local chunks: the last ten frames "
                     "run with the re-integration queue saturated, like the timed window of the GPU leg)")
+    ap.add_argument("--launch-check", action="store_true", help="(CPU test of the launch path) rendezvous over gloo, print the world size, exit")
     args = ap.parse_args()
 
+    plan = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if plan is not None:
+        # `python bench.py --gpus N` without a launcher around it: start the N ranks here (one process per GPU, torch.distributed.run on
+        # 127.0.0.1) instead of silently measuring one GPU.  Rank 0 of the children prints the JSON line; this process only forwards it.
+        import subprocess
+        sys.exit(subprocess.call(plan))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): no line is printed for a mismatched run" % (args.gpus, world))
+    if args.launch_check:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            import torch
+            t = torch.ones(1); dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world}))
+        return
     W, H = 640, 480
     pre = args.preroll + args.warmup
     if (world > 1 and args.mode == "auto") or args.mode == "chunks":
@@ -325,6 +345,19 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_plan(gpus, env, argv):
+    """The command that starts `gpus` ranks of this script, or None when this process already is one of them (a launcher set WORLD_SIZE) or
+    one GPU is asked for.  The driver launches N > 1 itself (torch.distributed.run); a bare `python bench.py --gpus N` gets the same launch."""
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def pmc_config(args):

@@ -203,7 +203,7 @@ class SceneRepHashSDF:
         check(lib.bf_scene_alloc_sync(self._h))
 
     def set_arith(self, mode):
-        """'exact' (IEEE op by op, default) or 'fast' (the reference GPU build's -use_fast_math contract): bf_scene_set_arith"""
+        """'fast' (the reference GPU build's -use_fast_math contract; library default) or 'exact' (IEEE op by op, bit-comparable with the oracle): bf_scene_set_arith"""
         check(lib.bf_scene_set_arith(self._h, {"exact": 0, "fast": 1}[mode]))
 
     def arith(self):

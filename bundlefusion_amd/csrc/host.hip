@@ -1558,8 +1558,6 @@ struct bf_pipeline {
     // first call that needs its result).  The per-frame work and its order are unchanged, so are the results.
     hipStream_t sDetect = nullptr;
     bool lookahead = true;
-    bool earlyChain = false;        // BF_PIPELINE_EARLY_CHAIN=1: enqueue a frame's matching chain in the call that delivers the frame instead of at the start of the next
-                                    // one.  Measured: no gain (650 / 656 vs 658 / 652 frames/s, gpurun r03j) - the chain is bound by its own GPU latency under the volume's load
     int deferred = -1;              // frame whose body has not run yet
     bool deferredBegun = false;     // ... but whose matching chain is already enqueued (plBodyBegin ran in the call that delivered it)
     static const int NEV = 8;
@@ -1760,10 +1758,6 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (prev >= 0) { p->deferred = -1; p->deferredBegun = false; BF_TRY(plBodyRest(p, (uint32_t)prev, true)); }
     if (ahead && got) {
         p->deferred = (int)frame;
-        // (experiment) the new frame's matching chain onto the bundling stream NOW - behind the previous frame's solves, which is where it belongs
-        // in the serial order - instead of at the start of the next call.  Same operations in the same stream order; only the moment the host
-        // issues them moves.
-        if (p->earlyChain) { BF_TRY(plBodyBegin(p, frame)); p->deferredBegun = true; }
     }
     else if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, got != 0));
     if (tm) {
@@ -1820,26 +1814,12 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         int least = 0, greatest = 0;
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sBundle, hipStreamNonBlocking, greatest));
-        // BF_VOLUME_CU_RESERVE=R (experiment, default off): the volume stream may use all but R compute units, so that the latency-bound kernels of
-        // the bundling chain always find idle CUs instead of sharing SIMDs with the voxel update's resident waves.  Measured (gpurun r03k, R = 0 / 16 /
-        // 32 / 64 / 96): the wait for the match result drops 0.80 -> 0.73 / 0.73 / 0.72 / 0.69 ms, the voxel update slows 93.8 -> 102.5 / 103.6 /
-        // 113.0 / 126.4 us, frames/s 656 -> 655 / 648 / 623 / 565: the loop is balanced between the two, no reservation wins
-        uint32_t reserve = 0;
-        if (const char* e = getenv("BF_VOLUME_CU_RESERVE")) reserve = (uint32_t)atoi(e);
-        int cus = 0;
-        int devId = 0;
-        (void)hipGetDevice(&devId);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devId);
-        if (reserve > 0 && cus > 0 && reserve < (uint32_t)cus) {
-            std::vector<uint32_t> mask(((uint32_t)cus + 31) / 32, 0u);
-            for (uint32_t c = 0; c < (uint32_t)cus - reserve; ++c) mask[c / 32] |= 1u << (c % 32);
-            BF_HIP_TRY(hipExtStreamCreateWithCUMask(&p->sVolume, (uint32_t)mask.size(), mask.data()));
-        } else
+        // (measured and withdrawn, gpurun r03k: reserving R = 16 .. 96 CUs for the chain by masking the volume stream - the wait for the match result drops
+        // 0.80 -> 0.69 ms while the voxel update slows 93.8 -> 126 us; frames/s 656 -> 655 / 648 / 623 / 565)
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
-    if (const char* e = getenv("BF_PIPELINE_EARLY_CHAIN")) p->earlyChain = atoi(e) != 0;
     BF_TRY(bf_image_manager_set_stream(p->im, p->sDetect));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_online_bundler_set_detect_stream(p->ob, p->sDetect));

@@ -418,43 +418,12 @@ template <class T> BF_DEV void swp(T& a, T& b) { const T t = a; a = b; b = t; }
 //   lanes < n       rank of each residual = its slot after sortKabschResiduals (:376-384); the selection sort's result is
 //                   unique when all residuals are finite and distinct — otherwise lane 0 runs the literal sort
 //   lanes 0 and 1   covariance eigenvalues of the (sorted) source / target points
-// `spread` (BF_KABSCH_LANES=1): the accumulation loops of the fit and of the two covariance solves - 6 + 9 and 6 + 18 INDEPENDENT sums, each
-// over the points in index order - run one sum per lane instead of all on one lane.  Every sum is the same sequence of operations on the same
-// values as in kabsch() / covarianceEig() (a wave issues one instruction per four cycles whatever the number of active lanes, so the ~1100
-// instructions of the loops at n = 20 become ~150); nothing is re-associated.
-struct ReprojShared { m44 T; float ev[3]; float cond[2]; float mean[6]; float V[18]; };
+// (Measured and withdrawn in round 4, gpurun r04a: the accumulation loops of the fit and of the two covariance solves spread one sum per lane, bit-identical -
+// 244 vs 259 us per launch, no change at the frame level: the time is in the dependent SVD / eigenvalue chains, not in the sums.)
+struct ReprojShared { m44 T; float ev[3]; float cond[2]; };
 
-BF_DEV float comp3(const f3* pts, unsigned i, unsigned c) { return reinterpret_cast<const float*>(pts)[i * 3u + c]; }
-
-// centroids of src (mean[0..2]) and tgt (mean[3..5]) on lanes 0..5: `p0 = p0 + src[i]` from (0, 0, 0), then `/ (float)n`
-BF_DEV void spreadMeans(uint32_t lane, const f3* src, const f3* tgt, unsigned n, ReprojShared* sh) {
-    if (lane < 6u) {
-        const f3* pts = lane < 3u ? src : tgt;
-        const unsigned c = lane < 3u ? lane : lane - 3u;
-        float acc = 0.0f;
-        for (unsigned i = 0; i < n; ++i) acc = acc + comp3(pts, i, c);
-        sh->mean[lane] = acc / (float)n;
-    }
-}
-
-__device__ __noinline__ bool computeReprojection(uint32_t lane, f3* src, f3* tgt, unsigned n, float* res, Sel* sel, ReprojShared* sh, bool spread) {
-    if (spread) {
-        spreadMeans(lane, src, tgt, n, sh);
-        __syncthreads();
-        if (lane < 9u) {                                         // V[r * 3 + c] += (src[i] - p0)[r] * (tgt[i] - q0)[c]
-            const unsigned r = lane / 3u, c = lane % 3u;
-            const float pr0 = sh->mean[r], qc0 = sh->mean[3u + c];
-            float acc = 0.0f;
-            for (unsigned i = 0; i < n; ++i) { const float pr = comp3(src, i, r) - pr0, qc = comp3(tgt, i, c) - qc0; acc += pr * qc; }
-            sh->V[lane] = acc / (float)n;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            f3 ev;
-            sh->T = kabschFromMoments(sh->V, mk3(sh->mean[0], sh->mean[1], sh->mean[2]), mk3(sh->mean[3], sh->mean[4], sh->mean[5]), ev);
-            sh->ev[0] = ev.x; sh->ev[1] = ev.y; sh->ev[2] = ev.z;
-        }
-    } else if (lane == 0) {
+__device__ __noinline__ bool computeReprojection(uint32_t lane, f3* src, f3* tgt, unsigned n, float* res, Sel* sel, ReprojShared* sh) {
+    if (lane == 0) {
         f3 ev;
         sh->T = kabsch(src, tgt, n, ev);
         sh->ev[0] = ev.x; sh->ev[1] = ev.y; sh->ev[2] = ev.z;
@@ -480,20 +449,7 @@ __device__ __noinline__ bool computeReprojection(uint32_t lane, f3* src, f3* tgt
                 if (res[i] > res[j]) { swp(res[i], res[j]); swp(src[i], src[j]); swp(tgt[i], tgt[j]); swp(sel[i], sel[j]); }
     }
     __syncthreads();
-    if (spread) {
-        spreadMeans(lane, src, tgt, n, sh);
-        __syncthreads();
-        if (lane < 18u) {                                        // V[r * 3 + c] += (pts[i] - p0)[r] * (pts[i] - p0)[c], src on lanes 0..8, tgt on 9..17
-            const unsigned w = lane / 9u, k = lane % 9u, r = k / 3u, c = k % 3u;
-            const f3* pts = w ? tgt : src;
-            const float mr = sh->mean[3u * w + r], mc = sh->mean[3u * w + c];
-            float acc = 0.0f;
-            for (unsigned i = 0; i < n; ++i) { const float pr = comp3(pts, i, r) - mr, pc = comp3(pts, i, c) - mc; acc += pr * pc; }
-            sh->V[lane] = acc / (float)n;
-        }
-        __syncthreads();
-        if (lane < 2) { const f3 e = eigenValues3(sh->V + 9u * lane); sh->cond[lane] = e.x / e.y; }
-    } else if (lane < 2) { const f3 e = covarianceEig(lane == 0 ? src : tgt, n); sh->cond[lane] = e.x / e.y; }
+    if (lane < 2) { const f3 e = covarianceEig(lane == 0 ? src : tgt, n); sh->cond[lane] = e.x / e.y; }
     __syncthreads();
     const float c1 = sh->ev[0] / sh->ev[1], cp = sh->cond[0], cq = sh->cond[1];
     if (c1 != c1 || cp != cp || cq != cq || fabsf(c1) > 100.0f || fabsf(cp) > 100.0f || fabsf(cq) > 100.0f) return false;
@@ -505,7 +461,6 @@ struct FilterArgs {
     const int* numMatches; const float* dist; const uint2* idx;
     int* numFilt; float* fdist; uint2* fidx; m44* T; m44* Tinv;
     m44 Kinv; int minNumMatches; float maxKabschRes2;
-    int spread;             // see computeReprojection
 };
 
 // One wave per previous image.  The greedy filter is inherently sequential (every accepted match changes the Kabsch fit
@@ -559,7 +514,7 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
             if (cur >= 3) {
                 if (tid < cur) { src[tid] = ptI[sel[tid].r]; tgt[tid] = ptJ[sel[tid].r]; }
                 __syncthreads();
-                validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh, a.spread != 0);
+                validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
                 const bool b = validT;
                 if (tid < 16) prevT.e[tid] = sh.T.e[tid];
                 curMaxRes = res[cur - 1];
@@ -570,7 +525,7 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
                         lastRes = res[k];
                         cur--;
                         __syncthreads();
-                        validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh, a.spread != 0);
+                        validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
                         curMaxRes = res[cur - 1];
                         if (cur == 3 && (curMaxRes > a.maxKabschRes2 || (b && !validT))) {
                             cur++; curMaxRes = lastRes; validT = b;
@@ -1139,7 +1094,6 @@ struct bf_siftmgr {
     int* d_numMatches = nullptr; float* d_dist = nullptr; uint2* d_idx = nullptr;
     int* d_numFilt = nullptr; float* d_fdist = nullptr; uint2* d_fidx = nullptr; m44* d_T = nullptr; m44* d_Tinv = nullptr;
     int* d_validImages = nullptr; int* d_validOpt = nullptr;
-    bool kabschSpread = false;       // BF_KABSCH_LANES=1 (read when the manager is created): see computeReprojection
     bf_entry_j* d_glob = nullptr; uint2* d_globKeys = nullptr; int* d_globNum = nullptr;
     FrameResult* d_res = nullptr; FrameResult* h_res = nullptr;
     std::vector<int> validImages;
@@ -1174,7 +1128,6 @@ int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_sift
     BF_HIP_TRY(hipMemset(m->d_numFilt, 0, sizeof(int) * maxImages));
     BF_HIP_TRY(hipMemset(m->d_globNum, 0, sizeof(int)));
     BF_HIP_TRY(hipMemset(m->d_res, 0, sizeof(FrameResult)));
-    if (const char* e = getenv("BF_KABSCH_LANES")) m->kabschSpread = atoi(e) != 0;
     m->validImages.assign(maxImages, 0);
     m->validImages[0] = 1;
     BF_HIP_TRY(hipMemcpy(m->d_validImages, m->validImages.data(), sizeof(int) * maxImages, hipMemcpyHostToDevice));
@@ -1263,7 +1216,7 @@ int bf_siftmgr_filter_keypoint_matches(bf_siftmgr* m, uint32_t curFrame, uint32_
                                        uint32_t minNumMatches, float maxKabschRes2) {
     BF_REQUIRE(m && siftIntrinsicsInv && numFrames <= m->numImages && startFrame < numFrames, "frame range out of bounds");
     FilterArgs a = {m->d_keys, curFrame, startFrame, m->d_numMatches, m->d_dist, m->d_idx, m->d_numFilt, m->d_fdist, m->d_fidx, m->d_T, m->d_Tinv,
-                    toM44(siftIntrinsicsInv), (int)minNumMatches, maxKabschRes2, m->kabschSpread ? 1 : 0};
+                    toM44(siftIntrinsicsInv), (int)minNumMatches, maxKabschRes2};
     k_filter_kabsch<<<numFrames - startFrame, 64, 0, m->stream>>>(a);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;

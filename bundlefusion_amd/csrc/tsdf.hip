@@ -805,27 +805,7 @@ __global__ void k_list_commit(Dev d) {
 
 // ---------------------------------------------------------------------------------------
 // voxel update: integrate / de-integrate (CUDASceneRepHashSDF.cu:420-521)
-// one 512-thread workgroup per SDF block, persistent grid-stride over the frustum list
 // ---------------------------------------------------------------------------------------
-// projection of one voxel into the frame and the truncated signed distance sample (the part before the voxel is touched)
-BF_DEV bool voxelSample(const Frame& f, int4 e, int lx, int ly, int lz, const float* __restrict__ depth, uint32_t W, uint32_t H, float& sdf, size_t& pix) {
-    f3 pf = mk3((float)(e.x * BS + lx), (float)(e.y * BS + ly), (float)(e.z * BS + lz)) * f.voxelSize;
-    pf = xform(f.Tinv, pf);
-    const float sx = pf.x * f.cam.fx / pf.z + f.cam.mx;
-    const float sy = pf.y * f.cam.fy / pf.z + f.cam.my;
-    const uint32_t px = (uint32_t)f2i(sx + 0.5f), py = (uint32_t)f2i(sy + 0.5f);
-    if (!(px < W && py < H)) return false;
-    pix = (size_t)py * W + px;
-    const float dep = depth[pix];
-    if (dep == BF_MINF) return false;
-    if (!(dep < f.maxIntegrationDistance)) return false;
-    sdf = dep - pf.z;
-    const float trunc = f.truncation + f.truncScale * dep;
-    if (!(fabsf(sdf) < trunc)) return false;
-    if (sdf >= 0.0f) sdf = fminf(trunc, sdf); else sdf = fmaxf(-trunc, sdf);
-    return true;
-}
-
 // combineVoxel / its inverse on (sdf, weight, packed colour); DEINT resets a voxel whose weight drops to zero.
 //
 // Integrate: 0.2 c + 0.8 o with bytes c, o is (c + 4 o) / 5, never within 0.1 of a rounding tie, so roundf equals
@@ -865,68 +845,13 @@ BF_DEV void voxelApply(const FR& f, float sdf, uchar4 cc, float& vSdf, float& vW
     vSdf = nSdf; vW = nW; vC = nC;
 }
 
-template <bool DEINT>
-__global__ __launch_bounds__(512) void k_update(Dev d, Frame f, const float* __restrict__ depth,
-                                                const uchar4* __restrict__ color, int accumulate) {
-    if (color == nullptr) return;   // .cu:441-448: without colour data `color.x != MINF` never holds
-    const uint32_t n = (uint32_t)d.compactCount[0];
-    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
-    const uint32_t i = threadIdx.x;
-    const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
-    const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
-    for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
-        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];   // wave-uniform
-        float sdf; size_t pix;
-        if (!voxelSample(f, e, lx, ly, lz, depth, W, H, sdf, pix)) continue;
-        const uchar4 cc = color[pix];
-        uint32_t* vp = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + i));
-        float vSdf = __uint_as_float(vp[0]), vW = __uint_as_float(vp[1]);
-        uint32_t vC = vp[2];
-        voxelApply<DEINT>(f, sdf, cc, vSdf, vW, vC);
-        vp[0] = __float_as_uint(vSdf);
-        vp[1] = __float_as_uint(vW);
-        vp[2] = vC;
-    }
-}
-
-// Fused re-integration of one frame: de-integrate at the old pose (fo), then integrate at the new pose (f), in ONE pass over the
-// union of the two frustum lists — every touched voxel is read once and written once instead of twice.  Per voxel this is the
-// exact operation sequence of deIntegrate followed by integrate (DepthSensing.cpp:882-889): blocks carry their frustum
-// membership flags, the intermediate value goes through the same packed representation, and a block the new pose allocated
-// inside the old frustum sees a no-op de-integration (weight 0 -> reset to 0), as if it had not existed yet.
-__global__ __launch_bounds__(512) void k_reupdate(Dev d, Frame f, Frame fo, const float* __restrict__ depth,
-                                                  const uchar4* __restrict__ color, int accumulate) {
-    if (color == nullptr) return;
-    const uint32_t n = (uint32_t)d.compactCount[0];
-    if (accumulate && blockIdx.x == 0 && threadIdx.x == 0) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }      // union list length; operator blocks (counted by the compaction)
-    const uint32_t i = threadIdx.x;
-    const int lx = (int)(i & 7), ly = (int)((i >> 3) & 7), lz = (int)(i >> 6);
-    const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
-    for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
-        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];
-        const uint32_t flags = reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4];
-        float sdfDe = 0.0f, sdfIn = 0.0f; size_t pixDe = 0, pixIn = 0;
-        const bool doDe = (flags & 2u) && voxelSample(fo, e, lx, ly, lz, depth, W, H, sdfDe, pixDe);
-        const bool doIn = (flags & 1u) && voxelSample(f, e, lx, ly, lz, depth, W, H, sdfIn, pixIn);
-        if (!doDe && !doIn) continue;
-        uint32_t* vp = reinterpret_cast<uint32_t*>(d.vox + ((size_t)(uint32_t)e.w + i));
-        float vSdf = __uint_as_float(vp[0]), vW = __uint_as_float(vp[1]);
-        uint32_t vC = vp[2];
-        if (doDe) voxelApply<true>(fo, sdfDe, color[pixDe], vSdf, vW, vC);
-        if (doIn) voxelApply<false>(f, sdfIn, color[pixIn], vSdf, vW, vC);
-        vp[0] = __float_as_uint(vSdf);
-        vp[1] = __float_as_uint(vW);
-        vp[2] = vC;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // voxel update, column form: ONE WAVE per SDF block.  Lane (x, y) owns the z-column of 8 voxels and walks it in 4 steps of 2
 // voxels held in the two halves of packed-f32 registers (v_pk_mul/add/fma_f32: two IEEE operations per issue slot).
 //
-// Why: rocprofv3 SQ counters show the one-voxel-per-lane kernels above VALU-issue bound (profiles/r02_sq_tsdf_update.md: 234
-// vector instructions per 64 voxels, SQ_ACTIVE_INST_VALU ~ 86 % of the SIMD cycles), not HBM bound.  Per voxel the arithmetic is
-// unchanged — the same IEEE operation sequence as voxelSample / voxelApply, bit for bit — but
+// Why: rocprofv3 SQ counters showed the one-voxel-per-lane kernels of round 1 (512-thread workgroups, removed in round 4) VALU-issue bound
+// (profiles/r02_sq_tsdf_update.md: 234 vector instructions per 64 voxels, SQ_ACTIVE_INST_VALU ~ 86 % of the SIMD cycles), not HBM bound.
+// Per voxel the arithmetic is the IEEE operation sequence of voxelSampleU / voxelApply, bit for bit, but
 //   * the terms of the camera transform that depend on (x, y) only are computed once per column, the z term once per wave;
 //   * the two divisions of the projection share one refined reciprocal, and so do the four of a de-integration: the quotient is
 //     formed by the instruction sequence the compiler emits for an IEEE f32 division (rcp, 2 FMA Newton step, q = n*r, two
@@ -934,7 +859,7 @@ __global__ __launch_bounds__(512) void k_reupdate(Dev d, Frame f, Frame fo, cons
 //     handling is the identity.  That is guaranteed per block by a wave-uniform bound on the camera-space coordinates (projection)
 //     and checked per value where the result is stored (TSDF quotients); anything else takes the literal `/`;
 //   * independent operations of the two voxels of a pair are packed.
-// A wave whose block fails the bound runs voxelSample / voxelApply for its 512 voxels (colExact).
+// A wave whose block fails the bound runs voxelSampleU / voxelApply for its 512 voxels (colExact).
 // ---------------------------------------------------------------------------------------
 // f2i as the one instruction it describes (v_cvt_i32_f32: toward zero, saturating, NaN -> 0).  The portable spelling in bf_device.h
 // costs three compares and three exec-mask branches per conversion in the voxel kernels' inner loop.
@@ -1212,9 +1137,6 @@ struct ApxCam {
     float mxh, myh;            // principal point + 0.5 (the rounding offset of the pixel index)
     float voxelSize, maxDist, truncScale, truncation, weightMax;
     uint32_t W, H, bytes;      // image size, bytes of one image plane (W * H * 4)
-    uint32_t texel;            // 1: `depth` is an interleaved image of 8-byte texels {depth, colour} (k_interleave), `color` is only tested for null
-    uint32_t fullStores;       // 1: a voxel slice is written back by ALL lanes of the wave as soon as one of them changed its voxel (whole 768-byte rows instead of
-                               // byte-masked partial lines; the other lanes write what they read) - BF_APX_FULL_STORES, an experiment on the write path
 };
 struct ApxPose {
     float ax, bx, cx, dx;      // fx * voxelSize * (R00, R01, R02), fx * t0: numerator of the image x coordinate over the integer voxel coordinates
@@ -1261,10 +1183,7 @@ struct ApxBlock {
     ApxCol cDe, cIn;
     bool useDe, useIn;         // wave-uniform: the block lies in the frustum of the old / new pose
 };
-// Stage A of one voxel pair (z, z + 1): every load it needs, issued without waiting for any of them - the two voxels (speculatively:
-// about one in four is not touched), and depth + colour of the pixels both poses project them to.  No load depends on another load,
-// so stage A of the NEXT pair (or of the next block's first pair) is issued before stage B of the current one: the wave always has
-// two pairs' worth of loads in flight and its arithmetic runs in the shadow of the round trip.
+// One voxel pair (z, z + 1) of a block: the two voxels, and depth + colour of the pixels both poses project them to.
 struct ApxPair {
     v2f vS, vW; uint32_t vCA, vCB;
     v2f pczDe, pczIn, dDe, dIn;
@@ -1285,21 +1204,14 @@ BF_DEV ApxBlock apxBlock(const Dev& d, const ApxCam& c, const ApxPose& pIn, cons
     return b;
 }
 
-// depth and colour of one pixel: two 4-byte gathers from the two planes, or ONE 8-byte gather from the interleaved image the prep stream
-// builds per operator (k_interleave) - half the vector-memory instructions of a kernel that sits on the CU's memory pipeline
+// depth and colour of one pixel: ONE 8-byte gather from the interleaved image the prep stream builds per operator (k_interleave) - half the
+// vector-memory instructions of the two-plane form (two 4-byte gathers; measured 108.0 -> 88.9 us per fused launch, gpurun r03n; removed in round 4)
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-typedef uint32_t v3u __attribute__((ext_vector_type(3)));
 struct ApxTexel { float dep; uint32_t col; };
-template <bool TEX>
-BF_DEV ApxTexel apxGather(__amdgpu_buffer_rsrc_t depthRes, __amdgpu_buffer_rsrc_t colorRes, uint32_t off) {
+BF_DEV ApxTexel apxGather(__amdgpu_buffer_rsrc_t texRes, uint32_t off) {
     ApxTexel r;
-    if (TEX) {
-        const v2u t = __builtin_amdgcn_raw_buffer_load_b64(depthRes, (int)(off << 1), 0, 0);      // 0xFFFFFFFF << 1 stays beyond the range
-        r.dep = __uint_as_float(t.x); r.col = t.y;
-    } else {
-        r.dep = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depthRes, (int)off, 0, 0));
-        r.col = __builtin_amdgcn_raw_buffer_load_b32(colorRes, (int)off, 0, 0);
-    }
+    const v2u t = __builtin_amdgcn_raw_buffer_load_b64(texRes, (int)(off << 1), 0, 0);      // 0xFFFFFFFF << 1 stays beyond the range
+    r.dep = __uint_as_float(t.x); r.col = t.y;
     return r;
 }
 
@@ -1307,13 +1219,9 @@ __global__ void k_interleave(const float* __restrict__ depth, const uint32_t* __
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) texel[i] = make_uint2(__float_as_uint(depth[i]), color[i]);
 }
 
-template <bool DE, bool IN, bool TEX>
-BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, __amdgpu_buffer_rsrc_t depthRes,
-                         __amdgpu_buffer_rsrc_t colorRes) {
-    ApxPair o;
-    const uint32_t* vpA = b.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
-    o.vS.x = __uint_as_float(vpA[0]); o.vW.x = __uint_as_float(vpA[1]); o.vCA = vpA[2];
-    o.vS.y = __uint_as_float(vpB[0]); o.vW.y = __uint_as_float(vpB[1]); o.vCB = vpB[2];
+// the samples of a pair: projection of its two voxels under both poses and the four texel gathers (no load depends on another load)
+template <bool DE, bool IN>
+BF_DEV void apxSamples(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, __amdgpu_buffer_rsrc_t texRes, ApxPair& o) {
     v2f iz; iz.x = b.kz + (float)z; iz.y = b.kz + (float)(z + 1);                 // exact small integers
     const v2f pz = iz * sp2(c.voxelSize);
     o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
@@ -1321,16 +1229,31 @@ BF_DEV ApxPair apxStageA(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe
     if (DE) {
         const ApxSample a = apxProject(c, pDe, b.cDe, iz, pz, b.useDe);
         o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
-        const ApxTexel tA = apxGather<TEX>(depthRes, colorRes, a.offA), tB = apxGather<TEX>(depthRes, colorRes, a.offB);
+        const ApxTexel tA = apxGather(texRes, a.offA), tB = apxGather(texRes, a.offB);
         o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
     }
     if (IN) {
         const ApxSample a = apxProject(c, pIn, b.cIn, iz, pz, b.useIn);
         o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
-        const ApxTexel tA = apxGather<TEX>(depthRes, colorRes, a.offA), tB = apxGather<TEX>(depthRes, colorRes, a.offB);
+        const ApxTexel tA = apxGather(texRes, a.offA), tB = apxGather(texRes, a.offB);
         o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
     }
-    return o;
+}
+
+BF_DEV void apxLoadVoxels(const ApxBlock& b, int z, ApxPair& o) {
+    const uint32_t* vpA = b.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
+    o.vS.x = __uint_as_float(vpA[0]); o.vW.x = __uint_as_float(vpA[1]); o.vCA = vpA[2];
+    o.vS.y = __uint_as_float(vpB[0]); o.vW.y = __uint_as_float(vpB[1]); o.vCB = vpB[2];
+}
+
+// which voxels of a pair have a valid sample (the conditions of apxStageB, on the same values)
+template <bool DE, bool IN>
+BF_DEV void apxTouched(const ApxCam& c, const ApxPair& a, bool& anyA, bool& anyB) {
+    const v2f sDe = a.dDe - a.pczDe, sIn = a.dIn - a.pczIn;
+    const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * a.dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * a.dIn;
+    const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
+    const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
+    anyA = okDeA || okInA; anyB = okDeB || okInB;
 }
 
 // Stage B: sample validity, voxelApply<true> and / or voxelApply<false>, store.
@@ -1346,7 +1269,7 @@ BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& 
     const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
     const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
     const bool anyA = okDeA || okInA, anyB = okDeB || okInB;
-    const bool stA = c.fullStores ? __builtin_amdgcn_ballot_w64(anyA) != 0ull : anyA, stB = c.fullStores ? __builtin_amdgcn_ballot_w64(anyB) != 0ull : anyB;
+    const bool stA = anyA, stB = anyB;
     if (!stA && !stB) return;
     if (DE && (okDeA || okDeB)) {           // voxelApply<true>
         const v2f dd = vW - sp2(1.0f);
@@ -1398,113 +1321,20 @@ BF_DEV ApxEntry apxEntry(const Dev& d, uint32_t blk) {
     return r;
 }
 
-template <int MODE, bool RNE, bool PIPE, bool TEX>
-BF_DEV void updateApxBody(const Dev& d, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* __restrict__ depth, const uchar4* __restrict__ color,
-                          int accumulate) {
-    if (color == nullptr) return;
-    constexpr bool DE = MODE != 0, IN = MODE != 1;
-    const uint32_t n = (uint32_t)d.compactCount[0];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), nWaves = gridDim.x * 4u;
-    if (accumulate && wave == 0 && lane == 0) {          // block accounting of the timed launches
-        if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
-        else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
-    }
-    if (wave >= n) return;
-    const __amdgpu_buffer_rsrc_t depthRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(depth), 0, (int)(TEX ? 2u * c.bytes : c.bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t colorRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uchar4*>(color), 0, (int)c.bytes, 0x00020000);
-    if (!PIPE) {           // one pair at a time: one memory round trip per pair, hidden by the other waves of the SIMD only
-        for (uint32_t blk = wave; blk < n; blk += nWaves) {
-            const ApxEntry en = apxEntry<MODE>(d, blk);
-            const ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
-#pragma unroll 1
-            for (int z = 0; z < 8; z += 2) {
-                const ApxPair pa = apxStageA<DE, IN, TEX>(c, in, de, cur, z, depthRes, colorRes);
-                apxStageB<DE, IN, RNE>(c, cur, z, pa);
-            }
-        }
-        return;
-    }
-    // The wave's stream of work is (block, pair) for its blocks wave, wave + nWaves, ...; stage A runs one pair ahead of stage B, across
-    // block boundaries, and the list entry of the next block is fetched one block ahead.
-    uint32_t nextBlk = wave + nWaves;
-    ApxEntry en = apxEntry<MODE>(d, wave);
-    ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
-    if (nextBlk < n) en = apxEntry<MODE>(d, nextBlk);
-    ApxPair pa = apxStageA<DE, IN, TEX>(c, in, de, cur, 0, depthRes, colorRes);
-    int z = 0;
-    for (;;) {
-        ApxBlock nb = cur;
-        int nz = z + 2;
-        bool more = true;
-        if (z == 6) {                                   // wave-uniform
-            nz = 0;
-            more = nextBlk < n;
-            if (more) {
-                nb = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
-                nextBlk += nWaves;
-                if (nextBlk < n) en = apxEntry<MODE>(d, nextBlk);
-            }
-        }
-        ApxPair pn = pa;
-        if (more) pn = apxStageA<DE, IN, TEX>(c, in, de, nb, nz, depthRes, colorRes);
-        apxStageB<DE, IN, RNE>(c, cur, z, pa);
-        if (!more) break;
-        cur = nb; z = nz; pa = pn;
-    }
-}
-
-// Measured and withdrawn (gpurun r03i): the same body held to 80 SGPRs (8 workgroups per CU instead of 7; the ten spilled values are read back
-// once per block) - 92.7 vs 93.4 us per launch, inside the run-to-run spread; list entries through the scalar cache (s_load_dwordx8) - 92.8 us.
-template <int MODE, bool RNE, bool PIPE, bool TEX>
-__global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in, ApxPose de, const float* __restrict__ depth, const uchar4* __restrict__ color,
-                                                    int accumulate) {
-    updateApxBody<MODE, RNE, PIPE, TEX>(d, c, in, de, depth, color, accumulate);
-}
-
-// which voxels of a pair have a valid sample (the conditions of apxStageB, on the same values)
-template <bool DE, bool IN>
-BF_DEV void apxTouched(const ApxCam& c, const ApxPair& a, bool& anyA, bool& anyB) {
-    const v2f sDe = a.dDe - a.pczDe, sIn = a.dIn - a.pczIn;
-    const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * a.dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * a.dIn;
-    const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
-    const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
-    anyA = okDeA || okInA; anyB = okDeB || okInB;
-}
-
-// ---------------------------------------------------------------------------------------
-// The fast update with the voxel loads DEFERRED behind the samples (BF_APX_DEFER=1; prepared at the end of round 3, not yet timed).
-//
-// Whether a voxel is touched depends on its sample alone (apxTouched), and about 2.5 of a block's 8 slices are touched by no lane at all
-// (5.5 store instructions per block) - yet k_update_apx reads every slice, speculatively, together with the samples: 30 % of the voxel bytes
-// it reads, on a kernel that runs at the memory system's streaming rate (profiles/r03_lds_footprint.md).  Here a pair's samples are gathered
-// first, and its two slices are loaded only when some lane of the wave has a valid sample for one of them: two dependent round trips per touched
-// pair instead of one, no memory access at all for an untouched pair.  Same values, same operations: bit-identical to k_update_apx.
-// ---------------------------------------------------------------------------------------
-template <bool DE, bool IN>
-BF_DEV void apxSamplesTex(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, __amdgpu_buffer_rsrc_t texRes, ApxPair& o) {
-    v2f iz; iz.x = b.kz + (float)z; iz.y = b.kz + (float)(z + 1);
-    const v2f pz = iz * sp2(c.voxelSize);
-    o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
-    o.inDeA = o.inDeB = o.inInA = o.inInB = false;
-    if (DE) {
-        const ApxSample a = apxProject(c, pDe, b.cDe, iz, pz, b.useDe);
-        o.pczDe = a.pcz; o.inDeA = a.inA; o.inDeB = a.inB;
-        const ApxTexel tA = apxGather<true>(texRes, texRes, a.offA), tB = apxGather<true>(texRes, texRes, a.offB);
-        o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
-    }
-    if (IN) {
-        const ApxSample a = apxProject(c, pIn, b.cIn, iz, pz, b.useIn);
-        o.pczIn = a.pcz; o.inInA = a.inA; o.inInB = a.inB;
-        const ApxTexel tA = apxGather<true>(texRes, texRes, a.offA), tB = apxGather<true>(texRes, texRes, a.offB);
-        o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
-    }
-}
-
-template <int MODE, bool RNE>
-__global__ __launch_bounds__(256) void k_update_apx_defer(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, const uchar4* __restrict__ color,
-                                                          int accumulate) {
-    if (color == nullptr) return;
+// One wave per block of the frustum (or union) list, lane = (x, y) column, the eight z walked as four pairs.
+//   DEFER = true (the default since round 4): a pair's samples are gathered first and its two voxel slices are loaded only when some lane of the wave
+//     has a valid sample for one of them - two dependent round trips per touched pair, no voxel traffic at all for an untouched pair (about 2.5 of a
+//     block's 8 slices are touched by no lane).  Measured against the other form in the bench window: 79.2 -> 73.4 us per fused launch, 708.7 -> 743.7
+//     frames/s (gpurun r04a, profiles/r04_update_variants.md).
+//   DEFER = false (BF_APX_DEFER=0): voxels are loaded speculatively together with the samples, one round trip per pair.
+// Same values, same operations: the two forms are bit-identical (tests/test_tsdf_fast_gpu.py).
+// Measured and withdrawn in round 3 (profiles/r03_lds_footprint.md; the code is in the history): the block's pixel footprint staged through LDS
+// (83 us), plus all eight slices in one round trip (79.2), plus per-slice loads behind a second sampling pass (104), whole-row write-backs (79.7),
+// stage A of the next pair issued before stage B of the current one (113: 80 VGPRs -> 6 waves), the body held to 80 SGPRs (no change), 4096 / 2048
+// workgroups (97 / 106).
+template <int MODE, bool RNE, bool DEFER>
+__global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, int hasColor, int accumulate) {
+    if (!hasColor) return;          // CUDASceneRepHashSDF.cu:441-448: without colour data `color.x != MINF` never holds
     constexpr bool DE = MODE != 0, IN = MODE != 1;
     const uint32_t n = (uint32_t)d.compactCount[0];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1521,232 +1351,20 @@ __global__ __launch_bounds__(256) void k_update_apx_defer(Dev d, ApxCam c, ApxPo
 #pragma unroll 1
         for (int z = 0; z < 8; z += 2) {
             ApxPair pa;
-            apxSamplesTex<DE, IN>(c, in, de, cur, z, texRes, pa);
-            bool anyA, anyB;
-            apxTouched<DE, IN>(c, pa, anyA, anyB);
-            if (__builtin_amdgcn_ballot_w64(anyA || anyB) == 0ull) continue;          // wave-uniform: nothing of this pair is read or written
-            const uint32_t* vpA = cur.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
-            pa.vS.x = __uint_as_float(vpA[0]); pa.vW.x = __uint_as_float(vpA[1]); pa.vCA = vpA[2];
-            pa.vS.y = __uint_as_float(vpB[0]); pa.vW.y = __uint_as_float(vpB[1]); pa.vCB = vpB[2];
+            if (!DEFER) apxLoadVoxels(cur, z, pa);
+            apxSamples<DE, IN>(c, in, de, cur, z, texRes, pa);
+            if (DEFER) {
+                bool anyA, anyB;
+                apxTouched<DE, IN>(c, pa, anyA, anyB);
+                if (__builtin_amdgcn_ballot_w64(anyA || anyB) == 0ull) continue;          // wave-uniform: nothing of this pair is read or written
+                apxLoadVoxels(cur, z, pa);
+            }
             apxStageB<DE, IN, RNE>(c, cur, z, pa);
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// The fast update with the block's pixel footprint staged through LDS (BF_APX_LDS=1).
-//
-// What bounds k_update_apx is the CU's vector-memory path (profiles/r03_ta_tsdf_update.md): every gather of a voxel slice looks up ~25 cache
-// lines, and the eight slices of a block project onto nearly the same patch of the image, which each of them gathers again.  Here the wave
-// copies that patch ONCE per block and pose into LDS - up to three 1 KB pieces of LDS-DMA (global_load_lds_dwordx4: a lane fetches two
-// neighbouring texels, a piece is 8 rows of 16 or 4 rows of 32 texels, coalesced) - and the voxels fetch their samples from LDS.  The patch
-// is the bounding box of the block's eight corner voxels (a projective map is monotone along a line that does not cross the camera plane, so
-// the extreme pixel coordinates of the block are those of its corners); a sample outside the copied patch - a footprint larger than the
-// tile, a block that reaches behind the camera, a rounding difference at the rim - is gathered from memory as before, so the RESULT does not
-// depend on the patch at all: bit-identical to k_update_apx<.., TEX = true> (tests/test_tsdf_fast_gpu.py).
-// ---------------------------------------------------------------------------------------
-constexpr uint32_t TILE_TEXELS = 384;          // per wave and pose: 16 x 24 or 32 x 12 texels of 8 bytes = three LDS-DMA pieces of 1 KB
-constexpr uint32_t TEXEL_SLACK = 64;           // texels allocated behind the interleaved image: a piece may read up to 31 texels past a row's end
 
-struct ApxTile { int x0, y0; uint32_t shift, rows; };        // wave-uniform: origin (x0 even), log2 of the row length, rows copied
-
-BF_DEV void apxCorner(const ApxCam& c, const ApxPose& p, const ApxCol& col, float iz, float& hx, float& hy) {
-    const float pcz = (col.zc + p.r8 * (iz * c.voxelSize)) + p.t2;
-    const float r = __builtin_amdgcn_rcpf(pcz);
-    hx = __builtin_fmaf(__builtin_fmaf(p.cx, iz, col.nx0), r, c.mxh);
-    hy = __builtin_fmaf(__builtin_fmaf(p.cy, iz, col.ny0), r, c.myh);
-}
-
-BF_DEV int cornerMin(int v) { return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 7)), min(__builtin_amdgcn_readlane(v, 56), __builtin_amdgcn_readlane(v, 63))); }
-BF_DEV int cornerMax(int v) { return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 7)), max(__builtin_amdgcn_readlane(v, 56), __builtin_amdgcn_readlane(v, 63))); }
-
-// Bounding box of the block under pose `p`, then the copy: piece k holds the texels [128 k, 128 k + 128) of the tile in row-major order, lane l
-// the two texels 128 k + 2 l and + 1 (LDS-DMA writes lane l's 16 bytes at base + 16 l: the LDS image is linear, the source address per lane).
-BF_DEV ApxTile apxStage(const ApxCam& c, const ApxPose& p, const ApxCol& col, float kz, const uint2* __restrict__ tex, uint2* tile, uint32_t lane) {
-    float ax, ay, bx, by;
-    apxCorner(c, p, col, kz, ax, ay);
-    apxCorner(c, p, col, kz + 7.0f, bx, by);
-    const int xlo = cornerMin(f2iHw(fminf(ax, bx))), xhi = min(cornerMax(f2iHw(fmaxf(ax, bx))), (int)c.W);      // (the conversion saturates: keep the differences below in range)
-    const int ylo = cornerMin(f2iHw(fminf(ay, by))), yhi = min(cornerMax(f2iHw(fmaxf(ay, by))), (int)c.H);
-    ApxTile t;
-    t.x0 = min(max(xlo, 0), (int)c.W - 2) & ~1;
-    t.y0 = min(max(ylo, 0), (int)c.H - 1);
-    t.shift = (xhi - t.x0 >= 16) ? 5u : 4u;
-    const uint32_t perPiece = 128u >> t.shift;                       // rows per piece
-    const int need = min(max(yhi - t.y0 + 1, 1), (int)(TILE_TEXELS >> t.shift));
-    const uint32_t pieces = ((uint32_t)need + perPiece - 1u) / perPiece;
-    t.rows = pieces * perPiece;
-    const uint32_t wmask = (1u << t.shift) - 1u;
-#pragma unroll
-    for (uint32_t k = 0; k < 3u; ++k) {
-        if (k < pieces) {                                            // wave-uniform
-            const uint32_t q = 2u * lane + 128u * k, row = q >> t.shift, cx = q & wmask;
-            const uint32_t y = min((uint32_t)t.y0 + row, c.H - 1u);
-            const uint2* src = tex + (__umul24(y, c.W) + (uint32_t)t.x0 + cx);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(tile + 128u * k), 16, 0, 0);
-        }
-    }
-    return t;
-}
-
-struct ApxSampleXY { v2f pcz; uint32_t pxA, pyA, pxB, pyB; bool inA, inB; };
-
-BF_DEV ApxSampleXY apxProjectXY(const ApxCam& c, const ApxPose& p, const ApxCol& col, v2f iz, v2f pz, bool use) {      // apxProject, pixel coordinates kept apart
-    ApxSampleXY o;
-    o.pcz = (sp2(col.zc) + sp2(p.r8) * pz) + sp2(p.t2);
-    const v2f nx = pkfma(sp2(p.cx), iz, sp2(col.nx0)), ny = pkfma(sp2(p.cy), iz, sp2(col.ny0));
-    v2f r; r.x = __builtin_amdgcn_rcpf(o.pcz.x); r.y = __builtin_amdgcn_rcpf(o.pcz.y);
-    const v2f hx = pkfma(nx, r, sp2(c.mxh)), hy = pkfma(ny, r, sp2(c.myh));
-    o.pxA = (uint32_t)f2iHw(hx.x); o.pyA = (uint32_t)f2iHw(hy.x); o.pxB = (uint32_t)f2iHw(hx.y); o.pyB = (uint32_t)f2iHw(hy.y);
-    o.inA = use && o.pxA < c.W && o.pyA < c.H; o.inB = use && o.pxB < c.W && o.pyB < c.H;
-    return o;
-}
-
-// the texel of pixel (px, py): from the wave's tile when it lies inside the copied rows (apxFetchLds), from memory otherwise (apxFetchRest; a lane
-// outside the image keeps 0).  Two steps so that a pair's four LDS reads are issued together.
-struct ApxFetch { ApxTexel t; bool direct; };
-BF_DEV ApxFetch apxFetchLds(const ApxTile& t, const uint2* tile, uint32_t px, uint32_t py, bool in) {
-    const uint32_t cx = px - (uint32_t)t.x0, cy = py - (uint32_t)t.y0;
-    const bool inTile = in && cx < (1u << t.shift) && cy < t.rows;
-    const uint2 l = tile[inTile ? (cy << t.shift) + cx : 0u];
-    ApxFetch r;
-    r.t.dep = __uint_as_float(inTile ? l.x : 0u); r.t.col = inTile ? l.y : 0u;
-    r.direct = in && !inTile;
-    return r;
-}
-BF_DEV ApxTexel apxFetchRest(const ApxCam& c, ApxFetch f, __amdgpu_buffer_rsrc_t texRes, uint32_t px, uint32_t py) {
-    if (__builtin_amdgcn_ballot_w64(f.direct) != 0ull) {            // wave-uniform: no vector-memory instruction at all in the usual case; the use of the
-        const v2u g = __builtin_amdgcn_raw_buffer_load_b64(texRes, f.direct ? (int)((__umul24(py, c.W) + px) << 3) : -1, 0, 0);    // result stays inside the branch,
-        if (f.direct) { f.t.dep = __uint_as_float(g.x); f.t.col = g.y; }                                                            // so does the wait for it
-    }
-    return f.t;
-}
-
-// projection and samples of one voxel pair (the voxels themselves are loaded by the caller)
-template <bool DE, bool IN>
-BF_DEV void apxSamplesLds(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, const ApxBlock& b, int z, const ApxTile& tDe, const ApxTile& tIn,
-                          const uint2* tileDe, const uint2* tileIn, __amdgpu_buffer_rsrc_t texRes, ApxPair& o) {
-    const int zz = z & 7;                                             // z >= 8: a second pass over the pair (z - 8), no LDS-DMA pending
-    v2f iz; iz.x = b.kz + (float)zz; iz.y = b.kz + (float)(zz + 1);
-    const v2f pz = iz * sp2(c.voxelSize);
-    o.pczDe = o.pczIn = sp2(0.0f); o.dDe = o.dIn = sp2(0.0f); o.kDeA = o.kDeB = o.kInA = o.kInB = 0u;
-    o.inDeA = o.inDeB = o.inInA = o.inInB = false;
-    ApxSampleXY aDe, aIn;
-    if (DE) aDe = apxProjectXY(c, pDe, b.cDe, iz, pz, b.useDe);
-    if (IN) aIn = apxProjectXY(c, pIn, b.cIn, iz, pz, b.useIn);
-    // The block's LDS-DMA pieces were issued just before its first pair.  Nothing but the issuing wave's vmcnt orders a ds_read behind a pending
-    // LDS-DMA write, and hipcc does not insert that wait here (checked in the ISA): wait once per block, after the voxel loads went out and
-    // after the arithmetic that does not need them.
-    if (z == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ApxFetch fDeA, fDeB, fInA, fInB;
-    if (DE) { fDeA = apxFetchLds(tDe, tileDe, aDe.pxA, aDe.pyA, aDe.inA); fDeB = apxFetchLds(tDe, tileDe, aDe.pxB, aDe.pyB, aDe.inB); }
-    if (IN) { fInA = apxFetchLds(tIn, tileIn, aIn.pxA, aIn.pyA, aIn.inA); fInB = apxFetchLds(tIn, tileIn, aIn.pxB, aIn.pyB, aIn.inB); }
-    if (DE) {
-        o.pczDe = aDe.pcz; o.inDeA = aDe.inA; o.inDeB = aDe.inB;
-        const ApxTexel tA = apxFetchRest(c, fDeA, texRes, aDe.pxA, aDe.pyA), tB = apxFetchRest(c, fDeB, texRes, aDe.pxB, aDe.pyB);
-        o.dDe.x = tA.dep; o.kDeA = tA.col; o.dDe.y = tB.dep; o.kDeB = tB.col;
-    }
-    if (IN) {
-        o.pczIn = aIn.pcz; o.inInA = aIn.inA; o.inInB = aIn.inB;
-        const ApxTexel tA = apxFetchRest(c, fInA, texRes, aIn.pxA, aIn.pyA), tB = apxFetchRest(c, fInB, texRes, aIn.pxB, aIn.pyB);
-        o.dIn.x = tA.dep; o.kInA = tA.col; o.dIn.y = tB.dep; o.kInB = tB.col;
-    }
-}
-
-// PRE 1: all eight voxel slices of the block are loaded together with the LDS-DMA pieces - ONE memory round trip per block instead of one per
-// voxel pair (the samples come from LDS, so nothing else a pair needs is in memory); 24 more VGPRs.
-// PRE 2: as 1, but only the slices that hold a voxel with a valid sample are loaded at all.  Whether a voxel is touched depends on its sample
-// alone, not on the voxel: a first pass over the block's pairs (projection + LDS reads, no memory) collects one bit per slice, the loads of the
-// set bits go out together, a second pass repeats the sampling and updates.  About 2.5 of a block's 8 slices are untouched by any lane
-// (5.5 store instructions per block, profiles/r03_ta_tsdf_update.md) - 30 % of the voxel bytes read by the other forms of the kernel.
-template <int MODE, bool RNE, int PRE>
-__global__ __launch_bounds__(256) void k_update_apx_lds(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, const uchar4* __restrict__ color,
-                                                        int accumulate) {
-    if (color == nullptr) return;
-    constexpr bool DE = MODE != 0, IN = MODE != 1;
-    constexpr uint32_t NP = MODE == 2 ? 2u : 1u;
-    __shared__ __attribute__((aligned(16))) uint2 tiles[4u * NP * TILE_TEXELS];
-    const uint32_t n = (uint32_t)d.compactCount[0];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u) + wid, nWaves = gridDim.x * 4u;
-    if (accumulate && wave == 0 && lane == 0) {          // block accounting of the timed launches
-        if (MODE == 2) { d.occSum[2] += (unsigned long long)n; d.occSum[0] += (unsigned long long)(uint32_t)d.compactCount[1]; }
-        else { d.occSum[0] += (unsigned long long)n; d.occSum[1] += (unsigned long long)n; }
-    }
-    if (wave >= n) return;
-    uint2* tileDe = tiles + wid * NP * TILE_TEXELS;
-    uint2* tileIn = tileDe + (NP - 1u) * TILE_TEXELS;
-    const __amdgpu_buffer_rsrc_t texRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(tex), 0, (int)(2u * c.bytes), 0x00020000);
-    for (uint32_t blk = wave; blk < n; blk += nWaves) {
-        ApxEntry en = apxEntry<MODE>(d, blk);
-        en.flags = __builtin_amdgcn_readfirstlane(en.flags);
-        const ApxBlock cur = apxBlock<DE, IN>(d, c, in, de, en.e, en.flags, lane);
-        ApxTile tDe, tIn;
-        tDe.x0 = tDe.y0 = tIn.x0 = tIn.y0 = 0; tDe.shift = tIn.shift = 4u; tDe.rows = tIn.rows = 0u;
-        if (DE && (en.flags & 2u)) tDe = apxStage(c, de, cur.cDe, cur.kz, tex, tileDe, lane);
-        if (IN && (en.flags & 1u)) tIn = apxStage(c, in, cur.cIn, cur.kz, tex, tileIn, lane);
-        if (PRE == 2) {
-            uint32_t need = 0u;                                     // wave-uniform: bit z = slice z holds a voxel with a valid sample
-#pragma unroll
-            for (int z = 0; z < 8; z += 2) {
-                ApxPair pa;
-                pa.vS = pa.vW = sp2(0.0f); pa.vCA = pa.vCB = 0u;
-                apxSamplesLds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes, pa);
-                bool anyA, anyB;
-                apxTouched<DE, IN>(c, pa, anyA, anyB);
-                if (__builtin_amdgcn_ballot_w64(anyA) != 0ull) need |= 1u << z;
-                if (__builtin_amdgcn_ballot_w64(anyB) != 0ull) need |= 2u << z;
-            }
-            // the slices through a descriptor of the BLOCK (6 KB): a slice that is not needed gets an offset beyond it - the load returns 0 without a
-            // memory access, and no branch (with its wait at the join) separates the eight loads
-            const bf_voxel* blockBase = d.vox + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)en.e.w);
-            const __amdgpu_buffer_rsrc_t voxRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf_voxel*>(blockBase), 0, (int)(512u * sizeof(bf_voxel)), 0x00020000);
-            uint32_t vv[8][3];
-#pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                const v3u t = __builtin_amdgcn_raw_buffer_load_b96(voxRes, (need & (1u << z)) ? (int)(lane * 12u + (uint32_t)z * 768u) : -1, 0, 0);      // (the range check covers the VGPR offset only)
-                vv[z][0] = t.x; vv[z][1] = t.y; vv[z][2] = t.z;
-            }
-#pragma unroll
-            for (int z = 0; z < 8; z += 2) {
-                if ((need & (3u << z)) == 0u) continue;
-                ApxPair pa;
-                pa.vS.x = __uint_as_float(vv[z][0]); pa.vW.x = __uint_as_float(vv[z][1]); pa.vCA = vv[z][2];
-                pa.vS.y = __uint_as_float(vv[z + 1][0]); pa.vW.y = __uint_as_float(vv[z + 1][1]); pa.vCB = vv[z + 1][2];
-                apxSamplesLds<DE, IN>(c, in, de, cur, z + 8, tDe, tIn, tileDe, tileIn, texRes, pa);      // (z + 8: see apxSamplesLds - the DMA wait belongs to the first pass)
-                apxStageB<DE, IN, RNE>(c, cur, z, pa);
-            }
-        } else if (PRE == 1) {
-            uint32_t vv[8][3];
-#pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                const uint32_t* vp = cur.base + (size_t)z * 64u * 3u;
-                vv[z][0] = vp[0]; vv[z][1] = vp[1]; vv[z][2] = vp[2];
-            }
-#pragma unroll
-            for (int z = 0; z < 8; z += 2) {
-                ApxPair pa;
-                pa.vS.x = __uint_as_float(vv[z][0]); pa.vW.x = __uint_as_float(vv[z][1]); pa.vCA = vv[z][2];
-                pa.vS.y = __uint_as_float(vv[z + 1][0]); pa.vW.y = __uint_as_float(vv[z + 1][1]); pa.vCB = vv[z + 1][2];
-                apxSamplesLds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes, pa);
-                apxStageB<DE, IN, RNE>(c, cur, z, pa);
-            }
-        } else {
-#pragma unroll 1
-            for (int z = 0; z < 8; z += 2) {
-                ApxPair pa;
-                const uint32_t* vpA = cur.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
-                pa.vS.x = __uint_as_float(vpA[0]); pa.vW.x = __uint_as_float(vpA[1]); pa.vCA = vpA[2];
-                pa.vS.y = __uint_as_float(vpB[0]); pa.vW.y = __uint_as_float(vpB[1]); pa.vCB = vpB[2];
-                apxSamplesLds<DE, IN>(c, in, de, cur, z, tDe, tIn, tileDe, tileIn, texRes, pa);
-                apxStageB<DE, IN, RNE>(c, cur, z, pa);
-            }
-        }
-    }
-}
-
-// what v_cvt_pk_u8_f32 does on this device (see packByte)
 __global__ void k_probe_cvt(uint32_t* out) {
     const float v[8] = {0.5f, 1.5f, 2.5f, 2.7f, 254.4f, 300.0f, -3.0f, 3.49f};
     if (threadIdx.x < 8) out[threadIdx.x] = __builtin_amdgcn_cvt_pk_u8_f32(v[threadIdx.x], 1u, 0xAABBCCDDu);
@@ -1877,19 +1495,14 @@ struct bf_scene {
     hipStream_t stream = nullptr;
     uint32_t numIntegrated = 0;
     uint32_t dedupeSize = 0;
-    uint32_t gridCompact = 0, gridUpdate = 0, gridUpdateCol = 0, gridUpdateColPlain = 0;
-    bool columnUpdate = true;       // k_update_col (one wave per block); false: the one-voxel-per-lane kernels (BF_TSDF_UPDATE=voxel)
+    uint32_t gridCompact = 0, gridUpdateCol = 0, gridUpdateColPlain = 0;
     bool forceExactDiv = false;     // k_update_col takes the literal `/` path for every block (BF_TSDF_EXACT_DIV=1; tests)
     bool externalAlloc = false;     // bf_scene_set_external_alloc: integrate / re-integrate do not allocate (the caller ran bf_scene_alloc_collect / _ingest)
-    int arith = BF_TSDF_ARITH_EXACT; // bf_scene_set_arith / BF_TSDF_ARITH: exact (IEEE op by op, default) or fast (k_update_apx)
+    int arith = BF_TSDF_ARITH_FAST; // bf_scene_set_arith / BF_TSDF_ARITH: fast (k_update_apx: the contract of the reference's own GPU build; default since round 4) or
+                                    // exact (k_update_col: IEEE op by op, bit-comparable with a host build of the reference and with the oracle)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
-    bool apxTexel = true;           // k_update_apx gathers 8-byte {depth, colour} texels from an interleaved copy of the frame built per operator on the prep stream (BF_APX_TEXEL=0: the two planes)
-    uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // one per list buffer (NB)
-    int apxLds = 0;                 // k_update_apx_lds: the block's pixel footprint staged through LDS once per block and pose (BF_APX_LDS=1; 2: + all voxel slices of the block loaded up front; 3: + only the slices some lane touches); needs apxTexel
-    bool apxFullStores = false;     // see ApxCam::fullStores (BF_APX_FULL_STORES=1)
-    bool apxDefer = false;          // k_update_apx_defer: voxel slices loaded only behind a valid sample (BF_APX_DEFER=1); needs apxTexel
-    bool apxPipe = false;           // k_update_apx: stage A of the next voxel pair issued before stage B of the current one.  Measured SLOWER than one pair at a time
-                                    // (113 vs 94.5 us per fused launch, gpurun r03c: 80 VGPRs -> 6 waves per SIMD instead of 7, and more instructions); BF_APX_PIPE=1 selects it
+    uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // the operator's frame as 8-byte {depth, colour} texels (k_interleave), one per list buffer (NB)
+    bool apxDefer = true;           // k_update_apx<.., DEFER>: voxel slices loaded only behind a valid sample (BF_APX_DEFER=0: speculative loads)
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
@@ -1973,7 +1586,7 @@ ApxCam makeApxCam(const Frame& f) {
     ApxCam u;
     u.mxh = f.cam.mx + 0.5f; u.myh = f.cam.my + 0.5f;
     u.voxelSize = f.voxelSize; u.maxDist = f.maxIntegrationDistance; u.truncScale = f.truncScale; u.truncation = f.truncation; u.weightMax = f.weightMax;
-    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight; u.bytes = u.W * u.H * 4u; u.texel = 0u; u.fullStores = 0u;
+    u.W = f.cam.m_imageWidth; u.H = f.cam.m_imageHeight; u.bytes = u.W * u.H * 4u;
     return u;
 }
 ApxPose makeApxPose(const Frame& f) {
@@ -2011,22 +1624,10 @@ int probeCvt(bf_scene* s) {
 }
 
 template <int MODE>
-void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const float* depth, const uchar4* color, int acc) {
-#define BF_APX_LAUNCH(RNE, PIPE, TEX) hipLaunchKernelGGL((k_update_apx<MODE, RNE, PIPE, TEX>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, depth, color, acc)
-    if (c.texel && s->apxDefer) {
-        const uint2* tex = reinterpret_cast<const uint2*>(depth);
-        if (s->cvtRne) hipLaunchKernelGGL((k_update_apx_defer<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
-        else hipLaunchKernelGGL((k_update_apx_defer<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc);
-    } else if (c.texel && s->apxLds) {
-        const uint2* tex = reinterpret_cast<const uint2*>(depth);
-#define BF_APX_LDS_LAUNCH(RNE, PRE) hipLaunchKernelGGL((k_update_apx_lds<MODE, RNE, PRE>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, color, acc)
-        if (s->apxLds >= 3) { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, 2); else BF_APX_LDS_LAUNCH(false, 2); }
-        else if (s->apxLds == 2) { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, 1); else BF_APX_LDS_LAUNCH(false, 1); }
-        else { if (s->cvtRne) BF_APX_LDS_LAUNCH(true, 0); else BF_APX_LDS_LAUNCH(false, 0); }
-#undef BF_APX_LDS_LAUNCH
-    } else if (c.texel) { if (s->cvtRne) BF_APX_LAUNCH(true, false, true); else BF_APX_LAUNCH(false, false, true); }          // (the pipelined variant exists for the two-plane form only)
-    else if (s->apxPipe) { if (s->cvtRne) BF_APX_LAUNCH(true, true, false); else BF_APX_LAUNCH(false, true, false); }
-    else { if (s->cvtRne) BF_APX_LAUNCH(true, false, false); else BF_APX_LAUNCH(false, false, false); }
+void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const uint2* tex, int hasColor, int acc) {
+#define BF_APX_LAUNCH(RNE, DEFER) hipLaunchKernelGGL((k_update_apx<MODE, RNE, DEFER>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, hasColor, acc)
+    if (s->apxDefer) { if (s->cvtRne) BF_APX_LAUNCH(true, true); else BF_APX_LAUNCH(false, true); }
+    else { if (s->cvtRne) BF_APX_LAUNCH(true, false); else BF_APX_LAUNCH(false, false); }
 #undef BF_APX_LAUNCH
 }
 
@@ -2085,16 +1686,23 @@ void launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_d
     hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
 }
 
+// What the allocation stream has to wait for before it may touch the table or read a frame: the event the caller ordered the next operator behind
+// (bf_scene_wait_event: the frame's ingest) and the last exclusive section of the main stream (garbage collection, compactify).  Both are consumed here:
+// whoever touches the prep stream first - runOperator, or bf_scene_alloc_collect / _ingest / _place when the caller allocates itself - waits, and
+// everything issued on that stream afterwards is ordered behind it.
+int prepWaits(bf_scene* s, hipStream_t ps) {
+    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->pendingEv = nullptr; }
+    if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
+    return BF_OK;
+}
+
 // One operator = [allocation] -> frustum list -> voxel update.  kind 0 integrate(f), 1 de-integrate(f), 2 fused: de-integrate(fo) +
 // integrate(f).  With overlap enabled the first two phases go to the prep stream and only the update to the main stream.
 int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf_depth_camera_data* data) {
     const int b = s->overlap ? (s->cur + 1) % bf_scene::NB : s->cur;
     hipStream_t ps = s->overlap ? s->prep : s->stream;
-    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->pendingEv = nullptr; }
-    if (s->overlap) {
-        if (s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
-        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
-    }
+    BF_TRY_RC(prepWaits(s, ps));
+    if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
     const Dev dv = devBuf(s, b);
     if (kind != 1 && !s->externalAlloc) launchAllocOn(s, ps, f, data->d_depthData);      // de-integration neither allocates nor frees
     if (kind == 2) {
@@ -2104,12 +1712,12 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
         hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
     }
-    const bool useTexel = s->arith == BF_TSDF_ARITH_FAST && s->apxTexel && data->d_colorData != nullptr;
+    const bool useTexel = s->arith == BF_TSDF_ARITH_FAST && data->d_colorData != nullptr;
     if (useTexel) {          // the frame as 8-byte texels for this operator's gathers (2 x 2.4 MB at 640x480: a few microseconds on the stream that runs ahead)
         const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
         if (s->texelPixels < npx) {
             BF_TRY_RC(syncAll(s));
-            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], (npx + TEXEL_SLACK) * sizeof(uint2))); BF_HIP_TRY(hipMemsetAsync(s->texel[k] + npx, 0, TEXEL_SLACK * sizeof(uint2), ps)); }
+            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
             s->texelPixels = npx;
         }
         hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ps, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
@@ -2133,24 +1741,20 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     const uchar4* color = reinterpret_cast<const uchar4*>(data->d_colorData);
     const int acc = s->timing ? 1 : 0;
     if (s->arith == BF_TSDF_ARITH_FAST) {
-        ApxCam ac = makeApxCam(f);
-        ac.texel = useTexel ? 1u : 0u;
-        ac.fullStores = s->apxFullStores ? 1u : 0u;
-        const float* src = useTexel ? reinterpret_cast<const float*>(s->texel[b]) : data->d_depthData;
+        const ApxCam ac = makeApxCam(f);
         const ApxPose pin = makeApxPose(f), pde = makeApxPose(kind == 2 ? fo : f);
-        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, src, color, acc);
-        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, src, color, acc);
-        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, src, color, acc);
-    } else if (s->columnUpdate) {
+        const int hasColor = useTexel ? 1 : 0;
+        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, s->texel[b], hasColor, acc);
+        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, s->texel[b], hasColor, acc);
+        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, s->texel[b], hasColor, acc);
+    } else {
         const UpdCam uc = makeUpdCam(f);
         const UpdPose pin = makeUpdPose(f), pde = makeUpdPose(kind == 2 ? fo : f);
         const int fe = s->forceExactDiv ? 1 : 0;
         if (kind == 0) hipLaunchKernelGGL(k_update_col<0>, dim3(s->gridUpdateColPlain), dim3(256), 0, s->stream, dv, uc, pin, pde, data->d_depthData, color, acc, fe);
         else if (kind == 1) hipLaunchKernelGGL(k_update_col<1>, dim3(s->gridUpdateColPlain), dim3(256), 0, s->stream, dv, uc, pin, pde, data->d_depthData, color, acc, fe);
         else hipLaunchKernelGGL(k_update_col<2>, dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, uc, pin, pde, data->d_depthData, color, acc, fe);
-    } else if (kind == 0) hipLaunchKernelGGL(k_update<false>, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, data->d_depthData, color, acc);
-    else if (kind == 1) hipLaunchKernelGGL(k_update<true>, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, data->d_depthData, color, acc);
-    else hipLaunchKernelGGL(k_reupdate, dim3(s->gridUpdate), dim3(512), 0, s->stream, dv, f, fo, data->d_depthData, color, acc);
+    }
     if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
     if (s->overlap) { BF_HIP_TRY(hipEventRecord(s->evUpd[b], s->stream)); s->updRecorded[b] = true; }
     BF_HIP_TRY(hipGetLastError());
@@ -2221,23 +1825,16 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     for (hipEvent_t* e : {&s->evBarrier, &s->evTmp})
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
-    s->gridUpdate = 256 * 16;    // persistent 512-thread workgroups, 16 per CU: measured optimum with the feature pipeline running concurrently (2048: -4 %, 8192: -2 %, 16384: -25 %)
-    if (const char* e = getenv("BF_GRID_UPDATE")) s->gridUpdate = (uint32_t)atoi(e);      // tuning knob (experiments)
     s->gridUpdateCol = s->gridUpdateColPlain = 8192;      // see k_update_col
-    if (const char* e = getenv("BF_GRID_UPDATE_COL")) s->gridUpdateCol = s->gridUpdateColPlain = (uint32_t)atoi(e);
-    if (const char* e = getenv("BF_GRID_UPDATE_COL_PLAIN")) s->gridUpdateColPlain = (uint32_t)atoi(e);
-    if (const char* e = getenv("BF_TSDF_UPDATE")) s->columnUpdate = strcmp(e, "voxel") != 0;
+    if (const char* e = getenv("BF_GRID_UPDATE_COL")) s->gridUpdateCol = s->gridUpdateColPlain = (uint32_t)atoi(e);      // tuning knob (tools/tsdf_sweep.py)
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
-    if (const char* e = getenv("BF_APX_PIPE")) s->apxPipe = atoi(e) != 0;
-    if (const char* e = getenv("BF_APX_TEXEL")) s->apxTexel = atoi(e) != 0;
-    if (const char* e = getenv("BF_APX_LDS")) s->apxLds = atoi(e);
-    if (const char* e = getenv("BF_APX_FULL_STORES")) s->apxFullStores = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_DEFER")) s->apxDefer = atoi(e) != 0;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
-    if (const char* e = getenv("BF_TSDF_ARITH")) return bf_scene_set_arith(s, strcmp(e, "fast") == 0 ? BF_TSDF_ARITH_FAST : BF_TSDF_ARITH_EXACT);
-    return BF_OK;
+    int arith = BF_TSDF_ARITH_FAST;
+    if (const char* e = getenv("BF_TSDF_ARITH")) arith = strcmp(e, "exact") == 0 ? BF_TSDF_ARITH_EXACT : BF_TSDF_ARITH_FAST;
+    return bf_scene_set_arith(s, arith);
 }
 
 // ---- multi-GPU allocation: collect on a band of pixel tiles, exchange, ingest (see Collect above)
@@ -2260,6 +1857,7 @@ int bf_scene_alloc_collect(bf_scene* s, const float camToWorld[16], const bf_dep
     setLastRigidTransform(s, camToWorld);
     const Frame f = makeFrame(s);
     hipStream_t st = s->overlap ? s->prep : s->stream;
+    BF_TRY_RC(prepWaits(s, st));
     const uint32_t tiles = div_up(cam->m_imageWidth, 8) * div_up(cam->m_imageHeight, 8);
     Collect c;
     c.keys = reinterpret_cast<unsigned long long*>(d_keys); c.slots = d_slots; c.count = d_count; c.capacity = capacity;
@@ -2277,6 +1875,7 @@ int bf_scene_alloc_ingest(bf_scene* s, const uint64_t* d_keys, const uint32_t* d
     BF_REQUIRE(s && d_keys && d_count, "null argument");
     const Frame f = makeFrame(s);
     hipStream_t st = s->overlap ? s->prep : s->stream;
+    BF_TRY_RC(prepWaits(s, st));
     hipLaunchKernelGGL(k_alloc_ingest, dim3(std::min<uint32_t>(div_up(capacity, 256u), 1024u)), dim3(256), 0, st, s->d, f, reinterpret_cast<const unsigned long long*>(d_keys), d_count, capacity);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -2285,6 +1884,7 @@ int bf_scene_alloc_place(bf_scene* s) {
     BF_REQUIRE(s, "null scene");
     const Frame f = makeFrame(s);
     hipStream_t st = s->overlap ? s->prep : s->stream;
+    BF_TRY_RC(prepWaits(s, st));
     hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -2434,7 +2034,7 @@ int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
     BF_TRY_RC(beginExclusive(s));
     if (s->compactStale) BF_TRY_RC(launchCompactify(s));
     const Frame f = makeFrame(s);
-    hipLaunchKernelGGL(k_gc_identify, dim3(s->gridUpdate), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_gc_identify, dim3(4096), dim3(256), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_delete, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_finish, dim3(1), dim3(256), 0, s->stream, s->d);
     hipLaunchKernelGGL(k_compact_count<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);

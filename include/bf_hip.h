@@ -173,13 +173,15 @@ BF_API int bf_scene_alloc_ingest(bf_scene* s, const uint64_t* d_keys, const uint
 BF_API int bf_scene_alloc_place(bf_scene* s);
 BF_API int bf_scene_alloc_sync(bf_scene* s);
 /* Arithmetic contract of the voxel update, CUDASceneRepHashSDF.cu:425-516 (integrateDepthMapKernel / deIntegrateDepthMapKernel):
- *   BF_TSDF_ARITH_EXACT (default)  every operation as written, IEEE binary32, no contraction - bit-comparable with a host build of the
- *                                  reference (and with oracle/);
- *   BF_TSDF_ARITH_FAST             the contract of the reference's own Release GPU build (FriedLiver.vcxproj:124 <FastMath>true</FastMath>):
+ *   BF_TSDF_ARITH_FAST (default)   the contract of the reference's own Release GPU build (FriedLiver.vcxproj:124 <FastMath>true</FastMath>):
  *                                  approximate division (v_rcp_f32), FMA contraction.  Block set, bucket occupancy, heap and voxel
  *                                  weights are the same as in exact mode; sdf within 1e-5 x truncation, colour within 1 LSB, except
- *                                  voxels projecting within ~1e-4 pixel of a pixel boundary (they may sample the neighbouring pixel).
- * Environment: BF_TSDF_ARITH=fast|exact selects the mode of every scene created afterwards.  May be switched at any time. */
+ *                                  voxels projecting within ~1e-5 pixel of a pixel boundary (they may sample the neighbouring pixel).
+ *                                  This is the path bench.py measures.
+ *   BF_TSDF_ARITH_EXACT            every operation as written, IEEE binary32, no contraction - bit-comparable with a host build of the
+ *                                  reference (and with oracle/): the mode of every bit-for-bit test.
+ * Environment: BF_TSDF_ARITH=fast|exact selects the mode of every scene created afterwards.  May be switched at any time.
+ * (Until round 3 exact was the default and the benchmark measured fast; since round 4 the library default is what is measured.) */
 #define BF_TSDF_ARITH_EXACT 0
 #define BF_TSDF_ARITH_FAST 1
 BF_API int bf_scene_set_arith(bf_scene* s, int mode);

@@ -400,6 +400,28 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
 
 
+def test_bench_launches_its_own_ranks_and_refuses_a_mismatched_world():
+    """`python bench.py --gpus N` without a launcher around it starts N ranks itself (torch.distributed.run on 127.0.0.1) instead of measuring
+    one GPU under the label N; with a launcher whose world differs from --gpus it prints no line.  (--launch-check: the rendezvous over gloo
+    only, no GPU work.)"""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.launch_plan(1, {}, []) is None and bench.launch_plan(4, {"WORLD_SIZE": "4"}, []) is None
+    plan = bench.launch_plan(4, {}, ["--gpus", "4", "--steps", "20"])
+    assert plan[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in plan and plan[plan.index("--nproc-per-node") + 1] == "4"
+    assert plan[plan.index("--master-addr") + 1] == "127.0.0.1" and plan[-4:] == ["--gpus", "4", "--steps", "20"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": True, "n_gpus": 2}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "{" not in r.stdout and "mismatched" in r.stderr
+
+
 _POSEHELPER_CPP = r'''
 #include "bundlefusion/bundlefusion.hpp"
 using namespace bundlefusion;

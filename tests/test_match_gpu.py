@@ -80,12 +80,8 @@ def _chunk(gpu, n_frames, stride, first=30, w=640, h=480):
     return frames, K, sift, mgr, cache
 
 
-@pytest.mark.parametrize("kabsch_lanes", ["0", "1"])
-def test_match_and_filter_chain_bit_exact(gpu, oracle, monkeypatch, kabsch_lanes):
-    """kabsch_lanes = 1: the greedy Kabsch filter with the moment sums of every fit spread over lanes (BF_KABSCH_LANES, read when the manager is
-    created): one sum per lane, each in the sequential order - the same bits."""
+def test_match_and_filter_chain_bit_exact(gpu, oracle):
     import torch
-    monkeypatch.setenv("BF_KABSCH_LANES", kabsch_lanes)
     n_frames = 5
     frames, K, sift, mgr, cache = _chunk(gpu, n_frames, 5)
     Kinv = oracle.inverse44(K)

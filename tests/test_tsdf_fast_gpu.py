@@ -255,16 +255,12 @@ def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
     assert share(dw) < 5e-3 and share(ds > tol) < 2e-2 and share(dc > 1) < 2e-2
 
 
-_UNVERIFIED = pytest.mark.skipif(__import__("os").environ.get("BF_TEST_UNVERIFIED") != "1",
-                                 reason="variant written without GPU time left to run it (end of round 3): BF_TEST_UNVERIFIED=1 runs it, tools/gpu_r04a.sh")
-
-
-@pytest.mark.parametrize("variant", ["1", "2", "3", "full-stores", pytest.param("defer", marks=_UNVERIFIED)])
 @pytest.mark.parametrize("size", ["160x120@20mm", "640x480@4mm"])
-def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, size, variant):
-    """BF_APX_LDS=1 (k_update_apx_lds: the block's pixel footprint copied once per block and pose into LDS, samples outside the copied patch
-    gathered from memory as before) must not change ONE bit of the result of the fast contract: integrations, fused re-integrations with
-    translated and rotated poses (patches of different shapes), a de-integration, GC.  Variant 2 also loads all eight voxel slices of a block up front, variant 3 only the slices some lane has a valid sample for; `defer` is the gather kernel with a pair's voxel loads issued only behind a valid sample."""
+def test_fast_contract_deferred_voxel_loads_are_bit_identical(gpu, monkeypatch, size):
+    """The two forms of k_update_apx - voxel slices loaded only behind a valid sample (DEFER, the default) and loaded speculatively together with
+    the samples (BF_APX_DEFER=0) - must not differ in ONE bit: integrations, fused re-integrations with translated and rotated poses, a
+    de-integration, GC."""
+    variant = "defer"
     W, H = (160, 120) if size.startswith("160") else (640, 480)
     voxel = 0.02 if W == 160 else 0.004
     frames = [synth.scene_room(k * 9, W, H) for k in range(5)]
@@ -274,9 +270,7 @@ def test_fast_contract_lds_staged_footprint_is_bit_identical(gpu, monkeypatch, s
     dev = [_to_dev(f[0], f[1]) for f in frames]
     out = {}
     for lds in ("0", variant):
-        monkeypatch.setenv("BF_APX_LDS", lds if lds.isdigit() else "0")                 # both read when the scene is created
-        monkeypatch.setenv("BF_APX_FULL_STORES", "1" if lds == "full-stores" else "0")  # (whole voxel rows written back: an experiment on the write path)
-        monkeypatch.setenv("BF_APX_DEFER", "1" if lds == "defer" else "0")              # (voxel slices loaded only behind a valid sample)
+        monkeypatch.setenv("BF_APX_DEFER", "1" if lds == "defer" else "0")              # read when the scene is created
         gs = gpu.capi.SceneRepHashSDF(p); gs.set_arith("fast"); gs.set_overlap(True)
         poses = [f[2].copy() for f in frames]
         for i in range(len(frames)):
