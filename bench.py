@@ -59,6 +59,10 @@ def main():
                          "(-use_fast_math), 'exact' = IEEE op by op, bit-identical with the oracle")
     ap.add_argument("--both-contracts", action="store_true", default=True, help="(1 GPU) also measure the other contract, reported as other_contract")
     ap.add_argument("--one-contract", dest="both_contracts", action="store_false")
+    ap.add_argument("--solve-lag", type=int, default=int(os.environ.get("BF_BENCH_SOLVE_LAG", "0")),
+                    help="0: the reference's serial order (chunk solves inside the frame that closes the chunk).  L in 1..10: the chunk solves run on their own "
+                         "thread and stream and are applied exactly L frames later (bf_pipeline_set_solve_lag) - the reference's optimiser thread "
+                         "(FriedLiver.cpp:112-143) with a defined hand-over; same solves, same count, nothing skipped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the stream the CPU baseline processes (three local chunks: the last ten frames "
                     "run with the re-integration queue saturated, like the timed window of the GPU leg)")
@@ -187,6 +191,8 @@ def main():
         gas, gbs = params()
         pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
         pipe.scene().set_arith(arith)
+        if args.solve_lag and not chunked:
+            pipe.set_solve_lag(args.solve_lag)
         if shard_volume and world > 1:
             pipe.set_volume_shard(rank, world)
         runner = None
@@ -319,8 +325,11 @@ def main():
                 "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
                 "render_seconds_untimed": round(t_gen, 1),
                 "host_thread_ms_per_frame": {k: round(1e3 * v / max(hp["frames"], 1.0), 4) for k, v in hp.items() if k != "frames"},
-                "frame_loop": "serial order, detection of frame k+1 overlapped with matching/solve of frame k (BF_PIPELINE_LOOKAHEAD=%s)"
-                              % os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
+                "frame_loop": "two frames behind the input: the matching chain of frame k+1 is enqueued before frame k's result is read back, detection runs one frame "
+                              "further ahead (BF_PIPELINE_LOOKAHEAD=%s); chunk solves: %s" % (os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
+                              ("own thread + stream, applied exactly %d frames after the chunk's last frame (lagged mode)" % args.solve_lag) if (args.solve_lag and not chunked)
+                              else "serial order (inside the frame that closes the chunk)"),
+                "solve_lag": args.solve_lag if not chunked else 0,
                 "parallelism": ("one stream: local chunks round-robin over %d ranks, %d RCCL all-gathers of key-frame packages in the timed region, global half "
                                 "replicated, volume sharded by hash-bucket range; the timed window holds the global half of its %d frames and, on every rank, "
                                 "the chunk-local half of ONE whole chunk of the next round (%d of them ran here) - the steady state when steps == 10 x ranks, "

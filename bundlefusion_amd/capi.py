@@ -844,6 +844,16 @@ class Pipeline:
     def set_volume_shard(self, rank, world):
         check(lib.bf_pipeline_set_volume_shard(self._h, rank, world))
 
+    def set_solve_lag(self, lag):
+        """0: the reference's serial order (default).  1..s_submapSize: the chunk solves run on their own thread / stream and are applied exactly `lag`
+        frames after the frame that closed the chunk (bf_pipeline_set_solve_lag)."""
+        check(lib.bf_pipeline_set_solve_lag(self._h, int(lag)))
+
+    def solve_lag(self):
+        n = C.c_uint32()
+        check(lib.bf_pipeline_get_solve_lag(self._h, C.byref(n)))
+        return n.value
+
     def process_frame(self, depth, color):
         """depth float32 (H,W), color uint8 (H,W,4): host numpy arrays (PCIe path) or torch cuda tensors (HBM-resident path)."""
         got = C.c_int()

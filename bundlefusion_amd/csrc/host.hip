@@ -168,8 +168,15 @@ struct bf_image_manager {
     bool scratch = false;          // storeFramesOnGPU == 2: one frame slot that every process() overwrites (chunk workers keep no history)
     hipStream_t stream = nullptr;
     m44 depthIntrinsics, depthIntrinsicsInv, colorIntrinsics, colorIntrinsicsInv, depthExtrinsics, depthExtrinsicsInv, siftDepthIntrinsics;
+    // The ingest buffers at sensor resolution, TWO sets (frame parity): frame n + 1 can be ingested (on its own stream) while the feature detection of frame n
+    // still reads frame n's set.  d_depthInputRaw / d_depthInputFiltered / d_colorInput always name the set of the frame ingested last - what
+    // CUDAImageManager's members of these names hold after process().  inputGuard[k]: an event of the caller's that the ingest waits for before it
+    // overwrites set k (the consumer of the frame that used the set last), or null.
     float *d_depthInputRaw = nullptr, *d_depthInputFiltered = nullptr;
     uint8_t* d_colorInput = nullptr;
+    float *rawSet[2] = {nullptr, nullptr}, *filtSet[2] = {nullptr, nullptr};
+    uint8_t* colSet[2] = {nullptr, nullptr};
+    hipEvent_t inputGuard[2] = {nullptr, nullptr};
     // frames at integration resolution: slabs of SLAB frames in HBM (onGPU) or host vectors + one staging pair (reference default)
     static const uint32_t SLAB = 256;
     std::vector<float*> depthSlabs; std::vector<uint8_t*> colorSlabs;
@@ -197,9 +204,13 @@ int bf_image_manager_create(uint32_t wInt, uint32_t hInt, uint32_t wSIFT, uint32
     im->depthExtrinsics = toM(sensor->depthExtrinsics);
     im->depthExtrinsicsInv = inverse44(im->depthExtrinsics);
     const size_t nd = (size_t)sensor->depthWidth * sensor->depthHeight, nc = (size_t)sensor->colorWidth * sensor->colorHeight;
-    BF_HIP_TRY(hipMalloc((void**)&im->d_depthInputRaw, nd * 4));
-    BF_HIP_TRY(hipMalloc((void**)&im->d_depthInputFiltered, nd * 4));
-    BF_HIP_TRY(hipMalloc((void**)&im->d_colorInput, nc * 4));
+    for (int k = 0; k < (im->scratch ? 1 : 2); ++k) {
+        BF_HIP_TRY(hipMalloc((void**)&im->rawSet[k], nd * 4));
+        BF_HIP_TRY(hipMalloc((void**)&im->filtSet[k], nd * 4));
+        BF_HIP_TRY(hipMalloc((void**)&im->colSet[k], nc * 4));
+    }
+    if (im->scratch) { im->rawSet[1] = im->rawSet[0]; im->filtSet[1] = im->filtSet[0]; im->colSet[1] = im->colSet[0]; }
+    im->d_depthInputRaw = im->rawSet[0]; im->d_depthInputFiltered = im->filtSet[0]; im->d_colorInput = im->colSet[0];
     if (!im->onGPU) {
         BF_HIP_TRY(hipMalloc((void**)&im->d_stageDepth, im->nInt() * 4));
         BF_HIP_TRY(hipMalloc((void**)&im->d_stageColor, im->nInt() * 4));
@@ -222,13 +233,20 @@ int bf_image_manager_reset(bf_image_manager* im) {
 int bf_image_manager_destroy(bf_image_manager* im) {
     if (!im) return BF_OK;
     bf_image_manager_reset(im);
-    (void)hipFree(im->d_depthInputRaw); (void)hipFree(im->d_depthInputFiltered); (void)hipFree(im->d_colorInput);
+    for (int k = 0; k < (im->scratch ? 1 : 2); ++k) { (void)hipFree(im->rawSet[k]); (void)hipFree(im->filtSet[k]); (void)hipFree(im->colSet[k]); }
     (void)hipFree(im->d_stageDepth); (void)hipFree(im->d_stageColor);
     delete im;
     return BF_OK;
 }
 
 int bf_image_manager_set_stream(bf_image_manager* im, void* s) { BF_REQUIRE(im, "null manager"); im->stream = (hipStream_t)s; return BF_OK; }
+// see bf_image_manager::inputGuard: set k (0 / 1) is overwritten by frames of parity k; `hip_event` (or null) is recorded by whoever reads a frame's
+// input buffers on ANOTHER stream than the ingest's, after its last read
+int bf_image_manager_set_input_guard(bf_image_manager* im, uint32_t set, void* hip_event) {
+    BF_REQUIRE(im && set < 2, "bad argument");
+    im->inputGuard[set] = (hipEvent_t)hip_event;
+    return BF_OK;
+}
 
 static int im_process(bf_image_manager* im, const float* depth, const uint8_t* color, hipMemcpyKind kind, int* gotFrame) {
     BF_REQUIRE(im && gotFrame, "null argument");
@@ -252,6 +270,11 @@ static int im_process(bf_image_manager* im, const float* depth, const uint8_t* c
         frameColor = im->colorSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni * 4;
     } else {
         im->hostDepth.emplace_back(ni); im->hostColor.emplace_back(ni * 4);
+    }
+    {   // this frame's input set
+        const int k = (int)(im->currFrame & 1u);
+        if (im->inputGuard[k]) BF_HIP_TRY(hipStreamWaitEvent(st, im->inputGuard[k], 0));
+        im->d_depthInputRaw = im->rawSet[k]; im->d_depthInputFiltered = im->filtSet[k]; im->d_colorInput = im->colSet[k];
     }
     // ---- colour  (.cpp:39-60)
     BF_HIP_TRY(hipMemcpyAsync(im->d_colorInput, color, nc * 4, kind, st));
@@ -1014,7 +1037,7 @@ struct bf_online_bundler {
     std::vector<std::vector<int>> localTrajectoriesValid;
     std::vector<int> invalidImagesList;
     std::vector<m44> currIntegrateTransform;
-    m44* h_pinT = nullptr;
+    m44* h_pinT = nullptr;                 // two pinned slots, indexed by frame & 1 (two processInput calls may be in flight)
     // BundlerState (OnlineBundlerHelper.h:70-109)
     int lastFrameProcessed = -1; bool bLastFrameValid = false;
     int localToSolve = -1, lastLocalSolved = -1;
@@ -1031,8 +1054,31 @@ struct bf_online_bundler {
     hipStream_t detectStream = nullptr;
     hipEvent_t evDetect[2] = {nullptr, nullptr}, evStageFree[2] = {nullptr, nullptr};
     int stagedFrame[2] = {-1, -1};
-    // processInput in flight (between _begin and _end)
-    int pendPhase = 0; uint32_t pendFrame = 0, pendCur = 0, pendNum = 0; bool pendLastLocal = false, pendMatch = false;
+    // processInput calls in flight (between _begin and _end), oldest first.  Two deep: the matching chain of frame k + 1 is enqueued on the bundling
+    // stream BEHIND frame k's before the host waits for frame k's result - everything frame k + 1's chain needs of frame k is device state (key points,
+    // validity flags, the SIFT trajectory entry: the fix-up of an invalid frame, OnlineBundler.cpp:215-221, is the kernel k_sift_fixup).
+    struct Pend { int phase = 0; uint32_t frame = 0, cur = 0, num = 0; bool lastLocal = false, match = false, swapped = false; bf_bundler* b = nullptr; };
+    Pend pend[2];
+    int pendHead = 0, pendCount = 0;
+    // ---- lagged solve (bf_online_bundler_set_solve_lag): the chunk's solves (optimizeLocal + processGlobal + optimizeGlobal, OnlineBundler.cpp:229-240) run on
+    // their own host thread and stream, like the reference's optimiser thread (FriedLiver.cpp:112-123) - but their results become visible at a DEFINED
+    // frame: the solves started by chunk-closing frame b are applied when frame b + lag enters processInput (trajectory, last valid transform) and its
+    // re-integration scheduling (TrajectoryManager), never earlier and never later, so runs are reproducible and comparable with the oracle loop under the
+    // same lag (tests/oracle_pipeline.py: solve_lag).  lag = 0: the reference's serial order (the default).
+    uint32_t solveLag = 0;
+    hipStream_t sSolve = nullptr;          // stream of the solves: == stream when lag == 0
+    m44 *d_completeOut = nullptr, *d_completeShadow = nullptr;      // where k_update_trajectory writes: d_completeTrajectory itself (serial) or the shadow that is swapped in at apply time
+    hipEvent_t evChunk = nullptr;          // recorded on the bundling stream behind the chunk's last chain: the solve stream waits for it
+    struct Published { bool haveTraj = false; uint32_t numTotal = 0; bool setLastValid = false; uint32_t lastValid = 0; bool haveLost = false, trackingLost = false; std::vector<m44> complete; };
+    struct Job {
+        bool active = false, bundleApplied = false;
+        uint32_t applyAt = 0;              // first frame that sees the results
+        std::thread th; int rc = BF_OK; std::string message;
+        Published pub;
+        bf_bundler* chunk = nullptr;       // the optLocal the job works on (gets its stream back at apply time)
+    } job;
+    Published* pubTarget = nullptr;        // non-null while a job runs: obPublish stores here instead of applying
+    bool chunkClosed = false;              // prepareLocalSolve ran and its solves have not been started yet (main thread only; processState itself belongs to the solves)
     // chunk-parallel mode (bf_pipeline_process_frame_chunked): the local half of the chunk being closed comes from this package
     const bf_chunk_header* extChunk = nullptr;
     bool isLastLocalFrame(uint32_t curFrame) const { return curFrame >= submapSize && (curFrame % submapSize) == 0; }
@@ -1090,7 +1136,10 @@ int obAppendKeyFrame(bf_bundler* glob, const bf_chunk_header* h) {
     return BF_OK;
 }
 
-int obPrepareLocalSolve(bf_online_bundler* ob, uint32_t curFrame, bool isSequenceEnd) {            // OnlineBundler.cpp:134-165
+// `chunk`: the bundler that holds the chunk being closed (m_local at the time of the call in the reference); swap = false when processInput_begin has
+// already exchanged m_local / m_optLocal (it does so for a chunk's last frame, so that the next frame's chain can be enqueued before this frame's result
+// has been read back)
+int obPrepareLocalSolve(bf_online_bundler* ob, uint32_t curFrame, bool isSequenceEnd, bf_bundler* chunk, bool swap) {            // OnlineBundler.cpp:134-165
     ob->processState = bf_online_bundler::DO_NOTHING;
     uint32_t curLocalIdx = (std::max(curFrame, 1u) - 1) / ob->submapSize;
     if (isSequenceEnd && (curFrame % ob->submapSize) == 0) {
@@ -1099,11 +1148,37 @@ int obPrepareLocalSolve(bf_online_bundler* ob, uint32_t curFrame, bool isSequenc
         ob->processState = bf_online_bundler::INVALIDATE;
     } else {
         int valid = 0;
-        BF_TRY(bf_bundler_is_valid(ob->local, &valid));
+        BF_TRY(bf_bundler_is_valid(chunk, &valid));
         if (valid) { ob->localToSolve = (int)curLocalIdx; ob->processState = bf_online_bundler::PROCESS; }
         else { ob->localToSolve = -((int)curLocalIdx + ID_MARK_OFFSET); ob->processState = bf_online_bundler::INVALIDATE; }
     }
-    std::swap(ob->local, ob->optLocal);
+    if (swap) std::swap(ob->local, ob->optLocal);
+    ob->chunkClosed = true;
+    return BF_OK;
+}
+
+void obSetTrackingLost(bf_online_bundler* ob, bool v) {
+    if (ob->pubTarget) { ob->pubTarget->haveLost = true; ob->pubTarget->trackingLost = v; }
+    else ob->bGlobalTrackingLost = v;
+}
+
+// what a global optimisation makes visible to the frame loop (OnlineBundler.cpp:394-401): the complete trajectory (already written to d_completeOut by
+// obUpdateTrajectory) in the TrajectoryManager, the number of complete transforms and - after a valid solve - the last valid complete transform.
+// Serial order: at once.  Inside a lagged job: stored, applied by obApplyBundleSide / obApplyTmSide at the job's frame.
+int obPublishTrajectory(bf_online_bundler* ob, uint32_t numTotalFrames, bool setLastValid, uint32_t lastValid) {
+    if (ob->pubTarget) {
+        bf_online_bundler::Published& P = *ob->pubTarget;
+        P.haveTraj = true; P.numTotal = numTotalFrames; P.setLastValid = setLastValid; P.lastValid = lastValid;
+        P.complete.resize(numTotalFrames);
+        if (numTotalFrames) {
+            BF_HIP_TRY(hipMemcpyAsync(P.complete.data(), ob->d_completeOut, sizeof(m44) * numTotalFrames, hipMemcpyDeviceToHost, ob->sSolve));
+            BF_HIP_TRY(hipStreamSynchronize(ob->sSolve));
+        }
+        return BF_OK;
+    }
+    BF_TRY(bf_trajectory_manager_update_optimized_transform(ob->tm, (const float*)ob->d_completeTrajectory, numTotalFrames, ob->sSolve));
+    ob->numCompleteTransforms = numTotalFrames;
+    if (setLastValid) ob->lastValidCompleteTransform = lastValid;
     return BF_OK;
 }
 
@@ -1123,9 +1198,9 @@ int obOptimizeLocal(bf_online_bundler* ob, uint32_t numNonLin, uint32_t numLin) 
         ob->numLocalSolves++;
         if (valid) {
             if (ob->extChunk) BF_HIP_TRY(hipMemcpyAsync(ob->d_localTrajectories + (size_t)(ob->submapSize + 1) * curLocalIdx, ob->extChunk->localTrajectory,
-                                                        sizeof(m44) * (ob->submapSize + 1), hipMemcpyHostToDevice, ob->stream));
+                                                        sizeof(m44) * (ob->submapSize + 1), hipMemcpyHostToDevice, ob->sSolve));
             else BF_HIP_TRY(hipMemcpyAsync(ob->d_localTrajectories + (size_t)(ob->submapSize + 1) * curLocalIdx, ob->optLocal->d_trajectory, sizeof(m44) * (ob->submapSize + 1),
-                                      hipMemcpyDeviceToDevice, ob->stream));
+                                      hipMemcpyDeviceToDevice, ob->sSolve));
             ob->processState = bf_online_bundler::PROCESS;
         } else ob->processState = bf_online_bundler::INVALIDATE;
     } else if (optLocalState == bf_online_bundler::INVALIDATE) {
@@ -1175,14 +1250,14 @@ int obProcessGlobal(bf_online_bundler* ob) {                                    
         uint32_t nGlob;
         BF_TRY(bf_bundler_get_num_frames(ob->global, &nGlob));
         BF_TRY(bf_init_next_global_transform((float*)ob->global->d_trajectory, nGlob, curGlobalFrame, (const float*)ob->d_localTrajectories, lastValidLocal,
-                                             ob->submapSize + 1, ob->stream));
+                                             ob->submapSize + 1, ob->sSolve));
         if (!ob->extChunk) BF_TRY(bf_bundler_reset(ob->optLocal));
         if (nGlob > 1) {
             uint32_t lastMatchedGlobal;
             BF_TRY(bf_bundler_match_and_filter(ob->global, &lastMatchedGlobal));
-            if (lastMatchedGlobal == 0xFFFFFFFFu) { ob->bGlobalTrackingLost = true; ob->processState = bf_online_bundler::INVALIDATE; }
+            if (lastMatchedGlobal == 0xFFFFFFFFu) { obSetTrackingLost(ob, true); ob->processState = bf_online_bundler::INVALIDATE; }
             else {
-                ob->bGlobalTrackingLost = false;
+                obSetTrackingLost(ob, false);
                 const uint32_t revalidateIdx = ob->global->revalidatedIdx;
                 if (revalidateIdx != 0xFFFFFFFFu) {
                     const std::vector<int>& validLocal = ob->localTrajectoriesValid[revalidateIdx];
@@ -1201,11 +1276,12 @@ int obProcessGlobal(bf_online_bundler* ob) {                                    
 }
 
 int obUpdateTrajectory(bf_online_bundler* ob, uint32_t curFrame) {                                    // :363-371
-    if (curFrame) BF_HIP_TRY(hipMemcpyAsync(ob->d_imageInvalidateList, ob->invalidImagesList.data(), sizeof(int) * curFrame, hipMemcpyHostToDevice, ob->stream));
+    if (curFrame) BF_HIP_TRY(hipMemcpyAsync(ob->d_imageInvalidateList, ob->invalidImagesList.data(), sizeof(int) * curFrame, hipMemcpyHostToDevice, ob->sSolve));
     uint32_t nGlob;
     BF_TRY(bf_bundler_get_num_frames(ob->global, &nGlob));
-    return bf_update_trajectory((const float*)ob->global->d_trajectory, nGlob, (float*)ob->d_completeTrajectory, curFrame, (const float*)ob->d_localTrajectories,
-                                ob->submapSize + 1, nGlob, ob->d_imageInvalidateList, ob->stream);
+    ob->d_completeOut = ob->pubTarget ? ob->d_completeShadow : ob->d_completeTrajectory;      // a lagged job writes the shadow; it is swapped in at the job's frame
+    return bf_update_trajectory((const float*)ob->global->d_trajectory, nGlob, (float*)ob->d_completeOut, curFrame, (const float*)ob->d_localTrajectories,
+                                ob->submapSize + 1, nGlob, ob->d_imageInvalidateList, ob->sSolve);
 }
 
 int obOptimizeGlobal(bf_online_bundler* ob, uint32_t numNonLin, uint32_t numLin) {                   // :373-408
@@ -1230,15 +1306,12 @@ int obOptimizeGlobal(bf_online_bundler* ob, uint32_t numNonLin, uint32_t numLin)
             for (uint32_t i = 0; i < nGlob; ++i) if (v[i] == 0) ob->invalidateImages(i * ob->submapSize, std::min((i + 1) * ob->submapSize, numTotalFrames));
         }
         BF_TRY(obUpdateTrajectory(ob, numTotalFrames));
-        BF_TRY(bf_trajectory_manager_update_optimized_transform(ob->tm, (const float*)ob->d_completeTrajectory, numTotalFrames, ob->stream));
-        ob->numCompleteTransforms = numTotalFrames;
-        if (valid) ob->lastValidCompleteTransform = ob->submapSize * (uint32_t)ob->lastLocalSolved;
+        BF_TRY(obPublishTrajectory(ob, numTotalFrames, valid != 0, ob->submapSize * (uint32_t)ob->lastLocalSolved));
     } else if (state == bf_online_bundler::INVALIDATE) {
         BF_TRY(bf_bundler_invalidate_last_frame(ob->global));
         ob->invalidateImages(ob->submapSize * (uint32_t)ob->lastLocalSolved, ob->totalNumOptLocalFrames);
         BF_TRY(obUpdateTrajectory(ob, numTotalFrames));
-        BF_TRY(bf_trajectory_manager_update_optimized_transform(ob->tm, (const float*)ob->d_completeTrajectory, numTotalFrames, ob->stream));
-        ob->numCompleteTransforms = numTotalFrames;
+        BF_TRY(obPublishTrajectory(ob, numTotalFrames, false, 0));
     }
     ob->processState = bf_online_bundler::DO_NOTHING;
     return BF_OK;
@@ -1282,7 +1355,10 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
     BF_HIP_TRY(hipMalloc((void**)&ob->d_siftTrajectory, sizeof(m44) * nAll));
     BF_HIP_TRY(hipMalloc((void**)&ob->d_currIntegrateTransform, sizeof(m44) * nAll));
     BF_HIP_TRY(hipMalloc((void**)&ob->d_imageInvalidateList, sizeof(int) * nAll));
-    BF_HIP_TRY(hipHostMalloc((void**)&ob->h_pinT, sizeof(m44)));
+    BF_HIP_TRY(hipHostMalloc((void**)&ob->h_pinT, 2 * sizeof(m44)));
+    BF_HIP_TRY(hipMalloc((void**)&ob->d_completeShadow, sizeof(m44) * nAll));
+    BF_HIP_TRY(hipMemset(ob->d_completeShadow, 0, sizeof(m44) * nAll));
+    BF_HIP_TRY(hipEventCreateWithFlags(&ob->evChunk, hipEventDisableTiming));
     k_fill_identity<<<div_up((uint32_t)(maxNumImages * (S + 1)), 64), 64>>>(ob->d_localTrajectories, maxNumImages * (S + 1));
     k_fill_identity<<<1, 64>>>(ob->d_siftTrajectory, 1);
     k_fill_identity<<<1, 64>>>(ob->d_currIntegrateTransform, 1);
@@ -1298,6 +1374,9 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
 
 int bf_online_bundler_destroy(bf_online_bundler* ob) {
     if (!ob) return BF_OK;
+    if (ob->job.th.joinable()) ob->job.th.join();
+    (void)hipFree(ob->d_completeShadow);
+    if (ob->evChunk) (void)hipEventDestroy(ob->evChunk);
     bf_bundler_destroy(ob->local); bf_bundler_destroy(ob->optLocal); bf_bundler_destroy(ob->global); bf_bundler_destroy(ob->stage); bf_trajectory_manager_destroy(ob->tm);
     for (int k = 0; k < 2; ++k) { if (ob->evDetect[k]) (void)hipEventDestroy(ob->evDetect[k]); if (ob->evStageFree[k]) (void)hipEventDestroy(ob->evStageFree[k]); }
     (void)hipFree(ob->d_intensitySIFT); (void)hipFree(ob->d_intensityFilterHelper); (void)hipFree(ob->d_completeTrajectory); (void)hipFree(ob->d_localTrajectories);
@@ -1309,10 +1388,27 @@ int bf_online_bundler_destroy(bf_online_bundler* ob) {
 
 int bf_online_bundler_set_stream(bf_online_bundler* ob, void* s) {
     BF_REQUIRE(ob, "null bundler");
+    BF_REQUIRE(!ob->job.active && ob->pendCount == 0, "set_stream with work in flight");
     ob->stream = (hipStream_t)s;
-    BF_TRY(bf_bundler_set_stream(ob->local, s)); BF_TRY(bf_bundler_set_stream(ob->optLocal, s)); BF_TRY(bf_bundler_set_stream(ob->global, s));
+    BF_TRY(bf_bundler_set_stream(ob->local, s)); BF_TRY(bf_bundler_set_stream(ob->optLocal, s));
+    if (ob->solveLag == 0) { ob->sSolve = ob->stream; BF_TRY(bf_bundler_set_stream(ob->global, s)); }
     return BF_OK;
 }
+
+// Lagged solve (see the struct): lag in [1, s_submapSize] frames, on `solveStream` (a stream of the caller's, other than the bundling stream).  lag = 0
+// returns to the serial order.  Only between frames, with nothing in flight.
+int bf_online_bundler_set_solve_lag(bf_online_bundler* ob, uint32_t lag, void* solveStream) {
+    BF_REQUIRE(ob, "null bundler");
+    BF_REQUIRE(!ob->job.active && ob->pendCount == 0, "set_solve_lag with work in flight");
+    BF_REQUIRE(lag <= ob->submapSize, "the solve lag cannot exceed s_submapSize (the next chunk needs the optimiser's bundler back)");
+    BF_REQUIRE(lag == 0 || (solveStream && (hipStream_t)solveStream != ob->stream), "a lagged solve needs its own stream");
+    BF_HIP_TRY(hipStreamSynchronize(ob->stream));
+    if (ob->sSolve && ob->sSolve != ob->stream) BF_HIP_TRY(hipStreamSynchronize(ob->sSolve));
+    ob->solveLag = lag;
+    ob->sSolve = lag ? (hipStream_t)solveStream : ob->stream;
+    return bf_bundler_set_stream(ob->global, ob->sSolve);
+}
+int bf_online_bundler_get_solve_lag(bf_online_bundler* ob, uint32_t* lag) { BF_REQUIRE(ob && lag, "null argument"); *lag = ob->solveLag; return BF_OK; }
 
 // processInput (:167-227) in two halves: _begin enqueues everything up to the frame read-back, _end fetches the result and
 // finishes the host logic.  A caller may enqueue independent work (the re-integration of old frames on another stream)
@@ -1325,13 +1421,18 @@ int bf_online_bundler_set_detect_stream(bf_online_bundler* ob, void* s) {
 
 // Feature detection + dense cache frame of the image manager's current frame, into staging slot (frame & 1), on the detect
 // stream (which must also be the image manager's stream, so that it is ordered after the ingest).  No bundler state changes.
-int bf_online_bundler_detect_ahead(bf_online_bundler* ob) {
+int bf_online_bundler_detect_ahead(bf_online_bundler* ob) { return bf_online_bundler_detect_ahead_after(ob, nullptr); }
+
+// ... with the ingest on ANOTHER stream than the detect stream: `ingest_event` was recorded behind the frame's ingest.  The detection's own completion
+// event of the slot (frame parity) doubles as the guard of the image manager's input set of that parity (bf_image_manager_set_input_guard).
+int bf_online_bundler_detect_ahead_after(bf_online_bundler* ob, void* ingest_event) {
     BF_REQUIRE(ob && ob->detectStream, "detect_ahead needs bf_online_bundler_set_detect_stream");
     uint32_t frame;
     BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &frame));
     const int slot = (int)(frame & 1u);
     BF_REQUIRE(ob->stagedFrame[slot] < 0, "staging slot still holds an uncommitted frame");
     hipStream_t sd = ob->detectStream;
+    if (ingest_event) BF_HIP_TRY(hipStreamWaitEvent(sd, (hipEvent_t)ingest_event, 0));
     BF_HIP_TRY(hipStreamWaitEvent(sd, ob->evStageFree[slot], 0));          // the commit that last read this slot
     BF_TRY(bf_image_resample_to_intensity(ob->d_intensitySIFT, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, sd));
     if (ob->gas.s_colorFilter) {
@@ -1405,11 +1506,83 @@ int bf_online_bundler_process_input_begin(bf_online_bundler* ob) {
     return bf_online_bundler_process_input_begin_frame(ob, curFrame);
 }
 
+}  // extern "C"
+
+namespace {
+
+// OnlineBundler.cpp:215-221 on the device: a frame without a connection keeps the previous frame's SIFT pose
+__global__ void k_sift_fixup(const int32_t* frameResult, m44* siftTrajectory, uint32_t curFrameIndexAll) {
+    if (frameResult[1] == 0) siftTrajectory[curFrameIndexAll] = siftTrajectory[curFrameIndexAll - 1];
+}
+
+// ---- lagged solve: job = optimizeLocal + processGlobal + optimizeGlobal of one chunk, on the solve stream and its own host thread
+int obWaitJob(bf_online_bundler* ob) {                     // the job's work is complete (nothing is applied)
+    if (ob->job.th.joinable()) ob->job.th.join();
+    if (ob->job.active && ob->job.rc != BF_OK) { set_error("lagged solve: %s", ob->job.message.c_str()); return ob->job.rc; }
+    return BF_OK;
+}
+
+// what frame `frame`'s processInput sees of a finished job: the complete trajectory and the last valid complete transform (k_sift_transform's inputs)
+int obApplyBundleSide(bf_online_bundler* ob, uint32_t frame, bool force) {
+    if (!ob->job.active || ob->job.bundleApplied || (!force && frame < ob->job.applyAt)) return BF_OK;
+    BF_TRY(obWaitJob(ob));
+    const bf_online_bundler::Published& P = ob->job.pub;
+    if (P.haveTraj) {
+        std::swap(ob->d_completeTrajectory, ob->d_completeShadow);       // the job wrote every entry [0, numTotal) of the shadow; entries beyond are never read
+        ob->numCompleteTransforms = P.numTotal;
+        if (P.setLastValid) ob->lastValidCompleteTransform = P.lastValid;
+    }
+    BF_TRY(bf_bundler_set_stream(ob->job.chunk, ob->stream));             // the optimiser's bundler (reset by the job) goes back to the bundling stream
+    ob->job.bundleApplied = true;
+    return BF_OK;
+}
+// ... and what its re-integration scheduling sees: the optimised poses in the TrajectoryManager
+int obApplyTmSide(bf_online_bundler* ob, uint32_t frame, bool force) {
+    if (!ob->job.active || (!force && frame < ob->job.applyAt)) return BF_OK;
+    BF_TRY(obApplyBundleSide(ob, frame, true));
+    const bf_online_bundler::Published& P = ob->job.pub;
+    if (P.haveTraj) BF_TRY(bf_trajectory_manager_update_optimized_transform_host(ob->tm, (const float*)P.complete.data(), P.numTotal));
+    if (P.haveLost) ob->bGlobalTrackingLost = P.trackingLost;
+    ob->job.active = false;
+    return BF_OK;
+}
+
+int obSolves(bf_online_bundler* ob, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
+    BF_TRY(obOptimizeLocal(ob, nlLocal, linLocal));
+    BF_TRY(obProcessGlobal(ob));
+    return obOptimizeGlobal(ob, nlGlobal, linGlobal);
+}
+
+int obStartJob(bf_online_bundler* ob, uint32_t frame, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
+    BF_REQUIRE(!ob->job.active, "the previous chunk's lagged solve has not been applied yet (lag > s_submapSize?)");
+    bf_online_bundler::Job& J = ob->job;
+    J.active = true; J.bundleApplied = false; J.applyAt = frame + ob->solveLag; J.rc = BF_OK; J.message.clear();
+    J.pub = bf_online_bundler::Published();
+    J.chunk = ob->optLocal;
+    BF_TRY(bf_bundler_set_stream(ob->optLocal, ob->sSolve));
+    BF_HIP_TRY(hipStreamWaitEvent(ob->sSolve, ob->evChunk, 0));           // the chunk's chains (bundling stream) before the solve reads the chunk
+    ob->pubTarget = &J.pub;
+    int dev = 0;
+    BF_HIP_TRY(hipGetDevice(&dev));
+    J.th = std::thread([ob, dev, nlLocal, linLocal, nlGlobal, linGlobal] {
+        (void)hipSetDevice(dev);
+        int rc = obSolves(ob, nlLocal, linLocal, nlGlobal, linGlobal);
+        if (rc == BF_OK && hipStreamSynchronize(ob->sSolve) != hipSuccess) { set_error("solve stream failed"); rc = BF_ERR_HIP; }
+        if (rc != BF_OK) { ob->job.rc = rc; ob->job.message = bf_last_error(); }
+        ob->pubTarget = nullptr;
+    });
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 // processInput for an explicit frame: either the image manager's current frame (detected here, like the reference), or an
 // earlier frame whose detection was staged by bf_online_bundler_detect_ahead while newer frames were already ingested.
 int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t curFrame) {
     BF_REQUIRE(ob, "null bundler");
-    BF_REQUIRE(ob->pendPhase == 0, "processInput already in flight");
+    BF_REQUIRE(ob->pendCount < 2, "more than two processInput calls in flight");
     const bool staged = ob->stagedFrame[curFrame & 1u] == (int)curFrame;
     {
         uint32_t imFrame;
@@ -1417,9 +1590,13 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
         BF_REQUIRE(staged || imFrame == curFrame, "frame is neither staged nor the image manager's current frame");
     }
     const bool bIsLastLocal = ob->isLastLocalFrame(curFrame);
-    ob->pendFrame = curFrame; ob->pendLastLocal = bIsLastLocal; ob->pendMatch = false;
+    bf_online_bundler::Pend& P = ob->pend[(ob->pendHead + ob->pendCount) % 2];
+    P = bf_online_bundler::Pend();
+    P.frame = curFrame; P.lastLocal = bIsLastLocal; P.b = ob->local;
     if (curFrame > 0 && ob->lastFrameProcessed == (int)curFrame) {                 // sequence has ended
-        if (ob->numFramesPastEnd == 0 && ob->localToSolve == -1) { if (!bIsLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, true)); }
+        BF_REQUIRE(ob->pendCount == 0, "end-of-sequence iteration with a frame still in flight");
+        BF_TRY(obApplyTmSide(ob, curFrame, true));                                  // a lagged solve still pending is applied before the first iteration past the end
+        if (ob->numFramesPastEnd == 0 && ob->localToSolve == -1) { if (!bIsLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, true, ob->local, true)); }
         const uint32_t numSolveFramesBeforeExit = ob->gas.s_numSolveFramesBeforeExit;
         if (numSolveFramesBeforeExit != 0xFFFFFFFFu) {
             if (ob->numFramesPastEnd == numSolveFramesBeforeExit) {                 // USE_GLOBAL_DENSE_AT_END (GlobalBundlingState.h:9)
@@ -1432,9 +1609,11 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
             if (ob->numFramesPastEnd == numSolveFramesBeforeExit + 1) ob->bUseSolve = false;       // "stopping solve"
         }
         ob->numFramesPastEnd++;
-        ob->pendPhase = 2;                                                          // nothing to read back
+        P.phase = 2;                                                                // nothing to read back
+        ob->pendCount++;
         return BF_OK;
     }
+    BF_TRY(obApplyBundleSide(ob, curFrame, false));            // lagged solve: this is the frame that sees the new trajectory
     if (staged) BF_TRY(obCommitStaged(ob, curFrame));
     else {
         // getCurrentFrame (:106-116): luminance at SIFT resolution straight from the ingest buffer
@@ -1449,42 +1628,51 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
     uint32_t curLocalFrame;
     BF_TRY(bf_bundler_get_curr_frame_number(ob->local, &curLocalFrame));
     if (bIsLastLocal) BF_TRY(bf_bundler_copy_frame(ob->optLocal, ob->local, curLocalFrame));
-    ob->bLastFrameValid = true;
     if (curLocalFrame > 0) {
         // matchAndFilter + computeCurrentSiftTransform (:118-132) with ONE read-back: the pose kernel is enqueued before the frame
         // result is fetched (it writes nothing when no pair survived the filters, which is exactly the "invalid" case)
         uint32_t start;
-        BF_TRY(matchAndFilterEnqueue(ob->local, ob->pendCur, start, ob->pendNum));
-        const float* d_Tinv = nullptr; const int32_t* d_nf = nullptr;
+        BF_TRY(matchAndFilterEnqueue(ob->local, P.cur, start, P.num));
+        const float* d_Tinv = nullptr; const int32_t* d_nf = nullptr; const int32_t* d_res = nullptr;
         BF_TRY(bf_bundler_get_current_sift_transforms_gpu(ob->local, &d_Tinv));
         BF_TRY(bf_bundler_get_num_filt_matches_gpu(ob->local, &d_nf));
+        BF_TRY(bf_siftmgr_get_frame_result_gpu(ob->local->mgr, &d_res));
         BF_TRY(bf_compute_sift_transform(d_Tinv, d_nf, (const float*)ob->d_completeTrajectory, ob->lastValidCompleteTransform, (float*)ob->d_siftTrajectory, curFrame,
                                          curLocalFrame, (float*)(ob->d_currIntegrateTransform + curFrame), ob->stream));
-        BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT, ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
+        k_sift_fixup<<<1, 1, 0, ob->stream>>>(d_res, ob->d_siftTrajectory, curFrame);
+        BF_HIP_TRY(hipGetLastError());
+        BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT + (curFrame & 1u), ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
         BF_TRY(bf_siftmgr_prefetch_frame_result(ob->local->mgr));      // the read-back itself is enqueued now; _end only waits for it
-        ob->pendMatch = true;
+        P.match = true;
     }
-    ob->pendPhase = 1;
+    if (bIsLastLocal) {
+        // the chunk is complete on the device: from here on m_local is the next chunk (which starts with a copy of this frame) - the exchange of
+        // prepareLocalSolve (:164), done now so that the next frame's chain can be enqueued before this frame's result is back
+        BF_HIP_TRY(hipEventRecord(ob->evChunk, ob->stream));
+        std::swap(ob->local, ob->optLocal);
+        P.swapped = true;
+    }
+    P.phase = 1;
+    ob->pendCount++;
     return BF_OK;
 }
 
 int bf_online_bundler_process_input_end(bf_online_bundler* ob) {
     BF_REQUIRE(ob, "null bundler");
-    BF_REQUIRE(ob->pendPhase != 0, "process_input_end without process_input_begin");
-    const int phase = ob->pendPhase;
-    ob->pendPhase = 0;
-    if (phase == 2) return BF_OK;
-    const uint32_t curFrame = ob->pendFrame;
-    if (ob->pendMatch) {
+    BF_REQUIRE(ob->pendCount > 0, "process_input_end without process_input_begin");
+    const bf_online_bundler::Pend P = ob->pend[ob->pendHead];
+    ob->pendHead = (ob->pendHead + 1) % 2; ob->pendCount--;
+    if (P.phase == 2) return BF_OK;
+    const uint32_t curFrame = P.frame;
+    ob->bLastFrameValid = true;
+    if (P.match) {
         uint32_t last;
-        BF_TRY(matchAndFilterFinish(ob->local, ob->pendCur, ob->pendNum, &last));
+        BF_TRY(matchAndFilterFinish(P.b, P.cur, P.num, &last));
         ob->bLastFrameValid = last != 0xFFFFFFFFu;
-        if (!ob->bLastFrameValid) {
-            ob->currIntegrateTransform[curFrame] = minfM();
-            BF_HIP_TRY(hipMemcpyAsync(ob->d_siftTrajectory + curFrame, ob->d_siftTrajectory + curFrame - 1, sizeof(m44), hipMemcpyDeviceToDevice, ob->stream));
-        } else ob->currIntegrateTransform[curFrame] = *ob->h_pinT;
+        if (!ob->bLastFrameValid) ob->currIntegrateTransform[curFrame] = minfM();      // (the SIFT trajectory entry was fixed up on the device: k_sift_fixup)
+        else ob->currIntegrateTransform[curFrame] = ob->h_pinT[curFrame & 1u];
     }
-    if (ob->pendLastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, false));
+    if (P.lastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, false, P.b, !P.swapped));
     ob->lastFrameProcessed = (int)curFrame;
     return BF_OK;
 }
@@ -1494,14 +1682,35 @@ int bf_online_bundler_process_input(bf_online_bundler* ob) {                    
     return bf_online_bundler_process_input_end(ob);
 }
 
-int bf_online_bundler_process(bf_online_bundler* ob, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
+// `frame`: the frame whose body this is (only used by the lagged mode, to stamp the job)
+int bf_online_bundler_process_frame(bf_online_bundler* ob, uint32_t frame, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
     BF_REQUIRE(ob, "null bundler");
     if (!ob->bUseSolve) return BF_OK;
-    BF_TRY(obOptimizeLocal(ob, nlLocal, linLocal));
-    BF_TRY(obProcessGlobal(ob));
-    BF_TRY(obOptimizeGlobal(ob, nlGlobal, linGlobal));
-    return BF_OK;
+    if (ob->solveLag > 0 && ob->numFramesPastEnd == 0 && !ob->extChunk) {
+        if (!ob->chunkClosed) return BF_OK;              // process() does nothing between chunk ends (processState is not read here: a running job owns it)
+        ob->chunkClosed = false;
+        return obStartJob(ob, frame, nlLocal, linLocal, nlGlobal, linGlobal);
+    }
+    ob->chunkClosed = false;
+    if (ob->solveLag > 0) {       // past the end of the sequence the solves run in the serial order (on the solve stream, from this thread)
+        BF_TRY(obApplyTmSide(ob, frame, true));
+        BF_HIP_TRY(hipStreamSynchronize(ob->stream));
+        BF_TRY(obSolves(ob, nlLocal, linLocal, nlGlobal, linGlobal));
+        BF_HIP_TRY(hipStreamSynchronize(ob->sSolve));
+        return BF_OK;
+    }
+    return obSolves(ob, nlLocal, linLocal, nlGlobal, linGlobal);
 }
+
+int bf_online_bundler_process(bf_online_bundler* ob, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
+    BF_REQUIRE(ob, "null bundler");
+    return bf_online_bundler_process_frame(ob, ob->lastFrameProcessed >= 0 ? (uint32_t)ob->lastFrameProcessed : 0u, nlLocal, linLocal, nlGlobal, linGlobal);
+}
+
+// lagged mode: what frame `frame`'s re-integration scheduling has to see (call before the TrajectoryManager is consulted for that frame)
+int bf_online_bundler_apply_lagged_solve(bf_online_bundler* ob, uint32_t frame) { BF_REQUIRE(ob, "null bundler"); return obApplyTmSide(ob, frame, false); }
+// ... and: the solve thread has finished what it was given (nothing becomes visible earlier than its frame)
+int bf_online_bundler_wait_solves(bf_online_bundler* ob) { BF_REQUIRE(ob, "null bundler"); return obWaitJob(ob); }
 
 int bf_online_bundler_get_current_integration_frame(bf_online_bundler* ob, float siftTransform[16], uint32_t* frameIdx, int* bGlobalTrackingLost, int* valid) {
     BF_REQUIRE(ob && siftTransform && frameIdx && bGlobalTrackingLost && valid, "null argument");
@@ -1558,8 +1767,15 @@ struct bf_pipeline {
     // first call that needs its result).  The per-frame work and its order are unchanged, so are the results.
     hipStream_t sDetect = nullptr;
     bool lookahead = true;
-    int deferred = -1;              // frame whose body has not run yet
-    bool deferredBegun = false;     // ... but whose matching chain is already enqueued (plBodyBegin ran in the call that delivered it)
+    // Two frames behind the input (round 4): the call that delivers frame n (1) enqueues the matching chain of frame n - 1 on the bundling stream - behind the
+    // chain of frame n - 2, which the previous call enqueued -, (2) ingests and detects frame n, (3) runs the body of frame n - 2: its match result was
+    // enqueued a whole call ago, so this thread normally does not wait for the GPU any more (round 3: 0.77 ms per frame of waiting for the chain it had
+    // just enqueued).  A chunk's last frame in the serial order is the exception: its solves change what the next frame's chain reads, so its body
+    // runs BEFORE that chain is enqueued (in the lagged mode there is no such dependence).
+    int deferred = -1;              // frame that has been detected; its matching chain is not enqueued yet
+    std::deque<uint32_t> begun;     // frames whose chain is enqueued and whose body has not run, oldest first (at most 2)
+    hipStream_t sSolve = nullptr;   // stream of the lagged solves (bf_pipeline_set_solve_lag)
+    hipStream_t sIngest = nullptr;  // the ingest filters of frame n + 1 run beside the detection of frame n (two input sets in the image manager)
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
@@ -1688,6 +1904,7 @@ int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
     hipStream_t sa = p->sBundle, sv = p->sVolume;
     const bool tm = p->timings;
     const int evSlot = got ? (int)(frame % bf_pipeline::NEV) : -1;
+    if (got) BF_TRY(bf_online_bundler_apply_lagged_solve(p->ob, frame));      // lagged mode: the frame that sees an earlier chunk's optimised poses
     // ---- fix old frames (volume stream; launches issued by the volume thread), concurrently with the feature pipeline
     double t0 = plNow();
     if (tm) (void)hipEventRecord(p->ev[4], sv);
@@ -1714,8 +1931,8 @@ int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
     if (tm) (void)hipEventRecord(p->ev[7], sv);
     t1 = plNow(); p->hostProfile[4] += t1 - t0; t0 = t1;
     // ---- bundling optimisation (bundling stream)
-    BF_TRY(bf_online_bundler_process(p->ob, p->gbs.s_numLocalNonLinIterations, p->gbs.s_numLocalLinIterations, p->ob->gbs.s_numGlobalNonLinIterations,
-                                     p->gbs.s_numGlobalLinIterations));
+    BF_TRY(bf_online_bundler_process_frame(p->ob, frame, p->gbs.s_numLocalNonLinIterations, p->gbs.s_numLocalLinIterations, p->ob->gbs.s_numGlobalNonLinIterations,
+                                           p->gbs.s_numGlobalLinIterations));
     p->hostProfile[5] += plNow() - t0;
     if (got) p->hostProfile[7] += 1.0;
     return BF_OK;
@@ -1726,25 +1943,42 @@ int plBody(bf_pipeline* p, uint32_t frame, bool got) {
     return plBodyRest(p, frame, got);
 }
 
-// run the body of the frame that is still waiting for it
+// does the body of `frame` have to run before the next frame's chain may be enqueued?  Serial order: yes for a chunk's last frame (its solves write the
+// trajectory and the last valid transform the next chain's pose kernel reads, and hand the optimiser's bundler back).  Lagged mode: never.
+bool plBodyBeforeNextChain(const bf_pipeline* p, uint32_t frame) {
+    return p->ob->solveLag == 0 && p->ob->isLastLocalFrame(frame);
+}
+
+int plRestFront(bf_pipeline* p) {
+    const uint32_t f = p->begun.front();
+    p->begun.pop_front();
+    return plBodyRest(p, f, true);
+}
+
+// run the bodies of all frames that are still waiting for theirs, in stream order
 int plFlush(bf_pipeline* p) {
-    if (p->deferred < 0) return BF_OK;
-    const uint32_t f = (uint32_t)p->deferred;
-    const bool begun = p->deferredBegun;
-    p->deferred = -1; p->deferredBegun = false;
-    if (begun) return plBodyRest(p, f, true);
-    return plBody(p, f, true);
+    while (!p->begun.empty()) BF_TRY(plRestFront(p));
+    if (p->deferred >= 0) {
+        const uint32_t f = (uint32_t)p->deferred;
+        p->deferred = -1;
+        BF_TRY(plBody(p, f, true));
+    }
+    return bf_online_bundler_wait_solves(p->ob);          // a lagged solve has finished (it is APPLIED at its frame, not here)
 }
 
 int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool device, bool haveInput, int* gotFrame) {
-    hipStream_t sa = p->sBundle, sd = p->sDetect;
+    hipStream_t sa = p->sBundle, sd = p->sIngest;
     const bool tm = p->timings;
-    const bool ahead = p->lookahead && !tm;
-    // ---- look-ahead: the previous frame's matching chain is enqueued first, so the GPU works on it while this thread issues
-    //      the ~35 launches of the new frame's ingest and detection
-    const int prev = ahead ? p->deferred : -1;
-    if (prev >= 0) { if (!p->deferredBegun) BF_TRY(plBodyBegin(p, (uint32_t)prev)); }
-    else BF_TRY(plFlush(p));
+    const bool ahead = p->lookahead && !tm && haveInput;
+    if (!ahead) BF_TRY(plFlush(p));
+    // ---- the detected frame's matching chain onto the bundling stream (behind the chain of the frame before it, whose result is still outstanding) ...
+    if (p->deferred >= 0) {
+        if (!p->begun.empty() && plBodyBeforeNextChain(p, p->begun.back())) { while (!p->begun.empty()) BF_TRY(plRestFront(p)); }
+        const uint32_t f = (uint32_t)p->deferred;
+        p->deferred = -1;
+        BF_TRY(plBodyBegin(p, f));
+        p->begun.push_back(f);
+    }
     // ---- read input (detect stream)
     const double tIn = plNow();
     if (tm) (void)hipEventRecord(p->ev[0], sd);
@@ -1752,14 +1986,17 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (haveInput) BF_TRY(device ? bf_image_manager_process_device(p->im, depth, color, &got) : bf_image_manager_process(p->im, depth, color, &got));
     const uint32_t frame = p->im->currFrame > 0 ? p->im->currFrame - 1 : 0;
     if (got) BF_HIP_TRY(hipEventRecord(p->evIngest[frame % bf_pipeline::NEV], sd));
-    if (tm) { (void)hipEventRecord(p->ev[1], sd); BF_HIP_TRY(hipStreamWaitEvent(sa, p->ev[1], 0)); (void)hipEventRecord(p->ev[8], sa); }
-    if (got) BF_TRY(bf_online_bundler_detect_ahead(p->ob));
+    if (got && !ahead) BF_HIP_TRY(hipStreamWaitEvent(sa, p->evIngest[frame % bf_pipeline::NEV], 0));      // the frame is detected on the bundling stream, from the ingest buffers
+    if (tm) { (void)hipEventRecord(p->ev[1], sd); (void)hipEventRecord(p->ev[8], sa); }
+    if (got && ahead) BF_TRY(bf_online_bundler_detect_ahead_after(p->ob, p->evIngest[frame % bf_pipeline::NEV]));
     p->hostProfile[1] += plNow() - tIn;
-    if (prev >= 0) { p->deferred = -1; p->deferredBegun = false; BF_TRY(plBodyRest(p, (uint32_t)prev, true)); }
-    if (ahead && got) {
-        p->deferred = (int)frame;
+    // ---- ... and the body of the oldest frame in flight, whose chain was enqueued by the previous call
+    while (p->begun.size() > 1) BF_TRY(plRestFront(p));
+    if (ahead && got) p->deferred = (int)frame;
+    else if (p->im->currFrame > 0) {
+        BF_TRY(plBody(p, frame, got != 0));
+        if (got) BF_HIP_TRY(hipStreamSynchronize(sa));      // (the detection read the frame's input set on the bundling stream: done before the set's next ingest, two frames on)
     }
-    else if (p->im->currFrame > 0) BF_TRY(plBody(p, frame, got != 0));
     if (tm) {
         (void)hipEventRecord(p->ev[3], sa);
         (void)hipEventSynchronize(p->ev[3]);
@@ -1818,13 +2055,17 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // 0.80 -> 0.69 ms while the voxel update slows 93.8 -> 126 us; frames/s 656 -> 655 / 648 / 623 / 565)
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sSolve, hipStreamNonBlocking, least));      // lagged solves: nothing waits for them for `lag` frames
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sIngest, hipStreamNonBlocking, greatest));
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
-    BF_TRY(bf_image_manager_set_stream(p->im, p->sDetect));
+    BF_TRY(bf_image_manager_set_stream(p->im, p->sIngest));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_online_bundler_set_detect_stream(p->ob, p->sDetect));
+    for (uint32_t k = 0; k < 2; ++k) BF_TRY(bf_image_manager_set_input_guard(p->im, k, p->ob->evDetect[k]));      // the staged detection of the frame that used the set last
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
+    if (const char* e = getenv("BF_PIPELINE_SOLVE_LAG")) BF_TRY(bf_online_bundler_set_solve_lag(p->ob, (uint32_t)atoi(e), p->sSolve));
     int dev = 0;
     BF_HIP_TRY(hipGetDevice(&dev));
     p->worker = std::thread([p, dev] { (void)hipSetDevice(dev); volWorker(p); });
@@ -1846,9 +2087,22 @@ int bf_pipeline_destroy(bf_pipeline* p) {
     if (p->sBundle) (void)hipStreamDestroy(p->sBundle);
     if (p->sVolume) (void)hipStreamDestroy(p->sVolume);
     if (p->sDetect) (void)hipStreamDestroy(p->sDetect);
+    if (p->sSolve) (void)hipStreamDestroy(p->sSolve);
+    if (p->sIngest) (void)hipStreamDestroy(p->sIngest);
     delete p;
     return BF_OK;
 }
+
+// Lagged solve (bf_online_bundler_set_solve_lag): the chunk solves leave the frame loop's critical path - they run on their own thread and stream and
+// their results are applied exactly `lag` frames after the frame that closed the chunk (1 <= lag <= s_submapSize; 0 = the reference's serial order,
+// the default).  The reference's own multi-threaded build runs them on a separate thread with no defined hand-over point (FriedLiver.cpp:112-143).
+int bf_pipeline_set_solve_lag(bf_pipeline* p, uint32_t lag) {
+    BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFlush(p));
+    BF_REQUIRE(!p->ob->job.active, "a lagged solve is still waiting for its frame");
+    return bf_online_bundler_set_solve_lag(p->ob, lag, p->sSolve);
+}
+int bf_pipeline_get_solve_lag(bf_pipeline* p, uint32_t* lag) { BF_REQUIRE(p && lag, "null argument"); return bf_online_bundler_get_solve_lag(p->ob, lag); }
 
 int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world) {
     BF_REQUIRE(p, "null pipeline");
@@ -1873,8 +2127,10 @@ int bf_pipeline_synchronize(bf_pipeline* p) {
     BF_REQUIRE(p, "null pipeline");
     BF_TRY(plFlush(p));
     BF_TRY(volDrain(p));
+    BF_HIP_TRY(hipStreamSynchronize(p->sIngest));
     BF_HIP_TRY(hipStreamSynchronize(p->sDetect));
     BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
+    BF_HIP_TRY(hipStreamSynchronize(p->sSolve));
     BF_HIP_TRY(hipStreamSynchronize(p->sVolume));
     return BF_OK;
 }
@@ -2087,7 +2343,8 @@ namespace {
 
 // processInput (:167-227) for a frame whose chunk-local results are in `pkg`
 int obProcessInputChunked(bf_online_bundler* ob, uint32_t curFrame, const bf_chunk_header* pkg, uint32_t localIdx) {
-    BF_REQUIRE(ob->pendPhase == 0, "processInput already in flight");
+    BF_REQUIRE(ob->pendCount == 0, "processInput already in flight");
+    BF_REQUIRE(ob->solveLag == 0, "chunked mode runs the global half in the serial order (no lagged solve)");
     BF_REQUIRE(pkg && pkg->magic == BF_CHUNK_MAGIC && pkg->submapSize == ob->submapSize, "bad chunk package");
     BF_REQUIRE(localIdx < pkg->numFrames && curFrame == pkg->chunkIndex * ob->submapSize + localIdx, "frame is not frame localIdx of the package's chunk");
     BF_REQUIRE(!(curFrame > 0 && ob->lastFrameProcessed == (int)curFrame), "chunked mode: the sequence end is driven by bf_pipeline_process_end_of_sequence");
@@ -2135,7 +2392,7 @@ int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, cons
     }
     BF_TRY(plFlush(p));                                         // (a pipeline is driven either serially or chunked; nothing is deferred in chunked mode)
     const bf_chunk_header* pkg = reinterpret_cast<const bf_chunk_header*>(h_package);
-    hipStream_t sd = p->sDetect;
+    hipStream_t sd = p->sIngest;
     // ---- read input: the ingest filters produce the frame that is integrated (CUDAImageManager::process); no detection on this rank
     int got = 0;
     BF_TRY(bf_image_manager_process_device(p->im, d_depth, d_color, &got));
@@ -2146,7 +2403,12 @@ int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, cons
     // ---- fix old frames, processInput, reconstruction of the current frame, bundling optimisation: plBodyRest with the package in place of m_local / m_optLocal
     p->ob->extChunk = pkg;
     int rc = obProcessInputChunked(p->ob, frame, pkg, localIdx);
-    if (rc == BF_OK) { p->ob->pendPhase = 2; rc = plBodyRest(p, frame, true); }      // phase 2: processInput already complete, _end has nothing to read back
+    if (rc == BF_OK) {           // phase 2: processInput already complete, _end has nothing to read back
+        bf_online_bundler::Pend& P = p->ob->pend[(p->ob->pendHead + p->ob->pendCount) % 2];
+        P = bf_online_bundler::Pend(); P.phase = 2; P.frame = frame;
+        p->ob->pendCount++;
+        rc = plBodyRest(p, frame, true);
+    }
     p->ob->extChunk = nullptr;
     BF_TRY(rc);
     BF_HIP_TRY(hipEventSynchronize(p->evIngest[frame % bf_pipeline::NEV]));

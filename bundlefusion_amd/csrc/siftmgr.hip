@@ -1095,11 +1095,15 @@ struct bf_siftmgr {
     int* d_numFilt = nullptr; float* d_fdist = nullptr; uint2* d_fidx = nullptr; m44* d_T = nullptr; m44* d_Tinv = nullptr;
     int* d_validImages = nullptr; int* d_validOpt = nullptr;
     bf_entry_j* d_glob = nullptr; uint2* d_globKeys = nullptr; int* d_globNum = nullptr;
-    FrameResult* d_res = nullptr; FrameResult* h_res = nullptr;
+    // the frame's single read-back.  Up to RES_SLOTS read-backs may be in flight (bf_siftmgr_prefetch_frame_result enqueues one behind the work issued so
+    // far, bf_siftmgr_sync_frame_result consumes the oldest): the frame loop enqueues the matching chain of frame k + 1 before it waits for frame k.
+    static constexpr int RES_SLOTS = 2;
+    FrameResult* d_res = nullptr; FrameResult* h_res = nullptr;      // h_res: RES_SLOTS pinned records
+    hipEvent_t evRes[RES_SLOTS] = {nullptr, nullptr};
+    int resHead = 0, resCount = 0;
     std::vector<int> validImages;
     uint32_t numImages = 0, currentImage = 0, globNumResiduals = 0;
     bool finalized = true;
-    bool resPrefetched = false;
     bool validDirty = false;          // host copy of the valid flags changed since the last upload
     std::deque<uint32_t> retry;
     // scratch of the device-side fuseToGlobal (allocated at first use)
@@ -1122,7 +1126,8 @@ int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_sift
         (rc = dalloc(m->d_glob, m->maxResiduals)) || (rc = dalloc(m->d_globKeys, m->maxResiduals)) || (rc = dalloc(m->d_globNum, 1)) || (rc = dalloc(m->d_res, 1))) {
         delete m; return rc;
     }
-    BF_HIP_TRY(hipHostMalloc((void**)&m->h_res, sizeof(FrameResult)));
+    BF_HIP_TRY(hipHostMalloc((void**)&m->h_res, sizeof(FrameResult) * bf_siftmgr::RES_SLOTS));
+    for (auto& e : m->evRes) BF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     BF_HIP_TRY(hipMemset(m->d_numKeys, 0, sizeof(int) * maxImages));
     BF_HIP_TRY(hipMemset(m->d_numMatches, 0, sizeof(int) * maxImages));
     BF_HIP_TRY(hipMemset(m->d_numFilt, 0, sizeof(int) * maxImages));
@@ -1143,6 +1148,7 @@ int bf_siftmgr_destroy(bf_siftmgr* m) {
     if (m->fuseScratch) hipFree(m->fuseScratch);
     if (m->d_fuseError) hipFree(m->d_fuseError);
     if (m->h_res) hipHostFree(m->h_res);
+    for (auto& e : m->evRes) if (e) (void)hipEventDestroy(e);
     delete m;
     return BF_OK;
 }
@@ -1262,30 +1268,41 @@ int bf_siftmgr_add_curr_to_residuals(bf_siftmgr* m, uint32_t curFrame, uint32_t 
     return BF_OK;
 }
 
-// enqueue the D2H of the frame result behind the work issued so far (optional; lets the caller do other things before it waits)
+// enqueue the D2H of the frame result behind the work issued so far (optional; lets the caller do other things - including enqueueing the NEXT
+// frame's chain on the same stream - before it waits)
 int bf_siftmgr_prefetch_frame_result(bf_siftmgr* m) {
     BF_REQUIRE(m, "null manager");
-    BF_HIP_TRY(hipMemcpyAsync(m->h_res, m->d_res, sizeof(FrameResult), hipMemcpyDeviceToHost, m->stream));
-    m->resPrefetched = true;
+    BF_REQUIRE(m->resCount < bf_siftmgr::RES_SLOTS, "too many frame results in flight");
+    const int slot = (m->resHead + m->resCount) % bf_siftmgr::RES_SLOTS;
+    BF_HIP_TRY(hipMemcpyAsync(m->h_res + slot, m->d_res, sizeof(FrameResult), hipMemcpyDeviceToHost, m->stream));
+    BF_HIP_TRY(hipEventRecord(m->evRes[slot], m->stream));
+    m->resCount++;
     return BF_OK;
 }
 
-// the frame's single read-back: last matched frame, validity, #residuals, #keys of the current frame
+// the frame's single read-back: last matched frame, validity, #residuals, #keys of the current frame.  Waits for the OLDEST prefetched result
+// (an event behind its copy, not the whole stream: later frames' work may already be queued behind it).
 int bf_siftmgr_sync_frame_result(bf_siftmgr* m, uint32_t curFrame, uint32_t* lastMatchedFrame, int32_t* numKeysCur) {
     BF_REQUIRE(m && curFrame < m->maxImages, "frame out of range");
-    if (!m->resPrefetched) BF_HIP_TRY(hipMemcpyAsync(m->h_res, m->d_res, sizeof(FrameResult), hipMemcpyDeviceToHost, m->stream));
-    m->resPrefetched = false;
-    BF_HIP_TRY(hipStreamSynchronize(m->stream));
-    m->validImages[curFrame] = m->h_res->valid;
-    m->globNumResiduals = (uint32_t)m->h_res->numResiduals;
-    if (lastMatchedFrame) *lastMatchedFrame = (uint32_t)m->h_res->lastMatched;
-    if (numKeysCur) *numKeysCur = m->h_res->numKeysCur;
+    if (m->resCount == 0) { const int rc = bf_siftmgr_prefetch_frame_result(m); if (rc != BF_OK) return rc; }
+    const int slot = m->resHead;
+    BF_HIP_TRY(hipEventSynchronize(m->evRes[slot]));
+    m->resHead = (m->resHead + 1) % bf_siftmgr::RES_SLOTS; m->resCount--;
+    const FrameResult r = m->h_res[slot];
+    m->validImages[curFrame] = r.valid;
+    m->globNumResiduals = (uint32_t)r.numResiduals;
+    if (lastMatchedFrame) *lastMatchedFrame = (uint32_t)r.lastMatched;
+    if (numKeysCur) *numKeysCur = r.numKeysCur;
     return BF_OK;
 }
+
+// the device record behind it, for kernels that act on a frame's result without a host round trip: 4 x int32 {lastMatched (-1: none), valid, numResiduals, numKeysCur}
+int bf_siftmgr_get_frame_result_gpu(bf_siftmgr* m, const int32_t** d_out) { BF_REQUIRE(m && d_out, "null argument"); *d_out = reinterpret_cast<const int32_t*>(m->d_res); return BF_OK; }
 
 int bf_siftmgr_filter_frames(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames, uint32_t* lastMatchedFrame) {
     BF_REQUIRE(lastMatchedFrame, "null output");
     if (numFrames == 0) { *lastMatchedFrame = 0xFFFFFFFFu; return BF_OK; }
+    BF_REQUIRE(m->resCount == 0, "a prefetched frame result is still pending");
     int rc = bf_siftmgr_filter_frames_async(m, curFrame, startFrame, numFrames);
     if (rc) return rc;
     BF_HIP_TRY(hipMemcpyAsync(m->h_res, m->d_res, sizeof(FrameResult), hipMemcpyDeviceToHost, m->stream));

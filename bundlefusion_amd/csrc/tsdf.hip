@@ -1240,10 +1240,13 @@ BF_DEV void apxSamples(const ApxCam& c, const ApxPose& pIn, const ApxPose& pDe, 
     }
 }
 
-BF_DEV void apxLoadVoxels(const ApxBlock& b, int z, ApxPair& o) {
+// the pair's two voxel slices (768 contiguous bytes each); ldA / ldB wave-uniform: a slice no lane has a valid sample for is not read (its registers
+// hold zeros that are computed on and never stored)
+BF_DEV void apxLoadVoxels(const ApxBlock& b, int z, ApxPair& o, bool ldA, bool ldB) {
     const uint32_t* vpA = b.base + (size_t)z * 64u * 3u; const uint32_t* vpB = vpA + 64u * 3u;
-    o.vS.x = __uint_as_float(vpA[0]); o.vW.x = __uint_as_float(vpA[1]); o.vCA = vpA[2];
-    o.vS.y = __uint_as_float(vpB[0]); o.vW.y = __uint_as_float(vpB[1]); o.vCB = vpB[2];
+    o.vS = sp2(0.0f); o.vW = sp2(0.0f); o.vCA = o.vCB = 0u;
+    if (ldA) { o.vS.x = __uint_as_float(vpA[0]); o.vW.x = __uint_as_float(vpA[1]); o.vCA = vpA[2]; }
+    if (ldB) { o.vS.y = __uint_as_float(vpB[0]); o.vW.y = __uint_as_float(vpB[1]); o.vCB = vpB[2]; }
 }
 
 // which voxels of a pair have a valid sample (the conditions of apxStageB, on the same values)
@@ -1322,8 +1325,8 @@ BF_DEV ApxEntry apxEntry(const Dev& d, uint32_t blk) {
 }
 
 // One wave per block of the frustum (or union) list, lane = (x, y) column, the eight z walked as four pairs.
-//   DEFER = true (the default since round 4): a pair's samples are gathered first and its two voxel slices are loaded only when some lane of the wave
-//     has a valid sample for one of them - two dependent round trips per touched pair, no voxel traffic at all for an untouched pair (about 2.5 of a
+//   DEFER = true (the default since round 4): a pair's samples are gathered first and each of its two voxel slices is loaded only when some lane of the wave
+//     has a valid sample for it - two dependent round trips per touched pair, no voxel traffic at all for an untouched slice (about 2.5 of a
 //     block's 8 slices are touched by no lane).  Measured against the other form in the bench window: 79.2 -> 73.4 us per fused launch, 708.7 -> 743.7
 //     frames/s (gpurun r04a, profiles/r04_update_variants.md).
 //   DEFER = false (BF_APX_DEFER=0): voxels are loaded speculatively together with the samples, one round trip per pair.
@@ -1351,13 +1354,14 @@ __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in,
 #pragma unroll 1
         for (int z = 0; z < 8; z += 2) {
             ApxPair pa;
-            if (!DEFER) apxLoadVoxels(cur, z, pa);
+            if (!DEFER) apxLoadVoxels(cur, z, pa, true, true);
             apxSamples<DE, IN>(c, in, de, cur, z, texRes, pa);
             if (DEFER) {
                 bool anyA, anyB;
                 apxTouched<DE, IN>(c, pa, anyA, anyB);
-                if (__builtin_amdgcn_ballot_w64(anyA || anyB) == 0ull) continue;          // wave-uniform: nothing of this pair is read or written
-                apxLoadVoxels(cur, z, pa);
+                const bool ldA = __builtin_amdgcn_ballot_w64(anyA) != 0ull, ldB = __builtin_amdgcn_ballot_w64(anyB) != 0ull;      // wave-uniform
+                if (!ldA && !ldB) continue;                                               // nothing of this pair is read or written
+                apxLoadVoxels(cur, z, pa, ldA, ldB);
             }
             apxStageB<DE, IN, RNE>(c, cur, z, pa);
         }

@@ -94,6 +94,18 @@ def _finish_depth(depth, max_depth=4.0, border=2):
 
 
 # ---------------------------------------------------------------- S1: relief wall
+def add_depth_noise(depth, seed=42):
+    """SURVEY.md 8d's optional sensor noise: Gaussian in depth with sigma_z = 0.0012 + 0.0019 (z - 0.4)^2 metres (the Kinect model the
+    survey names), from a seeded generator; invalid pixels (-inf) stay invalid.  Returns a new float32 array."""
+    rng = np.random.RandomState(seed)
+    d = np.asarray(depth, np.float32)
+    ok = np.isfinite(d)
+    z = np.where(ok, d, np.float32(0.0)).astype(np.float64)
+    sigma = 0.0012 + 0.0019 * (z - 0.4) ** 2
+    out = (z + rng.standard_normal(d.shape) * sigma).astype(np.float32)
+    return np.where(ok, out, d).astype(np.float32)
+
+
 def scene_wall(width=640, height=480):
     """S1: plane z = 2.0 + 0.10 sin(2 pi x/0.8) sin(2 pi y/0.6), albedo noise seed 1234; identity pose."""
     K = intrinsics(width, height)

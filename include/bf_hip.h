@@ -433,8 +433,13 @@ BF_API int bf_siftmgr_add_curr_to_residuals(bf_siftmgr* m, uint32_t curFrame, ui
                                             const float colorIntrinsicsInv[16]);
 BF_API int bf_siftmgr_sync_frame_result(bf_siftmgr* m, uint32_t curFrame, uint32_t* lastMatchedFrame,
                                         int32_t* numKeyPointsCur);
-/* optional: enqueue that read-back now (after filter_frames_async / add_curr_to_residuals); sync_frame_result then only waits */
+/* optional: enqueue that read-back now (after filter_frames_async / add_curr_to_residuals); sync_frame_result then only waits - for an
+ * event behind the copy, not for the stream: up to two read-backs may be in flight, so the next frame's chain can be enqueued on the same
+ * stream before the previous frame's result is consumed (results are consumed oldest first). */
 BF_API int bf_siftmgr_prefetch_frame_result(bf_siftmgr* m);
+/* the device record behind the read-back, for kernels that act on a frame's result without a host round trip:
+ * 4 x int32 {lastMatched (-1: none), valid, numResiduals, numKeysCur}, rewritten by every filter_frames_async / add_curr_to_residuals */
+BF_API int bf_siftmgr_get_frame_result_gpu(bf_siftmgr* m, const int32_t** d_frameResult);
 /* InvalidateImageToImageCU / CheckForInvalidFrames[Simple]CU   :692-795 */
 BF_API int bf_siftmgr_invalidate_image_to_image(bf_siftmgr* m, uint32_t imageIdx_i, uint32_t imageIdx_j);
 BF_API int bf_siftmgr_check_for_invalid_frames_simple(bf_siftmgr* m, const int32_t* d_varToCorrNumEntriesPerRow,

@@ -109,6 +109,11 @@ BF_API int bf_image_manager_create(uint32_t widthIntegration, uint32_t heightInt
                                    bf_image_manager** out);
 BF_API int bf_image_manager_destroy(bf_image_manager* im);
 BF_API int bf_image_manager_set_stream(bf_image_manager* im, void* hip_stream);
+/* MI355X addition: the ingest buffers at sensor resolution (d_depthInputRaw / d_depthInputFiltered / d_colorInput, CUDAImageManager.h:268-284) exist
+ * twice, by frame parity, so that frame n + 1 can be ingested on its own stream while frame n's buffers are still being read (feature detection on
+ * another stream).  `hip_event` (a hipEvent_t, or null) guards set `set` (0 / 1): process() waits for it before it overwrites the set; the consumer of
+ * a frame's buffers records it after its last read.  The accessors always name the set of the frame ingested last. */
+BF_API int bf_image_manager_set_input_guard(bf_image_manager* im, uint32_t set, void* hip_event);
 BF_API int bf_image_manager_reset(bf_image_manager* im);
 /* process()  .cpp:22-158.  h_depth = sensor->getDepthFloat() (metres, -inf invalid), h_colorRGBX = getColorRGBX().
  * *gotFrame = 0 when the frame capacity (s_maxNumImages * s_submapSize) is reached.
@@ -246,7 +251,11 @@ BF_API int bf_online_bundler_destroy(bf_online_bundler* ob);
 BF_API int bf_online_bundler_set_stream(bf_online_bundler* ob, void* hip_stream);
 BF_API int bf_online_bundler_process_input(bf_online_bundler* ob);                               /* processInput :167-227 */
 /* the same in two halves: _begin enqueues all device work of processInput, _end performs its single read-back and the host
- * logic; independent work (e.g. re-integration on another stream) may be enqueued in between */
+ * logic; independent work (e.g. re-integration on another stream) may be enqueued in between.  Up to TWO calls may be in flight
+ * (_begin(k), _begin(k+1), _end(k), ...; _end completes the oldest): everything frame k+1's matching chain needs of frame k is
+ * device state - the fix-up of an unconnected frame (OnlineBundler.cpp:215-221) is a kernel - so a host loop never has to wait
+ * for the chain it has just enqueued.  Exception in the serial order: for a chunk's last frame k, run _end(k) and process()
+ * before _begin(k+1) (its solves write what the next chain's pose kernel reads). */
 BF_API int bf_online_bundler_process_input_begin(bf_online_bundler* ob);
 BF_API int bf_online_bundler_process_input_end(bf_online_bundler* ob);
 /* Detect-ahead: feature detection and the dense cache frame depend only on a frame's pixels.  _detect_ahead computes them for the
@@ -256,9 +265,25 @@ BF_API int bf_online_bundler_process_input_end(bf_online_bundler* ob);
  * matching / solving of frame k (what the reference's bundling thread does with its one-frame lag, OnlineBundler.cpp:167). */
 BF_API int bf_online_bundler_set_detect_stream(bf_online_bundler* ob, void* hip_stream);
 BF_API int bf_online_bundler_detect_ahead(bf_online_bundler* ob);
+/* the same when the ingest runs on ANOTHER stream than the detect stream: `ingest_event` (a hipEvent_t) was recorded behind the frame's ingest */
+BF_API int bf_online_bundler_detect_ahead_after(bf_online_bundler* ob, void* ingest_event);
 BF_API int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t frame);
 BF_API int bf_online_bundler_process(bf_online_bundler* ob, uint32_t numNonLinItersLocal, uint32_t numLinItersLocal,
                                      uint32_t numNonLinItersGlobal, uint32_t numLinItersGlobal);  /* process :410-416 */
+/* process() for the body of an explicit frame (what a loop with frames in flight calls) */
+BF_API int bf_online_bundler_process_frame(bf_online_bundler* ob, uint32_t frame, uint32_t numNonLinItersLocal, uint32_t numLinItersLocal,
+                                           uint32_t numNonLinItersGlobal, uint32_t numLinItersGlobal);
+/* Lagged solve - the reference's optimiser thread (FriedLiver.cpp:112-143, ConditionManager.h:49-78) with a DEFINED hand-over point:
+ * with lag L in [1, s_submapSize], process() for a chunk-closing frame b only STARTS optimizeLocal + processGlobal + optimizeGlobal
+ * (OnlineBundler.cpp:242-408) on an own host thread and on `solve_stream`; what they publish - the complete trajectory, the last
+ * valid complete transform, the TrajectoryManager's optimised poses, the tracking-lost flag - becomes visible exactly when frame
+ * b + L enters processInput (_begin) / its re-integration scheduling (_apply_lagged_solve, which a host loop calls before it consults
+ * the TrajectoryManager for that frame), and at the first iteration past the end of the sequence at the latest.  Results are a function
+ * of (input, L): reproducible, and comparable with the oracle loop under the same L.  L = 0 (default): the serial order. */
+BF_API int bf_online_bundler_set_solve_lag(bf_online_bundler* ob, uint32_t lag, void* solve_stream);
+BF_API int bf_online_bundler_get_solve_lag(bf_online_bundler* ob, uint32_t* lag);
+BF_API int bf_online_bundler_apply_lagged_solve(bf_online_bundler* ob, uint32_t frame);
+BF_API int bf_online_bundler_wait_solves(bf_online_bundler* ob);
 /* getCurrentIntegrationFrame(siftTransform, frameIdx, bGlobalTrackingLost) -> valid  :229-240 */
 BF_API int bf_online_bundler_get_current_integration_frame(bf_online_bundler* ob, float siftTransform[16], uint32_t* frameIdx,
                                                            int* bGlobalTrackingLost, int* valid);
@@ -300,9 +325,15 @@ BF_API int bf_pipeline_destroy(bf_pipeline* p);
 /* Multi-GPU mode "volume shard": every rank runs the (bit-deterministic) bundling on the whole stream and integrates only
  * its hash-bucket shard of the volume (bf_scene_set_shard).  Call before the first frame. */
 BF_API int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world);
+/* Lagged solve for the whole loop (bf_online_bundler_set_solve_lag on a stream of the pipeline's): the chunk solves leave the frame
+ * loop's critical path and are applied `lag` frames after the frame that closed the chunk.  0 = serial order (default; also
+ * BF_PIPELINE_SOLVE_LAG in the environment).  Only between frames. */
+BF_API int bf_pipeline_set_solve_lag(bf_pipeline* p, uint32_t lag);
+BF_API int bf_pipeline_get_solve_lag(bf_pipeline* p, uint32_t* lag);
 /* one iteration of the frame loop with a new sensor frame (host or device resident).  The two buffers may be reused as soon as
- * the call returns.  With the look-ahead (default; BF_PIPELINE_LOOKAHEAD=0 disables it) matching / integration / solves of this
- * frame are completed by the next call, by bf_pipeline_synchronize or by any accessor below - results are those of the serial order. */
+ * the call returns.  With the look-ahead (default; BF_PIPELINE_LOOKAHEAD=0 disables it) the loop runs two frames behind its input:
+ * matching / integration / solves of this frame are completed by the call after the next, by bf_pipeline_synchronize or by any
+ * accessor below - results are those of the serial order. */
 BF_API int bf_pipeline_process_frame(bf_pipeline* p, const float* h_depth, const uint8_t* h_colorRGBX, int* gotFrame);
 BF_API int bf_pipeline_process_frame_device(bf_pipeline* p, const float* d_depth, const uint8_t* d_colorRGBX, int* gotFrame);
 /* one iteration after the sensor stopped delivering frames (solve + re-integration continue, :175-196) */

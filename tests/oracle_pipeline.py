@@ -424,9 +424,17 @@ def effective_cpus():
 
 
 class OraclePipeline:
-    """The serial frame loop on the CPU.  `gas`/`gbs` are the ctypes parameter structs of bundlefusion_amd.capi."""
+    """The serial frame loop on the CPU.  `gas`/`gbs` are the ctypes parameter structs of bundlefusion_amd.capi.
 
-    def __init__(self, gas, gbs, width, height, K):
+    solve_lag = L > 0 restates the product's lagged-solve mode (bf_pipeline_set_solve_lag; the reference runs its optimiser on a second thread
+    with no defined hand-over, FriedLiver.cpp:112-143): the solves of a chunk-closing frame b are computed where the serial loop computes them,
+    but what they publish - the complete trajectory, the last valid complete transform, the TrajectoryManager's optimised poses, the tracking-lost
+    flag - becomes visible when frame b + L enters the loop (and before the first iteration past the end of the sequence at the latest)."""
+
+    def __init__(self, gas, gbs, width, height, K, solve_lag=0):
+        self.solve_lag = solve_lag
+        self._pending = None                  # (apply_at, complete, n_total, last_valid_complete or None, tracking_lost or None)
+        self._stage = None                    # collects what the solves of the current frame publish (lagged mode)
         self.gas, self.gbs, self.W, self.H = gas, gbs, width, height
         self.K = np.array(K, np.float32)
         gas._depthW, gas._depthH = width, height                 # depth and colour cameras coincide in the synthetic sensor
@@ -611,9 +619,9 @@ class OraclePipeline:
             if ng > 1:
                 last = self.glob.match_and_filter()
                 if last == INVALID:
-                    self.tracking_lost = True; self.state = "INVALIDATE"
+                    self._set_tracking_lost(True); self.state = "INVALIDATE"
                 else:
-                    self.tracking_lost = False
+                    self._set_tracking_lost(False)
                     r = self.glob.revalidated_idx
                     if r != INVALID:
                         for i, v in enumerate(self.local_valid[r]):
@@ -627,13 +635,41 @@ class OraclePipeline:
             for i in range(S * self.last_local_solved, self.total_opt_local):
                 self.invalid_list[i] = 0
 
+    def _set_tracking_lost(self, v):
+        if self._stage is not None:
+            self._stage["lost"] = v
+        else:
+            self.tracking_lost = v
+
     def _update_trajectory(self, n):
         S = self.S
+        out = self.complete if self._stage is None else self.complete.copy()
         for i in range(n):
             if self.invalid_list[i] == 0:
-                self.complete[i] = _minf()
+                out[i] = _minf()
             else:
-                self.complete[i] = o.mul44(self.glob.trajectory[i // S], self.local_traj[(i // S) * (S + 1) + i % S])
+                out[i] = o.mul44(self.glob.trajectory[i // S], self.local_traj[(i // S) * (S + 1) + i % S])
+        return out
+
+    def _publish(self, complete, n_total, last_valid):
+        """What a global optimisation makes visible (OnlineBundler.cpp:394-401); last_valid None: unchanged."""
+        if self._stage is not None:
+            self._stage.update(complete=complete, n_total=n_total, last_valid=last_valid)
+            return
+        self.complete = complete
+        self.tm.update_optimized(self.complete, n_total)
+        self.num_complete = n_total
+        if last_valid is not None:
+            self.last_valid_complete = last_valid
+
+    def _apply_pending(self):
+        if self._pending is None:
+            return
+        st, self._pending = self._pending[1], None
+        if "complete" in st:
+            self._publish(st["complete"], st["n_total"], st["last_valid"])
+        if "lost" in st:
+            self.tracking_lost = st["lost"]
 
     def _optimize_global(self):
         g = self.gbs
@@ -656,27 +692,27 @@ class OraclePipeline:
                     if self.glob.valid[i] == 0:
                         for k in range(i * self.S, min((i + 1) * self.S, n_total)):
                             self.invalid_list[k] = 0
-            self._update_trajectory(n_total)
-            self.tm.update_optimized(self.complete, n_total)
-            self.num_complete = n_total
-            if ok:
-                self.last_valid_complete = self.S * self.last_local_solved
+            self._publish(self._update_trajectory(n_total), n_total, self.S * self.last_local_solved if ok else None)
         elif st == "INVALIDATE":
             assert self.glob.num_images > 1, "INVALID_FIRST_CHUNK"
             self.glob.valid[self.glob.num_images - 1] = 0
             for i in range(self.S * self.last_local_solved, self.total_opt_local):
                 self.invalid_list[i] = 0
-            self._update_trajectory(n_total)
-            self.tm.update_optimized(self.complete, n_total)
-            self.num_complete = n_total
+            self._publish(self._update_trajectory(n_total), n_total, None)
         self.state = "NONE"
 
     def _bundler_process(self):
         if not self.use_solve:
             return
+        lagged = self.solve_lag > 0 and self.past_end == 0 and self.state != "NONE"
+        if lagged:
+            assert self._pending is None, "the previous chunk's lagged solve has not been applied yet"
+            self._stage = {}
         self._optimize_local()
         self._process_global()
         self._optimize_global()
+        if lagged:
+            self._pending, self._stage = (len(self.frames) - 1 + self.solve_lag, self._stage), None
 
     # ---- integrate / reintegrate
     def _integrate(self, frame, T, de):
@@ -712,6 +748,8 @@ class OraclePipeline:
             self.replay_log.append(("gc", -1, None))
 
     def process_frame(self, depth, color):
+        if self._pending is not None and len(self.frames) >= self._pending[0]:        # the frame entering the loop is frame len(self.frames)
+            self._apply_pending()
         raw, filt = self._ingest(depth, color)
         self.process_input(raw, filt, color)
         self._reintegrate()
@@ -725,6 +763,7 @@ class OraclePipeline:
         self._bundler_process()
 
     def process_end_of_sequence(self):
+        self._apply_pending()
         self.process_input()
         self._reintegrate()
         self._bundler_process()

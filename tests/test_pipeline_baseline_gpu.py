@@ -49,11 +49,12 @@ def _counts(op):
     return (sum(1 for k, _, _ in op.integrate_ops if k == "in"), sum(1 for k, _, _ in op.integrate_ops if k == "de"))
 
 
-def _replay(gpu, op, fused):
+def _replay(gpu, op, fused, arith="exact"):
     """Feed the oracle's operator log into a fresh GPU volume; returns the GPU scene."""
     import torch
     p = op.scene.params
     gs = gpu.capi.SceneRepHashSDF(p)
+    gs.set_arith(arith)
     gs.set_overlap(True)                              # the frame loop's configuration: operators software-pipelined on two streams
     dev = {}
 
@@ -119,6 +120,15 @@ def test_three_chunks_4mm_and_oracle_log_replay(gpu, oracle):
         gs = _replay(gpu, op, fused)
         _assert_volume_bit_equal(gs, op.scene, "replay (fused=%s)" % fused)
         del gs
+    # ... and under the FAST contract (the library default, what bench.py times), directly against the oracle: hash table, heap and every weight
+    # exact, sdf within 1e-5 x truncation, colour within the sequence bound, outside the float64 pixel-boundary band (tests/test_tsdf_fast_gpu.py)
+    from tests.test_tsdf_fast_gpu import _compare, _ostate, COLOUR_SEQ, SDF_TOL_LONG
+    gs = _replay(gpu, op, True, arith="fast")
+    poses = [T for kind, _, T in op.replay_log if kind != "gc"]
+    r = _compare(gs.download(), _ostate(op.scene), poses, op.cam, op.scene.params, "fast-contract replay of the oracle's log at 640x480 / 4 mm", COLOUR_SEQ,
+                 min_checked=5000000, max_boundary_share=0.25, sdf_tol=SDF_TOL_LONG)
+    print("fast contract vs ORACLE, replay of %d operators at 640x480 / 4 mm:" % len(poses), r)
+    del gs
 
 
 def test_resample_branch_sensor_640_integration_320(gpu, oracle):
@@ -231,26 +241,74 @@ def test_replay_1280x960_2mm_reintegration_sweep(gpu, oracle):
     Kd = frames[0][3]
     cam = camera_params(W2, H2, Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     p = default_hash_params(num_buckets=2000000, num_sdf_blocks=700000, voxel_size=0.002)
-    gs = gpu.capi.SceneRepHashSDF(p); gs.set_overlap(True)
+    gs = gpu.capi.SceneRepHashSDF(p); gs.set_arith("exact"); gs.set_overlap(True)
+    gf = gpu.capi.SceneRepHashSDF(p); gf.set_arith("fast"); gf.set_overlap(True)        # the same log under the fast contract (the library default)
     osc = oracle.OracleScene(p)
     dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
     poses = [f[2].astype(np.float32) for f in frames]
+    used = list(poses)
     rng = np.random.RandomState(777)
     nops = 0
     for k in range(NF):
         gs.integrate(poses[k], dev[k][0], dev[k][1], cam); osc.integrate(poses[k], frames[k][0], frames[k][1], cam, threads=64)
+        gf.integrate(poses[k], dev[k][0], dev[k][1], cam)
         nops += 1
         if nops % 8 == 0:
-            gs.garbage_collect(); osc.garbage_collect()
+            gs.garbage_collect(); osc.garbage_collect(); gf.garbage_collect()
     nblocks = gs.num_allocated_blocks()
     assert nblocks > 160000 and osc.num_dropped() == 0
     for k in range(NF):
         xi = rng.normal(0.0, 0.01, 6)
         T2 = (poses[k].astype(np.float64) @ se3_exp(xi[:3], xi[3:])).astype(np.float32)
         gs.reintegrate(poses[k], T2, dev[k][0], dev[k][1], cam)
+        gf.reintegrate(poses[k], T2, dev[k][0], dev[k][1], cam); used.append(T2)
         osc.deintegrate(poses[k], frames[k][0], frames[k][1], cam, threads=64); osc.integrate(T2, frames[k][0], frames[k][1], cam, threads=64)
         nops += 1
         if nops % 8 == 0:
-            gs.garbage_collect(); osc.garbage_collect()
+            gs.garbage_collect(); osc.garbage_collect(); gf.garbage_collect()
     _assert_volume_bit_equal(gs, osc, "1280x960 @2 mm sweep")
     print("1280x960 @2 mm: %d blocks after the integrations, %d after the sweep: bit-equal" % (nblocks, gs.num_allocated_blocks()))
+    del gs
+    from tests.test_tsdf_fast_gpu import _compare, _ostate, COLOUR_SEQ, SDF_TOL_LONG
+    r = _compare(gf.download(), _ostate(osc), used, cam, p, "fast-contract sweep at 1280x960 / 2 mm vs the oracle", COLOUR_SEQ, min_checked=20000000, max_boundary_share=0.25, sdf_tol=SDF_TOL_LONG)
+    print("fast contract vs ORACLE, 1280x960 @2 mm sweep:", r)
+
+
+def test_noisy_depth_stream_vs_oracle_loop(gpu, oracle):
+    """SURVEY.md 8d's sensor-noise variant through the whole loop at 640x480 / 4 mm: 33 frames (three local chunks, re-integrations, GC) with
+    depth noise sigma_z = 0.0012 + 0.0019 (z - 0.4)^2 m (seed 42) - the filters' decision boundaries (Kabsch residuals, surface area, dense
+    verification) see noisy key-point depths and noisy cache frames on the HIP path exactly as in the oracle loop.  Same bar as the noise-free
+    stream: identical tracking decisions and operation counts, integrated and optimised trajectories within 5e-4, ATE difference < 1 mm, and
+    the oracle's operator log replayed into the HIP volume bit for bit (exact contract) / within the fast contract."""
+    n = 33
+    frames = synth.render_frames(range(n))
+    frames = [(synth.add_depth_noise(d, seed=42 + k), c, T, Kd) for k, (d, c, T, Kd) in enumerate(frames)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gp, op = _run_both(gpu, frames, K, tail=4)
+    c = gp.counters()
+    o_in, o_de = _counts(op)
+    assert (c["integrate"], c["deintegrate"]) == (o_in, o_de) and o_de > 20
+    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves and c["global_solves"] == op.glob.num_solves >= 2
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert len(gt) == len(ot) == n and np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).sum() >= n - 3
+    v = np.isfinite(gt[:, 0, 0])
+    assert np.abs(gt[v] - ot[v]).max() < 5e-4
+    gopt = gp.optimized_trajectory()
+    oopt = np.stack([op.tm.opt[i] for i in range(len(gopt))])
+    vo = np.isfinite(oopt[:, 0, 0])
+    assert np.array_equal(np.isfinite(gopt[:, 0, 0]), vo) and np.abs(gopt[vo] - oopt[vo]).max() < 5e-4
+    T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
+    ref = np.stack([T0inv @ f[2].astype(np.float64) for f in frames])
+    ate = lambda t: float(np.sqrt(np.mean(np.sum((t[v][:, :3, 3] - ref[v][:, :3, 3]) ** 2, axis=1))))
+    print("noisy stream: ATE product %.3f mm, oracle %.3f mm; max pose deviation %.2e" % (1e3 * ate(gt), 1e3 * ate(ot), float(np.abs(gt[v] - ot[v]).max())))
+    assert abs(ate(gt) - ate(ot)) < 1e-3
+    del gp
+    gs = _replay(gpu, op, True)
+    _assert_volume_bit_equal(gs, op.scene, "noisy stream, replay")
+    del gs
+    from tests.test_tsdf_fast_gpu import _compare, _ostate, COLOUR_SEQ, SDF_TOL_LONG
+    gs = _replay(gpu, op, True, arith="fast")
+    poses = [T for kind, _, T in op.replay_log if kind != "gc"]
+    r = _compare(gs.download(), _ostate(op.scene), poses, op.cam, op.scene.params, "noisy stream, fast-contract replay", COLOUR_SEQ, min_checked=5000000, max_boundary_share=0.25, sdf_tol=SDF_TOL_LONG)
+    print("noisy stream, fast contract vs ORACLE:", r)

@@ -92,3 +92,36 @@ def test_loop_closure_fixture_is_what_the_oracle_produces(oracle):
     for k in ("integrated", "optimized"):
         assert np.array_equal(np.asarray(r[k], np.float32).view(np.uint32), fx[k].view(np.uint32)), k
     assert list(r["counts"]) == list(fx["counts"]) and r["key_frames"] == int(fx["key_frames"]) and r["span"] == int(fx["span"])
+
+
+def test_oracle_lagged_solve_publishes_exactly_lag_frames_later():
+    """solve_lag = L: what the solves of chunk-closing frame b publish (complete trajectory, last valid complete transform, optimised poses in the
+    TrajectoryManager) is invisible to frames b + 1 .. b + L - 1 and visible to frame b + L; with L = 0 it is visible to frame b + 1.  (The first
+    chunk publishes nothing on either side: a one-key-frame global problem is not solved, OnlineBundler.cpp:373-408.)"""
+    W, H, n, L = 320, 240, 25, 3
+    frames = [synth.scene_room(2 * k, W, H) for k in range(n)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+
+    def make(lag):
+        gas, gbs = default_app_state(), default_bundling_state()
+        gas.s_integrationWidth, gas.s_integrationHeight = W, H
+        gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.02, 40000, 16000
+        gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages = W, H, 6
+        return OraclePipeline(gas, gbs, W, H, K, solve_lag=lag)
+    serial, lagged = make(0), make(L)
+    seen = []
+    for k, (d, c, _, _) in enumerate(frames):
+        serial.process_frame(d, c); lagged.process_frame(d, c)
+        seen.append((serial.num_complete, lagged.num_complete, serial.last_valid_complete, lagged.last_valid_complete, lagged.tm.num_optimized))
+    # frame 20 closes the second chunk: the serial loop publishes inside frame 20, the lagged loop when frame 23 enters
+    assert [s[0] for s in seen[19:22]] == [0, 20, 20]
+    assert [s[1] for s in seen[19:25]] == [0, 0, 0, 0, 20, 20] and [s[4] for s in seen[19:25]] == [0, 0, 0, 0, 20, 20]
+    assert seen[20][2] == seen[23][3] == 10 and seen[22][3] == 0
+    a, b = serial.integrated_trajectory(), lagged.integrated_trajectory()
+    assert np.array_equal(a[:21].view(np.uint32), b[:21].view(np.uint32))      # nothing optimised is visible before frame 21 on either side
+    assert not np.array_equal(a[21:23].view(np.uint32), b[21:23].view(np.uint32))      # frames 21, 22: chained to the optimised trajectory in the serial order only
+    assert np.array_equal(np.isfinite(a[:, 0, 0]), np.isfinite(b[:, 0, 0]))
+    for _ in range(2):
+        serial.process_end_of_sequence(); lagged.process_end_of_sequence()
+    assert lagged._pending is None and lagged.num_complete == serial.num_complete

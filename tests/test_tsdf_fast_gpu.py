@@ -23,10 +23,14 @@ from bundlefusion_amd.capi import default_hash_params, camera_params, FREE_ENTRY
 
 pytestmark = pytest.mark.gpu
 
-BAND = 5e-4            # pixels
+BAND = 5e-4            # pixels at 640x480; scaled with the image width (band_for)
 COLOUR_SEQ = None      # sequences: histogram bound instead of a per-byte one (see _compare)
 COLOUR_SEQ_FRAC = 1e-4 # share of colour bytes that may deviate by more than 1 LSB after a sequence of operators (measured: none deviates at all)
 COLOUR_SEQ_MAX = 4     # LSB
+SDF_TOL = 1e-5         # x m_truncation: one operator on identical state, and short sequences
+SDF_TOL_LONG = 1e-4    # x m_truncation: operator logs of a frame loop (~100 fused re-integrations: a voxel is de- and re-integrated dozens of times; the quotient of a
+                       # de-integration, (sdf w - s) / (w - 1), doubles a deviation at w = 2 and the next integration halves it - a random walk of 1.5 ulp steps under
+                       # EITHER contract relative to real arithmetic; measured 3.5e-5 x truncation = 2 um after the 33-frame loop's log, gpurun r04b)
 
 
 def _to_dev(depth, color):
@@ -34,35 +38,47 @@ def _to_dev(depth, color):
     return torch.from_numpy(np.ascontiguousarray(depth)).cuda(), torch.from_numpy(np.ascontiguousarray(color)).cuda()
 
 
-def _boundary_mask(pos, ptr, poses, cam, voxel, n_voxels):
-    """[n_voxels] bool: voxel projects within BAND of a pixel boundary (or of the principal plane) under any of `poses`."""
+def band_for(cam):
+    """Width (pixels) of the band around a pixel boundary inside which the two contracts may pick different pixels.  Both evaluate the image
+    coordinate in float32: the exact contract as pf.x * fx / pf.z + mx on camera-space coordinates, the fast contract as one FMA chain over
+    the voxel's integer coordinates with fx * t folded in, whose numerator reaches a few thousand (half an ulp at 4096 is 2.4e-4) before it is
+    divided by z >= 0.4 m - a few 1e-4 pixel at 640x480, proportionally more on a wider image.  Every test prints the distance it actually
+    NEEDED (`needed_band`: the largest distance to a pixel boundary among the voxels that differ beyond the tolerance)."""
+    return BAND * max(cam.m_imageWidth, 640) / 640.0
+
+
+def _boundary_dist(pos, ptr, poses, cam, voxel, n_voxels, chunk=16384):
+    """[n_voxels] float32: the smallest distance (pixels) of a voxel's projection - recomputed in float64, on the GPU - to a pixel boundary
+    under any of `poses`; 0 where a projection is not finite or the voxel lies in the principal plane; 1 for voxels of unallocated blocks."""
+    import torch
     occ = ptr != FREE_ENTRY
-    bpos, bptr = pos[occ].astype(np.int64), ptr[occ].astype(np.int64)
-    l = np.arange(512)
-    lx, ly, lz = l & 7, (l >> 3) & 7, l >> 6
-    vx = (bpos[:, 0:1] * 8 + lx[None, :]).astype(np.float64) * voxel
-    vy = (bpos[:, 1:2] * 8 + ly[None, :]).astype(np.float64) * voxel
-    vz = (bpos[:, 2:3] * 8 + lz[None, :]).astype(np.float64) * voxel
-    near = np.zeros(vx.shape, bool)
-    for T in poses:
-        M = np.linalg.inv(np.asarray(T, np.float64))
-        cx = M[0, 0] * vx + M[0, 1] * vy + M[0, 2] * vz + M[0, 3]
-        cy = M[1, 0] * vx + M[1, 1] * vy + M[1, 2] * vz + M[1, 3]
-        cz = M[2, 0] * vx + M[2, 1] * vy + M[2, 2] * vz + M[2, 3]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            hx = cx * cam.fx / cz + cam.mx + 0.5
-            hy = cy * cam.fy / cz + cam.my + 0.5
-        for h in (hx, hy):
-            f = h - np.floor(h)
-            near |= ~np.isfinite(h) | (np.minimum(f, 1.0 - f) < BAND)
-        near |= np.abs(cz) < 1e-3
-    out = np.zeros(n_voxels, bool)
-    idx = (bptr[:, None] + l[None, :]).reshape(-1)
-    out[idx] = near.reshape(-1)
-    return out
+    bpos_all, bptr_all = pos[occ].astype(np.int64), ptr[occ].astype(np.int64)
+    dev = "cuda"
+    l = torch.arange(512, device=dev)
+    lx, ly, lz = (l & 7).double(), ((l >> 3) & 7).double(), (l >> 6).double()
+    Ms = [torch.from_numpy(np.linalg.inv(np.asarray(T, np.float64))).to(dev) for T in poses]
+    out = torch.ones(n_voxels, dtype=torch.float32, device=dev)
+    for c0 in range(0, len(bpos_all), chunk):
+        bpos = torch.from_numpy(bpos_all[c0:c0 + chunk]).to(dev); bptr = torch.from_numpy(bptr_all[c0:c0 + chunk]).to(dev)
+        vx = (bpos[:, 0:1].double() * 8 + lx[None, :]) * voxel
+        vy = (bpos[:, 1:2].double() * 8 + ly[None, :]) * voxel
+        vz = (bpos[:, 2:3].double() * 8 + lz[None, :]) * voxel
+        dist = torch.ones(vx.shape, dtype=torch.float64, device=dev)
+        for M in Ms:
+            cx = M[0, 0] * vx + M[0, 1] * vy + M[0, 2] * vz + M[0, 3]
+            cy = M[1, 0] * vx + M[1, 1] * vy + M[1, 2] * vz + M[1, 3]
+            cz = M[2, 0] * vx + M[2, 1] * vy + M[2, 2] * vz + M[2, 3]
+            for h in (cx * cam.fx / cz + cam.mx + 0.5, cy * cam.fy / cz + cam.my + 0.5):
+                f = h - torch.floor(h)
+                d = torch.minimum(f, 1.0 - f)
+                dist = torch.minimum(dist, torch.where(torch.isfinite(h), d, torch.zeros_like(d)))
+            dist = torch.where(cz.abs() < 1e-3, torch.zeros_like(dist), dist)
+        idx = (bptr[:, None] + l[None, :]).reshape(-1)
+        out[idx] = dist.reshape(-1).float()
+    return out.cpu().numpy()
 
 
-def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000):
+def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000, max_boundary_share=0.08, sdf_tol=SDF_TOL):
     """fast / exact: (hash, heap, heapCounter, voxels) of the two volumes"""
     fh, fheap, fcnt, fvox = fast
     eh, eheap, ecnt, evox = exact
@@ -72,36 +88,44 @@ def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000):
     assert np.array_equal(fheap, eheap), what + ": heap"
     n = len(evox)
     assert len(fvox) == n
-    m = _boundary_mask(eh["pos"], eh["ptr"], poses, cam, p.m_virtualVoxelSize, n)
+    dist = _boundary_dist(eh["pos"], eh["ptr"], poses, cam, p.m_virtualVoxelSize, n)
+    band = band_for(cam)
+    m = dist < band
     live = (evox["weight"][:n] > 0) | (fvox["weight"][:n] > 0)
     chk = ~m
-    assert np.array_equal(fvox["weight"][:n][chk], evox["weight"][:n][chk]), what + ": weights outside the boundary band"
+    dw = fvox["weight"][:n] != evox["weight"][:n]
     dsdf = np.abs(fvox["sdf"][:n].astype(np.float64) - evox["sdf"][:n].astype(np.float64))
-    tol = 1e-5 * p.m_truncation
-    assert dsdf[chk].max() <= tol, what + ": sdf deviates by %.3g (tolerance %.3g)" % (dsdf[chk].max(), tol)
+    tol = sdf_tol * p.m_truncation
     fc, ec = fvox["color"].astype(np.int32), evox["color"].astype(np.int32)
     dcol = np.abs(fc - ec).reshape(n, -1)
+    # the band this comparison actually needed: every voxel that differs beyond the contract lies this close to a pixel boundary
+    bad = dw | (dsdf > tol) | (dcol.max(axis=1) > (colour_tol if colour_tol is not None else COLOUR_SEQ_MAX))
+    needed = float(dist[bad].max(initial=0.0))
     hist = np.bincount(dcol[chk & live].reshape(-1), minlength=4)
+    frac_gt1 = float(hist[2:].sum()) / max(int(hist.sum()), 1)
+    share = float((m & live).sum()) / max(int(live.sum()), 1)
+    trunc_band = p.m_truncation + p.m_truncScale * p.m_maxIntegrationDistance
+    rep = dict(checked=int((chk & live).sum()), boundary_share=share, band=band, needed_band=needed, weights_differing_outside_band=int((dw & chk).sum()),
+               max_dsdf=float(dsdf[chk].max(initial=0.0)), sdf_tol=tol, max_dcol=int(dcol[chk].max(initial=0)), colour_beyond_1lsb=frac_gt1,
+               differing=int((dsdf[chk] > 0).sum()), colour_hist=hist[:10].tolist(), flips=int(bad.sum()),
+               max_dsdf_in_band=float(dsdf[m].max(initial=0.0)), max_dweight_in_band=float(np.abs(fvox["weight"][:n][m] - evox["weight"][:n][m]).max(initial=0.0)))
+    print(what + ":", rep)          # everything measured is on record before the first assertion
+    assert rep["weights_differing_outside_band"] == 0, what + ": %d weights differ outside the boundary band (needed band %.2e px, band %.2e)" % (rep["weights_differing_outside_band"], needed, band)
+    assert rep["max_dsdf"] <= tol, what + ": sdf deviates by %.3g (tolerance %.3g; needed band %.2e px, band %.2e)" % (rep["max_dsdf"], tol, needed, band)
     if colour_tol is not None:
-        assert dcol[chk].max() <= colour_tol, what + ": colour deviates by %d LSB" % dcol[chk].max()
+        assert rep["max_dcol"] <= colour_tol, what + ": colour deviates by %d LSB" % rep["max_dcol"]
     else:
         # a sequence of operators: the de-integration of a colour is ill-conditioned - it multiplies any deviation of the stored byte by
         # w / (w - 1) (2 for a voxel of weight 2), the following integration by 0.8, so a 1 LSB conversion difference can grow by 1.6 per
         # re-integration of a weight-2 voxel UNDER EITHER CONTRACT (the exact contract's own rounding errors are amplified the same way
         # relative to real arithmetic).  Bound: almost every byte within 1 LSB, none beyond COLOUR_SEQ_MAX.
-        frac_gt1 = float(hist[2:].sum()) / max(int(hist.sum()), 1)
-        assert frac_gt1 <= COLOUR_SEQ_FRAC and dcol[chk].max() <= COLOUR_SEQ_MAX, what + ": colour histogram %s (%.2e beyond 1 LSB)" % (hist[:12].tolist(), frac_gt1)
+        assert frac_gt1 <= COLOUR_SEQ_FRAC and rep["max_dcol"] <= COLOUR_SEQ_MAX, what + ": colour histogram %s (%.2e beyond 1 LSB)" % (hist[:12].tolist(), frac_gt1)
     # boundary voxels: few, and still inside the truncation band / a plausible weight
-    share = float((m & live).sum()) / max(int(live.sum()), 1)
-    assert int((chk & live).sum()) >= min_checked, what + ": only %d voxels compared" % int((chk & live).sum())
-    assert share < 0.08, what + ": %.1f %% boundary voxels" % (100 * share)
-    band = p.m_truncation + p.m_truncScale * p.m_maxIntegrationDistance
-    assert dsdf[m].max(initial=0.0) <= 2 * band
-    assert np.abs(fvox["weight"][:n][m] - evox["weight"][:n][m]).max(initial=0.0) <= len(poses)
-    differing = int((dsdf[chk] > 0).sum())
-    return dict(checked=int((chk & live).sum()), boundary_share=share, max_dsdf=float(dsdf[chk].max()), max_dcol=int(dcol[chk].max()), differing=differing,
-                colour_hist=hist[:10].tolist(),
-                flips=int(((dsdf > tol) & m).sum()))
+    assert rep["checked"] >= min_checked, what + ": only %d voxels compared" % rep["checked"]
+    assert share < max_boundary_share, what + ": %.1f %% boundary voxels" % (100 * share)
+    assert rep["max_dsdf_in_band"] <= 2 * trunc_band
+    assert rep["max_dweight_in_band"] <= len(poses)
+    return rep
 
 
 def _ostate(osc):
@@ -124,7 +148,7 @@ def test_fast_contract_single_operators_vs_oracle(gpu, oracle):
     r = _compare(gs.download(), _ostate(osc), [frames[0][2]], cam, p, "integrate", 1, min_checked=30000)
     assert r["max_dcol"] == 0          # the colour blend of an integration has no rounding ties: identical bytes
     del gs
-    gf = gpu.capi.SceneRepHashSDF(p)   # exact contract while the common state is built
+    gf = gpu.capi.SceneRepHashSDF(p); gf.set_arith("exact")   # exact contract while the common state is built (the library default is fast; the test session selects exact)
     assert gf.arith() == "exact"
     for i in (1, 2):
         osc.integrate(frames[i][2], frames[i][0], frames[i][1], cam)
@@ -251,8 +275,9 @@ def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
     print("frame loop, fast vs exact contract: %d live voxels; weights differ %.2e, sdf beyond 1e-5 x truncation %.2e, colour beyond 1 LSB %.2e of them"
           % (nlive, share(dw), share(ds > tol), share(dc > 1)))
     assert nlive > 5000000
-    # pixel-boundary voxels only: a few 1e-4 of the voxels per operator, ~60 operators
-    assert share(dw) < 5e-3 and share(ds > tol) < 2e-2 and share(dc > 1) < 2e-2
+    # pixel-boundary voxels only (the operator log of a pipeline is not replayed in float64 here - test_pipeline_baseline_gpu.py does that against the
+    # oracle): measured on MI355X 3.4e-5 / 7.2e-4 / 8.9e-5 (gpurun r03); bounds = 10 x that (until round 4: 5e-3 / 2e-2 / 2e-2)
+    assert share(dw) < 3.4e-4 and share(ds > tol) < 7.2e-3 and share(dc > 1) < 8.9e-4
 
 
 @pytest.mark.parametrize("size", ["160x120@20mm", "640x480@4mm"])
