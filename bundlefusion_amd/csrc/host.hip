@@ -435,7 +435,10 @@ int evaluateStage(bf_bundler* b, bool filtered, bool recompute, bool clear, cons
     return bf_correspondence_evaluator_evaluate(b->corrEvaluator, b->mgr, b->cache, b->siftIntrinsicsInv.e, &p, filtered, recompute, clear, type, b->stream, nullptr);
 }
 
-int matchAndFilterEnqueue(bf_bundler* b, uint32_t& curFrame, uint32_t& startFrame, uint32_t& numFrames) {
+// ... in two stages.  The PAIR stage - match, Kabsch filter, surface-area filter, dense verification - computes, per previous image, from the two images
+// alone; it runs on the stream and result set bf_siftmgr_set_pair_stage selected.  The COMMIT stage - which previous images count, filterFrames, the
+// frame's EntryJ rows - needs the valid flags of all earlier frames and runs on the bundler's stream.
+int matchAndFilterPairs(bf_bundler* b, uint32_t& curFrame, uint32_t& startFrame, uint32_t& numFrames) {
     BF_TRY(bf_siftmgr_get_num_images(b->mgr, &numFrames));
     BF_REQUIRE(numFrames > 1, "matchAndFilter needs more than one frame");
     BF_TRY(bf_siftmgr_get_current_frame(b->mgr, &curFrame));
@@ -458,10 +461,20 @@ int matchAndFilterEnqueue(bf_bundler* b, uint32_t& curFrame, uint32_t& startFram
                                                          b->gbs.s_projCorrNormalThres, b->gbs.s_projCorrColorThresh, b->gbs.s_verifySiftErrThresh,
                                                          b->gbs.s_verifySiftCorrThresh, b->gas.s_sensorDepthMin, b->gas.s_sensorDepthMax));
         BF_TRY(evaluateStage(b, true, false, true, "dense"));
+    }
+    return BF_OK;
+}
+int matchAndFilterCommit(bf_bundler* b, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames, bool speculative) {
+    if (curFrame > 0) {
+        if (speculative) BF_TRY(bf_siftmgr_commit_pairs(b->mgr, curFrame, startFrame, numFrames));
         BF_TRY(bf_siftmgr_filter_frames_async(b->mgr, curFrame, startFrame, numFrames));
         BF_TRY(bf_siftmgr_add_curr_to_residuals(b->mgr, curFrame, startFrame, numFrames, b->siftIntrinsicsInv.e));
     }
     return BF_OK;
+}
+int matchAndFilterEnqueue(bf_bundler* b, uint32_t& curFrame, uint32_t& startFrame, uint32_t& numFrames) {
+    BF_TRY(matchAndFilterPairs(b, curFrame, startFrame, numFrames));
+    return matchAndFilterCommit(b, curFrame, startFrame, numFrames, false);
 }
 
 int tryRevalidation(bf_bundler* b, uint32_t curGlobalFrame, bool bIsScanDone, uint32_t* out);
@@ -1079,6 +1092,15 @@ struct bf_online_bundler {
     } job;
     Published* pubTarget = nullptr;        // non-null while a job runs: obPublish stores here instead of applying
     bool chunkClosed = false;              // prepareLocalSolve ran and its solves have not been started yet (main thread only; processState itself belongs to the solves)
+    // ---- pair stages of consecutive frames side by side (bf_online_bundler_set_pair_streams): the staged detection of frame k is committed and its match /
+    // Kabsch / surface-area / dense-verification kernels run on pair stream k & 1, into the sift manager's result set k & 1, while frame k - 1's are still
+    // running on the other stream; the bundling stream only carries the short commit stage (valid flags, filterFrames, EntryJ rows, pose kernel).  The
+    // greedy Kabsch filter is a ~0.26 ms chain of dependent 3x3 SVDs on ten waves (profiles/r03_sq_feature_pipeline.md): it cannot be made shorter, but two
+    // of them fit beside each other.
+    hipStream_t sPair[2] = {nullptr, nullptr};
+    hipEvent_t evImage[2] = {nullptr, nullptr}, evPairDone[2] = {nullptr, nullptr}, evPairSetFree[2] = {nullptr, nullptr}, evChunkCopy = nullptr;
+    bool pairSetUsed[2] = {false, false};
+    hipEvent_t lastImageEvent = nullptr;   // behind the copy of the newest image into m_local (by a pair stream, or the chunk-boundary copy on the bundling stream)
     // chunk-parallel mode (bf_pipeline_process_frame_chunked): the local half of the chunk being closed comes from this package
     const bf_chunk_header* extChunk = nullptr;
     bool isLastLocalFrame(uint32_t curFrame) const { return curFrame >= submapSize && (curFrame % submapSize) == 0; }
@@ -1359,6 +1381,12 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
     BF_HIP_TRY(hipMalloc((void**)&ob->d_completeShadow, sizeof(m44) * nAll));
     BF_HIP_TRY(hipMemset(ob->d_completeShadow, 0, sizeof(m44) * nAll));
     BF_HIP_TRY(hipEventCreateWithFlags(&ob->evChunk, hipEventDisableTiming));
+    BF_HIP_TRY(hipEventCreateWithFlags(&ob->evChunkCopy, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) {
+        BF_HIP_TRY(hipEventCreateWithFlags(&ob->evImage[k], hipEventDisableTiming));
+        BF_HIP_TRY(hipEventCreateWithFlags(&ob->evPairDone[k], hipEventDisableTiming));
+        BF_HIP_TRY(hipEventCreateWithFlags(&ob->evPairSetFree[k], hipEventDisableTiming));
+    }
     k_fill_identity<<<div_up((uint32_t)(maxNumImages * (S + 1)), 64), 64>>>(ob->d_localTrajectories, maxNumImages * (S + 1));
     k_fill_identity<<<1, 64>>>(ob->d_siftTrajectory, 1);
     k_fill_identity<<<1, 64>>>(ob->d_currIntegrateTransform, 1);
@@ -1377,6 +1405,8 @@ int bf_online_bundler_destroy(bf_online_bundler* ob) {
     if (ob->job.th.joinable()) ob->job.th.join();
     (void)hipFree(ob->d_completeShadow);
     if (ob->evChunk) (void)hipEventDestroy(ob->evChunk);
+    if (ob->evChunkCopy) (void)hipEventDestroy(ob->evChunkCopy);
+    for (int k = 0; k < 2; ++k) for (hipEvent_t e : {ob->evImage[k], ob->evPairDone[k], ob->evPairSetFree[k]}) if (e) (void)hipEventDestroy(e);
     bf_bundler_destroy(ob->local); bf_bundler_destroy(ob->optLocal); bf_bundler_destroy(ob->global); bf_bundler_destroy(ob->stage); bf_trajectory_manager_destroy(ob->tm);
     for (int k = 0; k < 2; ++k) { if (ob->evDetect[k]) (void)hipEventDestroy(ob->evDetect[k]); if (ob->evStageFree[k]) (void)hipEventDestroy(ob->evStageFree[k]); }
     (void)hipFree(ob->d_intensitySIFT); (void)hipFree(ob->d_intensityFilterHelper); (void)hipFree(ob->d_completeTrajectory); (void)hipFree(ob->d_localTrajectories);
@@ -1407,6 +1437,15 @@ int bf_online_bundler_set_solve_lag(bf_online_bundler* ob, uint32_t lag, void* s
     ob->solveLag = lag;
     ob->sSolve = lag ? (hipStream_t)solveStream : ob->stream;
     return bf_bundler_set_stream(ob->global, ob->sSolve);
+}
+// Two streams of the caller's for the pair stages of consecutive frames (see the struct); (null, null): everything on the bundling stream (default).
+// Takes effect for frames whose detection was staged (bf_online_bundler_detect_ahead).
+int bf_online_bundler_set_pair_streams(bf_online_bundler* ob, void* stream0, void* stream1) {
+    BF_REQUIRE(ob, "null bundler");
+    BF_REQUIRE(ob->pendCount == 0, "set_pair_streams with a frame in flight");
+    BF_REQUIRE((stream0 == nullptr) == (stream1 == nullptr), "both pair streams or none");
+    ob->sPair[0] = (hipStream_t)stream0; ob->sPair[1] = (hipStream_t)stream1;
+    return BF_OK;
 }
 int bf_online_bundler_get_solve_lag(bf_online_bundler* ob, uint32_t* lag) { BF_REQUIRE(ob && lag, "null argument"); *lag = ob->solveLag; return BF_OK; }
 
@@ -1461,9 +1500,9 @@ __global__ __launch_bounds__(256) void k_copy_segments(CopySegs j) {
 }
 
 // the staged detection of `frame` becomes the local bundler's next image (what detectFeatures + storeCachedFrame would have produced)
-int obCommitStaged(bf_online_bundler* ob, uint32_t frame) {
+int obCommitStaged(bf_online_bundler* ob, uint32_t frame, hipStream_t st) {
     const int slot = (int)(frame & 1u);
-    BF_HIP_TRY(hipStreamWaitEvent(ob->stream, ob->evDetect[slot], 0));
+    BF_HIP_TRY(hipStreamWaitEvent(st, ob->evDetect[slot], 0));
     bf_bundler *b = ob->local, *from = ob->stage;
     bf_sift_image_gpu src, dst;
     BF_TRY(bf_siftmgr_get_image(from->mgr, (uint32_t)slot, &src));
@@ -1486,11 +1525,11 @@ int obCommitStaged(bf_online_bundler* ob, uint32_t frame) {
     j.s[6] = {(uint32_t*)cd.d_intensityDerivsDownsampled, (const uint32_t*)cs.d_intensityDerivsDownsampled, 2 * n};
     j.s[7] = {(uint32_t*)cd.d_normalsDownsampledUCHAR4, (const uint32_t*)cs.d_normalsDownsampledUCHAR4, n};
     j.s[8] = {(uint32_t*)cd.d_normalsDownsampled, (const uint32_t*)cs.d_normalsDownsampled, 4 * n};
-    hipLaunchKernelGGL(k_copy_segments, dim3(32, 9), dim3(256), 0, ob->stream, j);
+    hipLaunchKernelGGL(k_copy_segments, dim3(32, 9), dim3(256), 0, st, j);
     BF_HIP_TRY(hipGetLastError());
     BF_TRY(bf_siftmgr_finalize_image(b->mgr, -1));
     BF_TRY(bf_cache_increment(b->cache));
-    BF_HIP_TRY(hipEventRecord(ob->evStageFree[slot], ob->stream));
+    BF_HIP_TRY(hipEventRecord(ob->evStageFree[slot], st));
     ob->stagedFrame[slot] = -1;
     return BF_OK;
 }
@@ -1614,7 +1653,14 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
         return BF_OK;
     }
     BF_TRY(obApplyBundleSide(ob, curFrame, false));            // lagged solve: this is the frame that sees the new trajectory
-    if (staged) BF_TRY(obCommitStaged(ob, curFrame));
+    const int par = (int)(curFrame & 1u);
+    const bool spec = staged && ob->sPair[0] != nullptr && ob->local->corrEvaluator == nullptr;       // pair stage on its own stream
+    hipStream_t ps = spec ? ob->sPair[par] : ob->stream;
+    if (spec) {
+        if (ob->pairSetUsed[par]) BF_HIP_TRY(hipStreamWaitEvent(ps, ob->evPairSetFree[par], 0));      // the commit stage that read this result set two frames ago
+        if (ob->lastImageEvent) BF_HIP_TRY(hipStreamWaitEvent(ps, ob->lastImageEvent, 0));            // the previous image of the chunk is in place
+    }
+    if (staged) BF_TRY(obCommitStaged(ob, curFrame, ps));
     else {
         // getCurrentFrame (:106-116): luminance at SIFT resolution straight from the ingest buffer
         BF_TRY(bf_image_resample_to_intensity(ob->d_intensitySIFT, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->stream));
@@ -1625,14 +1671,25 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
         BF_TRY(bf_bundler_detect_features(ob->local, ob->d_intensitySIFT, ob->im->d_depthInputFiltered));
         BF_TRY(bf_bundler_store_cached_frame(ob->local, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH, ob->im->d_depthInputRaw));
     }
+    if (spec) { BF_HIP_TRY(hipEventRecord(ob->evImage[par], ps)); ob->lastImageEvent = ob->evImage[par]; }
+    else ob->lastImageEvent = nullptr;                                               // everything on the bundling stream: ordered by the stream
     uint32_t curLocalFrame;
     BF_TRY(bf_bundler_get_curr_frame_number(ob->local, &curLocalFrame));
+    uint32_t start = 0;
+    if (curLocalFrame > 0) {
+        // ---- pair stage (matchAndFilter up to the dense verification)
+        BF_TRY(bf_siftmgr_set_pair_stage(ob->local->mgr, spec ? (uint32_t)par : 0u, spec ? ps : nullptr, spec ? 1 : 0));
+        BF_TRY(matchAndFilterPairs(ob->local, P.cur, start, P.num));
+    }
+    if (spec) {
+        BF_HIP_TRY(hipEventRecord(ob->evPairDone[par], ps));
+        BF_HIP_TRY(hipStreamWaitEvent(ob->stream, ob->evPairDone[par], 0));
+    }
     if (bIsLastLocal) BF_TRY(bf_bundler_copy_frame(ob->optLocal, ob->local, curLocalFrame));
     if (curLocalFrame > 0) {
-        // matchAndFilter + computeCurrentSiftTransform (:118-132) with ONE read-back: the pose kernel is enqueued before the frame
+        // ---- commit stage + computeCurrentSiftTransform (:118-132) with ONE read-back: the pose kernel is enqueued before the frame
         // result is fetched (it writes nothing when no pair survived the filters, which is exactly the "invalid" case)
-        uint32_t start;
-        BF_TRY(matchAndFilterEnqueue(ob->local, P.cur, start, P.num));
+        BF_TRY(matchAndFilterCommit(ob->local, P.cur, start, P.num, spec));
         const float* d_Tinv = nullptr; const int32_t* d_nf = nullptr; const int32_t* d_res = nullptr;
         BF_TRY(bf_bundler_get_current_sift_transforms_gpu(ob->local, &d_Tinv));
         BF_TRY(bf_bundler_get_num_filt_matches_gpu(ob->local, &d_nf));
@@ -1643,12 +1700,15 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
         BF_HIP_TRY(hipGetLastError());
         BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT + (curFrame & 1u), ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
         BF_TRY(bf_siftmgr_prefetch_frame_result(ob->local->mgr));      // the read-back itself is enqueued now; _end only waits for it
+        BF_TRY(bf_siftmgr_set_pair_stage(ob->local->mgr, spec ? (uint32_t)par : 0u, nullptr, 0));      // (direct callers of this bundler get the reference's behaviour)
         P.match = true;
     }
+    if (spec) { BF_HIP_TRY(hipEventRecord(ob->evPairSetFree[par], ob->stream)); ob->pairSetUsed[par] = true; }
     if (bIsLastLocal) {
         // the chunk is complete on the device: from here on m_local is the next chunk (which starts with a copy of this frame) - the exchange of
         // prepareLocalSolve (:164), done now so that the next frame's chain can be enqueued before this frame's result is back
         BF_HIP_TRY(hipEventRecord(ob->evChunk, ob->stream));
+        if (spec) { BF_HIP_TRY(hipEventRecord(ob->evChunkCopy, ob->stream)); ob->lastImageEvent = ob->evChunkCopy; }      // the next chunk's first image: the copy above
         std::swap(ob->local, ob->optLocal);
         P.swapped = true;
     }
@@ -1776,6 +1836,7 @@ struct bf_pipeline {
     std::deque<uint32_t> begun;     // frames whose chain is enqueued and whose body has not run, oldest first (at most 2)
     hipStream_t sSolve = nullptr;   // stream of the lagged solves (bf_pipeline_set_solve_lag)
     hipStream_t sIngest = nullptr;  // the ingest filters of frame n + 1 run beside the detection of frame n (two input sets in the image manager)
+    hipStream_t sPair[2] = {nullptr, nullptr};      // pair stages of consecutive frames side by side (bf_online_bundler_set_pair_streams)
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
@@ -2055,14 +2116,21 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // 0.80 -> 0.69 ms while the voxel update slows 93.8 -> 126 us; frames/s 656 -> 655 / 648 / 623 / 565)
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
-        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sSolve, hipStreamNonBlocking, least));      // lagged solves: nothing waits for them for `lag` frames
+        // lagged solves: measured at the lowest priority (gpurun r04b) the cooperative PCG - up to 64 workgroups meeting at a grid barrier 450 times per
+        // global solve - is starved by the volume stream's wide launches and a chunk's solves take longer than the ten frames they have
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sSolve, hipStreamNonBlocking, greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sIngest, hipStreamNonBlocking, greatest));
+        for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
     BF_TRY(bf_image_manager_set_stream(p->im, p->sIngest));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_online_bundler_set_detect_stream(p->ob, p->sDetect));
     for (uint32_t k = 0; k < 2; ++k) BF_TRY(bf_image_manager_set_input_guard(p->im, k, p->ob->evDetect[k]));      // the staged detection of the frame that used the set last
+    {
+        const char* e = getenv("BF_PIPELINE_PAIR_STREAMS");            // 0: the pair stage on the bundling stream (one chain at a time), for A/B measurements
+        if (!e || atoi(e) != 0) BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPair[0], p->sPair[1]));
+    }
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
     if (const char* e = getenv("BF_PIPELINE_SOLVE_LAG")) BF_TRY(bf_online_bundler_set_solve_lag(p->ob, (uint32_t)atoi(e), p->sSolve));
@@ -2089,6 +2157,7 @@ int bf_pipeline_destroy(bf_pipeline* p) {
     if (p->sDetect) (void)hipStreamDestroy(p->sDetect);
     if (p->sSolve) (void)hipStreamDestroy(p->sSolve);
     if (p->sIngest) (void)hipStreamDestroy(p->sIngest);
+    for (auto st : p->sPair) if (st) (void)hipStreamDestroy(st);
     delete p;
     return BF_OK;
 }
@@ -2129,6 +2198,7 @@ int bf_pipeline_synchronize(bf_pipeline* p) {
     BF_TRY(volDrain(p));
     BF_HIP_TRY(hipStreamSynchronize(p->sIngest));
     BF_HIP_TRY(hipStreamSynchronize(p->sDetect));
+    for (auto st : p->sPair) BF_HIP_TRY(hipStreamSynchronize(st));
     BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
     BF_HIP_TRY(hipStreamSynchronize(p->sSolve));
     BF_HIP_TRY(hipStreamSynchronize(p->sVolume));

@@ -46,6 +46,7 @@ struct MatchArgs {
     uint32_t curFrame, startFrame;
     float distmax, ratiomax;
     int* numMatches; float* dist; uint2* idx;
+    int speculative;        // 1: pairs with an invalid previous image are matched too (bf_siftmgr_commit_pairs clears them once the flags are final)
 };
 
 BF_DEV void top2_merge(uint64_t& P, int& n, uint64_t P2, int n2) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(1024) void k_match(MatchArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
     int n1 = a.numKeys[prev], n2 = a.numKeys[a.curFrame];
     n1 = min(max(n1, 0), (int)a.maxKeys); n2 = min(max(n2, 0), (int)a.maxKeys);
-    if (a.validImages[prev] == 0 || n1 == 0 || n2 == 0) {       // Bundler.cpp:126-129
+    if ((!a.speculative && a.validImages[prev] == 0) || n1 == 0 || n2 == 0) {       // Bundler.cpp:126-129
         if (tid == 0) a.numMatches[prev] = 0;
         return;
     }
@@ -826,6 +827,13 @@ __global__ __launch_bounds__(DV_THREADS) void k_verify_trajectory(VerifyArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------ bookkeeping
+// Pairs computed ahead of the previous frame's verdict (bf_siftmgr_set_pair_stage): what Bundler::matchAndFilter would not have matched at all
+// (Bundler.cpp:126-129: the previous image is invalid) is cleared now that every flag of an earlier image is final
+__global__ void k_commit_pairs(uint32_t curFrame, uint32_t startFrame, uint32_t numFrames, const int* validImages, int* numMatches, int* numFilt) {
+    const uint32_t prev = startFrame + blockIdx.x * blockDim.x + threadIdx.x;
+    if (prev < numFrames && prev != curFrame && validImages[prev] == 0) { numMatches[prev] = 0; numFilt[prev] = 0; }
+}
+
 // filterFrames (SIFTImageManager.cpp:551-575) on the device
 __global__ void k_filter_frames(uint32_t curFrame, uint32_t startFrame, uint32_t numFrames, const int* numFilt, int* validImages, const int* numKeys,
                                 FrameResult* res) {
@@ -1091,6 +1099,15 @@ struct bf_siftmgr {
     uint32_t maxImages = 0, maxKeys = 0, maxResiduals = 0;
     hipStream_t stream = nullptr;
     Key* d_keys = nullptr; uint8_t* d_descs = nullptr; int* d_numKeys = nullptr;
+    // per-pair results of the current frame against every previous image (d_currNumMatchesPerImagePair ... d_currFilteredTransformsInv, SIFTImageManager.h:
+    // 262-276) exist TWICE: bf_siftmgr_set_pair_stage selects the set (and the stream) the pair kernels of the NEXT frame work on, so that the match / Kabsch /
+    // surface-area / dense-verification kernels of frame k + 1 run beside those of frame k (each pair depends on the two images only; which previous
+    // images are valid is applied afterwards, bf_siftmgr_commit_pairs).  The members below always name the active set.
+    struct PairSet { int* numMatches; float* dist; uint2* idx; int* numFilt; float* fdist; uint2* fidx; m44* T; m44* Tinv; };
+    PairSet sets[2] = {};
+    int pairSet = 0;
+    hipStream_t pairStream = nullptr;      // stream of the pair kernels; null: `stream`
+    bool speculative = false;
     int* d_numMatches = nullptr; float* d_dist = nullptr; uint2* d_idx = nullptr;
     int* d_numFilt = nullptr; float* d_fdist = nullptr; uint2* d_fidx = nullptr; m44* d_T = nullptr; m44* d_Tinv = nullptr;
     int* d_validImages = nullptr; int* d_validOpt = nullptr;
@@ -1110,7 +1127,33 @@ struct bf_siftmgr {
     void* fuseScratch = nullptr; size_t fuseScratchBytes = 0; int* d_fuseError = nullptr;
 };
 
+static void selectPairSet(bf_siftmgr* m, int k) {
+    const bf_siftmgr::PairSet& P = m->sets[k];
+    m->pairSet = k;
+    m->d_numMatches = P.numMatches; m->d_dist = P.dist; m->d_idx = P.idx;
+    m->d_numFilt = P.numFilt; m->d_fdist = P.fdist; m->d_fidx = P.fidx; m->d_T = P.T; m->d_Tinv = P.Tinv;
+}
+static hipStream_t pairStreamOf(const bf_siftmgr* m) { return m->pairStream ? m->pairStream : m->stream; }
+
 extern "C" {
+
+// The pair kernels (match, Kabsch filter, surface-area filter, dense verification) issued from now on work on result set `set` (0 / 1) and on `hip_stream`
+// (null: the manager's stream); speculative != 0: they do not consult the valid flags of the previous images (those may still be in the making on the
+// manager's stream) - bf_siftmgr_commit_pairs, on the manager's stream, clears the pairs Bundler::matchAndFilter would have skipped.  Ordering between the
+// two streams is the caller's (events).  The accessors of the per-pair arrays name the selected set.  (0, null, 0) is the reference's behaviour.
+int bf_siftmgr_set_pair_stage(bf_siftmgr* m, uint32_t set, void* hip_stream, int speculative) {
+    BF_REQUIRE(m && set < 2, "bad argument");
+    selectPairSet(m, (int)set);
+    m->pairStream = (hipStream_t)hip_stream;
+    m->speculative = speculative != 0;
+    return BF_OK;
+}
+int bf_siftmgr_commit_pairs(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames) {
+    BF_REQUIRE(m && numFrames <= m->numImages && startFrame < numFrames, "frame range out of bounds");
+    k_commit_pairs<<<div_up(numFrames - startFrame, 64), 64, 0, m->stream>>>(curFrame, startFrame, numFrames, m->d_validImages, m->d_numMatches, m->d_numFilt);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
 
 int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_siftmgr** out) {
     BF_REQUIRE(out && maxImages >= 1 && maxKeyPointsPerImage >= 16 && maxKeyPointsPerImage <= 1024, "maxKeyPointsPerImage must be in [16, 1024]");
@@ -1119,18 +1162,24 @@ int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_sift
     m->maxResiduals = MAX_FILT * (maxImages * (maxImages - 1)) / 2;
     int rc;
     const size_t nk = (size_t)maxImages * maxKeyPointsPerImage;
+    rc = BF_OK;
+    for (int k = 0; k < 2 && !rc; ++k) {
+        bf_siftmgr::PairSet& P = m->sets[k];
+        (rc = dalloc(P.numMatches, maxImages)) || (rc = dalloc(P.dist, (size_t)maxImages * MAX_RAW)) || (rc = dalloc(P.idx, (size_t)maxImages * MAX_RAW)) ||
+        (rc = dalloc(P.numFilt, maxImages)) || (rc = dalloc(P.fdist, (size_t)maxImages * MAX_FILT)) || (rc = dalloc(P.fidx, (size_t)maxImages * MAX_FILT)) ||
+        (rc = dalloc(P.T, maxImages)) || (rc = dalloc(P.Tinv, maxImages));
+        if (!rc) { BF_HIP_TRY(hipMemset(P.numMatches, 0, sizeof(int) * maxImages)); BF_HIP_TRY(hipMemset(P.numFilt, 0, sizeof(int) * maxImages)); }
+    }
+    if (rc) { delete m; return rc; }
+    selectPairSet(m, 0);
     if ((rc = dalloc(m->d_keys, nk)) || (rc = dalloc(m->d_descs, nk * 128)) || (rc = dalloc(m->d_numKeys, maxImages)) ||
-        (rc = dalloc(m->d_numMatches, maxImages)) || (rc = dalloc(m->d_dist, (size_t)maxImages * MAX_RAW)) || (rc = dalloc(m->d_idx, (size_t)maxImages * MAX_RAW)) ||
-        (rc = dalloc(m->d_numFilt, maxImages)) || (rc = dalloc(m->d_fdist, (size_t)maxImages * MAX_FILT)) || (rc = dalloc(m->d_fidx, (size_t)maxImages * MAX_FILT)) ||
-        (rc = dalloc(m->d_T, maxImages)) || (rc = dalloc(m->d_Tinv, maxImages)) || (rc = dalloc(m->d_validImages, maxImages)) || (rc = dalloc(m->d_validOpt, 1)) ||
+        (rc = dalloc(m->d_validImages, maxImages)) || (rc = dalloc(m->d_validOpt, 1)) ||
         (rc = dalloc(m->d_glob, m->maxResiduals)) || (rc = dalloc(m->d_globKeys, m->maxResiduals)) || (rc = dalloc(m->d_globNum, 1)) || (rc = dalloc(m->d_res, 1))) {
         delete m; return rc;
     }
     BF_HIP_TRY(hipHostMalloc((void**)&m->h_res, sizeof(FrameResult) * bf_siftmgr::RES_SLOTS));
     for (auto& e : m->evRes) BF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     BF_HIP_TRY(hipMemset(m->d_numKeys, 0, sizeof(int) * maxImages));
-    BF_HIP_TRY(hipMemset(m->d_numMatches, 0, sizeof(int) * maxImages));
-    BF_HIP_TRY(hipMemset(m->d_numFilt, 0, sizeof(int) * maxImages));
     BF_HIP_TRY(hipMemset(m->d_globNum, 0, sizeof(int)));
     BF_HIP_TRY(hipMemset(m->d_res, 0, sizeof(FrameResult)));
     m->validImages.assign(maxImages, 0);
@@ -1142,8 +1191,9 @@ int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_sift
 
 int bf_siftmgr_destroy(bf_siftmgr* m) {
     if (!m) return BF_OK;
-    hipFree(m->d_keys); hipFree(m->d_descs); hipFree(m->d_numKeys); hipFree(m->d_numMatches); hipFree(m->d_dist); hipFree(m->d_idx);
-    hipFree(m->d_numFilt); hipFree(m->d_fdist); hipFree(m->d_fidx); hipFree(m->d_T); hipFree(m->d_Tinv); hipFree(m->d_validImages); hipFree(m->d_validOpt);
+    hipFree(m->d_keys); hipFree(m->d_descs); hipFree(m->d_numKeys);
+    for (auto& P : m->sets) { hipFree(P.numMatches); hipFree(P.dist); hipFree(P.idx); hipFree(P.numFilt); hipFree(P.fdist); hipFree(P.fidx); hipFree(P.T); hipFree(P.Tinv); }
+    hipFree(m->d_validImages); hipFree(m->d_validOpt);
     hipFree(m->d_glob); hipFree(m->d_globKeys); hipFree(m->d_globNum); hipFree(m->d_res);
     if (m->fuseScratch) hipFree(m->fuseScratch);
     if (m->d_fuseError) hipFree(m->d_fuseError);
@@ -1212,8 +1262,8 @@ int bf_siftmgr_get_num_keypoints(bf_siftmgr* m, uint32_t first, uint32_t count, 
 
 int bf_siftmgr_match(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames, float distMax, float ratioMax) {
     BF_REQUIRE(m && numFrames <= m->numImages && curFrame < numFrames && startFrame < numFrames, "frame range out of bounds");
-    MatchArgs a = {m->d_descs, m->d_numKeys, m->d_validImages, m->maxKeys, curFrame, startFrame, distMax, ratioMax, m->d_numMatches, m->d_dist, m->d_idx};
-    k_match<<<numFrames - startFrame, 1024, 0, m->stream>>>(a);
+    MatchArgs a = {m->d_descs, m->d_numKeys, m->d_validImages, m->maxKeys, curFrame, startFrame, distMax, ratioMax, m->d_numMatches, m->d_dist, m->d_idx, m->speculative ? 1 : 0};
+    k_match<<<numFrames - startFrame, 1024, 0, pairStreamOf(m)>>>(a);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -1223,7 +1273,7 @@ int bf_siftmgr_filter_keypoint_matches(bf_siftmgr* m, uint32_t curFrame, uint32_
     BF_REQUIRE(m && siftIntrinsicsInv && numFrames <= m->numImages && startFrame < numFrames, "frame range out of bounds");
     FilterArgs a = {m->d_keys, curFrame, startFrame, m->d_numMatches, m->d_dist, m->d_idx, m->d_numFilt, m->d_fdist, m->d_fidx, m->d_T, m->d_Tinv,
                     toM44(siftIntrinsicsInv), (int)minNumMatches, maxKabschRes2};
-    k_filter_kabsch<<<numFrames - startFrame, 64, 0, m->stream>>>(a);
+    k_filter_kabsch<<<numFrames - startFrame, 64, 0, pairStreamOf(m)>>>(a);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -1232,7 +1282,7 @@ int bf_siftmgr_filter_matches_by_surface_area(bf_siftmgr* m, uint32_t curFrame, 
                                               float areaThresh) {
     BF_REQUIRE(m && colorIntrinsicsInv && numFrames <= m->numImages && startFrame < numFrames, "frame range out of bounds");
     AreaArgs a = {m->d_keys, curFrame, startFrame, m->d_numFilt, m->d_fidx, toM44(colorIntrinsicsInv), areaThresh};
-    k_filter_surface_area<<<numFrames - startFrame, 64, 0, m->stream>>>(a);
+    k_filter_surface_area<<<numFrames - startFrame, 64, 0, pairStreamOf(m)>>>(a);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -1248,7 +1298,7 @@ int bf_siftmgr_filter_matches_by_dense_verify(bf_siftmgr* m, uint32_t curFrame, 
     a.numFilt = m->d_numFilt; a.T = m->d_T; a.frames = d_cachedFrames;
     a.distThresh = distThresh; a.normalThresh = normalThresh; a.errThresh = errThresh; a.corrThresh = corrThresh; a.dmin = sensorDepthMin; a.dmax = sensorDepthMax;
     BF_REQUIRE(imageWidth * ((imageHeight + 31u) / 32u) <= DV_THREADS, "cache frame too large for the dense verification block");
-    k_filter_dense_verify<<<numFrames - startFrame, DV_THREADS, 0, m->stream>>>(a);
+    k_filter_dense_verify<<<numFrames - startFrame, DV_THREADS, 0, pairStreamOf(m)>>>(a);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }

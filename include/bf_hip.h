@@ -421,6 +421,14 @@ BF_API int bf_siftmgr_filter_matches_by_dense_verify(bf_siftmgr* m, uint32_t cur
                                                      float distThresh, float normalThresh, float colorThresh,
                                                      float errThresh, float corrThresh, float sensorDepthMin,
                                                      float sensorDepthMax);
+/* MI355X addition: the per-pair result arrays (d_currNumMatchesPerImagePair ... d_currFilteredTransformsInv, SIFTImageManager.h:262-276) exist twice.
+ * _set_pair_stage selects the set (0 / 1) and the stream (null: the manager's) the pair kernels above are issued on from now on, so that the pair
+ * kernels of frame k + 1 can run beside those of frame k; speculative != 0: match does not consult the valid flags of the previous images (they may
+ * still be in the making on the manager's stream) and _commit_pairs - on the manager's stream, once those flags are final - clears the pairs
+ * Bundler::matchAndFilter would not have matched (Bundler.cpp:126-129).  Ordering between the streams is the caller's.  The accessors of the per-pair
+ * arrays name the selected set.  Default (0, null, 0): the reference's behaviour. */
+BF_API int bf_siftmgr_set_pair_stage(bf_siftmgr* m, uint32_t set, void* hip_stream, int speculative);
+BF_API int bf_siftmgr_commit_pairs(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames);
 /* filterFrames                                                 SIFTImageManager.cpp:551-575 (syncs, returns the
  * last matched frame or 0xFFFFFFFF).  The _async form only enqueues the decision; it is read back together with
  * the residual count by bf_siftmgr_sync_frame_result (one D2H per frame).                              */

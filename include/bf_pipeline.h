@@ -280,6 +280,11 @@ BF_API int bf_online_bundler_process_frame(bf_online_bundler* ob, uint32_t frame
  * b + L enters processInput (_begin) / its re-integration scheduling (_apply_lagged_solve, which a host loop calls before it consults
  * the TrajectoryManager for that frame), and at the first iteration past the end of the sequence at the latest.  Results are a function
  * of (input, L): reproducible, and comparable with the oracle loop under the same L.  L = 0 (default): the serial order. */
+/* Pair stages side by side: with two streams of the caller's, the staged detection of frame k is committed and its per-pair kernels (match, Kabsch filter,
+ * surface-area filter, dense verification - each pair depends on its two images only) run on stream k & 1, into the sift manager's result set k & 1
+ * (bf_siftmgr_set_pair_stage), while frame k - 1's are still running on the other stream; the bundling stream carries the short commit stage (which
+ * previous images are valid, filterFrames, EntryJ rows, the pose kernel).  Same results as on one stream.  (null, null): off. */
+BF_API int bf_online_bundler_set_pair_streams(bf_online_bundler* ob, void* hip_stream0, void* hip_stream1);
 BF_API int bf_online_bundler_set_solve_lag(bf_online_bundler* ob, uint32_t lag, void* solve_stream);
 BF_API int bf_online_bundler_get_solve_lag(bf_online_bundler* ob, uint32_t* lag);
 BF_API int bf_online_bundler_apply_lagged_solve(bf_online_bundler* ob, uint32_t frame);
