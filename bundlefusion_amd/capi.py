@@ -187,6 +187,11 @@ class SceneRepHashSDF:
     def set_external_alloc(self, enable=True):
         check(lib.bf_scene_set_external_alloc(self._h, int(enable)))
 
+    def set_alloc_comm(self, comm, capacity_keys=1 << 15):
+        """The operators' own allocation with the ray march divided over the ranks of `comm` (capi.Comm or None): bf_scene_set_alloc_comm."""
+        check(lib.bf_scene_set_alloc_comm(self._h, comm._h if comm is not None else None, int(capacity_keys)))
+        self._alloc_comm = comm          # keep the callback alive
+
     def alloc_collect(self, cam_to_world, depth, cam, part, parts, keys, slots, count):
         """keys: torch int64 [capacity] cuda, slots: int32 [capacity], count: int32 [1] (see bf_scene_alloc_collect)"""
         d = self._data(depth, None)
@@ -821,6 +826,93 @@ def sensor_desc(width, height, K):
     return s
 
 
+_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class Comm:
+    """Python view of `bf_comm` (include/bf_comm.h): the all-gather of the multi-GPU partition.
+
+    Comm.rccl(world, rank, broadcast): RCCL, bootstrapped NCCL-style - rank 0 draws the unique id, `broadcast(bytes_or_None) -> bytes` hands it to every
+    rank (e.g. through torch.distributed's store or a gloo broadcast).  Comm.torch_group(group): the all-gather through a torch.distributed process
+    group (gloo: through host memory - how two ranks share the one GPU of a test box); collectives issued through one Comm must not interleave with
+    other collectives on the same group from another thread - give the volume thread its own group (dist.new_group)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._cb = None
+
+    @classmethod
+    def rccl(cls, world, rank, broadcast):
+        c = cls()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            check(lib.bf_comm_unique_id(ident))
+        raw = broadcast(bytes(ident) if rank == 0 else None)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        check(lib.bf_comm_create_rccl(ident, int(world), int(rank), C.byref(c._h)))
+        return c
+
+    @classmethod
+    def torch_group(cls, group=None):
+        import torch
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        nccl = dist.get_backend(group) == "nccl"
+
+        def gather(user, d_send, d_recv, nbytes, stream):
+            try:
+                n = int(nbytes)
+                check(lib.bf_stream_synchronize(C.c_void_p(stream)))
+                send = torch.empty(n, dtype=torch.uint8, device="cuda" if nccl else "cpu")
+                check(lib.bf_memcpy(C.c_void_p(send.data_ptr()), C.c_void_p(d_send), C.c_size_t(n)))
+                if nccl:
+                    out = torch.empty(world * n, dtype=torch.uint8, device="cuda")
+                    dist.all_gather_into_tensor(out, send, group=group)
+                    torch.cuda.synchronize()
+                else:
+                    parts = [torch.empty(n, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, send, group=group)
+                    out = torch.cat(parts)
+                check(lib.bf_memcpy(C.c_void_p(d_recv), C.c_void_p(out.data_ptr()), C.c_size_t(world * n)))
+                return 0
+            except Exception as e:          # never let an exception cross the C boundary
+                import sys
+                print("Comm.torch_group all-gather failed: %r" % (e,), file=sys.stderr)
+                return 1
+        c = cls()
+        c._cb = _ALL_GATHER_FN(gather)
+        check(lib.bf_comm_create_callback(c._cb, None, int(world), int(rank), C.byref(c._h)))
+        return c
+
+    def world(self):
+        w, r = C.c_uint32(), C.c_uint32()
+        check(lib.bf_comm_world(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def all_gather(self, send, recv, stream=None):
+        """send / recv: torch cuda uint8 tensors (recv = world x send)"""
+        check(lib.bf_comm_all_gather(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), C.c_uint64(send.numel()), C.c_void_p(stream)))
+
+    def chunk_exchange(self, mine, stream=None):
+        """One round of chunk packages: `mine` (uint8 numpy array) -> list of `world` arrays in owner order (bf_chunk_exchange)."""
+        w, _ = self.world()
+        mine = np.ascontiguousarray(mine, np.uint8)
+        out = np.zeros(w * mine.size, np.uint8)
+        check(lib.bf_chunk_exchange(self._h, mine.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint64(mine.size), C.c_void_p(stream)))
+        return [np.ascontiguousarray(out[r * mine.size:(r + 1) * mine.size]) for r in range(w)]
+
+    def close(self):
+        if self._h:
+            lib.bf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Pipeline:
     """Python view of `bf_pipeline`: the serial frame loop of DepthSensing.cpp (ingest -> bundling input -> re-integration ->
     integration of the current frame -> local / global optimisation)."""
@@ -843,6 +935,12 @@ class Pipeline:
 
     def set_volume_shard(self, rank, world):
         check(lib.bf_pipeline_set_volume_shard(self._h, rank, world))
+
+    def set_comm(self, comm, capacity_keys=1 << 15):
+        """Divide the allocation's ray march of every TSDF operator of this loop over the ranks of `comm` (bf_pipeline_set_comm; the volume must be
+        sharded with set_volume_shard(rank, world) of the same communicator)."""
+        check(lib.bf_pipeline_set_comm(self._h, comm._h if comm is not None else None, int(capacity_keys)))
+        self._comm = comm
 
     def set_solve_lag(self, lag):
         """0: the reference's serial order (default).  1..s_submapSize: the chunk solves run on their own thread / stream and are applied exactly `lag`

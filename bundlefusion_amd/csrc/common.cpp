@@ -43,6 +43,14 @@ int bf_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
     return BF_OK;
 }
 int bf_device_synchronize(void) { BF_HIP_TRY(hipDeviceSynchronize()); return BF_OK; }
+// one stream only, and a blocking copy whose direction follows from the pointers (hipMemcpyDefault): what an all-gather callback of a host language needs
+// (bf_comm_create_callback) without stopping the other streams of the process
+int bf_stream_synchronize(void* hip_stream) { BF_HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream)); return BF_OK; }
+int bf_memcpy(void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return BF_OK;
+    BF_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return BF_OK;
+}
 // CPUs of the NUMA node the HIP device hangs off, as a Linux cpulist ("0-63,128-191"); empty when the platform does not say.
 static std::string deviceCpuList(int device) {
     char bus[64] = {0};

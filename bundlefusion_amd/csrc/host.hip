@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/bf_pipeline.h"
+#include "../../include/bf_comm.h"
 #include "bf_device.h"
 #include "bf_internal.h"
 #include "bf_se3.h"
@@ -1050,7 +1051,7 @@ struct bf_online_bundler {
     std::vector<std::vector<int>> localTrajectoriesValid;
     std::vector<int> invalidImagesList;
     std::vector<m44> currIntegrateTransform;
-    m44* h_pinT = nullptr;                 // two pinned slots, indexed by frame & 1 (two processInput calls may be in flight)
+    m44* h_pinT = nullptr;                 // PEND pinned slots, indexed by frame % PEND (several processInput calls may be in flight)
     // BundlerState (OnlineBundlerHelper.h:70-109)
     int lastFrameProcessed = -1; bool bLastFrameValid = false;
     int localToSolve = -1, lastLocalSolved = -1;
@@ -1071,7 +1072,8 @@ struct bf_online_bundler {
     // stream BEHIND frame k's before the host waits for frame k's result - everything frame k + 1's chain needs of frame k is device state (key points,
     // validity flags, the SIFT trajectory entry: the fix-up of an invalid frame, OnlineBundler.cpp:215-221, is the kernel k_sift_fixup).
     struct Pend { int phase = 0; uint32_t frame = 0, cur = 0, num = 0; bool lastLocal = false, match = false, swapped = false; bf_bundler* b = nullptr; };
-    Pend pend[2];
+    static constexpr int PEND = 4;         // processInput calls that may be in flight
+    Pend pend[PEND];
     int pendHead = 0, pendCount = 0;
     // ---- lagged solve (bf_online_bundler_set_solve_lag): the chunk's solves (optimizeLocal + processGlobal + optimizeGlobal, OnlineBundler.cpp:229-240) run on
     // their own host thread and stream, like the reference's optimiser thread (FriedLiver.cpp:112-123) - but their results become visible at a DEFINED
@@ -1377,7 +1379,7 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
     BF_HIP_TRY(hipMalloc((void**)&ob->d_siftTrajectory, sizeof(m44) * nAll));
     BF_HIP_TRY(hipMalloc((void**)&ob->d_currIntegrateTransform, sizeof(m44) * nAll));
     BF_HIP_TRY(hipMalloc((void**)&ob->d_imageInvalidateList, sizeof(int) * nAll));
-    BF_HIP_TRY(hipHostMalloc((void**)&ob->h_pinT, 2 * sizeof(m44)));
+    BF_HIP_TRY(hipHostMalloc((void**)&ob->h_pinT, bf_online_bundler::PEND * sizeof(m44)));
     BF_HIP_TRY(hipMalloc((void**)&ob->d_completeShadow, sizeof(m44) * nAll));
     BF_HIP_TRY(hipMemset(ob->d_completeShadow, 0, sizeof(m44) * nAll));
     BF_HIP_TRY(hipEventCreateWithFlags(&ob->evChunk, hipEventDisableTiming));
@@ -1621,7 +1623,7 @@ extern "C" {
 // earlier frame whose detection was staged by bf_online_bundler_detect_ahead while newer frames were already ingested.
 int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t curFrame) {
     BF_REQUIRE(ob, "null bundler");
-    BF_REQUIRE(ob->pendCount < 2, "more than two processInput calls in flight");
+    BF_REQUIRE(ob->pendCount < bf_online_bundler::PEND, "too many processInput calls in flight");
     const bool staged = ob->stagedFrame[curFrame & 1u] == (int)curFrame;
     {
         uint32_t imFrame;
@@ -1629,7 +1631,7 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
         BF_REQUIRE(staged || imFrame == curFrame, "frame is neither staged nor the image manager's current frame");
     }
     const bool bIsLastLocal = ob->isLastLocalFrame(curFrame);
-    bf_online_bundler::Pend& P = ob->pend[(ob->pendHead + ob->pendCount) % 2];
+    bf_online_bundler::Pend& P = ob->pend[(ob->pendHead + ob->pendCount) % bf_online_bundler::PEND];
     P = bf_online_bundler::Pend();
     P.frame = curFrame; P.lastLocal = bIsLastLocal; P.b = ob->local;
     if (curFrame > 0 && ob->lastFrameProcessed == (int)curFrame) {                 // sequence has ended
@@ -1698,7 +1700,7 @@ int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t 
                                          curLocalFrame, (float*)(ob->d_currIntegrateTransform + curFrame), ob->stream));
         k_sift_fixup<<<1, 1, 0, ob->stream>>>(d_res, ob->d_siftTrajectory, curFrame);
         BF_HIP_TRY(hipGetLastError());
-        BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT + (curFrame & 1u), ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
+        BF_HIP_TRY(hipMemcpyAsync(ob->h_pinT + (curFrame % bf_online_bundler::PEND), ob->d_currIntegrateTransform + curFrame, sizeof(m44), hipMemcpyDeviceToHost, ob->stream));
         BF_TRY(bf_siftmgr_prefetch_frame_result(ob->local->mgr));      // the read-back itself is enqueued now; _end only waits for it
         BF_TRY(bf_siftmgr_set_pair_stage(ob->local->mgr, spec ? (uint32_t)par : 0u, nullptr, 0));      // (direct callers of this bundler get the reference's behaviour)
         P.match = true;
@@ -1721,7 +1723,7 @@ int bf_online_bundler_process_input_end(bf_online_bundler* ob) {
     BF_REQUIRE(ob, "null bundler");
     BF_REQUIRE(ob->pendCount > 0, "process_input_end without process_input_begin");
     const bf_online_bundler::Pend P = ob->pend[ob->pendHead];
-    ob->pendHead = (ob->pendHead + 1) % 2; ob->pendCount--;
+    ob->pendHead = (ob->pendHead + 1) % bf_online_bundler::PEND; ob->pendCount--;
     if (P.phase == 2) return BF_OK;
     const uint32_t curFrame = P.frame;
     ob->bLastFrameValid = true;
@@ -1730,7 +1732,7 @@ int bf_online_bundler_process_input_end(bf_online_bundler* ob) {
         BF_TRY(matchAndFilterFinish(P.b, P.cur, P.num, &last));
         ob->bLastFrameValid = last != 0xFFFFFFFFu;
         if (!ob->bLastFrameValid) ob->currIntegrateTransform[curFrame] = minfM();      // (the SIFT trajectory entry was fixed up on the device: k_sift_fixup)
-        else ob->currIntegrateTransform[curFrame] = ob->h_pinT[curFrame & 1u];
+        else ob->currIntegrateTransform[curFrame] = ob->h_pinT[curFrame % bf_online_bundler::PEND];
     }
     if (P.lastLocal) BF_TRY(obPrepareLocalSolve(ob, curFrame, false, P.b, !P.swapped));
     ob->lastFrameProcessed = (int)curFrame;
@@ -1833,7 +1835,10 @@ struct bf_pipeline {
     // just enqueued).  A chunk's last frame in the serial order is the exception: its solves change what the next frame's chain reads, so its body
     // runs BEFORE that chain is enqueued (in the lagged mode there is no such dependence).
     int deferred = -1;              // frame that has been detected; its matching chain is not enqueued yet
-    std::deque<uint32_t> begun;     // frames whose chain is enqueued and whose body has not run, oldest first (at most 2)
+    std::deque<uint32_t> begun;     // frames whose chain is enqueued and whose body has not run, oldest first (at most `depth`)
+    uint32_t depth = 3;             // chains in flight across a call boundary + 1 (BF_PIPELINE_DEPTH, 2 .. PEND): the call that delivers frame n enqueues the chain of frame
+                                    // n - 1 and runs the body of frame n - depth.  Measured (gpurun r04c, depth 2): a chain's twelve dependent launches take 1.0 - 1.2 ms from
+                                    // enqueue to result next to the volume's and the detector's queues - twice the sum of their kernel times - so one call of slack is not enough
     hipStream_t sSolve = nullptr;   // stream of the lagged solves (bf_pipeline_set_solve_lag)
     hipStream_t sIngest = nullptr;  // the ingest filters of frame n + 1 run beside the detection of frame n (two input sets in the image manager)
     hipStream_t sPair[2] = {nullptr, nullptr};      // pair stages of consecutive frames side by side (bf_online_bundler_set_pair_streams)
@@ -2052,7 +2057,7 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (got && ahead) BF_TRY(bf_online_bundler_detect_ahead_after(p->ob, p->evIngest[frame % bf_pipeline::NEV]));
     p->hostProfile[1] += plNow() - tIn;
     // ---- ... and the body of the oldest frame in flight, whose chain was enqueued by the previous call
-    while (p->begun.size() > 1) BF_TRY(plRestFront(p));
+    while (p->begun.size() + 1 > p->depth) BF_TRY(plRestFront(p));
     if (ahead && got) p->deferred = (int)frame;
     else if (p->im->currFrame > 0) {
         BF_TRY(plBody(p, frame, got != 0));
@@ -2123,13 +2128,16 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
+    if (const char* e = getenv("BF_PIPELINE_DEPTH")) p->depth = (uint32_t)std::min(std::max(atoi(e), 2), bf_online_bundler::PEND);
     BF_TRY(bf_image_manager_set_stream(p->im, p->sIngest));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_online_bundler_set_detect_stream(p->ob, p->sDetect));
     for (uint32_t k = 0; k < 2; ++k) BF_TRY(bf_image_manager_set_input_guard(p->im, k, p->ob->evDetect[k]));      // the staged detection of the frame that used the set last
     {
-        const char* e = getenv("BF_PIPELINE_PAIR_STREAMS");            // 0: the pair stage on the bundling stream (one chain at a time), for A/B measurements
-        if (!e || atoi(e) != 0) BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPair[0], p->sPair[1]));
+        // BF_PIPELINE_PAIR_STREAMS=1: the pair stages of consecutive frames on two streams.  Off by default: measured 659 vs 697 frames/s (gpurun r04c) - every
+        // cross-stream event hop costs ~40 us on this runtime and the stage needs four of them per frame, more than the overlap of two Kabsch filters returns
+        const char* e = getenv("BF_PIPELINE_PAIR_STREAMS");
+        if (e && atoi(e) != 0) BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPair[0], p->sPair[1]));
     }
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
@@ -2172,6 +2180,13 @@ int bf_pipeline_set_solve_lag(bf_pipeline* p, uint32_t lag) {
     return bf_online_bundler_set_solve_lag(p->ob, lag, p->sSolve);
 }
 int bf_pipeline_get_solve_lag(bf_pipeline* p, uint32_t* lag) { BF_REQUIRE(p && lag, "null argument"); return bf_online_bundler_get_solve_lag(p->ob, lag); }
+
+int bf_pipeline_set_comm(bf_pipeline* p, bf_comm* comm, uint32_t capacity_keys) {
+    BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFlush(p));
+    BF_TRY(volDrain(p));
+    return bf_scene_set_alloc_comm(p->scene, comm, capacity_keys);
+}
 
 int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world) {
     BF_REQUIRE(p, "null pipeline");
@@ -2474,7 +2489,7 @@ int bf_pipeline_process_frame_chunked(bf_pipeline* p, const float* d_depth, cons
     p->ob->extChunk = pkg;
     int rc = obProcessInputChunked(p->ob, frame, pkg, localIdx);
     if (rc == BF_OK) {           // phase 2: processInput already complete, _end has nothing to read back
-        bf_online_bundler::Pend& P = p->ob->pend[(p->ob->pendHead + p->ob->pendCount) % 2];
+        bf_online_bundler::Pend& P = p->ob->pend[(p->ob->pendHead + p->ob->pendCount) % bf_online_bundler::PEND];
         P = bf_online_bundler::Pend(); P.phase = 2; P.frame = frame;
         p->ob->pendCount++;
         rc = plBodyRest(p, frame, true);

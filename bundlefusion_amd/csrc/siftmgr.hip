@@ -1114,9 +1114,9 @@ struct bf_siftmgr {
     bf_entry_j* d_glob = nullptr; uint2* d_globKeys = nullptr; int* d_globNum = nullptr;
     // the frame's single read-back.  Up to RES_SLOTS read-backs may be in flight (bf_siftmgr_prefetch_frame_result enqueues one behind the work issued so
     // far, bf_siftmgr_sync_frame_result consumes the oldest): the frame loop enqueues the matching chain of frame k + 1 before it waits for frame k.
-    static constexpr int RES_SLOTS = 2;
+    static constexpr int RES_SLOTS = 4;
     FrameResult* d_res = nullptr; FrameResult* h_res = nullptr;      // h_res: RES_SLOTS pinned records
-    hipEvent_t evRes[RES_SLOTS] = {nullptr, nullptr};
+    hipEvent_t evRes[RES_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int resHead = 0, resCount = 0;
     std::vector<int> validImages;
     uint32_t numImages = 0, currentImage = 0, globNumResiduals = 0;

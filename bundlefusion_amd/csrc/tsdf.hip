@@ -26,6 +26,7 @@
 
 #include "bf_device.h"
 #include "bf_internal.h"
+#include "../../include/bf_comm.h"
 
 using namespace bf;
 
@@ -1502,6 +1503,11 @@ struct bf_scene {
     uint32_t gridCompact = 0, gridUpdateCol = 0, gridUpdateColPlain = 0;
     bool forceExactDiv = false;     // k_update_col takes the literal `/` path for every block (BF_TSDF_EXACT_DIV=1; tests)
     bool externalAlloc = false;     // bf_scene_set_external_alloc: integrate / re-integrate do not allocate (the caller ran bf_scene_alloc_collect / _ingest)
+    // bf_scene_set_alloc_comm: the operators' own allocation with the ray march divided over the ranks of a communicator - collect on this rank's band of the
+    // pixel tiles, ONE all-gather of fixed-size records {count, keys[capacity]} on the allocation stream, ingest of every rank's list, placement
+    bf_comm* allocComm = nullptr;
+    uint32_t allocCap = 0;          // keys per rank and operator
+    uint8_t *d_allocSend = nullptr, *d_allocRecv = nullptr; uint32_t* d_allocSlots = nullptr;
     int arith = BF_TSDF_ARITH_FAST; // bf_scene_set_arith / BF_TSDF_ARITH: fast (k_update_apx: the contract of the reference's own GPU build; default since round 4) or
                                     // exact (k_update_col: IEEE op by op, bit-comparable with a host build of the reference and with the oracle)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
@@ -1684,10 +1690,32 @@ int refreshStaleList(bf_scene* s) {                              // a fused re-i
     return endExclusive(s);
 }
 
-void launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_depth) {      // alloc :328-352
+int launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_depth) {      // alloc :328-352
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
+    if (s->allocComm) {
+        // the march divided over the ranks: rank r marches the tiles [r T / G, (r + 1) T / G) and collects the distinct in-frustum keys it
+        // meets; the records {count, keys} of all ranks are all-gathered on this stream (RCCL: ring over xGMI; nothing waits for it but the ingest behind
+        // it - the allocation stream runs up to three operators ahead of the voxel updates); every rank queues the keys of every list that it owns
+        uint32_t world = 1, rank = 0;
+        BF_TRY_RC(bf_comm_world(s->allocComm, &world, &rank));
+        const uint64_t rec = 8 + 8ull * s->allocCap;
+        uint32_t* cnt = reinterpret_cast<uint32_t*>(s->d_allocSend);
+        Collect c;
+        c.keys = reinterpret_cast<unsigned long long*>(s->d_allocSend + 8); c.slots = s->d_allocSlots; c.count = cnt; c.capacity = s->allocCap;
+        c.tile0 = (uint32_t)((uint64_t)tiles * rank / world); c.tile1 = (uint32_t)((uint64_t)tiles * (rank + 1) / world);
+        BF_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
+        if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, s->d, f, d_depth, c);
+        hipLaunchKernelGGL(k_collect_release, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 2048u)), dim3(256), 0, st, s->d, c);
+        BF_TRY_RC(bf_comm_all_gather(s->allocComm, s->d_allocSend, s->d_allocRecv, rec, st));
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint8_t* base = s->d_allocRecv + rec * r;
+            hipLaunchKernelGGL(k_alloc_ingest, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 1024u)), dim3(256), 0, st, s->d, f,
+                               reinterpret_cast<const unsigned long long*>(base + 8), reinterpret_cast<const uint32_t*>(base), s->allocCap);
+        }
+    } else
     hipLaunchKernelGGL(k_alloc_candidates<false>, dim3(div_up(tiles, 4)), dim3(256), 0, st, s->d, f, d_depth, Collect{});
     hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
+    return BF_OK;
 }
 
 // What the allocation stream has to wait for before it may touch the table or read a frame: the event the caller ordered the next operator behind
@@ -1708,7 +1736,7 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     BF_TRY_RC(prepWaits(s, ps));
     if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
     const Dev dv = devBuf(s, b);
-    if (kind != 1 && !s->externalAlloc) launchAllocOn(s, ps, f, data->d_depthData);      // de-integration neither allocates nor frees
+    if (kind != 1 && !s->externalAlloc) BF_TRY_RC(launchAllocOn(s, ps, f, data->d_depthData));      // de-integration neither allocates nor frees
     if (kind == 2) {
         hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
         hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
@@ -1899,6 +1927,29 @@ int bf_scene_alloc_sync(bf_scene* s) {          // the allocation stream has dra
     return BF_OK;
 }
 
+// The operators' own allocation over a communicator (see bf_scene::allocComm).  The volume must be sharded consistently (bf_scene_set_shard(rank, world) of the
+// same communicator); every rank must run the same operator sequence (the collective is issued inside integrate / re-integrate).  capacity_keys: upper bound
+// of the distinct in-frustum blocks one rank's band of pixel tiles meets in one operator (exceeding it raises the scene's error flag, never drops silently).
+// comm == null: back to the local march.
+int bf_scene_set_alloc_comm(bf_scene* s, bf_comm* comm, uint32_t capacity_keys) {
+    BF_REQUIRE(s, "null scene");
+    BF_TRY_RC(syncAll(s));
+    if (s->d_allocSend) { (void)hipFree(s->d_allocSend); s->d_allocSend = nullptr; }
+    if (s->d_allocRecv) { (void)hipFree(s->d_allocRecv); s->d_allocRecv = nullptr; }
+    if (s->d_allocSlots) { (void)hipFree(s->d_allocSlots); s->d_allocSlots = nullptr; }
+    s->allocComm = nullptr; s->allocCap = 0;
+    if (!comm) return BF_OK;
+    BF_REQUIRE(capacity_keys >= 64, "capacity_keys too small");
+    uint32_t world = 1, rank = 0;
+    BF_TRY_RC(bf_comm_world(comm, &world, &rank));
+    const uint64_t rec = 8 + 8ull * capacity_keys;
+    BF_HIP_TRY(hipMalloc((void**)&s->d_allocSend, rec));
+    BF_HIP_TRY(hipMalloc((void**)&s->d_allocRecv, rec * world));
+    BF_HIP_TRY(hipMalloc((void**)&s->d_allocSlots, sizeof(uint32_t) * capacity_keys));
+    s->allocComm = comm; s->allocCap = capacity_keys;
+    return BF_OK;
+}
+
 // Arithmetic contract of the voxel update (see k_update_apx): BF_TSDF_ARITH_EXACT evaluates CUDASceneRepHashSDF.cu:425-516 IEEE
 // operation by operation (bit-comparable with a host build of the reference); BF_TSDF_ARITH_FAST is the contract of the reference's
 // own GPU build (-use_fast_math, FriedLiver.vcxproj:124): approximate division, FMA contraction.  Allocation, lists, weights and
@@ -1922,6 +1973,9 @@ int bf_scene_destroy(bf_scene* s) {
     (void)syncAll(s);
     for (void* q : s->allocations) hipFree(q);
     for (uint2* t : s->texel) if (t) hipFree(t);
+    if (s->d_allocSend) hipFree(s->d_allocSend);
+    if (s->d_allocRecv) hipFree(s->d_allocRecv);
+    if (s->d_allocSlots) hipFree(s->d_allocSlots);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int b = 0; b < bf_scene::NB; ++b) { if (s->evPrep[b]) hipEventDestroy(s->evPrep[b]); if (s->evUpd[b]) hipEventDestroy(s->evUpd[b]); }
     for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);

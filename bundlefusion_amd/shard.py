@@ -65,9 +65,10 @@ class ChunkedRunner:
     of a local chunk without a package is reached, the round of `world` chunks containing it is produced: local half of this rank's
     chunk of the round (capi.ChunkWorker), then ONE all-gather.  Every rank must call advance() with the same arguments."""
 
-    def __init__(self, pipe, worker, feed, submap, rank=0, world=1, device=None, prefetch=True):
+    def __init__(self, pipe, worker, feed, submap, rank=0, world=1, device=None, prefetch=True, comm=None):
         self.pipe, self.worker, self.feed, self.S = pipe, worker, feed, submap
         self.rank, self.world, self.device = rank, world, device
+        self.comm = comm                # capi.Comm: the round's all-gather through the C ABI (bf_chunk_exchange: RCCL, or the host's callback) instead of torch.distributed
         self.next_frame = 0
         self.pkgs = {}
         self.rounds = 0
@@ -134,7 +135,7 @@ class ChunkedRunner:
             if isinstance(p, BaseException):
                 raise p
         self.local_chunks += len(produced)
-        got = gather_packages(mine, self.world, self.rank, self.device)
+        got = self.comm.chunk_exchange(mine) if self.comm is not None else gather_packages(mine, self.world, self.rank, self.device)
         self.rounds += 1
         for i, p in enumerate(got):
             self.pkgs[r0 + i] = p

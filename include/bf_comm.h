@@ -18,7 +18,7 @@
 #ifndef BF_COMM_H
 #define BF_COMM_H
 
-#include "bf_hip.h"
+#include "bf_pipeline.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -50,6 +50,18 @@ BF_API int bf_comm_all_gather(bf_comm* c, const void* d_send, void* d_recv, uint
  * `world` packages in owner order into h_all (world * package_bytes host bytes).  One all-gather through device staging buffers of
  * the comm (allocated at first use), on `hip_stream`; synchronous for the caller: h_all is complete when the call returns. */
 BF_API int bf_chunk_exchange(bf_comm* c, const void* h_mine, void* h_all, uint64_t package_bytes, void* hip_stream);
+
+/* The TSDF operators' own allocation with the ray march DIVIDED over the ranks (VoxelUtilHashSDF.h:478-479,623 is the table it fills;
+ * CUDASceneRepHashSDF.cu:165-251 the march).  With the volume sharded by home bucket (bf_scene_set_shard) every rank would have to march all pixels to
+ * find its own blocks.  Instead, inside every integrate / re-integrate: rank r marches a band of the 8x8 pixel tiles and collects the distinct in-frustum
+ * block keys it meets; ONE all-gather of fixed-size records {count, keys[capacity_keys]} on the scene's allocation stream; every rank queues the keys of
+ * every list whose home bucket it owns, then places.  The table is the one the local march builds (queuing is idempotent, bins are sorted before
+ * placement).  Every rank must issue the same operator sequence.  capacity_keys bounds the keys one rank collects per operator (exceeding it raises the
+ * scene's error flag).  comm == null: back to the local march. */
+BF_API int bf_scene_set_alloc_comm(bf_scene* s, bf_comm* comm, uint32_t capacity_keys);
+/* the same for the volume of a frame loop: the pipeline's volume thread issues the collectives (one per integrate / re-integrate), on the volume's
+ * allocation stream; bf_pipeline_set_volume_shard(rank, world) of the same communicator must have been called.  Every rank must feed the same frames. */
+BF_API int bf_pipeline_set_comm(bf_pipeline* p, bf_comm* comm, uint32_t capacity_keys);
 
 #ifdef __cplusplus
 }

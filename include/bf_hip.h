@@ -41,6 +41,9 @@ BF_API const char* bf_last_error(void);
 BF_API const char* bf_version(void);
 /* number of visible HIP devices, <0 on error (never falls back to a CPU path) */
 BF_API int bf_device_count(void);
+/* measurement aid (tools/hbm_block_probe.py): the voxel update's access pattern - one wave per 6144-byte SDF block of `d_list` (n block indices into the heap
+ * d_heap), read completely, writeRows12 twelfths written back - with no arithmetic; mean launch time over `reps` launches in microseconds */
+BF_API int bf_probe_block_copy(uint8_t* d_heap, const uint32_t* d_list, uint32_t n, uint32_t writeRows12, uint32_t grid, uint32_t reps, void* hip_stream, float* mean_us);
 /* Plumbing for hosts that hold raw pointers only: copies / a device-wide fence issued by this library's own HIP
  * runtime (a process may hold more than one copy of libamdhip64; work is only ordered within one of them). */
 /* Restrict every thread of the calling process to the CPUs of the NUMA node HIP device `device` is attached to (intersected with the
@@ -51,6 +54,9 @@ BF_API int bf_bind_host_threads_to_device(int device, char* cpulist_out, size_t 
 BF_API int bf_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 BF_API int bf_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 BF_API int bf_device_synchronize(void);
+/* one stream only / a blocking copy whose direction follows from the pointers (hipMemcpyDefault): for all-gather callbacks of a host language (bf_comm.h) */
+BF_API int bf_stream_synchronize(void* hip_stream);
+BF_API int bf_memcpy(void* dst, const void* src, size_t bytes);
 
 /* ------------------------------------------------------------------------- */
 /* Voxel-hash TSDF:  DepthSensing/CUDASceneRepHashSDF.h                       */

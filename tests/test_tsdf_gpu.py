@@ -417,3 +417,100 @@ def test_sharded_allocation_collect_exchange_ingest(gpu, oracle, overlap):
     for s in shards + [whole]:
         dbg = s.debug_hash()
         assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0 and dbg["dropped"] == 0
+
+
+def test_divided_allocation_through_the_communicator(gpu):
+    """bf_scene_set_alloc_comm: the operators' own allocation with the ray march divided over the ranks of a bf_comm.  Two volumes in TWO THREADS of this
+    process (hash-bucket shards 0 and 1 of 2) run the same operator sequence; their communicator is the callback transport, whose all-gather meets at a
+    thread barrier - every integrate / re-integrate blocks in the collective until the other rank has issued the same operator, like RCCL.  The union of
+    the shards equals the unsharded volume built by the local march, bit for bit.  Then the RCCL transport itself with a world of one (the only world a
+    single-GPU box has): unique id, ncclCommInitRank, ncclAllGather on the scene's allocation stream through dlopen'ed librccl - same volume."""
+    import ctypes as C
+    import threading
+    import torch
+    from bundlefusion_amd import capi
+    W, H = 160, 120
+    frames = [synth.scene_room(k * 10, W, H) for k in range(5)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=50000, num_sdf_blocks=40000, voxel_size=0.02)
+    dev = [_to_dev(f[0], f[1]) for f in frames]
+
+    def script(sc):
+        poses = [f[2].copy() for f in frames]
+        for i in range(5):
+            sc.integrate(poses[i], dev[i][0], dev[i][1], cam)
+        for i, dt in ((2, 0.04), (4, 0.3)):
+            T2 = poses[i].copy(); T2[:3, 3] += np.float32(dt)
+            sc.reintegrate(poses[i], T2, dev[i][0], dev[i][1], cam); poses[i] = T2
+        sc.deintegrate(poses[0], dev[0][0], dev[0][1], cam)
+        sc.garbage_collect()
+        sc.integrate(poses[0], dev[0][0], dev[0][1], cam)
+
+    def blocks(s):
+        gh, gheap, gcnt, gvox = s.download()
+        occ = gh[gh["ptr"] != FREE_ENTRY]
+        return {tuple(int(v) for v in e["pos"]): gvox[int(e["ptr"]):int(e["ptr"]) + VOX_PER_BLOCK].tobytes() for e in occ}
+    whole = gpu.capi.SceneRepHashSDF(p); whole.set_overlap(True)
+    script(whole)
+    w = blocks(whole)
+    assert len(w) > 200
+    G = 2
+    barrier = threading.Barrier(G)
+    slots = [None] * G
+    calls = [0] * G
+
+    def make_comm(rank):
+        def gather(user, d_send, d_recv, nbytes, stream):
+            n = int(nbytes)
+            capi.check(capi.lib.bf_stream_synchronize(C.c_void_p(stream)))
+            buf = np.zeros(n, np.uint8)
+            capi.check(capi.lib.bf_memcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_send), C.c_size_t(n)))
+            slots[rank] = buf
+            barrier.wait(timeout=60)
+            out = np.concatenate(slots)
+            barrier.wait(timeout=60)             # nobody overwrites its slot before everybody has read all of them
+            capi.check(capi.lib.bf_memcpy(C.c_void_p(d_recv), out.ctypes.data_as(C.c_void_p), C.c_size_t(G * n)))
+            calls[rank] += 1
+            return 0
+        c = capi.Comm()
+        c._cb = capi._ALL_GATHER_FN(gather)
+        capi.check(capi.lib.bf_comm_create_callback(c._cb, None, G, rank, C.byref(c._h)))
+        return c
+    shards, errors = [None] * G, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            s = gpu.capi.SceneRepHashSDF(p); s.set_overlap(True); s.set_shard(rank, G)
+            s.set_alloc_comm(make_comm(rank), 1 << 13)
+            script(s)
+            shards[rank] = blocks(s)
+            dbg = s.debug_hash()
+            assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0 and dbg["dropped"] == 0
+            s.set_alloc_comm(None)
+        except BaseException as e:
+            errors.append(e)
+            barrier.abort()
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    assert calls == [8, 8]                       # one collective per allocating operator: 6 integrations + 2 re-integrations (a de-integration does not allocate)
+    assert not (shards[0].keys() & shards[1].keys()) and min(len(b) for b in shards) > 50
+    union = dict(shards[0]); union.update(shards[1])
+    assert union.keys() == w.keys() and all(union[k] == w[k] for k in w)
+    # RCCL itself, world of one
+    comm = capi.Comm.rccl(1, 0, lambda b: b)
+    assert comm.world() == (1, 0)
+    a = torch.arange(4096, dtype=torch.uint8, device="cuda"); b = torch.zeros_like(a)
+    comm.all_gather(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    s = gpu.capi.SceneRepHashSDF(p); s.set_overlap(True)
+    s.set_alloc_comm(comm, 1 << 15)
+    script(s)
+    assert blocks(s) == w
+    s.set_alloc_comm(None)

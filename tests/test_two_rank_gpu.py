@@ -1,6 +1,8 @@
 """GPU test (-m gpu) of the multi-GPU path with REAL objects in TWO PROCESSES: each rank owns a capi.Pipeline
 with its hash-bucket shard of the volume and a capi.ChunkWorker, runs the chunk-local half of its chunks, exchanges the packages with ONE
-all-gather per round (torch.distributed, backend gloo: both ranks share the single GPU of the test box), runs the replicated global half.
+all-gather per round through the C ABI's communicator (bf_chunk_exchange; transport: torch.distributed / gloo behind its callback, because both ranks share
+the single GPU of the test box - RCCL on a multi-GPU node), runs the replicated global half; the ray march of every TSDF operator is DIVIDED over the two
+ranks (bf_pipeline_set_comm: the volume thread all-gathers the block keys each rank collected on its band of the pixel tiles).
 Against the serial loop in this process: both ranks' trajectories bit for bit, the same operation counts, and the union of the two
 shards is the serial volume bit for bit.  (The gloo tests of tests/test_host_cpu.py drive the same ChunkedRunner with stand-in
 worker / pipeline objects on the CPU; the collective is RCCL when bench.py runs with one GPU per rank.)"""

@@ -35,8 +35,16 @@ def main():
     gas, gbs = params()
     pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
     pipe.set_volume_shard(rank, world)
+    # Everything that crosses ranks goes through the C ABI's communicator (include/bf_comm.h) - here with torch.distributed/gloo behind its callback transport,
+    # RCCL on a multi-GPU node: the key-frame packages of a round (bf_chunk_exchange), and - issued by the pipeline's VOLUME THREAD, on the volume's
+    # allocation stream, once per integrate / re-integrate - the block keys of the divided ray march (bf_pipeline_set_comm).  The volume thread gets its
+    # own process group: its collectives must not interleave with the main thread's.
+    vol_group = dist.new_group(backend="gloo")
+    comm_pkg, comm_vol = bf.capi.Comm.torch_group(None), bf.capi.Comm.torch_group(vol_group)
+    if os.environ.get("BF_TEST_DIVIDED_ALLOC", "1") == "1":
+        pipe.set_comm(comm_vol, 1 << 14)
     worker = bf.capi.ChunkWorker(*params(), sensor_desc(W, H, K))
-    runner = shard.ChunkedRunner(pipe, worker, dev, gbs.s_submapSize, rank, world, device=None)
+    runner = shard.ChunkedRunner(pipe, worker, dev, gbs.s_submapSize, rank, world, device=None, comm=comm_pkg)
     assert runner.advance(n) == n
     runner.close()
     for _ in range(3):
@@ -51,6 +59,8 @@ def main():
     np.savez(out, integrated=pipe.integrated_trajectory(), optimized=pipe.optimized_trajectory(), keys=keys, vox=vox, same=int(same),
              counters=np.array([c["integrate"], c["deintegrate"], c["local_solves"], c["global_solves"]]), rounds=runner.rounds, local_chunks=runner.local_chunks)
     dist.barrier()
+    pipe.set_comm(None)
+    del runner, pipe
     dist.destroy_process_group()
 
 

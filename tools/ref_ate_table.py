@@ -40,7 +40,18 @@ def params(a):
 def stream(a):
     from bundlefusion_amd import synth
     fr = synth.render_frames([a.start + a.stride * k for k in range(a.frames)], a.width, a.height)
-    if a.perturb:
+    if a.perturb_seed >= 0:          # every valid depth sample moved by -1, 0 or +1 float ulp, independently, from a seeded generator
+        rng = np.random.RandomState(a.perturb_seed)
+        out = []
+        for d, c, T, K in fr:
+            d2 = d.copy(); v = np.isfinite(d2)
+            x = d2[v]
+            step = rng.randint(-1, 2, size=x.shape)
+            x = np.where(step > 0, np.nextafter(x, np.float32(np.inf), dtype=np.float32), np.where(step < 0, np.nextafter(x, np.float32(0), dtype=np.float32), x)).astype(np.float32)
+            d2[v] = x
+            out.append((d2, c, T, K))
+        fr = out
+    elif a.perturb:
         out = []
         for d, c, T, K in fr:
             d2 = d.copy(); v = np.isfinite(d2)
@@ -206,6 +217,7 @@ def main():
     p.add_argument("--submap", type=int, default=10); p.add_argument("--tail", type=int, default=5)
     p.add_argument("--voxel", type=float, default=0.05); p.add_argument("--buckets", type=int, default=5000); p.add_argument("--blocks", type=int, default=2000)
     p.add_argument("--perturb", type=int, default=0)
+    p.add_argument("--perturb-seed", type=int, default=-1, help="every valid depth sample moved by -1 / 0 / +1 float ulp at random (seed): independent sub-resolution perturbations")
     p.add_argument("--exit-frames", type=int, default=-1, help="s_numSolveFramesBeforeExit (default: the parameter file's 30, i.e. no end-of-scan dense solve within --tail)")
     p.add_argument("--out"); p.add_argument("--table", nargs="*")
     a = p.parse_args()
