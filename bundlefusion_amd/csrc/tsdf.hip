@@ -58,6 +58,8 @@ struct Dev {
     AllocRec* allocList;
     AllocRec* allocListAlt;
     uint32_t* allocCount;
+    uint32_t* allocSnap;       // length of the allocated-block list this operator's compaction covers: written behind the operator's allocation (the next operator's
+                               // allocation may append to the list while this one's lists are still being built on another stream)
     uint64_t* dedupe;
     uint32_t dedupeMask;
     BinRec* bins;
@@ -621,6 +623,7 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratc
         }
         d.heapCounter[0] = newCounter;
         d.allocCount[0] = allocBase + Mp;
+        d.allocSnap[0] = allocBase + Mp;
         if (dropped) atomicAdd(&d.stats[ST_DROPPED], dropped);
         d.overflowCount[0] = 0;
     }
@@ -710,7 +713,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f, Frame fo) {
     __shared__ uint32_t wsum[4];
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t n = d.allocCount[0];
+    const uint32_t n = MODE == 1 ? d.allocCount[0] : d.allocSnap[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
     if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) d.compactCount[1] = 0;      // the scatter pass (next launch) accumulates the operator blocks here
     for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame f
     __shared__ uint32_t wsum[4];
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t wscan[4];
-    const uint32_t n = d.allocCount[0];
+    const uint32_t n = MODE == 1 ? d.allocCount[0] : d.allocSnap[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (numTiles == 0) {
@@ -797,6 +800,8 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame f
         __syncthreads();
     }
 }
+
+__global__ void k_alloc_snapshot(Dev d) { d.allocSnap[0] = d.allocCount[0]; }      // an operator without an allocation of its own
 
 __global__ void k_list_commit(Dev d) {
     const uint32_t n = d.allocCount[0];
@@ -1528,8 +1533,18 @@ struct bf_scene {
     bf_hash_entry* cbuf[NB] = {nullptr, nullptr, nullptr, nullptr}; uint32_t* csrc[NB] = {nullptr, nullptr, nullptr, nullptr}; int32_t* ccnt[NB] = {nullptr, nullptr, nullptr, nullptr};
     int cur = 0;                    // buffer that holds the latest list (== d.compact / d.compactSrc / d.compactCount)
     hipEvent_t evPrep[NB] = {nullptr, nullptr, nullptr, nullptr}, evUpd[NB] = {nullptr, nullptr, nullptr, nullptr}, evBarrier = nullptr, evTmp = nullptr;
-    bool updRecorded[NB] = {false, false, false, false}, barrierPending = false;
+    // Round 4: the preparation of an operator is THREE streams, not one.  The kernel trace of the frame loop (profiles/r04_timeline_before.txt) showed the voxel
+    // updates 61 us long and 79 us apart: every operator's update waited for its own preparation - allocation march, placement, two compaction passes and the
+    // texel interleave, 83 us of kernels and five launch boundaries of 12-17 us each next to the update's resident waves, about 140 us in sequence - so the
+    // preparation stream, not the update, paced the loop (10 fused operators x 140 us = the 1.4 ms frame).  Now `prep` carries the allocation only, `lists`
+    // the two compaction passes of the operator whose allocation has finished (they read the allocated-block list up to that operator's snapshot), `texs` the
+    // texel interleave (it depends on the frame alone): allocation n + 1 runs beside lists n beside update n - 1.
+    hipStream_t lists = nullptr, texs = nullptr;
+    hipEvent_t evAlloc[NB] = {nullptr, nullptr, nullptr, nullptr}, evTex[NB] = {nullptr, nullptr, nullptr, nullptr};
+    bool updRecorded[NB] = {false, false, false, false};
+    bool barrierPending[3] = {false, false, false};       // per preparation stream (prep, lists, texs): the last exclusive section has not been waited for yet
     hipEvent_t pendingEv = nullptr; // bf_scene_wait_event: the next operator's first kernel waits for it
+    hipEvent_t frameEv = nullptr;   // ... and so does its texel interleave, on its own stream (set when pendingEv is consumed, cleared by the operator)
     bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
     // optional HIP-event timing of the voxel-update kernel
     bool timing = false;
@@ -1651,32 +1666,35 @@ void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepH
 
 Dev devBuf(const bf_scene* s, int b) {
     Dev d = s->d;
-    d.compact = s->cbuf[b]; d.compactSrc = s->csrc[b]; d.compactCount = s->ccnt[b];
+    d.compact = s->cbuf[b]; d.compactSrc = s->csrc[b]; d.compactCount = s->ccnt[b]; d.allocSnap = reinterpret_cast<uint32_t*>(s->ccnt[b]) + 2;
     return d;
 }
-void useBuf(bf_scene* s, int b) { s->cur = b; s->d.compact = s->cbuf[b]; s->d.compactSrc = s->csrc[b]; s->d.compactCount = s->ccnt[b]; }
+void useBuf(bf_scene* s, int b) { s->cur = b; s->d.compact = s->cbuf[b]; s->d.compactSrc = s->csrc[b]; s->d.compactCount = s->ccnt[b]; s->d.allocSnap = reinterpret_cast<uint32_t*>(s->ccnt[b]) + 2; }
 
 // exclusive section on the main stream: everything issued on `prep` so far happens before, everything issued on `prep` later after
 int beginExclusive(bf_scene* s) {
     if (!s->overlap) return BF_OK;
-    BF_HIP_TRY(hipEventRecord(s->evTmp, s->prep));
-    BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTmp, 0));
+    for (hipStream_t st : {s->prep, s->lists, s->texs}) {
+        BF_HIP_TRY(hipEventRecord(s->evTmp, st));
+        BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTmp, 0));
+    }
     return BF_OK;
 }
 int endExclusive(bf_scene* s) {
     if (!s->overlap) return BF_OK;
     BF_HIP_TRY(hipEventRecord(s->evBarrier, s->stream));
-    s->barrierPending = true;
+    for (bool& b : s->barrierPending) b = true;
     return BF_OK;
 }
 int syncAll(bf_scene* s) {
-    if (s->prep) BF_HIP_TRY(hipStreamSynchronize(s->prep));
+    for (hipStream_t st : {s->prep, s->lists, s->texs}) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
     return BF_OK;
 }
 
 int launchCompactify(bf_scene* s) {                              // compactifyHashEntries :355-391 (main stream, current buffer)
     const Frame f = makeFrame(s);
+    hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, s->stream, s->d);
     hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     BF_HIP_TRY(hipGetLastError());
@@ -1690,7 +1708,7 @@ int refreshStaleList(bf_scene* s) {                              // a fused re-i
     return endExclusive(s);
 }
 
-int launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_depth) {      // alloc :328-352
+int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, const float* d_depth) {      // alloc :328-352 (dv: the operator's view - its snapshot slot)
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
     if (s->allocComm) {
         // the march divided over the ranks: rank r marches the tiles [r T / G, (r + 1) T / G) and collects the distinct in-frustum keys it
@@ -1704,17 +1722,17 @@ int launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_de
         c.keys = reinterpret_cast<unsigned long long*>(s->d_allocSend + 8); c.slots = s->d_allocSlots; c.count = cnt; c.capacity = s->allocCap;
         c.tile0 = (uint32_t)((uint64_t)tiles * rank / world); c.tile1 = (uint32_t)((uint64_t)tiles * (rank + 1) / world);
         BF_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
-        if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, s->d, f, d_depth, c);
-        hipLaunchKernelGGL(k_collect_release, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 2048u)), dim3(256), 0, st, s->d, c);
+        if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, dv, f, d_depth, c);
+        hipLaunchKernelGGL(k_collect_release, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 2048u)), dim3(256), 0, st, dv, c);
         BF_TRY_RC(bf_comm_all_gather(s->allocComm, s->d_allocSend, s->d_allocRecv, rec, st));
         for (uint32_t r = 0; r < world; ++r) {
             const uint8_t* base = s->d_allocRecv + rec * r;
-            hipLaunchKernelGGL(k_alloc_ingest, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 1024u)), dim3(256), 0, st, s->d, f,
+            hipLaunchKernelGGL(k_alloc_ingest, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 1024u)), dim3(256), 0, st, dv, f,
                                reinterpret_cast<const unsigned long long*>(base + 8), reinterpret_cast<const uint32_t*>(base), s->allocCap);
         }
     } else
-    hipLaunchKernelGGL(k_alloc_candidates<false>, dim3(div_up(tiles, 4)), dim3(256), 0, st, s->d, f, d_depth, Collect{});
-    hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
+    hipLaunchKernelGGL(k_alloc_candidates<false>, dim3(div_up(tiles, 4)), dim3(256), 0, st, dv, f, d_depth, Collect{});
+    hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, dv, f);
     return BF_OK;
 }
 
@@ -1723,8 +1741,8 @@ int launchAllocOn(bf_scene* s, hipStream_t st, const Frame& f, const float* d_de
 // whoever touches the prep stream first - runOperator, or bf_scene_alloc_collect / _ingest / _place when the caller allocates itself - waits, and
 // everything issued on that stream afterwards is ordered behind it.
 int prepWaits(bf_scene* s, hipStream_t ps) {
-    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->pendingEv = nullptr; }
-    if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
+    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->frameEv = s->pendingEv; s->pendingEv = nullptr; }
+    if (s->overlap && s->barrierPending[0]) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending[0] = false; }
     return BF_OK;
 }
 
@@ -1732,32 +1750,54 @@ int prepWaits(bf_scene* s, hipStream_t ps) {
 // integrate(f).  With overlap enabled the first two phases go to the prep stream and only the update to the main stream.
 int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf_depth_camera_data* data) {
     const int b = s->overlap ? (s->cur + 1) % bf_scene::NB : s->cur;
-    hipStream_t ps = s->overlap ? s->prep : s->stream;
-    BF_TRY_RC(prepWaits(s, ps));
-    if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
-    const Dev dv = devBuf(s, b);
-    if (kind != 1 && !s->externalAlloc) BF_TRY_RC(launchAllocOn(s, ps, f, data->d_depthData));      // de-integration neither allocates nor frees
-    if (kind == 2) {
-        hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
-        hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
-    } else {
-        hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
-        hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
-    }
+    hipStream_t ps = s->overlap ? s->prep : s->stream, ls = s->overlap ? s->lists : s->stream, ts = s->overlap ? s->texs : s->stream;
     const bool useTexel = s->arith == BF_TSDF_ARITH_FAST && data->d_colorData != nullptr;
-    if (useTexel) {          // the frame as 8-byte texels for this operator's gathers (2 x 2.4 MB at 640x480: a few microseconds on the stream that runs ahead)
+    BF_TRY_RC(prepWaits(s, ps));
+    const hipEvent_t frameEv = s->frameEv;          // the frame's ingest (bf_scene_wait_event); an external allocation may have consumed it for `prep` already
+    s->frameEv = nullptr;
+    const Dev dv = devBuf(s, b);
+    // ---- allocation (prep).  It writes the operator's snapshot into buffer b's counters: not before the update that used buffer b NB operators ago has
+    // finished - which also keeps the allocation at most NB operators ahead of the updates
+    if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));
+    if (kind != 1 && !s->externalAlloc) BF_TRY_RC(launchAllocOn(s, ps, dv, f, data->d_depthData));      // de-integration neither allocates nor frees
+    else hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, ps, dv);
+    // ---- frustum (or union) list (lists): reads the allocated-block list up to this operator's snapshot, writes list buffer b
+    if (s->overlap) {
+        BF_HIP_TRY(hipEventRecord(s->evAlloc[b], ps));
+        BF_HIP_TRY(hipStreamWaitEvent(ls, s->evAlloc[b], 0));
+        if (s->barrierPending[1]) { BF_HIP_TRY(hipStreamWaitEvent(ls, s->evBarrier, 0)); s->barrierPending[1] = false; }
+        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ls, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
+    }
+    if (kind == 2) {
+        hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
+        hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
+    } else {
+        hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
+        hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
+    }
+    if (s->overlap) {
+        BF_HIP_TRY(hipEventRecord(s->evPrep[b], ls));
+        BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
+    }
+    // ---- the frame as 8-byte texels for this operator's gathers (texs; 2 x 2.4 MB at 640x480)
+    if (useTexel) {
         const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
         if (s->texelPixels < npx) {
             BF_TRY_RC(syncAll(s));
             for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
             s->texelPixels = npx;
         }
-        hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ps, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
-    }
-    if (s->overlap) {
-        BF_HIP_TRY(hipEventRecord(s->evPrep[b], ps));
-        BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
-    }
+        if (s->overlap) {
+            if (frameEv) BF_HIP_TRY(hipStreamWaitEvent(ts, frameEv, 0));
+            if (s->barrierPending[2]) { BF_HIP_TRY(hipStreamWaitEvent(ts, s->evBarrier, 0)); s->barrierPending[2] = false; }
+            if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ts, s->evUpd[b], 0));      // the update that gathered from texel buffer b NB operators ago
+        }
+        hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ts, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
+        if (s->overlap) {
+            BF_HIP_TRY(hipEventRecord(s->evTex[b], ts));
+            BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTex[b], 0));
+        }
+    } else if (s->overlap && frameEv) BF_HIP_TRY(hipStreamWaitEvent(s->stream, frameEv, 0));      // the exact kernel reads the frame itself
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (s->timing) {
         if (s->eventsUsed == s->events.size()) {
@@ -1852,8 +1892,11 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
         int least = 0, greatest = 0;
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&s->prep, hipStreamNonBlocking, greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&s->lists, hipStreamNonBlocking, greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&s->texs, hipStreamNonBlocking, greatest));
     }
-    for (int b = 0; b < bf_scene::NB; ++b) { BF_HIP_TRY(hipEventCreateWithFlags(&s->evPrep[b], hipEventDisableTiming)); BF_HIP_TRY(hipEventCreateWithFlags(&s->evUpd[b], hipEventDisableTiming)); }
+    for (int b = 0; b < bf_scene::NB; ++b)
+        for (hipEvent_t* e : {&s->evPrep[b], &s->evUpd[b], &s->evAlloc[b], &s->evTex[b]}) BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&s->evBarrier, &s->evTmp})
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
@@ -1977,9 +2020,9 @@ int bf_scene_destroy(bf_scene* s) {
     if (s->d_allocRecv) hipFree(s->d_allocRecv);
     if (s->d_allocSlots) hipFree(s->d_allocSlots);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (int b = 0; b < bf_scene::NB; ++b) { if (s->evPrep[b]) hipEventDestroy(s->evPrep[b]); if (s->evUpd[b]) hipEventDestroy(s->evUpd[b]); }
+    for (int b = 0; b < bf_scene::NB; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b], s->evAlloc[b], s->evTex[b]}) if (e) hipEventDestroy(e);
     for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
-    if (s->prep) hipStreamDestroy(s->prep);
+    for (hipStream_t st : {s->prep, s->lists, s->texs}) if (st) hipStreamDestroy(st);
     delete s;
     return BF_OK;
 }
@@ -1996,7 +2039,7 @@ int bf_scene_set_overlap(bf_scene* s, int enable) {
     BF_TRY_RC(syncAll(s));
     s->overlap = enable != 0;
     for (bool& u : s->updRecorded) u = false;
-    s->barrierPending = false;
+    for (bool& bp : s->barrierPending) bp = false;
     return BF_OK;
 }
 
@@ -2014,7 +2057,7 @@ int bf_scene_reset(bf_scene* s) {                                  // CUDASceneR
     memcpy(s->params.m_rigidTransformInverse, I.e, 64);
     s->params.m_numOccupiedBlocks = 0;
     BF_TRY_RC(syncAll(s));
-    s->compactStale = false; s->barrierPending = false; s->pendingEv = nullptr;
+    s->compactStale = false; for (bool& bp : s->barrierPending) bp = false; s->pendingEv = nullptr; s->frameEv = nullptr;
     for (bool& u : s->updRecorded) u = false;
     for (int b = 0; b < bf_scene::NB; ++b) BF_HIP_TRY(hipMemsetAsync(s->ccnt[b], 0, 16, s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;

@@ -146,6 +146,33 @@ def test_pcg_result_independent_of_workgroup_count(gpu, oracle, monkeypatch):
     assert dt < 2e-2 and dR < 2e-2
 
 
+@pytest.mark.parametrize("n", [500, 2000])
+def test_global_solve_at_scale_vs_oracle(gpu, oracle, monkeypatch, n):
+    """The global solve at the sizes of the long streams (N <= 500 key frames at 5000 frames, <= 2000 at 20000; SolverBundling.cu:1137-1220 is
+    what it replaces) against the oracle - until round 3 these sizes were timed (tools/solver_scaling.py), never checked.  The key-frame graph of that tool
+    (every key frame matched to three predecessors plus loop-closure pairs, 25 correspondences per pair, 2 mm noise), 3 Gauss-Newton x 150 PCG iterations,
+    sparse only, with both placements of the cooperative PCG's vectors (LDS, and global memory - the form N > ~1300 takes by itself): poses 1e-4,
+    energies 1e-3, largest residual 1e-4; the two placements bit-identical."""
+    from tools.solver_scaling import graph
+    corr, Tin = graph(n, 3, np.random.default_rng(1000 + n))
+    out = {}
+    for vec_global in ("0", "1"):
+        monkeypatch.setenv("BF_PCG_VEC_GLOBAL", vec_global)
+        solver, gcorr, ores, (orot, otr), (grot, gtr) = _solve_both(gpu, oracle, corr, Tin, 3, 150, [1.0] * 3, [0.0] * 3, [0.0] * 3)
+        assert np.abs(grot - orot).max() < 1e-4 and np.abs(gtr - otr).max() < 1e-4, (n, vec_global, np.abs(grot - orot).max(), np.abs(gtr - otr).max())
+        gn, pcg = solver.iteration_counts()
+        assert gn == ores["gn_iterations"] and list(pcg)[:gn] == list(ores["pcg_iterations"])[:gn]
+        gconv = np.array(solver.convergence()[: gn + 1]); oconv = ores["convergence"][: gn + 1]
+        assert np.allclose(gconv, oconv, rtol=1e-3, atol=1e-7), (gconv, oconv)
+        mres, _ = solver.max_residual()
+        assert abs(mres - ores["max_residual"]) < 1e-4
+        out[vec_global] = (grot, gtr)
+        print("N = %d, vectors in %s: max pose deviation from the oracle %.2e / %.2e, energies %s" % (n, "global memory" if vec_global == "1" else "LDS (automatic)",
+                                                                                                     np.abs(grot - orot).max(), np.abs(gtr - otr).max(), gconv.tolist()))
+    monkeypatch.delenv("BF_PCG_VEC_GLOBAL", raising=False)
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+
+
 def _dense_pair(gpu, oracle, n_frames, width=160, height=120, perturb=(0.004, 0.01)):
     frames, K, T_gt, T_init = bs.dense_chunk(n_frames=n_frames, width=width, height=height, perturb=perturb)
     Kin = intrinsics_matrix(K["fx"], K["fy"], K["mx"], K["my"])
