@@ -33,6 +33,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The frame loop drives six HIP streams (ingest, detection, bundling, volume, allocation, lists); the runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+# queues - four by default - and streams that share a queue serialise (measured: 270 instead of 700+ frames/s with eleven streams on the default).  Read by
+# the HIP runtime when it initialises, i.e. before torch is imported.  INTEGRATION.md says the same to a C++ host.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s HBM3E
 

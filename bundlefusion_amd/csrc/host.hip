@@ -2121,11 +2121,9 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // 0.80 -> 0.69 ms while the voxel update slows 93.8 -> 126 us; frames/s 656 -> 655 / 648 / 623 / 565)
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
-        // lagged solves: measured at the lowest priority (gpurun r04b) the cooperative PCG - up to 64 workgroups meeting at a grid barrier 450 times per
-        // global solve - is starved by the volume stream's wide launches and a chunk's solves take longer than the ten frames they have
-        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sSolve, hipStreamNonBlocking, greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sIngest, hipStreamNonBlocking, greatest));
-        for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+        // (the solve stream of the lagged mode and the two pair streams are created when those modes are switched on: every HIP stream beyond the runtime's
+        // GPU_MAX_HW_QUEUES hardware queues - four by default; bench.py and the tools ask for eight - shares a queue with another one and serialises with it)
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
     if (const char* e = getenv("BF_PIPELINE_DEPTH")) p->depth = (uint32_t)std::min(std::max(atoi(e), 2), bf_online_bundler::PEND);
@@ -2137,11 +2135,16 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // BF_PIPELINE_PAIR_STREAMS=1: the pair stages of consecutive frames on two streams.  Off by default: measured 659 vs 697 frames/s (gpurun r04c) - every
         // cross-stream event hop costs ~40 us on this runtime and the stage needs four of them per frame, more than the overlap of two Kabsch filters returns
         const char* e = getenv("BF_PIPELINE_PAIR_STREAMS");
-        if (e && atoi(e) != 0) BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPair[0], p->sPair[1]));
+        if (e && atoi(e) != 0) {
+            int least = 0, greatest = 0;
+            BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+            BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPair[0], p->sPair[1]));
+        }
     }
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
-    if (const char* e = getenv("BF_PIPELINE_SOLVE_LAG")) BF_TRY(bf_online_bundler_set_solve_lag(p->ob, (uint32_t)atoi(e), p->sSolve));
+    if (const char* e = getenv("BF_PIPELINE_SOLVE_LAG")) BF_TRY(bf_pipeline_set_solve_lag(p, (uint32_t)atoi(e)));
     int dev = 0;
     BF_HIP_TRY(hipGetDevice(&dev));
     p->worker = std::thread([p, dev] { (void)hipSetDevice(dev); volWorker(p); });
@@ -2177,6 +2180,13 @@ int bf_pipeline_set_solve_lag(bf_pipeline* p, uint32_t lag) {
     BF_REQUIRE(p, "null pipeline");
     BF_TRY(plFlush(p));
     BF_REQUIRE(!p->ob->job.active, "a lagged solve is still waiting for its frame");
+    if (lag && !p->sSolve) {
+        // Not the lowest priority: measured (gpurun r04b) the cooperative PCG - up to 64 workgroups meeting at a grid barrier 450 times per global solve - is
+        // then starved by the volume stream's wide launches and a chunk's solves take longer than the ten frames they have
+        int least = 0, greatest = 0;
+        BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sSolve, hipStreamNonBlocking, greatest));
+    }
     return bf_online_bundler_set_solve_lag(p->ob, lag, p->sSolve);
 }
 int bf_pipeline_get_solve_lag(bf_pipeline* p, uint32_t* lag) { BF_REQUIRE(p && lag, "null argument"); return bf_online_bundler_get_solve_lag(p->ob, lag); }
@@ -2213,9 +2223,9 @@ int bf_pipeline_synchronize(bf_pipeline* p) {
     BF_TRY(volDrain(p));
     BF_HIP_TRY(hipStreamSynchronize(p->sIngest));
     BF_HIP_TRY(hipStreamSynchronize(p->sDetect));
-    for (auto st : p->sPair) BF_HIP_TRY(hipStreamSynchronize(st));
+    for (auto st : p->sPair) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
     BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
-    BF_HIP_TRY(hipStreamSynchronize(p->sSolve));
+    if (p->sSolve) BF_HIP_TRY(hipStreamSynchronize(p->sSolve));
     BF_HIP_TRY(hipStreamSynchronize(p->sVolume));
     return BF_OK;
 }

@@ -1536,13 +1536,15 @@ struct bf_scene {
     // Round 4: the preparation of an operator is THREE streams, not one.  The kernel trace of the frame loop (profiles/r04_timeline_before.txt) showed the voxel
     // updates 61 us long and 79 us apart: every operator's update waited for its own preparation - allocation march, placement, two compaction passes and the
     // texel interleave, 83 us of kernels and five launch boundaries of 12-17 us each next to the update's resident waves, about 140 us in sequence - so the
-    // preparation stream, not the update, paced the loop (10 fused operators x 140 us = the 1.4 ms frame).  Now `prep` carries the allocation only, `lists`
-    // the two compaction passes of the operator whose allocation has finished (they read the allocated-block list up to that operator's snapshot), `texs` the
-    // texel interleave (it depends on the frame alone): allocation n + 1 runs beside lists n beside update n - 1.
-    hipStream_t lists = nullptr, texs = nullptr;
-    hipEvent_t evAlloc[NB] = {nullptr, nullptr, nullptr, nullptr}, evTex[NB] = {nullptr, nullptr, nullptr, nullptr};
+    // preparation stream, not the update, paced the loop (10 fused operators x 140 us = the 1.4 ms frame).  Now `prep` carries the allocation only and `lists`
+    // the texel interleave (it depends on the frame alone) followed by the two compaction passes of the operator whose allocation has finished (they read the
+    // allocated-block list up to that operator's snapshot): allocation n + 1 runs beside lists n beside update n - 1.  (A third stream for the interleave
+    // alone was one HIP stream too many: the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues - four by default - and streams that share a
+    // queue serialise; the frame loop already owns a detect, a bundling, an ingest and a volume stream.  gpurun r04e: 270 frames/s with eleven streams.)
+    hipStream_t lists = nullptr;
+    hipEvent_t evAlloc[NB] = {nullptr, nullptr, nullptr, nullptr};
     bool updRecorded[NB] = {false, false, false, false};
-    bool barrierPending[3] = {false, false, false};       // per preparation stream (prep, lists, texs): the last exclusive section has not been waited for yet
+    bool barrierPending[2] = {false, false};       // per preparation stream (prep, lists): the last exclusive section has not been waited for yet
     hipEvent_t pendingEv = nullptr; // bf_scene_wait_event: the next operator's first kernel waits for it
     hipEvent_t frameEv = nullptr;   // ... and so does its texel interleave, on its own stream (set when pendingEv is consumed, cleared by the operator)
     bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
@@ -1674,7 +1676,7 @@ void useBuf(bf_scene* s, int b) { s->cur = b; s->d.compact = s->cbuf[b]; s->d.co
 // exclusive section on the main stream: everything issued on `prep` so far happens before, everything issued on `prep` later after
 int beginExclusive(bf_scene* s) {
     if (!s->overlap) return BF_OK;
-    for (hipStream_t st : {s->prep, s->lists, s->texs}) {
+    for (hipStream_t st : {s->prep, s->lists}) {
         BF_HIP_TRY(hipEventRecord(s->evTmp, st));
         BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTmp, 0));
     }
@@ -1687,7 +1689,7 @@ int endExclusive(bf_scene* s) {
     return BF_OK;
 }
 int syncAll(bf_scene* s) {
-    for (hipStream_t st : {s->prep, s->lists, s->texs}) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
+    for (hipStream_t st : {s->prep, s->lists}) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
     return BF_OK;
 }
@@ -1750,7 +1752,7 @@ int prepWaits(bf_scene* s, hipStream_t ps) {
 // integrate(f).  With overlap enabled the first two phases go to the prep stream and only the update to the main stream.
 int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf_depth_camera_data* data) {
     const int b = s->overlap ? (s->cur + 1) % bf_scene::NB : s->cur;
-    hipStream_t ps = s->overlap ? s->prep : s->stream, ls = s->overlap ? s->lists : s->stream, ts = s->overlap ? s->texs : s->stream;
+    hipStream_t ps = s->overlap ? s->prep : s->stream, ls = s->overlap ? s->lists : s->stream;
     const bool useTexel = s->arith == BF_TSDF_ARITH_FAST && data->d_colorData != nullptr;
     BF_TRY_RC(prepWaits(s, ps));
     const hipEvent_t frameEv = s->frameEv;          // the frame's ingest (bf_scene_wait_event); an external allocation may have consumed it for `prep` already
@@ -1761,12 +1763,26 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));
     if (kind != 1 && !s->externalAlloc) BF_TRY_RC(launchAllocOn(s, ps, dv, f, data->d_depthData));      // de-integration neither allocates nor frees
     else hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, ps, dv);
-    // ---- frustum (or union) list (lists): reads the allocated-block list up to this operator's snapshot, writes list buffer b
+    // ---- lists stream, first the frame as 8-byte texels for this operator's gathers (2 x 2.4 MB at 640x480; depends on the frame alone, so it runs while the
+    // allocation is still marching) ...
+    if (s->overlap) {
+        if (s->barrierPending[1]) { BF_HIP_TRY(hipStreamWaitEvent(ls, s->evBarrier, 0)); s->barrierPending[1] = false; }
+        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ls, s->evUpd[b], 0));      // the update that read list buffer b / texel buffer b NB operators ago
+    }
+    if (useTexel) {
+        const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
+        if (s->texelPixels < npx) {
+            BF_TRY_RC(syncAll(s));
+            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
+            s->texelPixels = npx;
+        }
+        if (s->overlap && frameEv) BF_HIP_TRY(hipStreamWaitEvent(ls, frameEv, 0));
+        hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ls, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
+    }
+    // ---- ... then the frustum (or union) list: reads the allocated-block list up to this operator's snapshot, writes list buffer b
     if (s->overlap) {
         BF_HIP_TRY(hipEventRecord(s->evAlloc[b], ps));
         BF_HIP_TRY(hipStreamWaitEvent(ls, s->evAlloc[b], 0));
-        if (s->barrierPending[1]) { BF_HIP_TRY(hipStreamWaitEvent(ls, s->evBarrier, 0)); s->barrierPending[1] = false; }
-        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ls, s->evUpd[b], 0));      // the update that read this list buffer NB operators ago
     }
     if (kind == 2) {
         hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
@@ -1779,25 +1795,6 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         BF_HIP_TRY(hipEventRecord(s->evPrep[b], ls));
         BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
     }
-    // ---- the frame as 8-byte texels for this operator's gathers (texs; 2 x 2.4 MB at 640x480)
-    if (useTexel) {
-        const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
-        if (s->texelPixels < npx) {
-            BF_TRY_RC(syncAll(s));
-            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
-            s->texelPixels = npx;
-        }
-        if (s->overlap) {
-            if (frameEv) BF_HIP_TRY(hipStreamWaitEvent(ts, frameEv, 0));
-            if (s->barrierPending[2]) { BF_HIP_TRY(hipStreamWaitEvent(ts, s->evBarrier, 0)); s->barrierPending[2] = false; }
-            if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ts, s->evUpd[b], 0));      // the update that gathered from texel buffer b NB operators ago
-        }
-        hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ts, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
-        if (s->overlap) {
-            BF_HIP_TRY(hipEventRecord(s->evTex[b], ts));
-            BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTex[b], 0));
-        }
-    } else if (s->overlap && frameEv) BF_HIP_TRY(hipStreamWaitEvent(s->stream, frameEv, 0));      // the exact kernel reads the frame itself
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (s->timing) {
         if (s->eventsUsed == s->events.size()) {
@@ -1893,10 +1890,9 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&s->prep, hipStreamNonBlocking, greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&s->lists, hipStreamNonBlocking, greatest));
-        BF_HIP_TRY(hipStreamCreateWithPriority(&s->texs, hipStreamNonBlocking, greatest));
     }
     for (int b = 0; b < bf_scene::NB; ++b)
-        for (hipEvent_t* e : {&s->evPrep[b], &s->evUpd[b], &s->evAlloc[b], &s->evTex[b]}) BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&s->evPrep[b], &s->evUpd[b], &s->evAlloc[b]}) BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&s->evBarrier, &s->evTmp})
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
@@ -2020,9 +2016,9 @@ int bf_scene_destroy(bf_scene* s) {
     if (s->d_allocRecv) hipFree(s->d_allocRecv);
     if (s->d_allocSlots) hipFree(s->d_allocSlots);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (int b = 0; b < bf_scene::NB; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b], s->evAlloc[b], s->evTex[b]}) if (e) hipEventDestroy(e);
+    for (int b = 0; b < bf_scene::NB; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b], s->evAlloc[b]}) if (e) hipEventDestroy(e);
     for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
-    for (hipStream_t st : {s->prep, s->lists, s->texs}) if (st) hipStreamDestroy(st);
+    for (hipStream_t st : {s->prep, s->lists}) if (st) hipStreamDestroy(st);
     delete s;
     return BF_OK;
 }
