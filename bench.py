@@ -33,10 +33,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The frame loop drives six HIP streams (ingest, detection, bundling, volume, allocation, lists); the runtime maps streams onto GPU_MAX_HW_QUEUES hardware
-# queues - four by default - and streams that share a queue serialise (measured: 270 instead of 700+ frames/s with eleven streams on the default).  Read by
-# the HIP runtime when it initialises, i.e. before torch is imported.  INTEGRATION.md says the same to a C++ host.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s HBM3E
 
@@ -67,6 +63,11 @@ def main():
                     help="0: the reference's serial order (chunk solves inside the frame that closes the chunk).  L in 1..10: the chunk solves run on their own "
                          "thread and stream and are applied exactly L frames later (bf_pipeline_set_solve_lag) - the reference's optimiser thread "
                          "(FriedLiver.cpp:112-143) with a defined hand-over; same solves, same count, nothing skipped")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the secondary block `sweep` (BASELINE configs[4] in small: the 1280x960 @2 mm re-integration sweep, the "
+                    "workload north_star's >= 6x scaling target is quoted on; ~20 s, most of it rendering 24 frames on the host)")
+    ap.add_argument("--long-stream", type=int, default=0, help="also run a stream of this many frames from frame 0 through a fresh pipeline and report it as `long_stream` "
+                    "(2000: BASELINE configs[2], the stride-1 loop-closure stream; 5000: configs[3], 2.5 loops + vertical sinusoid).  Rendering takes ~1 s of host time per "
+                    "16 frames, which is why it is not part of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the stream the CPU baseline processes (three local chunks: the last ten frames "
                     "run with the re-integration queue saturated, like the timed window of the GPU leg)")
@@ -224,6 +225,7 @@ def main():
             sc.kernel_timing(True)                               # HIP events around every voxel-update launch, on the pipeline's stream
         c0 = pipe.counters()
         pipe.host_profile(reset=True)
+        pipe.volume_thread_profile(reset=True)
         torch.cuda.synchronize()
         rounds0 = runner.rounds if chunked else 0
         chunks0 = runner.local_runs if chunked else 0
@@ -241,7 +243,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        L = {"arith": arith, "c0": c0, "c1": pipe.counters(), "hp": pipe.host_profile()}
+        L = {"arith": arith, "c0": c0, "c1": pipe.counters(), "hp": pipe.host_profile(), "vp": pipe.volume_thread_profile()}
         L["occ_sum"], L["vis_plain"], L["vis_fused"], L["n_ops"] = sc.kernel_timing_blocks()
         L["n_launch"], L["kernel_ms"] = sc.kernel_timing_read()
         sc.kernel_timing(False)
@@ -329,6 +331,8 @@ def main():
                 "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
                 "render_seconds_untimed": round(t_gen, 1),
                 "host_thread_ms_per_frame": {k: round(1e3 * v / max(hp["frames"], 1.0), 4) for k, v in hp.items() if k != "frames"},
+                "volume_thread": {"busy_share_of_wall": round(main_leg["vp"]["busy_seconds"] / elapsed, 3), "operators": int(main_leg["vp"]["operators"]),
+                                  "us_of_api_calls_per_operator": round(1e6 * main_leg["vp"]["busy_seconds"] / max(main_leg["vp"]["operators"], 1.0), 1)},
                 "frame_loop": "two frames behind the input: the matching chain of frame k+1 is enqueued before frame k's result is read back, detection runs one frame "
                               "further ahead (BF_PIPELINE_LOOKAHEAD=%s); chunk solves: %s" % (os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
                               ("own thread + stream, applied exactly %d frames after the chunk's last frame (lagged mode)" % args.solve_lag) if (args.solve_lag and not chunked)
@@ -355,6 +359,14 @@ def main():
                                      "same_trajectory": other["ate"] == main_leg["ate"]}
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], feed[:args.cpu_frames], params, K, W, H, args.arith)
+    del frames, feed
+    if not args.no_sweep:
+        sw = sweep_block(args, rank, world)
+        if rank == 0:
+            out["sweep"] = sw
+    if args.long_stream and world == 1:
+        out["long_stream"] = long_stream_block(args, K, W, H)
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -371,6 +383,79 @@ def launch_plan(gpus, env, argv):
         port = s.getsockname()[1]
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def sweep_block(args, rank, world):
+    """BASELINE configs[4] in small (DepthSensing.cpp:854-902 is the loop it stands for): 24 frames of the room at 1280x960 integrated into a
+    2 mm volume, then every frame re-integrated at a perturbed pose (xi ~ N(0, diag(0.01 rad, 0.01 m)), seed 777) with the fused operator - the volume operators
+    alone, no bundling.  With N ranks the ONE volume is sharded by hash-bucket range and the allocation's ray march is divided over the ranks inside the operators
+    (bf_scene_set_alloc_comm: one RCCL all-gather of block keys per operator on the allocation stream); value = fused re-integrations of the one volume per second
+    (strong scaling) - the number north_star's ">= 6x at 8 GPUs on the TSDF re-integration sweep" is about."""
+    from tools.tsdf_sweep import parser as sweep_parser, run as sweep_run
+    argv = ["--frames", "24", "--stride", "10", "--width", "1280", "--height", "960", "--voxel", "0.002", "--buckets", "4000000", "--blocks", "1500000", "--sweeps", "1"]
+    if world > 1:
+        argv.append("--comm-alloc")
+    sa = sweep_parser().parse_args(argv)
+    sa.arith = args.arith
+    r = sweep_run(sa, rank, world)
+    if r is not None:
+        r["metric"] = "fused re-integrations/s of one 1280x960 @2 mm volume"
+        r["value"] = r["reintegrations_per_s"]
+        r["n_gpus"] = world
+    return r
+
+
+def long_stream_block(args, K, W, H):
+    """A whole stream from frame 0 through a fresh pipeline (frames resident in HBM, rendered and uploaded in batches): frames/s overall and per 1000 frames, tracked
+    frames, ATE of the integrated and of the optimised trajectory, key frames, solve and operation counts."""
+    import numpy as np
+    import torch
+    import bundlefusion_amd as bf
+    from bundlefusion_amd import synth
+    from bundlefusion_amd.capi import default_app_state, default_bundling_state, sensor_desc
+    n = args.long_stream
+    bob = 0.3 if n > 2000 else 0.0                      # SURVEY.md 8d: config 4 = 2.5 loops + vertical sinusoid, config 3 = the plain loop (frame 1800 closes it)
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize = args.voxel
+    gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 4000000, 3000000
+    gbs.s_maxNumImages = n // 10 + 8
+    pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    pipe.scene().set_arith(args.arith)
+    if args.solve_lag:
+        pipe.set_solve_lag(args.solve_lag)
+    poses, marks = [], []
+    t_run = 0.0
+    done = 0
+    for c0 in range(0, n, 500):
+        part = synth.render_frames(range(c0, min(c0 + 500, n)), W, H, bob=bob)
+        dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in part]
+        poses += [f[2] for f in part]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for d, c in dev:
+            if not pipe.process_frame(d, c):
+                raise RuntimeError("long stream: frame not accepted")
+        pipe.synchronize(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t_run += dt; done += len(dev)
+        marks.append({"frames": "%d-%d" % (c0, done - 1), "fps": round(len(dev) / dt, 1)})
+        del dev
+    T0inv = np.linalg.inv(poses[0].astype(np.float64))
+    gt = np.stack([T0inv @ T.astype(np.float64) for T in poses])
+
+    def ate(t):
+        v = np.isfinite(t[:, 0, 0])
+        return (float(np.sqrt(np.mean(np.sum((t[v][:, :3, 3] - gt[:len(t)][v][:, :3, 3]) ** 2, axis=1)))) if v.any() else None), int(v.sum())
+    a_int, v_int = ate(pipe.integrated_trajectory())
+    a_opt, v_opt = ate(pipe.optimized_trajectory())
+    c = pipe.counters()
+    dbg = pipe.scene().debug_hash()
+    first, last = marks[0]["fps"], marks[-1]["fps"]
+    return {"frames": n, "stream": "S2 room from frame 0, stride 1%s" % (", vertical sinusoid 0.3 m" if bob else ""), "value": done / t_run, "unit": "frames/s", "per_500_frames": marks,
+            "last_over_first": round(last / first, 3), "frames_tracked": v_int, "ate_integrated_m": a_int, "ate_optimized_m": a_opt, "frames_with_optimized_pose": v_opt,
+            "key_frames": (n - 1) // 10, "counters": {k: int(v) for k, v in c.items()}, "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
+            "timing": "per batch of 500 frames: frames resident in HBM, pipeline synchronised at the batch end (rendering and upload of the next batch untimed)"}
 
 
 def pmc_config(args):

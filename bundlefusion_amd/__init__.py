@@ -8,13 +8,6 @@ the tests and bench.py; torch is used for device memory and streams, nothing els
 There is no CPU fallback: `bundlefusion_amd.capi` (loaded on first use) fails loudly with ImportError if the shared
 library is missing, and every entry point returns an error without a GPU.
 """
-import os as _os
-
-# The frame loop drives six HIP streams (ingest, detection, bundling, volume, allocation, lists).  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES
-# hardware queues - four by default - and streams that share a queue serialise.  The runtime reads the variable when libamdhip64 is loaded, i.e. before
-# torch is imported: import this package (or set the variable) first.  A C++ host sets it in its environment (INTEGRATION.md).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import importlib
 
 

@@ -1002,6 +1002,11 @@ class Pipeline:
         names = ("enqueue_match_chain", "ingest_detect_enqueue", "reintegrate_commands", "wait_match_result", "integrate_command", "solves", "wait_ingest", "frames")
         return dict(zip(names, [float(v) for v in out]))
 
+    def volume_thread_profile(self, reset=False):
+        b, n = C.c_double(), C.c_double()
+        check(lib.bf_pipeline_get_volume_thread_profile(self._h, C.byref(b), C.byref(n), int(reset)))
+        return dict(busy_seconds=b.value, operators=n.value)
+
     def enable_timings(self, on=True):
         check(lib.bf_pipeline_enable_timings(self._h, int(on)))
 

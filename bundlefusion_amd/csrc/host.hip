@@ -181,6 +181,9 @@ struct bf_image_manager {
     // frames at integration resolution: slabs of SLAB frames in HBM (onGPU) or host vectors + one staging pair (reference default)
     static const uint32_t SLAB = 256;
     std::vector<float*> depthSlabs; std::vector<uint8_t*> colorSlabs;
+    // optional third plane per stored frame: depth and colour interleaved as 8-byte texels (bf_image_manager_set_store_texels), made once at ingest for the
+    // voxel update's gathers - every operator on the frame would otherwise interleave it again (11 times per input frame in the saturated loop)
+    bool storeTexels = false; std::vector<uint8_t*> texelSlabs;
     std::vector<std::vector<float>> hostDepth; std::vector<std::vector<uint8_t>> hostColor;
     float* d_stageDepth = nullptr; uint8_t* d_stageColor = nullptr;
     int activeDepth = -1, activeColor = -1;
@@ -225,6 +228,8 @@ int bf_image_manager_reset(bf_image_manager* im) {
     (void)hipStreamSynchronize(im->stream);
     for (auto p : im->depthSlabs) (void)hipFree(p);
     for (auto p : im->colorSlabs) (void)hipFree(p);
+    for (auto p : im->texelSlabs) (void)hipFree(p);
+    im->texelSlabs.clear();
     im->depthSlabs.clear(); im->colorSlabs.clear(); im->hostDepth.clear(); im->hostColor.clear();
     im->activeDepth = im->activeColor = -1;
     im->currFrame = 0;
@@ -241,6 +246,20 @@ int bf_image_manager_destroy(bf_image_manager* im) {
 }
 
 int bf_image_manager_set_stream(bf_image_manager* im, void* s) { BF_REQUIRE(im, "null manager"); im->stream = (hipStream_t)s; return BF_OK; }
+// keep, per stored frame, its depth and colour interleaved as 8-byte texels as well (before the first frame; frames on the GPU only): +8 bytes per pixel and frame
+int bf_image_manager_set_store_texels(bf_image_manager* im, int enable) {
+    BF_REQUIRE(im, "null manager");
+    BF_REQUIRE(im->currFrame == 0, "set_store_texels after the first frame");
+    im->storeTexels = enable != 0 && im->onGPU && !im->scratch;
+    return BF_OK;
+}
+int bf_image_manager_get_integrate_frame_texels(bf_image_manager* im, uint32_t frame, const void** d_texels) {
+    BF_REQUIRE(im && d_texels, "null argument");
+    *d_texels = nullptr;
+    if (!im->storeTexels || frame >= im->currFrame || frame / bf_image_manager::SLAB >= im->texelSlabs.size()) return BF_OK;
+    *d_texels = im->texelSlabs[frame / bf_image_manager::SLAB] + (size_t)(frame % bf_image_manager::SLAB) * im->nInt() * 8;
+    return BF_OK;
+}
 // see bf_image_manager::inputGuard: set k (0 / 1) is overwritten by frames of parity k; `hip_event` (or null) is recorded by whoever reads a frame's
 // input buffers on ANOTHER stream than the ingest's, after its last read
 int bf_image_manager_set_input_guard(bf_image_manager* im, uint32_t set, void* hip_event) {
@@ -266,6 +285,7 @@ static int im_process(bf_image_manager* im, const float* depth, const uint8_t* c
             BF_HIP_TRY(hipMalloc((void**)&pd, ni * 4 * slots));
             BF_HIP_TRY(hipMalloc((void**)&pc, ni * 4 * slots));
             im->depthSlabs.push_back(pd); im->colorSlabs.push_back(pc);
+            if (im->storeTexels) { uint8_t* pt = nullptr; BF_HIP_TRY(hipMalloc((void**)&pt, ni * 8 * slots)); im->texelSlabs.push_back(pt); }
         }
         frameDepth = im->depthSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni;
         frameColor = im->colorSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni * 4;
@@ -297,6 +317,8 @@ static int im_process(bf_image_manager* im, const float* depth, const uint8_t* c
     float* depthDst = im->onGPU ? frameDepth : im->d_stageDepth;
     if (sameD) BF_HIP_TRY(hipMemcpyAsync(depthDst, im->gbs.s_erodeSIFTdepth ? im->d_depthInputFiltered : im->d_depthInputRaw, ni * 4, hipMemcpyDeviceToDevice, st));
     else BF_TRY(bf_image_resample_float(depthDst, im->wInt, im->hInt, im->d_depthInputFiltered, sn.depthWidth, sn.depthHeight, st));
+    if (im->onGPU && im->storeTexels && f / bf_image_manager::SLAB < im->texelSlabs.size())
+        BF_TRY(bf_image_interleave_texels(im->texelSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni * 8, frameDepth, frameColor, (uint32_t)ni, st));
     if (!im->onGPU) {
         BF_HIP_TRY(hipMemcpyAsync(im->hostDepth.back().data(), im->d_stageDepth, ni * 4, hipMemcpyDeviceToHost, st));
         BF_HIP_TRY(hipMemcpyAsync(im->hostColor.back().data(), im->d_stageColor, ni * 4, hipMemcpyDeviceToHost, st));
@@ -1836,7 +1858,7 @@ struct bf_pipeline {
     // runs BEFORE that chain is enqueued (in the lagged mode there is no such dependence).
     int deferred = -1;              // frame that has been detected; its matching chain is not enqueued yet
     std::deque<uint32_t> begun;     // frames whose chain is enqueued and whose body has not run, oldest first (at most `depth`)
-    uint32_t depth = 3;             // chains in flight across a call boundary + 1 (BF_PIPELINE_DEPTH, 2 .. PEND): the call that delivers frame n enqueues the chain of frame
+    uint32_t depth = 2;             // chains in flight across a call boundary + 1 (BF_PIPELINE_DEPTH, 2 .. PEND): the call that delivers frame n enqueues the chain of frame
                                     // n - 1 and runs the body of frame n - depth.  Measured (gpurun r04c, depth 2): a chain's twelve dependent launches take 1.0 - 1.2 ms from
                                     // enqueue to result next to the volume's and the detector's queues - twice the sum of their kernel times - so one call of slack is not enough
     hipStream_t sSolve = nullptr;   // stream of the lagged solves (bf_pipeline_set_solve_lag)
@@ -1847,7 +1869,7 @@ struct bf_pipeline {
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
     // and posts commands; the worker issues the launches, so the ~55 TSDF launches per frame do not serialize with the ~60
     // launches of the bundling stream on one CPU thread.
-    struct VolCmd { int kind; bf_depth_camera_data data; float T0[16], T1[16]; int waitEv; };   // kind: 0 integrate, 1 de-integrate, 2 fused re-integrate, 3 GC
+    struct VolCmd { int kind; bf_depth_camera_data data; const void* texels; float T0[16], T1[16]; int waitEv; };   // kind: 0 integrate, 1 de-integrate, 2 fused re-integrate, 3 GC
     static const size_t MAX_QUEUE = 48;          // back-pressure: the volume thread may lag the bundling thread by a few frames at most
     std::thread worker;
     std::mutex mu;
@@ -1857,6 +1879,7 @@ struct bf_pipeline {
     int workerError = BF_OK;
     std::string workerMessage;
     uint32_t numIntegrate = 0, numDeIntegrate = 0;
+    double volBusy = 0.0, volCommands = 0.0;      // the volume thread: seconds spent issuing operators (HIP API calls), operators issued (bf_pipeline_get_volume_thread_profile)
     // wall time the calling thread spent in each part of plFrame, accumulated (bf_pipeline_get_host_profile): where the frame loop's
     // critical path lies without a profiler.  [0] enqueue of the previous frame's matching chain, [1] ingest + detection enqueue,
     // [2] re-integration commands, [3] wait for the matching result + host logic, [4] integration command, [5] solves, [6] ingest wait, [7] frames
@@ -1871,6 +1894,7 @@ namespace {
 int volExecute(bf_pipeline* p, const bf_pipeline::VolCmd& c) {                                     // DepthSensing.cpp:723-762
     if (c.kind == 3) return bf_scene_garbage_collect(p->scene);
     if (c.waitEv >= 0) BF_TRY(bf_scene_wait_event(p->scene, p->evIngest[c.waitEv]));
+    if (c.texels) BF_TRY(bf_scene_set_frame_texels(p->scene, c.texels));
     if (c.kind == 0) return bf_scene_integrate(p->scene, c.T0, &c.data, &p->cam, nullptr);
     if (c.kind == 1) return bf_scene_deintegrate(p->scene, c.T0, &c.data, &p->cam, nullptr);
     return bf_scene_reintegrate(p->scene, c.T0, c.T1, &c.data, &p->cam);
@@ -1886,9 +1910,12 @@ void volWorker(bf_pipeline* p) {
             c = p->queue.front(); p->queue.pop_front();
             p->busy = true;
         }
+        const double tv = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         const int rc = volExecute(p, c);
+        const double dv = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tv;
         {
             std::lock_guard<std::mutex> lk(p->mu);
+            p->volBusy += dv; p->volCommands += 1.0;
             if (rc != BF_OK && p->workerError == BF_OK) { p->workerError = rc; p->workerMessage = bf_last_error(); }
             p->busy = false;
             p->cvIdle.notify_all();
@@ -1900,7 +1927,11 @@ int volPost(bf_pipeline* p, int kind, uint32_t frame, const float* T0, const flo
     bf_pipeline::VolCmd c;
     c.kind = kind; c.waitEv = waitEv;
     c.data.d_depthData = nullptr; c.data.d_colorData = nullptr;
-    if (kind != 3) BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frame, &c.data.d_depthData, &c.data.d_colorData));   // resolved on the calling thread
+    c.texels = nullptr;
+    if (kind != 3) {
+        BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frame, &c.data.d_depthData, &c.data.d_colorData));   // resolved on the calling thread
+        BF_TRY(bf_image_manager_get_integrate_frame_texels(p->im, frame, &c.texels));
+    }
     if (T0) memcpy(c.T0, T0, 64);
     if (T1) memcpy(c.T1, T1, 64);
     if (p->timings) return volExecute(p, c);        // stage timings are taken with everything issued from the calling thread
@@ -2093,6 +2124,14 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
     p->gas = *gas; p->gbs = *gbs; p->sensor = *sensor;
     memset(&p->last, 0, sizeof p->last);
     int rc = bf_image_manager_create(gas->s_integrationWidth, gas->s_integrationHeight, gbs->s_widthSIFT, gbs->s_heightSIFT, sensor, gbs, 1, &p->im);
+    if (!rc) {
+        // texel images of the stored frames (see bf_image_manager::storeTexels) when all of them fit a budget: 8 bytes per pixel and frame on top of the 8 the
+        // frames take (5000 frames at 640x480: 12 GB; BASELINE configs[4], 20000 frames at 1280x960, would need 197 GB more - the operators interleave per use there)
+        const double texBytes = 8.0 * gas->s_integrationWidth * gas->s_integrationHeight * (double)gbs->s_maxNumImages * gbs->s_submapSize;
+        double budget = 0.0;          // off by default: measured no gain (gpurun r04l: 680 vs 685 frames/s - an operator that interleaves its frame itself also leaves it in the cache)
+        if (const char* e = getenv("BF_PIPELINE_TEXEL_BUDGET_GB")) budget = 1e9 * atof(e);
+        if (texBytes <= budget) rc = bf_image_manager_set_store_texels(p->im, 1);
+    }
     if (!rc) rc = bf_online_bundler_create(sensor, p->im, gas, gbs, &p->ob);
     bf_hash_params hp;                                          // CUDASceneRepHashSDF::parametersFromGlobalAppState :39-59
     memset(&hp, 0, sizeof hp);
@@ -2121,9 +2160,14 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // 0.80 -> 0.69 ms while the voxel update slows 93.8 -> 126 us; frames/s 656 -> 655 / 648 / 623 / 565)
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
+        // The HIP runtime maps streams onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, four by default) by priority class and creation order, and streams
+        // that share a queue serialise.  Which streams exist - even idle ones - therefore decides the frame rate: measured on one box (gpurun r04i - r04k) 710
+        // frames/s with exactly this set in exactly this order (allocation [the scene's], bundling, volume, detection, solve, ingest, pair x 2), 440 - 660 with
+        // any other set tried (a second preparation stream, no solve / pair streams, the ingest on the bundling stream, 2 - 16 queues requested).  The solve
+        // and pair streams are used by the lagged-solve / side-by-side pair modes only; they are created regardless, as placeholders in that order.
+        BF_HIP_TRY(hipStreamCreateWithPriority(&p->sSolve, hipStreamNonBlocking, greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sIngest, hipStreamNonBlocking, greatest));
-        // (the solve stream of the lagged mode and the two pair streams are created when those modes are switched on: every HIP stream beyond the runtime's
-        // GPU_MAX_HW_QUEUES hardware queues - four by default; bench.py and the tools ask for eight - shares a queue with another one and serialises with it)
+        for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
     if (const char* e = getenv("BF_PIPELINE_DEPTH")) p->depth = (uint32_t)std::min(std::max(atoi(e), 2), bf_online_bundler::PEND);
@@ -2138,7 +2182,7 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         if (e && atoi(e) != 0) {
             int least = 0, greatest = 0;
             BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+            for (auto& st : p->sPair) if (!st) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
             BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPair[0], p->sPair[1]));
         }
     }
@@ -2271,6 +2315,18 @@ int bf_pipeline_get_host_profile(bf_pipeline* p, double out[8], int reset) {
     BF_TRY(plFlush(p));
     for (int i = 0; i < 8; ++i) out[i] = p->hostProfile[i];
     if (reset) for (double& v : p->hostProfile) v = 0.0;
+    return BF_OK;
+}
+// where the volume thread's time goes: seconds it spent inside the operators' HIP API calls and the number of operators it issued since the last reset -
+// if busy / wall is near 1, the thread's launch rate, not the GPU, paces the volume
+int bf_pipeline_get_volume_thread_profile(bf_pipeline* p, double* busySeconds, double* commands, int reset) {
+    BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFlush(p));
+    BF_TRY(volDrain(p));
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (busySeconds) *busySeconds = p->volBusy;
+    if (commands) *commands = p->volCommands;
+    if (reset) { p->volBusy = 0.0; p->volCommands = 0.0; }
     return BF_OK;
 }
 int bf_pipeline_enable_timings(bf_pipeline* p, int enable) {

@@ -258,6 +258,9 @@ BF_DEV bool waveSetInsert(unsigned long long* set, uint64_t key) {
 // emitCandidate - followed by the usual placement.  Queuing a key is idempotent and bins are sorted before placement, so the table does not
 // depend on who found a block or in which order.
 struct Collect { unsigned long long* keys; uint32_t* slots; uint32_t* count; uint32_t capacity; uint32_t tile0, tile1; };
+// the march reads every pixel's depth anyway: when the operator's update wants the frame as 8-byte {depth, colour} texels (fast contract), the march writes them
+// on the way - one launch less on the allocation stream than a separate interleave pass (texel == null: no)
+struct TexelOut { const uint32_t* color; uint2* texel; };
 
 BF_DEV void collectCandidate(const Dev& d, const Collect& c, i3 b) {
     if (!keyable(b)) return;
@@ -292,7 +295,7 @@ BF_DEV void waveSetFlush(const Dev& d, const Frame& f, const Collect& c, unsigne
 }
 
 template <bool COLLECT>
-__global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth, Collect c) {
+__global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth, Collect c, TexelOut tx) {
     __builtin_amdgcn_s_setprio(3);          // see PREP_PRIO
     __shared__ unsigned long long setAll[4][WSET];
     __shared__ unsigned long long listAll[4][WLIST];
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
     const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
     bool alive = x < W && y < H && (!COLLECT || tile < c.tile1);
     const float dd = alive ? depth[(size_t)y * W + x] : BF_MINF;
+    if (tx.texel != nullptr && alive) tx.texel[(size_t)y * W + x] = make_uint2(__float_as_uint(dd), tx.color[(size_t)y * W + x]);
     if (dd == BF_MINF || dd == 0.0f) alive = false;
     if (dd >= f.maxIntegrationDistance) alive = false;
     const float t = f.truncation + f.truncScale * dd;
@@ -624,6 +628,7 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratc
         d.heapCounter[0] = newCounter;
         d.allocCount[0] = allocBase + Mp;
         d.allocSnap[0] = allocBase + Mp;
+        d.compactCount[0] = 0; d.compactCount[1] = 0;          // the list pass (k_compact_append) appends to these
         if (dropped) atomicAdd(&d.stats[ST_DROPPED], dropped);
         d.overflowCount[0] = 0;
     }
@@ -801,7 +806,58 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame f
     }
 }
 
-__global__ void k_alloc_snapshot(Dev d) { d.allocSnap[0] = d.allocCount[0]; }      // an operator without an allocation of its own
+// The frustum (MODE 0) or union (MODE 2) list in ONE pass (round 4; the two-pass form above remains for the list maintenance after a garbage collection, MODE 1):
+// every workgroup filters its tile of the allocated-block list, reserves a contiguous range of the list with one atomic add and writes its keepers there - tile
+// ranges in arrival order, the order inside a tile kept.  The list's ORDER is not part of any result (the voxel update treats every block on its own, garbage
+// collection bins and sorts what it takes from the list; the reference's own compactify appends with atomicAdd, CUDASceneRepHashSDF.cu:324-366), and one launch
+// boundary less on the preparation chain - which paces the re-integration loop - is worth more than a reproducible order.  compactCount[0] / [1] are zeroed behind
+// the operator's allocation (k_alloc_place's tail / k_alloc_snapshot).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_compact_append(Dev d, Frame f, Frame fo) {
+    __shared__ uint32_t wscan[4];
+    __shared__ uint32_t sbase;
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t n = d.allocSnap[0];
+    const uint32_t numTiles = (n + TILE - 1) / TILE;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        AllocRec recs[4];
+        uint32_t keep[4];
+        uint32_t c = 0, ob = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
+            keep[k] = 0u;
+            if (i < n) { recs[k] = d.allocList[i]; keep[k] = keepRec<MODE>(f, fo, recs[k]); }
+            c += keep[k] ? 1u : 0u;
+            ob += (keep[k] & 1u) + ((keep[k] >> 1) & 1u);
+        }
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+        if (lane == 63) wscan[wave] = incl;
+        if (MODE == 2) { ob = (uint32_t)wave_sum_i((int)ob); if (lane == 0 && ob) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, ob); }
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t tot = wscan[0] + wscan[1] + wscan[2] + wscan[3]; sbase = tot ? atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount), tot) : 0u; }
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += wscan[w];
+        uint32_t pos = sbase + woff + incl - c;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (!keep[k]) continue;
+            const i3 b = unpackKey(recs[k].key);
+            uint4* o4 = reinterpret_cast<uint4*>(d.compact + pos);
+            o4[0] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)recs[k].ptr);
+            o4[1] = make_uint4(MODE == 2 ? keep[k] : 0u, 0u, 0u, 0u);     // offset field doubles as the frustum flags of the union list
+            d.compactSrc[pos] = tile * TILE + threadIdx.x * 4 + k;
+            ++pos;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_alloc_snapshot(Dev d) { d.allocSnap[0] = d.allocCount[0]; d.compactCount[0] = 0; d.compactCount[1] = 0; }      // an operator without an allocation of its own
 
 __global__ void k_list_commit(Dev d) {
     const uint32_t n = d.allocCount[0];
@@ -1516,7 +1572,7 @@ struct bf_scene {
     int arith = BF_TSDF_ARITH_FAST; // bf_scene_set_arith / BF_TSDF_ARITH: fast (k_update_apx: the contract of the reference's own GPU build; default since round 4) or
                                     // exact (k_update_col: IEEE op by op, bit-comparable with a host build of the reference and with the oracle)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
-    uint2* texel[4] = {nullptr, nullptr, nullptr, nullptr}; size_t texelPixels = 0;      // the operator's frame as 8-byte {depth, colour} texels (k_interleave), one per list buffer (NB)
+    uint2* texel[8] = {}; size_t texelPixels = 0;      // the operator's frame as 8-byte {depth, colour} texels (k_interleave), one per list buffer (NB)
     bool apxDefer = true;           // k_update_apx<.., DEFER>: voxel slices loaded only behind a valid sample (BF_APX_DEFER=0: speculative loads)
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
@@ -1529,23 +1585,30 @@ struct bf_scene {
     // NB list buffers: allocation + list of operator n+1 .. n+NB-1 may be prepared while operator n updates voxels.  (With two buffers the
     // prep stream had to wait for the update two operators back, and the two cross-stream event hops of ~40 us each sat inside the
     // steady-state cycle: period = hop + (prep + update) / 2, profiles/r03_timeline_fast_before.txt: 50 us idle between consecutive updates.)
-    static constexpr int NB = 4;
-    bf_hash_entry* cbuf[NB] = {nullptr, nullptr, nullptr, nullptr}; uint32_t* csrc[NB] = {nullptr, nullptr, nullptr, nullptr}; int32_t* ccnt[NB] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NBMAX = 8;
+    int NB = 4;                     // list buffers in use (BF_SCENE_LIST_BUFFERS, 2 .. NBMAX)
+    bool orderedLists = false;      // BF_SCENE_ORDERED_LISTS=1: the two-pass, order-preserving form of the frustum lists (until round 3; k_compact_count / k_compact_scatter)
+    bool splitPrep = false;         // BF_SCENE_SPLIT_PREP=1: the lists on their own stream (see `lists` below).  Off by default: the HIP runtime maps streams onto four
+                                    // hardware queues (GPU_MAX_HW_QUEUES) in creation order, the frame loop's four streams - allocation, bundling, volume, detection -
+                                    // take exactly those, and a fifth active stream shares a queue with one of them and serialises with it (measured, gpurun r04h - r04j:
+                                    // 710 frames/s with four streams, 440 - 530 with five to seven, whatever GPU_MAX_HW_QUEUES says)
+    bf_hash_entry* cbuf[NBMAX] = {}; uint32_t* csrc[NBMAX] = {}; int32_t* ccnt[NBMAX] = {};
     int cur = 0;                    // buffer that holds the latest list (== d.compact / d.compactSrc / d.compactCount)
-    hipEvent_t evPrep[NB] = {nullptr, nullptr, nullptr, nullptr}, evUpd[NB] = {nullptr, nullptr, nullptr, nullptr}, evBarrier = nullptr, evTmp = nullptr;
-    // Round 4: the preparation of an operator is THREE streams, not one.  The kernel trace of the frame loop (profiles/r04_timeline_before.txt) showed the voxel
+    hipEvent_t evPrep[NBMAX] = {}, evUpd[NBMAX] = {}, evBarrier = nullptr, evTmp = nullptr;
+    // Round 4 experiment (BF_SCENE_SPLIT_PREP=1): the preparation of an operator on TWO streams.  The kernel trace of the frame loop (profiles/r04_timeline_before.txt) showed the voxel
     // updates 61 us long and 79 us apart: every operator's update waited for its own preparation - allocation march, placement, two compaction passes and the
     // texel interleave, 83 us of kernels and five launch boundaries of 12-17 us each next to the update's resident waves, about 140 us in sequence - so the
-    // preparation stream, not the update, paced the loop (10 fused operators x 140 us = the 1.4 ms frame).  Now `prep` carries the allocation only and `lists`
+    // preparation stream, not the update, paced the loop (10 fused operators x 140 us = the 1.4 ms frame).  With the split `prep` carries the allocation only and `lists`
     // the texel interleave (it depends on the frame alone) followed by the two compaction passes of the operator whose allocation has finished (they read the
     // allocated-block list up to that operator's snapshot): allocation n + 1 runs beside lists n beside update n - 1.  (A third stream for the interleave
     // alone was one HIP stream too many: the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues - four by default - and streams that share a
     // queue serialise; the frame loop already owns a detect, a bundling, an ingest and a volume stream.  gpurun r04e: 270 frames/s with eleven streams.)
     hipStream_t lists = nullptr;
-    hipEvent_t evAlloc[NB] = {nullptr, nullptr, nullptr, nullptr};
-    bool updRecorded[NB] = {false, false, false, false};
+    hipEvent_t evAlloc[NBMAX] = {};
+    bool updRecorded[NBMAX] = {};
     bool barrierPending[2] = {false, false};       // per preparation stream (prep, lists): the last exclusive section has not been waited for yet
     hipEvent_t pendingEv = nullptr; // bf_scene_wait_event: the next operator's first kernel waits for it
+    const uint2* frameTexels = nullptr;   // bf_scene_set_frame_texels: the next operator's frame as interleaved texels, made once when the frame was ingested
     hipEvent_t frameEv = nullptr;   // ... and so does its texel interleave, on its own stream (set when pendingEv is consumed, cleared by the operator)
     bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
     // optional HIP-event timing of the voxel-update kernel
@@ -1697,8 +1760,10 @@ int syncAll(bf_scene* s) {
 int launchCompactify(bf_scene* s) {                              // compactifyHashEntries :355-391 (main stream, current buffer)
     const Frame f = makeFrame(s);
     hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, s->stream, s->d);
-    hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
-    hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
+    if (s->orderedLists) {
+        hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
+        hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
+    } else hipLaunchKernelGGL(k_compact_append<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     BF_HIP_TRY(hipGetLastError());
     s->compactStale = false;
     return BF_OK;
@@ -1710,7 +1775,7 @@ int refreshStaleList(bf_scene* s) {                              // a fused re-i
     return endExclusive(s);
 }
 
-int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, const float* d_depth) {      // alloc :328-352 (dv: the operator's view - its snapshot slot)
+int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, const float* d_depth, TexelOut tx) {      // alloc :328-352 (dv: the operator's view - its snapshot slot)
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
     if (s->allocComm) {
         // the march divided over the ranks: rank r marches the tiles [r T / G, (r + 1) T / G) and collects the distinct in-frustum keys it
@@ -1724,7 +1789,7 @@ int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, co
         c.keys = reinterpret_cast<unsigned long long*>(s->d_allocSend + 8); c.slots = s->d_allocSlots; c.count = cnt; c.capacity = s->allocCap;
         c.tile0 = (uint32_t)((uint64_t)tiles * rank / world); c.tile1 = (uint32_t)((uint64_t)tiles * (rank + 1) / world);
         BF_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
-        if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, dv, f, d_depth, c);
+        if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, dv, f, d_depth, c, TexelOut{nullptr, nullptr});
         hipLaunchKernelGGL(k_collect_release, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 2048u)), dim3(256), 0, st, dv, c);
         BF_TRY_RC(bf_comm_all_gather(s->allocComm, s->d_allocSend, s->d_allocRecv, rec, st));
         for (uint32_t r = 0; r < world; ++r) {
@@ -1733,7 +1798,7 @@ int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, co
                                reinterpret_cast<const unsigned long long*>(base + 8), reinterpret_cast<const uint32_t*>(base), s->allocCap);
         }
     } else
-    hipLaunchKernelGGL(k_alloc_candidates<false>, dim3(div_up(tiles, 4)), dim3(256), 0, st, dv, f, d_depth, Collect{});
+    hipLaunchKernelGGL(k_alloc_candidates<false>, dim3(div_up(tiles, 4)), dim3(256), 0, st, dv, f, d_depth, Collect{}, tx);
     hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, dv, f);
     return BF_OK;
 }
@@ -1751,46 +1816,56 @@ int prepWaits(bf_scene* s, hipStream_t ps) {
 // One operator = [allocation] -> frustum list -> voxel update.  kind 0 integrate(f), 1 de-integrate(f), 2 fused: de-integrate(fo) +
 // integrate(f).  With overlap enabled the first two phases go to the prep stream and only the update to the main stream.
 int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf_depth_camera_data* data) {
-    const int b = s->overlap ? (s->cur + 1) % bf_scene::NB : s->cur;
-    hipStream_t ps = s->overlap ? s->prep : s->stream, ls = s->overlap ? s->lists : s->stream;
+    const int b = s->overlap ? (s->cur + 1) % s->NB : s->cur;
+    hipStream_t ps = s->overlap ? s->prep : s->stream, ls = s->overlap ? (s->splitPrep ? s->lists : s->prep) : s->stream;
     const bool useTexel = s->arith == BF_TSDF_ARITH_FAST && data->d_colorData != nullptr;
     BF_TRY_RC(prepWaits(s, ps));
     const hipEvent_t frameEv = s->frameEv;          // the frame's ingest (bf_scene_wait_event); an external allocation may have consumed it for `prep` already
     s->frameEv = nullptr;
     const Dev dv = devBuf(s, b);
-    // ---- allocation (prep).  It writes the operator's snapshot into buffer b's counters: not before the update that used buffer b NB operators ago has
-    // finished - which also keeps the allocation at most NB operators ahead of the updates
+    const uint2* opTexels = s->frameTexels;        // the caller's per-frame texel image (consumed by this operator), or the one made here
+    s->frameTexels = nullptr;
+    const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
+    if (useTexel && !opTexels && s->texelPixels < npx) {
+        BF_TRY_RC(syncAll(s));
+        for (int k = 0; k < bf_scene::NBMAX; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
+        s->texelPixels = npx;
+    }
+    // ---- allocation (prep).  It writes the operator's snapshot into buffer b's counters (and, fast contract, the frame's texels into texel buffer b): not before the
+    // update that used buffer b NB operators ago has finished - which also keeps the allocation at most NB operators ahead of the updates
     if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));
-    if (kind != 1 && !s->externalAlloc) BF_TRY_RC(launchAllocOn(s, ps, dv, f, data->d_depthData));      // de-integration neither allocates nor frees
-    else hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, ps, dv);
-    // ---- lists stream, first the frame as 8-byte texels for this operator's gathers (2 x 2.4 MB at 640x480; depends on the frame alone, so it runs while the
-    // allocation is still marching) ...
+    const bool marches = kind != 1 && !s->externalAlloc;                       // de-integration neither allocates nor frees
+    const bool texelsFromMarch = marches && !s->allocComm && useTexel && !opTexels;      // (the divided march covers a band of the image only)
+    if (marches) {
+        TexelOut tx{nullptr, nullptr};
+        if (texelsFromMarch) { tx.color = reinterpret_cast<const uint32_t*>(data->d_colorData); tx.texel = s->texel[b]; opTexels = s->texel[b]; }
+        BF_TRY_RC(launchAllocOn(s, ps, dv, f, data->d_depthData, tx));
+    } else hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, ps, dv);
+    // ---- lists stream (the allocation stream itself unless BF_SCENE_SPLIT_PREP=1): the texel interleave where the march did not make the texels ...
     if (s->overlap) {
         if (s->barrierPending[1]) { BF_HIP_TRY(hipStreamWaitEvent(ls, s->evBarrier, 0)); s->barrierPending[1] = false; }
         if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ls, s->evUpd[b], 0));      // the update that read list buffer b / texel buffer b NB operators ago
     }
-    if (useTexel) {
-        const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
-        if (s->texelPixels < npx) {
-            BF_TRY_RC(syncAll(s));
-            for (int k = 0; k < bf_scene::NB; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
-            s->texelPixels = npx;
-        }
+    if (useTexel && !opTexels) {
         if (s->overlap && frameEv) BF_HIP_TRY(hipStreamWaitEvent(ls, frameEv, 0));
         hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ls, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
+        opTexels = s->texel[b];
     }
     // ---- ... then the frustum (or union) list: reads the allocated-block list up to this operator's snapshot, writes list buffer b
-    if (s->overlap) {
+    if (s->overlap && ls != ps) {
         BF_HIP_TRY(hipEventRecord(s->evAlloc[b], ps));
         BF_HIP_TRY(hipStreamWaitEvent(ls, s->evAlloc[b], 0));
     }
-    if (kind == 2) {
-        hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
-        hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
-    } else {
-        hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
-        hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
-    }
+    if (s->orderedLists) {
+        if (kind == 2) {
+            hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
+            hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
+        } else {
+            hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
+            hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
+        }
+    } else if (kind == 2) hipLaunchKernelGGL(k_compact_append<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
+    else hipLaunchKernelGGL(k_compact_append<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
     if (s->overlap) {
         BF_HIP_TRY(hipEventRecord(s->evPrep[b], ls));
         BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
@@ -1813,9 +1888,9 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         const ApxCam ac = makeApxCam(f);
         const ApxPose pin = makeApxPose(f), pde = makeApxPose(kind == 2 ? fo : f);
         const int hasColor = useTexel ? 1 : 0;
-        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, s->texel[b], hasColor, acc);
-        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, s->texel[b], hasColor, acc);
-        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, s->texel[b], hasColor, acc);
+        if (kind == 0) launchApx<0>(s, s->gridUpdateColPlain, dv, ac, pin, pde, opTexels, hasColor, acc);
+        else if (kind == 1) launchApx<1>(s, s->gridUpdateColPlain, dv, ac, pin, pde, opTexels, hasColor, acc);
+        else launchApx<2>(s, s->gridUpdateCol, dv, ac, pin, pde, opTexels, hasColor, acc);
     } else {
         const UpdCam uc = makeUpdCam(f);
         const UpdPose pin = makeUpdPose(f), pde = makeUpdPose(kind == 2 ? fo : f);
@@ -1867,7 +1942,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     A(s->d.heap, N);
     A(s->d.heapCounter, 1);
     A(s->d.vox, N * VOX);
-    for (int b = 0; b < bf_scene::NB; ++b) { A(s->cbuf[b], N); A(s->csrc[b], N); A(s->ccnt[b], 4); }      // ccnt: [0] list length, [1] operator blocks of a union list (entries in the new frustum + entries in the old one)
+    for (int b = 0; b < bf_scene::NBMAX; ++b) { A(s->cbuf[b], N); A(s->csrc[b], N); A(s->ccnt[b], 4); }      // ccnt: [0] list length, [1] operator blocks of a union list (entries in the new frustum + entries in the old one)
     A(s->d.occSum, 3);
     A(s->d.allocList, N);
     A(s->d.allocListAlt, N);
@@ -1889,9 +1964,8 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
         int least = 0, greatest = 0;
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&s->prep, hipStreamNonBlocking, greatest));
-        BF_HIP_TRY(hipStreamCreateWithPriority(&s->lists, hipStreamNonBlocking, greatest));
     }
-    for (int b = 0; b < bf_scene::NB; ++b)
+    for (int b = 0; b < bf_scene::NBMAX; ++b)
         for (hipEvent_t* e : {&s->evPrep[b], &s->evUpd[b], &s->evAlloc[b]}) BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&s->evBarrier, &s->evTmp})
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -1900,6 +1974,14 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_GRID_UPDATE_COL")) s->gridUpdateCol = s->gridUpdateColPlain = (uint32_t)atoi(e);      // tuning knob (tools/tsdf_sweep.py)
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_DEFER")) s->apxDefer = atoi(e) != 0;
+    if (const char* e = getenv("BF_SCENE_LIST_BUFFERS")) s->NB = std::min(std::max(atoi(e), 2), (int)bf_scene::NBMAX);
+    if (const char* e = getenv("BF_SCENE_SPLIT_PREP")) s->splitPrep = atoi(e) != 0;
+    if (const char* e = getenv("BF_SCENE_ORDERED_LISTS")) s->orderedLists = atoi(e) != 0;
+    if (s->splitPrep) {
+        int least = 0, greatest = 0;
+        BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        BF_HIP_TRY(hipStreamCreateWithPriority(&s->lists, hipStreamNonBlocking, greatest));
+    }
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
@@ -1934,7 +2016,7 @@ int bf_scene_alloc_collect(bf_scene* s, const float camToWorld[16], const bf_dep
     c.keys = reinterpret_cast<unsigned long long*>(d_keys); c.slots = d_slots; c.count = d_count; c.capacity = capacity;
     c.tile0 = (uint32_t)((uint64_t)tiles * part / parts); c.tile1 = (uint32_t)((uint64_t)tiles * (part + 1) / parts);
     BF_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
-    if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, s->d, f, data->d_depthData, c);
+    if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, s->d, f, data->d_depthData, c, TexelOut{nullptr, nullptr});
     hipLaunchKernelGGL(k_collect_release, dim3(std::min<uint32_t>(div_up(capacity, 256u), 2048u)), dim3(256), 0, st, s->d, c);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -2016,7 +2098,7 @@ int bf_scene_destroy(bf_scene* s) {
     if (s->d_allocRecv) hipFree(s->d_allocRecv);
     if (s->d_allocSlots) hipFree(s->d_allocSlots);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (int b = 0; b < bf_scene::NB; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b], s->evAlloc[b]}) if (e) hipEventDestroy(e);
+    for (int b = 0; b < bf_scene::NBMAX; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b], s->evAlloc[b]}) if (e) hipEventDestroy(e);
     for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
     for (hipStream_t st : {s->prep, s->lists}) if (st) hipStreamDestroy(st);
     delete s;
@@ -2039,6 +2121,23 @@ int bf_scene_set_overlap(bf_scene* s, int enable) {
     return BF_OK;
 }
 
+// The fast contract gathers depth and colour of a sample as ONE 8-byte texel {depth f32, colour RGBX8}.  Without this call every operator interleaves its frame
+// itself (one more launch on the allocation stream, per operator); a caller that keeps its frames anyway can interleave each frame once, when it arrives
+// (bf_image_interleave_texels), and hand the image to every operator that integrates or de-integrates that frame: `d_texels` (width x height x 8 bytes) is
+// consumed by the NEXT operator only.  The pipeline does this when the frames' texel images fit its budget.
+int bf_scene_set_frame_texels(bf_scene* s, const void* d_texels) {
+    BF_REQUIRE(s, "null scene");
+    s->frameTexels = reinterpret_cast<const uint2*>(d_texels);
+    return BF_OK;
+}
+int bf_image_interleave_texels(void* d_texels, const float* d_depth, const uint8_t* d_colorRGBX, uint32_t numPixels, void* hip_stream) {
+    BF_REQUIRE(d_texels && d_depth && d_colorRGBX && numPixels > 0, "bad argument");
+    hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up(numPixels, 256u), 2048u)), dim3(256), 0, (hipStream_t)hip_stream, d_depth, reinterpret_cast<const uint32_t*>(d_colorRGBX),
+                       reinterpret_cast<uint2*>(d_texels), numPixels);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
 int bf_scene_wait_event(bf_scene* s, void* hip_event) {
     BF_REQUIRE(s, "null scene");
     s->pendingEv = (hipEvent_t)hip_event;
@@ -2055,7 +2154,7 @@ int bf_scene_reset(bf_scene* s) {                                  // CUDASceneR
     BF_TRY_RC(syncAll(s));
     s->compactStale = false; for (bool& bp : s->barrierPending) bp = false; s->pendingEv = nullptr; s->frameEv = nullptr;
     for (bool& u : s->updRecorded) u = false;
-    for (int b = 0; b < bf_scene::NB; ++b) BF_HIP_TRY(hipMemsetAsync(s->ccnt[b], 0, 16, s->stream));
+    for (int b = 0; b < bf_scene::NBMAX; ++b) BF_HIP_TRY(hipMemsetAsync(s->ccnt[b], 0, 16, s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
     BF_HIP_TRY(hipMemsetAsync(s->d.vox, 0, (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel), s->stream));
     hipLaunchKernelGGL(k_reset, dim3(2048), dim3(256), 0, s->stream, s->d, s->params.m_numSDFBlocks, (uint32_t)numEntries,

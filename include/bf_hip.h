@@ -191,6 +191,11 @@ BF_API int bf_scene_alloc_sync(bf_scene* s);
 #define BF_TSDF_ARITH_EXACT 0
 #define BF_TSDF_ARITH_FAST 1
 BF_API int bf_scene_set_arith(bf_scene* s, int mode);
+/* MI355X addition (fast contract): a sample's depth and colour are gathered as ONE 8-byte texel {depth f32, colour RGBX8}.  Without _set_frame_texels every
+ * operator interleaves its frame itself (one more launch on its allocation stream).  A caller that keeps its frames can interleave each frame once
+ * (bf_image_interleave_texels: numPixels x 8 bytes) and hand that image to the NEXT operator on the frame with _set_frame_texels (consumed by one operator). */
+BF_API int bf_scene_set_frame_texels(bf_scene* s, const void* d_texels);
+BF_API int bf_image_interleave_texels(void* d_texels, const float* d_depth, const uint8_t* d_colorRGBX, uint32_t numPixels, void* hip_stream);
 BF_API int bf_scene_get_arith(bf_scene* s, int* mode);
 /* MI355X addition: deIntegrate(oldT) + integrate(newT) of the same frame (DepthSensing.cpp:882-889) as ONE pass over
  * the union of the two frustum lists — each touched voxel is read and written once.  Bit-identical to the two calls. */

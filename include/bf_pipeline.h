@@ -114,6 +114,10 @@ BF_API int bf_image_manager_set_stream(bf_image_manager* im, void* hip_stream);
  * another stream).  `hip_event` (a hipEvent_t, or null) guards set `set` (0 / 1): process() waits for it before it overwrites the set; the consumer of
  * a frame's buffers records it after its last read.  The accessors always name the set of the frame ingested last. */
 BF_API int bf_image_manager_set_input_guard(bf_image_manager* im, uint32_t set, void* hip_event);
+/* MI355X addition: keep, per stored frame, depth and colour ALSO interleaved as 8-byte texels (what the fast voxel update gathers, bf_scene_set_frame_texels):
+ * made once at ingest instead of once per operator on the frame.  Before the first frame; needs storeFramesOnGPU.  _get_..._texels returns null when off. */
+BF_API int bf_image_manager_set_store_texels(bf_image_manager* im, int enable);
+BF_API int bf_image_manager_get_integrate_frame_texels(bf_image_manager* im, uint32_t frame, const void** d_texels);
 BF_API int bf_image_manager_reset(bf_image_manager* im);
 /* process()  .cpp:22-158.  h_depth = sensor->getDepthFloat() (metres, -inf invalid), h_colorRGBX = getColorRGBX().
  * *gotFrame = 0 when the frame capacity (s_maxNumImages * s_submapSize) is reached.
@@ -333,6 +337,8 @@ BF_API int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t 
 /* Lagged solve for the whole loop (bf_online_bundler_set_solve_lag on a stream of the pipeline's): the chunk solves leave the frame
  * loop's critical path and are applied `lag` frames after the frame that closed the chunk.  0 = serial order (default; also
  * BF_PIPELINE_SOLVE_LAG in the environment).  Only between frames. */
+/* measurement aid: seconds the volume thread spent issuing TSDF operators (HIP API calls) and the number of operators, since the last reset */
+BF_API int bf_pipeline_get_volume_thread_profile(bf_pipeline* p, double* busySeconds, double* commands, int reset);
 BF_API int bf_pipeline_set_solve_lag(bf_pipeline* p, uint32_t lag);
 BF_API int bf_pipeline_get_solve_lag(bf_pipeline* p, uint32_t* lag);
 /* one iteration of the frame loop with a new sensor frame (host or device resident).  The two buffers may be reused as soon as

@@ -12,7 +12,6 @@ if ROOT not in sys.path:
 # The bit-for-bit tests hold the product to the oracle, which is a host build's arithmetic: they run under `exact`, selected here for every scene
 # a test creates; the tests of the fast contract (tests/test_tsdf_fast_gpu.py and the fast legs of the pipeline tests) switch explicitly.
 os.environ.setdefault("BF_TSDF_ARITH", "exact")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # before torch is imported: see bundlefusion_amd/__init__.py
 
 
 def pytest_configure(config):

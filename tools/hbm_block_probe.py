@@ -14,7 +14,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import bundlefusion_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime is loaded)
 import torch
 
 from bundlefusion_amd.capi import lib, check

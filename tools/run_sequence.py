@@ -9,7 +9,6 @@ import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import bundlefusion_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime is loaded)
 import torch
 
 import bundlefusion_amd as bf

@@ -35,7 +35,7 @@ def se3_exp(w, t):
     return M
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--stride", type=int, default=10)
@@ -49,25 +49,51 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not software-pipeline consecutive operators")
     ap.add_argument("--shard-alloc", action="store_true", help="(several ranks) divide the allocation's ray march over the ranks: every rank marches a band of the pixel "
                     "tiles (bf_scene_alloc_collect), ONE all-gather of the key lists per operator, every rank ingests all lists (bf_scene_alloc_ingest / _place)")
-    a = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    ap.add_argument("--comm-alloc", action="store_true", help="(several ranks) the divided march INSIDE the operators: bf_scene_set_alloc_comm with an RCCL communicator of the C ABI "
+                    "(include/bf_comm.h) - the collective is issued by the library on the allocation stream, no host round trip per operator")
+    return ap
 
-    from bundlefusion_amd import synth
-    W, H = a.width, a.height
-    frames = synth.render_frames([k * a.stride for k in range(a.frames)], W, H, workers=min(32, os.cpu_count() or 1))
+
+def main():
+    a = parser().parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    out = run(a, rank, world)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run(a, rank=0, world=1):
+    """The sweep on an initialised process group (or one rank); returns the result dict (meaningful on rank 0)."""
+    from bundlefusion_amd import synth
+    W, H = a.width, a.height
+    frames = synth.render_frames([k * a.stride for k in range(a.frames)], W, H, workers=min(32, max(1, (os.cpu_count() or 1) // max(world, 1))))
+    import torch
+    import torch.distributed as dist
     import bundlefusion_amd as bf
     from bundlefusion_amd.capi import default_hash_params, camera_params
     K = frames[0][3]
     cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
     p = default_hash_params(num_buckets=a.buckets, num_sdf_blocks=a.blocks, voxel_size=a.voxel)
     sc = bf.capi.SceneRepHashSDF(p)
+    if getattr(a, "arith", None):
+        sc.set_arith(a.arith)
     if world > 1:
         sc.set_shard(rank, world)
+    comm = None
+    if getattr(a, "comm_alloc", False) and world > 1:
+        def bcast(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = bf.capi.Comm.rccl(world, rank, bcast)
+        sc.set_alloc_comm(comm, 1 << 16)
     if not a.no_overlap:
         sc.set_overlap(True)
     dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
@@ -138,10 +164,11 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
         t_sweep, t_int = float(v[0]), float(v[1])
     dbg = sc.debug_hash()
+    if comm is not None:
+        sc.set_alloc_comm(None)
     n_re = a.sweeps * a.frames
     alg_bytes = occ_sum * (512 * 24 + 32) + n_ops * W * H * 8          # SURVEY.md §8d, per rank (its shard of the lists)
-    if rank == 0:
-        print(json.dumps({
+    return ({
             "workload": "%d frames %dx%d @%.0f mm, %d re-integration sweeps (%s), %d rank(s)" %
                         (a.frames, W, H, a.voxel * 1e3, a.sweeps, "separate operators" if a.separate else "fused operator", world),
             "integrate_us_per_op": 1e6 * t_int / a.frames,
@@ -153,9 +180,9 @@ def main():
             "algorithmic_GBps_of_update_kernel_rank0": alg_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else None,
             "algorithmic_GBps_wall_rank0": alg_bytes / t_sweep / 1e9,
             "blocks_allocated_rank0": dbg["occupied"], "dropped": dbg["dropped"],
-        }))
-    if world > 1:
-        dist.destroy_process_group()
+            "allocation": "march divided over the ranks inside the operators (RCCL all-gather of block keys per operator)" if comm is not None else
+                          ("march divided over the ranks, exchange through torch.distributed" if a.shard_alloc else "every rank marches all pixels"),
+        })
 
 
 if __name__ == "__main__":
