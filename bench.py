@@ -277,7 +277,7 @@ def main():
         avg_kernel_s = (L["kernel_ms"] / 1e3) / max(n_launch, 1)
         achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         traffic = pmc_traffic(args, L["arith"], L["vis_plain"], L["vis_fused"], n_launch)
-        kern = "k_update_apx<2> (fused de-integrate + integrate) + k_update_apx<0> (integrate)" if L["arith"] == "fast" else \
+        kern = "k_update_apx<2,.,DEFER> (fused de-integrate + integrate) + k_update_apx<0,.,DEFER> (integrate)" if L["arith"] == "fast" else \
                "k_update_col<2> (fused de-integrate + integrate) + k_update_col<0> (integrate)"
         return {
             "kernel": kern + " - TSDF voxel update, tsdf.hip",
@@ -288,7 +288,7 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch, "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": L["occ_sum"] / max(n_ops, 1),
             "blocks_visited_per_launch": (L["vis_plain"] + L["vis_fused"]) / max(n_launch, 1),
             "accounting": "fused launch = union list once: N_union*(512*24+32) + W*H*8 B; traffic = PMC bytes per visited block "
-                          "(profiles/r03_pmc_tsdf_update.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes, same contract) x blocks visited here",
+                          "(profiles/r04_pmc_tsdf_update.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes, same contract and same kernel source: update_kernel_sha256) x blocks visited here; null when that file was collected on another version of the kernel",
             "share_of_step_time": (L["kernel_ms"] / 1e3) / L["elapsed"] if L["elapsed"] > 0 else None,
         }
 
@@ -463,15 +463,18 @@ def pmc_config(args):
 
 
 def pmc_traffic(args, arith, vis_plain, vis_fused, n_launch):
-    """HBM bytes per voxel-update launch of THIS run, from the committed PMC passes (profiles/r03_pmc_tsdf_update.json: rocprofv3
+    """HBM bytes per voxel-update launch of THIS run, from the committed PMC passes (profiles/r04_pmc_tsdf_update.json: rocprofv3
     FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, each in its own run of this command with --pmc-out): bytes per visited SDF block
     of the plain and of the fused kernel under the same arithmetic contract, times the blocks the timed launches of this run visited.
     None when the counters were collected on another configuration (pre-roll / volume parameters / contract)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_tsdf_update.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_tsdf_update.json")
     if not os.path.exists(path) or n_launch == 0:
         return None
     pmc = json.load(open(path)).get(arith)
     if not pmc or pmc["config"] != pmc_config(args):
+        return None
+    from tools.pmc_to_json import update_kernel_sha
+    if pmc.get("update_kernel_sha256") != update_kernel_sha():          # counters of another version of the update kernels: stale, not reported
         return None
     return (vis_fused * pmc["fused"]["hbm_bytes_per_visited_block"] + vis_plain * pmc["plain"]["hbm_bytes_per_visited_block"]) / n_launch
 

@@ -169,15 +169,16 @@ struct bf_image_manager {
     bool scratch = false;          // storeFramesOnGPU == 2: one frame slot that every process() overwrites (chunk workers keep no history)
     hipStream_t stream = nullptr;
     m44 depthIntrinsics, depthIntrinsicsInv, colorIntrinsics, colorIntrinsicsInv, depthExtrinsics, depthExtrinsicsInv, siftDepthIntrinsics;
-    // The ingest buffers at sensor resolution, TWO sets (frame parity): frame n + 1 can be ingested (on its own stream) while the feature detection of frame n
+    // The ingest buffers at sensor resolution, NSETS sets (frame n uses set n % NSETS): frame n + 1 can be ingested (on its own stream) while the feature detection of frame n
     // still reads frame n's set.  d_depthInputRaw / d_depthInputFiltered / d_colorInput always name the set of the frame ingested last - what
     // CUDAImageManager's members of these names hold after process().  inputGuard[k]: an event of the caller's that the ingest waits for before it
     // overwrites set k (the consumer of the frame that used the set last), or null.
     float *d_depthInputRaw = nullptr, *d_depthInputFiltered = nullptr;
     uint8_t* d_colorInput = nullptr;
-    float *rawSet[2] = {nullptr, nullptr}, *filtSet[2] = {nullptr, nullptr};
-    uint8_t* colSet[2] = {nullptr, nullptr};
-    hipEvent_t inputGuard[2] = {nullptr, nullptr};
+    static const uint32_t NSETS = 4;     // frame n uses set n % NSETS (== the staging slot of the frame's detection, BF_STAGE_SLOTS below)
+    float *rawSet[NSETS] = {}, *filtSet[NSETS] = {};
+    uint8_t* colSet[NSETS] = {};
+    hipEvent_t inputGuard[NSETS] = {};
     // frames at integration resolution: slabs of SLAB frames in HBM (onGPU) or host vectors + one staging pair (reference default)
     static const uint32_t SLAB = 256;
     std::vector<float*> depthSlabs; std::vector<uint8_t*> colorSlabs;
@@ -208,12 +209,12 @@ int bf_image_manager_create(uint32_t wInt, uint32_t hInt, uint32_t wSIFT, uint32
     im->depthExtrinsics = toM(sensor->depthExtrinsics);
     im->depthExtrinsicsInv = inverse44(im->depthExtrinsics);
     const size_t nd = (size_t)sensor->depthWidth * sensor->depthHeight, nc = (size_t)sensor->colorWidth * sensor->colorHeight;
-    for (int k = 0; k < (im->scratch ? 1 : 2); ++k) {
+    for (uint32_t k = 0; k < (im->scratch ? 1u : bf_image_manager::NSETS); ++k) {
         BF_HIP_TRY(hipMalloc((void**)&im->rawSet[k], nd * 4));
         BF_HIP_TRY(hipMalloc((void**)&im->filtSet[k], nd * 4));
         BF_HIP_TRY(hipMalloc((void**)&im->colSet[k], nc * 4));
     }
-    if (im->scratch) { im->rawSet[1] = im->rawSet[0]; im->filtSet[1] = im->filtSet[0]; im->colSet[1] = im->colSet[0]; }
+    if (im->scratch) for (uint32_t k = 1; k < bf_image_manager::NSETS; ++k) { im->rawSet[k] = im->rawSet[0]; im->filtSet[k] = im->filtSet[0]; im->colSet[k] = im->colSet[0]; }
     im->d_depthInputRaw = im->rawSet[0]; im->d_depthInputFiltered = im->filtSet[0]; im->d_colorInput = im->colSet[0];
     if (!im->onGPU) {
         BF_HIP_TRY(hipMalloc((void**)&im->d_stageDepth, im->nInt() * 4));
@@ -239,7 +240,7 @@ int bf_image_manager_reset(bf_image_manager* im) {
 int bf_image_manager_destroy(bf_image_manager* im) {
     if (!im) return BF_OK;
     bf_image_manager_reset(im);
-    for (int k = 0; k < (im->scratch ? 1 : 2); ++k) { (void)hipFree(im->rawSet[k]); (void)hipFree(im->filtSet[k]); (void)hipFree(im->colSet[k]); }
+    for (uint32_t k = 0; k < (im->scratch ? 1u : bf_image_manager::NSETS); ++k) { (void)hipFree(im->rawSet[k]); (void)hipFree(im->filtSet[k]); (void)hipFree(im->colSet[k]); }
     (void)hipFree(im->d_stageDepth); (void)hipFree(im->d_stageColor);
     delete im;
     return BF_OK;
@@ -263,7 +264,7 @@ int bf_image_manager_get_integrate_frame_texels(bf_image_manager* im, uint32_t f
 // see bf_image_manager::inputGuard: set k (0 / 1) is overwritten by frames of parity k; `hip_event` (or null) is recorded by whoever reads a frame's
 // input buffers on ANOTHER stream than the ingest's, after its last read
 int bf_image_manager_set_input_guard(bf_image_manager* im, uint32_t set, void* hip_event) {
-    BF_REQUIRE(im && set < 2, "bad argument");
+    BF_REQUIRE(im && set < bf_image_manager::NSETS, "bad argument");
     im->inputGuard[set] = (hipEvent_t)hip_event;
     return BF_OK;
 }
@@ -293,7 +294,7 @@ static int im_process(bf_image_manager* im, const float* depth, const uint8_t* c
         im->hostDepth.emplace_back(ni); im->hostColor.emplace_back(ni * 4);
     }
     {   // this frame's input set
-        const int k = (int)(im->currFrame & 1u);
+        const uint32_t k = im->currFrame % bf_image_manager::NSETS;
         if (im->inputGuard[k]) BF_HIP_TRY(hipStreamWaitEvent(st, im->inputGuard[k], 0));
         im->d_depthInputRaw = im->rawSet[k]; im->d_depthInputFiltered = im->filtSet[k]; im->d_colorInput = im->colSet[k];
     }
@@ -841,7 +842,9 @@ struct bf_trajectory_manager {
         // 1.5 ms per call, 0.8 ms per input frame - the term that made the long stream decay, profiles/r03_5000_frame_stream.md)
         m44 intOf, optOf; f3 ri, ti, ro, to; bool haveInt = false, haveOpt = false;
     };
+    struct Cand { Frame* f; uint32_t pos; };
     std::vector<char> picked;            // scratch of generate_update_lists
+    std::vector<Cand> candScratch; std::vector<Frame*> restScratch;
     std::vector<m44> optimizedTransforms;
     std::vector<Frame> frames;
     std::vector<Frame*> framesSort;
@@ -939,20 +942,23 @@ int bf_trajectory_manager_generate_update_lists(bf_trajectory_manager* tm) {    
     // frame has type Integrated and a distance > m_minPoseDistSqrt >= 0, and among those the order is strict except for bit-equal
     // distances of different frames, which the position decides like the stable sort of the full array would.
     {
-        struct Cand { bf_trajectory_manager::Frame* f; uint32_t pos; };
-        std::vector<Cand> c(numFrames);
+        typedef bf_trajectory_manager::Cand Cand;
+        std::vector<Cand>& c = tm->candScratch;            // owned by the manager: no allocation per call
+        c.resize(numFrames);
         for (uint32_t i = 0; i < numFrames; ++i) c[i] = {tm->framesSort[i], i};
         const uint32_t K = std::min<uint32_t>(tm->topNActive, numFrames);
         auto before = [](const Cand& l, const Cand& r) {
             const bool li = l.f->type == BF_TF_INTEGRATED, ri = r.f->type == BF_TF_INTEGRATED;
             if (li != ri) return li;
             if (li && l.f->dist != r.f->dist) return l.f->dist > r.f->dist;
+            if (li) return l.f->frameIdx < r.f->frameIdx;      // bit-equal distances of two Integrated frames: by frame index, not by a position that depends on the history of earlier calls
             return l.pos < r.pos;
         };
         std::partial_sort(c.begin(), c.begin() + K, c.end(), before);
         tm->picked.assign(numFrames, 0);
         for (uint32_t i = 0; i < K; ++i) tm->picked[c[i].pos] = 1;
-        std::vector<bf_trajectory_manager::Frame*> rest;
+        std::vector<bf_trajectory_manager::Frame*>& rest = tm->restScratch;
+        rest.clear();
         rest.reserve(numFrames - K);
         for (uint32_t i = 0; i < numFrames; ++i) if (!tm->picked[i]) rest.push_back(tm->framesSort[i]);
         for (uint32_t i = 0; i < K; ++i) tm->framesSort[i] = c[i].f;
@@ -1088,8 +1094,9 @@ struct bf_online_bundler {
     // matched / solved; processInput then commits the staged slot (one copy kernel) instead of detecting.
     bf_bundler* stage = nullptr;
     hipStream_t detectStream = nullptr;
-    hipEvent_t evDetect[2] = {nullptr, nullptr}, evStageFree[2] = {nullptr, nullptr};
-    int stagedFrame[2] = {-1, -1};
+    static const uint32_t STAGE = 4;      // staging slots: frame n is detected into slot n % STAGE (the loop may run up to STAGE - 1 frames behind its input)
+    hipEvent_t evDetect[STAGE] = {}, evStageFree[STAGE] = {};
+    int stagedFrame[STAGE] = {-1, -1, -1, -1};
     // processInput calls in flight (between _begin and _end), oldest first.  Two deep: the matching chain of frame k + 1 is enqueued on the bundling
     // stream BEHIND frame k's before the host waits for frame k's result - everything frame k + 1's chain needs of frame k is device state (key points,
     // validity flags, the SIFT trajectory entry: the fix-up of an invalid frame, OnlineBundler.cpp:215-221, is the kernel k_sift_fixup).
@@ -1382,14 +1389,14 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
     if (!rc) rc = bf_bundler_create(S + 1, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 1, gas, gbs, &ob->optLocal);
     if (!rc) rc = bf_bundler_create(maxNumImages, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 0, gas, gbs, &ob->global);
     if (!rc) rc = bf_trajectory_manager_create(maxNumImages * S, gas->s_topNActive, gas->s_minPoseDistSqrt, &ob->tm);
-    if (!rc) rc = bf_bundler_create(2, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 1, gas, gbs, &ob->stage);
-    for (int k = 0; k < 2 && !rc; ++k) {                     // the two staging slots exist from the start (empty images)
+    if (!rc) rc = bf_bundler_create(bf_online_bundler::STAGE, gbs->s_maxNumKeysPerImage, ob->siftIntrinsicsInv.e, im, 1, gas, gbs, &ob->stage);
+    for (uint32_t k = 0; k < bf_online_bundler::STAGE && !rc; ++k) {                     // the staging slots exist from the start (empty images)
         bf_sift_image_gpu img;
         rc = bf_siftmgr_create_image(ob->stage->mgr, &img);
         if (!rc) rc = bf_siftmgr_finalize_image(ob->stage->mgr, 0);
     }
     if (rc) { bf_online_bundler_destroy(ob); return rc; }
-    for (int k = 0; k < 2; ++k) {
+    for (uint32_t k = 0; k < bf_online_bundler::STAGE; ++k) {
         BF_HIP_TRY(hipEventCreateWithFlags(&ob->evDetect[k], hipEventDisableTiming));
         BF_HIP_TRY(hipEventCreateWithFlags(&ob->evStageFree[k], hipEventDisableTiming));
     }
@@ -1432,7 +1439,7 @@ int bf_online_bundler_destroy(bf_online_bundler* ob) {
     if (ob->evChunkCopy) (void)hipEventDestroy(ob->evChunkCopy);
     for (int k = 0; k < 2; ++k) for (hipEvent_t e : {ob->evImage[k], ob->evPairDone[k], ob->evPairSetFree[k]}) if (e) (void)hipEventDestroy(e);
     bf_bundler_destroy(ob->local); bf_bundler_destroy(ob->optLocal); bf_bundler_destroy(ob->global); bf_bundler_destroy(ob->stage); bf_trajectory_manager_destroy(ob->tm);
-    for (int k = 0; k < 2; ++k) { if (ob->evDetect[k]) (void)hipEventDestroy(ob->evDetect[k]); if (ob->evStageFree[k]) (void)hipEventDestroy(ob->evStageFree[k]); }
+    for (uint32_t k = 0; k < bf_online_bundler::STAGE; ++k) { if (ob->evDetect[k]) (void)hipEventDestroy(ob->evDetect[k]); if (ob->evStageFree[k]) (void)hipEventDestroy(ob->evStageFree[k]); }
     (void)hipFree(ob->d_intensitySIFT); (void)hipFree(ob->d_intensityFilterHelper); (void)hipFree(ob->d_completeTrajectory); (void)hipFree(ob->d_localTrajectories);
     (void)hipFree(ob->d_siftTrajectory); (void)hipFree(ob->d_currIntegrateTransform); (void)hipFree(ob->d_imageInvalidateList);
     if (ob->h_pinT) (void)hipHostFree(ob->h_pinT);
@@ -1482,7 +1489,7 @@ int bf_online_bundler_set_detect_stream(bf_online_bundler* ob, void* s) {
     return bf_bundler_set_stream(ob->stage, s);
 }
 
-// Feature detection + dense cache frame of the image manager's current frame, into staging slot (frame & 1), on the detect
+// Feature detection + dense cache frame of the image manager's current frame, into staging slot (frame % STAGE), on the detect
 // stream (which must also be the image manager's stream, so that it is ordered after the ingest).  No bundler state changes.
 int bf_online_bundler_detect_ahead(bf_online_bundler* ob) { return bf_online_bundler_detect_ahead_after(ob, nullptr); }
 
@@ -1492,7 +1499,7 @@ int bf_online_bundler_detect_ahead_after(bf_online_bundler* ob, void* ingest_eve
     BF_REQUIRE(ob && ob->detectStream, "detect_ahead needs bf_online_bundler_set_detect_stream");
     uint32_t frame;
     BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &frame));
-    const int slot = (int)(frame & 1u);
+    const int slot = (int)(frame % bf_online_bundler::STAGE);
     BF_REQUIRE(ob->stagedFrame[slot] < 0, "staging slot still holds an uncommitted frame");
     hipStream_t sd = ob->detectStream;
     if (ingest_event) BF_HIP_TRY(hipStreamWaitEvent(sd, (hipEvent_t)ingest_event, 0));
@@ -1525,7 +1532,7 @@ __global__ __launch_bounds__(256) void k_copy_segments(CopySegs j) {
 
 // the staged detection of `frame` becomes the local bundler's next image (what detectFeatures + storeCachedFrame would have produced)
 int obCommitStaged(bf_online_bundler* ob, uint32_t frame, hipStream_t st) {
-    const int slot = (int)(frame & 1u);
+    const int slot = (int)(frame % bf_online_bundler::STAGE);
     BF_HIP_TRY(hipStreamWaitEvent(st, ob->evDetect[slot], 0));
     bf_bundler *b = ob->local, *from = ob->stage;
     bf_sift_image_gpu src, dst;
@@ -1646,7 +1653,7 @@ extern "C" {
 int bf_online_bundler_process_input_begin_frame(bf_online_bundler* ob, uint32_t curFrame) {
     BF_REQUIRE(ob, "null bundler");
     BF_REQUIRE(ob->pendCount < bf_online_bundler::PEND, "too many processInput calls in flight");
-    const bool staged = ob->stagedFrame[curFrame & 1u] == (int)curFrame;
+    const bool staged = ob->stagedFrame[curFrame % bf_online_bundler::STAGE] == (int)curFrame;
     {
         uint32_t imFrame;
         BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &imFrame));
@@ -1862,7 +1869,7 @@ struct bf_pipeline {
                                     // n - 1 and runs the body of frame n - depth.  Measured (gpurun r04c, depth 2): a chain's twelve dependent launches take 1.0 - 1.2 ms from
                                     // enqueue to result next to the volume's and the detector's queues - twice the sum of their kernel times - so one call of slack is not enough
     hipStream_t sSolve = nullptr;   // stream of the lagged solves (bf_pipeline_set_solve_lag)
-    hipStream_t sIngest = nullptr;  // the ingest filters of frame n + 1 run beside the detection of frame n (two input sets in the image manager)
+    hipStream_t sIngest = nullptr;  // the ingest filters of frame n + 1 run beside the detection of frame n (several input sets in the image manager)
     hipStream_t sPair[2] = {nullptr, nullptr};      // pair stages of consecutive frames side by side (bf_online_bundler_set_pair_streams)
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
@@ -2170,11 +2177,12 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
     }
     if (const char* e = getenv("BF_PIPELINE_LOOKAHEAD")) p->lookahead = atoi(e) != 0;
-    if (const char* e = getenv("BF_PIPELINE_DEPTH")) p->depth = (uint32_t)std::min(std::max(atoi(e), 2), bf_online_bundler::PEND);
+    if (const char* e = getenv("BF_PIPELINE_DEPTH")) p->depth = (uint32_t)std::min(std::max(atoi(e), 2), std::min<int>(bf_online_bundler::PEND, (int)bf_online_bundler::STAGE));
     BF_TRY(bf_image_manager_set_stream(p->im, p->sIngest));
     BF_TRY(bf_online_bundler_set_stream(p->ob, p->sBundle));
     BF_TRY(bf_online_bundler_set_detect_stream(p->ob, p->sDetect));
-    for (uint32_t k = 0; k < 2; ++k) BF_TRY(bf_image_manager_set_input_guard(p->im, k, p->ob->evDetect[k]));      // the staged detection of the frame that used the set last
+    static_assert(bf_image_manager::NSETS == bf_online_bundler::STAGE, "the image manager's input sets and the staging slots are indexed alike");
+    for (uint32_t k = 0; k < bf_image_manager::NSETS; ++k) BF_TRY(bf_image_manager_set_input_guard(p->im, k, p->ob->evDetect[k]));      // the staged detection of the frame that used the set last
     {
         // BF_PIPELINE_PAIR_STREAMS=1: the pair stages of consecutive frames on two streams.  Off by default: measured 659 vs 697 frames/s (gpurun r04c) - every
         // cross-stream event hop costs ~40 us on this runtime and the stage needs four of them per frame, more than the overlap of two Kabsch filters returns

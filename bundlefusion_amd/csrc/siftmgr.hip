@@ -1031,6 +1031,8 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse_to_global(FuseArgs a) {
         const uint32_t ch = changed;
         __syncthreads();
         if (!ch) break;
+        if (it == 4095 && t == 0) *a.error = 2;          // labelling not converged within the sweep cap (a chain longer than 4096 keys cannot occur with <= 11 x 1024 keys per
+                                                          // chunk and label propagation by atomicMin; reported, never silently split: bf_siftmgr_fuse_error)
     }
     // 3. the reference's depth-first search, one thread per component.  No stack: every key has ONE list position (a.fill) and the key it
     //    was entered from (a.outPos, free until step 4); `depth` counts the open calls.  The start key is entered a second time when one of
@@ -1559,7 +1561,8 @@ int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float
     return bf_siftmgr_finalize_image(global, -1);          // the count was written on the device
 }
 
-// reserved for capacity conditions of the device search (none at present: the search needs no stack); always 0
+// conditions of the device search of the LAST fuse: 0 none; 2 the connected-component labelling did not converge within its sweep cap (never observed; a split
+// track would silently differ from the host form otherwise)
 int bf_siftmgr_fuse_error(bf_siftmgr* local, int* err) {
     BF_REQUIRE(local && err, "null argument");
     *err = 0;

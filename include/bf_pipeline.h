@@ -110,8 +110,8 @@ BF_API int bf_image_manager_create(uint32_t widthIntegration, uint32_t heightInt
 BF_API int bf_image_manager_destroy(bf_image_manager* im);
 BF_API int bf_image_manager_set_stream(bf_image_manager* im, void* hip_stream);
 /* MI355X addition: the ingest buffers at sensor resolution (d_depthInputRaw / d_depthInputFiltered / d_colorInput, CUDAImageManager.h:268-284) exist
- * twice, by frame parity, so that frame n + 1 can be ingested on its own stream while frame n's buffers are still being read (feature detection on
- * another stream).  `hip_event` (a hipEvent_t, or null) guards set `set` (0 / 1): process() waits for it before it overwrites the set; the consumer of
+ * four times (frame n uses set n % 4), so that later frames can be ingested on their own stream while frame n's buffers are still being read (feature
+ * detection on another stream).  `hip_event` (a hipEvent_t, or null) guards set `set` (0 .. 3): process() waits for it before it overwrites the set; the consumer of
  * a frame's buffers records it after its last read.  The accessors always name the set of the frame ingested last. */
 BF_API int bf_image_manager_set_input_guard(bf_image_manager* im, uint32_t set, void* hip_event);
 /* MI355X addition: keep, per stored frame, depth and colour ALSO interleaved as 8-byte texels (what the fast voxel update gathers, bf_scene_set_frame_texels):

@@ -397,7 +397,9 @@ class OTrajectoryManager:
                     return True
                 if a["type"] != 0:
                     return False
-                return a["dist"] > b["dist"]
+                if a["dist"] != b["dist"]:
+                    return a["dist"] > b["dist"]
+                return a["idx"] < b["idx"]           # bit-equal distances: by frame index (the reference's std::sort leaves ties undefined)
             return -1 if less(l, r) else (1 if less(r, l) else 0)
         head.sort(key=functools.cmp_to_key(cmp))            # list.sort is stable
         self.sort[:n] = head

@@ -16,8 +16,18 @@ export TMPDIR=/tmp
 db() { ls -S "$1"/*/*_results.db "$1"/*_results.db 2>/dev/null | head -1; }
 for step in $STEPS; do
   case $step in
-    tests)
-      (cd "$ROOT" && timeout 900 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | tail -16 | tee "$OUT/pytest_gpu.txt") ;;
+    tests)      # the whole GPU suite; the captured output of passed tests (the fast-contract reports, the reference-fixture comparison) is kept
+      (cd "$ROOT" && timeout 1100 python -m pytest tests -q -m gpu --durations=12 -rP > "$OUT/pytest_gpu_full.txt" 2>&1; tail -22 "$OUT/pytest_gpu_full.txt" | tee "$OUT/pytest_gpu.txt"
+       grep -E "vs ORACLE|vs the REFERENCE|fast contract|noisy stream|frame loop, fast|^N = |integrations /" "$OUT/pytest_gpu_full.txt" | cut -c1-900 > "$OUT/test_reports.txt") ;;
+    smoke)
+      (cd "$ROOT" && timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee "$OUT/smoke.txt") ;;
+    long)       # BASELINE configs[2] (2000-frame loop closure) and configs[3] (5000 frames) at full length through bench.py's long_stream block
+      for N in ${LONG_FRAMES:-2000 5000}; do
+        (cd "$ROOT" && timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream $N > "$OUT/bench_long_$N.json" 2> "$OUT/bench_long_$N.err"; python -c "
+import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print({k: j[k] for k in ('frames','value','last_over_first','frames_tracked','ate_integrated_m','ate_optimized_m','counters')})"; tail -2 "$OUT/bench_long_$N.err")
+      done ;;
+    probe)
+      (cd "$ROOT" && timeout 200 python tools/hbm_block_probe.py > "$OUT/hbm_block_probe.json" 2>/dev/null; cut -c1-600 "$OUT/hbm_block_probe.json") ;;
     tests_new)
       (cd "$ROOT" && timeout 900 python -m pytest tests/test_pipeline_baseline_gpu.py -x -q --durations=8 2>&1 | tail -25 | tee "$OUT/pytest_new.txt") ;;
     bench)

@@ -8,9 +8,19 @@ The output file holds one entry per arithmetic contract of the voxel update ("fa
 
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes of a wide
 coalesced read stream).  The accounting file is what the profiled run itself counted over ALL its launches."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+
+def update_kernel_sha():
+    """sha256 of the voxel-update section of csrc/tsdf.hip (from the column kernel's header to the cvt probe): bench.py refuses PMC figures collected on another
+    version of these kernels (the committed per-block traffic went stale silently when the kernel changed)."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bundlefusion_amd", "csrc", "tsdf.hip")).read()
+    a, b = src.index("// voxel update, column form: ONE WAVE per SDF block"), src.index("__global__ void k_probe_cvt")
+    return hashlib.sha256(src[a:b].encode()).hexdigest()
 
 
 def totals(db, counter):
@@ -44,6 +54,7 @@ def main():
         lines.append("| voxel update, %s contract, `%s` | %d / %d | %.1f | %.1f | %.0f | %d |" % (arith, k, n, lau[k], fb / max(n, 1) / 1e6, wb / max(n2, 1) / 1e6, res[k]["hbm_bytes_per_visited_block"], 512 * 24 + 32))
     import os
     allres = json.load(open(outp)) if os.path.exists(outp) else {}
+    res["update_kernel_sha256"] = update_kernel_sha()
     allres[arith] = res
     json.dump(allres, open(outp, "w"), indent=1)
     text = "\n".join(lines)
