@@ -36,7 +36,7 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
       (cd "$ROOT" && timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"; cut -c1-260 "$OUT/bench_driver.json"; tail -3 "$OUT/bench_driver.err") ;;
     trace)
       rm -rf /tmp/r_trace
-      (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS > "$OUT/bench_traced.json" 2> /dev/null)
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --steps 20 --warmup 5 --one-contract $BENCH_ARGS > "$OUT/bench_traced.json" 2> /dev/null)
       D=$(db /tmp/r_trace)
       rm -f "$OUT/kernel_stats.md"
       python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" --exclude "Cijk_,at::native" | head -14
@@ -45,14 +45,14 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
       for A in ${PMC_CONTRACTS:-fast exact}; do
         for C in FETCH_SIZE WRITE_SIZE; do
           rm -rf /tmp/r_pmc_$C
-          (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
+          (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --steps 20 --warmup 5 --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
         done
         python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A
       done ;;
     sq)   # where do the voxel-update waves spend their cycles: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
       rm -rf /tmp/r_sq
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES \
-          -d /tmp/r_sq -o run -- python "$ROOT/bench.py" --no-cpu-baseline > /dev/null 2>&1)
+          -d /tmp/r_sq -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep > /dev/null 2>&1)
       python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_sq)" update | tee "$OUT/pmc_sq.txt" | tail -18 ;;
     stream)
       (cd "$ROOT" && timeout 500 python tools/run_sequence.py --frames 5000 --bob 0.3 --voxel 0.004 --buckets 4000000 --blocks 3000000 --tail 35 2>&1 \
