@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
     const uint32_t tile = (COLLECT ? c.tile0 : 0u) + blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     for (uint32_t i = lane; i < WSET; i += 64) set[i] = EMPTY64;
+    if (!COLLECT && blockIdx.x == 0 && threadIdx.x == 0) { d.compactCount[0] = 0; d.compactCount[1] = 0; }      // the operator's list: the placement kernel behind this one appends to it
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7);
     const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
     bool alive = x < W && y < H && (!COLLECT || tile < c.tile1);
@@ -454,6 +455,87 @@ BF_DEV uint32_t binPrefix(const uint32_t* binCount, uint32_t limit, uint32_t* sc
 }
 
 // ---------------------------------------------------------------------------------------
+// the operator's block list (frustum list, or union list of a fused re-integration)
+//   LISTS 0: blocks in the frustum of f (replaces compactifyHashAllInOneKernel, .cu:324-366);  LISTS 1: every live block (list maintenance after GC);
+//   LISTS 2: blocks in the frustum of f (bit 0 of the flags) or of fo (bit 1)
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+BF_DEV uint32_t keepRec(const Frame& f, const Frame& fo, const AllocRec& r) {
+    if (r.ptr == BF_FREE_ENTRY) return 0u;
+    if (MODE == 1) return 1u;
+    const i3 b = unpackKey(r.key);
+    if (MODE == 0) return blockInFrustum(f, b) ? 1u : 0u;
+    return (blockInFrustum(f, b) ? 1u : 0u) | (blockInFrustum(fo, b) ? 2u : 0u);
+}
+
+BF_DEV void listWrite(const Dev& d, uint32_t pos, uint64_t key, int32_t ptr, uint32_t flags, uint32_t src) {
+    const i3 b = unpackKey(key);
+    uint4* o4 = reinterpret_cast<uint4*>(d.compact + pos);
+    o4[0] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)ptr);
+    o4[1] = make_uint4(flags, 0u, 0u, 0u);       // the offset field doubles as the frustum flags of a union list
+    d.compactSrc[pos] = src;
+}
+
+// every lane of the (converged) wave calls this; lanes with keep != 0 append their block: one reservation per wave
+template <int MODE>
+BF_DEV void listAppendWave(const Dev& d, uint32_t keep, uint64_t key, int32_t ptr, uint32_t src) {
+    const unsigned long long m = __ballot(keep != 0u);
+    if (m == 0ull) return;                                      // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t ob = 0;
+    if (MODE == 2) ob = (uint32_t)wave_sum_i((int)((keep & 1u) + ((keep >> 1) & 1u)));
+    uint32_t base = 0;
+    if ((int)lane == leader) {
+        base = atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount), (uint32_t)__popcll(m));
+        if (MODE == 2) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, ob);
+    }
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (keep) listWrite(d, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), key, ptr, MODE == 2 ? keep : 0u, src);
+}
+
+// One pass over the tiles tile0, tile0 + tileStep, ... of the allocated-block list's first n entries (a tile = K entries per thread of the workgroup): every
+// workgroup filters its tile, reserves a contiguous range of the list with one atomic add and writes its keepers there - tile ranges in arrival order, the
+// order inside a tile kept.
+template <int MODE, uint32_t K>
+BF_DEV void listAppendTiles(const Dev& d, const Frame& f, const Frame& fo, uint32_t n, uint32_t tile0, uint32_t tileStep, uint32_t* wscan, uint32_t* sbase) {
+    const uint32_t tileSize = K * 256u;
+    const uint32_t numTiles = (n + tileSize - 1) / tileSize;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t tile = tile0; tile < numTiles; tile += tileStep) {
+        AllocRec recs[K];
+        uint32_t keep[K];
+        uint32_t c = 0, ob = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t i = tile * tileSize + threadIdx.x * K + k;
+            keep[k] = 0u;
+            if (i < n) { recs[k] = d.allocList[i]; keep[k] = keepRec<MODE>(f, fo, recs[k]); }
+            c += keep[k] ? 1u : 0u;
+            ob += (keep[k] & 1u) + ((keep[k] >> 1) & 1u);
+        }
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+        if (lane == 63) wscan[wave] = incl;
+        if (MODE == 2) { ob = (uint32_t)wave_sum_i((int)ob); if (lane == 0 && ob) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, ob); }
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t tot = wscan[0] + wscan[1] + wscan[2] + wscan[3]; *sbase = tot ? atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount), tot) : 0u; }
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += wscan[w];
+        uint32_t pos = *sbase + woff + incl - c;
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) {
+            if (!keep[k]) continue;
+            listWrite(d, pos, recs[k].key, recs[k].ptr, MODE == 2 ? keep[k] : 0u, tile * tileSize + threadIdx.x * K + k);
+            ++pos;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // alloc, pass B: one workgroup per bin — sort, rank, place into home buckets
 //   (serial-equivalent of allocBlock's in-bucket branch, VoxelUtilHashSDF.h:553-612)
 // ---------------------------------------------------------------------------------------
@@ -469,7 +551,8 @@ constexpr uint32_t PLACE_WGS = 256;
 BF_DEV void storeThrough(void* p, uint64_t v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 BF_DEV uint64_t pack2(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
-BF_DEV void placeBin(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch, int8_t* sel, uint32_t bin) {
+template <int LISTS>
+BF_DEV void placeBin(const Dev& d, const Frame& f, const Frame& fo, SortLds& s, uint32_t* scratch, int8_t* sel, uint32_t bin) {
     const uint32_t n = min(d.binCount[bin], BINCAP);
     if (n == 0) return;                       // block-uniform
     loadBinSorted(s, d.bins + (size_t)bin * BINCAP, n);
@@ -496,27 +579,35 @@ BF_DEV void placeBin(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch
         sel[idx] = (int8_t)slot;
     }
     __syncthreads();
-    // phase 2 (writes): disjoint slots, rank-ordered heap consumption
-    for (uint32_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
+    // phase 2 (writes): disjoint slots, rank-ordered heap consumption.  (Whole waves walk the loop: the list append below is a wave operation.)
+    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+        const uint32_t idx = i0 + threadIdx.x;
+        uint32_t keep = 0; uint64_t key = 0; int32_t ptr = 0;
         const uint32_t gi = base + idx;
-        const uint64_t key = s.key[idx];
-        const uint32_t h = s.bucket[idx];
-        d.dedupe[s.aux[idx]] = EMPTY64;
-        if (gi >= heapFree) { atomicAdd(&d.stats[ST_DROPPED], 1u); continue; }     // heap exhausted
-        const int32_t ptr = (int32_t)(d.heap[heapC - gi] * (uint32_t)VOX);          // consumeHeap :536-540
-        uint64_t* ar = reinterpret_cast<uint64_t*>(d.allocList + allocBase + gi);      // AllocRec {key, ptr, pad}
-        storeThrough(ar, key); storeThrough(ar + 1, pack2((uint32_t)ptr, 0u));
-        const int slot = sel[idx];
-        if (slot >= 0) {
-            const i3 b = unpackKey(key);
-            uint64_t* e = reinterpret_cast<uint64_t*>(d.hash + ((size_t)h * BF_HASH_BUCKET_SIZE + (uint32_t)slot));   // {pos.xyz, ptr, offset = NO_OFFSET :608, pad}
-            storeThrough(e, pack2((uint32_t)b.x, (uint32_t)b.y)); storeThrough(e + 1, pack2((uint32_t)b.z, (uint32_t)ptr));
-            storeThrough(e + 2, 0ull); storeThrough(e + 3, 0ull);
-        } else {
-            const uint32_t ov = atomicAdd(d.overflowCount, 1u);
-            if (ov < OVCAP) { uint64_t* r = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(r, key); storeThrough(r + 1, pack2(h, gi)); }      // BinRec {key, bucket, aux}
-            else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
+        if (idx < n) {
+            key = s.key[idx];
+            const uint32_t h = s.bucket[idx];
+            d.dedupe[s.aux[idx]] = EMPTY64;
+            if (gi >= heapFree) atomicAdd(&d.stats[ST_DROPPED], 1u);                    // heap exhausted
+            else {
+                ptr = (int32_t)(d.heap[heapC - gi] * (uint32_t)VOX);                    // consumeHeap :536-540
+                uint64_t* ar = reinterpret_cast<uint64_t*>(d.allocList + allocBase + gi);      // AllocRec {key, ptr, pad}
+                storeThrough(ar, key); storeThrough(ar + 1, pack2((uint32_t)ptr, 0u));
+                const int slot = sel[idx];
+                if (slot >= 0) {
+                    const i3 b = unpackKey(key);
+                    uint64_t* e = reinterpret_cast<uint64_t*>(d.hash + ((size_t)h * BF_HASH_BUCKET_SIZE + (uint32_t)slot));   // {pos.xyz, ptr, offset = NO_OFFSET :608, pad}
+                    storeThrough(e, pack2((uint32_t)b.x, (uint32_t)b.y)); storeThrough(e + 1, pack2((uint32_t)b.z, (uint32_t)ptr));
+                    storeThrough(e + 2, 0ull); storeThrough(e + 3, 0ull);
+                    if (LISTS >= 0) { AllocRec r; r.key = key; r.ptr = ptr; r.pad = 0; keep = keepRec<(LISTS < 0 ? 0 : LISTS)>(f, fo, r); }
+                } else {                                                                // the tail walks the collision window (and puts the block on the list)
+                    const uint32_t ov = atomicAdd(d.overflowCount, 1u);
+                    if (ov < OVCAP) { uint64_t* r = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(r, key); storeThrough(r + 1, pack2(h, gi)); }      // BinRec {key, bucket, aux}
+                    else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
+                }
+            }
         }
+        if (LISTS >= 0) listAppendWave<(LISTS < 0 ? 0 : LISTS)>(d, keep, key, ptr, allocBase + gi);
     }
     __syncthreads();                          // s and sel are reused for the next bin
 }
@@ -524,7 +615,8 @@ BF_DEV void placeBin(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch
 // A bin of at most 64 records (every bin once the scan is under way) is placed by ONE wave: bitonic sort in registers (lane
 // exchanges, no LDS, no barriers), rank by lane exchange, and two memory round trips in all - {bin records, bin counts, counters} and
 // {the four slots of the home bucket, the heap block}.  Same order and same decisions as placeBin.
-BF_DEV void placeBinWave(const Dev& d, const Frame& f, uint32_t n, BinRec r, uint32_t base, uint32_t heapC, uint32_t allocBase, uint32_t lane) {
+template <int LISTS>
+BF_DEV void placeBinWave(const Dev& d, const Frame& f, const Frame& fo, uint32_t n, BinRec r, uint32_t base, uint32_t heapC, uint32_t allocBase, uint32_t lane) {
     uint32_t bucket = lane < n ? r.bucket : 0xFFFFFFFFu;
     uint64_t key = lane < n ? r.key : EMPTY64;
     uint32_t aux = lane < n ? r.aux : 0u;
@@ -544,44 +636,51 @@ BF_DEV void placeBinWave(const Dev& d, const Frame& f, uint32_t n, BinRec r, uin
     const uint32_t idx = lane;
     const uint32_t b1 = (uint32_t)__shfl_up((int)bucket, 1, 64), b2 = (uint32_t)__shfl_up((int)bucket, 2, 64);
     const uint32_t b3 = (uint32_t)__shfl_up((int)bucket, 3, 64), b4 = (uint32_t)__shfl_up((int)bucket, 4, 64);
-    if (idx >= n) return;
-    uint32_t rank = 0;
-    if (idx >= 1 && b1 == bucket) { rank = 1; if (idx >= 2 && b2 == bucket) { rank = 2; if (idx >= 3 && b3 == bucket) { rank = 3; if (idx >= 4 && b4 == bucket) rank = 4; } } }
-    const uint32_t heapFree = min(heapC + 1u, f.numSDFBlocks - min(allocBase, f.numSDFBlocks));
     const uint32_t gi = base + idx;
-    int32_t p[BF_HASH_BUCKET_SIZE];
+    uint32_t keep = 0; int32_t ptr = 0;
+    if (idx < n) {
+        uint32_t rank = 0;
+        if (idx >= 1 && b1 == bucket) { rank = 1; if (idx >= 2 && b2 == bucket) { rank = 2; if (idx >= 3 && b3 == bucket) { rank = 3; if (idx >= 4 && b4 == bucket) rank = 4; } } }
+        const uint32_t heapFree = min(heapC + 1u, f.numSDFBlocks - min(allocBase, f.numSDFBlocks));
+        int32_t p[BF_HASH_BUCKET_SIZE];
 #pragma unroll
-    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) p[j] = d.hash[bucket * BF_HASH_BUCKET_SIZE + j].ptr;
-    const uint32_t heapBlock = gi < heapFree ? d.heap[heapC - gi] : 0u;                                // consumeHeap :536-540
-    int slot = -1;
-    if (rank < BF_HASH_BUCKET_SIZE) {
-        uint32_t seen = 0;
+        for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j) p[j] = d.hash[bucket * BF_HASH_BUCKET_SIZE + j].ptr;
+        const uint32_t heapBlock = gi < heapFree ? d.heap[heapC - gi] : 0u;                                // consumeHeap :536-540
+        int slot = -1;
+        if (rank < BF_HASH_BUCKET_SIZE) {
+            uint32_t seen = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j)
-            if (p[j] == BF_FREE_ENTRY) { if (seen == rank && slot < 0) slot = (int)j; ++seen; }
+            for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE; ++j)
+                if (p[j] == BF_FREE_ENTRY) { if (seen == rank && slot < 0) slot = (int)j; ++seen; }
+        }
+        d.dedupe[aux] = EMPTY64;
+        if (gi >= heapFree) atomicAdd(&d.stats[ST_DROPPED], 1u);                                           // heap exhausted
+        else {
+            ptr = (int32_t)(heapBlock * (uint32_t)VOX);
+            uint64_t* ar = reinterpret_cast<uint64_t*>(d.allocList + allocBase + gi);
+            storeThrough(ar, key); storeThrough(ar + 1, pack2((uint32_t)ptr, 0u));
+            if (slot >= 0) {
+                const i3 b = unpackKey(key);
+                uint64_t* e = reinterpret_cast<uint64_t*>(d.hash + ((size_t)bucket * BF_HASH_BUCKET_SIZE + (uint32_t)slot));
+                storeThrough(e, pack2((uint32_t)b.x, (uint32_t)b.y)); storeThrough(e + 1, pack2((uint32_t)b.z, (uint32_t)ptr));
+                storeThrough(e + 2, 0ull); storeThrough(e + 3, 0ull);
+                if (LISTS >= 0) { AllocRec ar2; ar2.key = key; ar2.ptr = ptr; ar2.pad = 0; keep = keepRec<(LISTS < 0 ? 0 : LISTS)>(f, fo, ar2); }
+            } else {                                                                                       // the tail walks the collision window (and puts the block on the list)
+                const uint32_t ov = atomicAdd(d.overflowCount, 1u);
+                if (ov < OVCAP) { uint64_t* o = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(o, key); storeThrough(o + 1, pack2(bucket, gi)); }
+                else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
+            }
+        }
     }
-    d.dedupe[aux] = EMPTY64;
-    if (gi >= heapFree) { atomicAdd(&d.stats[ST_DROPPED], 1u); return; }                               // heap exhausted
-    const int32_t ptr = (int32_t)(heapBlock * (uint32_t)VOX);
-    uint64_t* ar = reinterpret_cast<uint64_t*>(d.allocList + allocBase + gi);
-    storeThrough(ar, key); storeThrough(ar + 1, pack2((uint32_t)ptr, 0u));
-    if (slot >= 0) {
-        const i3 b = unpackKey(key);
-        uint64_t* e = reinterpret_cast<uint64_t*>(d.hash + ((size_t)bucket * BF_HASH_BUCKET_SIZE + (uint32_t)slot));
-        storeThrough(e, pack2((uint32_t)b.x, (uint32_t)b.y)); storeThrough(e + 1, pack2((uint32_t)b.z, (uint32_t)ptr));
-        storeThrough(e + 2, 0ull); storeThrough(e + 3, 0ull);
-    } else {
-        const uint32_t ov = atomicAdd(d.overflowCount, 1u);
-        if (ov < OVCAP) { uint64_t* o = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(o, key); storeThrough(o + 1, pack2(bucket, gi)); }
-        else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
-    }
+    if (LISTS >= 0) listAppendWave<(LISTS < 0 ? 0 : LISTS)>(d, keep, key, ptr, allocBase + gi);
 }
 
 // ---------------------------------------------------------------------------------------
 // alloc, pass C: single workgroup tail — bucket-full keys walk the collision window in
 // sorted order (VoxelUtilHashSDF.h:614-654), counters are committed, bins are recycled.
 // ---------------------------------------------------------------------------------------
-BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratch) {
+template <int LISTS>
+BF_DEV void placeTail(const Dev& d, const Frame& f, const Frame& fo, SortLds& s, uint32_t* scratch) {
     const uint32_t M = binPrefix(d.binCount, NBINS, scratch);
     const uint32_t nov = min(d.overflowCount[0], OVCAP);
     if (nov > 0) loadBinSorted(s, d.overflow, nov);
@@ -614,6 +713,15 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratc
                     d.hash[i].ptr = ptr;
                     d.hash[last].offset = (uint32_t)offset;
                     done = true;
+                    if (LISTS >= 0) {                                 // (one lane: bucket-full keys are a handful per operator at most)
+                        AllocRec r; r.key = s.key[k]; r.ptr = ptr; r.pad = 0;
+                        const uint32_t keep = keepRec<(LISTS < 0 ? 0 : LISTS)>(f, fo, r);
+                        if (keep) {
+                            const uint32_t pos = atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount), 1u);
+                            if (LISTS == 2) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, (keep & 1u) + ((keep >> 1) & 1u));
+                            listWrite(d, pos, r.key, ptr, LISTS == 2 ? keep : 0u, allocBase + gi);
+                        }
+                    }
                     break;
                 }
                 maxIter++;
@@ -628,7 +736,6 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratc
         d.heapCounter[0] = newCounter;
         d.allocCount[0] = allocBase + Mp;
         d.allocSnap[0] = allocBase + Mp;
-        d.compactCount[0] = 0; d.compactCount[1] = 0;          // the list pass (k_compact_append) appends to these
         if (dropped) atomicAdd(&d.stats[ST_DROPPED], dropped);
         d.overflowCount[0] = 0;
     }
@@ -653,12 +760,22 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, SortLds& s, uint32_t* scratc
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
 #error "k_alloc_place: the workgroup hand-off is written for gfx942 / gfx950"
 #endif
-__global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
+// LISTS >= 0 (round 4): the same launch also builds the operator's block list - frustum list (0) or union list of a fused re-integration (2).  The list is
+// {entries of the allocated-block list as it stood before this placement that pass the frustum test} + {the blocks placed now}: every workgroup, once its bin is
+// placed, filters its share of the old entries (nobody writes them during this launch) and appends them; every placed block is appended by the lane that placed it
+// (bucket-full keys by the tail).  The list's ORDER is not part of any result (the voxel update treats every block on its own, garbage collection bins and sorts
+// what it takes from the list; the reference's own compactify appends with atomicAdd, CUDASceneRepHashSDF.cu:324-366).  The preparation chain of an operator -
+// which paces the re-integration loop (profiles/r04_streams_and_queues.md section 3) - is then two launches: march, place + list.  The list counters are zeroed
+// by the march (or by the host in front of an exchanged march).
+template <int LISTS>
+__global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f, Frame fo) {
     __shared__ SortLds s;
     __shared__ uint32_t scratch[16];
     __shared__ int8_t sel[BINCAP];
     __shared__ uint32_t lastFlag;
     __shared__ uint32_t bigBin;
+    __shared__ uint32_t wscan[4];
+    __shared__ uint32_t sbase;
     __builtin_amdgcn_s_setprio(3);
     static_assert(PLACE_WGS == NBINS && NBINS == 256, "one workgroup per bin");
     // One workgroup per bin.  The usual bin holds a handful of new keys and is placed by the workgroup's first wave alone (registers only);
@@ -680,10 +797,12 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
         if (lane * 4 + 3 < bin) pre += min(c4.w, BINCAP);
         const uint32_t base = (uint32_t)wave_sum_i((int)pre);
         if (lane == 0) bigBin = n > 64 ? 1u : 0u;
-        if (n > 0 && n <= 64) placeBinWave(d, f, n, r, base, heapC, allocBase, lane);
+        if (n > 0 && n <= 64) placeBinWave<LISTS>(d, f, fo, n, r, base, heapC, allocBase, lane);
     }
     __syncthreads();
-    if (bigBin) placeBin(d, f, s, scratch, sel, bin);          // block-uniform
+    if (bigBin) placeBin<LISTS>(d, f, fo, s, scratch, sel, bin);          // block-uniform
+    // (one entry per thread: ~60 000 allocated blocks in the bench window are 230 tiles over the 256 workgroups; allocCount: the tail writes it after every workgroup has been here)
+    if (LISTS >= 0) listAppendTiles<(LISTS < 0 ? 0 : LISTS), 1>(d, f, fo, d.allocCount[0], blockIdx.x, gridDim.x, wscan, &sbase);
     // hand-off to the workgroup that arrives last: every wave drains its (write-through) stores, then one lane takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -694,39 +813,24 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f) {
     }
     __syncthreads();
     if (!lastFlag) return;
-    placeTail(d, f, s, scratch);
+    placeTail<LISTS>(d, f, fo, s, scratch);
     if (threadIdx.x == 0) d.stats[ST_TICKET] = 0;
 }
 
 // ---------------------------------------------------------------------------------------
-// ordered stream compaction over the allocated-block list (two passes, deterministic)
-//   MODE 0: frustum list (replaces compactifyHashAllInOneKernel, .cu:324-366)
-//   MODE 1: drop holes from the allocated list (after GC)
+// list maintenance after a garbage collection: ordered stream compaction of the allocated-block list (holes dropped, order kept; two passes, deterministic)
 // ---------------------------------------------------------------------------------------
-// MODE 0: blocks in the frustum of f;  MODE 1: every live block (list maintenance);  MODE 2: blocks in the frustum of f
-// (bit 0 of the result) or of fo (bit 1) — the union list of a fused re-integration
-template <int MODE>
-BF_DEV uint32_t keepRec(const Frame& f, const Frame& fo, const AllocRec& r) {
-    if (r.ptr == BF_FREE_ENTRY) return 0u;
-    if (MODE == 1) return 1u;
-    const i3 b = unpackKey(r.key);
-    if (MODE == 0) return blockInFrustum(f, b) ? 1u : 0u;
-    return (blockInFrustum(f, b) ? 1u : 0u) | (blockInFrustum(fo, b) ? 2u : 0u);
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f, Frame fo) {
+__global__ __launch_bounds__(256) void k_compact_count(Dev d) {
     __shared__ uint32_t wsum[4];
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t n = MODE == 1 ? d.allocCount[0] : d.allocSnap[0];
+    const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
-    if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) d.compactCount[1] = 0;      // the scatter pass (next launch) accumulates the operator blocks here
     for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
         uint32_t c = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
-            if (i < n) c += keepRec<MODE>(f, fo, d.allocList[i]) ? 1u : 0u;
+            if (i < n) c += d.allocList[i].ptr != BF_FREE_ENTRY ? 1u : 0u;
         }
         c = (uint32_t)wave_sum_i((int)c);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -736,18 +840,13 @@ __global__ __launch_bounds__(256) void k_compact_count(Dev d, Frame f, Frame fo)
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame fo) {
+__global__ __launch_bounds__(256) void k_compact_scatter(Dev d) {
     __shared__ uint32_t wsum[4];
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t wscan[4];
-    const uint32_t n = MODE == 1 ? d.allocCount[0] : d.allocSnap[0];
+    const uint32_t n = d.allocCount[0];
     const uint32_t numTiles = (n + TILE - 1) / TILE;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (numTiles == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { if (MODE != 1) d.compactCount[0] = 0; }
-        return;
-    }
     for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
         // exclusive prefix of the preceding tiles
         uint32_t v = 0;
@@ -758,13 +857,13 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame f
         const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
         AllocRec recs[4];
-        uint32_t keep[4];
+        bool keep[4];
         uint32_t c = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
-            keep[k] = 0u;
-            if (i < n) { recs[k] = d.allocList[i]; keep[k] = keepRec<MODE>(f, fo, recs[k]); }
+            keep[k] = false;
+            if (i < n) { recs[k] = d.allocList[i]; keep[k] = recs[k].ptr != BF_FREE_ENTRY; }
             c += keep[k] ? 1u : 0u;
         }
         // exclusive scan of c across the block: wave scan + wave totals
@@ -778,83 +877,20 @@ __global__ __launch_bounds__(256) void k_compact_scatter(Dev d, Frame f, Frame f
         const uint32_t tileTotal = wscan[0] + wscan[1] + wscan[2] + wscan[3];
         uint32_t pos = base + woff + incl - c;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (!keep[k]) continue;
-            if (MODE != 1) {
-                const i3 b = unpackKey(recs[k].key);
-                uint4* o4 = reinterpret_cast<uint4*>(d.compact + pos);
-                o4[0] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)recs[k].ptr);
-                o4[1] = make_uint4(MODE == 2 ? keep[k] : 0u, 0u, 0u, 0u);     // offset field doubles as the frustum flags of the union list
-                d.compactSrc[pos] = tile * TILE + threadIdx.x * 4 + k;
-            } else {
-                d.allocListAlt[pos] = recs[k];
-            }
-            ++pos;
-        }
-        if (MODE == 2) {           // blocks in the new pose's frustum + blocks in the old pose's: the two operators' list lengths (integer sum, order-free)
-            uint32_t ob = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) ob += (keep[k] & 1u) + ((keep[k] >> 1) & 1u);
-            ob = (uint32_t)wave_sum_i((int)ob);
-            if (lane == 0 && ob) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, ob);
-        }
-        if (tile == numTiles - 1 && threadIdx.x == 0) {
-            if (MODE != 1) d.compactCount[0] = (int32_t)(base + tileTotal);
-            else d.tileCounts[numTiles] = base + tileTotal;      // new list length, committed by k_list_commit
-        }
+        for (uint32_t k = 0; k < 4; ++k) if (keep[k]) d.allocListAlt[pos++] = recs[k];
+        if (tile == numTiles - 1 && threadIdx.x == 0) d.tileCounts[numTiles] = base + tileTotal;      // new list length, committed by k_list_commit
         __syncthreads();
     }
 }
 
-// The frustum (MODE 0) or union (MODE 2) list in ONE pass (round 4; the two-pass form above remains for the list maintenance after a garbage collection, MODE 1):
-// every workgroup filters its tile of the allocated-block list, reserves a contiguous range of the list with one atomic add and writes its keepers there - tile
-// ranges in arrival order, the order inside a tile kept.  The list's ORDER is not part of any result (the voxel update treats every block on its own, garbage
-// collection bins and sorts what it takes from the list; the reference's own compactify appends with atomicAdd, CUDASceneRepHashSDF.cu:324-366), and one launch
-// boundary less on the preparation chain - which paces the re-integration loop - is worth more than a reproducible order.  compactCount[0] / [1] are zeroed behind
-// the operator's allocation (k_alloc_place's tail / k_alloc_snapshot).
+// The frustum (MODE 0) or union (MODE 2) list of an operator that does not allocate (a de-integration, an operator behind an external allocation, the frustum
+// list after a fused re-integration): one pass over the allocated-block list up to the operator's snapshot.  compactCount[0] / [1] are zeroed by k_alloc_snapshot.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_compact_append(Dev d, Frame f, Frame fo) {
     __shared__ uint32_t wscan[4];
     __shared__ uint32_t sbase;
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t n = d.allocSnap[0];
-    const uint32_t numTiles = (n + TILE - 1) / TILE;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
-        AllocRec recs[4];
-        uint32_t keep[4];
-        uint32_t c = 0, ob = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t i = tile * TILE + threadIdx.x * 4 + k;
-            keep[k] = 0u;
-            if (i < n) { recs[k] = d.allocList[i]; keep[k] = keepRec<MODE>(f, fo, recs[k]); }
-            c += keep[k] ? 1u : 0u;
-            ob += (keep[k] & 1u) + ((keep[k] >> 1) & 1u);
-        }
-        uint32_t incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
-        if (lane == 63) wscan[wave] = incl;
-        if (MODE == 2) { ob = (uint32_t)wave_sum_i((int)ob); if (lane == 0 && ob) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, ob); }
-        __syncthreads();
-        if (threadIdx.x == 0) { const uint32_t tot = wscan[0] + wscan[1] + wscan[2] + wscan[3]; sbase = tot ? atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount), tot) : 0u; }
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; ++w) woff += wscan[w];
-        uint32_t pos = sbase + woff + incl - c;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (!keep[k]) continue;
-            const i3 b = unpackKey(recs[k].key);
-            uint4* o4 = reinterpret_cast<uint4*>(d.compact + pos);
-            o4[0] = make_uint4((uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)recs[k].ptr);
-            o4[1] = make_uint4(MODE == 2 ? keep[k] : 0u, 0u, 0u, 0u);     // offset field doubles as the frustum flags of the union list
-            d.compactSrc[pos] = tile * TILE + threadIdx.x * 4 + k;
-            ++pos;
-        }
-        __syncthreads();
-    }
+    listAppendTiles<MODE, 4>(d, f, fo, d.allocSnap[0], blockIdx.x, gridDim.x, wscan, &sbase);
 }
 
 __global__ void k_alloc_snapshot(Dev d) { d.allocSnap[0] = d.allocCount[0]; d.compactCount[0] = 0; d.compactCount[1] = 0; }      // an operator without an allocation of its own
@@ -1587,29 +1623,13 @@ struct bf_scene {
     // steady-state cycle: period = hop + (prep + update) / 2, profiles/r03_timeline_fast_before.txt: 50 us idle between consecutive updates.)
     static constexpr int NBMAX = 8;
     int NB = 4;                     // list buffers in use (BF_SCENE_LIST_BUFFERS, 2 .. NBMAX)
-    bool orderedLists = false;      // BF_SCENE_ORDERED_LISTS=1: the two-pass, order-preserving form of the frustum lists (until round 3; k_compact_count / k_compact_scatter)
-    bool splitPrep = false;         // BF_SCENE_SPLIT_PREP=1: the lists on their own stream (see `lists` below).  Off by default: the HIP runtime maps streams onto four
-                                    // hardware queues (GPU_MAX_HW_QUEUES) in creation order, the frame loop's four streams - allocation, bundling, volume, detection -
-                                    // take exactly those, and a fifth active stream shares a queue with one of them and serialises with it (measured, gpurun r04h - r04j:
-                                    // 710 frames/s with four streams, 440 - 530 with five to seven, whatever GPU_MAX_HW_QUEUES says)
     bf_hash_entry* cbuf[NBMAX] = {}; uint32_t* csrc[NBMAX] = {}; int32_t* ccnt[NBMAX] = {};
     int cur = 0;                    // buffer that holds the latest list (== d.compact / d.compactSrc / d.compactCount)
     hipEvent_t evPrep[NBMAX] = {}, evUpd[NBMAX] = {}, evBarrier = nullptr, evTmp = nullptr;
-    // Round 4 experiment (BF_SCENE_SPLIT_PREP=1): the preparation of an operator on TWO streams.  The kernel trace of the frame loop (profiles/r04_timeline_before.txt) showed the voxel
-    // updates 61 us long and 79 us apart: every operator's update waited for its own preparation - allocation march, placement, two compaction passes and the
-    // texel interleave, 83 us of kernels and five launch boundaries of 12-17 us each next to the update's resident waves, about 140 us in sequence - so the
-    // preparation stream, not the update, paced the loop (10 fused operators x 140 us = the 1.4 ms frame).  With the split `prep` carries the allocation only and `lists`
-    // the texel interleave (it depends on the frame alone) followed by the two compaction passes of the operator whose allocation has finished (they read the
-    // allocated-block list up to that operator's snapshot): allocation n + 1 runs beside lists n beside update n - 1.  (A third stream for the interleave
-    // alone was one HIP stream too many: the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues - four by default - and streams that share a
-    // queue serialise; the frame loop already owns a detect, a bundling, an ingest and a volume stream.  gpurun r04e: 270 frames/s with eleven streams.)
-    hipStream_t lists = nullptr;
-    hipEvent_t evAlloc[NBMAX] = {};
     bool updRecorded[NBMAX] = {};
-    bool barrierPending[2] = {false, false};       // per preparation stream (prep, lists): the last exclusive section has not been waited for yet
+    bool barrierPending = false;    // the last exclusive section of the main stream has not been waited for by the preparation stream yet
     hipEvent_t pendingEv = nullptr; // bf_scene_wait_event: the next operator's first kernel waits for it
     const uint2* frameTexels = nullptr;   // bf_scene_set_frame_texels: the next operator's frame as interleaved texels, made once when the frame was ingested
-    hipEvent_t frameEv = nullptr;   // ... and so does its texel interleave, on its own stream (set when pendingEv is consumed, cleared by the operator)
     bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
     // optional HIP-event timing of the voxel-update kernel
     bool timing = false;
@@ -1739,20 +1759,18 @@ void useBuf(bf_scene* s, int b) { s->cur = b; s->d.compact = s->cbuf[b]; s->d.co
 // exclusive section on the main stream: everything issued on `prep` so far happens before, everything issued on `prep` later after
 int beginExclusive(bf_scene* s) {
     if (!s->overlap) return BF_OK;
-    for (hipStream_t st : {s->prep, s->lists}) {
-        BF_HIP_TRY(hipEventRecord(s->evTmp, st));
-        BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTmp, 0));
-    }
+    BF_HIP_TRY(hipEventRecord(s->evTmp, s->prep));
+    BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evTmp, 0));
     return BF_OK;
 }
 int endExclusive(bf_scene* s) {
     if (!s->overlap) return BF_OK;
     BF_HIP_TRY(hipEventRecord(s->evBarrier, s->stream));
-    for (bool& b : s->barrierPending) b = true;
+    s->barrierPending = true;
     return BF_OK;
 }
 int syncAll(bf_scene* s) {
-    for (hipStream_t st : {s->prep, s->lists}) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
+    if (s->prep) BF_HIP_TRY(hipStreamSynchronize(s->prep));
     BF_HIP_TRY(hipStreamSynchronize(s->stream));
     return BF_OK;
 }
@@ -1760,10 +1778,7 @@ int syncAll(bf_scene* s) {
 int launchCompactify(bf_scene* s) {                              // compactifyHashEntries :355-391 (main stream, current buffer)
     const Frame f = makeFrame(s);
     hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, s->stream, s->d);
-    if (s->orderedLists) {
-        hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
-        hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
-    } else hipLaunchKernelGGL(k_compact_append<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
+    hipLaunchKernelGGL(k_compact_append<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     BF_HIP_TRY(hipGetLastError());
     s->compactStale = false;
     return BF_OK;
@@ -1775,7 +1790,9 @@ int refreshStaleList(bf_scene* s) {                              // a fused re-i
     return endExclusive(s);
 }
 
-int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, const float* d_depth, TexelOut tx) {      // alloc :328-352 (dv: the operator's view - its snapshot slot)
+// alloc :328-352 (dv: the operator's view - its list buffer and snapshot slot) and, in the same launch as the placement, the operator's block list:
+// frustum list of f (fused == false) or union list of f and fo
+int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, const Frame& fo, bool fused, const float* d_depth, TexelOut tx) {
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
     if (s->allocComm) {
         // the march divided over the ranks: rank r marches the tiles [r T / G, (r + 1) T / G) and collects the distinct in-frustum keys it
@@ -1789,6 +1806,7 @@ int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, co
         c.keys = reinterpret_cast<unsigned long long*>(s->d_allocSend + 8); c.slots = s->d_allocSlots; c.count = cnt; c.capacity = s->allocCap;
         c.tile0 = (uint32_t)((uint64_t)tiles * rank / world); c.tile1 = (uint32_t)((uint64_t)tiles * (rank + 1) / world);
         BF_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
+        BF_HIP_TRY(hipMemsetAsync(dv.compactCount, 0, 8, st));      // the operator's list counters (the local march zeroes them itself)
         if (c.tile1 > c.tile0) hipLaunchKernelGGL(k_alloc_candidates<true>, dim3(div_up(c.tile1 - c.tile0, 4)), dim3(256), 0, st, dv, f, d_depth, c, TexelOut{nullptr, nullptr});
         hipLaunchKernelGGL(k_collect_release, dim3(std::min<uint32_t>(div_up(s->allocCap, 256u), 2048u)), dim3(256), 0, st, dv, c);
         BF_TRY_RC(bf_comm_all_gather(s->allocComm, s->d_allocSend, s->d_allocRecv, rec, st));
@@ -1799,7 +1817,8 @@ int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, co
         }
     } else
     hipLaunchKernelGGL(k_alloc_candidates<false>, dim3(div_up(tiles, 4)), dim3(256), 0, st, dv, f, d_depth, Collect{}, tx);
-    hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, dv, f);
+    if (fused) hipLaunchKernelGGL(k_alloc_place<2>, dim3(PLACE_WGS), dim3(256), 0, st, dv, f, fo);
+    else hipLaunchKernelGGL(k_alloc_place<0>, dim3(PLACE_WGS), dim3(256), 0, st, dv, f, f);
     return BF_OK;
 }
 
@@ -1808,20 +1827,20 @@ int launchAllocOn(bf_scene* s, hipStream_t st, const Dev& dv, const Frame& f, co
 // whoever touches the prep stream first - runOperator, or bf_scene_alloc_collect / _ingest / _place when the caller allocates itself - waits, and
 // everything issued on that stream afterwards is ordered behind it.
 int prepWaits(bf_scene* s, hipStream_t ps) {
-    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->frameEv = s->pendingEv; s->pendingEv = nullptr; }
-    if (s->overlap && s->barrierPending[0]) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending[0] = false; }
+    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->pendingEv = nullptr; }
+    if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
     return BF_OK;
 }
 
-// One operator = [allocation] -> frustum list -> voxel update.  kind 0 integrate(f), 1 de-integrate(f), 2 fused: de-integrate(fo) +
-// integrate(f).  With overlap enabled the first two phases go to the prep stream and only the update to the main stream.
+// One operator = preparation (allocation + block list) -> voxel update.  kind 0 integrate(f), 1 de-integrate(f), 2 fused: de-integrate(fo) +
+// integrate(f).  With overlap enabled the preparation goes to the prep stream and only the update to the main stream.  The preparation of an operator that
+// allocates is two launches - the march (which also writes the frame's texels for the fast contract) and the placement, which builds the list on the way;
+// an operator that does not allocate takes its snapshot and filters the allocated-block list.
 int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf_depth_camera_data* data) {
     const int b = s->overlap ? (s->cur + 1) % s->NB : s->cur;
-    hipStream_t ps = s->overlap ? s->prep : s->stream, ls = s->overlap ? (s->splitPrep ? s->lists : s->prep) : s->stream;
+    hipStream_t ps = s->overlap ? s->prep : s->stream;
     const bool useTexel = s->arith == BF_TSDF_ARITH_FAST && data->d_colorData != nullptr;
-    BF_TRY_RC(prepWaits(s, ps));
-    const hipEvent_t frameEv = s->frameEv;          // the frame's ingest (bf_scene_wait_event); an external allocation may have consumed it for `prep` already
-    s->frameEv = nullptr;
+    BF_TRY_RC(prepWaits(s, ps));                   // incl. the frame's ingest (bf_scene_wait_event)
     const Dev dv = devBuf(s, b);
     const uint2* opTexels = s->frameTexels;        // the caller's per-frame texel image (consumed by this operator), or the one made here
     s->frameTexels = nullptr;
@@ -1831,43 +1850,26 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         for (int k = 0; k < bf_scene::NBMAX; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
         s->texelPixels = npx;
     }
-    // ---- allocation (prep).  It writes the operator's snapshot into buffer b's counters (and, fast contract, the frame's texels into texel buffer b): not before the
-    // update that used buffer b NB operators ago has finished - which also keeps the allocation at most NB operators ahead of the updates
+    // The preparation writes the operator's snapshot and list into buffer b (and, fast contract, the frame's texels into texel buffer b): not before the update
+    // that used buffer b NB operators ago has finished - which also keeps the preparation at most NB operators ahead of the updates
     if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));
     const bool marches = kind != 1 && !s->externalAlloc;                       // de-integration neither allocates nor frees
     const bool texelsFromMarch = marches && !s->allocComm && useTexel && !opTexels;      // (the divided march covers a band of the image only)
+    if (useTexel && !opTexels && !texelsFromMarch) {
+        hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ps, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
+        opTexels = s->texel[b];
+    }
     if (marches) {
         TexelOut tx{nullptr, nullptr};
         if (texelsFromMarch) { tx.color = reinterpret_cast<const uint32_t*>(data->d_colorData); tx.texel = s->texel[b]; opTexels = s->texel[b]; }
-        BF_TRY_RC(launchAllocOn(s, ps, dv, f, data->d_depthData, tx));
-    } else hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, ps, dv);
-    // ---- lists stream (the allocation stream itself unless BF_SCENE_SPLIT_PREP=1): the texel interleave where the march did not make the texels ...
+        BF_TRY_RC(launchAllocOn(s, ps, dv, f, fo, kind == 2, data->d_depthData, tx));
+    } else {
+        hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, ps, dv);
+        if (kind == 2) hipLaunchKernelGGL(k_compact_append<2>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, fo);
+        else hipLaunchKernelGGL(k_compact_append<0>, dim3(s->gridCompact), dim3(256), 0, ps, dv, f, f);
+    }
     if (s->overlap) {
-        if (s->barrierPending[1]) { BF_HIP_TRY(hipStreamWaitEvent(ls, s->evBarrier, 0)); s->barrierPending[1] = false; }
-        if (s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ls, s->evUpd[b], 0));      // the update that read list buffer b / texel buffer b NB operators ago
-    }
-    if (useTexel && !opTexels) {
-        if (s->overlap && frameEv) BF_HIP_TRY(hipStreamWaitEvent(ls, frameEv, 0));
-        hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ls, data->d_depthData, reinterpret_cast<const uint32_t*>(data->d_colorData), s->texel[b], (uint32_t)npx);
-        opTexels = s->texel[b];
-    }
-    // ---- ... then the frustum (or union) list: reads the allocated-block list up to this operator's snapshot, writes list buffer b
-    if (s->overlap && ls != ps) {
-        BF_HIP_TRY(hipEventRecord(s->evAlloc[b], ps));
-        BF_HIP_TRY(hipStreamWaitEvent(ls, s->evAlloc[b], 0));
-    }
-    if (s->orderedLists) {
-        if (kind == 2) {
-            hipLaunchKernelGGL(k_compact_count<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
-            hipLaunchKernelGGL(k_compact_scatter<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
-        } else {
-            hipLaunchKernelGGL(k_compact_count<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
-            hipLaunchKernelGGL(k_compact_scatter<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
-        }
-    } else if (kind == 2) hipLaunchKernelGGL(k_compact_append<2>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, fo);
-    else hipLaunchKernelGGL(k_compact_append<0>, dim3(s->gridCompact), dim3(256), 0, ls, dv, f, f);
-    if (s->overlap) {
-        BF_HIP_TRY(hipEventRecord(s->evPrep[b], ls));
+        BF_HIP_TRY(hipEventRecord(s->evPrep[b], ps));
         BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
     }
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -1966,7 +1968,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
         BF_HIP_TRY(hipStreamCreateWithPriority(&s->prep, hipStreamNonBlocking, greatest));
     }
     for (int b = 0; b < bf_scene::NBMAX; ++b)
-        for (hipEvent_t* e : {&s->evPrep[b], &s->evUpd[b], &s->evAlloc[b]}) BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&s->evPrep[b], &s->evUpd[b]}) BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&s->evBarrier, &s->evTmp})
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
@@ -1975,13 +1977,6 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     if (const char* e = getenv("BF_APX_DEFER")) s->apxDefer = atoi(e) != 0;
     if (const char* e = getenv("BF_SCENE_LIST_BUFFERS")) s->NB = std::min(std::max(atoi(e), 2), (int)bf_scene::NBMAX);
-    if (const char* e = getenv("BF_SCENE_SPLIT_PREP")) s->splitPrep = atoi(e) != 0;
-    if (const char* e = getenv("BF_SCENE_ORDERED_LISTS")) s->orderedLists = atoi(e) != 0;
-    if (s->splitPrep) {
-        int least = 0, greatest = 0;
-        BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        BF_HIP_TRY(hipStreamCreateWithPriority(&s->lists, hipStreamNonBlocking, greatest));
-    }
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
@@ -2038,7 +2033,7 @@ int bf_scene_alloc_place(bf_scene* s) {
     const Frame f = makeFrame(s);
     hipStream_t st = s->overlap ? s->prep : s->stream;
     BF_TRY_RC(prepWaits(s, st));
-    hipLaunchKernelGGL(k_alloc_place, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f);
+    hipLaunchKernelGGL(k_alloc_place<-1>, dim3(PLACE_WGS), dim3(256), 0, st, s->d, f, f);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -2098,9 +2093,9 @@ int bf_scene_destroy(bf_scene* s) {
     if (s->d_allocRecv) hipFree(s->d_allocRecv);
     if (s->d_allocSlots) hipFree(s->d_allocSlots);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (int b = 0; b < bf_scene::NBMAX; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b], s->evAlloc[b]}) if (e) hipEventDestroy(e);
+    for (int b = 0; b < bf_scene::NBMAX; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b]}) if (e) hipEventDestroy(e);
     for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
-    for (hipStream_t st : {s->prep, s->lists}) if (st) hipStreamDestroy(st);
+    if (s->prep) hipStreamDestroy(s->prep);
     delete s;
     return BF_OK;
 }
@@ -2117,7 +2112,7 @@ int bf_scene_set_overlap(bf_scene* s, int enable) {
     BF_TRY_RC(syncAll(s));
     s->overlap = enable != 0;
     for (bool& u : s->updRecorded) u = false;
-    for (bool& bp : s->barrierPending) bp = false;
+    s->barrierPending = false;
     return BF_OK;
 }
 
@@ -2152,7 +2147,7 @@ int bf_scene_reset(bf_scene* s) {                                  // CUDASceneR
     memcpy(s->params.m_rigidTransformInverse, I.e, 64);
     s->params.m_numOccupiedBlocks = 0;
     BF_TRY_RC(syncAll(s));
-    s->compactStale = false; for (bool& bp : s->barrierPending) bp = false; s->pendingEv = nullptr; s->frameEv = nullptr;
+    s->compactStale = false; s->barrierPending = false; s->pendingEv = nullptr;
     for (bool& u : s->updRecorded) u = false;
     for (int b = 0; b < bf_scene::NBMAX; ++b) BF_HIP_TRY(hipMemsetAsync(s->ccnt[b], 0, 16, s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
@@ -2233,8 +2228,8 @@ int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
     hipLaunchKernelGGL(k_gc_identify, dim3(4096), dim3(256), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_delete, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_finish, dim3(1), dim3(256), 0, s->stream, s->d);
-    hipLaunchKernelGGL(k_compact_count<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
-    hipLaunchKernelGGL(k_compact_scatter<1>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
+    hipLaunchKernelGGL(k_compact_count, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d);
     hipLaunchKernelGGL(k_list_commit, dim3(1), dim3(1), 0, s->stream, s->d);
     std::swap(s->d.allocList, s->d.allocListAlt);
     BF_HIP_TRY(hipGetLastError());

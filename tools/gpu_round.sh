@@ -40,7 +40,8 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
       D=$(db /tmp/r_trace)
       rm -f "$OUT/kernel_stats.md"
       python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" --exclude "Cijk_,at::native" | head -14
-      python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 "Cijk_,at::native" > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt" ;;
+      python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 "Cijk_,at::native" > "$OUT/timeline.txt" 2>&1; tail -1 "$OUT/timeline.txt"
+      python "$ROOT/tools/rocpd_timeline.py" "$D" 0.8 "Cijk_,at::native" --dump ${DUMP_MS:-4} --dump-end ${DUMP_END_MS:-6} > "$OUT/timeline_window.txt" 2>&1; wc -l "$OUT/timeline_window.txt" ;;
     pmc)   # HBM traffic of the voxel update in the bench configuration, per arithmetic contract: two passes (FETCH_SIZE, WRITE_SIZE), then bytes per visited block
       for A in ${PMC_CONTRACTS:-fast exact}; do
         for C in FETCH_SIZE WRITE_SIZE; do

@@ -1,10 +1,19 @@
 #!/usr/bin/env python3
-"""Per-queue busy time / overlap / idle gaps from a rocprofv3 kernel-trace rocpd database.  usage: rocpd_timeline.py <db> [last_fraction]"""
+"""Per-queue busy time / overlap / idle gaps from a rocprofv3 kernel-trace rocpd database.
+usage: rocpd_timeline.py <db> [last_fraction] [exclude,names] [--dump MS [--dump-end MS_BEFORE_END]]
+--dump MS: instead of the summary, list every kernel of a MS-millisecond window (start relative to the window, duration, queue, name) - the window ends
+MS_BEFORE_END milliseconds before the last kernel (default 3: past the teardown of the run, inside the timed frames)."""
 import sqlite3
 import sys
 
 
 def main():
+    dump = dump_end = None
+    if "--dump" in sys.argv:
+        i = sys.argv.index("--dump"); dump = float(sys.argv[i + 1]); del sys.argv[i:i + 2]
+        dump_end = 3.0
+        if "--dump-end" in sys.argv:
+            i = sys.argv.index("--dump-end"); dump_end = float(sys.argv[i + 1]); del sys.argv[i:i + 2]
     db = sys.argv[1]
     frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
     c = sqlite3.connect(db)
@@ -14,6 +23,14 @@ def main():
     excl = [e for e in (sys.argv[3].split(",") if len(sys.argv) > 3 else []) if e]      # e.g. "Cijk_,at::native": bench.py's untimed clock warm-up
     rows = [r for r in rows if not any(e in r[2] for e in excl)]
     t0, t1 = rows[0][0], rows[-1][1]
+    if dump is not None:
+        hi = t1 - dump_end * 1e6; lo = hi - dump * 1e6
+        qs = {}
+        for s, e, n, q in rows:
+            if e >= lo and s <= hi:
+                short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
+                print("%9.1f us  %7.1f us  q%-2s %s" % ((s - lo) / 1e3, (e - s) / 1e3, qs.setdefault(q, len(qs)), short))
+        return
     lo = t1 - (t1 - t0) * frac                      # analyse the steady-state tail
     rows = [r for r in rows if r[0] >= lo]
     span = (rows[-1][1] - rows[0][0]) / 1e6
