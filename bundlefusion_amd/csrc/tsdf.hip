@@ -801,8 +801,13 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f, Frame fo) {
     }
     __syncthreads();
     if (bigBin) placeBin<LISTS>(d, f, fo, s, scratch, sel, bin);          // block-uniform
-    // (one entry per thread: ~60 000 allocated blocks in the bench window are 230 tiles over the 256 workgroups; allocCount: the tail writes it after every workgroup has been here)
-    if (LISTS >= 0) listAppendTiles<(LISTS < 0 ? 0 : LISTS), 1>(d, f, fo, d.allocCount[0], blockIdx.x, gridDim.x, wscan, &sbase);
+    // (allocCount: the tail writes it after every workgroup has been here.  One entry per thread while that gives every workgroup at most one tile - the ~60 000 allocated
+    // blocks of the bench window are 230 tiles over the 256 workgroups - and four per thread beyond: 262 000 blocks of the 5000-frame stream are one tile per workgroup again)
+    if (LISTS >= 0) {
+        const uint32_t nOld = d.allocCount[0];
+        if (nOld <= gridDim.x * 256u) listAppendTiles<(LISTS < 0 ? 0 : LISTS), 1>(d, f, fo, nOld, blockIdx.x, gridDim.x, wscan, &sbase);
+        else listAppendTiles<(LISTS < 0 ? 0 : LISTS), 4>(d, f, fo, nOld, blockIdx.x, gridDim.x, wscan, &sbase);
+    }
     // hand-off to the workgroup that arrives last: every wave drains its (write-through) stores, then one lane takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

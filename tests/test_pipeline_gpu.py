@@ -162,6 +162,39 @@ def test_lagged_solve_mode_vs_oracle_loop_with_the_same_lag(gpu, oracle, lag):
     assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["free_and_allocated"] == 0
 
 
+@pytest.mark.gpu
+def test_frame_loop_depths_give_identical_results(gpu, monkeypatch):
+    """BF_PIPELINE_DEPTH = 2, 3, 4 (frames the loop may be behind its input): the schedule of every operation is the serial one, so trajectories, counters, hash table,
+    heap and every voxel byte are the same bit for bit (33 frames: three chunks, three global solves, re-integrations)."""
+    import torch
+    frames = synth.render_frames(range(33))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    dev = [(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()) for d, c, _, _ in frames]
+
+    def run(depth):
+        monkeypatch.setenv("BF_PIPELINE_DEPTH", str(depth))
+        gas, gbs = _params()
+        gp = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+        for d, c in dev:
+            assert gp.process_frame(d, c)
+        for _ in range(4):
+            gp.process_end_of_sequence()
+        gp.synchronize()
+        h, heap, cnt, vox = gp.scene().download()
+        return gp.integrated_trajectory(), gp.optimized_trajectory(), gp.counters(), h, heap, cnt, vox
+
+    ref = run(2)
+    assert ref[2]["deintegrate"] > 20 and ref[2]["global_solves"] >= 3
+    for depth in (3, 4):
+        got = run(depth)
+        assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)), depth
+        assert got[2] == ref[2], depth
+        assert np.array_equal(got[3]["pos"], ref[3]["pos"]) and np.array_equal(got[3]["ptr"], ref[3]["ptr"]) and got[5] == ref[5], depth
+        assert np.array_equal(got[4][:got[5] + 1], ref[4][:ref[5] + 1]), depth
+        assert np.array_equal(got[6].view(np.uint8), ref[6].view(np.uint8)), depth
+
+
 def _run_both(gpu, frames, K, tail=4, **kw):
     import torch
     from tests.oracle_pipeline import OraclePipeline

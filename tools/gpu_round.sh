@@ -19,6 +19,8 @@ for step in $STEPS; do
     tests)      # the whole GPU suite; the captured output of passed tests (the fast-contract reports, the reference-fixture comparison) is kept
       (cd "$ROOT" && timeout 1100 python -m pytest tests -q -m gpu --durations=12 -rP > "$OUT/pytest_gpu_full.txt" 2>&1; tail -22 "$OUT/pytest_gpu_full.txt" | tee "$OUT/pytest_gpu.txt"
        grep -E "vs ORACLE|vs the REFERENCE|fast contract|noisy stream|frame loop, fast|^N = |integrations /" "$OUT/pytest_gpu_full.txt" | cut -c1-900 > "$OUT/test_reports.txt") ;;
+    tests_sel)  # a selection of the GPU suite: TESTS="tests/test_tsdf_gpu.py tests/test_pipeline_gpu.py"
+      (cd "$ROOT" && timeout 900 python -m pytest ${TESTS:-tests/test_tsdf_gpu.py tests/test_tsdf_fast_gpu.py tests/test_pipeline_gpu.py} -q -m gpu --durations=5 2>&1 | tail -12 | tee "$OUT/pytest_sel.txt") ;;
     smoke)
       (cd "$ROOT" && timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee "$OUT/smoke.txt") ;;
     long)       # BASELINE configs[2] (2000-frame loop closure) and configs[3] (5000 frames) at full length through bench.py's long_stream block

@@ -2,7 +2,7 @@
 """Per-queue busy time / overlap / idle gaps from a rocprofv3 kernel-trace rocpd database.
 usage: rocpd_timeline.py <db> [last_fraction] [exclude,names] [--dump MS [--dump-end MS_BEFORE_END]]
 --dump MS: instead of the summary, list every kernel of a MS-millisecond window (start relative to the window, duration, queue, name) - the window ends
-MS_BEFORE_END milliseconds before the last kernel (default 3: past the teardown of the run, inside the timed frames)."""
+MS_BEFORE_END milliseconds before the end of the last voxel-update kernel (the last kernel of the run if there is none)."""
 import sqlite3
 import sys
 
@@ -24,7 +24,8 @@ def main():
     rows = [r for r in rows if not any(e in r[2] for e in excl)]
     t0, t1 = rows[0][0], rows[-1][1]
     if dump is not None:
-        hi = t1 - dump_end * 1e6; lo = hi - dump * 1e6
+        upd = [e for _, e, n, _ in rows if "k_update" in n]       # the frame loop ends with its last voxel update (teardown work may follow much later)
+        hi = (upd[-1] if upd else t1) - dump_end * 1e6; lo = hi - dump * 1e6
         qs = {}
         for s, e, n, q in rows:
             if e >= lo and s <= hi:

@@ -156,7 +156,7 @@ def run(a, rank=0, world=1):
             cur[k] = tgt[k]
     sync()
     t_sweep = time.perf_counter() - t0
-    occ_sum, n_ops = sc.kernel_timing_occupied()
+    occ_sum, vis_plain, vis_fused, n_ops = sc.kernel_timing_blocks()
     n_launch, kernel_ms = sc.kernel_timing_read()
     sc.kernel_timing(False)
     if world > 1:
@@ -167,7 +167,9 @@ def run(a, rank=0, world=1):
     if comm is not None:
         sc.set_alloc_comm(None)
     n_re = a.sweeps * a.frames
-    alg_bytes = occ_sum * (512 * 24 + 32) + n_ops * W * H * 8          # SURVEY.md §8d, per rank (its shard of the lists)
+    # SURVEY.md §8d, per rank (its shard of the lists).  The bytes a launch MOVES: a fused launch walks the union list of its two poses once (bench.py's accounting)
+    alg_bytes = (vis_plain + vis_fused) * (512 * 24 + 32) + n_launch * W * H * 8
+    op_bytes = occ_sum * (512 * 24 + 32) + n_ops * W * H * 8           # per OPERATOR (a fused launch = two operators' B_op): what two separate operators would move
     return ({
             "workload": "%d frames %dx%d @%.0f mm, %d re-integration sweeps (%s), %d rank(s)" %
                         (a.frames, W, H, a.voxel * 1e3, a.sweeps, "separate operators" if a.separate else "fused operator", world),
@@ -177,8 +179,9 @@ def run(a, rank=0, world=1):
             "update_kernel_us_per_launch": 1e3 * kernel_ms / max(n_launch, 1),
             "update_kernel_share_of_wall": (kernel_ms / 1e3) / t_sweep,
             "n_occ_mean_per_op": occ_sum / max(n_ops, 1),
-            "algorithmic_GBps_of_update_kernel_rank0": alg_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else None,
+            "algorithmic_GBps_of_update_kernel_rank0": alg_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else None,      # union accounting: bytes the launches move
             "algorithmic_GBps_wall_rank0": alg_bytes / t_sweep / 1e9,
+            "operator_equivalent_GBps_of_update_kernel_rank0": op_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else None,  # two separate operators' bytes per fused launch (may exceed the HBM peak: the fused launch moves the union once)
             "blocks_allocated_rank0": dbg["occupied"], "dropped": dbg["dropped"],
             "allocation": "march divided over the ranks inside the operators (RCCL all-gather of block keys per operator)" if comm is not None else
                           ("march divided over the ranks, exchange through torch.distributed" if a.shard_alloc else "every rank marches all pixels"),
