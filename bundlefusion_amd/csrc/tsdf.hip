@@ -494,6 +494,23 @@ BF_DEV void listAppendWave(const Dev& d, uint32_t keep, uint64_t key, int32_t pt
     if (keep) listWrite(d, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), key, ptr, MODE == 2 ? keep : 0u, src);
 }
 
+// every thread of the (converged) 256-thread workgroup calls this with at most one block: one reservation per workgroup, the order inside the workgroup kept
+template <int MODE>
+BF_DEV void listAppendBlock(const Dev& d, uint32_t keep, uint64_t key, int32_t ptr, uint32_t src, uint32_t* wscan, uint32_t* sbase) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(keep != 0u);
+    const uint32_t c = (uint32_t)__popcll(m);
+    if (lane == 0) wscan[wave] = c;
+    if (MODE == 2) { const uint32_t ob = (uint32_t)wave_sum_i((int)((keep & 1u) + ((keep >> 1) & 1u))); if (lane == 0 && ob) atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount) + 1, ob); }
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t tot = wscan[0] + wscan[1] + wscan[2] + wscan[3]; *sbase = tot ? atomicAdd(reinterpret_cast<uint32_t*>(d.compactCount), tot) : 0u; }
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < wave; ++w) woff += wscan[w];
+    if (keep) listWrite(d, *sbase + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), key, ptr, MODE == 2 ? keep : 0u, src);
+    __syncthreads();
+}
+
 // One pass over the tiles tile0, tile0 + tileStep, ... of the allocated-block list's first n entries (a tile = K entries per thread of the workgroup): every
 // workgroup filters its tile, reserves a contiguous range of the list with one atomic add and writes its keepers there - tile ranges in arrival order, the
 // order inside a tile kept.
@@ -679,14 +696,13 @@ BF_DEV void placeBinWave(const Dev& d, const Frame& f, const Frame& fo, uint32_t
 // alloc, pass C: single workgroup tail — bucket-full keys walk the collision window in
 // sorted order (VoxelUtilHashSDF.h:614-654), counters are committed, bins are recycled.
 // ---------------------------------------------------------------------------------------
+// M (keys queued in all bins), heapC, allocBase and stuckAll are inputs of the launch that every workgroup read in its first round trip (nothing changes them before
+// this point); the only thing the tail has to fetch is what the other workgroups produced: the number of bucket-full keys.
 template <int LISTS>
-BF_DEV void placeTail(const Dev& d, const Frame& f, const Frame& fo, SortLds& s, uint32_t* scratch) {
-    const uint32_t M = binPrefix(d.binCount, NBINS, scratch);
+BF_DEV void placeTail(const Dev& d, const Frame& f, const Frame& fo, SortLds& s, uint32_t M, uint32_t heapC, uint32_t allocBase, uint32_t stuckAll) {
     const uint32_t nov = min(d.overflowCount[0], OVCAP);
     if (nov > 0) loadBinSorted(s, d.overflow, nov);
     if (threadIdx.x == 0) {
-        const uint32_t heapC = d.heapCounter[0];
-        const uint32_t allocBase = d.allocCount[0];
         const uint32_t listRoom = f.numSDFBlocks - min(allocBase, f.numSDFBlocks);
         const uint32_t heapFree = min(heapC + 1u, listRoom);          // the same limit placeBin applied
         if (M > listRoom && listRoom < heapC + 1u) atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_LIST_FULL);
@@ -743,13 +759,11 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, const Frame& fo, SortLds& s,
     {   // keys that found their bin full: release their de-dup slots now that nobody probes any more.  Only the first OVCAP of them
         // were recorded; beyond that (ERR_BIN_OVERFLOW is set anyway) the whole set is cleared - at this point every slot of the set
         // belongs to a key that has been placed or dropped, so "empty everywhere" is its correct state.
-        const uint32_t stuckAll = d.stats[ST_STUCK];
         const uint32_t stuck = min(stuckAll, OVCAP);
         for (uint32_t q = threadIdx.x; q < stuck; q += blockDim.x) d.dedupe[d.stuckSlots[q]] = EMPTY64;
         if (stuckAll > OVCAP)
             for (uint32_t i = threadIdx.x; i <= d.dedupeMask; i += blockDim.x) d.dedupe[i] = EMPTY64;
-        __syncthreads();
-        if (threadIdx.x == 0) d.stats[ST_STUCK] = 0;
+        if (stuckAll) { __syncthreads(); if (threadIdx.x == 0) d.stats[ST_STUCK] = 0; }      // block-uniform
     }
     for (uint32_t b = threadIdx.x; b < NBINS; b += blockDim.x) d.binCount[b] = 0;
 }
@@ -776,8 +790,17 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f, Frame fo) {
     __shared__ uint32_t bigBin;
     __shared__ uint32_t wscan[4];
     __shared__ uint32_t sbase;
+    __shared__ uint32_t tailIn[4];      // M, heapC, allocBase, stuck keys: the launch's inputs the tail needs (read in the first round trip)
     __builtin_amdgcn_s_setprio(3);
     static_assert(PLACE_WGS == NBINS && NBINS == 256, "one workgroup per bin");
+    // The kernel is a chain of dependent memory round trips, each 3-6 us next to the voxel update of the previous operator (profiles/r04_pipeline_timeline_window.txt:
+    // 50-65 us per launch in the saturated window); everything that does not depend on another workgroup is therefore requested in the FIRST one - the bin, the
+    // counters, and the workgroup's tile of the allocated-block list for the list pass below.
+    constexpr int LM = LISTS < 0 ? 0 : LISTS;
+    AllocRec rec0; rec0.key = 0; rec0.ptr = BF_FREE_ENTRY; rec0.pad = 0;
+    uint32_t nOld = 0;
+    const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+    if (LISTS >= 0) { nOld = d.allocCount[0]; if (i0 < f.numSDFBlocks) rec0 = d.allocList[i0]; }
     // One workgroup per bin.  The usual bin holds a handful of new keys and is placed by the workgroup's first wave alone (registers only);
     // a bin with more than 64 keys - first frames of a scan, fast motion, every operator of a 2 mm sweep - is sorted by the whole workgroup
     // in LDS.  (Round 2 gave each of 64 workgroups four bins and walked its big bins one after the other: 409 us per operator on the
@@ -788,25 +811,26 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f, Frame fo) {
         const uint32_t nRaw = d.binCount[bin];
         const uint4 c4 = reinterpret_cast<const uint4*>(d.binCount)[lane];
         const BinRec r = d.bins[(size_t)bin * BINCAP + lane];
-        const uint32_t heapC = d.heapCounter[0], allocBase = d.allocCount[0];
+        const uint32_t heapC = d.heapCounter[0], allocBase = d.allocCount[0], stuckAll = d.stats[ST_STUCK];
         const uint32_t n = min(nRaw, BINCAP);
+        const uint32_t M = (uint32_t)wave_sum_i((int)(min(c4.x, BINCAP) + min(c4.y, BINCAP) + min(c4.z, BINCAP) + min(c4.w, BINCAP)));
         uint32_t pre = 0;
         if (lane * 4 + 0 < bin) pre += min(c4.x, BINCAP);
         if (lane * 4 + 1 < bin) pre += min(c4.y, BINCAP);
         if (lane * 4 + 2 < bin) pre += min(c4.z, BINCAP);
         if (lane * 4 + 3 < bin) pre += min(c4.w, BINCAP);
         const uint32_t base = (uint32_t)wave_sum_i((int)pre);
-        if (lane == 0) bigBin = n > 64 ? 1u : 0u;
+        if (lane == 0) { bigBin = n > 64 ? 1u : 0u; tailIn[0] = M; tailIn[1] = heapC; tailIn[2] = allocBase; tailIn[3] = stuckAll; }
         if (n > 0 && n <= 64) placeBinWave<LISTS>(d, f, fo, n, r, base, heapC, allocBase, lane);
     }
     __syncthreads();
     if (bigBin) placeBin<LISTS>(d, f, fo, s, scratch, sel, bin);          // block-uniform
-    // (allocCount: the tail writes it after every workgroup has been here.  One entry per thread while that gives every workgroup at most one tile - the ~60 000 allocated
-    // blocks of the bench window are 230 tiles over the 256 workgroups - and four per thread beyond: 262 000 blocks of the 5000-frame stream are one tile per workgroup again)
+    // The list pass over the allocated-block list as it stood before this placement (the tail writes allocCount after every workgroup has been here).  One entry per
+    // thread - the record requested above - while that gives every workgroup at most one tile (the ~60 000 allocated blocks of the bench window are 230 tiles over
+    // the 256 workgroups), four per thread beyond (262 000 blocks of the 5000-frame stream are one tile per workgroup again).
     if (LISTS >= 0) {
-        const uint32_t nOld = d.allocCount[0];
-        if (nOld <= gridDim.x * 256u) listAppendTiles<(LISTS < 0 ? 0 : LISTS), 1>(d, f, fo, nOld, blockIdx.x, gridDim.x, wscan, &sbase);
-        else listAppendTiles<(LISTS < 0 ? 0 : LISTS), 4>(d, f, fo, nOld, blockIdx.x, gridDim.x, wscan, &sbase);
+        if (nOld <= gridDim.x * 256u) listAppendBlock<LM>(d, i0 < nOld ? keepRec<LM>(f, fo, rec0) : 0u, rec0.key, rec0.ptr, i0, wscan, &sbase);
+        else listAppendTiles<LM, 4>(d, f, fo, nOld, blockIdx.x, gridDim.x, wscan, &sbase);
     }
     // hand-off to the workgroup that arrives last: every wave drains its (write-through) stores, then one lane takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(256) void k_alloc_place(Dev d, Frame f, Frame fo) {
     }
     __syncthreads();
     if (!lastFlag) return;
-    placeTail<LISTS>(d, f, fo, s, scratch);
+    placeTail<LISTS>(d, f, fo, s, tailIn[0], tailIn[1], tailIn[2], tailIn[3]);
     if (threadIdx.x == 0) d.stats[ST_TICKET] = 0;
 }
 
