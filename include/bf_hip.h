@@ -153,9 +153,11 @@ BF_API int bf_scene_integrate(bf_scene* s, const float cam_to_world[16],
 BF_API int bf_scene_deintegrate(bf_scene* s, const float cam_to_world[16],
                                 const bf_depth_camera_data* data,
                                 const bf_depth_camera_params* cam, const uint32_t* d_bitMask);
-/* Software pipelining of consecutive operators: with overlap enabled, allocation + frustum compaction of operator n+1 run on
- * an internal stream while the voxel update of operator n runs on the scene's stream (the frustum list is double-buffered;
- * the update never reads the hash table, allocation never touches voxels).  Results are unchanged.  The caller then must
+/* Software pipelining of consecutive operators: with overlap enabled, the preparation of operators n+1 .. n+3 (allocation: the ray march and the
+ * placement, which also builds the operator's block list - two launches) runs on an internal stream while the voxel update of operator n runs on the
+ * scene's stream (four list buffers; the update never reads the hash table, allocation never touches voxels).  Results are unchanged.  The ORDER of
+ * d_hashCompactified is unspecified (as in the reference, whose compactify appends with atomicAdd, CUDASceneRepHashSDF.cu:324-366): compare it as a
+ * set.  The caller then must
  * order its input frames against the scene with bf_scene_wait_event (or have them complete) instead of relying on stream
  * order: bf_scene_wait_event makes the next operator's first kernel wait for `hip_event`.                               */
 BF_API int bf_scene_set_overlap(bf_scene* s, int enable);
@@ -182,7 +184,8 @@ BF_API int bf_scene_alloc_sync(bf_scene* s);
  *   BF_TSDF_ARITH_FAST (default)   the contract of the reference's own Release GPU build (FriedLiver.vcxproj:124 <FastMath>true</FastMath>):
  *                                  approximate division (v_rcp_f32), FMA contraction.  Block set, bucket occupancy, heap and voxel
  *                                  weights are the same as in exact mode; sdf within 1e-5 x truncation, colour within 1 LSB, except
- *                                  voxels projecting within ~1e-5 pixel of a pixel boundary (they may sample the neighbouring pixel).
+ *                                  voxels projecting within 2e-4 pixel (640x480; 6e-4 at 1280x960; measured 1.1e-4 / 4.8e-4) of a pixel
+ *                                  boundary (they may sample the neighbouring pixel) - held against the oracle, tests/test_tsdf_fast_gpu.py.
  *                                  This is the path bench.py measures.
  *   BF_TSDF_ARITH_EXACT            every operation as written, IEEE binary32, no contraction - bit-comparable with a host build of the
  *                                  reference (and with oracle/): the mode of every bit-for-bit test.
@@ -191,8 +194,9 @@ BF_API int bf_scene_alloc_sync(bf_scene* s);
 #define BF_TSDF_ARITH_EXACT 0
 #define BF_TSDF_ARITH_FAST 1
 BF_API int bf_scene_set_arith(bf_scene* s, int mode);
-/* MI355X addition (fast contract): a sample's depth and colour are gathered as ONE 8-byte texel {depth f32, colour RGBX8}.  Without _set_frame_texels every
- * operator interleaves its frame itself (one more launch on its allocation stream).  A caller that keeps its frames can interleave each frame once
+/* MI355X addition (fast contract): a sample's depth and colour are gathered as ONE 8-byte texel {depth f32, colour RGBX8}.  Without _set_frame_texels an
+ * operator's own ray march writes the texels of its frame on the way (a de-integration, or an operator behind an external / exchanged allocation,
+ * interleaves the frame in a launch of its own).  A caller that keeps its frames can interleave each frame once
  * (bf_image_interleave_texels: numPixels x 8 bytes) and hand that image to the NEXT operator on the frame with _set_frame_texels (consumed by one operator). */
 BF_API int bf_scene_set_frame_texels(bf_scene* s, const void* d_texels);
 BF_API int bf_image_interleave_texels(void* d_texels, const float* d_depth, const uint8_t* d_colorRGBX, uint32_t numPixels, void* hip_stream);
