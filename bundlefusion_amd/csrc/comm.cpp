@@ -39,7 +39,7 @@ Rccl& rccl() {
         for (const char* n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL); if (r.handle) break; }
         if (const char* e = getenv("BF_RCCL_LIBRARY")) { if (!r.handle) r.handle = dlopen(e, RTLD_NOW | RTLD_LOCAL); }
         for (const char* n : names) { if (r.handle) break; r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
-        if (!r.handle) { r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.handle) { const char* why = dlerror(); r.error = std::string("librccl not found: ") + (why ? why : "?"); return; }      // (dlerror clears itself: one call)
         r.GetUniqueId = (int (*)(ncclUniqueId*))dlsym(r.handle, "ncclGetUniqueId");
         r.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId, int))dlsym(r.handle, "ncclCommInitRank");
         r.CommDestroy = (int (*)(ncclComm_t))dlsym(r.handle, "ncclCommDestroy");

@@ -556,3 +556,45 @@ def test_processed_summary_file(built, tmp_path):
     assert write_processed_summary(p, 799, T) is False                   # the heap is (almost) used up
     assert write_processed_summary(p, 800, T) is True
     assert write_processed_summary(p, 5000, T, aborted=True) is False and p.read_text() == "valid = false\nABORTED\n"
+
+
+def test_comm_callback_transport_and_single_rank_exchange(built):
+    """include/bf_comm.h without a device: a callback communicator hands the caller's pointers to the host's all-gather and reports its failure; a world of one
+    exchanges chunk packages without touching the transport; bad arguments are refused."""
+    from bundlefusion_amd import capi
+    from bundlefusion_amd.capi import lib
+    calls = []
+
+    def gather(user, send, recv, nbytes, stream):          # "rank 1 of 3": the host's own transport; here it fills all three slots from the one buffer it has
+        calls.append((int(nbytes), stream))
+        if nbytes == 13:
+            return 7
+        for r in range(3):
+            C.memmove(recv + r * nbytes, send, nbytes)
+            C.memset(recv + r * nbytes, r, 1)
+        return 0
+    cb = capi._ALL_GATHER_FN(gather)
+    h = C.c_void_p()
+    assert lib.bf_comm_create_callback(cb, None, 3, 3, C.byref(h)) != 0            # rank >= world
+    assert lib.bf_comm_create_callback(cb, None, 3, 1, C.byref(h)) == 0
+    w, r = C.c_uint32(), C.c_uint32()
+    assert lib.bf_comm_world(h, C.byref(w), C.byref(r)) == 0 and (w.value, r.value) == (3, 1)
+    send = np.arange(64, dtype=np.uint8); recv = np.zeros(3 * 64, np.uint8)
+    assert lib.bf_comm_all_gather(h, send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p), C.c_uint64(64), None) == 0
+    assert calls == [(64, None)]
+    for k in range(3):
+        assert recv[k * 64] == k and np.array_equal(recv[k * 64 + 1:(k + 1) * 64], send[1:])
+    assert lib.bf_comm_all_gather(h, send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p), C.c_uint64(0), None) == 0 and len(calls) == 1      # nothing to do
+    assert lib.bf_comm_all_gather(h, send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p), C.c_uint64(13), None) != 0                           # the host's failure is reported
+    assert b"callback failed with 7" in lib.bf_last_error()
+    assert lib.bf_comm_all_gather(h, None, recv.ctypes.data_as(C.c_void_p), C.c_uint64(8), None) != 0
+    assert lib.bf_comm_destroy(h) == 0
+    # a world of one: bf_chunk_exchange is a copy, the transport is never called
+    calls.clear()
+    h1 = C.c_void_p()
+    assert lib.bf_comm_create_callback(cb, None, 1, 0, C.byref(h1)) == 0
+    mine = np.random.RandomState(3).randint(0, 256, 1000).astype(np.uint8); got = np.zeros_like(mine)
+    assert lib.bf_chunk_exchange(h1, mine.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_uint64(mine.size), None) == 0
+    assert np.array_equal(got, mine) and not calls
+    assert lib.bf_chunk_exchange(h1, mine.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_uint64(0), None) != 0
+    assert lib.bf_comm_destroy(h1) == 0 and lib.bf_comm_destroy(None) == 0
