@@ -1849,13 +1849,14 @@ struct bf_pipeline {
     bf_global_app_state gas; bf_global_bundling_state gbs; bf_rgbd_sensor_desc sensor;
     bf_image_manager* im = nullptr; bf_online_bundler* ob = nullptr; bf_scene* scene = nullptr;
     bf_depth_camera_params cam;
-    // Two HIP streams: the bundling stream carries ingest, SIFT, matching, filters and the solves; the volume stream carries every
-    // TSDF operator.  Re-integration of old frames depends only on host-side lists and on frames ingested earlier, so it runs
-    // concurrently with the current frame's feature pipeline; integration of the current frame waits for its ingest (evIngest).
+    // The bundling stream carries matching, filters, pose chaining and (serial order) the solves; the volume stream carries every voxel update and the
+    // garbage collection (the volume's own preparation stream: allocation + block lists).  Re-integration of old frames depends only on host-side lists
+    // and on frames ingested earlier, so it runs concurrently with the current frame's feature pipeline; integration of the current frame waits for its
+    // ingest (evIngest).
     hipStream_t sBundle = nullptr, sVolume = nullptr;
-    // Look-ahead: ingest + feature detection + dense cache frame of frame k+1 run on a third stream (sDetect) while frame k is
-    // matched, filtered, integrated and solved; the body of frame k is executed by the call that delivers frame k+1 (or by the
-    // first call that needs its result).  The per-frame work and its order are unchanged, so are the results.
+    // Look-ahead: feature detection + dense cache frame of frame k+1 run on the detect stream (its ingest on sIngest) while frame k is matched, filtered,
+    // integrated and solved; the body of a frame is executed by a later call (`depth` below) or by the first call that needs its result.  The per-frame
+    // work and its order are unchanged, so are the results.
     hipStream_t sDetect = nullptr;
     bool lookahead = true;
     // Two frames behind the input (round 4): the call that delivers frame n (1) enqueues the matching chain of frame n - 1 on the bundling stream - behind the
@@ -1874,8 +1875,8 @@ struct bf_pipeline {
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
-    // and posts commands; the worker issues the launches, so the ~55 TSDF launches per frame do not serialize with the ~60
-    // launches of the bundling stream on one CPU thread.
+    // and posts commands; the worker issues the launches (three per operator + the event operations: 13 us of HIP calls per operator,
+    // 12 % of the wall time), so they do not serialize with the ~60 launches of the detect and bundling streams on one CPU thread.
     struct VolCmd { int kind; bf_depth_camera_data data; const void* texels; float T0[16], T1[16]; int waitEv; };   // kind: 0 integrate, 1 de-integrate, 2 fused re-integrate, 3 GC
     static const size_t MAX_QUEUE = 48;          // back-pressure: the volume thread may lag the bundling thread by a few frames at most
     std::thread worker;
