@@ -360,12 +360,29 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], feed[:args.cpu_frames], params, K, W, H, args.arith)
     del frames, feed
+    # The secondary blocks must not cost the line its headline: an exception becomes {"error": ...}; a collective that never returns (the sweep's RCCL
+    # communicator is created here, after the measurement) is cut off by a watchdog that prints the line without the block and ends every rank.
+    def secondary(name, fn, limit_s):
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out[name] = {"error": "no result after %d s (abandoned; the headline measurement above it is complete)" % limit_s}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(limit_s, give_up); wd.daemon = True; wd.start()
+        try:
+            return fn()
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            wd.cancel()
     if not args.no_sweep:
-        sw = sweep_block(args, rank, world)
+        sw = secondary("sweep", lambda: sweep_block(args, rank, world), 300)
         if rank == 0:
             out["sweep"] = sw
     if args.long_stream and world == 1:
-        out["long_stream"] = long_stream_block(args, K, W, H)
+        out["long_stream"] = secondary("long_stream", lambda: long_stream_block(args, K, W, H), 1500)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
