@@ -1649,7 +1649,7 @@ struct bf_scene {
     hipStream_t prep = nullptr;
     // NB list buffers: allocation + list of operator n+1 .. n+NB-1 may be prepared while operator n updates voxels.  (With two buffers the
     // prep stream had to wait for the update two operators back, and the two cross-stream event hops of ~40 us each sat inside the
-    // steady-state cycle: period = hop + (prep + update) / 2, profiles/r03_timeline_fast_before.txt: 50 us idle between consecutive updates.)
+    // steady-state cycle: period = hop + (prep + update) / 2, profiles/r02_pipeline_timeline.txt: 44 us idle between consecutive updates.)
     static constexpr int NBMAX = 8;
     int NB = 4;                     // list buffers in use (BF_SCENE_LIST_BUFFERS, 2 .. NBMAX)
     bf_hash_entry* cbuf[NBMAX] = {}; uint32_t* csrc[NBMAX] = {}; int32_t* ccnt[NBMAX] = {};
