@@ -598,3 +598,14 @@ def test_comm_callback_transport_and_single_rank_exchange(built):
     assert np.array_equal(got, mine) and not calls
     assert lib.bf_chunk_exchange(h1, mine.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_uint64(0), None) != 0
     assert lib.bf_comm_destroy(h1) == 0 and lib.bf_comm_destroy(None) == 0
+
+
+def test_sweep_key_capacity_covers_the_measured_key_counts():
+    """tools/tsdf_sweep.py --comm-alloc (bench.py's `sweep` block at N > 1): the per-rank key capacity must cover the keys a rank's band collects - measured ~210 k distinct
+    in-frustum blocks per 1280x960 frame at 2 mm and ~15 k per 640x480 frame at 4 mm - with a factor of two, at every rank count the driver uses."""
+    from tools.tsdf_sweep import alloc_comm_capacity
+    for world in (2, 4, 8):
+        assert alloc_comm_capacity(1280, 960, 0.002, world) >= 2 * 210000 / world
+        assert alloc_comm_capacity(640, 480, 0.004, world) >= 2 * 15000 / world
+        cap = alloc_comm_capacity(1280, 960, 0.002, world)
+        assert cap & (cap - 1) == 0 and cap * 8 * world <= 64 << 20          # a power of two; the gathered records of one operator stay below 64 MB

@@ -69,6 +69,16 @@ def main():
         dist.destroy_process_group()
 
 
+def alloc_comm_capacity(W, H, voxel, world):
+    """Keys per rank and operator for bf_scene_set_alloc_comm: twice the estimate of the distinct in-frustum blocks the rays of a W x H frame cross (0.22 per pixel at 2 mm,
+    scaling with 1 / voxel^2), divided over the ranks, as a power of two >= 65536."""
+    est = 0.22 * W * H * (0.002 / voxel) ** 2
+    cap = 1 << 16
+    while cap < 2.0 * est / world:
+        cap <<= 1
+    return cap
+
+
 def run(a, rank=0, world=1):
     """The sweep on an initialised process group (or one rank); returns the result dict (meaningful on rank 0)."""
     from bundlefusion_amd import synth
@@ -96,11 +106,7 @@ def run(a, rank=0, world=1):
         # keys one rank's band of the image may collect per operator: the distinct in-frustum blocks its rays cross - measured ~270 k per 1280x960 frame at 2 mm
         # (`n_occ_mean_per_op`), i.e. ~0.22 per pixel at 2 mm and 8x less at 4 mm; twice that, divided over the ranks, rounded up to a power of two.  The exchanged
         # records are fixed-size (8 bytes x capacity per rank and operator); exceeding the capacity raises the scene's error flag, it never drops silently.
-        est = 0.22 * W * H * (0.002 / a.voxel) ** 2
-        cap = 1 << 16
-        while cap < 2.0 * est / world:
-            cap <<= 1
-        sc.set_alloc_comm(comm, cap)
+        sc.set_alloc_comm(comm, alloc_comm_capacity(W, H, a.voxel, world))
     if not a.no_overlap:
         sc.set_overlap(True)
     dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
