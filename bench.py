@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s HBM3E
+PMC_FILE = "r05_pmc_tsdf_update.json"
 
 
 def main():
@@ -63,6 +64,9 @@ def main():
                     help="0: the reference's serial order (chunk solves inside the frame that closes the chunk).  L in 1..10: the chunk solves run on their own "
                          "thread and stream and are applied exactly L frames later (bf_pipeline_set_solve_lag) - the reference's optimiser thread "
                          "(FriedLiver.cpp:112-143) with a defined hand-over; same solves, same count, nothing skipped")
+    ap.add_argument("--volume-batching", choices=["on", "off"], default="on", help="on (library default): the frame loop issues a frame's TSDF operators - the integration of the previous "
+                    "frame and this frame's up to s_maxFrameFixes re-integrations - as ONE bf_scene_run_batch (one march, one placement, one pass over the touched blocks); "
+                    "off: one operator at a time (the rounds 1-4 path), for comparison.  Same volume either way (tests/test_tsdf_batch_gpu.py)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary block `sweep` (BASELINE configs[4] in small: the 1280x960 @2 mm re-integration sweep, the "
                     "workload north_star's >= 6x scaling target is quoted on; ~20 s, most of it rendering 24 frames on the host)")
     ap.add_argument("--long-stream", type=int, default=0, help="also run a stream of this many frames from frame 0 through a fresh pipeline and report it as `long_stream` "
@@ -114,6 +118,7 @@ def main():
     mode = args.mode if args.mode != "auto" else ("chunks" if world > 1 else "serial")
     chunked = mode == "chunks"
     shard_volume = (mode == "volume-shard" and world > 1) or chunked
+    chunked_alloc_comm = False                                       # (the headline leg keeps the local march; the divided march is the sweep block's)
     one_stream = shard_volume or mode == "serial" or world == 1
     first = 0 if one_stream else segment(rank, world, total)[0]   # segments: each rank its own contiguous part of the S2 loop
     n_render = total
@@ -196,6 +201,7 @@ def main():
         gas, gbs = params()
         pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
         pipe.scene().set_arith(arith)
+        pipe.set_volume_batching(args.volume_batching == "on")
         if args.solve_lag and not chunked:
             pipe.set_solve_lag(args.solve_lag)
         if shard_volume and world > 1:
@@ -245,6 +251,7 @@ def main():
         elapsed = time.perf_counter() - t0
         L = {"arith": arith, "c0": c0, "c1": pipe.counters(), "hp": pipe.host_profile(), "vp": pipe.volume_thread_profile()}
         L["occ_sum"], L["vis_plain"], L["vis_fused"], L["n_ops"] = sc.kernel_timing_blocks()
+        L["n_images"] = sc.kernel_timing_images()
         L["n_launch"], L["kernel_ms"] = sc.kernel_timing_read()
         sc.kernel_timing(False)
         L["elapsed"] = max_over_ranks(elapsed, "cuda")
@@ -268,27 +275,43 @@ def main():
         return L
 
     def roofline_of(L):
-        # dominant kernel: the TSDF voxel update.  Algorithmic bytes: one integrate / de-integrate operator moves
-        # N_occ*(512*24+32) + W*H*8 bytes; a FUSED re-integration launch (de-integrate old pose + integrate new pose in one pass) reads and
-        # writes every voxel of the UNION of its two frustum lists once, so it is charged N_union*(512*24+32) + W*H*8, not 2 B.
-        n_launch, n_ops = L["n_launch"], L["n_ops"]
-        n_fused = n_ops - n_launch                                   # operators = plain + 2 * fused, launches = plain + fused
-        bytes_per_launch = ((L["vis_plain"] + L["vis_fused"]) * (512 * 24 + 32) + n_launch * W * H * 8) / max(n_launch, 1)
+        # dominant kernel: the TSDF voxel update.  SURVEY.md 8d charges ONE integrate / de-integrate operator N_occ*(512*24+32) + W*H*8 bytes (every voxel of its
+        # frustum list read and written, its frame read).  Two accountings are reported:
+        #  * `achieved` / `frac` - the bytes this LAUNCH has to move whatever its schedule: every block of its list once (a fused re-integration walks the union of
+        #    its two frustum lists once; a batch walks the union of all its operators' lists once) plus every frame image it samples once.  This is what HBM
+        #    actually has to deliver, so frac <= 1 and it is comparable with the PMC traffic.
+        #  * `achieved_per_operator` / `frac_per_operator` - 8d by the letter: the sum over the launch's operators of their own N_occ*(512*24+32) + W*H*8.  A batched
+        #    launch applies up to 21 operators to a block per trip through HBM, so this figure can exceed the HBM peak: the re-reads the serial schedule pays
+        #    are gone, not accelerated.
+        n_launch, n_ops, n_img = L["n_launch"], L["n_ops"], L["n_images"]
+        batched = args.volume_batching == "on" and not chunked_alloc_comm
+        bytes_per_launch = ((L["vis_plain"] + L["vis_fused"]) * (512 * 24 + 32) + n_img * W * H * 8) / max(n_launch, 1)
+        bytes_per_operator_sum = (L["occ_sum"] * (512 * 24 + 32) + n_ops * W * H * 8) / max(n_launch, 1)
         avg_kernel_s = (L["kernel_ms"] / 1e3) / max(n_launch, 1)
         achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        achieved_op = bytes_per_operator_sum / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         traffic = pmc_traffic(args, L["arith"], L["vis_plain"], L["vis_fused"], n_launch)
-        kern = "k_update_apx<2,.,DEFER> (fused de-integrate + integrate) + k_update_apx<0,.,DEFER> (integrate)" if L["arith"] == "fast" else \
-               "k_update_col<2> (fused de-integrate + integrate) + k_update_col<0> (integrate)"
+        if batched:
+            kern = ("k_update_batch_apx (tsdf_batch.h): one wave per block of the batch's union list, voxels loaded once, the batch's operators applied in order from registers"
+                    if L["arith"] == "fast" else "k_update_batch_col (tsdf_batch.h): the batch's operators one after the other per block, exact contract")
+        else:
+            kern = "k_update_apx<2,.,DEFER> (fused de-integrate + integrate) + k_update_apx<0,.,DEFER> (integrate)" if L["arith"] == "fast" else \
+                   "k_update_col<2> (fused de-integrate + integrate) + k_update_col<0> (integrate)"
         return {
             "kernel": kern + " - TSDF voxel update, tsdf.hip",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "achieved_per_operator": achieved_op, "frac_per_operator": achieved_op / HBM_PEAK_GBS,
             "hbm_frac_measured": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_kernel_s > 0) else None,
-            "launches": n_launch, "fused_launches": n_fused, "avg_launch_us": 1e6 * avg_kernel_s,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": L["occ_sum"] / max(n_ops, 1),
+            "launches": n_launch, "operators": n_ops, "frames_sampled": n_img, "avg_launch_us": 1e6 * avg_kernel_s,
+            "us_per_operator": 1e6 * (L["kernel_ms"] / 1e3) / max(n_ops, 1),
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_launch_per_operator_accounting": bytes_per_operator_sum,
+            "ops_per_launch": n_ops / max(n_launch, 1), "n_occ_mean_per_op": L["occ_sum"] / max(n_ops, 1),
             "blocks_visited_per_launch": (L["vis_plain"] + L["vis_fused"]) / max(n_launch, 1),
-            "accounting": "fused launch = union list once: N_union*(512*24+32) + W*H*8 B; traffic = PMC bytes per visited block "
-                          "(profiles/r04_pmc_tsdf_update.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes, same contract and same kernel source: update_kernel_sha256) x blocks visited here; null when that file was collected on another version of the kernel",
+            "accounting": "achieved = (blocks of the launch's list x (512*24+32) + frames sampled x W*H*8) / launch time: each block and each frame once per launch (union list of a "
+                          "fused re-integration / of a batch); achieved_per_operator = SURVEY 8d by the letter, summed over the launch's operators; traffic = PMC bytes per visited "
+                          "block (profiles/%s: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes, same contract, same kernel source: update_kernel_sha256) x blocks visited "
+                          "here; null when that file was collected on another version of the kernel" % PMC_FILE,
             "share_of_step_time": (L["kernel_ms"] / 1e3) / L["elapsed"] if L["elapsed"] > 0 else None,
         }
 
@@ -297,7 +320,8 @@ def main():
     if args.both_contracts and world == 1 and not args.pmc_out:
         other = run_leg("exact" if args.arith == "fast" else "fast")
     if args.pmc_out and rank == 0:
-        json.dump({"config": pmc_config(args), "launches": main_leg["n_launch"], "fused_launches": main_leg["n_ops"] - main_leg["n_launch"],
+        json.dump({"config": pmc_config(args), "launches": main_leg["n_launch"],
+                   "fused_launches": main_leg["n_launch"] if args.volume_batching == "on" else main_leg["n_ops"] - main_leg["n_launch"],      # launches over a union list
                    "visited_blocks_plain": main_leg["vis_plain"], "visited_blocks_fused": main_leg["vis_fused"], "operator_blocks": main_leg["occ_sum"]}, open(args.pmc_out, "w"))
     elapsed, c0, c1, hp, dbg = main_leg["elapsed"], main_leg["c0"], main_leg["c1"], main_leg["hp"], main_leg["dbg"]
     ate = main_leg["ate"]
@@ -487,7 +511,7 @@ def long_stream_block(args, K, W, H):
 
 
 def pmc_config(args):
-    return {"preroll": args.preroll, "voxel": args.voxel, "buckets": args.buckets, "blocks": args.blocks, "host": bool(args.host)}
+    return {"preroll": args.preroll, "voxel": args.voxel, "buckets": args.buckets, "blocks": args.blocks, "host": bool(args.host), "volume_batching": args.volume_batching}
 
 
 def pmc_traffic(args, arith, vis_plain, vis_fused, n_launch):
@@ -495,7 +519,7 @@ def pmc_traffic(args, arith, vis_plain, vis_fused, n_launch):
     FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, each in its own run of this command with --pmc-out): bytes per visited SDF block
     of the plain and of the fused kernel under the same arithmetic contract, times the blocks the timed launches of this run visited.
     None when the counters were collected on another configuration (pre-roll / volume parameters / contract)."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_tsdf_update.json")
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     if not os.path.exists(path) or n_launch == 0:
         return None
     pmc = json.load(open(path)).get(arith)

@@ -67,6 +67,15 @@ class DepthCameraData(C.Structure):
     _fields_ = [("d_depthData", C.c_void_p), ("d_colorData", C.c_void_p)]
 
 
+SCENE_BATCH_MAX = 12
+
+
+class SceneBatchOp(C.Structure):
+    """bf_scene_batch_op: kind 0 integrate(T0), 1 deIntegrate(T0), 2 deIntegrate(T0) + integrate(T1) of the same frame"""
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("T0", C.c_float * 16), ("T1", C.c_float * 16), ("data", DepthCameraData),
+                ("d_texels", C.c_void_p), ("wait_event", C.c_void_p)]
+
+
 class HashData(C.Structure):
     _fields_ = [
         ("d_heap", C.c_void_p), ("d_heapCounter", C.c_void_p), ("d_hashDecision", C.c_void_p),
@@ -221,6 +230,19 @@ class SceneRepHashSDF:
         data = self._data(depth, color)
         check(lib.bf_scene_reintegrate(self._h, mat16(old_cam_to_world), mat16(new_cam_to_world), C.byref(data), C.byref(cam)))
 
+    def run_batch(self, ops, cam):
+        """ops: list of (kind, T0, T1 or None, depth, color) - kind "in" / 0 integrate(T0), "de" / 1 deIntegrate(T0), "re" / 2 deIntegrate(T0) + integrate(T1) -
+        executed as ONE batch (bf_scene_run_batch): same volume as the same operators issued one by one, in that order."""
+        assert 1 <= len(ops) <= SCENE_BATCH_MAX
+        arr = (SceneBatchOp * len(ops))()
+        for o, (kind, T0, T1, depth, color) in zip(arr, ops):
+            o.kind = {"in": 0, "de": 1, "re": 2}.get(kind, kind)
+            o.T0[:] = np.asarray(T0, np.float32).reshape(16).tolist()
+            o.T1[:] = np.asarray(T1 if T1 is not None else T0, np.float32).reshape(16).tolist()
+            o.data = self._data(depth, color)
+            o.d_texels = None; o.wait_event = None
+        check(lib.bf_scene_run_batch(self._h, arr, len(ops), C.byref(cam)))
+
     def garbage_collect(self):
         check(lib.bf_scene_garbage_collect(self._h))
 
@@ -276,6 +298,12 @@ class SceneRepHashSDF:
         a = C.c_uint64(); b = C.c_uint64(); c = C.c_uint64(); n = C.c_uint32()
         check(lib.bf_scene_kernel_timing_blocks(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
         return a.value, b.value, c.value, n.value
+
+    def kernel_timing_images(self):
+        """frames (depth + colour images) the timed launches sampled: one per operator, n per batch of n"""
+        n = C.c_uint32()
+        check(lib.bf_scene_kernel_timing_images(self._h, C.byref(n)))
+        return n.value
 
     # ---- test helpers: copy raw arrays back (hipMemcpy through torch) ----
     def download(self):
@@ -935,6 +963,10 @@ class Pipeline:
 
     def set_volume_shard(self, rank, world):
         check(lib.bf_pipeline_set_volume_shard(self._h, rank, world))
+
+    def set_volume_batching(self, enable=True):
+        """one bf_scene_run_batch per frame (default) or one operator at a time: bf_pipeline_set_volume_batching"""
+        check(lib.bf_pipeline_set_volume_batching(self._h, int(enable)))
 
     def set_comm(self, comm, capacity_keys=1 << 15):
         """Divide the allocation's ray march of every TSDF operator of this loop over the ranks of `comm` (bf_pipeline_set_comm; the volume must be

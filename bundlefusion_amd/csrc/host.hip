@@ -1877,7 +1877,13 @@ struct bf_pipeline {
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
     // and posts commands; the worker issues the launches (three per operator + the event operations: 13 us of HIP calls per operator,
     // 12 % of the wall time), so they do not serialize with the ~60 launches of the detect and bundling streams on one CPU thread.
-    struct VolCmd { int kind; bf_depth_camera_data data; const void* texels; float T0[16], T1[16]; int waitEv; };   // kind: 0 integrate, 1 de-integrate, 2 fused re-integrate, 3 GC
+    struct VolCmd { int kind; bf_depth_camera_data data; const void* texels; float T0[16], T1[16]; int waitEv; };   // kind: 0 integrate, 1 de-integrate, 2 fused re-integrate, 3 GC, 4 flush
+    // Batched volume operators (round 5, bf_scene_run_batch): the volume thread collects a frame's operators - the integration of the previous frame, which
+    // arrives last in that frame's body, and this frame's re-integrations - and issues them as ONE batch when the frame's garbage collection arrives
+    // (DepthSensing.cpp:854-902 order kept: ..., integrate(k-1), fixes(k), GC(k), integrate(k), ...); a flush command (every accessor, bf_pipeline_synchronize)
+    // issues what is pending.  Per batch: four launches and one pass over the touched blocks instead of 3 launches and one pass per operator.
+    bool volBatching = true;
+    std::vector<VolCmd> volPending;                // worker-thread only
     static const size_t MAX_QUEUE = 48;          // back-pressure: the volume thread may lag the bundling thread by a few frames at most
     std::thread worker;
     std::mutex mu;
@@ -1908,6 +1914,33 @@ int volExecute(bf_pipeline* p, const bf_pipeline::VolCmd& c) {                  
     return bf_scene_reintegrate(p->scene, c.T0, c.T1, &c.data, &p->cam);
 }
 
+int volSubmitPending(bf_pipeline* p) {
+    std::vector<bf_pipeline::VolCmd>& q = p->volPending;
+    if (q.empty()) return BF_OK;
+    bf_scene_batch_op ops[BF_SCENE_BATCH_MAX];
+    const uint32_t n = (uint32_t)q.size();
+    for (uint32_t k = 0; k < n; ++k) {
+        const bf_pipeline::VolCmd& c = q[k];
+        ops[k].kind = c.kind; ops[k].reserved = 0;
+        memcpy(ops[k].T0, c.T0, 64); memcpy(ops[k].T1, c.kind == 2 ? c.T1 : c.T0, 64);
+        ops[k].data = c.data; ops[k].d_texels = c.texels;
+        ops[k].wait_event = c.waitEv >= 0 ? (void*)p->evIngest[c.waitEv] : nullptr;
+    }
+    q.clear();
+    return bf_scene_run_batch(p->scene, ops, n, &p->cam);
+}
+
+// the volume thread's handling of one command (see bf_pipeline::volBatching)
+int volHandle(bf_pipeline* p, const bf_pipeline::VolCmd& c) {
+    if (!p->volBatching) return c.kind == 4 ? BF_OK : volExecute(p, c);
+    if (c.kind <= 2) {
+        p->volPending.push_back(c);
+        return p->volPending.size() == BF_SCENE_BATCH_MAX ? volSubmitPending(p) : BF_OK;
+    }
+    BF_TRY(volSubmitPending(p));
+    return c.kind == 3 ? bf_scene_garbage_collect(p->scene) : BF_OK;
+}
+
 void volWorker(bf_pipeline* p) {
     for (;;) {
         bf_pipeline::VolCmd c;
@@ -1919,7 +1952,7 @@ void volWorker(bf_pipeline* p) {
             p->busy = true;
         }
         const double tv = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        const int rc = volExecute(p, c);
+        const int rc = volHandle(p, c);
         const double dv = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tv;
         {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -1953,6 +1986,11 @@ int volPost(bf_pipeline* p, int kind, uint32_t frame, const float* T0, const flo
 
 int volDrain(bf_pipeline* p) {
     std::unique_lock<std::mutex> lk(p->mu);
+    if (p->worker.joinable() && p->workerError == BF_OK) {      // what the volume thread holds back for the next batch is issued now
+        bf_pipeline::VolCmd f; memset(&f, 0, sizeof f); f.kind = 4; f.waitEv = -1;
+        p->queue.push_back(f);
+        p->cvWork.notify_one();
+    }
     p->cvIdle.wait(lk, [p] { return p->queue.empty() && !p->busy; });
     if (p->workerError != BF_OK) { set_error("volume worker: %s", p->workerMessage.c_str()); return p->workerError; }
     return BF_OK;
@@ -2249,6 +2287,16 @@ int bf_pipeline_set_comm(bf_pipeline* p, bf_comm* comm, uint32_t capacity_keys) 
     BF_TRY(plFlush(p));
     BF_TRY(volDrain(p));
     return bf_scene_set_alloc_comm(p->scene, comm, capacity_keys);
+}
+
+// Batched volume operators on / off (on by default; see bf_pipeline::volBatching).  Off: every operator is issued on its own (bf_scene_integrate / _deintegrate /
+// _reintegrate), as before round 5 - same volume either way.
+int bf_pipeline_set_volume_batching(bf_pipeline* p, int enable) {
+    BF_REQUIRE(p, "null pipeline");
+    BF_TRY(plFlush(p));
+    BF_TRY(volDrain(p));
+    p->volBatching = enable != 0;
+    return BF_OK;
 }
 
 int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world) {

@@ -126,20 +126,21 @@ BF_HD i3 virtualVoxelPosToSDFBlock(i3 v) {                     // :290-299
 BF_HD f3 SDFBlockToWorld(float voxelSize, i3 b) {
     return mk3((float)(b.x * BS), (float)(b.y * BS), (float)(b.z * BS)) * voxelSize;
 }
-BF_HD bool blockInFrustum(const Frame& f, i3 b) {              // :322-326, DepthCameraUtil.h:97-142
-    f3 w = SDFBlockToWorld(f.voxelSize, b);
-    const float off = f.voxelSize * 0.5f * ((float)BS - 1.0f);
+BF_HD bool blockInFrustumT(const m44& Tinv, const bf_depth_camera_params& cam, float voxelSize, i3 b) {              // :322-326, DepthCameraUtil.h:97-142
+    f3 w = SDFBlockToWorld(voxelSize, b);
+    const float off = voxelSize * 0.5f * ((float)BS - 1.0f);
     w = w + mk3(off, off, off);
-    f3 pc = xform(f.Tinv, w);
-    const float sx = pc.x * f.cam.fx / pc.z + f.cam.mx;
-    const float sy = pc.y * f.cam.fy / pc.z + f.cam.my;
-    const float wm1 = (float)f.cam.m_imageWidth - 1.0f, hm1 = (float)f.cam.m_imageHeight - 1.0f;
+    f3 pc = xform(Tinv, w);
+    const float sx = pc.x * cam.fx / pc.z + cam.mx;
+    const float sy = pc.y * cam.fy / pc.z + cam.my;
+    const float wm1 = (float)cam.m_imageWidth - 1.0f, hm1 = (float)cam.m_imageHeight - 1.0f;
     float px = (2.0f * sx - wm1) / wm1;
     float py = (hm1 - 2.0f * sy) / hm1;
-    float pz = (pc.z - f.cam.m_sensorDepthWorldMin) / (f.cam.m_sensorDepthWorldMax - f.cam.m_sensorDepthWorldMin);
+    float pz = (pc.z - cam.m_sensorDepthWorldMin) / (cam.m_sensorDepthWorldMax - cam.m_sensorDepthWorldMin);
     px *= 0.95f; py *= 0.95f; pz *= 0.95f;
     return !(px < -1.0f || px > 1.0f || py < -1.0f || py > 1.0f || pz < 0.0f || pz > 1.0f);
 }
+BF_HD bool blockInFrustum(const Frame& f, i3 b) { return blockInFrustumT(f.Tinv, f.cam, f.voxelSize, b); }
 
 // read-only lookup, VoxelUtilHashSDF.h:441-485.  The four entries of the home bucket and its chain head are loaded unconditionally
 // (one memory round trip instead of up to five dependent ones: next to the voxel kernel of the other stream a round trip costs 2-3 us).
@@ -280,38 +281,65 @@ BF_DEV void collectCandidate(const Dev& d, const Collect& c, i3 b) {
     atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
 }
 
-template <bool COLLECT>
-BF_DEV void waveSetFlush(const Dev& d, const Frame& f, const Collect& c, unsigned long long* set, const unsigned long long* list, uint32_t n, uint32_t lane) {
+// Batched allocation (bf_scene_run_batch): ONE march over the frames of all operators of a batch.  The march touches neither the hash table nor the
+// bins: every distinct in-frustum block key of operator `op` is claimed in the batch's own key set together with the SMALLEST operator index that needs
+// it (the operator that allocates it in the serial order: operators before it must not see the block, operators after it find it present).  The table
+// look-up, the ownership test and the binning per operator follow in k_batch_bin, behind whatever still has to free table entries (garbage collection).
+struct BatchSink {
+    unsigned long long* set; uint32_t mask;      // 64-bit keys, open addressing (EMPTY64 = free)
+    uint32_t* opMin;                             // per slot: smallest operator index (0xFFFFFFFF = none)
+    uint32_t* list; uint32_t* count; uint32_t cap;   // slots claimed by this batch, in arrival order (the order reaches no result: k_batch_place sorts)
+    uint32_t* flags;                             // [0] bit 0: a home bucket cannot take all its new keys (k_batch_bin), bit 1: the slot list overflowed
+    uint32_t op;
+};
+
+BF_DEV void claimCandidate(const Dev& d, const BatchSink& bs, i3 b) {
+    if (!keyable(b)) return;
+    const uint64_t key = packKey(b);
+    uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & bs.mask;
+    for (uint32_t probe = 0; probe <= bs.mask; ++probe) {
+        const unsigned long long old = atomicCAS(&bs.set[slot], (unsigned long long)EMPTY64, (unsigned long long)key);
+        if (old == EMPTY64) {
+            const uint32_t pos = atomicAdd(bs.count, 1u);
+            if (pos < bs.cap) bs.list[pos] = slot;
+            else { atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW); atomicOr(bs.flags, 2u); }      // the set is cleared as a whole behind this batch
+        }
+        if (old == EMPTY64 || old == key) { atomicMin(&bs.opMin[slot], bs.op); return; }
+        slot = (slot + 1) & bs.mask;
+    }
+    atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
+}
+
+// SINK 0: queue the missing keys this volume owns (emitCandidate), 1: collect the distinct in-frustum keys of a band (collectCandidate), 2: claim for a batch
+template <int SINK>
+BF_DEV void waveSetFlush(const Dev& d, const Frame& f, const Collect& c, const BatchSink& bs, unsigned long long* set, const unsigned long long* list, uint32_t n, uint32_t lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the list entries were written by other lanes of this wave
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
         if (i < n) {
             const i3 b = unpackKey(list[i]);
-            if (blockInFrustum(f, b)) { if (COLLECT) collectCandidate(d, c, b); else emitCandidate(d, f, b); }
+            if (blockInFrustum(f, b)) { if (SINK == 1) collectCandidate(d, c, b); else if (SINK == 2) claimCandidate(d, bs, b); else emitCandidate(d, f, b); }
         }
     }
     for (uint32_t i = lane; i < WSET; i += 64) set[i] = EMPTY64;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <bool COLLECT>
-__global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth, Collect c, TexelOut tx) {
-    __builtin_amdgcn_s_setprio(3);          // see PREP_PRIO
-    __shared__ unsigned long long setAll[4][WSET];
-    __shared__ unsigned long long listAll[4][WLIST];
-    unsigned long long* set = setAll[threadIdx.x >> 6];
-    unsigned long long* list = listAll[threadIdx.x >> 6];
+// the march of one 8x8 pixel tile by one wave (set / list: the wave's LDS scratch); marches == false: the tile's texels only (an operator that does not allocate)
+template <int SINK>
+BF_DEV void marchTile(const Dev& d, const Frame& f, const float* __restrict__ depth, const Collect& c, const TexelOut& tx, const BatchSink& bs, uint32_t tile, bool marches,
+                      unsigned long long* set, unsigned long long* list) {
+    constexpr bool COLLECT = SINK == 1;
     const uint32_t W = f.cam.m_imageWidth, H = f.cam.m_imageHeight;
     const uint32_t tilesX = (W + 7) / 8;
-    const uint32_t tile = (COLLECT ? c.tile0 : 0u) + blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     for (uint32_t i = lane; i < WSET; i += 64) set[i] = EMPTY64;
-    if (!COLLECT && blockIdx.x == 0 && threadIdx.x == 0) { d.compactCount[0] = 0; d.compactCount[1] = 0; }      // the operator's list: the placement kernel behind this one appends to it
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7);
     const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
     bool alive = x < W && y < H && (!COLLECT || tile < c.tile1);
     const float dd = alive ? depth[(size_t)y * W + x] : BF_MINF;
     if (tx.texel != nullptr && alive) tx.texel[(size_t)y * W + x] = make_uint2(__float_as_uint(dd), tx.color[(size_t)y * W + x]);
+    if (!marches) return;       // wave-uniform
     if (dd == BF_MINF || dd == 0.0f) alive = false;
     if (dd >= f.maxIntegrationDistance) alive = false;
     const float t = f.truncation + f.truncScale * dd;
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
         const unsigned long long mask = __ballot((int)fresh);
         if (fresh) list[uniq + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = key;
         uniq += (uint32_t)__popcll(mask);
-        if (uniq > WLIST - 64) { waveSetFlush<COLLECT>(d, f, c, set, list, uniq, lane); uniq = 0; }
+        if (uniq > WLIST - 64) { waveSetFlush<SINK>(d, f, c, bs, set, list, uniq, lane); uniq = 0; }
         if (alive) {
             if (tMax.x < tMax.y && tMax.x < tMax.z) {
                 cur.x = f2i((float)cur.x + step.x);
@@ -378,7 +406,17 @@ __global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const 
             }
         }
     }
-    if (uniq) waveSetFlush<COLLECT>(d, f, c, set, list, uniq, lane);
+    if (uniq) waveSetFlush<SINK>(d, f, c, bs, set, list, uniq, lane);
+}
+
+template <bool COLLECT>
+__global__ __launch_bounds__(256) void k_alloc_candidates(Dev d, Frame f, const float* __restrict__ depth, Collect c, TexelOut tx) {
+    __builtin_amdgcn_s_setprio(3);          // see PREP_PRIO
+    __shared__ unsigned long long setAll[4][WSET];
+    __shared__ unsigned long long listAll[4][WLIST];
+    if (!COLLECT && blockIdx.x == 0 && threadIdx.x == 0) { d.compactCount[0] = 0; d.compactCount[1] = 0; }      // the operator's list: the placement kernel behind this one appends to it
+    const uint32_t tile = (COLLECT ? c.tile0 : 0u) + blockIdx.x * 4 + (threadIdx.x >> 6);
+    marchTile<COLLECT ? 1 : 0>(d, f, depth, c, tx, BatchSink{}, tile, true, setAll[threadIdx.x >> 6], listAll[threadIdx.x >> 6]);
 }
 
 // after a collect pass: give the borrowed de-dup entries back
@@ -1386,11 +1424,10 @@ BF_DEV void apxTouched(const ApxCam& c, const ApxPair& a, bool& anyA, bool& anyB
     anyA = okDeA || okInA; anyB = okDeB || okInB;
 }
 
-// Stage B: sample validity, voxelApply<true> and / or voxelApply<false>, store.
+// Stage B on registers: sample validity, voxelApply<true> and / or voxelApply<false> on the pair's two voxels (vS, vW, vCA, vCB); stA / stB: the voxel has a
+// valid sample (its new value is in the registers), otherwise its registers are unchanged.
 template <bool DE, bool IN, bool RNE>
-BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& a) {
-    uint32_t* vpA = b.base + (size_t)z * 64u * 3u; uint32_t* vpB = vpA + 64u * 3u;
-    v2f vS = a.vS, vW = a.vW; uint32_t vCA = a.vCA, vCB = a.vCB;
+BF_DEV void apxCompute(const ApxCam& c, const ApxPair& a, v2f& vS, v2f& vW, uint32_t& vCA, uint32_t& vCB, bool& stA, bool& stB) {
     // sample validity (voxelSample): the depth -inf of an invalid pixel fails |sdf| < trunc by itself; |sdf| < trunc makes the reference's
     // clamp to [-trunc, trunc] the identity.  Truncation in the exact contract's operations: the validity of a sample (hence every
     // weight) does not depend on the contract.
@@ -1398,8 +1435,7 @@ BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& 
     const v2f tDe = sp2(c.truncation) + sp2(c.truncScale) * a.dDe, tIn = sp2(c.truncation) + sp2(c.truncScale) * a.dIn;
     const bool okDeA = DE && a.inDeA && a.dDe.x < c.maxDist && fabsf(sDe.x) < tDe.x, okDeB = DE && a.inDeB && a.dDe.y < c.maxDist && fabsf(sDe.y) < tDe.y;
     const bool okInA = IN && a.inInA && a.dIn.x < c.maxDist && fabsf(sIn.x) < tIn.x, okInB = IN && a.inInB && a.dIn.y < c.maxDist && fabsf(sIn.y) < tIn.y;
-    const bool anyA = okDeA || okInA, anyB = okDeB || okInB;
-    const bool stA = anyA, stB = anyB;
+    stA = okDeA || okInA; stB = okDeB || okInB;
     if (!stA && !stB) return;
     if (DE && (okDeA || okDeB)) {           // voxelApply<true>
         const v2f dd = vW - sp2(1.0f);
@@ -1438,6 +1474,15 @@ BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& 
         if (okInA) { vS.x = s.x; vW.x = fminf(c.weightMax, dd.x); vCA = nA; }
         if (okInB) { vS.y = s.y; vW.y = fminf(c.weightMax, dd.y); vCB = nB; }
     }
+}
+
+// Stage B of the per-operator kernels: compute, store.
+template <bool DE, bool IN, bool RNE>
+BF_DEV void apxStageB(const ApxCam& c, const ApxBlock& b, int z, const ApxPair& a) {
+    uint32_t* vpA = b.base + (size_t)z * 64u * 3u; uint32_t* vpB = vpA + 64u * 3u;
+    v2f vS = a.vS, vW = a.vW; uint32_t vCA = a.vCA, vCB = a.vCB;
+    bool stA, stB;
+    apxCompute<DE, IN, RNE>(c, a, vS, vW, vCA, vCB, stA, stB);
     if (stA) { vpA[0] = __float_as_uint(vS.x); vpA[1] = __float_as_uint(vW.x); vpA[2] = vCA; }
     if (stB) { vpB[0] = __float_as_uint(vS.y); vpB[1] = __float_as_uint(vW.y); vpB[2] = vCB; }
 }
@@ -1501,13 +1546,18 @@ __global__ void k_probe_cvt(uint32_t* out) {
     if (threadIdx.x < 8) out[threadIdx.x] = __builtin_amdgcn_cvt_pk_u8_f32(v[threadIdx.x], 1u, 0xAABBCCDDu);
 }
 
+#include "tsdf_batch.h"
+
 // ---------------------------------------------------------------------------------------
 // garbage collection (CUDASceneRepHashSDF.cu:584-668, VoxelUtilHashSDF.h:740-826)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gc_identify(Dev d, Frame f) {
+// needMask != 0: d.compact is a union list (fused re-integration, batch) whose entries with (flags & needMask) != 0 are exactly the frustum list of the last
+// pose - the list the reference's garbageCollect walks (its last compactify) - so the union list is filtered here instead of being re-compacted first
+__global__ __launch_bounds__(256) void k_gc_identify(Dev d, Frame f, uint32_t needMask) {
     __shared__ uint32_t wmax[4];
     const uint32_t n = (uint32_t)d.compactCount[0];
     for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
+        if (needMask != 0u && (reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4] & needMask) == 0u) continue;      // block-uniform
         const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];
         const bf_voxel* v = d.vox + (size_t)(uint32_t)e.w;
         const uint32_t w0 = (uint32_t)f2i(v[2 * threadIdx.x + 0].weight);      // uint shared_MaxWeight, .cu:581,606
@@ -1642,6 +1692,7 @@ struct bf_scene {
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
+    uint32_t imagesTimed = 0;       // frames (depth + colour images) the timed launches sampled: one per operator, n per batch of n
     // Software pipelining of consecutive operators (bf_scene_set_overlap): allocation + frustum compaction of operator n+1 run on
     // the internal `prep` stream while the voxel update of operator n runs on `stream`.  The update never reads the hash table and
     // allocation never touches voxels; the only shared object is the frustum list, which is double-buffered.
@@ -1659,7 +1710,12 @@ struct bf_scene {
     bool barrierPending = false;    // the last exclusive section of the main stream has not been waited for by the preparation stream yet
     hipEvent_t pendingEv = nullptr; // bf_scene_wait_event: the next operator's first kernel waits for it
     const uint2* frameTexels = nullptr;   // bf_scene_set_frame_texels: the next operator's frame as interleaved texels, made once when the frame was ingested
-    bool compactStale = false;      // d.compact holds a union list (fused re-integration), not the frustum list of the last pose
+    bool compactStale = false;      // d.compact holds a union list (fused re-integration, batch) or nothing usable (behind a garbage collection), not the frustum list of the last pose
+    uint32_t gcMask = 0;            // compactStale and != 0: the entries of d.compact with (flags & gcMask) != 0 ARE the frustum list of the last pose (k_gc_identify filters)
+    // batched operators (bf_scene_run_batch, tsdf_batch.h)
+    BatchDev bd{};
+    bool batchReady = false;
+    uint2* btexel[NBMAX][BF_SCENE_BATCH_MAX] = {}; size_t btexelPixels = 0;      // the batch's frames as texel images, one set per list buffer
     // optional HIP-event timing of the voxel-update kernel
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1809,7 +1865,7 @@ int launchCompactify(bf_scene* s) {                              // compactifyHa
     hipLaunchKernelGGL(k_alloc_snapshot, dim3(1), dim3(1), 0, s->stream, s->d);
     hipLaunchKernelGGL(k_compact_append<0>, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d, f, f);
     BF_HIP_TRY(hipGetLastError());
-    s->compactStale = false;
+    s->compactStale = false; s->gcMask = 0;
     return BF_OK;
 }
 int refreshStaleList(bf_scene* s) {                              // a fused re-integration left a union list behind
@@ -1911,6 +1967,7 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
         }
         ev = &s->events[s->eventsUsed++];
         s->opsTimed += kind == 2 ? 2 : 1;
+        s->imagesTimed += 1;
         BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
     }
     const uchar4* color = reinterpret_cast<const uchar4*>(data->d_colorData);
@@ -1935,6 +1992,139 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     BF_HIP_TRY(hipGetLastError());
     useBuf(s, b);
     s->compactStale = kind == 2;
+    s->gcMask = kind == 2 ? 1u : 0u;      // bit 0 of a union list's flags: the block lies in the frustum of the new pose (keepRec<2>)
+    return BF_OK;
+}
+
+// ---- batched operators (tsdf_batch.h)
+int ensureBatch(bf_scene* s) {
+    if (s->batchReady) return BF_OK;
+    const size_t N = s->params.m_numSDFBlocks;
+    uint32_t ds = 1u << 18;
+    while (ds < (1u << 22) && (size_t)ds < 4u * N) ds <<= 1;
+    BatchDev& bd = s->bd;
+    int rc = BF_OK;
+#define A(ptr, cnt) if (rc == BF_OK) rc = devAlloc(s, &(ptr), (cnt))
+    A(bd.set, (size_t)ds);
+    A(bd.opMin, (size_t)ds);
+    A(bd.candList, (size_t)ds / 2);
+    A(bd.candCount, 1);
+    A(bd.bins, (size_t)BMAX * NBINS * BINCAP);
+    A(bd.binCount, (size_t)BMAX * NBINS);
+    A(bd.bucketCnt, (size_t)s->params.m_hashNumBuckets);
+    A(bd.flags, 4);
+#undef A
+    if (rc != BF_OK) return rc;
+    bd.setMask = ds - 1; bd.candCap = ds / 2;
+    hipStream_t ps = s->overlap ? s->prep : s->stream;
+    hipLaunchKernelGGL(k_batch_reset, dim3(2048), dim3(256), 0, ps, bd, s->params.m_hashNumBuckets);
+    BF_HIP_TRY(hipGetLastError());
+    s->batchReady = true;
+    return BF_OK;
+}
+
+// A batch of operators in the serial order ops[0], ops[1], ...: one march, one binning, one placement + union list (preparation stream), one voxel update.
+int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
+    BF_TRY_RC(ensureBatch(s));
+    const int b = s->overlap ? (s->cur + 1) % s->NB : s->cur;
+    hipStream_t ps = s->overlap ? s->prep : s->stream;
+    const Dev dv = devBuf(s, b);
+    const bool fast = s->arith == BF_TSDF_ARITH_FAST;
+    const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
+    if (fast && s->btexelPixels < npx) {
+        BF_TRY_RC(syncAll(s));
+        for (int q = 0; q < bf_scene::NBMAX; ++q)
+            for (uint32_t k = 0; k < BMAX; ++k) { if (s->btexel[q][k]) (void)hipFree(s->btexel[q][k]); s->btexel[q][k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->btexel[q][k], npx * sizeof(uint2))); }
+        s->btexelPixels = npx;
+    }
+    // the frames' ingest (per-operator events, bf_scene_wait_event) and the update that read list buffer b and its texel set NB batches ago
+    for (uint32_t k = 0; k < n; ++k) if (ops[k].wait_event) BF_HIP_TRY(hipStreamWaitEvent(ps, (hipEvent_t)ops[k].wait_event, 0));
+    if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->pendingEv, 0)); s->pendingEv = nullptr; }
+    if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));
+    s->frameTexels = nullptr;
+    // per-operator frames: integration pose (kinds 0, 2), de-integration pose (kinds 1, 2)
+    Frame fin[BMAX], fde[BMAX];
+    BatchCommon bc;
+    BatchMarchArgs ma;
+    BatchFrusta fr;
+    memset(&ma, 0, sizeof ma); memset(&fr, 0, sizeof fr);
+    uint32_t opsCount = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const bf_scene_batch_op& o = ops[k];
+        setLastRigidTransform(s, o.T0);
+        const Frame f0 = makeFrame(s);
+        Frame f1 = f0;
+        if (o.kind == 2) { setLastRigidTransform(s, o.T1); f1 = makeFrame(s); }
+        fin[k] = o.kind == 2 ? f1 : f0;          // kind 0: integrate at T0; kind 2: integrate at T1
+        fde[k] = f0;                             // kind 1: de-integrate at T0; kind 2: de-integrate at T0
+        fr.TinvIn[k] = fin[k].Tinv; fr.TinvDe[k] = fde[k].Tinv;
+        fr.bits[k] = o.kind == 0 ? 1u : o.kind == 1 ? 2u : 3u;
+        BatchMarchOp& m = ma.op[k];
+        m.T = fin[k].T; m.Tinv = fin[k].Tinv;
+        m.depth = o.data.d_depthData; m.color = reinterpret_cast<const uint32_t*>(o.data.d_colorData);
+        m.marches = (o.kind != 1 && !s->externalAlloc) ? 1u : 0u;      // a de-integration neither allocates nor frees
+        m.texel = (fast && o.data.d_colorData && !o.d_texels) ? s->btexel[b][k] : nullptr;
+        opsCount += o.kind == 2 ? 2u : 1u;
+    }
+    const Frame fl = fin[n - 1];                // (the last pose set above is the last operator's: what a compactify / garbage collection behind the batch refers to)
+    bc.cam = s->cam;
+    bc.numBuckets = fl.numBuckets; bc.maxChain = fl.maxChain; bc.numSDFBlocks = fl.numSDFBlocks;
+    bc.voxelSize = fl.voxelSize; bc.maxIntegrationDistance = fl.maxIntegrationDistance; bc.truncScale = fl.truncScale; bc.truncation = fl.truncation;
+    bc.shardLo = fl.shardLo; bc.shardHi = fl.shardHi; bc.nOps = n;
+    const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
+    hipLaunchKernelGGL(k_batch_march, dim3(div_up(tiles, 4), n), dim3(256), 0, ps, dv, s->bd, bc, ma);
+    // the table look-ups wait for whatever frees table entries (the last garbage collection); the march above does not
+    if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
+    hipLaunchKernelGGL(k_batch_bin, dim3(1024), dim3(256), 0, ps, dv, s->bd, bc);
+    hipLaunchKernelGGL(k_batch_place, dim3(PLACE_WGS), dim3(256), 0, ps, dv, s->bd, bc, fr);
+    if (s->overlap) {
+        BF_HIP_TRY(hipEventRecord(s->evPrep[b], ps));
+        BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
+    }
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (s->timing) {
+        if (s->eventsUsed == s->events.size()) {
+            hipEvent_t e0, e1;
+            BF_HIP_TRY(hipEventCreate(&e0));
+            BF_HIP_TRY(hipEventCreate(&e1));
+            s->events.push_back({e0, e1});
+        }
+        ev = &s->events[s->eventsUsed++];
+        s->opsTimed += opsCount;
+        s->imagesTimed += n;
+        BF_HIP_TRY(hipEventRecord(ev->first, s->stream));
+    }
+    const int acc = s->timing ? 1 : 0;
+    if (fast) {
+        BatchUpdApxArgs ua;
+        memset(&ua, 0, sizeof ua);
+        ua.nOps = n;
+        for (uint32_t k = 0; k < n; ++k) {
+            ua.op[k].in = makeApxPose(fin[k]); ua.op[k].de = makeApxPose(fde[k]);
+            ua.op[k].tex = ops[k].d_texels ? reinterpret_cast<const uint2*>(ops[k].d_texels) : ma.op[k].texel;
+            if (ops[k].data.d_colorData) ua.liveMask |= 3u << (2u * k);      // CUDASceneRepHashSDF.cu:441-448: no colour data, no update
+        }
+        const ApxCam ac = makeApxCam(fl);
+        if (s->cvtRne) hipLaunchKernelGGL((k_update_batch_apx<true>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, ac, ua, acc);
+        else hipLaunchKernelGGL((k_update_batch_apx<false>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, ac, ua, acc);
+    } else {
+        BatchUpdColArgs ua;
+        memset(&ua, 0, sizeof ua);
+        ua.nOps = n;
+        for (uint32_t k = 0; k < n; ++k) {
+            ua.op[k].in = makeUpdPose(fin[k]); ua.op[k].de = makeUpdPose(fde[k]);
+            ua.op[k].depth = ops[k].data.d_depthData; ua.op[k].color = reinterpret_cast<const uchar4*>(ops[k].data.d_colorData);
+        }
+        hipLaunchKernelGGL(k_update_batch_col, dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, makeUpdCam(fl), ua, acc, s->forceExactDiv ? 1 : 0);
+    }
+    if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
+    if (s->overlap) { BF_HIP_TRY(hipEventRecord(s->evUpd[b], s->stream)); s->updRecorded[b] = true; }
+    BF_HIP_TRY(hipGetLastError());
+    useBuf(s, b);
+    s->compactStale = true;
+    // the frustum list of the LAST pose inside the union list: the blocks with the last operator's bit (integration pose, or the pose of a de-integration)
+    s->gcMask = (ops[n - 1].kind == 1 ? 2u : 1u) << (2u * (n - 1));
+    for (uint32_t k = 0; k < n; ++k) s->numIntegrated += ops[k].kind == 0 ? 1u : ops[k].kind == 1 ? (uint32_t)-1 : 0u;
     return BF_OK;
 }
 
@@ -2176,14 +2366,17 @@ int bf_scene_reset(bf_scene* s) {                                  // CUDASceneR
     memcpy(s->params.m_rigidTransformInverse, I.e, 64);
     s->params.m_numOccupiedBlocks = 0;
     BF_TRY_RC(syncAll(s));
-    s->compactStale = false; s->barrierPending = false; s->pendingEv = nullptr;
+    s->compactStale = false; s->gcMask = 0; s->barrierPending = false; s->pendingEv = nullptr;
+
     for (bool& u : s->updRecorded) u = false;
     for (int b = 0; b < bf_scene::NBMAX; ++b) BF_HIP_TRY(hipMemsetAsync(s->ccnt[b], 0, 16, s->stream));
     const size_t numEntries = (size_t)s->params.m_hashNumBuckets * BF_HASH_BUCKET_SIZE;
     BF_HIP_TRY(hipMemsetAsync(s->d.vox, 0, (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel), s->stream));
     hipLaunchKernelGGL(k_reset, dim3(2048), dim3(256), 0, s->stream, s->d, s->params.m_numSDFBlocks, (uint32_t)numEntries,
                        s->dedupeSize);
+    if (s->batchReady) hipLaunchKernelGGL(k_batch_reset, dim3(2048), dim3(256), 0, s->stream, s->bd, s->params.m_hashNumBuckets);
     BF_HIP_TRY(hipGetLastError());
+    if (s->prep) BF_HIP_TRY(hipStreamSynchronize(s->stream));      // the next operator's allocation runs on the preparation stream
     return BF_OK;
 }
 
@@ -2239,6 +2432,31 @@ int bf_scene_reintegrate(bf_scene* s, const float oldT[16], const float newT[16]
     return runOperator(s, 2, f, fo, data);
 }
 
+// A batch of operators in the serial order ops[0] .. ops[n - 1] (MI355X addition; DepthSensing.cpp:854-902 issues them one by one): the same table, heap and
+// voxels as bf_scene_integrate / _deintegrate / _reintegrate called in that order, in four launches and one pass over the touched blocks.
+int bf_scene_run_batch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n, const bf_depth_camera_params* cam) {
+    BF_REQUIRE(s && ops && cam, "null argument");
+    BF_REQUIRE(n >= 1 && n <= BF_SCENE_BATCH_MAX, "1 .. BF_SCENE_BATCH_MAX operators per batch");
+    BF_REQUIRE(cam->m_imageWidth > 0 && cam->m_imageHeight > 0, "empty image");
+    for (uint32_t k = 0; k < n; ++k) {
+        BF_REQUIRE(ops[k].kind >= 0 && ops[k].kind <= 2, "unknown operator kind");
+        BF_REQUIRE(ops[k].data.d_depthData, "d_depthData is null");
+    }
+    s->cam = *cam; s->haveCam = true;
+    if (s->allocComm) {          // the divided march is a per-operator exchange: issue the operators one by one
+        for (uint32_t k = 0; k < n; ++k) {
+            const bf_scene_batch_op& o = ops[k];
+            if (o.wait_event) s->pendingEv = (hipEvent_t)o.wait_event;
+            if (o.d_texels) s->frameTexels = reinterpret_cast<const uint2*>(o.d_texels);
+            int rc = o.kind == 0 ? bf_scene_integrate(s, o.T0, &o.data, cam, nullptr) : o.kind == 1 ? bf_scene_deintegrate(s, o.T0, &o.data, cam, nullptr)
+                                                                                                     : bf_scene_reintegrate(s, o.T0, o.T1, &o.data, cam);
+            if (rc) return rc;
+        }
+        return BF_OK;
+    }
+    return runBatch(s, ops, n);
+}
+
 int bf_scene_set_last_rigid_transform_and_compactify(bf_scene* s, const float T[16], const bf_depth_camera_params* cam) {
     BF_REQUIRE(s && T && cam, "null argument");
     s->cam = *cam; s->haveCam = true;
@@ -2252,9 +2470,10 @@ int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
     BF_REQUIRE(s, "null scene");
     if (!s->haveCam) return BF_OK;                                  // nothing was ever compactified
     BF_TRY_RC(beginExclusive(s));
-    if (s->compactStale) BF_TRY_RC(launchCompactify(s));
+    uint32_t needMask = 0;
+    if (s->compactStale) { if (s->gcMask) needMask = s->gcMask; else BF_TRY_RC(launchCompactify(s)); }
     const Frame f = makeFrame(s);
-    hipLaunchKernelGGL(k_gc_identify, dim3(4096), dim3(256), 0, s->stream, s->d, f);
+    hipLaunchKernelGGL(k_gc_identify, dim3(4096), dim3(256), 0, s->stream, s->d, f, needMask);
     hipLaunchKernelGGL(k_gc_delete, dim3(NBINS), dim3(1024), 0, s->stream, s->d, f);
     hipLaunchKernelGGL(k_gc_finish, dim3(1), dim3(256), 0, s->stream, s->d);
     hipLaunchKernelGGL(k_compact_count, dim3(s->gridCompact), dim3(256), 0, s->stream, s->d);
@@ -2262,7 +2481,9 @@ int bf_scene_garbage_collect(bf_scene* s) {                          // :110-126
     hipLaunchKernelGGL(k_list_commit, dim3(1), dim3(1), 0, s->stream, s->d);
     std::swap(s->d.allocList, s->d.allocListAlt);
     BF_HIP_TRY(hipGetLastError());
-    BF_TRY_RC(launchCompactify(s));
+    // The list in d.compact refers to positions of the allocated-block list before its compaction: nothing usable.  It is rebuilt when somebody needs the
+    // frustum list of the last pose (the accessors, a garbage collection with no operator in between); every operator builds its own list anyway.
+    s->compactStale = true; s->gcMask = 0;
     return endExclusive(s);
 }
 
@@ -2379,6 +2600,7 @@ int bf_scene_kernel_timing(bf_scene* s, int enable) {
     s->timing = enable != 0;
     s->eventsUsed = 0;
     s->opsTimed = 0;
+    s->imagesTimed = 0;
     BF_HIP_TRY(hipMemsetAsync(s->d.occSum, 0, 3 * sizeof(unsigned long long), s->stream));
     return BF_OK;
 }
@@ -2400,6 +2622,12 @@ int bf_scene_kernel_timing_read(bf_scene* s, uint32_t* count, float* total_ms) {
 
 int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlocks, uint32_t* numOps) {
     return bf_scene_kernel_timing_blocks(s, sumOccupiedBlocks, nullptr, nullptr, numOps);
+}
+
+int bf_scene_kernel_timing_images(bf_scene* s, uint32_t* numImages) {
+    BF_REQUIRE(s && numImages, "null argument");
+    *numImages = s->imagesTimed;
+    return BF_OK;
 }
 
 int bf_scene_kernel_timing_blocks(bf_scene* s, uint64_t* sumOperatorBlocks, uint64_t* visitedPlain, uint64_t* visitedFused, uint32_t* numOps) {

@@ -206,6 +206,22 @@ BF_API int bf_scene_get_arith(bf_scene* s, int* mode);
 BF_API int bf_scene_reintegrate(bf_scene* s, const float old_cam_to_world[16], const float new_cam_to_world[16],
                                 const bf_depth_camera_data* data, const bf_depth_camera_params* cam);
 /* garbageCollect()                                         :110-126              */
+/* A batch of operators (MI355X addition).  DepthSensing.cpp:854-902 issues the up to s_maxFrameFixes re-integrations of a frame one after the other, each
+ * with its own allocation, compactify and passes over the volume; bf_scene_run_batch takes them together - kind 0: integrate(T0), 1: deIntegrate(T0),
+ * 2: deIntegrate(T0) + integrate(T1) of the same frame - and leaves the hash table, the heap and every voxel exactly as the same calls issued in that order
+ * would (CUDASceneRepHashSDF.h:65-155), with one ray march over all frames, one placement, one union block list and ONE pass of the voxel update in which
+ * every touched block is loaded once, updated by the batch's operators in order and stored once.  `wait_event` (optional hipEvent_t): the operator's frame is
+ * complete when the event is; `d_texels` (optional): the frame as interleaved texels (bf_image_interleave_texels).  cam as in bf_scene_integrate. */
+#define BF_SCENE_BATCH_MAX 12
+typedef struct bf_scene_batch_op {
+    int32_t kind;
+    int32_t reserved;
+    float T0[16], T1[16];
+    bf_depth_camera_data data;
+    const void* d_texels;
+    void* wait_event;
+} bf_scene_batch_op;
+BF_API int bf_scene_run_batch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n, const bf_depth_camera_params* cam);
 BF_API int bf_scene_garbage_collect(bf_scene* s);
 /* setLastRigidTransformAndCompactify(T)                    :136-139
  * (needs the camera of the following ray cast / GC for the frustum test)         */
@@ -240,6 +256,8 @@ BF_API int bf_scene_kernel_timing_occupied(bf_scene* s, uint64_t* sumOccupiedBlo
 /* the same plus the sum of the list lengths per LAUNCH, separately for the plain (integrate / de-integrate) and the fused
  * re-integration kernel: a fused launch visits the union of its two frustum lists once (each voxel read and written once), so its
  * algorithmic traffic is unionBlocks * (512*24 + 32) B, not 2 B                                                              */
+/* frames (depth + colour images) the timed launches sampled: one per operator, n per batch of n */
+BF_API int bf_scene_kernel_timing_images(bf_scene* s, uint32_t* numImages);
 BF_API int bf_scene_kernel_timing_blocks(bf_scene* s, uint64_t* sumOperatorBlocks, uint64_t* visitedPlain, uint64_t* visitedFused, uint32_t* numOps);
 
 

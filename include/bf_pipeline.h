@@ -334,6 +334,10 @@ BF_API int bf_pipeline_destroy(bf_pipeline* p);
 /* Multi-GPU mode "volume shard": every rank runs the (bit-deterministic) bundling on the whole stream and integrates only
  * its hash-bucket shard of the volume (bf_scene_set_shard).  Call before the first frame. */
 BF_API int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t world);
+/* Batched volume operators (default on): the integration of a frame and the up to s_maxFrameFixes re-integrations of the next frame (DepthSensing.cpp:854-902,
+ * :966-1095) are issued as ONE bf_scene_run_batch when that frame's garbage collection is posted - same order, same volume as one operator at a time
+ * (enable = 0), which stays available for comparison. */
+BF_API int bf_pipeline_set_volume_batching(bf_pipeline* p, int enable);
 /* Lagged solve for the whole loop (bf_online_bundler_set_solve_lag on a stream of the pipeline's): the chunk solves leave the frame
  * loop's critical path and are applied `lag` frames after the frame that closed the chunk.  0 = serial order (default; also
  * BF_PIPELINE_SOLVE_LAG in the environment).  Only between frames. */

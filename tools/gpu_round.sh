@@ -36,6 +36,11 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
       (cd "$ROOT" && timeout 400 python bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-260 "$OUT/bench.json"; tail -3 "$OUT/bench.err") ;;
     bench_driver)   # the driver's invocation
       (cd "$ROOT" && timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"; cut -c1-260 "$OUT/bench_driver.json"; tail -3 "$OUT/bench_driver.err") ;;
+    bench_ab)       # the driver's window with the frame's TSDF operators batched (default) and one at a time: same code, same box
+      for B in on off; do
+        (cd "$ROOT" && timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --volume-batching $B $BENCH_ARGS > "$OUT/bench_batching_$B.json" 2> "$OUT/bench_batching_$B.err"; python -c "
+import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; print('$B', round(j['value'],1), 'fps', {k: (round(r[k],3) if isinstance(r[k], float) else r[k]) for k in ('avg_launch_us','us_per_operator','frac','frac_per_operator','launches','operators','blocks_visited_per_launch')}, j['config']['host_thread_ms_per_frame'], j['config']['volume_thread'])"; tail -2 "$OUT/bench_batching_$B.err")
+      done ;;
     trace)
       rm -rf /tmp/r_trace
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --steps 20 --warmup 5 --one-contract $BENCH_ARGS > "$OUT/bench_traced.json" 2> /dev/null)

@@ -20,14 +20,15 @@ def update_kernel_sha():
     version of these kernels (the committed per-block traffic went stale silently when the kernel changed)."""
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bundlefusion_amd", "csrc", "tsdf.hip")).read()
     a, b = src.index("// voxel update, column form: ONE WAVE per SDF block"), src.index("__global__ void k_probe_cvt")
-    return hashlib.sha256(src[a:b].encode()).hexdigest()
+    batch = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bundlefusion_amd", "csrc", "tsdf_batch.h")).read()
+    return hashlib.sha256((src[a:b] + batch[batch.index("// the batch's voxel update, fast contract"):]).encode()).hexdigest()
 
 
 def totals(db, counter):
     c = sqlite3.connect(db)
     out = {}
     for name, n, tot in c.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
-        fused = "k_reupdate" in name or "k_update_col<2>" in name or "k_update_apx<2" in name          # fused re-integration (any of the voxel-update kernels)
+        fused = "k_reupdate" in name or "k_update_col<2>" in name or "k_update_apx<2" in name or "k_update_batch" in name      # union-list launches: fused re-integration, batch
         plain = not fused and ("k_update<" in name or "k_update_col<" in name or "k_update_apx<" in name)
         key = "fused" if fused else ("plain" if plain else None)
         if key:
