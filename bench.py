@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--both-contracts", action="store_true", default=True, help="(1 GPU) also measure the other contract, reported as other_contract")
     ap.add_argument("--one-contract", dest="both_contracts", action="store_false")
     ap.add_argument("--solve-lag", type=int, default=int(os.environ.get("BF_BENCH_SOLVE_LAG", "0")),
-                    help="0: the reference's serial order (chunk solves inside the frame that closes the chunk).  L in 1..10: the chunk solves run on their own "
+                    help="0: the reference's serial order (chunk solves inside the frame that closes the chunk).  L in 2..10 (at least the frame loop's depth): the chunk solves run on their own "
                          "thread and stream and are applied exactly L frames later (bf_pipeline_set_solve_lag) - the reference's optimiser thread "
                          "(FriedLiver.cpp:112-143) with a defined hand-over; same solves, same count, nothing skipped")
     ap.add_argument("--volume-batching", choices=["on", "off"], default="on", help="on (library default): the frame loop issues a frame's TSDF operators - the integration of the previous "
@@ -69,9 +69,9 @@ def main():
                     "off: one operator at a time (the rounds 1-4 path), for comparison.  Same volume either way (tests/test_tsdf_batch_gpu.py)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary block `sweep` (BASELINE configs[4] in small: the 1280x960 @2 mm re-integration sweep, the "
                     "workload north_star's >= 6x scaling target is quoted on; ~20 s, most of it rendering 24 frames on the host)")
-    ap.add_argument("--long-stream", type=int, default=0, help="also run a stream of this many frames from frame 0 through a fresh pipeline and report it as `long_stream` "
-                    "(2000: BASELINE configs[2], the stride-1 loop-closure stream; 5000: configs[3], 2.5 loops + vertical sinusoid).  Rendering takes ~1 s of host time per "
-                    "16 frames, which is why it is not part of the default run")
+    ap.add_argument("--long-stream", type=int, default=2000, help="also run a stream of this many frames from frame 0 through a fresh pipeline and report it as `long_stream` "
+                    "(2000, the default: BASELINE configs[2], the stride-1 loop-closure stream, the one tests/golden/oracle_stream_2000.npz holds the oracle's results for; "
+                    "5000: configs[3], 2.5 loops + vertical sinusoid; 0: skip).  Rendering takes ~1 s of host time per 16 frames (2000 frames: ~2 minutes, untimed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the stream the CPU baseline processes (three local chunks: the last ten frames "
                     "run with the re-integration queue saturated, like the timed window of the GPU leg)")
@@ -386,29 +386,48 @@ def main():
     del frames, feed
     # The secondary blocks must not cost the line its headline: an exception becomes {"error": ...}; a collective that never returns (the sweep's RCCL
     # communicator is created here, after the measurement) is cut off by a watchdog that prints the line without the block and ends every rank.
+    import threading
+    line_lock = threading.Lock()
+    line_state = {"printed": False}
+
+    def print_line():             # the ONE JSON line: whoever gets here first prints it (the main path, or a watchdog that gives a secondary block up)
+        with line_lock:
+            if line_state["printed"]:
+                return
+            line_state["printed"] = True
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+
     def secondary(name, fn, limit_s):
-        import threading
+        state = {"done": False}
 
         def give_up():
-            if rank == 0:
-                out[name] = {"error": "no result after %d s (abandoned; the headline measurement above it is complete)" % limit_s}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            with line_lock:
+                if state["done"] or line_state["printed"]:
+                    return
+                if rank == 0:
+                    out[name] = {"error": "no result after %d s (abandoned; the headline measurement above it is complete)" % limit_s}
+            print_line()
+            os._exit(3)           # a block that never returned (a collective that hung): the line is out, the exit status says the run was cut short
         wd = threading.Timer(limit_s, give_up); wd.daemon = True; wd.start()
         try:
-            return fn()
+            r = fn()
         except Exception as e:      # noqa: BLE001 - reported in the line
-            return {"error": "%s: %s" % (type(e).__name__, e)}
-        finally:
-            wd.cancel()
+            r = {"error": "%s: %s" % (type(e).__name__, e)}
+        wd.cancel()
+        with line_lock:
+            state["done"] = True
+        return r
     if not args.no_sweep:
         sw = secondary("sweep", lambda: sweep_block(args, rank, world), 300)
         if rank == 0:
-            out["sweep"] = sw
+            with line_lock:
+                out["sweep"] = sw
     if args.long_stream and world == 1:
-        out["long_stream"] = secondary("long_stream", lambda: long_stream_block(args, K, W, H), 1500)
-    if rank == 0:
-        print(json.dumps(out))
+        ls = secondary("long_stream", lambda: long_stream_block(args, K, W, H), 1500)
+        with line_lock:
+            out["long_stream"] = ls
+    print_line()
     if world > 1:
         dist.destroy_process_group()
 

@@ -145,6 +145,17 @@ def camera_params(width, height, fx, fy, mx, my, dmin=0.1, dmax=4.0):
     return c
 
 
+def alloc_comm_capacity(W, H, voxel, world):
+    """Keys per rank and operator for bf_scene_set_alloc_comm / bf_pipeline_set_comm: twice the estimate of the distinct in-frustum blocks the rays of a W x H frame
+    cross (0.22 per pixel at 2 mm, scaling with 1 / voxel^2; tests/test_host_cpu.py holds it against measured key counts), divided over the ranks, as a power of
+    two >= 65536."""
+    est = 0.22 * W * H * (0.002 / voxel) ** 2
+    cap = 1 << 16
+    while cap < 2.0 * est / max(world, 1):
+        cap <<= 1
+    return cap
+
+
 class SceneRepHashSDF:
     """Python view of `bf_scene` (== the reference's CUDASceneRepHashSDF)."""
 
@@ -196,8 +207,9 @@ class SceneRepHashSDF:
     def set_external_alloc(self, enable=True):
         check(lib.bf_scene_set_external_alloc(self._h, int(enable)))
 
-    def set_alloc_comm(self, comm, capacity_keys=1 << 15):
-        """The operators' own allocation with the ray march divided over the ranks of `comm` (capi.Comm or None): bf_scene_set_alloc_comm."""
+    def set_alloc_comm(self, comm, capacity_keys=1 << 17):
+        """The operators' own allocation with the ray march divided over the ranks of `comm` (capi.Comm or None): bf_scene_set_alloc_comm.  capacity_keys: see
+        alloc_comm_capacity(W, H, voxel, world) (the default covers 640x480 @4 mm on one rank four times over)."""
         check(lib.bf_scene_set_alloc_comm(self._h, comm._h if comm is not None else None, int(capacity_keys)))
         self._alloc_comm = comm          # keep the callback alive
 
@@ -968,9 +980,12 @@ class Pipeline:
         """one bf_scene_run_batch per frame (default) or one operator at a time: bf_pipeline_set_volume_batching"""
         check(lib.bf_pipeline_set_volume_batching(self._h, int(enable)))
 
-    def set_comm(self, comm, capacity_keys=1 << 15):
+    def set_comm(self, comm, capacity_keys=None):
         """Divide the allocation's ray march of every TSDF operator of this loop over the ranks of `comm` (bf_pipeline_set_comm; the volume must be
-        sharded with set_volume_shard(rank, world) of the same communicator)."""
+        sharded with set_volume_shard(rank, world) of the same communicator).  capacity_keys: keys per rank and operator; None sizes it from the integration
+        resolution and the voxel size for ONE rank's share being the whole frame (alloc_comm_capacity with world = 1: never too small)."""
+        if capacity_keys is None:
+            capacity_keys = alloc_comm_capacity(self.gas.s_integrationWidth, self.gas.s_integrationHeight, self.gas.s_SDFVoxelSize, 1)
         check(lib.bf_pipeline_set_comm(self._h, comm._h if comm is not None else None, int(capacity_keys)))
         self._comm = comm
 

@@ -2137,6 +2137,9 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     while (p->begun.size() + 1 > p->depth) BF_TRY(plRestFront(p));
     if (ahead && got) p->deferred = (int)frame;
     else if (p->im->currFrame > 0) {
+        // no new frame although one was offered (the image manager is full, CUDAImageManager.cpp:22-35): `frame` is the last accepted frame, whose chain was
+        // enqueued above and whose body has not run - every frame in flight completes first, then this call is the iteration past the end of the sequence
+        BF_TRY(plFlush(p));
         BF_TRY(plBody(p, frame, got != 0));
         if (got) BF_HIP_TRY(hipStreamSynchronize(sa));      // (the detection read the frame's input set on the bundling stream: done before the set's next ingest, two frames on)
     }
@@ -2271,6 +2274,10 @@ int bf_pipeline_set_solve_lag(bf_pipeline* p, uint32_t lag) {
     BF_REQUIRE(p, "null pipeline");
     BF_TRY(plFlush(p));
     BF_REQUIRE(!p->ob->job.active, "a lagged solve is still waiting for its frame");
+    // The call that delivers frame n enqueues the chain of frame n - 1 BEFORE it runs the body of frame n - depth (where a chunk's job gets its frame of
+    // application): a lag below the depth would ask for a chain that is already enqueued to see the result.  (lag >= depth: exactly `lag` frames, as the oracle
+    // loop under the same lag - tests/test_pipeline_gpu.py, lag = depth included.)
+    BF_REQUIRE(lag == 0 || !p->lookahead || lag >= p->depth, "the solve lag must be 0 or at least the frame loop's depth (BF_PIPELINE_DEPTH, default 2)");
     if (lag && !p->sSolve) {
         // Not the lowest priority: measured (gpurun r04b) the cooperative PCG - up to 64 workgroups meeting at a grid barrier 450 times per global solve - is
         // then starved by the volume stream's wide launches and a chunk's solves take longer than the ten frames they have

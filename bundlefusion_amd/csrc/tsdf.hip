@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <strings.h>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -282,12 +283,13 @@ BF_DEV void collectCandidate(const Dev& d, const Collect& c, i3 b) {
 }
 
 // Batched allocation (bf_scene_run_batch): ONE march over the frames of all operators of a batch.  The march touches neither the hash table nor the
-// bins: every distinct in-frustum block key of operator `op` is claimed in the batch's own key set together with the SMALLEST operator index that needs
-// it (the operator that allocates it in the serial order: operators before it must not see the block, operators after it find it present).  The table
+// bins: every distinct in-frustum block key of operator `op` is claimed in the batch's own key set together with the set of operators that need it.  The
+// FIRST of them allocates it in the serial order (operators before it must not see the block, operators after it find it present); the others matter only
+// when that allocation fails (heap or collision window exhausted): the serial operators would each try again, and so does the batch's replay.  The table
 // look-up, the ownership test and the binning per operator follow in k_batch_bin, behind whatever still has to free table entries (garbage collection).
 struct BatchSink {
     unsigned long long* set; uint32_t mask;      // 64-bit keys, open addressing (EMPTY64 = free)
-    uint32_t* opMin;                             // per slot: smallest operator index (0xFFFFFFFF = none)
+    uint32_t* opMask;                            // per slot: bit k = operator k needs the key
     uint32_t* list; uint32_t* count; uint32_t cap;   // slots claimed by this batch, in arrival order (the order reaches no result: k_batch_place sorts)
     uint32_t* flags;                             // [0] bit 0: a home bucket cannot take all its new keys (k_batch_bin), bit 1: the slot list overflowed
     uint32_t op;
@@ -304,7 +306,7 @@ BF_DEV void claimCandidate(const Dev& d, const BatchSink& bs, i3 b) {
             if (pos < bs.cap) bs.list[pos] = slot;
             else { atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW); atomicOr(bs.flags, 2u); }      // the set is cleared as a whole behind this batch
         }
-        if (old == EMPTY64 || old == key) { atomicMin(&bs.opMin[slot], bs.op); return; }
+        if (old == EMPTY64 || old == key) { atomicOr(&bs.opMask[slot], 1u << bs.op); return; }
         slot = (slot + 1) & bs.mask;
     }
     atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
@@ -429,6 +431,7 @@ __global__ void k_collect_release(Dev d, Collect c) {
 __global__ __launch_bounds__(256) void k_alloc_ingest(Dev d, Frame f, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ count, uint32_t capacity) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t n = min(count[0], capacity);
+    if (count[0] > capacity && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW);      // the collecting rank dropped keys: every rank that ingests its list reports it
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) emitCandidate(d, f, unpackKey(keys[i]));
 }
 
@@ -2006,7 +2009,7 @@ int ensureBatch(bf_scene* s) {
     int rc = BF_OK;
 #define A(ptr, cnt) if (rc == BF_OK) rc = devAlloc(s, &(ptr), (cnt))
     A(bd.set, (size_t)ds);
-    A(bd.opMin, (size_t)ds);
+    A(bd.opMask, (size_t)ds);
     A(bd.candList, (size_t)ds / 2);
     A(bd.candCount, 1);
     A(bd.bins, (size_t)BMAX * NBINS * BINCAP);
@@ -2200,7 +2203,11 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
     int arith = BF_TSDF_ARITH_FAST;
-    if (const char* e = getenv("BF_TSDF_ARITH")) arith = strcmp(e, "exact") == 0 ? BF_TSDF_ARITH_EXACT : BF_TSDF_ARITH_FAST;
+    if (const char* e = getenv("BF_TSDF_ARITH")) {
+        if (strcasecmp(e, "exact") == 0) arith = BF_TSDF_ARITH_EXACT;
+        else if (strcasecmp(e, "fast") == 0) arith = BF_TSDF_ARITH_FAST;
+        else { set_error("BF_TSDF_ARITH must be 'fast' or 'exact' (got '%s')", e); bf_scene_destroy(s); *out = nullptr; return BF_ERR_INVALID_ARG; }
+    }
     return bf_scene_set_arith(s, arith);
 }
 

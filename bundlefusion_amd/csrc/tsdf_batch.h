@@ -13,10 +13,11 @@
 
 constexpr uint32_t BMAX = BF_SCENE_BATCH_MAX;
 static_assert(2 * BMAX <= 32, "two membership bits per operator in the 32-bit flags word of a list entry");
+static_assert(BMAX <= 12 && (uint64_t)NBINS * BINCAP <= (1u << 20), "record packing: operator in 4 bits, needing operators in 12, rank among an operator's keys in 20");
 
 struct BatchDev {
     unsigned long long* set; uint32_t setMask;   // the batch's key set (own storage: the per-operator path releases its set key by key)
-    uint32_t* opMin;                             // per slot: first operator that needs the key
+    uint32_t* opMask;                            // per slot: the operators that need the key (bit k = operator k)
     uint32_t* candList; uint32_t* candCount; uint32_t candCap;
     BinRec* bins;                                // [BMAX][NBINS][BINCAP]
     uint32_t* binCount;                          // [BMAX][NBINS]
@@ -38,7 +39,7 @@ struct BatchFrusta { m44 TinvIn[BMAX], TinvDe[BMAX]; uint32_t bits[BMAX]; };
 
 __global__ void k_batch_reset(BatchDev bd, uint32_t numBuckets) {
     const uint32_t stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t i = gid; i <= bd.setMask; i += stride) { bd.set[i] = EMPTY64; bd.opMin[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = gid; i <= bd.setMask; i += stride) { bd.set[i] = EMPTY64; bd.opMask[i] = 0u; }
     for (uint32_t i = gid; i < numBuckets; i += stride) bd.bucketCnt[i] = 0u;
     for (uint32_t i = gid; i < BMAX * NBINS; i += stride) bd.binCount[i] = 0u;
     if (gid == 0) { bd.candCount[0] = 0u; bd.flags[0] = 0u; }
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_batch_march(Dev d, BatchDev bd, BatchCo
     f.voxelSize = c.voxelSize; f.maxIntegrationDistance = c.maxIntegrationDistance; f.truncScale = c.truncScale; f.truncation = c.truncation;
     f.shardLo = c.shardLo; f.shardHi = c.shardHi; f.weightMax = 0.0f;
     BatchSink bs;
-    bs.set = bd.set; bs.mask = bd.setMask; bs.opMin = bd.opMin; bs.list = bd.candList; bs.count = bd.candCount; bs.cap = bd.candCap; bs.flags = bd.flags; bs.op = op;
+    bs.set = bd.set; bs.mask = bd.setMask; bs.opMask = bd.opMask; bs.list = bd.candList; bs.count = bd.candCount; bs.cap = bd.candCap; bs.flags = bd.flags; bs.op = op;
     TexelOut tx; tx.color = o.color; tx.texel = o.texel;
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     marchTile<2>(d, f, o.depth, Collect{}, tx, bs, tile, o.marches != 0u, setAll[threadIdx.x >> 6], listAll[threadIdx.x >> 6]);
@@ -105,8 +106,9 @@ __global__ __launch_bounds__(256) void k_batch_bin(Dev d, BatchDev bd, BatchComm
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = bd.candList[i];
         const uint64_t key = bd.set[slot];
-        const uint32_t op = bd.opMin[slot];
-        bd.set[slot] = EMPTY64; bd.opMin[slot] = 0xFFFFFFFFu;      // nobody probes the set during this kernel
+        const uint32_t need = bd.opMask[slot];                      // != 0: the claimant set its bit before the march ended
+        const uint32_t op = (uint32_t)__ffs((int)need) - 1u;         // the first operator that needs the block allocates it
+        bd.set[slot] = EMPTY64; bd.opMask[slot] = 0u;               // nobody probes the set during this kernel
         const i3 b = unpackKey(key);
         const uint32_t h = hashPos(c.numBuckets, b);
         if (h < c.shardLo || h >= c.shardHi) continue;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void k_batch_bin(Dev d, BatchDev bd, BatchComm
         const uint32_t bin = (uint32_t)(((uint64_t)h * NBINS) / c.numBuckets);
         const uint32_t pos = atomicAdd(&bd.binCount[op * NBINS + bin], 1u);
         if (pos >= BINCAP) { atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW); continue; }
-        BinRec r; r.key = key; r.bucket = h; r.aux = op;
+        BinRec r; r.key = key; r.bucket = h; r.aux = (need << 4) | op;      // aux: operator in the low 4 bits, above them every operator that needs the key
         bd.bins[((size_t)(op * NBINS + bin)) * BINCAP + pos] = r;
         // a home bucket that cannot take all its new keys sends some of them through the collision window of OTHER buckets: the one case in which the
         // operators' placements depend on each other beyond the bucket itself - k_batch_place then replays the batch operator by operator
@@ -171,7 +173,7 @@ BF_DEV void batchAppendBlock(const Dev& d, uint32_t keep, uint64_t key, int32_t 
     __syncthreads();
 }
 
-// LDS bitonic sort by (home bucket, operator [aux], key): inside a bucket the serial order of slot consumption
+// LDS bitonic sort by (home bucket, operator [low 4 bits of aux], key): inside a bucket the serial order of slot consumption
 BF_DEV void ldsBitonicSort3(SortLds& s, uint32_t npad) {
     for (uint32_t k = 2; k <= npad; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -182,7 +184,7 @@ BF_DEV void ldsBitonicSort3(SortLds& s, uint32_t npad) {
                 const uint32_t bl = s.bucket[lo], bh = s.bucket[hi];
                 const uint32_t al = s.aux[lo], ah = s.aux[hi];
                 const uint64_t kl = s.key[lo], kh = s.key[hi];
-                const bool gt = (bl != bh) ? (bl > bh) : (al != ah) ? (al > ah) : (kl > kh);
+                const bool gt = (bl != bh) ? (bl > bh) : ((al & 15u) != (ah & 15u)) ? ((al & 15u) > (ah & 15u)) : (kl > kh);
                 if (gt == up) {
                     s.bucket[lo] = bh; s.bucket[hi] = bl;
                     s.key[lo] = kh; s.key[hi] = kl;
@@ -235,7 +237,7 @@ BF_DEV void batchPlaceBin(const Dev& d, const BatchDev& bd, const BatchCommon& c
     for (uint32_t k = 0; k < c.nOps; ++k) {
         const uint32_t nk = L.cnts[k * NBINS + bin];
         const BinRec* recs = bd.bins + ((size_t)(k * NBINS + bin)) * BINCAP;
-        for (uint32_t i = tid; i < nk; i += 256u) { const BinRec r = recs[i]; s.key[off + i] = r.key; s.bucket[off + i] = r.bucket; s.aux[off + i] = k; }
+        for (uint32_t i = tid; i < nk; i += 256u) { const BinRec r = recs[i]; s.key[off + i] = r.key; s.bucket[off + i] = r.bucket; s.aux[off + i] = r.aux; }
         off += nk;
     }
     for (uint32_t i = total + tid; i < npad; i += 256u) { s.key[i] = EMPTY64; s.bucket[i] = 0xFFFFFFFFu; s.aux[i] = 0xFFFFFFFFu; }
@@ -246,7 +248,7 @@ BF_DEV void batchPlaceBin(const Dev& d, const BatchDev& bd, const BatchCommon& c
     for (uint32_t k = 0; k < c.nOps; ++k) {
         if (L.cnts[k * NBINS + bin] == 0u) continue;      // block-uniform
         uint32_t cnt = 0;
-        for (uint32_t e = 0; e < E; ++e) { const uint32_t j = c0 + e; if (j < total && s.aux[j] == k) ++cnt; }
+        for (uint32_t e = 0; e < E; ++e) { const uint32_t j = c0 + e; if (j < total && (s.aux[j] & 15u) == k) ++cnt; }
         uint32_t incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
@@ -254,7 +256,7 @@ BF_DEV void batchPlaceBin(const Dev& d, const BatchDev& bd, const BatchCommon& c
         __syncthreads();
         uint32_t run = incl - cnt;
         for (uint32_t w = 0; w < wave; ++w) run += L.wscan[w];
-        for (uint32_t e = 0; e < E; ++e) { const uint32_t j = c0 + e; if (j < total && s.aux[j] == k) L.opIdx[j] = (uint16_t)run++; }
+        for (uint32_t e = 0; e < E; ++e) { const uint32_t j = c0 + e; if (j < total && (s.aux[j] & 15u) == k) L.opIdx[j] = (uint16_t)run++; }
         __syncthreads();
     }
     // slots (reads only: nobody else writes this bin's buckets)
@@ -270,10 +272,12 @@ BF_DEV void batchPlaceBin(const Dev& d, const BatchDev& bd, const BatchCommon& c
         uint32_t keep = 0, src = 0; uint64_t key = 0; int32_t ptr = 0;
         if (idx < total) {
             key = s.key[idx];
-            const uint32_t h = s.bucket[idx], k = s.aux[idx];
+            const uint32_t h = s.bucket[idx], k = s.aux[idx] & 15u;
             const uint32_t gi = L.opPre[k] + (uint32_t)L.opIdx[idx];
             bd.bucketCnt[h] = 0u;
-            if (gi >= L.opHeapFree[k]) atomicAdd(&d.stats[ST_DROPPED], 1u);                                  // heap exhausted
+            // heap exhausted: in the serial order operator k drops the key and so does every later operator that needs it (nothing gives a block back inside a
+            // batch on this path), each counting its own drop
+            if (gi >= L.opHeapFree[k]) atomicAdd(&d.stats[ST_DROPPED], (uint32_t)__popc(s.aux[idx] >> (4u + k)));
             else {
                 ptr = (int32_t)(d.heap[L.opHeapC[k] - gi] * (uint32_t)VOX);                                   // consumeHeap :536-540
                 src = L.opAllocBase[k] + gi;
@@ -287,6 +291,19 @@ BF_DEV void batchPlaceBin(const Dev& d, const BatchDev& bd, const BatchCommon& c
         batchAppendWave(d, keep, key, ptr, src);
     }
     __syncthreads();
+}
+
+// replay only: operator k could not place the key (heap or collision window exhausted) - the serial order's next operator that needs the block tries again
+BF_DEV void batchRequeue(const Dev& d, const BatchDev& bd, const BatchCommon& c, BatchLds& L, uint64_t key, uint32_t h, uint32_t need, uint32_t k) {
+    const uint32_t rest = need >> (k + 1u);
+    if (rest == 0u) return;
+    const uint32_t kn = k + (uint32_t)__ffs((int)rest);
+    const uint32_t bin = (uint32_t)(((uint64_t)h * NBINS) / c.numBuckets);
+    const uint32_t pos = atomicAdd(&L.cnts[kn * NBINS + bin], 1u);
+    if (pos >= BINCAP) { atomicSub(&L.cnts[kn * NBINS + bin], 1u); atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW); return; }
+    uint64_t* r = reinterpret_cast<uint64_t*>(bd.bins + ((size_t)(kn * NBINS + bin)) * BINCAP + pos);
+    storeThrough(r, key); storeThrough(r + 1, pack2(h, (need << 4) | kn));
+    atomicAdd(&L.opM[kn], 1u);
 }
 
 // Replay (one workgroup, the last one): the batch's operators one after the other, each bin by bin and followed by the walk of its bucket-full keys through
@@ -324,7 +341,7 @@ BF_DEV void batchReplay(const Dev& d, const BatchDev& bd, const BatchCommon& c, 
                     key = s.key[idx];
                     const uint32_t h = s.bucket[idx], gi = base + idx;
                     bd.bucketCnt[h] = 0u;
-                    if (gi >= heapFree) atomicAdd(&d.stats[ST_DROPPED], 1u);
+                    if (gi >= heapFree) { atomicAdd(&d.stats[ST_DROPPED], 1u); batchRequeue(d, bd, c, L, key, h, s.aux[idx] >> 4, k); }
                     else {
                         ptr = (int32_t)(d.heap[hc - gi] * (uint32_t)VOX);
                         src = ab + gi;
@@ -334,7 +351,7 @@ BF_DEV void batchReplay(const Dev& d, const BatchDev& bd, const BatchCommon& c, 
                         if (slot >= 0) { writeEntry(d, h, slot, key, ptr); keep = keepMask(c, fr, key, ptr, k); }
                         else {
                             const uint32_t ov = atomicAdd(&L.rp[2], 1u);
-                            if (ov < OVCAP) { uint64_t* o = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(o, key); storeThrough(o + 1, pack2(h, gi)); }
+                            if (ov < OVCAP) { uint64_t* o = reinterpret_cast<uint64_t*>(d.overflow + ov); storeThrough(o, key); storeThrough(o + 1, pack2(h, (gi << 12) | ((s.aux[idx] >> 4) & 0xFFFu))); }
                             else atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_OV_OVERFLOW);
                         }
                     }
@@ -350,7 +367,7 @@ BF_DEV void batchReplay(const Dev& d, const BatchDev& bd, const BatchCommon& c, 
         if (tid == 0) {                   // VoxelUtilHashSDF.h:614-654, keys in sorted order
             uint32_t newCounter = hc - Mp, dropped = 0;
             for (uint32_t q = 0; q < nov; ++q) {
-                const uint32_t h = s.bucket[q], gi = s.aux[q];
+                const uint32_t h = s.bucket[q], gi = s.aux[q] >> 12, need = s.aux[q] & 0xFFFu;      // (gi < NBINS * BINCAP = 2^20)
                 const uint32_t last = (h + 1) * BF_HASH_BUCKET_SIZE - 1;
                 const int32_t ptr = d.allocList[ab + gi].ptr;
                 bool done = false;
@@ -382,6 +399,7 @@ BF_DEV void batchReplay(const Dev& d, const BatchDev& bd, const BatchCommon& c, 
                     newCounter++;
                     d.heap[newCounter] = (uint32_t)ptr / (uint32_t)VOX;       // appendHeap :542-546
                     dropped++;
+                    batchRequeue(d, bd, c, L, s.key[q], h, need, k);
                 }
             }
             if (dropped) atomicAdd(&d.stats[ST_DROPPED], dropped);
@@ -475,7 +493,7 @@ __global__ __launch_bounds__(256) void k_batch_place(Dev d, BatchDev bd, BatchCo
     }
     for (uint32_t i = tid; i < nOps * NBINS; i += 256u) bd.binCount[i] = 0u;
     if (fl & 2u)          // the slot list overflowed: claimed slots nobody recorded - at this point every slot of the set belongs to a handled or dropped key
-        for (uint32_t i = tid; i <= bd.setMask; i += 256u) { bd.set[i] = EMPTY64; bd.opMin[i] = 0xFFFFFFFFu; }
+        for (uint32_t i = tid; i <= bd.setMask; i += 256u) { bd.set[i] = EMPTY64; bd.opMask[i] = 0u; }
 }
 
 // ---------------------------------------------------------------------------------------

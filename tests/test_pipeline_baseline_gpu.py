@@ -229,6 +229,65 @@ def test_loop_closure_stream_vs_oracle_loop(gpu):
     assert abs(ate(gt, vi) - ate(ot, vi)) < 1e-3 and abs(ate(gopt, vo) - ate(oopt, vo)) < 1e-3
 
 
+def test_config2_stream_2000_vs_oracle_fixture(gpu):
+    """BASELINE configs[2] AT ITS STATED LENGTH: 2000 frames of the S2 room from frame 0, stride 1, 640x480 @4 mm - the camera closes its loop at frame 1800,
+    frames 1800..1999 re-observe the start; 199 key frames in the global problem, the re-integration queue saturated for 1980 frames (DepthSensing.cpp:854-902,
+    Bundler.cpp:205-210) - through the product's frame loop, exactly as bench.py's `long_stream` block runs it, against the ORACLE frame loop's results for the
+    same stream (tests/golden/oracle_stream_2000.npz, written by tests/golden/make_oracle_stream_2000.py: 11 minutes of host time, not spent on the GPU box).
+
+    Bar: every frame tracked on both sides; the same key frames; the same number of local and global solves at every 500 frames; the scheduled TSDF operations
+    per 500 frames within 1 % (they depend on the poses through the re-integration ranking's thresholds); |ATE(product) - ATE(oracle)| < 1 mm for the integrated and
+    for the optimised trajectory (north_star); every pose within the bound printed below of the oracle's."""
+    import torch
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = np.load(os.path.join(root, "tests", "golden", "oracle_stream_2000.npz"))
+    spec = importlib.util.spec_from_file_location("make_oracle_stream_2000", os.path.join(root, "tests", "golden", "make_oracle_stream_2000.py"))
+    g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+    NF = int(fx["frames"])
+    assert NF == g.NF == 2000 and int(fx["key_frames"]) == 199
+    gas, gbs = g.params(NF)
+    gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 4000000, 3000000          # bench.py's long_stream volume (the fixture's oracle did not execute its volume operators)
+    Kd = synth.intrinsics(W, H)
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gp = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    marks = []
+    for c0 in range(0, NF, 250):
+        part = synth.render_frames(range(c0, c0 + 250), W, H)
+        dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in part]
+        for k, (d, c) in enumerate(dev):
+            assert gp.process_frame(d, c)
+            if (c0 + k + 1) % g.MARK == 0:
+                cc = gp.counters()
+                marks.append([c0 + k + 1, cc["integrate"], cc["deintegrate"], cc["local_solves"], cc["global_solves"]])
+        gp.synchronize()
+        del dev, part
+    om = fx["marks"]
+    assert len(marks) == len(om) == 4
+    for m, o in zip(marks, om):
+        assert m[0] == o[0] and m[3] == o[3] and m[4] == o[4], "solves at frame %d: product %s oracle %s" % (m[0], m[3:], list(o[3:5]))
+        assert abs(m[1] - o[1]) <= 0.01 * o[1] and abs(m[2] - o[2]) <= 0.01 * o[2], "TSDF operations at frame %d: product %s oracle %s" % (m[0], m[1:3], list(o[1:3]))
+    gt, ot = gp.integrated_trajectory(), fx["integrated"]
+    gopt, oopt = gp.optimized_trajectory()[:NF], fx["optimized"]
+    assert len(gt) == NF and np.isfinite(gt[:, 0, 0]).all() and np.isfinite(ot[:, 0, 0]).all(), "frames lost"
+    assert np.array_equal(np.isfinite(gopt[:, 0, 0]), np.isfinite(oopt[:, 0, 0]))
+    vo = np.isfinite(gopt[:, 0, 0])
+    ref = fx["ground_truth"].astype(np.float64)
+
+    def ate(t, v=slice(None)):
+        return float(np.sqrt(np.mean(np.sum((t[v][:, :3, 3] - ref[v][:, :3, 3]) ** 2, axis=1))))
+    dev_int_t, dev_opt_t = float(np.abs(gt[:, :3, 3] - ot[:, :3, 3]).max()), float(np.abs(gopt[vo][:, :3, 3] - oopt[vo][:, :3, 3]).max())
+    dev_int_r, dev_opt_r = float(np.abs(gt[:, :3, :3] - ot[:, :3, :3]).max()), float(np.abs(gopt[vo][:, :3, :3] - oopt[vo][:, :3, :3]).max())
+    dbg = gp.scene().debug_hash()
+    print("configs[2] at length vs the ORACLE fixture: 2000 frames tracked, 199 key frames, solves %s, operations product %s oracle %s; largest pose deviation: integrated "
+          "%.2e m / %.2e (rotation), optimised %.2e m / %.2e; ATE integrated product %.3f mm oracle %.3f mm, optimised %.3f / %.3f mm; %d blocks, %d dropped"
+          % (marks[-1][3:], marks[-1][1:3], list(om[-1][1:3]), dev_int_t, dev_int_r, dev_opt_t, dev_opt_r, 1e3 * ate(gt), 1e3 * ate(ot), 1e3 * ate(gopt, vo), 1e3 * ate(oopt, vo),
+             dbg["occupied"], dbg["dropped"]))
+    assert abs(ate(gt) - ate(ot)) < 1e-3 and abs(ate(gopt, vo) - ate(oopt, vo)) < 1e-3          # north_star: ATE within 1 mm
+    assert dev_int_t < 1e-2 and dev_opt_t < 1e-2 and dev_int_r < 5e-3 and dev_opt_r < 5e-3
+    assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["dropped"] == 0
+
+
 def test_replay_1280x960_2mm_reintegration_sweep(gpu, oracle):
     """BASELINE configs[4] in small: 1280x960 depth, 2 mm voxels.  24 frames integrated at their poses, then one re-integration sweep
     (every frame de-integrated at P_k and integrated at P_k * exp(xi_k), xi ~ N(0, diag(0.01 rad, 0.01 m)), seed 777),

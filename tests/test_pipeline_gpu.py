@@ -117,7 +117,52 @@ def test_three_chunks_with_reintegration(gpu, oracle):
     assert worst_sdf < 2e-3 and worst_w <= 1.0, (worst_sdf, worst_w)
 
 
-@pytest.mark.parametrize("lag", [3, 10])
+def test_frames_beyond_the_image_managers_capacity(gpu, oracle):
+    """CUDAImageManager::process returns false once s_maxNumImages * s_submapSize frames are stored (CUDAImageManager.cpp:22-35) and the frame loop then iterates past
+    the end of the sequence (DepthSensing.cpp:966-1095 with bGotDepth == false).  Here with the frame loop two frames behind its input: the refused calls must first
+    complete the frames in flight - 20 frames accepted, 3 more offered - against the oracle loop fed 20 frames and 3 iterations past the end."""
+    import torch
+    from tests.oracle_pipeline import OraclePipeline
+    frames = synth.render_frames(range(23))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    gas, gbs = _params(max_images=2)
+    gp = gpu.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    gas2, gbs2 = _params(max_images=2)
+    op = OraclePipeline(gas2, gbs2, W, H, K)
+    cap = gbs.s_maxNumImages * gbs.s_submapSize
+    assert cap == 20
+    for i, (d, c, T, _) in enumerate(frames):
+        got = gp.process_frame(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda())
+        assert got == (i < cap), "frame %d" % i
+        if i < cap:
+            op.process_frame(d, c)
+        else:
+            op.process_end_of_sequence()
+    gp.synchronize()
+    assert gp.num_frames() == cap
+    c = gp.counters()
+    o_in = sum(1 for k, _, _ in op.integrate_ops if k == "in"); o_de = sum(1 for k, _, _ in op.integrate_ops if k == "de")
+    assert (c["integrate"], c["deintegrate"]) == (o_in, o_de)
+    assert c["local_solves"] == op.local.num_solves + op.opt_local.num_solves and c["global_solves"] == op.glob.num_solves
+    gt, ot = gp.integrated_trajectory(), op.integrated_trajectory()
+    assert len(gt) == len(ot) == cap and np.array_equal(np.isfinite(gt[:, 0, 0]), np.isfinite(ot[:, 0, 0])) and np.isfinite(gt[:, 0, 0]).all()
+    assert np.abs(gt - ot).max() < 5e-4
+    dbg = gp.scene().debug_hash()
+    assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0
+
+
+def test_solve_lag_below_the_loop_depth_is_refused(gpu):
+    from bundlefusion_amd.capi import BFError
+    Kd = synth.intrinsics(W, H)
+    gp = gpu.capi.Pipeline(*_params(), sensor_desc(W, H, intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])))
+    with pytest.raises(BFError):
+        gp.set_solve_lag(1)
+    gp.set_solve_lag(2); assert gp.solve_lag() == 2
+    gp.set_solve_lag(0)
+
+
+@pytest.mark.parametrize("lag", [2, 3, 10])
 def test_lagged_solve_mode_vs_oracle_loop_with_the_same_lag(gpu, oracle, lag):
     """bf_pipeline_set_solve_lag(L): the chunk solves run on their own thread and stream and their results - complete trajectory, last valid
     complete transform, TrajectoryManager poses - become visible exactly L frames after the frame that closed the chunk (the reference's

@@ -38,12 +38,12 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
       (cd "$ROOT" && timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"; cut -c1-260 "$OUT/bench_driver.json"; tail -3 "$OUT/bench_driver.err") ;;
     bench_ab)       # the driver's window with the frame's TSDF operators batched (default) and one at a time: same code, same box
       for B in on off; do
-        (cd "$ROOT" && timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --volume-batching $B $BENCH_ARGS > "$OUT/bench_batching_$B.json" 2> "$OUT/bench_batching_$B.err"; python -c "
+        (cd "$ROOT" && timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 --volume-batching $B $BENCH_ARGS > "$OUT/bench_batching_$B.json" 2> "$OUT/bench_batching_$B.err"; python -c "
 import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; print('$B', round(j['value'],1), 'fps', {k: (round(r[k],3) if isinstance(r[k], float) else r[k]) for k in ('avg_launch_us','us_per_operator','frac','frac_per_operator','launches','operators','blocks_visited_per_launch')}, j['config']['host_thread_ms_per_frame'], j['config']['volume_thread'])"; tail -2 "$OUT/bench_batching_$B.err")
       done ;;
     trace)
       rm -rf /tmp/r_trace
-      (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --steps 20 --warmup 5 --one-contract $BENCH_ARGS > "$OUT/bench_traced.json" 2> /dev/null)
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/r_trace -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract $BENCH_ARGS > "$OUT/bench_traced.json" 2> /dev/null)
       D=$(db /tmp/r_trace)
       rm -f "$OUT/kernel_stats.md"
       python "$ROOT/tools/rocpd_stats.py" "$D" "$OUT/kernel_stats.md" --exclude "Cijk_,at::native" | head -14
@@ -53,14 +53,14 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
       for A in ${PMC_CONTRACTS:-fast exact}; do
         for C in FETCH_SIZE WRITE_SIZE; do
           rm -rf /tmp/r_pmc_$C
-          (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --steps 20 --warmup 5 --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
+          (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_pmc_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_$C.json > /dev/null 2>&1)
         done
         python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A
       done ;;
     sq)   # where do the voxel-update waves spend their cycles: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
       rm -rf /tmp/r_sq
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES \
-          -d /tmp/r_sq -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep > /dev/null 2>&1)
+          -d /tmp/r_sq -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 > /dev/null 2>&1)
       python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_sq)" update | tee "$OUT/pmc_sq.txt" | tail -18 ;;
     stream)
       (cd "$ROOT" && timeout 500 python tools/run_sequence.py --frames 5000 --bob 0.3 --voxel 0.004 --buckets 4000000 --blocks 3000000 --tail 35 2>&1 \

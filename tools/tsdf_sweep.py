@@ -69,14 +69,7 @@ def main():
         dist.destroy_process_group()
 
 
-def alloc_comm_capacity(W, H, voxel, world):
-    """Keys per rank and operator for bf_scene_set_alloc_comm: twice the estimate of the distinct in-frustum blocks the rays of a W x H frame cross (0.22 per pixel at 2 mm,
-    scaling with 1 / voxel^2), divided over the ranks, as a power of two >= 65536."""
-    est = 0.22 * W * H * (0.002 / voxel) ** 2
-    cap = 1 << 16
-    while cap < 2.0 * est / world:
-        cap <<= 1
-    return cap
+from bundlefusion_amd.capi import alloc_comm_capacity      # noqa: E402,F401  (tests/test_host_cpu.py imports it from here)
 
 
 def run(a, rank=0, world=1):
