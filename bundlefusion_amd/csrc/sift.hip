@@ -55,6 +55,7 @@ struct SiftDev {
     int* counts;           // [0]=numRaw, [1]=numFeat, [2..2+NKL) levelNum after limit0, [16..16+NKL) final level counts, [30]=error
     Feat* feats;
     float* des;            // numFeat*128 floats
+    uint32_t* ticket;      // k_keys_finalize: arrivals of its per-level workgroups
 };
 
 enum { CNT_RAW = 0, CNT_FEAT = 1, CNT_LEVEL0 = 2, CNT_LEVEL1 = 16, CNT_ERR = 30, CNT_TOTAL = 32 };
@@ -170,12 +171,15 @@ __global__ __launch_bounds__(256) void k_detect(Levels lv, DetectCfg c, SiftDev 
     if (pos < (uint32_t)L.cap) d.cand[d.candOff[li] + pos] = ((uint32_t)row << 16) | (uint32_t)col;
 }
 
-// single workgroup: per level sort the candidates by (row, col), keep the first fmax, apply
-// LimitFeatureCount(0) (SiftPyramid.cpp:227-255), emit the compact ordered key list.
+// One workgroup per level sorts that level's candidates by (row, col) (round 5: one workgroup walked the twelve levels one after the other, 70-90 us per frame);
+// the workgroup that finishes last keeps the first fmax per level, applies LimitFeatureCount(0) (SiftPyramid.cpp:227-255) and emits the compact ordered key
+// list.  Hand-off: write-through stores, drained, ticket, agent acquire (the pattern of k_alloc_place, tsdf.hip).
 __global__ __launch_bounds__(1024) void k_keys_finalize(Levels lv, SiftDev d, int featureCountThreshold) {
     __shared__ uint32_t keys[8192];
     __shared__ int levelNum[NKL], levelStart[NKL + 1];
-    for (int li = 0; li < NKL; ++li) {
+    __shared__ uint32_t lastFlag;
+    {
+        const int li = blockIdx.x;
         const int cap = lv.l[li].cap;
         const uint32_t cnt = min(d.candCount[li], (uint32_t)cap);
         uint32_t npad = 64;
@@ -192,11 +196,19 @@ __global__ __launch_bounds__(1024) void k_keys_finalize(Levels lv, SiftDev d, in
                 }
                 __syncthreads();
             }
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) d.cand[d.candOff[li] + i] = keys[i];
-        if (threadIdx.x == 0) levelNum[li] = (int)min(cnt, (uint32_t)lv.l[li].fmax);
-        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) __hip_atomic_store(d.cand + d.candOff[li] + i, keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(d.ticket, 1u);
+        lastFlag = t == gridDim.x - 1 ? 1u : 0u;
+        if (lastFlag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!lastFlag) return;
+    if (threadIdx.x == 0) {
+        for (int li = 0; li < NKL; ++li) levelNum[li] = (int)min(min(d.candCount[li], (uint32_t)lv.l[li].cap), (uint32_t)lv.l[li].fmax);
         if (featureCountThreshold > 0) {
             int total = 0;
             for (int i = 0; i < NKL; ++i) total += levelNum[i];
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(1024) void k_keys_finalize(Levels lv, SiftDev d, in
         levelStart[NKL] = s;
         d.counts[CNT_RAW] = s;
         d.counts[CNT_ERR] = 0;
+        d.ticket[0] = 0u;
     }
     __syncthreads();
     for (int li = 0; li < NKL; ++li)
@@ -312,23 +325,44 @@ __global__ __launch_bounds__(1024) void k_reshape(Levels lv, SiftDev d, float mi
         nOri[i] = (uint8_t)n;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // per level: running output index, capped at fmax (atomic cap of the reference, in list order)
-        int cur = 0;
-        for (int li = 0; li < NKL; ++li) {
-            const int ln = d.counts[CNT_LEVEL0 + li];
-            int out = 0;
-            for (int k = 0; k < ln; ++k) {
-                const int i = cur + k;
-                int n = nOri[i];
-                if (out + n > lv.l[li].fmax) n = max(lv.l[li].fmax - out, 0);
-                nOri[i] = (uint8_t)n;
-                outPos[i] = out;
-                out += n;
-            }
-            finalNum[li] = out;
-            cur += ln;
+    // Per level: running output index in list order, capped at fmax (the atomic cap of the reference).  With e_i the number of orientations in front of key i
+    // inside its level, the capped walk gives out_i = min(e_i, fmax) and n_i' = min(n_i, fmax - out_i): a block-wide exclusive scan (round 5; thread 0 walked
+    // the up to 6144 keys alone, 50-90 us per frame).
+    {
+        __shared__ int waveSum[16];
+        __shared__ int levelBase[NKL];       // e of the level's first key in the scan over the whole list
+        const int E = (nRaw + (int)blockDim.x - 1) / (int)blockDim.x, c0 = (int)threadIdx.x * E;
+        int cnt = 0;
+        for (int e = 0; e < E; ++e) { const int i = c0 + e; if (i < nRaw) cnt += nOri[i]; }
+        int incl = cnt;
+        const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) waveSum[wv] = incl;
+        __syncthreads();
+        int run = incl - cnt;
+        for (int q = 0; q < wv; ++q) run += waveSum[q];
+        for (int e = 0; e < E; ++e) { const int i = c0 + e; if (i < nRaw) { outPos[i] = run; run += nOri[i]; } }      // exclusive scan over the whole list
+        __syncthreads();
+        if (threadIdx.x < NKL) {
+            int start = 0;
+            for (int q = 0; q < (int)threadIdx.x; ++q) start += d.counts[CNT_LEVEL0 + q];
+            const int ln = d.counts[CNT_LEVEL0 + threadIdx.x];
+            const int base = ln > 0 ? outPos[start] : 0;
+            const int tot = ln > 0 ? outPos[start + ln - 1] + nOri[start + ln - 1] - base : 0;
+            levelBase[threadIdx.x] = base;
+            finalNum[threadIdx.x] = min(tot, lv.l[threadIdx.x].fmax);
         }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nRaw; i += blockDim.x) {
+            const int li = d.raw[i].li, fmax = lv.l[li].fmax;
+            const int out = min(outPos[i] - levelBase[li], fmax);
+            nOri[i] = (uint8_t)min((int)nOri[i], fmax - out);
+            outPos[i] = out;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
         if (featureCountThreshold > 0) {
             int total = 0;
             for (int i = 0; i < NKL; ++i) total += finalNum[i];
@@ -532,8 +566,9 @@ int bf_sift_create(uint32_t width, uint32_t height, uint32_t depthWidth, uint32_
     s->detect.edgeT = (10.0f + 1) * (10.0f + 1) / 10.0f;
     ok = A((void**)&s->d.cand, (size_t)candTotal * 4) && A((void**)&s->d.candCount, NKL * 4) && A((void**)&s->d.raw, MAXRAW * sizeof(RawKey)) &&
          A((void**)&s->d.counts, CNT_TOTAL * 4) && A((void**)&s->d.feats, (size_t)(maxNumKeysPerImage + 8) * sizeof(Feat)) &&
-         A((void**)&s->d.des, (size_t)(maxNumKeysPerImage + 8) * 128 * 4) && A((void**)&s->d_count, 4);
+         A((void**)&s->d.des, (size_t)(maxNumKeysPerImage + 8) * 128 * 4) && A((void**)&s->d_count, 4) && A((void**)&s->d.ticket, 4);
     if (!ok) { set_error("bf_sift_create: hipMalloc failed"); bf_sift_destroy(s); return BF_ERR_HIP; }
+    (void)hipMemset(s->d.ticket, 0, 4);
     (void)hipMemset(s->d.candCount, 0, NKL * 4);
     (void)hipMemset(s->d.counts, 0, CNT_TOTAL * 4);
     // wavefront schedule of the pyramid (SiftPyramid::BuildPyramid, SiftPyramid.cpp:82-145)
@@ -593,7 +628,7 @@ int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_depth, floa
     }
     hipLaunchKernelGGL(k_grad, dim3(s->gradBlocks), dim3(256), 0, st, s->gradJobs);
     hipLaunchKernelGGL(k_detect, dim3(s->detectBlocks), dim3(256), 0, st, s->levels, s->detect, s->d, d_depth);
-    hipLaunchKernelGGL(k_keys_finalize, dim3(1), dim3(1024), 0, st, s->levels, s->d, s->featureCountThreshold);
+    hipLaunchKernelGGL(k_keys_finalize, dim3(NKL), dim3(1024), 0, st, s->levels, s->d, s->featureCountThreshold);
     hipLaunchKernelGGL(k_orientation, dim3(2048), dim3(64), 0, st, s->levels, s->d);
     hipLaunchKernelGGL(k_reshape, dim3(1), dim3(1024), 0, st, s->levels, s->d, s->minKeyScale, s->featureCountThreshold, s->maxFeatures);
     hipLaunchKernelGGL(k_descriptor, dim3(4 * (uint32_t)s->maxFeatures), dim3(256), 0, st, s->levels, s->d);

@@ -73,135 +73,138 @@ BF_DEV int decode_idx(uint64_t P) {
     return lo == 0xFFFFFFFFu ? -1 : (int)((0xFFFFFFFEu - lo) & 0xFFFFu);
 }
 
-__global__ __launch_bounds__(1024) void k_match(MatchArgs a) {
+// One image pair = 32 workgroups of four waves (round 5; rounds 1-4 ran a pair in ONE 1024-thread workgroup: 170 us per frame with ten pairs, 430 us in the frame
+// that closes a chunk - ten workgroups on a 256-CU device, VALU-bound on the best-2 bookkeeping - and the longest link of the chain the frame loop waits for).
+//   workgroups 0..15   ROW slabs: 64 keys of the previous image against ALL keys of the current one -> per row best / second-best -> RowMatch_Kernel's verdict
+//   workgroups 16..31  COLUMN slabs: 64 keys of the current image against all keys of the previous one -> ColMatch_Kernel's verdict
+//                      (the 128-byte dot products are computed twice; the matrix cores idle either way)
+//   the LAST workgroup of the pair to finish (ticket) runs the mutual check, the ordered compaction and the stable distance sort
+// A wave owns 16 keys of its side (one MFMA row chunk) and walks the other side's 16-key tiles: its best-2 state is complete in its own registers - nothing is
+// merged across waves or workgroups.  best = max over the packed (dot product, tie-break key) words and second-best = max over the rest are order-independent
+// (top2_add / top2_merge), so the results are those of the single-workgroup form bit for bit.
+struct MatchScratch { int* rowRes; float* rowDist; int* colRes; uint32_t* ticket; };      // per previous image: 1024 / 1024 / 1024 / 1
+
+BF_DEV void storeAgent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BF_DEV void storeAgentF(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchScratch sc) {
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
     int n1 = a.numKeys[prev], n2 = a.numKeys[a.curFrame];
     n1 = min(max(n1, 0), (int)a.maxKeys); n2 = min(max(n2, 0), (int)a.maxKeys);
-    if ((!a.speculative && a.validImages[prev] == 0) || n1 == 0 || n2 == 0) {       // Bundler.cpp:126-129
-        if (tid == 0) a.numMatches[prev] = 0;
+    if ((!a.speculative && a.validImages[prev] == 0) || n1 == 0 || n2 == 0) {       // Bundler.cpp:126-129 (every workgroup of the pair takes this branch)
+        if (tid == 0 && blockIdx.y == 0) a.numMatches[prev] = 0;
         return;
     }
-    __shared__ uint64_t colP[1024];
-    __shared__ int colN[1024], colSum[1024], rowSum[1024], rowRes[1024];
-    __shared__ float rowDist[1024];
+    __shared__ int otherSum[1024];
+    __shared__ int ownSum[64];
     __shared__ int rawR[MAX_RAW], rawC[MAX_RAW];
     __shared__ float rawD[MAX_RAW];
-    __shared__ int waveTot[16];
-
+    __shared__ int waveTot[4];
+    __shared__ uint32_t lastFlag;
+    const bool cols = blockIdx.y >= 16;                  // block-uniform
+    const uint32_t slab = blockIdx.y & 15u;
     const uint8_t* D1 = a.descs + (size_t)prev * a.maxKeys * 128;
     const uint8_t* D2 = a.descs + (size_t)a.curFrame * a.maxKeys * 128;
-    // byte sums (bias correction) and column state
-    for (uint32_t k = tid; k < 1024; k += 1024) {
-        int s1 = 0, s2 = 0;
-        if ((int)k < n1) { const v4i* p = (const v4i*)(D1 + (size_t)k * 128); for (int i = 0; i < 8; ++i) s1 += byte_sum16(p[i]); }
-        if ((int)k < n2) { const v4i* p = (const v4i*)(D2 + (size_t)k * 128); for (int i = 0; i < 8; ++i) s2 += byte_sum16(p[i]); }
-        rowSum[k] = s1 - 16384; colSum[k] = s2 - 16384;
-        colP[k] = P_NONE; colN[k] = 0;
-    }
-    __syncthreads();
-
-    const int nRC = (n1 + 15) >> 4, nCT = (n2 + 15) >> 4;
-    const int T = max(16, nCT);
-    uint64_t rP[4][4]; int rN[4][4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { rP[s][r] = P_NONE; rN[s][r] = 0; }
-
-    for (int t = 0; t < T; ++t) {
-        const int ct = (int)((w + t) % (uint32_t)T);
-        if (ct < nCT) {
-            const int col = ct * 16 + (int)c16;
-            v4i b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-            if (col < n2) {
-                const uint8_t* p = D2 + (size_t)col * 128 + 16 * g;
-                b0 = *(const v4i*)p; b1 = *(const v4i*)(p + 64);
-            }
-            b0 ^= (int)0x80808080; b1 ^= (int)0x80808080;
-            const int sb = colSum[min(col, 1023)];
-            uint64_t lp = P_NONE; int ln = 0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int chunk = (int)w + 16 * s;
-                if (chunk < nRC) {
-                    const int arow = chunk * 16 + (int)c16;
-                    v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-                    if (arow < n1) {
-                        const uint8_t* p = D1 + (size_t)arow * 128 + 16 * g;
-                        a0 = *(const v4i*)p; a1 = *(const v4i*)(p + 64);
-                    }
-                    a0 ^= (int)0x80808080; a1 ^= (int)0x80808080;
-                    v4i acc = {0, 0, 0, 0};
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rr = chunk * 16 + 4 * (int)g + r;
-                        const bool ok = rr < n1 && col < n2;
-                        const int d = ok ? acc[r] + 128 * (rowSum[rr] + sb) + 2097152 : 0;
-                        const uint32_t kr = ((uint32_t)(col & 31) << 16) | (uint32_t)col;
-                        const uint32_t kc = ((uint32_t)((rr >> 2) & 31) << 16) | (uint32_t)rr;
-                        const uint64_t Pr = ok ? (((uint64_t)(uint32_t)d << 32) | (0xFFFFFFFEu - kr)) : 0ull;
-                        const uint64_t Pc = ok ? (((uint64_t)(uint32_t)d << 32) | (0xFFFFFFFEu - kc)) : 0ull;
-                        top2_add(rP[s][r], rN[s][r], Pr, d);
-                        top2_add(lp, ln, Pc, d);
-                    }
-                }
-            }
-            // fold the four lane groups, then the column's running state (this wave owns the tile this step)
-            for (int m = 16; m <= 32; m <<= 1) { const uint64_t oP = shfl_xor_u64(lp, m); const int oN = __shfl_xor(ln, m, 64); top2_merge(lp, ln, oP, oN); }
-            if (g == 0 && col < n2) {
-                uint64_t cp = colP[col]; int cn = colN[col];
-                top2_merge(cp, cn, lp, ln);
-                colP[col] = cp; colN[col] = cn;
-            }
+    const uint8_t* DO = cols ? D2 : D1; const uint8_t* DX = cols ? D1 : D2;      // own side (this slab's 64 keys), other side (all keys)
+    const int nOwn = cols ? n2 : n1, nOther = cols ? n1 : n2;
+    int* resRow = sc.rowRes + (size_t)prev * 1024; float* distRow = sc.rowDist + (size_t)prev * 1024; int* resCol = sc.colRes + (size_t)prev * 1024;
+    if ((int)(slab * 64u) < nOwn) {
+        // byte sums (the bias correction of the signed MFMA operands)
+        for (uint32_t k = tid; k < 1024; k += 256) {
+            int sx = 0;
+            if ((int)k < nOther) { const v4i* p = (const v4i*)(DX + (size_t)k * 128); for (int i = 0; i < 8; ++i) sx += byte_sum16(p[i]); }
+            otherSum[k] = sx - 16384;
+        }
+        if (tid < 64) {
+            const int k = (int)(slab * 64u + tid);
+            int so = 0;
+            if (k < nOwn) { const v4i* p = (const v4i*)(DO + (size_t)k * 128); for (int i = 0; i < 8; ++i) so += byte_sum16(p[i]); }
+            ownSum[tid] = so - 16384;
         }
         __syncthreads();
-    }
-    // rows: fold the 16 lanes that share a row
+        const int chunk = (int)(slab * 4u + w);          // 16 keys of the own side
+        if (chunk * 16 < nOwn) {                          // wave-uniform
+            const int arow = chunk * 16 + (int)c16;
+            v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+            if (arow < nOwn) { const uint8_t* p = DO + (size_t)arow * 128 + 16 * g; a0 = *(const v4i*)p; a1 = *(const v4i*)(p + 64); }
+            a0 ^= (int)0x80808080; a1 ^= (int)0x80808080;
+            uint64_t rP[4]; int rN[4]; int so[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+            for (int r = 0; r < 4; ++r) { rP[r] = P_NONE; rN[r] = 0; so[r] = ownSum[(int)w * 16 + 4 * (int)g + r]; }
+            const int nOT = (nOther + 15) >> 4;
+            for (int ct = 0; ct < nOT; ++ct) {
+                const int col = ct * 16 + (int)c16;
+                v4i b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+                if (col < nOther) { const uint8_t* p = DX + (size_t)col * 128 + 16 * g; b0 = *(const v4i*)p; b1 = *(const v4i*)(p + 64); }
+                b0 ^= (int)0x80808080; b1 ^= (int)0x80808080;
+                const int sb = otherSum[min(col, 1023)];
+                v4i acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+                // the tie-break key of the OTHER side's index: rows prefer columns by ((col & 31) << 16 | col), columns prefer rows by (((row >> 2) & 31) << 16 | row)
+                // - the traversal orders of RowMatch_Kernel / ColMatch_Kernel (ProgramCU.cu:1780-1916)
+                const uint32_t kx = cols ? ((((uint32_t)col >> 2) & 31u) << 16) | (uint32_t)col : (((uint32_t)col & 31u) << 16) | (uint32_t)col;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uint64_t P = rP[s][r]; int n = rN[s][r];
-            for (int m = 1; m <= 8; m <<= 1) { const uint64_t oP = shfl_xor_u64(P, m); const int oN = __shfl_xor(n, m, 64); top2_merge(P, n, oP, oN); }
-            const int rr = ((int)w + 16 * s) * 16 + 4 * (int)g + r;
-            if (c16 == 0 && rr < n1) {      // RowMatch_Kernel :1813-1829
-                const float dist = bf_dm_acos(fminf((float)(int)(P >> 32) * 0.000003814697265625f, 1.0f));
-                const float distn = bf_dm_acos(fminf((float)n * 0.000003814697265625f, 1.0f));
-                rowRes[rr] = (dist < a.distmax) && (dist < distn * a.ratiomax) ? decode_idx(P) : -1;
-                rowDist[rr] = dist;
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = chunk * 16 + 4 * (int)g + r;
+                    const bool ok = rr < nOwn && col < nOther;
+                    const int d = ok ? acc[r] + 128 * (so[r] + sb) + 2097152 : 0;
+                    const uint64_t P = ok ? (((uint64_t)(uint32_t)d << 32) | (0xFFFFFFFEu - kx)) : 0ull;
+                    top2_add(rP[r], rN[r], P, d);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                  // fold the 16 lanes that share an own-side key
+                uint64_t P = rP[r]; int n = rN[r];
+                for (int m = 1; m <= 8; m <<= 1) { const uint64_t oP = shfl_xor_u64(P, m); const int oN = __shfl_xor(n, m, 64); top2_merge(P, n, oP, oN); }
+                const int rr = chunk * 16 + 4 * (int)g + r;
+                if (c16 == 0 && rr < nOwn) {               // RowMatch_Kernel :1813-1829 / ColMatch_Kernel :1898-1916
+                    const float dist = bf_dm_acos(fminf((float)(int)(P >> 32) * 0.000003814697265625f, 1.0f));
+                    const float distn = bf_dm_acos(fminf((float)n * 0.000003814697265625f, 1.0f));
+                    const int res = (dist < a.distmax) && (dist < distn * a.ratiomax) ? decode_idx(P) : -1;
+                    if (cols) storeAgent(resCol + rr, res);
+                    else { storeAgent(resRow + rr, res); storeAgentF(distRow + rr, dist); }
+                }
             }
         }
-    __syncthreads();
-    // columns: ColMatch_Kernel :1898-1916, appended in ascending column order
-    int f1 = -1; bool hit = false;
-    if ((int)tid < n2) {
-        const uint64_t P = colP[tid];
-        const float dist = bf_dm_acos(fminf((float)(int)(P >> 32) * 0.000003814697265625f, 1.0f));
-        const float distn = bf_dm_acos(fminf((float)colN[tid] * 0.000003814697265625f, 1.0f));
-        f1 = (dist < a.distmax) && (dist < distn * a.ratiomax) ? decode_idx(P) : -1;
-        hit = f1 >= 0 && rowRes[f1] == (int)tid;
     }
-    const uint64_t ball = __ballot(hit);
-    if (lane == 0) waveTot[w] = __popcll(ball);
+    // hand-off to the pair's last workgroup (write-through stores drained, ticket, acquire: see k_alloc_place in tsdf.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int base = 0, total = 0;
-    for (int i = 0; i < 16; ++i) { if (i < (int)w) base += waveTot[i]; total += waveTot[i]; }
-    const int pos = base + __popcll(ball & ((1ull << lane) - 1ull));
-    if (hit && pos < MAX_RAW) { rawR[pos] = f1; rawC[pos] = (int)tid; rawD[pos] = rowDist[f1]; }
+    if (tid == 0) {
+        const uint32_t t = atomicAdd(sc.ticket + prev, 1u);
+        lastFlag = t == gridDim.y - 1 ? 1u : 0u;
+        if (lastFlag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
+    if (!lastFlag) return;
+    // columns in ascending order: ColMatch's verdict, the mutual check, ordered append
+    int total = 0;
+    for (int c0 = 0; c0 < n2; c0 += 256) {
+        const int col = c0 + (int)tid;
+        int f1 = -1; bool hit = false;
+        if (col < n2) { f1 = resCol[col]; hit = f1 >= 0 && f1 < n1 && resRow[f1] == col; }
+        const uint64_t ball = __ballot(hit);
+        if (lane == 0) waveTot[w] = __popcll(ball);
+        __syncthreads();
+        int base = total, add = 0;
+        for (int i = 0; i < 4; ++i) { if (i < (int)w) base += waveTot[i]; add += waveTot[i]; }
+        const int pos = base + __popcll(ball & ((1ull << lane) - 1ull));
+        if (hit && pos < MAX_RAW) { rawR[pos] = f1; rawC[pos] = col; rawD[pos] = distRow[f1]; }
+        total += add;
+        __syncthreads();
+    }
     const int m = min(total, MAX_RAW);
-    if ((int)tid < m) {           // SortKeyPointMatchesCU :59-143 — stable ascending by distance
+    if ((int)tid < m) {           // SortKeyPointMatchesCU :59-143 - stable ascending by distance
         const float di = rawD[tid];
         int rank = 0;
         for (int j = 0; j < m; ++j) { const float dj = rawD[j]; rank += (dj < di || (dj == di && j < (int)tid)) ? 1 : 0; }
         a.idx[prev * MAX_RAW + rank] = make_uint2(prev * a.maxKeys + (uint32_t)rawR[tid], a.curFrame * a.maxKeys + (uint32_t)rawC[tid]);
         a.dist[prev * MAX_RAW + rank] = di;
     }
-    if (tid == 0) a.numMatches[prev] = total;
+    if (tid == 0) { a.numMatches[prev] = total; sc.ticket[prev] = 0u; }
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 helpers
@@ -423,7 +426,19 @@ template <class T> BF_DEV void swp(T& a, T& b) { const T t = a; a = b; b = t; }
 // 244 vs 259 us per launch, no change at the frame level: the time is in the dependent SVD / eigenvalue chains, not in the sums.)
 struct ReprojShared { m44 T; float ev[3]; float cond[2]; };
 
-__device__ __noinline__ bool computeReprojection(uint32_t lane, f3* src, f3* tgt, unsigned n, float* res, Sel* sel, ReprojShared* sh) {
+// The verdict of ComputeReprojection (:404-418): condition numbers of the fit and of the two point sets, on the state the last computeReprojection left behind.
+// Round 5: evaluated only where the greedy filter READS it (the end of the walk, and the two places of the removal loop) - the reference computes the two
+// covariance eigen-decompositions after every fit and overwrites the result unread in all but 1-3 of the ~35 fits of a pair (a quarter of the kernel's time).
+__device__ __noinline__ bool reprojectionValid(uint32_t lane, const f3* src, const f3* tgt, unsigned n, ReprojShared* sh) {
+    if (lane < 2) { const f3 e = covarianceEig(lane == 0 ? src : tgt, n); sh->cond[lane] = e.x / e.y; }
+    __syncthreads();
+    const float c1 = sh->ev[0] / sh->ev[1], cp = sh->cond[0], cq = sh->cond[1];
+    __syncthreads();
+    if (c1 != c1 || cp != cp || cq != cq || fabsf(c1) > 100.0f || fabsf(cp) > 100.0f || fabsf(cq) > 100.0f) return false;
+    return true;
+}
+
+__device__ __noinline__ void computeReprojection(uint32_t lane, f3* src, f3* tgt, unsigned n, float* res, Sel* sel, ReprojShared* sh) {
     if (lane == 0) {
         f3 ev;
         sh->T = kabsch(src, tgt, n, ev);
@@ -450,11 +465,6 @@ __device__ __noinline__ bool computeReprojection(uint32_t lane, f3* src, f3* tgt
                 if (res[i] > res[j]) { swp(res[i], res[j]); swp(src[i], src[j]); swp(tgt[i], tgt[j]); swp(sel[i], sel[j]); }
     }
     __syncthreads();
-    if (lane < 2) { const f3 e = covarianceEig(lane == 0 ? src : tgt, n); sh->cond[lane] = e.x / e.y; }
-    __syncthreads();
-    const float c1 = sh->ev[0] / sh->ev[1], cp = sh->cond[0], cq = sh->cond[1];
-    if (c1 != c1 || cp != cp || cq != cq || fabsf(c1) > 100.0f || fabsf(cp) > 100.0f || fabsf(cq) > 100.0f) return false;
-    return true;
 }
 
 struct FilterArgs {
@@ -495,8 +505,10 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
     int i = 0;
     float curMaxRes = 100.0f;
     bool validT = false;
+    bool pending = false;           // validT is the verdict of the state in (src, tgt, cur, sh.ev) and has not been evaluated yet
     for (;;) {
         if (i == numRaw || cur >= (unsigned)MAX_FILT) {
+            if (pending) { validT = reprojectionValid(tid, src, tgt, cur, &sh); pending = false; }
             if ((int)cur < a.minNumMatches || curMaxRes >= a.maxKabschRes2 || !validT) cur = 0;
             break;
         }
@@ -515,21 +527,25 @@ __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
             if (cur >= 3) {
                 if (tid < cur) { src[tid] = ptI[sel[tid].r]; tgt[tid] = ptJ[sel[tid].r]; }
                 __syncthreads();
-                validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
-                const bool b = validT;
+                computeReprojection(tid, src, tgt, cur, res, sel, &sh);
+                pending = true;
                 if (tid < 16) prevT.e[tid] = sh.T.e[tid];
                 curMaxRes = res[cur - 1];
                 if (curMaxRes > a.maxKabschRes2) {
+                    const bool b = reprojectionValid(tid, src, tgt, cur, &sh);      // the verdict of this fit: read below if the removals go down to three matches
+                    validT = b; pending = false;
                     float lastRes = -1;
                     const int startIdx = (int)cur - 1;
                     for (int k = startIdx; k >= 3; --k) {
                         lastRes = res[k];
                         cur--;
                         __syncthreads();
-                        validT = computeReprojection(tid, src, tgt, cur, res, sel, &sh);
+                        computeReprojection(tid, src, tgt, cur, res, sel, &sh);
+                        pending = true;
                         curMaxRes = res[cur - 1];
+                        if (cur == 3) { validT = reprojectionValid(tid, src, tgt, cur, &sh); pending = false; }
                         if (cur == 3 && (curMaxRes > a.maxKabschRes2 || (b && !validT))) {
-                            cur++; curMaxRes = lastRes; validT = b;
+                            cur++; curMaxRes = lastRes; validT = b; pending = false;
                             __syncthreads();
                             if (tid < 16) sh.T.e[tid] = prevT.e[tid];
                             break;
@@ -624,17 +640,21 @@ __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
     const int n = min(a.numFilt[prev], MAX_FILT);
     if (n <= 0) return;
     __shared__ f3 ptsAll[2][MAX_FILT];
-    __shared__ float px[MAX_FILT], py[MAX_FILT];
+    __shared__ float pxAll[2][MAX_FILT], pyAll[2][MAX_FILT];
+    __shared__ float area[2];
     if ((int)threadIdx.x < 2 * n) {                  // back-project both images' keys in parallel
         const int which = (int)threadIdx.x / n, i = (int)threadIdx.x % n;
         const uint2 k = a.fidx[prev * MAX_FILT + i];
         ptsAll[which][i] = backProject(a.Kinv, a.keys[which ? k.y : k.x]);
     }
+    if (threadIdx.x < 2) area[threadIdx.x] = 0.0f;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    float area[2] = {0.0f, 0.0f};
-    float t[32];
-    for (int which = 0; which < 2; ++which) {
+    // lanes 0 and 1: the two images' areas side by side (round 5; one lane computed both, one after the other) - each is the reference's sequence for its image
+    if (threadIdx.x < 2) {
+        const int which = (int)threadIdx.x;
+        float t[32];
+        float* px = pxAll[which]; float* py = pyAll[which];
+        do {
         const f3* pts = ptsAll[which];
         // every sum below is a warpReduceSum of the reference's 32-thread block (cuda_surfaceArea.h:13-84, cudaUtil.h:25-29): warpTree32
         f3 mean;
@@ -657,7 +677,7 @@ __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) V[i] /= (float)n;
         float evals[3], ev[3][3];
-        if (!eigenSystem3(V, evals, ev)) continue;
+        if (!eigenSystem3(V, evals, ev)) break;
         const f3 ev0 = mk3(ev[0][0], ev[0][1], ev[0][2]), ev1 = mk3(ev[1][0], ev[1][1], ev[1][2]), ev2 = mk3(ev[2][0], ev[2][1], ev[2][2]);
         for (int i = 0; i < n; ++i) {                   // projectKeysToPlane, cuda_surfaceArea.h:134-158
             const f3 s = (pts[i] - ev2 * dot3(ev2, pts[i] - mean)) - mean;
@@ -688,8 +708,10 @@ __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
         }
         const float ex = maxx - minx, ey = maxy - miny;
         area[which] = (ex < 0.00001f || ey < 0.00001f) ? 0.0f : ex * ey;
+        } while (false);
     }
-    if (area[0] < a.areaThresh && area[1] < a.areaThresh) a.numFilt[prev] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0 && area[0] < a.areaThresh && area[1] < a.areaThresh) a.numFilt[prev] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ dense verify
@@ -747,7 +769,8 @@ struct VerifyArgs {
 // columns 0-15 three times, 32-47 and 64-79 twice, the rest not at all.  Here: the per-pixel terms are evaluated by all threads in
 // parallel into LDS, then DV_THREADS "virtual threads" replay that reduction (HIP's width-32 shuffles have the same out-of-range rule);
 // the adders are summed in ascending thread order (the reference's atomicAdd order is arbitrary).
-constexpr unsigned DV_THREADS = 512;         // >= W * ceil(H/32) (checked on the host); 8 waves
+constexpr unsigned DV_THREADS = 1024;        // >= W * ceil(H/32) (checked on the host); 16 waves: five pixels per thread at 80 x 60 (round 5; 512 threads walked ten
+                                             // dependent gather round trips each and the kernel took 78 us for 0.4 MB of input)
 constexpr unsigned DV_MAX_PIX = 5120;        // per-pixel terms kept in LDS (80 x 60 = 4800 pixels: 60 KB); larger images recompute
 
 BF_DEV bool denseVerifyPair(const VerifyArgs& a, const bf_cached_frame& fi, const bf_cached_frame& fm, const m44& T) {
@@ -1105,13 +1128,14 @@ struct bf_siftmgr {
     // 262-276) exist TWICE: bf_siftmgr_set_pair_stage selects the set (and the stream) the pair kernels of the NEXT frame work on, so that the match / Kabsch /
     // surface-area / dense-verification kernels of frame k + 1 run beside those of frame k (each pair depends on the two images only; which previous
     // images are valid is applied afterwards, bf_siftmgr_commit_pairs).  The members below always name the active set.
-    struct PairSet { int* numMatches; float* dist; uint2* idx; int* numFilt; float* fdist; uint2* fidx; m44* T; m44* Tinv; };
+    struct PairSet { int* numMatches; float* dist; uint2* idx; int* numFilt; float* fdist; uint2* fidx; m44* T; m44* Tinv; MatchScratch ms; };
     PairSet sets[2] = {};
     int pairSet = 0;
     hipStream_t pairStream = nullptr;      // stream of the pair kernels; null: `stream`
     bool speculative = false;
     int* d_numMatches = nullptr; float* d_dist = nullptr; uint2* d_idx = nullptr;
     int* d_numFilt = nullptr; float* d_fdist = nullptr; uint2* d_fidx = nullptr; m44* d_T = nullptr; m44* d_Tinv = nullptr;
+    MatchScratch matchScratch{};           // of the active pair set
     int* d_validImages = nullptr; int* d_validOpt = nullptr;
     bf_entry_j* d_glob = nullptr; uint2* d_globKeys = nullptr; int* d_globNum = nullptr;
     // the frame's single read-back.  Up to RES_SLOTS read-backs may be in flight (bf_siftmgr_prefetch_frame_result enqueues one behind the work issued so
@@ -1134,6 +1158,7 @@ static void selectPairSet(bf_siftmgr* m, int k) {
     m->pairSet = k;
     m->d_numMatches = P.numMatches; m->d_dist = P.dist; m->d_idx = P.idx;
     m->d_numFilt = P.numFilt; m->d_fdist = P.fdist; m->d_fidx = P.fidx; m->d_T = P.T; m->d_Tinv = P.Tinv;
+    m->matchScratch = P.ms;
 }
 static hipStream_t pairStreamOf(const bf_siftmgr* m) { return m->pairStream ? m->pairStream : m->stream; }
 
@@ -1169,8 +1194,10 @@ int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_sift
         bf_siftmgr::PairSet& P = m->sets[k];
         (rc = dalloc(P.numMatches, maxImages)) || (rc = dalloc(P.dist, (size_t)maxImages * MAX_RAW)) || (rc = dalloc(P.idx, (size_t)maxImages * MAX_RAW)) ||
         (rc = dalloc(P.numFilt, maxImages)) || (rc = dalloc(P.fdist, (size_t)maxImages * MAX_FILT)) || (rc = dalloc(P.fidx, (size_t)maxImages * MAX_FILT)) ||
-        (rc = dalloc(P.T, maxImages)) || (rc = dalloc(P.Tinv, maxImages));
-        if (!rc) { BF_HIP_TRY(hipMemset(P.numMatches, 0, sizeof(int) * maxImages)); BF_HIP_TRY(hipMemset(P.numFilt, 0, sizeof(int) * maxImages)); }
+        (rc = dalloc(P.T, maxImages)) || (rc = dalloc(P.Tinv, maxImages)) ||
+        (rc = dalloc(P.ms.rowRes, (size_t)maxImages * 1024)) || (rc = dalloc(P.ms.rowDist, (size_t)maxImages * 1024)) || (rc = dalloc(P.ms.colRes, (size_t)maxImages * 1024)) ||
+        (rc = dalloc(P.ms.ticket, maxImages));
+        if (!rc) { BF_HIP_TRY(hipMemset(P.numMatches, 0, sizeof(int) * maxImages)); BF_HIP_TRY(hipMemset(P.numFilt, 0, sizeof(int) * maxImages)); BF_HIP_TRY(hipMemset(P.ms.ticket, 0, sizeof(uint32_t) * maxImages)); }
     }
     if (rc) { delete m; return rc; }
     selectPairSet(m, 0);
@@ -1194,7 +1221,8 @@ int bf_siftmgr_create(uint32_t maxImages, uint32_t maxKeyPointsPerImage, bf_sift
 int bf_siftmgr_destroy(bf_siftmgr* m) {
     if (!m) return BF_OK;
     hipFree(m->d_keys); hipFree(m->d_descs); hipFree(m->d_numKeys);
-    for (auto& P : m->sets) { hipFree(P.numMatches); hipFree(P.dist); hipFree(P.idx); hipFree(P.numFilt); hipFree(P.fdist); hipFree(P.fidx); hipFree(P.T); hipFree(P.Tinv); }
+    for (auto& P : m->sets) { hipFree(P.numMatches); hipFree(P.dist); hipFree(P.idx); hipFree(P.numFilt); hipFree(P.fdist); hipFree(P.fidx); hipFree(P.T); hipFree(P.Tinv);
+                              hipFree(P.ms.rowRes); hipFree(P.ms.rowDist); hipFree(P.ms.colRes); hipFree(P.ms.ticket); }
     hipFree(m->d_validImages); hipFree(m->d_validOpt);
     hipFree(m->d_glob); hipFree(m->d_globKeys); hipFree(m->d_globNum); hipFree(m->d_res);
     if (m->fuseScratch) hipFree(m->fuseScratch);
@@ -1265,7 +1293,7 @@ int bf_siftmgr_get_num_keypoints(bf_siftmgr* m, uint32_t first, uint32_t count, 
 int bf_siftmgr_match(bf_siftmgr* m, uint32_t curFrame, uint32_t startFrame, uint32_t numFrames, float distMax, float ratioMax) {
     BF_REQUIRE(m && numFrames <= m->numImages && curFrame < numFrames && startFrame < numFrames, "frame range out of bounds");
     MatchArgs a = {m->d_descs, m->d_numKeys, m->d_validImages, m->maxKeys, curFrame, startFrame, distMax, ratioMax, m->d_numMatches, m->d_dist, m->d_idx, m->speculative ? 1 : 0};
-    k_match<<<numFrames - startFrame, 1024, 0, pairStreamOf(m)>>>(a);
+    k_match<<<dim3(numFrames - startFrame, 32), 256, 0, pairStreamOf(m)>>>(a, m->matchScratch);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }

@@ -18,9 +18,10 @@ for step in $STEPS; do
   case $step in
     tests)      # the whole GPU suite; the captured output of passed tests (the fast-contract reports, the reference-fixture comparison) is kept
       (cd "$ROOT" && timeout 1100 python -m pytest tests -q -m gpu --durations=12 -rP > "$OUT/pytest_gpu_full.txt" 2>&1; tail -22 "$OUT/pytest_gpu_full.txt" | tee "$OUT/pytest_gpu.txt"
-       grep -E "vs ORACLE|vs the REFERENCE|fast contract|noisy stream|frame loop, fast|^N = |integrations /" "$OUT/pytest_gpu_full.txt" | cut -c1-900 > "$OUT/test_reports.txt") ;;
+       grep -E "^E  " "$OUT/pytest_gpu_full.txt" | head -40
+       grep -E "vs ORACLE|vs the REFERENCE|fast contract|noisy stream|frame loop, fast|^N = |integrations /|configs\[2\] at length" "$OUT/pytest_gpu_full.txt" | cut -c1-900 > "$OUT/test_reports.txt") ;;
     tests_sel)  # a selection of the GPU suite: TESTS="tests/test_tsdf_gpu.py tests/test_pipeline_gpu.py"
-      (cd "$ROOT" && timeout 900 python -m pytest ${TESTS:-tests/test_tsdf_gpu.py tests/test_tsdf_fast_gpu.py tests/test_pipeline_gpu.py} -q -m gpu --durations=5 2>&1 | tail -12 | tee "$OUT/pytest_sel.txt") ;;
+      (cd "$ROOT" && timeout 900 python -m pytest ${TESTS:-tests/test_tsdf_gpu.py tests/test_tsdf_fast_gpu.py tests/test_pipeline_gpu.py} -q -m gpu --durations=5 > "$OUT/pytest_sel_full.txt" 2>&1; grep -E "^E  |Error|assert" "$OUT/pytest_sel_full.txt" | head -30; tail -12 "$OUT/pytest_sel_full.txt" | tee "$OUT/pytest_sel.txt") ;;
     smoke)
       (cd "$ROOT" && timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee "$OUT/smoke.txt") ;;
     long)       # BASELINE configs[2] (2000-frame loop closure) and configs[3] (5000 frames) at full length through bench.py's long_stream block
@@ -36,6 +37,13 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
       (cd "$ROOT" && timeout 400 python bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-260 "$OUT/bench.json"; tail -3 "$OUT/bench.err") ;;
     bench_driver)   # the driver's invocation
       (cd "$ROOT" && timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"; cut -c1-260 "$OUT/bench_driver.json"; tail -3 "$OUT/bench_driver.err") ;;
+    bench_env)      # the driver's window under environment variants: ENVS="A=1;B=2 C=3" runs once per ';'-separated assignment list
+      IFS=';' read -ra VARIANTS <<< "${ENVS:-}"
+      for V in "${VARIANTS[@]}"; do
+        TAG=$(echo "$V" | tr ' =' '__')
+        (cd "$ROOT" && env $V timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 $BENCH_ARGS > "$OUT/bench_env_$TAG.json" 2> "$OUT/bench_env_$TAG.err"; python -c "
+import json; j=json.load(open('$OUT/bench_env_$TAG.json')); print('$V', round(j['value'],1), 'fps', j['config']['host_thread_ms_per_frame'])"; tail -1 "$OUT/bench_env_$TAG.err")
+      done ;;
     bench_ab)       # the driver's window with the frame's TSDF operators batched (default) and one at a time: same code, same box
       for B in on off; do
         (cd "$ROOT" && timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 --volume-batching $B $BENCH_ARGS > "$OUT/bench_batching_$B.json" 2> "$OUT/bench_batching_$B.err"; python -c "
