@@ -63,6 +63,18 @@ def build_lib(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_probe(force=False):
+    """tools/probe/libbf_probe.so: memory-system probe kernels for the measurement tools (tools/hbm_block_probe.py, tools/pmc_calibrate.py) - NOT part of the product library."""
+    src = os.path.join(ROOT, "tools", "probe", "probe.hip")
+    out = os.path.join(ROOT, "tools", "probe", "libbf_probe.so")
+    if force or _stale(out, [src]):
+        r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", src, "-o", out],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("probe build failed:\n" + r.stdout.decode())
+    return out
+
+
 def build_oracle(force=False):
     """Compile the CPU oracle (oracle/*.cpp) into oracle/_build/liboracle.so via its Makefile."""
     args = ["make", "-s", "-C", ORACLE_DIR]
@@ -88,5 +100,6 @@ def build_ref():
 
 if __name__ == "__main__":
     print(build_lib(force="-f" in sys.argv, verbose=True))
+    print(build_probe(force="-f" in sys.argv))
     print(build_oracle(force="-f" in sys.argv))
     print(build_ref())

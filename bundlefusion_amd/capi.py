@@ -292,6 +292,13 @@ class SceneRepHashSDF:
         return dict(occupied=out[0], heap_free=out[1], duplicate_keys=out[2], free_and_allocated=out[3], leaked=out[4],
                     dropped=out[5])
 
+    def find_blocks(self, pos):
+        """pos: torch int32 [n, 3] cuda (block coordinates) -> torch int32 [n]: ptr or FREE_ENTRY (bf_scene_debug_find_blocks)"""
+        import torch
+        out = torch.empty(pos.shape[0], dtype=torch.int32, device=pos.device)
+        check(lib.bf_scene_debug_find_blocks(self._h, C.c_void_p(pos.data_ptr()), int(pos.shape[0]), C.c_void_p(out.data_ptr())))
+        return out
+
     def kernel_timing(self, enable):
         check(lib.bf_scene_kernel_timing(self._h, int(enable)))
 

@@ -2602,6 +2602,34 @@ int bf_scene_debug_hash(bf_scene* s, uint32_t out[6]) {              // debugHas
     return BF_OK;
 }
 
+// test / tooling aid: ptr of each of n blocks (d_pos: n x int3 block coordinates on the device) or FREE_ENTRY - the table as it stands behind everything issued so far
+namespace {
+__global__ void k_find_blocks(Dev d, uint32_t numBuckets, uint32_t maxChain, const int* __restrict__ pos, uint32_t n, int32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    i3 b; b.x = pos[3 * i]; b.y = pos[3 * i + 1]; b.z = pos[3 * i + 2];
+    const uint32_t h = hashPos(numBuckets, b), hp = h * BF_HASH_BUCKET_SIZE, total = BF_HASH_BUCKET_SIZE * numBuckets;
+    int32_t r = BF_FREE_ENTRY;
+    for (uint32_t j = 0; j < BF_HASH_BUCKET_SIZE && r == BF_FREE_ENTRY; ++j) { const bf_hash_entry e = d.hash[hp + j]; if (e.pos[0] == b.x && e.pos[1] == b.y && e.pos[2] == b.z && e.ptr != BF_FREE_ENTRY) r = e.ptr; }
+    const uint32_t last = hp + BF_HASH_BUCKET_SIZE - 1;
+    uint32_t off = d.hash[last].offset;
+    for (uint32_t it = 0; it < maxChain && r == BF_FREE_ENTRY && off != 0; ++it) {
+        const bf_hash_entry e = d.hash[(last + off) % total];
+        if (e.pos[0] == b.x && e.pos[1] == b.y && e.pos[2] == b.z && e.ptr != BF_FREE_ENTRY) r = e.ptr;
+        off = e.offset;
+    }
+    out[i] = r;
+}
+}  // namespace
+int bf_scene_debug_find_blocks(bf_scene* s, const int32_t* d_pos, uint32_t n, int32_t* d_ptr_out) {
+    BF_REQUIRE(s && d_pos && d_ptr_out, "null argument");
+    BF_TRY_RC(syncAll(s));
+    if (n) hipLaunchKernelGGL(k_find_blocks, dim3(div_up(n, 256u)), dim3(256), 0, s->stream, s->d, s->params.m_hashNumBuckets, s->params.m_hashMaxCollisionLinkedListSize, d_pos, n, d_ptr_out);
+    BF_HIP_TRY(hipGetLastError());
+    BF_HIP_TRY(hipStreamSynchronize(s->stream));
+    return BF_OK;
+}
+
 int bf_scene_kernel_timing(bf_scene* s, int enable) {
     BF_REQUIRE(s, "null scene");
     s->timing = enable != 0;

@@ -41,9 +41,6 @@ BF_API const char* bf_last_error(void);
 BF_API const char* bf_version(void);
 /* number of visible HIP devices, <0 on error (never falls back to a CPU path) */
 BF_API int bf_device_count(void);
-/* measurement aid (tools/hbm_block_probe.py): the voxel update's access pattern - one wave per 6144-byte SDF block of `d_list` (n block indices into the heap
- * d_heap), read completely, writeRows12 twelfths written back - with no arithmetic; mean launch time over `reps` launches in microseconds */
-BF_API int bf_probe_block_copy(uint8_t* d_heap, const uint32_t* d_list, uint32_t n, uint32_t writeRows12, uint32_t grid, uint32_t reps, void* hip_stream, float* mean_us);
 /* Plumbing for hosts that hold raw pointers only: copies / a device-wide fence issued by this library's own HIP
  * runtime (a process may hold more than one copy of libamdhip64; work is only ordered within one of them). */
 /* Restrict every thread of the calling process to the CPUs of the NUMA node HIP device `device` is attached to (intersected with the
@@ -242,6 +239,8 @@ BF_API int bf_scene_get_num_integrated_frames(bf_scene* s, uint32_t* out);
  * out[3]=#entries whose ptr is also on the free heap out[4]=#leaked blocks
  * out[5]=#blocks dropped by the allocator so far (chain window / heap exhausted) */
 BF_API int bf_scene_debug_hash(bf_scene* s, uint32_t out[6]);
+/* test / tooling aid: d_ptr_out[i] = ptr of block d_pos[3 i .. 3 i + 2] (device arrays) or FREE_ENTRY, behind everything issued so far (synchronises) */
+BF_API int bf_scene_debug_find_blocks(bf_scene* s, const int32_t* d_pos, uint32_t n, int32_t* d_ptr_out);
 /* number of allocated SDF blocks (= occupied hash entries), syncs */
 BF_API int bf_scene_get_num_allocated_blocks(bf_scene* s, uint32_t* out);
 /* Opt-in HIP-event timing of the voxel-update kernel (integrateDepthMapKernel<>'s

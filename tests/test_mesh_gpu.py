@@ -72,3 +72,37 @@ def test_marching_cubes_at_4mm_and_after_reintegration(gpu, oracle):
     otris, on = oracle.mc_extract(osc, 0.04, 0.04, e, t, 3000000)
     assert found == on == len(tris) > 100000
     assert np.array_equal(tris.view(np.uint32), otris.view(np.uint32))
+
+
+def test_marching_cubes_on_a_volume_built_under_the_default_contract(gpu):
+    """The consumers of the volume normally see one built by the library's DEFAULT voxel update (fast contract, batched operators).  Here: the same three frames + a
+    re-integration, once operator by operator under the exact contract (the volume the tests above hold to the oracle bit for bit), once as ONE batch under the fast
+    contract; both extracted by the product.  Contract-level bar: sdf differs by <= 1e-5 x truncation, so the zero crossings move by a fraction of a micron - same
+    triangle count within 0.2 %, surface area within 1e-4, centroid within 10 um."""
+    import torch
+    W, H, voxel = 640, 480, 0.004
+    frames = [synth.scene_room(k, W, H) for k in (0, 12, 24)]
+    K = frames[0][3]
+    cam = camera_params(W, H, K["fx"], K["fy"], K["mx"], K["my"])
+    p = default_hash_params(num_buckets=100003, num_sdf_blocks=120000, voxel_size=voxel)
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    T2 = frames[1][2].copy(); T2[:3, 3] += np.float32(0.003)
+    ge = gpu.capi.SceneRepHashSDF(p); ge.set_arith("exact")
+    for (d, c), f in zip(dev, frames):
+        ge.integrate(f[2], d, c, cam)
+    ge.reintegrate(frames[1][2], T2, dev[1][0], dev[1][1], cam)
+    gf = gpu.capi.SceneRepHashSDF(p); gf.set_arith("fast")
+    gf.run_batch([("in", f[2], None, d, c) for (d, c), f in zip(dev, frames)] + [("re", frames[1][2], T2, dev[1][0], dev[1][1])], cam)
+    for g in (ge, gf):
+        g.garbage_collect()
+    mc = gpu.capi.MarchingCubesHashSDF(3000000, p.m_hashNumBuckets, voxel)
+
+    def stats(g):
+        tris, found = mc.extract(g)
+        v = tris[:, :, :3].astype(np.float64)
+        area = 0.5 * np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1)
+        return found, float(area.sum()), (v.mean(axis=1) * area[:, None]).sum(axis=0) / area.sum()
+    ne, ae, ce = stats(ge)
+    nf, af, cf = stats(gf)
+    print("marching cubes, exact vs default contract: %d / %d triangles, area %.6f / %.6f m^2, centroid distance %.2e m" % (ne, nf, ae, af, float(np.linalg.norm(ce - cf))))
+    assert ne > 100000 and abs(nf - ne) <= 0.002 * ne and abs(af - ae) <= 1e-4 * ae and np.linalg.norm(ce - cf) < 1e-5

@@ -80,8 +80,179 @@ def _boundary_dist(pos, ptr, poses, cam, voxel, n_voxels, chunk=16384):
     return out.cpu().numpy()
 
 
-def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000, max_boundary_share=0.08, sdf_tol=SDF_TOL):
-    """fast / exact: (hash, heap, heapCounter, voxels) of the two volumes"""
+def _block_keys(bad, eh):
+    """block coordinates [n_blocks, 3] of the blocks the voxels `bad` live in, and for every voxel the row of its block"""
+    occ = eh["ptr"] != FREE_ENTRY
+    ptrs, poss = eh["ptr"][occ].astype(np.int64), eh["pos"][occ].astype(np.int64)
+    o = np.argsort(ptrs); ptrs, poss = ptrs[o], poss[o]
+    blk = np.searchsorted(ptrs, (bad // VOX_PER_BLOCK) * VOX_PER_BLOCK)
+    assert (ptrs[blk] == (bad // VOX_PER_BLOCK) * VOX_PER_BLOCK).all(), "a differing voxel outside every allocated block"
+    ub, inv = np.unique(blk, return_inverse=True)
+    return poss[ub].astype(np.int32), inv
+
+
+def _existence_gpu(bad, eh, log, frames, cam, p):
+    """exists[t][v]: the block of voxel bad[v] is in the table when the update of the t-th operator of `log` (garbage collections not counted) runs.  The log is
+    replayed through a fresh volume of the product (allocation and garbage collection do not depend on the arithmetic contract) and the blocks are looked up after
+    every operator.  A voxel of a block that does not exist yet is not updated even when its sample is valid - its block is allocated by the rays of OTHER pixels."""
+    import torch
+    import bundlefusion_amd.capi as capi
+    keys, inv = _block_keys(bad, eh)
+    gs = capi.SceneRepHashSDF(p); gs.set_arith("exact")
+    dk = torch.from_numpy(keys).cuda()
+    inv_t = torch.from_numpy(inv).cuda()
+    dev = {}
+    out = []
+    for kind, i, T in log:
+        if kind == "gc":
+            gs.garbage_collect(); continue
+        if i not in dev:
+            d, c = frames[i]
+            dev[i] = (torch.from_numpy(np.ascontiguousarray(d)).cuda(), torch.from_numpy(np.ascontiguousarray(c)).cuda())
+        (gs.deintegrate if kind == "de" else gs.integrate)(T, dev[i][0], dev[i][1], cam)
+        out.append((gs.find_blocks(dk) != FREE_ENTRY)[inv_t])
+    return out
+
+
+def _explain(bad, fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, slots=32, exists=None):
+    """Every voxel that differs between the two volumes beyond the contract must be EXPLAINED (masking every voxel near a pixel boundary
+    would also hide a bug confined to such voxels).  For the voxels `bad` (indices into the voxel arrays) the whole operator log is replayed in float64, here, per
+    voxel: wherever a voxel's projection lies within `band` pixel of a pixel boundary the update is evaluated for the pixel on EITHER side (up to four candidates per
+    operator, every combination carried along - `slots` alternatives per voxel at most).  A voxel is explained when one of its alternatives reproduces the product's
+    (sdf, weight, colour) within the contract's tolerances - i.e. product and oracle only disagree about which side of a pixel boundary a projection fell on at some
+    operator; the oracle's own value must be among the alternatives as well (that checks this replay, not the product).
+    log: [(kind "in" | "de" | "gc", frame, T)], frames[frame] = (depth HxW float32, colour HxWx4 uint8); exists: see _existence_gpu.
+    Returns (unexplained, not_reproducing_the_oracle, most_alternatives)."""
+    import torch
+    dev = "cuda" if torch.cuda.is_available() else "cpu"          # (the CPU form is what tests/test_tsdf_oracle.py checks the replay itself with)
+    nb = len(bad)
+    if nb == 0:
+        return 0, 0, 0
+    occ = eh["ptr"] != FREE_ENTRY
+    ptrs, poss = eh["ptr"][occ].astype(np.int64), eh["pos"][occ].astype(np.int64)
+    o = np.argsort(ptrs); ptrs, poss = ptrs[o], poss[o]
+    blk = np.searchsorted(ptrs, (bad // VOX_PER_BLOCK) * VOX_PER_BLOCK)
+    assert (ptrs[blk] == (bad // VOX_PER_BLOCK) * VOX_PER_BLOCK).all(), "a differing voxel outside every allocated block"
+    l = bad % VOX_PER_BLOCK
+    vox = float(np.float32(p.m_virtualVoxelSize))
+    world = np.stack([(poss[blk, 0] * 8 + (l & 7)), (poss[blk, 1] * 8 + ((l >> 3) & 7)), (poss[blk, 2] * 8 + (l >> 6))], axis=1).astype(np.float64) * vox
+    X = torch.from_numpy(world).to(dev)
+    # the centre of every voxel's block: an operator only updates blocks of its frustum list (blockInFrustum, VoxelUtilHashSDF.h:322-326 / DepthCameraUtil.h:97-142)
+    BC = torch.from_numpy((poss[blk] * 8).astype(np.float64) * vox + vox * 3.5).to(dev)
+    zmin, zmax = float(cam.m_sensorDepthWorldMin), float(cam.m_sensorDepthWorldMax)
+    W_, H_ = cam.m_imageWidth, cam.m_imageHeight
+    max_dist, trunc0, trunc_s, w_max = float(p.m_maxIntegrationDistance), float(p.m_truncation), float(p.m_truncScale), float(p.m_integrationWeightMax)
+    S = torch.zeros((nb, slots), dtype=torch.float64, device=dev); Wt = torch.zeros_like(S); C = torch.zeros((nb, slots, 3), dtype=torch.float64, device=dev)
+    nvalid = torch.ones(nb, dtype=torch.int64, device=dev)
+    overflow = torch.zeros(nb, dtype=torch.bool, device=dev)
+    ar = torch.arange(nb, device=dev)
+    dev_frames = {}
+
+    def apply(kind, s_old, w_old, c_old, ok, sdf, col):
+        """voxelApply (CUDASceneRepHashSDF.cu:425-516) in float64 on arrays of any shape (colour: last axis 3); ok: the sample is valid"""
+        if kind == "in":
+            first = (w_old == 0).unsqueeze(-1)
+            c_new = torch.where(first, col, torch.clamp(torch.round(0.2 * col + 0.8 * c_old), 0.0, 254.0))
+            s_new = (sdf + s_old * w_old) / (1.0 + w_old)
+            w_new = torch.clamp(w_old + 1.0, max=w_max)
+        else:
+            den = w_old - 1.0
+            q = (c_old * w_old.unsqueeze(-1) - col) / den.unsqueeze(-1)
+            c_new = torch.clamp(torch.floor(torch.abs(q) + 0.5) * torch.sign(q), 0.0, 254.0)       # roundf: half away from zero
+            s_new = (s_old * w_old - sdf) / den
+            w_new = torch.clamp(den, min=0.0)
+            dead = (w_new <= 0.001)
+            c_new = torch.where(dead.unsqueeze(-1), torch.zeros_like(c_new), torch.nan_to_num(c_new, nan=0.0, posinf=254.0, neginf=0.0))
+            s_new = torch.where(dead, torch.zeros_like(s_new), s_new)
+            w_new = torch.where(dead, torch.zeros_like(w_new), w_new)
+        okc = ok.unsqueeze(-1)
+        return torch.where(ok, s_new, s_old), torch.where(ok, w_new, w_old), torch.where(okc, c_new, c_old)
+
+    most = 1
+    t_op = -1
+    for kind, fi, T in log:
+        if kind == "gc":
+            continue                # a block is only freed when all its voxels are zero: the states are zero already
+        t_op += 1
+        if fi not in dev_frames:
+            d, c = frames[fi]
+            dev_frames[fi] = (torch.from_numpy(np.ascontiguousarray(d, np.float32)).to(dev).double(), torch.from_numpy(np.ascontiguousarray(c)[..., :3].astype(np.float64)).to(dev))
+        D, Cimg = dev_frames[fi]
+        M = torch.from_numpy(np.linalg.inv(np.asarray(T, np.float64))).to(dev)
+        pc = X @ M[:3, :3].T + M[:3, 3]
+        cz = pc[:, 2]
+        hx, hy = pc[:, 0] * cam.fx / cz + cam.mx + 0.5, pc[:, 1] * cam.fy / cz + cam.my + 0.5
+        fin = torch.isfinite(hx) & torch.isfinite(hy)
+        bc = BC @ M[:3, :3].T + M[:3, 3]
+        bx = (2.0 * (bc[:, 0] * cam.fx / bc[:, 2] + cam.mx) - (W_ - 1.0)) / (W_ - 1.0) * 0.95
+        by = ((H_ - 1.0) - 2.0 * (bc[:, 1] * cam.fy / bc[:, 2] + cam.my)) / (H_ - 1.0) * 0.95
+        bz = (bc[:, 2] - zmin) / (zmax - zmin) * 0.95
+        fin = fin & ~((bx < -1.0) | (bx > 1.0) | (by < -1.0) | (by > 1.0) | (bz < 0.0) | (bz > 1.0))
+        if exists is not None:
+            fin = fin & exists[t_op].to(dev)          # no block, no update
+        hx, hy = torch.where(fin, hx, torch.full_like(hx, -10.0)), torch.where(fin, hy, torch.full_like(hy, -10.0))
+        px0, py0 = torch.trunc(hx).long(), torch.trunc(hy).long()
+        fx_, fy_ = hx - torch.floor(hx), hy - torch.floor(hy)
+        ax = torch.where(fx_ < band, -1, torch.where(fx_ > 1.0 - band, 1, 0)).long()
+        ay = torch.where(fy_ < band, -1, torch.where(fy_ > 1.0 - band, 1, 0)).long()
+        cands = [(torch.zeros_like(ax), torch.zeros_like(ay), torch.ones(nb, dtype=torch.bool, device=dev)), (ax, torch.zeros_like(ay), ax != 0),
+                 (torch.zeros_like(ax), ay, ay != 0), (ax, ay, (ax != 0) & (ay != 0))]
+        samples = []
+        for dx, dy, en in cands:
+            px, py = px0 + dx, py0 + dy
+            inimg = (px >= 0) & (px < W_) & (py >= 0) & (py < H_) & fin & (hx > -1.0) & (hy > -1.0)      # (uint)(int)h < W: h in (-1, 0) converts to 0
+            pxc, pyc = px.clamp(0, W_ - 1), py.clamp(0, H_ - 1)
+            dep = D[pyc, pxc]
+            sdf = dep - cz
+            ok = inimg & torch.isfinite(dep) & (dep < max_dist) & (sdf.abs() < trunc0 + trunc_s * dep)
+            samples.append((en, ok, torch.where(ok, sdf, torch.zeros_like(sdf)), Cimg[pyc, pxc]))
+        ncand = sum(en.long() for en, _, _, _ in samples)
+        single = ncand == 1
+        # voxels with one candidate: every alternative is updated in place
+        en, ok, sdf, col = samples[0]
+        s1, w1, c1 = apply(kind, S, Wt, C, (ok & single).unsqueeze(-1).expand(-1, slots), sdf.unsqueeze(-1).expand(-1, slots), col.unsqueeze(1).expand(-1, slots, -1))
+        multi = torch.nonzero(~single).squeeze(-1)
+        if len(multi):
+            nv = nvalid[multi]
+            newS, newW, newC = torch.zeros((len(multi), slots), dtype=torch.float64, device=dev), torch.zeros((len(multi), slots), dtype=torch.float64, device=dev), torch.zeros((len(multi), slots, 3), dtype=torch.float64, device=dev)
+            before = torch.zeros(len(multi), dtype=torch.int64, device=dev)
+            mS, mW, mC = S[multi], Wt[multi], C[multi]
+            for en, ok, sdf, col in samples:
+                enm = en[multi]
+                a_s, a_w, a_c = apply(kind, mS, mW, mC, ok[multi].unsqueeze(-1).expand(-1, slots), sdf[multi].unsqueeze(-1).expand(-1, slots), col[multi].unsqueeze(1).expand(-1, slots, -1))
+                for sl in range(slots):
+                    tgt = before * nv + sl
+                    m = enm & (sl < nv) & (tgt < slots)
+                    if bool(m.any()):
+                        rows = torch.nonzero(m).squeeze(-1)
+                        newS[rows, tgt[rows]] = a_s[rows, sl]; newW[rows, tgt[rows]] = a_w[rows, sl]; newC[rows, tgt[rows]] = a_c[rows, sl]
+                before = before + enm.long()
+            s1[multi], w1[multi], c1[multi] = newS, newW, newC
+            overflow[multi] |= nv * ncand[multi] > slots
+            nvalid[multi] = torch.clamp(nv * ncand[multi], max=slots)
+            most = max(most, int(nvalid.max()))
+        S, Wt, C = s1, w1, c1
+
+    def matches(vox_arr):
+        tw = torch.from_numpy(vox_arr["weight"][bad].astype(np.float64)).to(dev).unsqueeze(-1)
+        ts = torch.from_numpy(vox_arr["sdf"][bad].astype(np.float64)).to(dev).unsqueeze(-1)
+        tc = torch.from_numpy(vox_arr["color"][bad][:, :3].astype(np.float64)).to(dev).unsqueeze(1)
+        live = torch.arange(slots, device=dev).unsqueeze(0) < nvalid.unsqueeze(-1)
+        hit = live & (Wt == tw) & ((S - ts).abs() <= tol_sdf) & ((C - tc).abs().amax(dim=-1) <= tol_col)
+        return hit.any(dim=1)
+    prod_ok, orac_ok = matches(fvox), matches(evox)
+    for v in torch.nonzero(~prod_ok).squeeze(-1)[:5].tolist():          # on record for a failing run: what the product holds, what the oracle holds, the alternatives
+        k = int(nvalid[v])
+        print("  unexplained voxel %d: product (sdf %.7g, w %g, rgb %s) oracle (sdf %.7g, w %g, rgb %s) alternatives %s" % (
+            int(bad[v]), fvox["sdf"][bad[v]], fvox["weight"][bad[v]], fvox["color"][bad[v]][:3].tolist(), evox["sdf"][bad[v]], evox["weight"][bad[v]], evox["color"][bad[v]][:3].tolist(),
+            [(round(float(S[v, q]), 7), float(Wt[v, q]), C[v, q].tolist()) for q in range(min(k, 6))]))
+    return int((~prod_ok).sum()), int((~orac_ok).sum()), most
+
+
+def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000, max_boundary_share=0.08, sdf_tol=SDF_TOL, explain=None):
+    """fast / exact: (hash, heap, heapCounter, voxels) of the two volumes.  explain = (log, frames): the operator log [(kind, frame, T)] and its frames - every voxel
+    that differs beyond the contract is then replayed per voxel (_explain) and must be reproduced by a neighbouring-pixel choice; the share of voxels near a pixel
+    boundary is reported but no longer bounds anything (poses is ignored in favour of the log's)."""
     fh, fheap, fcnt, fvox = fast
     eh, eheap, ecnt, evox = exact
     assert fcnt == ecnt, what + ": heap counter"
@@ -124,7 +295,18 @@ def _compare(fast, exact, poses, cam, p, what, colour_tol, min_checked=10000, ma
         assert frac_gt1 <= COLOUR_SEQ_FRAC and rep["max_dcol"] <= COLOUR_SEQ_MAX, what + ": colour histogram %s (%.2e beyond 1 LSB)" % (hist[:12].tolist(), frac_gt1)
     # boundary voxels: few, and still inside the truncation band / a plausible weight
     assert rep["checked"] >= min_checked, what + ": only %d voxels compared" % rep["checked"]
-    assert share < max_boundary_share, what + ": %.1f %% boundary voxels" % (100 * share)
+    if explain is not None:
+        log, frames = explain
+        bad_idx = np.nonzero(bad)[0]
+        unexplained, oracle_missed, most = _explain(bad_idx, fvox, evox, eh, log, frames, cam, p, band, max(tol, 2e-6), COLOUR_SEQ_MAX if colour_tol is None else max(colour_tol, 1),
+                                                    exists=_existence_gpu(bad_idx, eh, log, frames, cam, p))
+        rep["explained"] = dict(differing_voxels=int(len(bad_idx)), unexplained=unexplained, oracle_not_reproduced=oracle_missed, most_alternatives=most, of_live_voxels=int(live.sum()))
+        print(what + ": every live voxel compared; %d of %d differ beyond the contract, all within %.1e px of a pixel boundary; replayed per voxel with the neighbouring pixel as alternative: "
+              "%d unexplained (the oracle's own value not reproduced for %d; at most %d alternatives per voxel)" % (len(bad_idx), int(live.sum()), band, unexplained, oracle_missed, most))
+        assert unexplained == 0, what + ": %d differing voxels are not explained by a neighbouring-pixel choice" % unexplained
+        assert oracle_missed <= max(2, len(bad_idx) // 200), what + ": the per-voxel replay does not reproduce the oracle for %d voxels" % oracle_missed
+    else:
+        assert share < max_boundary_share, what + ": %.1f %% boundary voxels" % (100 * share)
     assert rep["max_dsdf_in_band"] <= 2 * trunc_band
     assert rep["max_dweight_in_band"] <= len(poses)
     return rep

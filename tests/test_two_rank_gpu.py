@@ -26,8 +26,12 @@ def _free_port():
     return p
 
 
-def test_two_processes_real_pipeline_and_chunk_worker(gpu, tmp_path):
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_two_processes_real_pipeline_and_chunk_worker(gpu, tmp_path, monkeypatch, arith):
+    """arith: the voxel update's contract in all three processes (BF_TSDF_ARITH) - `fast` is the library default; both are deterministic, so the union of the shards
+    is the serial volume bit for bit under either."""
     import torch
+    monkeypatch.setenv("BF_TSDF_ARITH", arith)
     W, H, n, world = 320, 240, 41, 2            # 4 local chunks = 2 rounds of 2
     port = _free_port()
     procs = []

@@ -65,6 +65,12 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
         done
         python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A
       done ;;
+    calibrate)   # FETCH_SIZE / WRITE_SIZE against KNOWN byte counts on the update's own access widths (tools/pmc_calibrate.py)
+      for C in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/r_cal_$C
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_cal_$C -o run -- python "$ROOT/tools/pmc_calibrate.py" run > /dev/null 2>&1)
+      done
+      python "$ROOT/tools/pmc_calibrate.py" read "$(db /tmp/r_cal_FETCH_SIZE)" "$(db /tmp/r_cal_WRITE_SIZE)" "$OUT/pmc_calibration.json" | grep -E "factor|bytes_per_launch" ;;
     sq)   # where do the voxel-update waves spend their cycles: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)
       rm -rf /tmp/r_sq
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES \

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The memory system's rate for the voxel update's ACCESS PATTERN, without its arithmetic and gathers.
 
-bf_probe_block_copy (csrc/probe.hip): one wave per 6144-byte SDF block, blocks scattered over the heap in list order, every block read with
+bf_probe_block_copy (tools/probe/probe.hip -> tools/probe/libbf_probe.so, built by bundlefusion_amd.build.build_probe; not part of the product library): one wave per 6144-byte SDF block, blocks scattered over the heap in list order, every block read with
 global_load_dwordx4 (fully coalesced 1 KB rows) and 9/12 of it written back (the update reads 6.1 KB and writes ~4.6 KB per block), launch geometry
 of the update.  Two list orders: ascending block index (what a fresh heap gives: consecutive allocations) and a random permutation (a long-running
 volume after garbage collections).  Heap 3.6 GB like the bench configuration (600 000 blocks), 34 000 blocks per launch.
@@ -16,7 +16,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from bundlefusion_amd.capi import lib, check
+from bundlefusion_amd import build as _build
+
+lib = C.CDLL(_build.build_probe())
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("probe call failed: %d" % rc)
 
 
 def main():

@@ -6,7 +6,9 @@
 // what the memory system gives to this pattern the update reaches.
 #include <hip/hip_runtime.h>
 
-#include "bf_internal.h"
+#include <stdint.h>
+
+#define PROBE_TRY(expr) do { if ((expr) != hipSuccess) return 2; } while (0)
 
 namespace {
 
@@ -29,28 +31,60 @@ __global__ __launch_bounds__(256) void k_probe_blocks(const uint32_t* __restrict
     }
 }
 
+// The same walk with the voxel update's own access widths: a block is 8 slices of 64 voxels x 12 bytes; lane l reads the three dwords of voxel l of every slice
+// (three global_load_dword per slice, lanes 12 bytes apart: together the 768 contiguous bytes of the slice) and writes `writeSlices` of the 8 slices back the same
+// way - what k_update_apx / k_update_batch_apx issue (tsdf.hip, tsdf_batch.h).  Used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on THIS access pattern
+// (tools/pmc_calibrate.py): the bytes it moves are known exactly.
+__global__ __launch_bounds__(256) void k_probe_slices(const uint32_t* __restrict__ list, uint32_t n, uint8_t* __restrict__ heap, uint32_t writeSlices, uint32_t salt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), nWaves = gridDim.x * 4u;
+    for (uint32_t blk = wave; blk < n; blk += nWaves) {
+        uint32_t* base = reinterpret_cast<uint32_t*>(heap + (size_t)list[blk] * 6144u) + lane * 3u;      // voxel `lane` of slice 0
+        uint32_t r[8][3];
+#pragma unroll
+        for (int z = 0; z < 8; ++z)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r[z][k] = base[z * 192 + k];
+#pragma unroll
+        for (int z = 0; z < 8; ++z)
+            if ((uint32_t)z < writeSlices) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) base[z * 192 + k] = r[z][k] ^ (k == 0 ? salt : 0u);
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
+// `reps` launches of the slice-pattern kernel (no timing: a counter-collection run)
+__attribute__((visibility("default"))) int bf_probe_slices(uint8_t* d_heap, const uint32_t* d_list, uint32_t n, uint32_t writeSlices, uint32_t grid, uint32_t reps, void* hip_stream) {
+    if (!(d_heap && d_list && reps > 0 && grid > 0 && writeSlices <= 8)) return 1;
+    for (uint32_t r = 0; r < reps; ++r) hipLaunchKernelGGL(k_probe_slices, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_list, n, d_heap, writeSlices, r + 2u);
+    PROBE_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    return 0;
+}
+
+
 // heap: numBlocks x 6144 bytes; d_list: n block indices (< numBlocks).  writeRows12: twelfths of a block written back (9 = 4.6 KB of 6.1 KB).  Runs `reps`
 // launches on `hip_stream` between two events and returns the mean launch time in microseconds.
-int bf_probe_block_copy(uint8_t* d_heap, const uint32_t* d_list, uint32_t n, uint32_t writeRows12, uint32_t grid, uint32_t reps, void* hip_stream, float* mean_us) {
-    BF_REQUIRE(d_heap && d_list && mean_us && reps > 0 && grid > 0 && writeRows12 <= 12, "bad argument");
+__attribute__((visibility("default"))) int bf_probe_block_copy(uint8_t* d_heap, const uint32_t* d_list, uint32_t n, uint32_t writeRows12, uint32_t grid, uint32_t reps, void* hip_stream, float* mean_us) {
+    if (!(d_heap && d_list && mean_us && reps > 0 && grid > 0 && writeRows12 <= 12)) return 1;
     hipStream_t st = (hipStream_t)hip_stream;
     hipEvent_t e0, e1;
-    BF_HIP_TRY(hipEventCreate(&e0));
-    BF_HIP_TRY(hipEventCreate(&e1));
+    PROBE_TRY(hipEventCreate(&e0));
+    PROBE_TRY(hipEventCreate(&e1));
     hipLaunchKernelGGL(k_probe_blocks, dim3(grid), dim3(256), 0, st, d_list, n, d_heap, writeRows12, 1u);       // warm-up
-    BF_HIP_TRY(hipEventRecord(e0, st));
+    PROBE_TRY(hipEventRecord(e0, st));
     for (uint32_t r = 0; r < reps; ++r) hipLaunchKernelGGL(k_probe_blocks, dim3(grid), dim3(256), 0, st, d_list, n, d_heap, writeRows12, r + 2u);
-    BF_HIP_TRY(hipEventRecord(e1, st));
-    BF_HIP_TRY(hipEventSynchronize(e1));
+    PROBE_TRY(hipEventRecord(e1, st));
+    PROBE_TRY(hipEventSynchronize(e1));
     float ms = 0.0f;
-    BF_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    PROBE_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *mean_us = 1e3f * ms / (float)reps;
-    return BF_OK;
+    return 0;
 }
 
 }  // extern "C"
