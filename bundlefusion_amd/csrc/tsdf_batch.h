@@ -49,7 +49,6 @@ __global__ void k_batch_reset(BatchDev bd, uint32_t numBuckets) {
 // march: grid (tiles / 4, operators)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_batch_march(Dev d, BatchDev bd, BatchCommon c, BatchMarchArgs a) {
-    __builtin_amdgcn_s_setprio(3);
     __shared__ unsigned long long setAll[4][WSET];
     __shared__ unsigned long long listAll[4][WLIST];
     const uint32_t op = blockIdx.y;

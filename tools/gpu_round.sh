@@ -65,6 +65,12 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
         done
         python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A
       done ;;
+    hiptrace)   # host side: HIP API calls per thread (totals) and a merged API + kernel window (no counters: --pmc must not be combined with the hip trace)
+      rm -rf /tmp/r_hip
+      (cd /tmp && timeout 400 rocprofv3 --hip-trace --kernel-trace -d /tmp/r_hip -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract $BENCH_ARGS > "$OUT/bench_hiptraced.json" 2> /dev/null)
+      D=$(db /tmp/r_hip)
+      python "$ROOT/tools/rocpd_hip_trace.py" "$D" > "$OUT/hip_api_totals.txt" 2>&1; head -40 "$OUT/hip_api_totals.txt"
+      python "$ROOT/tools/rocpd_hip_trace.py" "$D" --window ${HIP_WINDOW_MS:-5} --end ${HIP_END_MS:-9} > "$OUT/hip_window.txt" 2>&1; wc -l "$OUT/hip_window.txt" ;;
     calibrate)   # FETCH_SIZE / WRITE_SIZE against KNOWN byte counts on the update's own access widths (tools/pmc_calibrate.py)
       for C in FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/r_cal_$C
