@@ -105,6 +105,72 @@ __global__ __launch_bounds__(256) void k_blur(BlurJobs jobs, Taps taps) {
     }
 }
 
+// One launch per OCTAVE (round 5; rounds 1-4 built the pyramid with 18 dependent launches of the kernel above, 190-330 us per frame of 8-18 us launches).
+// A workgroup owns an OT_W x OT_H tile of the octave and computes ALL six levels of it: level a is the blur of level a - 1, so the tile of level 5 needs level 4
+// on a halo of r5, level 3 on r5 + r4, ... - the region shrinks from level to level inside LDS (two buffers: the current level, and the H pass of the next).  Every
+// level's region is kept replicate-padded (the value stored for a position outside the image is the value at the clamped position), so the H and V passes read
+// their taps without clamping - exactly the clamp-to-edge fetches of FilterH / FilterV (ProgramCU.cu:159-264): same taps, same order, same bits as k_blur.
+// Level 0 is the blur of the input image (octave 0, filter 0) or the 2:1 down-sample of the previous octave's level 3 (DownsampleKernel :330-354).
+constexpr int OT_W = 40, OT_H = 32;
+struct OctaveJob {
+    const float* src; float* dst[NLEV];
+    int w, h, srcW, first, tilesX;
+    int halo[NLEV]; int haloIn;       // halo of level a's region around the tile; of the input region (octave 0)
+};
+
+BF_DEV void octaveBlurLevel(const float* A, float* B, float* Aout, const float* k, int fw, int x0, int y0, int w, int h, int Hs, int Hd) {
+    const int r = fw >> 1;
+    const int SW = OT_W + 2 * Hs, SH = OT_H + 2 * Hs, DW = OT_W + 2 * Hd, DH = OT_H + 2 * Hd;
+    for (int t = threadIdx.x; t < SH * DW; t += blockDim.x) {          // H pass: every row of the source region, the destination's columns
+        const int row = t / DW, dx = t % DW;
+        const int xc = min(max(x0 - Hd + dx, 0), w - 1);
+        const float* a = A + row * SW + (xc - x0) + Hs - r;
+        float v = 0.0f;
+        for (int i = 0; i < fw; ++i) v += a[i] * k[i];
+        B[t] = v;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < DH * DW; t += blockDim.x) {          // V pass
+        const int dy = t / DW, dx = t % DW;
+        const int yc = min(max(y0 - Hd + dy, 0), h - 1);
+        const float* b = B + ((yc - y0) + Hs - r) * DW + dx;
+        float v = 0.0f;
+        for (int i = 0; i < fw; ++i) v += b[i * DW] * k[i];
+        Aout[t] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void k_octave(OctaveJob job, Taps taps, int floatsA) {
+    extern __shared__ float oct_lds[];
+    float* A = oct_lds; float* B = oct_lds + floatsA;
+    const int x0 = ((int)blockIdx.x % job.tilesX) * OT_W, y0 = ((int)blockIdx.x / job.tilesX) * OT_H;
+    const int w = job.w, h = job.h;
+    int H = job.first ? job.haloIn : job.halo[0];
+    {   // the first region: replicate-padded input image, or the down-sampled previous octave
+        const int SW = OT_W + 2 * H, SH = OT_H + 2 * H;
+        for (int t = threadIdx.x; t < SW * SH; t += blockDim.x) {
+            const int xc = min(max(x0 - H + t % SW, 0), w - 1), yc = min(max(y0 - H + t / SW, 0), h - 1);
+            A[t] = job.first ? job.src[(size_t)yc * w + xc] : job.src[(size_t)(yc << 1) * job.srcW + min(xc << 1, job.srcW - 1)];
+        }
+        __syncthreads();
+    }
+    for (int a = 0; a < NLEV; ++a) {
+        if (a > 0 || job.first) {
+            const int Hd = job.halo[a];
+            octaveBlurLevel(A, B, A, taps.k[a], taps.fw[a], x0, y0, w, h, H, Hd);
+            H = Hd;
+        }
+        const int DW = OT_W + 2 * H;
+        float* dst = job.dst[a];
+        for (int t = threadIdx.x; t < OT_W * OT_H; t += blockDim.x) {
+            const int tx = t % OT_W, ty = t / OT_W;
+            if (x0 + tx < w && y0 + ty < h) dst[(size_t)(y0 + ty) * w + x0 + tx] = A[(ty + H) * DW + tx + H];
+        }
+        // (no barrier: the next level's H pass only reads A)
+    }
+}
+
 // gradient magnitude / orientation of a gaussian level (ComputeDOG_Kernel :550-569); linear fetches
 // outside the image buffer read 0 like tex1Dfetch
 struct GradJob { const float* g; float* mag; float* ang; int w, h, blocks; };
@@ -500,7 +566,8 @@ struct bf_sift {
     Levels levels;
     GradJobs gradJobs; int gradBlocks = 0;
     DetectCfg detect; int detectBlocks = 0;
-    std::vector<BlurJobs> schedule;
+    std::vector<BlurJobs> schedule;        // the level-by-level pyramid (k_blur), kept for bf_sift_set_fused_octaves(0)
+    OctaveJob octave[NUM_OCT]; int octaveBlocks[NUM_OCT]; int octFloatsA = 0, octFloatsB = 0; bool fusedOctaves = true;
     float* gauss[NUM_OCT][NLEV];
     float* mag[NUM_OCT][3]; float* ang[NUM_OCT][3];
     SiftDev d{};
@@ -600,9 +667,35 @@ int bf_sift_create(uint32_t width, uint32_t height, uint32_t depthWidth, uint32_
             }
         if (bj.n) s->schedule.push_back(bj);
     }
+    {   // the per-octave jobs of k_octave: halos from the filter widths
+        int r[NLEV];
+        for (int a = 0; a < NLEV; ++a) r[a] = s->taps.fw[a] >> 1;
+        int halo[NLEV];
+        halo[NLEV - 1] = 0;
+        for (int a = NLEV - 2; a >= 0; --a) halo[a] = halo[a + 1] + r[a + 1];
+        const int haloIn = halo[0] + r[0];
+        s->octFloatsA = (OT_W + 2 * haloIn) * (OT_H + 2 * haloIn);
+        s->octFloatsB = (OT_H + 2 * haloIn) * (OT_W + 2 * halo[0]);
+        for (int o = 0; o < NUM_OCT; ++o) {
+            OctaveJob& j = s->octave[o];
+            memset(&j, 0, sizeof j);
+            j.w = s->W >> o; j.h = s->H >> o; j.first = o == 0 ? 1 : 0;
+            j.src = o == 0 ? nullptr : s->gauss[o - 1][3]; j.srcW = o == 0 ? j.w : (s->W >> (o - 1));
+            for (int a = 0; a < NLEV; ++a) { j.dst[a] = s->gauss[o][a]; j.halo[a] = halo[a]; }
+            j.haloIn = haloIn;
+            j.tilesX = (j.w + OT_W - 1) / OT_W;
+            s->octaveBlocks[o] = j.tilesX * ((j.h + OT_H - 1) / OT_H);
+        }
+        const size_t bytes = (size_t)(s->octFloatsA + s->octFloatsB) * 4;
+        if (bytes > 160 * 1024 - 512) { set_error("bf_sift_create: octave tile does not fit the LDS"); bf_sift_destroy(s); return BF_ERR_INVALID_ARG; }
+        BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_octave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
     *out = s;
     return BF_OK;
 }
+
+// 1 (default): one launch per octave (k_octave); 0: one launch per pyramid level (k_blur) - same pyramid bit for bit
+int bf_sift_set_fused_octaves(bf_sift* s, int enable) { BF_REQUIRE(s, "null sift"); s->fusedOctaves = enable != 0; return BF_OK; }
 
 int bf_sift_destroy(bf_sift* s) {
     if (!s) return BF_OK;
@@ -620,6 +713,13 @@ int bf_sift_set_stream(bf_sift* s, void* st) { BF_REQUIRE(s, "null sift"); s->st
 int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_depth, float* d_keyPoints, uint8_t* d_descs, int32_t* d_numKeys) {
     BF_REQUIRE(s && d_intensity && d_depth && d_keyPoints && d_descs && d_numKeys, "null argument");
     hipStream_t st = s->stream;
+    if (s->fusedOctaves) {
+        for (int o = 0; o < NUM_OCT; ++o) {
+            OctaveJob j = s->octave[o];
+            if (o == 0) j.src = d_intensity;
+            hipLaunchKernelGGL(k_octave, dim3(s->octaveBlocks[o]), dim3(512), (size_t)(s->octFloatsA + s->octFloatsB) * 4, st, j, s->taps, s->octFloatsA);
+        }
+    } else
     for (size_t i = 0; i < s->schedule.size(); ++i) {
         BlurJobs bj = s->schedule[i];
         int blocks = 0;

@@ -31,6 +31,30 @@ def test_pyramid_bit_exact(gpu, oracle):
             assert np.array_equal(sift.debug_level(o, a), oracle.sift_pyramid_level(I, o, a)), (o, a)
 
 
+@pytest.mark.parametrize("size", [(640, 480), (320, 240), (200, 136)])
+def test_pyramid_one_launch_per_octave_equals_one_per_level(gpu, oracle, size):
+    """k_octave (the default: all six levels of a tile in LDS, halos shrinking from level to level) against k_blur (one launch per level group) and the oracle: every
+    level of every octave bit for bit, incl. image sizes that are not a multiple of the 40 x 32 tile, and the features built on top."""
+    import torch
+    W, H = size
+    d, c, T, K = synth.scene_room(300, W, H)
+    I = rgbx_to_intensity(c)
+    res = []
+    for fused in (True, False):
+        sift = gpu.capi.Sift(W, H, W, H)
+        sift.set_fused_octaves(fused)
+        keys = torch.zeros(1024, 4, device="cuda"); descs = torch.zeros(1024, 128, dtype=torch.uint8, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        sift.run(torch.from_numpy(I).cuda(), torch.from_numpy(d).cuda(), keys, descs, cnt)
+        n = int(cnt.item())
+        res.append(([[sift.debug_level(o, a) for a in range(6)] for o in range(4)], n, keys.cpu().numpy()[:n], descs.cpu().numpy()[:n]))
+    for o in range(4):
+        for a in range(6):
+            assert np.array_equal(res[0][0][o][a].view(np.uint32), res[1][0][o][a].view(np.uint32)), (o, a)
+            if a in (0, 3, 5):
+                assert np.array_equal(res[0][0][o][a], oracle.sift_pyramid_level(I, o, a)), (o, a)
+    assert res[0][1] == res[1][1] > 10 and np.array_equal(res[0][2].view(np.uint32), res[1][2].view(np.uint32)) and np.array_equal(res[0][3], res[1][3])
+
+
 @pytest.mark.parametrize("k", [0, 200, 450, 777])
 def test_features_bit_exact(gpu, oracle, k):
     d, c, T, K = synth.scene_room(k)

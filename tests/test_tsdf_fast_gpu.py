@@ -80,6 +80,24 @@ def _boundary_dist(pos, ptr, poses, cam, voxel, n_voxels, chunk=16384):
     return out.cpu().numpy()
 
 
+def _inverse44_f32(T):
+    """bf::inverse44 (csrc/bf_device.h) operation by operation in float32: the world -> camera transform both the product and the oracle project voxels with"""
+    m = np.asarray(T, np.float32).reshape(16)
+    f = np.float32
+    adj = np.zeros(16, np.float32)
+    for r in range(4):
+        for c in range(4):
+            rows = [i for i in range(4) if i != c]; cols = [j for j in range(4) if j != r]
+            s_ = f(-1.0) if ((r + c) & 1) else f(1.0)
+            A = lambda i, j: m[rows[i] * 4 + cols[j]]
+            adj[r * 4 + c] = f(f(f(f(f(f(s_ * A(0, 0)) * A(1, 1)) * A(2, 2)) - f(f(f(s_ * A(0, 0)) * A(1, 2)) * A(2, 1))) - f(f(f(s_ * A(1, 0)) * A(0, 1)) * A(2, 2))) +
+                                 f(f(f(s_ * A(1, 0)) * A(0, 2)) * A(2, 1)))
+            adj[r * 4 + c] = f(f(adj[r * 4 + c] + f(f(f(s_ * A(2, 0)) * A(0, 1)) * A(1, 2))) - f(f(f(s_ * A(2, 0)) * A(0, 2)) * A(1, 1)))
+    det = f(f(f(f(m[0] * adj[0]) + f(m[1] * adj[4])) + f(m[2] * adj[8])) + f(m[3] * adj[12]))
+    detr = f(f(1.0) / det)
+    return (adj * detr).astype(np.float32).reshape(4, 4)
+
+
 def _block_keys(bad, eh):
     """block coordinates [n_blocks, 3] of the blocks the voxels `bad` live in, and for every voxel the row of its block"""
     occ = eh["ptr"] != FREE_ENTRY
@@ -114,7 +132,7 @@ def _existence_gpu(bad, eh, log, frames, cam, p):
     return out
 
 
-def _explain(bad, fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, slots=32, exists=None):
+def _explain(bad, fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, slots=64, exists=None):
     """Every voxel that differs between the two volumes beyond the contract must be EXPLAINED (masking every voxel near a pixel boundary
     would also hide a bug confined to such voxels).  For the voxels `bad` (indices into the voxel arrays) the whole operator log is replayed in float64, here, per
     voxel: wherever a voxel's projection lies within `band` pixel of a pixel boundary the update is evaluated for the pixel on EITHER side (up to four candidates per
@@ -178,7 +196,7 @@ def _explain(bad, fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, s
             d, c = frames[fi]
             dev_frames[fi] = (torch.from_numpy(np.ascontiguousarray(d, np.float32)).to(dev).double(), torch.from_numpy(np.ascontiguousarray(c)[..., :3].astype(np.float64)).to(dev))
         D, Cimg = dev_frames[fi]
-        M = torch.from_numpy(np.linalg.inv(np.asarray(T, np.float64))).to(dev)
+        M = torch.from_numpy(_inverse44_f32(T).astype(np.float64)).to(dev)          # the float32 inverse the kernels use, not the exact one: the pixel a projection falls into is decided with it
         pc = X @ M[:3, :3].T + M[:3, 3]
         cz = pc[:, 2]
         hx, hy = pc[:, 0] * cam.fx / cz + cam.mx + 0.5, pc[:, 1] * cam.fy / cz + cam.my + 0.5
@@ -193,8 +211,9 @@ def _explain(bad, fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, s
         hx, hy = torch.where(fin, hx, torch.full_like(hx, -10.0)), torch.where(fin, hy, torch.full_like(hy, -10.0))
         px0, py0 = torch.trunc(hx).long(), torch.trunc(hy).long()
         fx_, fy_ = hx - torch.floor(hx), hy - torch.floor(hy)
-        ax = torch.where(fx_ < band, -1, torch.where(fx_ > 1.0 - band, 1, 0)).long()
-        ay = torch.where(fy_ < band, -1, torch.where(fy_ > 1.0 - band, 1, 0)).long()
+        eb = 2.0 * band          # alternatives are enumerated in a wider band than the one the differing voxels must lie in: the projection here is a float64 evaluation, not either kernel's
+        ax = torch.where(fx_ < eb, -1, torch.where(fx_ > 1.0 - eb, 1, 0)).long()
+        ay = torch.where(fy_ < eb, -1, torch.where(fy_ > 1.0 - eb, 1, 0)).long()
         cands = [(torch.zeros_like(ax), torch.zeros_like(ay), torch.ones(nb, dtype=torch.bool, device=dev)), (ax, torch.zeros_like(ay), ax != 0),
                  (torch.zeros_like(ax), ay, ay != 0), (ax, ay, (ax != 0) & (ay != 0))]
         samples = []
@@ -205,7 +224,12 @@ def _explain(bad, fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, s
             dep = D[pyc, pxc]
             sdf = dep - cz
             ok = inimg & torch.isfinite(dep) & (dep < max_dist) & (sdf.abs() < trunc0 + trunc_s * dep)
-            samples.append((en, ok, torch.where(ok, sdf, torch.zeros_like(sdf)), Cimg[pyc, pxc]))
+            sdf = torch.where(ok, sdf, torch.zeros_like(sdf))
+            col = torch.where(ok.unsqueeze(-1), Cimg[pyc, pxc], torch.zeros_like(Cimg[pyc, pxc]))
+            if samples:          # an alternative only counts when it differs from one already listed (same validity, depth and colour: the same update)
+                for _, ok0, sdf0, col0 in samples:
+                    en = en & ~((ok == ok0) & (sdf == sdf0) & (col == col0).all(dim=-1))
+            samples.append((en, ok, sdf, col))
         ncand = sum(en.long() for en, _, _, _ in samples)
         single = ncand == 1
         # voxels with one candidate: every alternative is updated in place

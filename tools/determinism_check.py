@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Run-to-run determinism of the frame loop: the same 33 frames (640x480 @4 mm, three local chunks, re-integrations, GC) through R fresh pipelines per arithmetic
+contract of the voxel update; trajectories, counters and (per contract) the whole volume must be bit-identical across runs, and the trajectories across contracts.
+    python tools/determinism_check.py [runs]"""
+import hashlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bundlefusion_amd as bf
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, sensor_desc
+
+
+def main():
+    runs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    W, H, n = 640, 480, 33
+    frames = synth.render_frames(range(n))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    out = []
+    for r in range(runs):
+        for arith in ("exact", "fast"):
+            gas = default_app_state(); gbs = default_bundling_state()
+            gas.s_integrationWidth, gas.s_integrationHeight = W, H
+            gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.004, 1000000, 250000
+            gbs.s_maxNumImages = 8
+            p = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+            p.scene().set_arith(arith)
+            for d, c in dev:
+                assert p.process_frame(d, c)
+            for _ in range(4):
+                p.process_end_of_sequence()
+            p.synchronize()
+            h, heap, cnt, vox = p.scene().download()
+            sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+            out.append({"run": r, "arith": arith, "integrated": sha(p.integrated_trajectory()), "optimized": sha(p.optimized_trajectory()), "counters": p.counters(),
+                        "table": sha(h["pos"]) + sha(h["ptr"]), "heap": sha(heap[:cnt + 1]), "voxels": sha(vox.view(np.uint8))})
+            print(json.dumps(out[-1]), flush=True)
+            del p
+    traj = {(o["integrated"], o["optimized"]) for o in out}
+    vol = {a: {(o["table"], o["heap"], o["voxels"]) for o in out if o["arith"] == a} for a in ("exact", "fast")}
+    print(json.dumps({"distinct_trajectories": len(traj), "distinct_volumes_exact": len(vol["exact"]), "distinct_volumes_fast": len(vol["fast"])}))
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,8 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
         done
         python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A
       done ;;
+    determinism)
+      (cd "$ROOT" && timeout 300 python tools/determinism_check.py ${DET_RUNS:-3} 2>&1 | grep -v amdgpu.ids | tee "$OUT/determinism.txt" | tail -8) ;;
     hiptrace)   # host side: HIP API calls per thread (totals) and a merged API + kernel window (no counters: --pmc must not be combined with the hip trace)
       rm -rf /tmp/r_hip
       (cd /tmp && timeout 400 rocprofv3 --hip-trace --kernel-trace -d /tmp/r_hip -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract $BENCH_ARGS > "$OUT/bench_hiptraced.json" 2> /dev/null)
