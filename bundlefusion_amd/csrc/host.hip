@@ -298,6 +298,17 @@ static int im_process(bf_image_manager* im, const float* depth, const uint8_t* c
         if (im->inputGuard[k]) BF_HIP_TRY(hipStreamWaitEvent(st, im->inputGuard[k], 0));
         im->d_depthInputRaw = im->rawSet[k]; im->d_depthInputFiltered = im->filtSet[k]; im->d_colorInput = im->colSet[k];
     }
+    // ---- the frame is in device memory already, sensor and integration resolution coincide, erosion and depth filter on (the frame loop's usual case): the same
+    // images in three launches - erosion 1 straight from the caller's depth with the colour copies riding along, erosion 2, depth filter writing the stored frame too
+    if (kind == hipMemcpyDeviceToDevice && im->onGPU && !im->storeTexels && nc == nd && sn.colorWidth == im->wInt && sn.colorHeight == im->hInt && sn.depthWidth == im->wInt &&
+        sn.depthHeight == im->hInt && im->gbs.s_erodeSIFTdepth && im->gbs.s_depthFilter) {
+        BF_TRY(bf_image_erode_depth_map_and_copy(im->d_depthInputFiltered, depth, 3, sn.depthWidth, sn.depthHeight, 0.05f, 0.3f, color, im->d_colorInput, frameColor, st));
+        BF_TRY(bf_image_erode_depth_map(im->d_depthInputRaw, im->d_depthInputFiltered, 3, sn.depthWidth, sn.depthHeight, 0.05f, 0.3f, st));
+        BF_TRY(bf_image_gauss_filter_depth_map2(im->d_depthInputFiltered, frameDepth, im->d_depthInputRaw, im->gbs.s_depthSigmaD, im->gbs.s_depthSigmaR, sn.depthWidth, sn.depthHeight, st));
+        im->currFrame++;
+        *gotFrame = 1;
+        return BF_OK;
+    }
     // ---- colour  (.cpp:39-60)
     BF_HIP_TRY(hipMemcpyAsync(im->d_colorInput, color, nc * 4, kind, st));
     const bool sameC = sn.colorWidth == im->wInt && sn.colorHeight == im->hInt;

@@ -29,9 +29,12 @@ Taps makeTaps(float sigma, int r) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void k_erode(float* __restrict__ out, const float* __restrict__ in, int s, int w, int h, float dThresh, float fracReq) {
+// csrc / cdst1 / cdst2 (optional): a pixel-wise copy of a 4-byte-per-pixel image of the same size riding along (the ingest's colour copies: one launch less per copy)
+__global__ __launch_bounds__(256) void k_erode(float* __restrict__ out, const float* __restrict__ in, int s, int w, int h, float dThresh, float fracReq,
+                                               const uint32_t* __restrict__ csrc, uint32_t* __restrict__ cdst1, uint32_t* __restrict__ cdst2) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
+    if (csrc) { const uint32_t c = csrc[y * w + x]; if (cdst1) cdst1[y * w + x] = c; if (cdst2) cdst2[y * w + x] = c; }
     unsigned count = 0;
     const float old = in[y * w + x];
     for (int i = -s; i <= s; ++i)
@@ -44,7 +47,8 @@ __global__ __launch_bounds__(256) void k_erode(float* __restrict__ out, const fl
     out[y * w + x] = ((float)count / (float)sum >= fracReq) ? BF_MINF : old;
 }
 
-__global__ __launch_bounds__(256) void k_gauss_depth(float* __restrict__ out, const float* __restrict__ in, Taps t, float sigmaR, int w, int h) {
+// out2 (optional): a second copy of the result (the ingest's stored frame)
+__global__ __launch_bounds__(256) void k_gauss_depth(float* __restrict__ out, const float* __restrict__ in, Taps t, float sigmaR, int w, int h, float* __restrict__ out2) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
     const int r = t.r, n = 2 * r + 1;
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(256) void k_gauss_depth(float* __restrict__ out, co
                 }
     if (sumW > 0.0f) res = sum / sumW;
     out[y * w + x] = res;
+    if (out2) out2[y * w + x] = res;
 }
 
 __global__ __launch_bounds__(256) void k_gauss_intensity(float* __restrict__ out, const float* __restrict__ in, Taps t, int w, int h) {
@@ -115,7 +120,18 @@ extern "C" {
 int bf_image_erode_depth_map(float* d_output, const float* d_input, int structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq,
                              void* stream) {
     BF_REQUIRE(d_output && d_input && d_output != d_input && structureSize >= 0 && width && height, "bad argument");
-    k_erode<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq);
+    k_erode<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq, nullptr, nullptr, nullptr);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+// The erosion with a pixel-wise copy of a 4-byte-per-pixel image of the same size riding along (d_copySrc -> d_copyDst1 and, if not null, d_copyDst2): what
+// CUDAImageManager::process does with three launches (CUDAImageManager.cpp:39-60, :66-86) when the frame already lives in device memory.
+int bf_image_erode_depth_map_and_copy(float* d_output, const float* d_input, int structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq,
+                                      const void* d_copySrc, void* d_copyDst1, void* d_copyDst2, void* stream) {
+    BF_REQUIRE(d_output && d_input && d_output != d_input && structureSize >= 0 && width && height && d_copySrc && d_copyDst1, "bad argument");
+    k_erode<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq,
+                                                                           (const uint32_t*)d_copySrc, (uint32_t*)d_copyDst1, (uint32_t*)d_copyDst2);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -124,7 +140,17 @@ int bf_image_gauss_filter_depth_map(float* d_output, const float* d_input, float
     BF_REQUIRE(d_output && d_input && d_output != d_input && width && height, "bad argument");
     const int r = (int)ceil(2.0 * sigmaD);
     BF_REQUIRE(r >= 0 && r <= MAX_R, "sigmaD too large (kernel radius > 8)");
-    k_gauss_depth<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, makeTaps(sigmaD, r), sigmaR, (int)width, (int)height);
+    k_gauss_depth<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, makeTaps(sigmaD, r), sigmaR, (int)width, (int)height, nullptr);
+    BF_HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+// ... writing the filtered map to a second buffer as well (the ingest's stored frame, CUDAImageManager.cpp:121-136)
+int bf_image_gauss_filter_depth_map2(float* d_output, float* d_output2, const float* d_input, float sigmaD, float sigmaR, uint32_t width, uint32_t height, void* stream) {
+    BF_REQUIRE(d_output && d_output2 && d_input && d_output != d_input && d_output2 != d_input && width && height, "bad argument");
+    const int r = (int)ceil(2.0 * sigmaD);
+    BF_REQUIRE(r >= 0 && r <= MAX_R, "sigmaD too large (kernel radius > 8)");
+    k_gauss_depth<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, makeTaps(sigmaD, r), sigmaR, (int)width, (int)height, d_output2);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }

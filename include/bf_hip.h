@@ -548,6 +548,11 @@ BF_API int bf_image_erode_depth_map(float* d_output, const float* d_input, int s
 /* gaussFilterDepthMap(d_output, d_input, sigmaD, sigmaR, w, h)                :759-809 */
 BF_API int bf_image_gauss_filter_depth_map(float* d_output, const float* d_input, float sigmaD, float sigmaR, uint32_t width,
                                            uint32_t height, void* hip_stream);
+/* fused forms for an ingest whose frame already lives in device memory: the first erosion carries the colour image's copies along, the depth filter writes
+ * the stored frame as well (three launches instead of seven; same images bit for bit) */
+BF_API int bf_image_erode_depth_map_and_copy(float* d_output, const float* d_input, int structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq,
+                                             const void* d_copySrc, void* d_copyDst1, void* d_copyDst2, void* stream);
+BF_API int bf_image_gauss_filter_depth_map2(float* d_output, float* d_output2, const float* d_input, float sigmaD, float sigmaR, uint32_t width, uint32_t height, void* stream);
 /* gaussFilterIntensity(d_output, d_input, sigmaD, w, h)                       :811-859 */
 BF_API int bf_image_gauss_filter_intensity(float* d_output, const float* d_input, float sigmaD, uint32_t width, uint32_t height,
                                            void* hip_stream);
