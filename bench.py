@@ -79,6 +79,11 @@ def main():
     args = ap.parse_args()
 
     plan = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if not args.launch_check:
+        # fewer devices than ranks: say so at once (every rank would otherwise reach ncclCommInitRank on a device that does not exist, or share one, and hang or fail late)
+        visible = visible_devices()
+        if visible is not None and visible < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible to this process (rocm-smi / HIP_VISIBLE_DEVICES): no line is printed" % (args.gpus, visible))
     if plan is not None:
         # `python bench.py --gpus N` without a launcher around it: start the N ranks here (one process per GPU, torch.distributed.run on
         # 127.0.0.1) instead of silently measuring one GPU.  Rank 0 of the children prints the JSON line; this process only forwards it.
@@ -430,6 +435,15 @@ def main():
     print_line()
     if world > 1:
         dist.destroy_process_group()
+
+
+def visible_devices():
+    """GPUs this process can use (torch's count, which honours HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), or None if torch cannot say"""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def launch_plan(gpus, env, argv):

@@ -118,55 +118,67 @@ struct OctaveJob {
     int halo[NLEV]; int haloIn;       // halo of level a's region around the tile; of the input region (octave 0)
 };
 
-BF_DEV void octaveBlurLevel(const float* A, float* B, float* Aout, const float* k, int fw, int x0, int y0, int w, int h, int Hs, int Hd) {
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// One level: H pass A -> B, V pass B -> A.  A lane owns TWO adjacent destination columns and keeps both running sums in one packed register pair (v_pk_mul_f32 +
+// v_pk_add_f32: every tap is `v += a * k` per output, in tap order, exactly FilterH / FilterV's sequence); waves stride over the rows, so there is no index division
+// anywhere.  The taps come through scalar loads (`k` is a kernel-argument pointer, the tap index is wave-uniform).
+BF_DEV void octaveBlurLevel(const float* A, float* B, float* Aout, const float* __restrict__ k, int fw, int x0, int y0, int w, int h, int Hs, int Hd) {
     const int r = fw >> 1;
-    const int SW = OT_W + 2 * Hs, SH = OT_H + 2 * Hs, DW = OT_W + 2 * Hd, DH = OT_H + 2 * Hd;
-    for (int t = threadIdx.x; t < SH * DW; t += blockDim.x) {          // H pass: every row of the source region, the destination's columns
-        const int row = t / DW, dx = t % DW;
-        const int xc = min(max(x0 - Hd + dx, 0), w - 1);
-        const float* a = A + row * SW + (xc - x0) + Hs - r;
-        float v = 0.0f;
-        for (int i = 0; i < fw; ++i) v += a[i] * k[i];
-        B[t] = v;
+    const int SW = OT_W + 2 * Hs, SH = OT_H + 2 * Hs, DW = OT_W + 2 * Hd, DH = OT_H + 2 * Hd;      // (all even)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int dx = 2 * lane;                         // this lane's column pair (DW <= 128)
+    if (dx < DW) {
+        const int xc0 = min(max(x0 - Hd + dx, 0), w - 1), xc1 = min(max(x0 - Hd + dx + 1, 0), w - 1);
+        const int o0 = (xc0 - x0) + Hs - r, o1 = (xc1 - x0) + Hs - r;
+        for (int row = wave; row < SH; row += nw) {          // H pass
+            const float* a = A + row * SW;
+            f2v v = {0.0f, 0.0f};
+            for (int i = 0; i < fw; ++i) { f2v s; s.x = a[o0 + i]; s.y = a[o1 + i]; const float ki = k[i]; f2v kk = {ki, ki}; v = v + s * kk; }
+            *reinterpret_cast<f2v*>(B + row * DW + dx) = v;
+        }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < DH * DW; t += blockDim.x) {          // V pass
-        const int dy = t / DW, dx = t % DW;
-        const int yc = min(max(y0 - Hd + dy, 0), h - 1);
-        const float* b = B + ((yc - y0) + Hs - r) * DW + dx;
-        float v = 0.0f;
-        for (int i = 0; i < fw; ++i) v += b[i * DW] * k[i];
-        Aout[t] = v;
+    if (dx < DW) {
+        for (int dy = wave; dy < DH; dy += nw) {             // V pass
+            const int yc = min(max(y0 - Hd + dy, 0), h - 1);
+            const float* b = B + ((yc - y0) + Hs - r) * DW + dx;
+            f2v v = {0.0f, 0.0f};
+            for (int i = 0; i < fw; ++i) { const f2v s = *reinterpret_cast<const f2v*>(b + i * DW); const float ki = k[i]; f2v kk = {ki, ki}; v = v + s * kk; }
+            *reinterpret_cast<f2v*>(Aout + dy * DW + dx) = v;
+        }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void k_octave(OctaveJob job, Taps taps, int floatsA) {
+__global__ __launch_bounds__(512) void k_octave(OctaveJob job, const float* __restrict__ tapK, const int* __restrict__ tapW, int floatsA) {
     extern __shared__ float oct_lds[];
     float* A = oct_lds; float* B = oct_lds + floatsA;
     const int x0 = ((int)blockIdx.x % job.tilesX) * OT_W, y0 = ((int)blockIdx.x / job.tilesX) * OT_H;
     const int w = job.w, h = job.h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int H = job.first ? job.haloIn : job.halo[0];
     {   // the first region: replicate-padded input image, or the down-sampled previous octave
         const int SW = OT_W + 2 * H, SH = OT_H + 2 * H;
-        for (int t = threadIdx.x; t < SW * SH; t += blockDim.x) {
-            const int xc = min(max(x0 - H + t % SW, 0), w - 1), yc = min(max(y0 - H + t / SW, 0), h - 1);
-            A[t] = job.first ? job.src[(size_t)yc * w + xc] : job.src[(size_t)(yc << 1) * job.srcW + min(xc << 1, job.srcW - 1)];
+        for (int row = wave; row < SH; row += nw) {
+            const int yc = min(max(y0 - H + row, 0), h - 1);
+            for (int col = lane; col < SW; col += 64) {
+                const int xc = min(max(x0 - H + col, 0), w - 1);
+                A[row * SW + col] = job.first ? job.src[(size_t)yc * w + xc] : job.src[(size_t)(yc << 1) * job.srcW + min(xc << 1, job.srcW - 1)];
+            }
         }
         __syncthreads();
     }
     for (int a = 0; a < NLEV; ++a) {
         if (a > 0 || job.first) {
             const int Hd = job.halo[a];
-            octaveBlurLevel(A, B, A, taps.k[a], taps.fw[a], x0, y0, w, h, H, Hd);
+            octaveBlurLevel(A, B, A, tapK + a * MAX_FW, tapW[a], x0, y0, w, h, H, Hd);
             H = Hd;
         }
         const int DW = OT_W + 2 * H;
         float* dst = job.dst[a];
-        for (int t = threadIdx.x; t < OT_W * OT_H; t += blockDim.x) {
-            const int tx = t % OT_W, ty = t / OT_W;
-            if (x0 + tx < w && y0 + ty < h) dst[(size_t)(y0 + ty) * w + x0 + tx] = A[(ty + H) * DW + tx + H];
-        }
+        for (int ty = wave; ty < OT_H; ty += nw)
+            if (lane < OT_W && x0 + lane < w && y0 + ty < h) dst[(size_t)(y0 + ty) * w + x0 + lane] = A[(ty + H) * DW + lane + H];
         // (no barrier: the next level's H pass only reads A)
     }
 }
@@ -568,6 +580,7 @@ struct bf_sift {
     DetectCfg detect; int detectBlocks = 0;
     std::vector<BlurJobs> schedule;        // the level-by-level pyramid (k_blur), kept for bf_sift_set_fused_octaves(0)
     OctaveJob octave[NUM_OCT]; int octaveBlocks[NUM_OCT]; int octFloatsA = 0, octFloatsB = 0; bool fusedOctaves = true;
+    float* d_tapK = nullptr; int* d_tapW = nullptr;        // the taps in device memory: k_octave reads them through scalar loads
     float* gauss[NUM_OCT][NLEV];
     float* mag[NUM_OCT][3]; float* ang[NUM_OCT][3];
     SiftDev d{};
@@ -689,6 +702,9 @@ int bf_sift_create(uint32_t width, uint32_t height, uint32_t depthWidth, uint32_
         const size_t bytes = (size_t)(s->octFloatsA + s->octFloatsB) * 4;
         if (bytes > 160 * 1024 - 512) { set_error("bf_sift_create: octave tile does not fit the LDS"); bf_sift_destroy(s); return BF_ERR_INVALID_ARG; }
         BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_octave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        if (!A((void**)&s->d_tapK, sizeof(float) * NLEV * MAX_FW) || !A((void**)&s->d_tapW, sizeof(int) * NLEV)) { set_error("bf_sift_create: hipMalloc failed"); bf_sift_destroy(s); return BF_ERR_HIP; }
+        BF_HIP_TRY(hipMemcpy(s->d_tapK, s->taps.k, sizeof(float) * NLEV * MAX_FW, hipMemcpyHostToDevice));
+        BF_HIP_TRY(hipMemcpy(s->d_tapW, s->taps.fw, sizeof(int) * NLEV, hipMemcpyHostToDevice));
     }
     *out = s;
     return BF_OK;
@@ -717,7 +733,7 @@ int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_depth, floa
         for (int o = 0; o < NUM_OCT; ++o) {
             OctaveJob j = s->octave[o];
             if (o == 0) j.src = d_intensity;
-            hipLaunchKernelGGL(k_octave, dim3(s->octaveBlocks[o]), dim3(512), (size_t)(s->octFloatsA + s->octFloatsB) * 4, st, j, s->taps, s->octFloatsA);
+            hipLaunchKernelGGL(k_octave, dim3(s->octaveBlocks[o]), dim3(512), (size_t)(s->octFloatsA + s->octFloatsB) * 4, st, j, s->d_tapK, s->d_tapW, s->octFloatsA);
         }
     } else
     for (size_t i = 0; i < s->schedule.size(); ++i) {

@@ -420,6 +420,9 @@ def test_bench_launches_its_own_ranks_and_refuses_a_mismatched_world():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "{" not in r.stdout and "mismatched" in r.stderr
+    # more ranks than devices: refused at once, before any rank is started (this box has no GPU: 0 < 2)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "{" not in r.stdout and "GPU(s) are visible" in r.stderr
 
 
 _POSEHELPER_CPP = r'''

@@ -265,6 +265,13 @@ def _explain(bad, fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, s
         hit = live & (Wt == tw) & ((S - ts).abs() <= tol_sdf) & ((C - tc).abs().amax(dim=-1) <= tol_col)
         return hit.any(dim=1)
     prod_ok, orac_ok = matches(fvox), matches(evox)
+    if slots < 1024 and bool((~prod_ok | ~orac_ok).any()):
+        # the few voxels left: their projections touch a boundary under many operators of the log (the same frame re-integrated at almost the same pose) and the
+        # alternatives did not fit - once more, for them alone, with room for every combination
+        redo = torch.nonzero(~prod_ok | ~orac_ok).squeeze(-1).cpu().numpy()
+        sub_ex = [e.to(dev)[torch.from_numpy(redo).to(dev)] for e in exists] if exists is not None else None
+        un2, om2, most2 = _explain(bad[redo], fvox, evox, eh, log, frames, cam, p, band, tol_sdf, tol_col, slots=1024, exists=sub_ex)
+        return un2, om2, max(most, most2)
     for v in torch.nonzero(~prod_ok).squeeze(-1)[:5].tolist():          # on record for a failing run: what the product holds, what the oracle holds, the alternatives
         k = int(nvalid[v])
         print("  unexplained voxel %d: product (sdf %.7g, w %g, rgb %s) oracle (sdf %.7g, w %g, rgb %s) alternatives %s" % (

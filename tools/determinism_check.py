@@ -24,14 +24,16 @@ def main():
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
     dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
     out = []
+    keep = {}
     for r in range(runs):
-        for arith in ("exact", "fast"):
+        for arith, batching in (("exact", True), ("fast", True), ("fast", False)):
             gas = default_app_state(); gbs = default_bundling_state()
             gas.s_integrationWidth, gas.s_integrationHeight = W, H
             gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.004, 1000000, 250000
             gbs.s_maxNumImages = 8
             p = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
             p.scene().set_arith(arith)
+            p.set_volume_batching(batching)
             for d, c in dev:
                 assert p.process_frame(d, c)
             for _ in range(4):
@@ -39,13 +41,23 @@ def main():
             p.synchronize()
             h, heap, cnt, vox = p.scene().download()
             sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
-            out.append({"run": r, "arith": arith, "integrated": sha(p.integrated_trajectory()), "optimized": sha(p.optimized_trajectory()), "counters": p.counters(),
+            key = (arith, batching)
+            if key in keep:          # what differs from the first run of this configuration
+                v0 = keep[key]
+                dif = np.nonzero((v0["sdf"] != vox["sdf"]) | (v0["weight"] != vox["weight"]) | (v0["color"] != vox["color"]).any(axis=1))[0]
+                if len(dif):
+                    ex = [(int(i), float(v0["sdf"][i]), float(vox["sdf"][i]), float(v0["weight"][i]), float(vox["weight"][i]), v0["color"][i].tolist(), vox["color"][i].tolist()) for i in dif[:6]]
+                    print(json.dumps({"differing_voxels_vs_run0": int(len(dif)), "blocks": int(len(np.unique(dif // 512))), "examples": ex}), flush=True)
+            else:
+                keep[key] = vox.copy()
+            out.append({"run": r, "arith": arith, "batching": batching, "integrated": sha(p.integrated_trajectory()), "optimized": sha(p.optimized_trajectory()), "counters": p.counters(),
                         "table": sha(h["pos"]) + sha(h["ptr"]), "heap": sha(heap[:cnt + 1]), "voxels": sha(vox.view(np.uint8))})
             print(json.dumps(out[-1]), flush=True)
             del p
     traj = {(o["integrated"], o["optimized"]) for o in out}
-    vol = {a: {(o["table"], o["heap"], o["voxels"]) for o in out if o["arith"] == a} for a in ("exact", "fast")}
-    print(json.dumps({"distinct_trajectories": len(traj), "distinct_volumes_exact": len(vol["exact"]), "distinct_volumes_fast": len(vol["fast"])}))
+    vol = {k: {(o["table"], o["heap"], o["voxels"]) for o in out if (o["arith"], o["batching"]) == k} for k in (("exact", True), ("fast", True), ("fast", False))}
+    print(json.dumps({"distinct_trajectories": len(traj), "distinct_volumes_exact_batched": len(vol[("exact", True)]), "distinct_volumes_fast_batched": len(vol[("fast", True)]),
+                      "distinct_volumes_fast_per_operator": len(vol[("fast", False)])}))
 
 
 if __name__ == "__main__":
