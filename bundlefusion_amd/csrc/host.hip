@@ -1909,6 +1909,11 @@ struct bf_pipeline {
     // critical path lies without a profiler.  [0] enqueue of the previous frame's matching chain, [1] ingest + detection enqueue,
     // [2] re-integration commands, [3] wait for the matching result + host logic, [4] integration command, [5] solves, [6] ingest wait, [7] frames
     double hostProfile[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // diagnostic (BF_PIPELINE_TRACE=<file>): per frame the host times of the chain's enqueue and of the wait for its result, and the GPU times (HIP events on the
+    // streams) at which the frame's detection ended and its matching chain started / ended, all on one clock - written when the pipeline is destroyed
+    struct TraceRec { uint32_t frame; double hEnq0, hEnq1, hDet0, hDet1, hWait0, hWait1, hBody1; hipEvent_t gDet, gChain0, gChain1; };
+    std::string tracePath; std::vector<TraceRec> trace; hipEvent_t traceBase = nullptr; double traceBaseHost = 0.0;
+    TraceRec* traceOf(uint32_t frame) { for (size_t i = trace.size(); i-- > 0;) if (trace[i].frame == frame) return &trace[i]; return nullptr; }
     bool timings = false;
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bf_frame_timing last;
@@ -2049,7 +2054,10 @@ inline double plNow() { return std::chrono::duration<double>(std::chrono::steady
 int plBodyBegin(bf_pipeline* p, uint32_t frame) {
     // ---- processInput: enqueue (bundling stream) ...
     const double t0 = plNow();
+    bf_pipeline::TraceRec* tr = p->tracePath.empty() ? nullptr : p->traceOf(frame);
+    if (tr) { tr->hEnq0 = t0; (void)hipEventRecord(tr->gChain0, p->sBundle); }
     const int rc = bf_online_bundler_process_input_begin_frame(p->ob, frame);
+    if (tr) { (void)hipEventRecord(tr->gChain1, p->sBundle); tr->hEnq1 = plNow(); }
     p->hostProfile[0] += plNow() - t0;
     return rc;
 }
@@ -2066,8 +2074,11 @@ int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
     if (tm) (void)hipEventRecord(p->ev[5], sv);
     double t1 = plNow(); p->hostProfile[2] += t1 - t0; t0 = t1;
     // ---- ... and its read-back
+    bf_pipeline::TraceRec* tr = p->tracePath.empty() ? nullptr : p->traceOf(frame);
+    if (tr) tr->hWait0 = plNow();
     BF_TRY(bf_online_bundler_process_input_end(p->ob));
     t1 = plNow(); p->hostProfile[3] += t1 - t0; t0 = t1;
+    if (tr) tr->hWait1 = t1;
     if (tm) (void)hipEventRecord(p->ev[2], sa);
     // ---- reconstruction of the current frame (volume stream, after this frame's ingest)
     if (tm) (void)hipEventRecord(p->ev[6], sv);
@@ -2089,6 +2100,7 @@ int plBodyRest(bf_pipeline* p, uint32_t frame, bool got) {
                                            p->gbs.s_numGlobalLinIterations));
     p->hostProfile[5] += plNow() - t0;
     if (got) p->hostProfile[7] += 1.0;
+    if (tr) tr->hBody1 = plNow();
     return BF_OK;
 }
 
@@ -2142,7 +2154,14 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
     if (got) BF_HIP_TRY(hipEventRecord(p->evIngest[frame % bf_pipeline::NEV], sd));
     if (got && !ahead) BF_HIP_TRY(hipStreamWaitEvent(sa, p->evIngest[frame % bf_pipeline::NEV], 0));      // the frame is detected on the bundling stream, from the ingest buffers
     if (tm) { (void)hipEventRecord(p->ev[1], sd); (void)hipEventRecord(p->ev[8], sa); }
+    if (got && !p->tracePath.empty() && p->trace.size() < 4096) {
+        bf_pipeline::TraceRec r; memset(&r, 0, sizeof r); r.frame = frame; r.hDet0 = tIn;
+        (void)hipEventCreate(&r.gDet); (void)hipEventCreate(&r.gChain0); (void)hipEventCreate(&r.gChain1);
+        if (!p->traceBase) { (void)hipEventCreate(&p->traceBase); (void)hipEventRecord(p->traceBase, p->sDetect); (void)hipEventSynchronize(p->traceBase); p->traceBaseHost = plNow(); }
+        p->trace.push_back(r);
+    }
     if (got && ahead) BF_TRY(bf_online_bundler_detect_ahead_after(p->ob, p->evIngest[frame % bf_pipeline::NEV]));
+    if (got && !p->tracePath.empty()) { bf_pipeline::TraceRec* tr = p->traceOf(frame); if (tr) { if (ahead) (void)hipEventRecord(tr->gDet, p->sDetect); tr->hDet1 = plNow(); } }
     p->hostProfile[1] += plNow() - tIn;
     // ---- ... and the body of the oldest frame in flight, whose chain was enqueued by the previous call
     while (p->begun.size() + 1 > p->depth) BF_TRY(plRestFront(p));
@@ -2250,6 +2269,7 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
     if (const char* e = getenv("BF_PIPELINE_SOLVE_LAG")) BF_TRY(bf_pipeline_set_solve_lag(p, (uint32_t)atoi(e)));
+    if (const char* e = getenv("BF_PIPELINE_TRACE")) p->tracePath = e;
     int dev = 0;
     BF_HIP_TRY(hipGetDevice(&dev));
     p->worker = std::thread([p, dev] { (void)hipSetDevice(dev); volWorker(p); });
@@ -2265,6 +2285,21 @@ int bf_pipeline_destroy(bf_pipeline* p) {
         p->worker.join();
     }
     (void)hipDeviceSynchronize();
+    if (!p->tracePath.empty() && !p->trace.empty()) {
+        if (FILE* f = fopen(p->tracePath.c_str(), "a")) {
+            fprintf(f, "# frame | host: detect enqueue (begin end) chain enqueue (begin end) wait for the result (begin end) body end | GPU: detection end, chain begin, chain end   [ms since the first traced frame]\n");
+            for (auto& r : p->trace) {
+                float gd = -1.0f, g0 = -1.0f, g1 = -1.0f;
+                if (hipEventQuery(r.gDet) == hipSuccess) (void)hipEventElapsedTime(&gd, p->traceBase, r.gDet);
+                if (r.hEnq0 > 0.0) { (void)hipEventElapsedTime(&g0, p->traceBase, r.gChain0); (void)hipEventElapsedTime(&g1, p->traceBase, r.gChain1); }
+                const double b = p->traceBaseHost;
+                fprintf(f, "%5u | %8.3f %8.3f  %8.3f %8.3f  %8.3f %8.3f  %8.3f | %8.3f %8.3f %8.3f\n", r.frame, 1e3 * (r.hDet0 - b), 1e3 * (r.hDet1 - b), 1e3 * (r.hEnq0 - b), 1e3 * (r.hEnq1 - b),
+                        1e3 * (r.hWait0 - b), 1e3 * (r.hWait1 - b), 1e3 * (r.hBody1 - b), gd, g0, g1);
+                (void)hipEventDestroy(r.gDet); (void)hipEventDestroy(r.gChain0); (void)hipEventDestroy(r.gChain1);
+            }
+            fclose(f);
+        }
+    }
     bf_online_bundler_destroy(p->ob); bf_image_manager_destroy(p->im); bf_scene_destroy(p->scene);
     for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : p->evIngest) if (e) (void)hipEventDestroy(e);

@@ -2019,7 +2019,7 @@ int ensureBatch(bf_scene* s) {
 #undef A
     if (rc != BF_OK) return rc;
     bd.setMask = ds - 1; bd.candCap = ds / 2;
-    hipLaunchKernelGGL(k_batch_reset, dim3(2048), dim3(256), 0, s->stream, bd, s->params.m_hashNumBuckets);      // (the main stream: the first march follows on it)
+    hipLaunchKernelGGL(k_batch_reset, dim3(2048), dim3(256), 0, s->overlap ? s->prep : s->stream, bd, s->params.m_hashNumBuckets);      // (the stream the first march follows on)
     BF_HIP_TRY(hipGetLastError());
     s->batchReady = true;
     return BF_OK;
@@ -2039,14 +2039,14 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
             for (uint32_t k = 0; k < BMAX; ++k) { if (s->btexel[q][k]) (void)hipFree(s->btexel[q][k]); s->btexel[q][k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->btexel[q][k], npx * sizeof(uint2))); }
         s->btexelPixels = npx;
     }
-    // The march runs on the MAIN (volume) stream: it is long (one launch over all the batch's frames, 100-180 us) and touches no table, and the volume stream has
-    // the lowest priority - on the preparation stream (highest priority, s_setprio 3) it sat in front of the feature pipeline's short kernels, which then waited
-    // ~55 us each for a wave slot (profiles/r05_pipeline_timeline_window.txt, first Gauss-Newton iteration of a chunk's local solve).  The main stream also orders it
-    // behind the update that read list buffer b and its texel set.  It waits for the frames' ingest (per-operator events, bf_scene_wait_event).
-    hipStream_t ms = s->stream;
+    // The march runs on the preparation stream like everything else of the preparation.  (Round 5 tried it on the main stream, behind the previous batch's update: the
+    // frame loop then produced volumes that differed from run to run under the fast contract - single 64-byte lines of a texel image, which the march writes and the
+    // update gathers from, were stale in the update's view when writer and reader sat in the same queue; with the writer on this stream and the reader behind a
+    // cross-queue event the volumes are bit-identical run after run: tools/determinism_check.py, tests/test_pipeline_gpu.py::test_frame_loop_is_deterministic.)
+    hipStream_t ms = ps;
     for (uint32_t k = 0; k < n; ++k) if (ops[k].wait_event) BF_HIP_TRY(hipStreamWaitEvent(ms, (hipEvent_t)ops[k].wait_event, 0));
     if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ms, s->pendingEv, 0)); s->pendingEv = nullptr; }
-    if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));
+    if (s->overlap && s->updRecorded[b]) BF_HIP_TRY(hipStreamWaitEvent(ps, s->evUpd[b], 0));      // the update that read list buffer b and its texel set NB batches ago
     s->frameTexels = nullptr;
     // per-operator frames: integration pose (kinds 0, 2), de-integration pose (kinds 1, 2)
     Frame fin[BMAX], fde[BMAX];
@@ -2079,11 +2079,8 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
     bc.shardLo = fl.shardLo; bc.shardHi = fl.shardHi; bc.nOps = n;
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
     hipLaunchKernelGGL(k_batch_march, dim3(div_up(tiles, 4), n), dim3(256), 0, ms, dv, s->bd, bc, ma);
-    if (s->overlap) {       // binning and placement (preparation stream) behind the march, and behind whatever freed table entries before it (the last garbage collection)
-        BF_HIP_TRY(hipEventRecord(s->evTmp, ms));
-        BF_HIP_TRY(hipStreamWaitEvent(ps, s->evTmp, 0));
-        s->barrierPending = false;          // (the main stream's order covers it)
-    }
+    // the table look-ups wait for whatever frees table entries (the last garbage collection); the march above does not
+    if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
     hipLaunchKernelGGL(k_batch_bin, dim3(1024), dim3(256), 0, ps, dv, s->bd, bc);
     hipLaunchKernelGGL(k_batch_place, dim3(PLACE_WGS), dim3(256), 0, ps, dv, s->bd, bc, fr);
     if (s->overlap) {

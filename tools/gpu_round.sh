@@ -65,6 +65,9 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
         done
         python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A
       done ;;
+    pltrace)    # the frame loop's own per-frame trace (BF_PIPELINE_TRACE): host enqueue / wait times and the GPU times of detection end, chain begin / end, untraced otherwise
+      rm -f "$OUT/pltrace.txt"
+      (cd "$ROOT" && BF_PIPELINE_TRACE="$OUT/pltrace.txt" timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 $BENCH_ARGS > "$OUT/bench_pltrace.json" 2> /dev/null; cut -c1-120 "$OUT/bench_pltrace.json"; tail -26 "$OUT/pltrace.txt") ;;
     determinism)
       (cd "$ROOT" && timeout 300 python tools/determinism_check.py ${DET_RUNS:-3} 2>&1 | grep -v amdgpu.ids | tee "$OUT/determinism.txt" | tail -8) ;;
     hiptrace)   # host side: HIP API calls per thread (totals) and a merged API + kernel window (no counters: --pmc must not be combined with the hip trace)
