@@ -1105,8 +1105,10 @@ struct bf_online_bundler {
     // matched / solved; processInput then commits the staged slot (one copy kernel) instead of detecting.
     bf_bundler* stage = nullptr;
     hipStream_t detectStream = nullptr;
+    // a second detection queue (bf_online_bundler_set_second_detect_stream): odd frames detect on it, with their own detector and intensity images - two detections in flight
+    hipStream_t detectStream2 = nullptr; bf_sift* sift2 = nullptr; float *d_intensitySIFT2 = nullptr, *d_intensityFilterHelper2 = nullptr;
     static const uint32_t STAGE = 4;      // staging slots: frame n is detected into slot n % STAGE (the loop may run up to STAGE - 1 frames behind its input)
-    hipEvent_t evDetect[STAGE] = {}, evStageFree[STAGE] = {};
+    hipEvent_t evDetect[STAGE] = {}, evStageFree[STAGE] = {}, evCache[STAGE] = {};
     int stagedFrame[STAGE] = {-1, -1, -1, -1};
     // processInput calls in flight (between _begin and _end), oldest first.  Two deep: the matching chain of frame k + 1 is enqueued on the bundling
     // stream BEHIND frame k's before the host waits for frame k's result - everything frame k + 1's chain needs of frame k is device state (key points,
@@ -1409,6 +1411,7 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
     if (rc) { bf_online_bundler_destroy(ob); return rc; }
     for (uint32_t k = 0; k < bf_online_bundler::STAGE; ++k) {
         BF_HIP_TRY(hipEventCreateWithFlags(&ob->evDetect[k], hipEventDisableTiming));
+        BF_HIP_TRY(hipEventCreateWithFlags(&ob->evCache[k], hipEventDisableTiming));
         BF_HIP_TRY(hipEventCreateWithFlags(&ob->evStageFree[k], hipEventDisableTiming));
     }
     const size_t nAll = (size_t)maxNumImages * S;
@@ -1450,7 +1453,9 @@ int bf_online_bundler_destroy(bf_online_bundler* ob) {
     if (ob->evChunkCopy) (void)hipEventDestroy(ob->evChunkCopy);
     for (int k = 0; k < 2; ++k) for (hipEvent_t e : {ob->evImage[k], ob->evPairDone[k], ob->evPairSetFree[k]}) if (e) (void)hipEventDestroy(e);
     bf_bundler_destroy(ob->local); bf_bundler_destroy(ob->optLocal); bf_bundler_destroy(ob->global); bf_bundler_destroy(ob->stage); bf_trajectory_manager_destroy(ob->tm);
-    for (uint32_t k = 0; k < bf_online_bundler::STAGE; ++k) { if (ob->evDetect[k]) (void)hipEventDestroy(ob->evDetect[k]); if (ob->evStageFree[k]) (void)hipEventDestroy(ob->evStageFree[k]); }
+    for (uint32_t k = 0; k < bf_online_bundler::STAGE; ++k) { if (ob->evDetect[k]) (void)hipEventDestroy(ob->evDetect[k]); if (ob->evCache[k]) (void)hipEventDestroy(ob->evCache[k]); if (ob->evStageFree[k]) (void)hipEventDestroy(ob->evStageFree[k]); }
+    if (ob->sift2) bf_sift_destroy(ob->sift2);
+    (void)hipFree(ob->d_intensitySIFT2); (void)hipFree(ob->d_intensityFilterHelper2);
     (void)hipFree(ob->d_intensitySIFT); (void)hipFree(ob->d_intensityFilterHelper); (void)hipFree(ob->d_completeTrajectory); (void)hipFree(ob->d_localTrajectories);
     (void)hipFree(ob->d_siftTrajectory); (void)hipFree(ob->d_currIntegrateTransform); (void)hipFree(ob->d_imageInvalidateList);
     if (ob->h_pinT) (void)hipHostFree(ob->h_pinT);
@@ -1500,6 +1505,21 @@ int bf_online_bundler_set_detect_stream(bf_online_bundler* ob, void* s) {
     return bf_bundler_set_stream(ob->stage, s);
 }
 
+// Odd frames detect on `s` with a detector of their own: the detection of a frame is ~30 dependent launches that leave most of the device idle, and one queue's worth of
+// them (0.85 ms per frame in the frame loop) was what set the loop's period (profiles/r05_loop_trace.md).  Null: back to one queue.
+int bf_online_bundler_set_second_detect_stream(bf_online_bundler* ob, void* s) {
+    BF_REQUIRE(ob && ob->detectStream, "set_second_detect_stream needs bf_online_bundler_set_detect_stream first");
+    ob->detectStream2 = (hipStream_t)s;
+    if (!s) return BF_OK;
+    if (!ob->sift2) {
+        const bf_bundler* b = ob->stage;
+        BF_TRY(bf_sift_create(b->gbs.s_widthSIFT, b->gbs.s_heightSIFT, ob->depthW, ob->depthH, 150, b->gas.s_sensorDepthMin, b->gas.s_sensorDepthMax, b->gbs.s_minKeyScale, b->maxKeys, &ob->sift2));
+        BF_HIP_TRY(hipMalloc((void**)&ob->d_intensitySIFT2, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+        BF_HIP_TRY(hipMalloc((void**)&ob->d_intensityFilterHelper2, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+    }
+    return bf_sift_set_stream(ob->sift2, s);
+}
+
 // Feature detection + dense cache frame of the image manager's current frame, into staging slot (frame % STAGE), on the detect
 // stream (which must also be the image manager's stream, so that it is ordered after the ingest).  No bundler state changes.
 int bf_online_bundler_detect_ahead(bf_online_bundler* ob) { return bf_online_bundler_detect_ahead_after(ob, nullptr); }
@@ -1512,19 +1532,39 @@ int bf_online_bundler_detect_ahead_after(bf_online_bundler* ob, void* ingest_eve
     BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &frame));
     const int slot = (int)(frame % bf_online_bundler::STAGE);
     BF_REQUIRE(ob->stagedFrame[slot] < 0, "staging slot still holds an uncommitted frame");
-    hipStream_t sd = ob->detectStream;
+    const bool odd = ob->detectStream2 != nullptr && (frame & 1u) != 0u;
+    hipStream_t sd = odd ? ob->detectStream2 : ob->detectStream;
+    bf_sift* sift = odd ? ob->sift2 : ob->stage->sift;
+    float*& intensity = odd ? ob->d_intensitySIFT2 : ob->d_intensitySIFT;
+    float*& helper = odd ? ob->d_intensityFilterHelper2 : ob->d_intensityFilterHelper;
     if (ingest_event) BF_HIP_TRY(hipStreamWaitEvent(sd, (hipEvent_t)ingest_event, 0));
     BF_HIP_TRY(hipStreamWaitEvent(sd, ob->evStageFree[slot], 0));          // the commit that last read this slot
-    BF_TRY(bf_image_resample_to_intensity(ob->d_intensitySIFT, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, sd));
+    // The dense cache frame needs the ingest's images only, not the detection: with the ingest on its own stream it follows the ingest THERE (two launches, ~115 us),
+    // beside the ~30 launches of the detection instead of behind them - the detect stream was the frame loop's saturated queue (profiles/r05_loop_trace.md)
+    hipStream_t si = ingest_event ? ob->im->stream : nullptr;
+    const bool cacheBeside = si != nullptr && si != sd;
+    if (cacheBeside) {
+        BF_HIP_TRY(hipStreamWaitEvent(si, ob->evStageFree[slot], 0));
+        BF_TRY(bf_cache_set_stream(ob->stage->cache, si));
+        BF_TRY(bf_cache_set_current_frame(ob->stage->cache, (uint32_t)slot));
+        const int rc = bf_cache_store_frame(ob->stage->cache, ob->im->d_depthInputRaw, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH);
+        BF_TRY(bf_cache_set_stream(ob->stage->cache, sd));
+        BF_TRY(rc);
+        BF_HIP_TRY(hipEventRecord(ob->evCache[slot], si));
+    }
+    BF_TRY(bf_image_resample_to_intensity(intensity, ob->widthSIFT, ob->heightSIFT, ob->im->d_colorInput, ob->colorW, ob->colorH, sd));
     if (ob->gas.s_colorFilter) {
-        BF_TRY(bf_image_gauss_filter_intensity(ob->d_intensityFilterHelper, ob->d_intensitySIFT, ob->gas.s_colorSigmaD, ob->widthSIFT, ob->heightSIFT, sd));
-        std::swap(ob->d_intensityFilterHelper, ob->d_intensitySIFT);
+        BF_TRY(bf_image_gauss_filter_intensity(helper, intensity, ob->gas.s_colorSigmaD, ob->widthSIFT, ob->heightSIFT, sd));
+        std::swap(helper, intensity);
     }
     bf_sift_image_gpu img;
     BF_TRY(bf_siftmgr_get_image(ob->stage->mgr, (uint32_t)slot, &img));
-    BF_TRY(bf_sift_run(ob->stage->sift, ob->d_intensitySIFT, ob->im->d_depthInputFiltered, (float*)img.d_keyPoints, (uint8_t*)img.d_keyPointDescs, img.d_numKeyPoints));
-    BF_TRY(bf_cache_set_current_frame(ob->stage->cache, (uint32_t)slot));
-    BF_TRY(bf_cache_store_frame(ob->stage->cache, ob->im->d_depthInputRaw, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH));
+    BF_TRY(bf_sift_run(sift, intensity, ob->im->d_depthInputFiltered, (float*)img.d_keyPoints, (uint8_t*)img.d_keyPointDescs, img.d_numKeyPoints));
+    if (cacheBeside) BF_HIP_TRY(hipStreamWaitEvent(sd, ob->evCache[slot], 0));      // evDetect covers both: it is also the guard of the input set both read
+    else {
+        BF_TRY(bf_cache_set_current_frame(ob->stage->cache, (uint32_t)slot));
+        BF_TRY(bf_cache_store_frame(ob->stage->cache, ob->im->d_depthInputRaw, ob->depthW, ob->depthH, ob->im->d_colorInput, ob->colorW, ob->colorH));
+    }
     BF_HIP_TRY(hipEventRecord(ob->evDetect[slot], sd));
     ob->stagedFrame[slot] = (int)frame;
     return BF_OK;
@@ -1868,7 +1908,7 @@ struct bf_pipeline {
     // Look-ahead: feature detection + dense cache frame of frame k+1 run on the detect stream (its ingest on sIngest) while frame k is matched, filtered,
     // integrated and solved; the body of a frame is executed by a later call (`depth` below) or by the first call that needs its result.  The per-frame
     // work and its order are unchanged, so are the results.
-    hipStream_t sDetect = nullptr;
+    hipStream_t sDetect = nullptr, sDetect2 = nullptr;      // sDetect2: the queue of the odd frames' detections (one of sPair) or null
     bool lookahead = true;
     // Two frames behind the input (round 4): the call that delivers frame n (1) enqueues the matching chain of frame n - 1 on the bundling stream - behind the
     // chain of frame n - 2, which the previous call enqueued -, (2) ingests and detects frame n, (3) runs the body of frame n - 2: its match result was
@@ -2161,7 +2201,7 @@ int plFrame(bf_pipeline* p, const float* depth, const uint8_t* color, bool devic
         p->trace.push_back(r);
     }
     if (got && ahead) BF_TRY(bf_online_bundler_detect_ahead_after(p->ob, p->evIngest[frame % bf_pipeline::NEV]));
-    if (got && !p->tracePath.empty()) { bf_pipeline::TraceRec* tr = p->traceOf(frame); if (tr) { if (ahead) (void)hipEventRecord(tr->gDet, p->sDetect); tr->hDet1 = plNow(); } }
+    if (got && !p->tracePath.empty()) { bf_pipeline::TraceRec* tr = p->traceOf(frame); if (tr) { if (ahead) (void)hipEventRecord(tr->gDet, (p->sDetect2 && (frame & 1u)) ? p->sDetect2 : p->sDetect); tr->hDet1 = plNow(); } }
     p->hostProfile[1] += plNow() - tIn;
     // ---- ... and the body of the oldest frame in flight, whose chain was enqueued by the previous call
     while (p->begun.size() + 1 > p->depth) BF_TRY(plRestFront(p));
@@ -2259,6 +2299,9 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // BF_PIPELINE_PAIR_STREAMS=1: the pair stages of consecutive frames on two streams.  Off by default: measured 659 vs 697 frames/s (gpurun r04c) - every
         // cross-stream event hop costs ~40 us on this runtime and the stage needs four of them per frame, more than the overlap of two Kabsch filters returns
         const char* e = getenv("BF_PIPELINE_PAIR_STREAMS");
+        const char* e2 = getenv("BF_PIPELINE_DETECT_STREAMS");
+        // odd frames detect on a second queue (bf_online_bundler_set_second_detect_stream): the first pair stream, a placeholder otherwise
+        if (!(e && atoi(e) != 0) && !(e2 && atoi(e2) == 1)) { BF_TRY(bf_online_bundler_set_second_detect_stream(p->ob, p->sPair[0])); p->sDetect2 = p->sPair[0]; }
         if (e && atoi(e) != 0) {
             int least = 0, greatest = 0;
             BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));

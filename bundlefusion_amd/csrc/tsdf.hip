@@ -2078,7 +2078,10 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
     bc.voxelSize = fl.voxelSize; bc.maxIntegrationDistance = fl.maxIntegrationDistance; bc.truncScale = fl.truncScale; bc.truncation = fl.truncation;
     bc.shardLo = fl.shardLo; bc.shardHi = fl.shardHi; bc.nOps = n;
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
+    static const int dbgSync = [] { const char* e = getenv("BF_DEBUG_BATCH_SYNC"); return e ? atoi(e) : 0; }();      // TEMPORARY (bisecting a race)
+    if (dbgSync & 8) (void)hipDeviceSynchronize();
     hipLaunchKernelGGL(k_batch_march, dim3(div_up(tiles, 4), n), dim3(256), 0, ms, dv, s->bd, bc, ma);
+    if (dbgSync & 1) (void)hipDeviceSynchronize();
     // the table look-ups wait for whatever frees table entries (the last garbage collection); the march above does not
     if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
     hipLaunchKernelGGL(k_batch_bin, dim3(1024), dim3(256), 0, ps, dv, s->bd, bc);
@@ -2087,6 +2090,7 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
         BF_HIP_TRY(hipEventRecord(s->evPrep[b], ps));
         BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
     }
+    if (dbgSync & 2) (void)hipDeviceSynchronize();
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (s->timing) {
         if (s->eventsUsed == s->events.size()) {
@@ -2126,6 +2130,7 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
     if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
     if (s->overlap) { BF_HIP_TRY(hipEventRecord(s->evUpd[b], s->stream)); s->updRecorded[b] = true; }
     BF_HIP_TRY(hipGetLastError());
+    if (dbgSync & 4) (void)hipDeviceSynchronize();
     useBuf(s, b);
     s->compactStale = true;
     // the frustum list of the LAST pose inside the union list: the blocks with the last operator's bit (integration pose, or the pose of a de-integration)

@@ -268,6 +268,8 @@ BF_API int bf_online_bundler_process_input_end(bf_online_bundler* ob);
  * when the image manager has ingested a newer frame meanwhile.  A host loop can so overlap detection of frame k+1 with the
  * matching / solving of frame k (what the reference's bundling thread does with its one-frame lag, OnlineBundler.cpp:167). */
 BF_API int bf_online_bundler_set_detect_stream(bf_online_bundler* ob, void* hip_stream);
+/* Odd frames detect on a second stream with a detector of their own (two detections in flight); null: one stream again.  After set_detect_stream. */
+BF_API int bf_online_bundler_set_second_detect_stream(bf_online_bundler* ob, void* hip_stream);
 BF_API int bf_online_bundler_detect_ahead(bf_online_bundler* ob);
 /* the same when the ingest runs on ANOTHER stream than the detect stream: `ingest_event` (a hipEvent_t) was recorded behind the frame's ingest */
 BF_API int bf_online_bundler_detect_ahead_after(bf_online_bundler* ob, void* ingest_event);
