@@ -1031,7 +1031,12 @@ BF_DEV void voxelApply(const FR& f, float sdf, uchar4 cc, float& vSdf, float& vW
 // ---------------------------------------------------------------------------------------
 // f2i as the one instruction it describes (v_cvt_i32_f32: toward zero, saturating, NaN -> 0).  The portable spelling in bf_device.h
 // costs three compares and three exec-mask branches per conversion in the voxel kernels' inner loop.
-BF_DEV int f2iHw(float v) { int r; asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+// Spelled as HIP's own conversion (a plain v_cvt_i32_f32_e32 in the generated code), NOT as inline assembly: up to round 5 this was
+// `asm("v_cvt_i32_f32_e32 %0, %1")`, and with it the fast update gave run-to-run different voxels whenever other kernels shared the device - always lanes 48-63
+// (the last of a wave64 instruction's four passes) of a block's first voxel pair, one sample read at a neighbouring pixel or missed.  The compiler pads the VALU
+// forwarding hazards of gfx950 with s_nop where it can see the instructions (it does so in front of this very conversion when it follows a packed FMA); it
+// cannot see into an asm statement.  With the conversion visible: 8 of 8 runs of the frame loop bit-identical (profiles/r05_determinism.md).
+BF_DEV int f2iHw(float v) { return __float2int_rz(v); }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 BF_DEV v2f sp2(float a) { v2f r; r.x = a; r.y = a; return r; }
@@ -2039,10 +2044,8 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
             for (uint32_t k = 0; k < BMAX; ++k) { if (s->btexel[q][k]) (void)hipFree(s->btexel[q][k]); s->btexel[q][k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->btexel[q][k], npx * sizeof(uint2))); }
         s->btexelPixels = npx;
     }
-    // The march runs on the preparation stream like everything else of the preparation.  (Round 5 tried it on the main stream, behind the previous batch's update: the
-    // frame loop then produced volumes that differed from run to run under the fast contract - single 64-byte lines of a texel image, which the march writes and the
-    // update gathers from, were stale in the update's view when writer and reader sat in the same queue; with the writer on this stream and the reader behind a
-    // cross-queue event the volumes are bit-identical run after run: tools/determinism_check.py, tests/test_pipeline_gpu.py::test_frame_loop_is_deterministic.)
+    // The march runs on the preparation stream like everything else of the preparation (on the main stream behind the previous batch's update it measured the same
+    // frame rate, gpurun r05c / r05f).
     hipStream_t ms = ps;
     for (uint32_t k = 0; k < n; ++k) if (ops[k].wait_event) BF_HIP_TRY(hipStreamWaitEvent(ms, (hipEvent_t)ops[k].wait_event, 0));
     if (s->pendingEv) { BF_HIP_TRY(hipStreamWaitEvent(ms, s->pendingEv, 0)); s->pendingEv = nullptr; }
@@ -2078,10 +2081,7 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
     bc.voxelSize = fl.voxelSize; bc.maxIntegrationDistance = fl.maxIntegrationDistance; bc.truncScale = fl.truncScale; bc.truncation = fl.truncation;
     bc.shardLo = fl.shardLo; bc.shardHi = fl.shardHi; bc.nOps = n;
     const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
-    static const int dbgSync = [] { const char* e = getenv("BF_DEBUG_BATCH_SYNC"); return e ? atoi(e) : 0; }();      // TEMPORARY (bisecting a race)
-    if (dbgSync & 8) (void)hipDeviceSynchronize();
     hipLaunchKernelGGL(k_batch_march, dim3(div_up(tiles, 4), n), dim3(256), 0, ms, dv, s->bd, bc, ma);
-    if (dbgSync & 1) (void)hipDeviceSynchronize();
     // the table look-ups wait for whatever frees table entries (the last garbage collection); the march above does not
     if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
     hipLaunchKernelGGL(k_batch_bin, dim3(1024), dim3(256), 0, ps, dv, s->bd, bc);
@@ -2090,7 +2090,6 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
         BF_HIP_TRY(hipEventRecord(s->evPrep[b], ps));
         BF_HIP_TRY(hipStreamWaitEvent(s->stream, s->evPrep[b], 0));
     }
-    if (dbgSync & 2) (void)hipDeviceSynchronize();
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (s->timing) {
         if (s->eventsUsed == s->events.size()) {
@@ -2130,7 +2129,6 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
     if (ev) BF_HIP_TRY(hipEventRecord(ev->second, s->stream));
     if (s->overlap) { BF_HIP_TRY(hipEventRecord(s->evUpd[b], s->stream)); s->updRecorded[b] = true; }
     BF_HIP_TRY(hipGetLastError());
-    if (dbgSync & 4) (void)hipDeviceSynchronize();
     useBuf(s, b);
     s->compactStale = true;
     // the frustum list of the LAST pose inside the union list: the blocks with the last operator's bit (integration pose, or the pose of a de-integration)

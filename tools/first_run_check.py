@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""One frame loop per PROCESS (33 frames, 640x480 @4 mm, the library's defaults), trajectory / volume hashes on one line: a result that depends on what device memory
+held before the run (something read before it was written) shows as a hash that differs between processes.  Before the pipeline is created a large part of the device
+memory is filled with a pattern and handed back to the driver, so that the pipeline's allocations start from that pattern instead of whatever the box held.
+    python tools/first_run_check.py [pattern as hex, e.g. 7fc00000 | ffffffff | 0 | none]"""
+import hashlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bundlefusion_amd as bf
+from bundlefusion_amd import synth
+from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, sensor_desc
+
+
+def main():
+    pat = sys.argv[1] if len(sys.argv) > 1 else "none"
+    W, H, n = 640, 480, 33
+    frames = synth.render_frames(range(n))
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    if pat != "none":
+        v = int(pat, 16)
+        fill = [torch.full((1 << 28,), v - (1 << 32) if v >= (1 << 31) else v, dtype=torch.int32, device="cuda") for _ in range(int(os.environ.get("POISON_GB", "24")))]      # 1 GiB each
+        torch.cuda.synchronize()
+        del fill
+        torch.cuda.empty_cache()
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.004, 1000000, 250000
+    gbs.s_maxNumImages = 8
+    p = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
+    for d, c in dev:
+        assert p.process_frame(d, c)
+    for _ in range(4):
+        p.process_end_of_sequence()
+    p.synchronize()
+    h, heap, cnt, vox = p.scene().download()
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    it, ot = p.integrated_trajectory(), p.optimized_trajectory()
+    print(json.dumps({"pattern": pat, "integrated": sha(it), "optimized": sha(ot), "counters": p.counters(), "table": sha(h["pos"]) + sha(h["ptr"]), "voxels": sha(vox.view(np.uint8)),
+                      "first_rows_differing_hint": [float(np.abs(it[k]).sum()) for k in (1, 5, 11, 21, 32)]}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

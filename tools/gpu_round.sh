@@ -70,11 +70,17 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
       (cd "$ROOT" && BF_PIPELINE_TRACE="$OUT/pltrace.txt" timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 $BENCH_ARGS > "$OUT/bench_pltrace.json" 2> /dev/null; cut -c1-120 "$OUT/bench_pltrace.json"; tail -26 "$OUT/pltrace.txt") ;;
     determinism)
       (cd "$ROOT" && timeout 300 python tools/determinism_check.py ${DET_RUNS:-3} 2>&1 | grep -v amdgpu.ids | tee "$OUT/determinism.txt" | tail -8) ;;
+    firstrun)    # one frame loop per process over poisoned device memory (tools/first_run_check.py): PATTERNS="none 0 ffffffff 7fc00000 ..."
+      rm -f "$OUT/first_run.txt"
+      for P in ${PATTERNS:-none 0 ffffffff 7fc00000 none 12345678 ff7fffff none}; do
+        (cd "$ROOT" && timeout 120 python tools/first_run_check.py $P 2>&1 | grep -v amdgpu.ids | tail -1 >> "$OUT/first_run.txt")
+      done
+      cut -c1-200 "$OUT/first_run.txt" ;;
     det_bisect)  # the fast batched configuration only, under environment variants (ENVS="A=1;B=2"): which overlap a run-to-run difference needs
       IFS=";" read -ra VARIANTS <<< "${DET_ENVS:-X=0}"
       for V in "${VARIANTS[@]}"; do
         TAG=$(echo "$V" | tr ' =' '__')
-        (cd "$ROOT" && env $V timeout 200 python tools/determinism_check.py ${DET_RUNS:-3} fast-batched 2>&1 | grep -v amdgpu.ids > "$OUT/det_$TAG.txt"; echo "== $V"; grep -E "^  block|differing" "$OUT/det_$TAG.txt" | cut -c1-420 | head -12; tail -1 "$OUT/det_$TAG.txt")
+        (cd "$ROOT" && env $V timeout 200 python tools/determinism_check.py ${DET_RUNS:-3} fast-batched 2>&1 | grep -v amdgpu.ids > "$OUT/det_$TAG.txt"; echo "== $V"; grep -E "^  block|differing|stale-read" "$OUT/det_$TAG.txt" | cut -c1-300 | head -14; tail -1 "$OUT/det_$TAG.txt")
       done ;;
     hiptrace)   # host side: HIP API calls per thread (totals) and a merged API + kernel window (no counters: --pmc must not be combined with the hip trace)
       rm -rf /tmp/r_hip
