@@ -8,6 +8,29 @@
 
 #include "../../include/bf_hip.h"
 
+// Diagnostic (tools/first_run_check.py): BF_DEBUG_POISON="<file>[:<line>]=<hex32>[,...]" fills every allocation made at that place (or "*": everywhere) with the
+// 32-bit pattern - a result that changes with the pattern was computed from memory nobody had written.  Without the variable: hipMalloc and one getenv per process.
+#include <cstdlib>
+#include <cstring>
+inline hipError_t bf_debug_malloc(void** p, size_t n, const char* file, int line) {
+    const hipError_t e = hipMalloc(p, n);
+    static const char* env = getenv("BF_DEBUG_POISON");
+    if (e != hipSuccess || !env || n < 4) return e;
+    const char* base = strrchr(file, '/'); base = base ? base + 1 : file;
+    char key[128]; snprintf(key, sizeof key, "%s:%d=", base, line);
+    char keyFile[128]; snprintf(keyFile, sizeof keyFile, "%s=", base);
+    const char* hit = strstr(env, key);
+    if (!hit) { hit = strstr(env, keyFile); }
+    if (!hit) { hit = strstr(env, "*="); }
+    if (!hit) return e;
+    const unsigned v = (unsigned)strtoul(strchr(hit, '=') + 1, nullptr, 16);
+    (void)hipMemsetD32((hipDeviceptr_t)*p, (int)v, n / 4);
+    (void)hipDeviceSynchronize();
+    return e;
+}
+#define hipMalloc(p, n) bf_debug_malloc((void**)(p), (n), __FILE__, __LINE__)
+
+
 namespace bf {
 
 void set_error(const char* fmt, ...);

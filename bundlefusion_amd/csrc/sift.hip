@@ -303,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_keys_finalize(Levels lv, SiftDev d, in
     __syncthreads();
     for (int li = 0; li < NKL; ++li)
         for (int i = threadIdx.x; i < levelNum[li]; i += blockDim.x) {
-            const uint32_t key = d.cand[d.candOff[li] + i];
+            const uint32_t key = __hip_atomic_load(d.cand + d.candOff[li] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (sorted by the level's workgroup: read at the scope it was stored at)
             RawKey r; r.x = (int)(key & 0xFFFF); r.y = (int)(key >> 16); r.li = li; r.ori = 0xFFFFFFFFu;
             d.raw[levelStart[li] + i] = r;
         }

@@ -86,6 +86,8 @@ struct MatchScratch { int* rowRes; float* rowDist; int* colRes; uint32_t* ticket
 
 BF_DEV void storeAgent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 BF_DEV void storeAgentF(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BF_DEV int loadAgent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+BF_DEV float loadAgentF(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchScratch sc) {
     const uint32_t prev = blockIdx.x + a.startFrame;
@@ -185,14 +187,14 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchScratch sc) {
     for (int c0 = 0; c0 < n2; c0 += 256) {
         const int col = c0 + (int)tid;
         int f1 = -1; bool hit = false;
-        if (col < n2) { f1 = resCol[col]; hit = f1 >= 0 && f1 < n1 && resRow[f1] == col; }
+        if (col < n2) { f1 = loadAgent(resCol + col); hit = f1 >= 0 && f1 < n1 && loadAgent(resRow + f1) == col; }      // (other workgroups' results: loads at the scope they were stored at)
         const uint64_t ball = __ballot(hit);
         if (lane == 0) waveTot[w] = __popcll(ball);
         __syncthreads();
         int base = total, add = 0;
         for (int i = 0; i < 4; ++i) { if (i < (int)w) base += waveTot[i]; add += waveTot[i]; }
         const int pos = base + __popcll(ball & ((1ull << lane) - 1ull));
-        if (hit && pos < MAX_RAW) { rawR[pos] = f1; rawC[pos] = col; rawD[pos] = distRow[f1]; }
+        if (hit && pos < MAX_RAW) { rawR[pos] = f1; rawC[pos] = col; rawD[pos] = loadAgentF(distRow + f1); }
         total += add;
         __syncthreads();
     }

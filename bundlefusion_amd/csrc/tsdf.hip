@@ -471,10 +471,22 @@ BF_DEV void ldsBitonicSort(SortLds& s, uint32_t npad) {
     }
 }
 
+// AGENT: the records were written by OTHER workgroups of this launch (the overflow list in a placement's tail): read at the scope they were stored at.  (Round 5: a
+// plain load behind the tail's agent-scope acquire fence can return what this XCD's L2 held before - measured on the matcher's and the key list's last-workgroup
+// hand-offs, where 3 of 16 runs of the frame loop gave another trajectory until the finisher's loads became agent-scope loads: profiles/r05_determinism.md.)
+template <bool AGENT = false>
 BF_DEV uint32_t loadBinSorted(SortLds& s, const BinRec* recs, uint32_t n) {
     const uint32_t npad = nextPow2(n);
     for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x) {
-        if (i < n) { const BinRec r = recs[i]; s.key[i] = r.key; s.bucket[i] = r.bucket; s.aux[i] = r.aux; }
+        if (i < n) {
+            BinRec r;
+            if (AGENT) {
+                const unsigned long long* q = reinterpret_cast<const unsigned long long*>(recs + i);
+                const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r.key = a; r.bucket = (uint32_t)b; r.aux = (uint32_t)(b >> 32);
+            } else r = recs[i];
+            s.key[i] = r.key; s.bucket[i] = r.bucket; s.aux[i] = r.aux;
+        }
         else { s.key[i] = EMPTY64; s.bucket[i] = 0xFFFFFFFFu; s.aux[i] = 0; }
     }
     __syncthreads();
@@ -741,8 +753,8 @@ BF_DEV void placeBinWave(const Dev& d, const Frame& f, const Frame& fo, uint32_t
 // this point); the only thing the tail has to fetch is what the other workgroups produced: the number of bucket-full keys.
 template <int LISTS>
 BF_DEV void placeTail(const Dev& d, const Frame& f, const Frame& fo, SortLds& s, uint32_t M, uint32_t heapC, uint32_t allocBase, uint32_t stuckAll) {
-    const uint32_t nov = min(d.overflowCount[0], OVCAP);
-    if (nov > 0) loadBinSorted(s, d.overflow, nov);
+    const uint32_t nov = min(__hip_atomic_load(d.overflowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), OVCAP);
+    if (nov > 0) loadBinSorted<true>(s, d.overflow, nov);
     if (threadIdx.x == 0) {
         const uint32_t listRoom = f.numSDFBlocks - min(allocBase, f.numSDFBlocks);
         const uint32_t heapFree = min(heapC + 1u, listRoom);          // the same limit placeBin applied
@@ -755,7 +767,7 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, const Frame& fo, SortLds& s,
             const uint32_t h = s.bucket[k];
             const uint32_t gi = s.aux[k];
             const uint32_t last = (h + 1) * BF_HASH_BUCKET_SIZE - 1;
-            const int32_t ptr = d.allocList[allocBase + gi].ptr;
+            const int32_t ptr = __hip_atomic_load(&d.allocList[allocBase + gi].ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool done = false;
             uint32_t maxIter = 0;
             int offset = 0;
@@ -763,10 +775,10 @@ BF_DEV void placeTail(const Dev& d, const Frame& f, const Frame& fo, SortLds& s,
                 offset++;
                 const uint32_t i = (last + (uint32_t)offset) % total;
                 if ((offset % BF_HASH_BUCKET_SIZE) == 0) continue;      // never a bucket's last slot :624
-                if (d.hash[i].ptr == BF_FREE_ENTRY) {
+                if (__hip_atomic_load(&d.hash[i].ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == BF_FREE_ENTRY) {
                     const i3 b = unpackKey(s.key[k]);
                     d.hash[i].pos[0] = b.x; d.hash[i].pos[1] = b.y; d.hash[i].pos[2] = b.z;
-                    d.hash[i].offset = d.hash[last].offset;
+                    d.hash[i].offset = __hip_atomic_load(&d.hash[last].offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     d.hash[i].ptr = ptr;
                     d.hash[last].offset = (uint32_t)offset;
                     done = true;

@@ -43,6 +43,8 @@ def main():
     h, heap, cnt, vox = p.scene().download()
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
     it, ot = p.integrated_trajectory(), p.optimized_trajectory()
+    if os.environ.get("FIRST_RUN_SAVE"):
+        np.save(os.environ["FIRST_RUN_SAVE"], it)
     print(json.dumps({"pattern": pat, "integrated": sha(it), "optimized": sha(ot), "counters": p.counters(), "table": sha(h["pos"]) + sha(h["ptr"]), "voxels": sha(vox.view(np.uint8)),
                       "first_rows_differing_hint": [float(np.abs(it[k]).sum()) for k in (1, 5, 11, 21, 32)]}), flush=True)
 

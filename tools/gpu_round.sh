@@ -70,12 +70,23 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
       (cd "$ROOT" && BF_PIPELINE_TRACE="$OUT/pltrace.txt" timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 $BENCH_ARGS > "$OUT/bench_pltrace.json" 2> /dev/null; cut -c1-120 "$OUT/bench_pltrace.json"; tail -26 "$OUT/pltrace.txt") ;;
     determinism)
       (cd "$ROOT" && timeout 300 python tools/determinism_check.py ${DET_RUNS:-3} 2>&1 | grep -v amdgpu.ids | tee "$OUT/determinism.txt" | tail -8) ;;
-    firstrun)    # one frame loop per process over poisoned device memory (tools/first_run_check.py): PATTERNS="none 0 ffffffff 7fc00000 ..."
+    firstrun)    # one frame loop per process (tools/first_run_check.py) with allocations poisoned: POISONS="*=12345678;sift.hip=12345678;siftmgr.hip:812=ffffffff" (BF_DEBUG_POISON values)
       rm -f "$OUT/first_run.txt"
-      for P in ${PATTERNS:-none 0 ffffffff 7fc00000 none 12345678 ff7fffff none}; do
-        (cd "$ROOT" && timeout 120 python tools/first_run_check.py $P 2>&1 | grep -v amdgpu.ids | tail -1 >> "$OUT/first_run.txt")
+      IFS=';' read -ra PV <<< "${POISONS:-none;*=12345678;*=0;*=ffffffff}"
+      for P in "${PV[@]}"; do
+        (cd "$ROOT" && if [ "$P" = none ]; then unset BF_DEBUG_POISON; else export BF_DEBUG_POISON="$P"; fi; timeout 120 python tools/first_run_check.py none 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s|^|$P  |" >> "$OUT/first_run.txt")
       done
-      cut -c1-200 "$OUT/first_run.txt" ;;
+      cut -c1-150 "$OUT/first_run.txt" ;;
+    racehunt)    # how often does a fresh process produce another trajectory?  RH_ENVS="X=0;BF_PIPELINE_LOOKAHEAD=0" x RH_N processes each
+      IFS=';' read -ra RV <<< "${RH_ENVS:-X=0}"
+      for V in "${RV[@]}"; do
+        TAG=$(echo "$V" | tr ' =' '__')
+        rm -f "$OUT/race_$TAG.txt"
+        for i in $(seq 1 ${RH_N:-8}); do
+          (cd "$ROOT" && env $V timeout 120 python tools/first_run_check.py ${RH_PATTERN:-12345678} 2>&1 | grep -v amdgpu.ids | tail -1 >> "$OUT/race_$TAG.txt")
+        done
+        echo "== $V: $(grep -c integrated "$OUT/race_$TAG.txt") runs, trajectories: $(grep -o '"integrated": "[0-9a-f]*"' "$OUT/race_$TAG.txt" | sort | uniq -c | sort -rn | awk '{printf "%s x%s  ", substr($3,2,8), $1}')"
+      done ;;
     det_bisect)  # the fast batched configuration only, under environment variants (ENVS="A=1;B=2"): which overlap a run-to-run difference needs
       IFS=";" read -ra VARIANTS <<< "${DET_ENVS:-X=0}"
       for V in "${VARIANTS[@]}"; do
