@@ -201,14 +201,15 @@ def main():
     T0inv = np.linalg.inv(frames[0][2].astype(np.float64))
     gt = np.stack([T0inv @ f[2].astype(np.float64) for f in frames])
 
-    def run_leg(arith):
+    def run_leg(arith, solve_lag=None):
         """The whole measurement (pre-roll, warm-up, K timed steps) with the voxel update under one arithmetic contract."""
         gas, gbs = params()
         pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
         pipe.scene().set_arith(arith)
         pipe.set_volume_batching(args.volume_batching == "on")
-        if args.solve_lag and not chunked:
-            pipe.set_solve_lag(args.solve_lag)
+        solve_lag = args.solve_lag if solve_lag is None else solve_lag
+        if solve_lag and not chunked:
+            pipe.set_solve_lag(solve_lag)
         if shard_volume and world > 1:
             pipe.set_volume_shard(rank, world)
         runner = None
@@ -315,7 +316,7 @@ def main():
             "blocks_visited_per_launch": (L["vis_plain"] + L["vis_fused"]) / max(n_launch, 1),
             "accounting": "achieved = (blocks of the launch's list x (512*24+32) + frames sampled x W*H*8) / launch time: each block and each frame once per launch (union list of a "
                           "fused re-integration / of a batch); achieved_per_operator = SURVEY 8d by the letter, summed over the launch's operators; traffic = PMC bytes per visited "
-                          "block (profiles/%s: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, own passes, same contract, same kernel source: update_kernel_sha256) x blocks visited "
+                          "block (profiles/%s: FETCH_SIZE x the factor measured on this access pattern with known byte counts [tools/pmc_calibrate.py, recorded in that file] + WRITE_SIZE, own passes, same contract, same kernel source: update_kernel_sha256) x blocks visited "
                           "here; null when that file was collected on another version of the kernel" % PMC_FILE,
             "share_of_step_time": (L["kernel_ms"] / 1e3) / L["elapsed"] if L["elapsed"] > 0 else None,
         }
@@ -324,6 +325,11 @@ def main():
     other = None
     if args.both_contracts and world == 1 and not args.pmc_out:
         other = run_leg("exact" if args.arith == "fast" else "fast")
+    lagged = None
+    if args.both_contracts and world == 1 and not args.pmc_out and not args.solve_lag and not chunked:
+        # the same window with the chunk solves on their own thread and stream, applied exactly 10 frames (one chunk) later: the schedule of the reference's optimiser
+        # thread made deterministic (tests/test_pipeline_gpu.py holds it to the oracle loop with the same lag).  Reported beside the serial order, never as `value`.
+        lagged = run_leg(args.arith, solve_lag=10)
     if args.pmc_out and rank == 0:
         json.dump({"config": pmc_config(args), "launches": main_leg["n_launch"],
                    "fused_launches": main_leg["n_launch"] if args.volume_batching == "on" else main_leg["n_ops"] - main_leg["n_launch"],      # launches over a union list
@@ -386,6 +392,11 @@ def main():
             out["other_contract"] = {"arith": other["arith"], "value": args.steps / other["elapsed"], "unit": "frames/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
                                      "roofline": roofline_of(other), "timed_ops": {k: other["c1"][k] - other["c0"][k] for k in other["c1"]},
                                      "same_trajectory": other["ate"] == main_leg["ate"]}
+        if lagged is not None:
+            out["lagged_solve"] = {"solve_lag_frames": 10, "value": args.steps / lagged["elapsed"], "unit": "frames/s", "ms_per_step": 1e3 * lagged["elapsed"] / args.steps,
+                                   "timed_ops": {k: lagged["c1"][k] - lagged["c0"][k] for k in lagged["c1"]},
+                                   "note": "chunk solves on their own thread and stream, applied exactly one chunk (10 frames) later - the reference runs its optimiser in a second "
+                                           "thread; parity of this schedule: tests/test_pipeline_gpu.py::test_lagged_solve_mode_vs_oracle_loop_with_the_same_lag.  Not `value`."}
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], feed[:args.cpu_frames], params, K, W, H, args.arith)
     del frames, feed
@@ -428,6 +439,9 @@ def main():
         if rank == 0:
             with line_lock:
                 out["sweep"] = sw
+                # the same update kernels on a volume far beyond the 256 MB Infinity Cache (1280x960 @2 mm, ~6 GB of blocks walked per sweep): what HBM itself delivers
+                g = (sw or {}).get("algorithmic_GBps_of_update_kernel_rank0") if isinstance(sw, dict) else None
+                out["roofline"]["frac_beyond_l3"] = (g / HBM_PEAK_GBS) if g else None
     if args.long_stream and world == 1:
         ls = secondary("long_stream", lambda: long_stream_block(args, K, W, H), 1500)
         with line_lock:

@@ -2243,14 +2243,8 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
     p->gas = *gas; p->gbs = *gbs; p->sensor = *sensor;
     memset(&p->last, 0, sizeof p->last);
     int rc = bf_image_manager_create(gas->s_integrationWidth, gas->s_integrationHeight, gbs->s_widthSIFT, gbs->s_heightSIFT, sensor, gbs, 1, &p->im);
-    if (!rc) {
-        // texel images of the stored frames (see bf_image_manager::storeTexels) when all of them fit a budget: 8 bytes per pixel and frame on top of the 8 the
-        // frames take (5000 frames at 640x480: 12 GB; BASELINE configs[4], 20000 frames at 1280x960, would need 197 GB more - the operators interleave per use there)
-        const double texBytes = 8.0 * gas->s_integrationWidth * gas->s_integrationHeight * (double)gbs->s_maxNumImages * gbs->s_submapSize;
-        double budget = 0.0;          // off by default: measured no gain (gpurun r04l: 680 vs 685 frames/s - an operator that interleaves its frame itself also leaves it in the cache)
-        if (const char* e = getenv("BF_PIPELINE_TEXEL_BUDGET_GB")) budget = 1e9 * atof(e);
-        if (texBytes <= budget) rc = bf_image_manager_set_store_texels(p->im, 1);
-    }
+    // (bf_image_manager_set_store_texels - a third plane per stored frame, depth and colour interleaved for the fast voxel update - is not used here: measured no
+    // gain, 680 vs 685 frames/s, gpurun r04l; since round 5 the batch's march writes the texels of its operators.)
     if (!rc) rc = bf_online_bundler_create(sensor, p->im, gas, gbs, &p->ob);
     bf_hash_params hp;                                          // CUDASceneRepHashSDF::parametersFromGlobalAppState :39-59
     memset(&hp, 0, sizeof hp);
@@ -2296,18 +2290,9 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
     static_assert(bf_image_manager::NSETS == bf_online_bundler::STAGE, "the image manager's input sets and the staging slots are indexed alike");
     for (uint32_t k = 0; k < bf_image_manager::NSETS; ++k) BF_TRY(bf_image_manager_set_input_guard(p->im, k, p->ob->evDetect[k]));      // the staged detection of the frame that used the set last
     {
-        // BF_PIPELINE_PAIR_STREAMS=1: the pair stages of consecutive frames on two streams.  Off by default: measured 659 vs 697 frames/s (gpurun r04c) - every
-        // cross-stream event hop costs ~40 us on this runtime and the stage needs four of them per frame, more than the overlap of two Kabsch filters returns
-        const char* e = getenv("BF_PIPELINE_PAIR_STREAMS");
-        const char* e2 = getenv("BF_PIPELINE_DETECT_STREAMS");
-        // odd frames detect on a second queue (bf_online_bundler_set_second_detect_stream): the first pair stream, a placeholder otherwise
-        if (!(e && atoi(e) != 0) && !(e2 && atoi(e2) == 1)) { BF_TRY(bf_online_bundler_set_second_detect_stream(p->ob, p->sPair[0])); p->sDetect2 = p->sPair[0]; }
-        if (e && atoi(e) != 0) {
-            int least = 0, greatest = 0;
-            BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            for (auto& st : p->sPair) if (!st) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
-            BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPair[0], p->sPair[1]));
-        }
+        // odd frames detect on a second queue (bf_online_bundler_set_second_detect_stream): the first of the two pair streams.  (The pair stages of consecutive frames
+        // on those two streams - bf_online_bundler_set_pair_streams, round 4 - lost: 659 vs 697 frames/s, gpurun r04c; the mode is reachable through that call only.)
+        BF_TRY(bf_online_bundler_set_second_detect_stream(p->ob, p->sPair[0])); p->sDetect2 = p->sPair[0];
     }
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation

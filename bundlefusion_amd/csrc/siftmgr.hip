@@ -1556,8 +1556,6 @@ int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float
                               const float colorIntrinsicsInv[16]) {
     BF_REQUIRE(local && global && colorIntrinsics && d_transforms, "null argument");
     BF_REQUIRE(local->globNumResiduals > 0, "no correspondences to fuse");
-    static const bool hostPath = [] { const char* e = getenv("BF_FUSE_HOST"); return e && atoi(e) != 0; }();
-    if (hostPath) return bf_siftmgr_fuse_to_global_host(local, global, colorIntrinsics, d_transforms, colorIntrinsicsInv);
     const uint32_t R = local->globNumResiduals, nI = local->numImages, mk = local->maxKeys;
     const size_t N = (size_t)nI * mk;
     // scratch: 8 arrays of N words + N key points + 2R edges
@@ -1600,7 +1598,7 @@ int bf_siftmgr_fuse_error(bf_siftmgr* local, int* err) {
     return BF_OK;
 }
 
-// The reference's own form: everything to the host, recursive search there, upload (kept for comparison and as BF_FUSE_HOST=1).
+// The reference's own form: everything to the host, recursive search there, upload (kept for comparison: tests/test_siftmgr_gpu.py).
 int bf_siftmgr_fuse_to_global_host(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16], const float* d_transforms,
                                    const float colorIntrinsicsInv[16]) {
     (void)colorIntrinsicsInv;

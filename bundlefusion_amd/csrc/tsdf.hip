@@ -1517,17 +1517,14 @@ BF_DEV ApxEntry apxEntry(const Dev& d, uint32_t blk) {
 }
 
 // One wave per block of the frustum (or union) list, lane = (x, y) column, the eight z walked as four pairs.
-//   DEFER = true (the default since round 4): a pair's samples are gathered first and each of its two voxel slices is loaded only when some lane of the wave
-//     has a valid sample for it - two dependent round trips per touched pair, no voxel traffic at all for an untouched slice (about 2.5 of a
-//     block's 8 slices are touched by no lane).  Measured against the other form in the bench window: 79.2 -> 73.4 us per fused launch, 708.7 -> 743.7
-//     frames/s (gpurun r04a, profiles/r04_update_variants.md).
-//   DEFER = false (BF_APX_DEFER=0): voxels are loaded speculatively together with the samples, one round trip per pair.
-// Same values, same operations: the two forms are bit-identical (tests/test_tsdf_fast_gpu.py).
+// A pair's samples are gathered first and each of its two voxel slices is loaded only when some lane of the wave has a valid sample for it - two dependent round
+// trips per touched pair, no voxel traffic at all for an untouched slice (about 2.5 of a block's 8 slices are touched by no lane).  Against speculative loads
+// beside the samples (one round trip; the form until round 4, removed in round 5): 79.2 -> 73.4 us per fused launch (gpurun r04a, profiles/r04_update_variants.md).
 // Measured and withdrawn in round 3 (profiles/r03_lds_footprint.md; the code is in the history): the block's pixel footprint staged through LDS
 // (83 us), plus all eight slices in one round trip (79.2), plus per-slice loads behind a second sampling pass (104), whole-row write-backs (79.7),
 // stage A of the next pair issued before stage B of the current one (113: 80 VGPRs -> 6 waves), the body held to 80 SGPRs (no change), 4096 / 2048
 // workgroups (97 / 106).
-template <int MODE, bool RNE, bool DEFER>
+template <int MODE, bool RNE>
 __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in, ApxPose de, const uint2* __restrict__ tex, int hasColor, int accumulate) {
     if (!hasColor) return;          // CUDASceneRepHashSDF.cu:441-448: without colour data `color.x != MINF` never holds
     constexpr bool DE = MODE != 0, IN = MODE != 1;
@@ -1546,15 +1543,12 @@ __global__ __launch_bounds__(256) void k_update_apx(Dev d, ApxCam c, ApxPose in,
 #pragma unroll 1
         for (int z = 0; z < 8; z += 2) {
             ApxPair pa;
-            if (!DEFER) apxLoadVoxels(cur, z, pa, true, true);
             apxSamples<DE, IN>(c, in, de, cur, z, texRes, pa);
-            if (DEFER) {
-                bool anyA, anyB;
-                apxTouched<DE, IN>(c, pa, anyA, anyB);
-                const bool ldA = __builtin_amdgcn_ballot_w64(anyA) != 0ull, ldB = __builtin_amdgcn_ballot_w64(anyB) != 0ull;      // wave-uniform
-                if (!ldA && !ldB) continue;                                               // nothing of this pair is read or written
-                apxLoadVoxels(cur, z, pa, ldA, ldB);
-            }
+            bool anyA, anyB;
+            apxTouched<DE, IN>(c, pa, anyA, anyB);
+            const bool ldA = __builtin_amdgcn_ballot_w64(anyA) != 0ull, ldB = __builtin_amdgcn_ballot_w64(anyB) != 0ull;      // wave-uniform
+            if (!ldA && !ldB) continue;                                               // nothing of this pair is read or written
+            apxLoadVoxels(cur, z, pa, ldA, ldB);
             apxStageB<DE, IN, RNE>(c, cur, z, pa);
         }
     }
@@ -1708,7 +1702,6 @@ struct bf_scene {
                                     // exact (k_update_col: IEEE op by op, bit-comparable with a host build of the reference and with the oracle)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
     uint2* texel[8] = {}; size_t texelPixels = 0;      // the operator's frame as 8-byte {depth, colour} texels (k_interleave), one per list buffer (NB)
-    bool apxDefer = true;           // k_update_apx<.., DEFER>: voxel slices loaded only behind a valid sample (BF_APX_DEFER=0: speculative loads)
     int32_t* d_hashDecision = nullptr;
     uint32_t shardLo = 0, shardHi = 0xFFFFFFFFu;      // bf_scene_set_shard
     uint32_t opsTimed = 0;          // integrate / de-integrate operations covered by the timed launches (a fused launch counts 2)
@@ -1840,10 +1833,8 @@ int probeCvt(bf_scene* s) {
 
 template <int MODE>
 void launchApx(bf_scene* s, uint32_t grid, const Dev& dv, const ApxCam& c, const ApxPose& in, const ApxPose& de, const uint2* tex, int hasColor, int acc) {
-#define BF_APX_LAUNCH(RNE, DEFER) hipLaunchKernelGGL((k_update_apx<MODE, RNE, DEFER>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, hasColor, acc)
-    if (s->apxDefer) { if (s->cvtRne) BF_APX_LAUNCH(true, true); else BF_APX_LAUNCH(false, true); }
-    else { if (s->cvtRne) BF_APX_LAUNCH(true, false); else BF_APX_LAUNCH(false, false); }
-#undef BF_APX_LAUNCH
+    if (s->cvtRne) hipLaunchKernelGGL((k_update_apx<MODE, true>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, hasColor, acc);
+    else hipLaunchKernelGGL((k_update_apx<MODE, false>), dim3(grid), dim3(256), 0, s->stream, dv, c, in, de, tex, hasColor, acc);
 }
 
 void setLastRigidTransform(bf_scene* s, const float* T) {       // CUDASceneRepHashSDF.h:128-134
@@ -2213,10 +2204,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
         BF_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
     s->gridUpdateCol = s->gridUpdateColPlain = 8192;      // see k_update_col
-    if (const char* e = getenv("BF_GRID_UPDATE_COL")) s->gridUpdateCol = s->gridUpdateColPlain = (uint32_t)atoi(e);      // tuning knob (tools/tsdf_sweep.py)
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
-    if (const char* e = getenv("BF_APX_DEFER")) s->apxDefer = atoi(e) != 0;
-    if (const char* e = getenv("BF_SCENE_LIST_BUFFERS")) s->NB = std::min(std::max(atoi(e), 2), (int)bf_scene::NBMAX);
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;

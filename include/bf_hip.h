@@ -529,7 +529,7 @@ BF_API int bf_siftmgr_get_top_retry_image(bf_siftmgr* m, uint32_t* idx, int* fou
  * Runs on the device (track building by connected components + the reference's depth-first order per component; the new key frame
  * and its key count are written in HBM, nothing is copied to the host); asynchronous on the manager's stream.
  * bf_siftmgr_fuse_to_global_host is the reference's own form (all key points / descriptors / correspondences to the host, recursive
- * search there, upload) - same results bit for bit; BF_FUSE_HOST=1 routes the first entry to it.
+ * search there, upload) - same results bit for bit.
  * bf_siftmgr_fuse_error: capacity conditions of the device search since creation (none at present: always 0). */
 BF_API int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float colorIntrinsics[16],
                                      const float* d_transforms, const float colorIntrinsicsInv[16]);

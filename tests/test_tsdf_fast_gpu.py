@@ -496,11 +496,11 @@ def test_fast_contract_in_the_frame_loop_changes_voxel_values_only(gpu):
 
 
 @pytest.mark.parametrize("size", ["160x120@20mm", "640x480@4mm"])
-def test_fast_contract_deferred_voxel_loads_are_bit_identical(gpu, monkeypatch, size):
-    """The two forms of k_update_apx - voxel slices loaded only behind a valid sample (DEFER, the default) and loaded speculatively together with
-    the samples (BF_APX_DEFER=0) - must not differ in ONE bit: integrations, fused re-integrations with translated and rotated poses, a
-    de-integration, GC."""
-    variant = "defer"
+def test_fast_contract_operators_are_bit_identical_run_to_run(gpu, size):
+    """The same operators through two fresh scenes must not differ in ONE bit: integrations, fused re-integrations with translated and rotated poses, a
+    de-integration, GC.  (Until round 5 this test compared two forms of k_update_apx; the speculative-load form was removed.  Run-to-run identity is not a
+    formality for this kernel: see f2iHw in csrc/tsdf.hip.)"""
+    variant = "second"
     W, H = (160, 120) if size.startswith("160") else (640, 480)
     voxel = 0.02 if W == 160 else 0.004
     frames = [synth.scene_room(k * 9, W, H) for k in range(5)]
@@ -510,7 +510,6 @@ def test_fast_contract_deferred_voxel_loads_are_bit_identical(gpu, monkeypatch, 
     dev = [_to_dev(f[0], f[1]) for f in frames]
     out = {}
     for lds in ("0", variant):
-        monkeypatch.setenv("BF_APX_DEFER", "1" if lds == "defer" else "0")              # read when the scene is created
         gs = gpu.capi.SceneRepHashSDF(p); gs.set_arith("fast"); gs.set_overlap(True)
         poses = [f[2].copy() for f in frames]
         for i in range(len(frames)):

@@ -2,12 +2,14 @@
 """Turn the two PMC passes of `bench.py --pmc-out acc.json` (rocprofv3 --kernel-trace --pmc FETCH_SIZE, and --pmc WRITE_SIZE, each its
 own run) into profiles/rNN_pmc_tsdf_update.json: HBM bytes per visited SDF block for the plain and for the fused voxel-update kernel.
 
-    python tools/pmc_to_json.py <fetch_db> <write_db> <acc.json> <out.json> [out.md] [arith]
+    python tools/pmc_to_json.py <fetch_db> <write_db> <acc.json> <out.json> [out.md] [arith] [calibration.json]
 
 The output file holds one entry per arithmetic contract of the voxel update ("fast" / "exact", bench.py --arith); a run adds or replaces its own.
 
-FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes of a wide
-coalesced read stream).  The accounting file is what the profiled run itself counted over ALL its launches."""
+FETCH_SIZE / WRITE_SIZE are in KiB.  FETCH_SIZE under-reports on gfx950 (MI355X_MICROARCH.md: half the bytes of a wide coalesced read stream); the factor applied
+is the one MEASURED with known byte counts on the voxel update's own access pattern (tools/pmc_calibrate.py -> calibration.json: k_probe_slices, 12-byte
+voxels in 768-byte slices: 2.65; 16 bytes per lane: 1.99; WRITE_SIZE: 1.00) when that file is given, the guide's 2.0 otherwise.  Both factors are recorded.
+The accounting file is what the profiled run itself counted over ALL its launches."""
 import hashlib
 import json
 import os
@@ -41,14 +43,19 @@ def main():
     acc = json.load(open(accp))
     F, Wr = totals(fdb, "FETCH_SIZE"), totals(wdb, "WRITE_SIZE")
     res = {"config": acc["config"], "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) around `python bench.py --no-cpu-baseline --pmc-out ...`; "
-                                              "FETCH_SIZE x2 (gfx950), KiB -> bytes"}
+                                              "FETCH_SIZE x calibrated factor, KiB -> bytes"}
     vis = {"fused": acc["visited_blocks_fused"], "plain": acc["visited_blocks_plain"]}
     lau = {"fused": acc["fused_launches"], "plain": acc["launches"] - acc["fused_launches"]}
     arith = sys.argv[6] if len(sys.argv) > 6 else "fast"
-    lines = ["| kernel | launches (PMC pass / run accounting) | FETCH_SIZE x2 [MB/launch] | WRITE_SIZE [MB/launch] | HBM bytes / visited block | algorithmic bytes / block |", "|---|---|---|---|---|---|"]
+    cal = json.load(open(sys.argv[7])) if len(sys.argv) > 7 and os.path.exists(sys.argv[7]) else None
+    ff = cal["k_probe_slices"]["fetch_factor"] if cal else 2.0
+    wf = cal["k_probe_slices"]["write_factor"] if cal else 1.0
+    res["fetch_factor_applied"] = ff; res["write_factor_applied"] = wf
+    res["calibration"] = ({"k_probe_slices": cal["k_probe_slices"], "k_probe_blocks": cal["k_probe_blocks"]} if cal else "none given: the guide's x2")
+    lines = ["| kernel | launches (PMC pass / run accounting) | FETCH_SIZE x factor [MB/launch] | WRITE_SIZE [MB/launch] | HBM bytes / visited block | algorithmic bytes / block |", "|---|---|---|---|---|---|"]
     for k in ("fused", "plain"):
         n, f = F.get(k, [0, 0.0]); n2, w = Wr.get(k, [0, 0.0])
-        fb, wb = 2.0 * f * 1024.0, w * 1024.0
+        fb, wb = ff * f * 1024.0, wf * w * 1024.0
         res[k] = {"launches": n, "fetch_bytes_per_launch": fb / max(n, 1), "write_bytes_per_launch": wb / max(n2, 1),
                   "hbm_bytes_per_launch": fb / max(n, 1) + wb / max(n2, 1), "visited_blocks": vis[k],
                   "hbm_bytes_per_visited_block": (fb + wb) / max(vis[k], 1)}
