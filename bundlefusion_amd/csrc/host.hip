@@ -1574,7 +1574,7 @@ int bf_online_bundler_detect_ahead_after(bf_online_bundler* ob, void* ingest_eve
 
 namespace {
 
-struct CopySeg { uint32_t* dst; const uint32_t* src; uint32_t words; };
+struct alignas(32) CopySeg { uint32_t* dst; const uint32_t* src; uint32_t words; };      // (read at a run-time index: no scalar load of one straddles a 64-byte line)
 struct CopySegs { CopySeg s[9]; };
 __global__ __launch_bounds__(256) void k_copy_segments(CopySegs j) {
     const CopySeg c = j.s[blockIdx.y];

@@ -32,10 +32,12 @@ constexpr uint32_t MAXRAW = 6144;
 
 struct Taps { int fw[6]; float k[6][MAX_FW]; };
 
-struct BlurJob { const float* src; float* dst; int w, h, srcW, mode, filter, blocks; };   // mode 0 blur, 1 down-sample copy
+// (jobs and levels are read from the kernel arguments at a run-time index: laid out so that no scalar load of one straddles a 64-byte line - a straddling
+// s_load_dwordx8 of run-time-indexed arguments is what gave the batched voxel update its rare run-to-run differences, csrc/tsdf_batch.h BatchUpdOpApx)
+struct alignas(64) BlurJob { const float* src; float* dst; int w, h, srcW, mode, filter, blocks; };   // mode 0 blur, 1 down-sample copy
 struct BlurJobs { int n; BlurJob j[3]; };
 
-struct LevelInfo {        // one (octave, key level): DoG level j = g[j+1]-g[j], j = 1..3
+struct alignas(128) LevelInfo {        // one (octave, key level): DoG level j = g[j+1]-g[j], j = 1..3
     const float* g[4];    // gaussian array index j-1 .. j+2   (DoG j-1, j, j+1)
     int w, h, octave, fmax, cap;
     float keyLocScale;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(512) void k_octave(OctaveJob job, const float* __re
 
 // gradient magnitude / orientation of a gaussian level (ComputeDOG_Kernel :550-569); linear fetches
 // outside the image buffer read 0 like tex1Dfetch
-struct GradJob { const float* g; float* mag; float* ang; int w, h, blocks; };
+struct alignas(64) GradJob { const float* g; float* mag; float* ang; int w, h, blocks; };
 struct GradJobs { GradJob j[NKL]; };
 __global__ __launch_bounds__(256) void k_grad(GradJobs jobs) {
     int b = blockIdx.x, ji = 0;

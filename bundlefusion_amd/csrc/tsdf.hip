@@ -1459,8 +1459,8 @@ BF_DEV void apxCompute(const ApxCam& c, const ApxPair& a, v2f& vS, v2f& vW, uint
     if (!stA && !stB) return;
     if (DE && (okDeA || okDeB)) {           // voxelApply<true>
         const v2f dd = vW - sp2(1.0f);
-        v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
-        uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
+            v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
+            uint32_t nA = 0xFF000000u, nB = 0xFF000000u;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             v2f o, cc; o.x = byteF(vCA, k); o.y = byteF(vCB, k); cc.x = byteF(a.kDeA, k); cc.y = byteF(a.kDeB, k);
@@ -1479,8 +1479,8 @@ BF_DEV void apxCompute(const ApxCam& c, const ApxPair& a, v2f& vS, v2f& vW, uint
     }
     if (IN && (okInA || okInB)) {           // voxelApply<false>
         const v2f dd = sp2(1.0f) + vW;
-        v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
-        v2f ca, cb;                         // colour blend 0.2 new + 0.8 old; a voxel without weight takes the new colour
+            v2f r; r.x = __builtin_amdgcn_rcpf(dd.x); r.y = __builtin_amdgcn_rcpf(dd.y);
+            v2f ca, cb;                         // colour blend 0.2 new + 0.8 old; a voxel without weight takes the new colour
         ca.x = vW.x == 0.0f ? 1.0f : 0.2f; cb.x = vW.x == 0.0f ? 0.0f : 0.8f;
         ca.y = vW.y == 0.0f ? 1.0f : 0.2f; cb.y = vW.y == 0.0f ? 0.0f : 0.8f;
         uint32_t nA = 0xFF000000u, nB = 0xFF000000u;

@@ -32,10 +32,11 @@ struct BatchCommon {
     uint32_t shardLo, shardHi;
     uint32_t nOps;
 };
-struct BatchMarchOp { m44 T, Tinv; const float* depth; const uint32_t* color; uint2* texel; uint32_t marches; uint32_t pad; };
+// (kernel arguments read at a run-time index - an operator, a level, a job - are laid out so that no scalar load of them straddles a 64-byte line: see BatchUpdOpApx)
+struct alignas(64) BatchMarchOp { m44 T, Tinv; const float* depth; const uint32_t* color; uint2* texel; uint32_t marches; uint32_t pad; };
 struct BatchMarchArgs { BatchMarchOp op[BMAX]; };
 // bits[k]: bit 0 operator k integrates (pose TinvIn[k]), bit 1 it de-integrates (pose TinvDe[k])
-struct BatchFrusta { m44 TinvIn[BMAX], TinvDe[BMAX]; uint32_t bits[BMAX]; };
+struct alignas(64) BatchFrusta { m44 TinvIn[BMAX], TinvDe[BMAX]; uint32_t bits[BMAX]; };
 
 __global__ void k_batch_reset(BatchDev bd, uint32_t numBuckets) {
     const uint32_t stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,7 +501,9 @@ __global__ __launch_bounds__(256) void k_batch_place(Dev d, BatchDev bd, BatchCo
 // (24 per lane), the batch's operators are applied in order - each gathers its samples from its own frame's texel image -, and every slice some lane changed
 // goes back whole.  Per voxel and operator the operations are k_update_apx's (apxSamples / apxCompute): the same bits as the operators issued one by one.
 // ---------------------------------------------------------------------------------------
-struct BatchUpdOpApx { ApxPose in, de; const uint2* tex; };
+// 64-byte aligned, each pose in a cache line of its own: the wave reads an operator's constants with scalar loads at a run-time index, once per block and operator,
+// and no s_load_dwordx8 / x4 of them may straddle a 64-byte line (with the natural 104-byte stride they did).
+struct alignas(64) BatchUpdOpApx { ApxPose in; float padIn[4]; ApxPose de; float padDe[4]; const uint2* tex; };
 struct BatchUpdApxArgs { BatchUpdOpApx op[BMAX]; uint32_t nOps; uint32_t liveMask; };      // liveMask: membership bits of the operators that update voxels (an operator without colour data does not)
 
 template <bool RNE>
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(256) void k_update_batch_apx(Dev d, ApxCam c, Batch
 
 // exact contract: the batch's operators one after the other on the block, each through k_update_col's column form (colFast / colExact) - the voxels travel
 // through the wave's own cache lines between operators instead of through registers; same bits as the operators issued one by one
-struct BatchUpdOpCol { UpdPose in, de; const float* depth; const uchar4* color; };
+struct alignas(64) BatchUpdOpCol { UpdPose in; float padIn[2]; UpdPose de; float padDe[2]; const float* depth; const uchar4* color; };      // 56-byte poses, one 64-byte line each
 struct BatchUpdColArgs { BatchUpdOpCol op[BMAX]; uint32_t nOps; uint32_t pad; };
 
 __global__ __launch_bounds__(256) void k_update_batch_col(Dev d, UpdCam c, BatchUpdColArgs a, int accumulate, int forceExact) {
