@@ -60,7 +60,6 @@ def main():
                   "hbm_bytes_per_launch": fb / max(n, 1) + wb / max(n2, 1), "visited_blocks": vis[k],
                   "hbm_bytes_per_visited_block": (fb + wb) / max(vis[k], 1)}
         lines.append("| voxel update, %s contract, `%s` | %d / %d | %.1f | %.1f | %.0f | %d |" % (arith, k, n, lau[k], fb / max(n, 1) / 1e6, wb / max(n2, 1) / 1e6, res[k]["hbm_bytes_per_visited_block"], 512 * 24 + 32))
-    import os
     allres = json.load(open(outp)) if os.path.exists(outp) else {}
     res["update_kernel_sha256"] = update_kernel_sha()
     allres[arith] = res
