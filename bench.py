@@ -301,7 +301,7 @@ def main():
             kern = ("k_update_batch_apx (tsdf_batch.h): one wave per block of the batch's union list, voxels loaded once, the batch's operators applied in order from registers"
                     if L["arith"] == "fast" else "k_update_batch_col (tsdf_batch.h): the batch's operators one after the other per block, exact contract")
         else:
-            kern = "k_update_apx<2,.,DEFER> (fused de-integrate + integrate) + k_update_apx<0,.,DEFER> (integrate)" if L["arith"] == "fast" else \
+            kern = "k_update_apx<2> (fused de-integrate + integrate) + k_update_apx<0> (integrate)" if L["arith"] == "fast" else \
                    "k_update_col<2> (fused de-integrate + integrate) + k_update_col<0> (integrate)"
         return {
             "kernel": kern + " - TSDF voxel update, tsdf.hip",
