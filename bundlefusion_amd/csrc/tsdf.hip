@@ -1318,12 +1318,13 @@ __global__ __launch_bounds__(256) void k_update_col(Dev d, UpdCam c, UpdPose in,
 // Depth and colour are fetched through buffer descriptors (32-bit offsets, out-of-image lanes read 0 and are masked) - no 64-bit
 // address arithmetic, no divergent branches around the loads.
 // ---------------------------------------------------------------------------------------
-struct ApxCam {
+// (64-byte aligned like every kernel argument the fast update reads with wide scalar loads: none of them straddles a 64-byte line - tsdf_batch.h BatchUpdOpApx)
+struct alignas(64) ApxCam {
     float mxh, myh;            // principal point + 0.5 (the rounding offset of the pixel index)
     float voxelSize, maxDist, truncScale, truncation, weightMax;
     uint32_t W, H, bytes;      // image size, bytes of one image plane (W * H * 4)
 };
-struct ApxPose {
+struct alignas(64) ApxPose {
     float ax, bx, cx, dx;      // fx * voxelSize * (R00, R01, R02), fx * t0: numerator of the image x coordinate over the integer voxel coordinates
     float ay, by, cy, dy;      // fy * voxelSize * (R10, R11, R12), fy * t1
     float r6, r7, r8, t2;      // third row of the world -> camera transform (camera-space z in the exact kernel's operation order)

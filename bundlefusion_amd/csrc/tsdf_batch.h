@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_batch_place(Dev d, BatchDev bd, BatchCo
 // ---------------------------------------------------------------------------------------
 // 64-byte aligned, each pose in a cache line of its own: the wave reads an operator's constants with scalar loads at a run-time index, once per block and operator,
 // and no s_load_dwordx8 / x4 of them may straddle a 64-byte line (with the natural 104-byte stride they did).
-struct alignas(64) BatchUpdOpApx { ApxPose in; float padIn[4]; ApxPose de; float padDe[4]; const uint2* tex; };
+struct alignas(64) BatchUpdOpApx { ApxPose in, de; const uint2* tex; };          // (ApxPose is 64-byte aligned itself)
 struct BatchUpdApxArgs { BatchUpdOpApx op[BMAX]; uint32_t nOps; uint32_t liveMask; };      // liveMask: membership bits of the operators that update voxels (an operator without colour data does not)
 
 template <bool RNE>
