@@ -400,6 +400,34 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
 
 
+def test_round5_bench_line_and_pmc_file_are_consistent():
+    """profiles/r05_bench_driver.json (the driver's invocation on the MI355X box) against the contract and against the PMC file its `traffic` comes from: the
+    counters were collected on the update kernels' CURRENT source (bench.py reports no traffic otherwise), with the calibrated factor on record."""
+    import json
+    import sys
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_driver.json")).read().strip().split("\n")[-1])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], typ), key
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["vs_baseline"] is None
+    assert abs(line["value"] - 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
+    assert 0.0 < r["frac"] < 1.0 and r["frac_per_operator"] > r["frac"] and 0.0 < r["frac_beyond_l3"] < 1.0
+    assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
+    assert line["lagged_solve"]["solve_lag_frames"] == 10 and line["lagged_solve"]["value"] > 0
+    ls = line["long_stream"]
+    assert ls["frames"] == 2000 and ls["frames_tracked"] == 2000 and ls["ate_optimized_m"] < 0.01
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"]
+    sys.path.insert(0, ROOT)
+    from tools.pmc_to_json import update_kernel_sha
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_tsdf_update.json")))["fast"]
+    assert pmc["update_kernel_sha256"] == update_kernel_sha(), "the committed PMC traffic was collected on another version of the voxel-update kernels"
+    assert abs(pmc["fetch_factor_applied"] - pmc["calibration"]["k_probe_slices"]["fetch_factor"]) < 1e-12 and 2.0 < pmc["fetch_factor_applied"] < 3.0
+    assert pmc["fused"]["launches"] > 200 and 12320 < pmc["fused"]["hbm_bytes_per_visited_block"] < 60000
+
+
 def test_bench_launches_its_own_ranks_and_refuses_a_mismatched_world():
     """`python bench.py --gpus N` without a launcher around it starts N ranks itself (torch.distributed.run on 127.0.0.1) instead of measuring
     one GPU under the label N; with a launcher whose world differs from --gpus it prints no line.  (--launch-check: the rendezvous over gloo
