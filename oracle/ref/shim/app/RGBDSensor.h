@@ -10,8 +10,12 @@ public:
         : m_dw(depthW), m_dh(depthH), m_cw(colorW), m_ch(colorH), m_depthIntrinsics(depthIntrinsics), m_depthIntrinsicsInv(depthIntrinsics.getInverse()),
           m_colorIntrinsics(colorIntrinsics), m_extrinsics(mat4f::identity()), m_depth((size_t)depthW * depthH), m_color((size_t)colorW * colorH * 4) {}
     void setFrame(const float* depth, const unsigned char* colorRGBX) { m_depth.assign(depth, depth + m_depth.size()); m_color.assign(colorRGBX, colorRGBX + m_color.size()); }
-    bool processDepth() { return true; }
+    bool processDepth() { return m_receiving; }           // false once the test has declared the sequence over (ref_loop.cpp: the compiled frame loop polls the sensor)
     bool processColor() { return true; }
+    void setReceiving(bool r) { m_receiving = r; }
+    bool isReceivingFrames() const { return m_receiving; }
+    mat4f getRigidTransform() const { return mat4f::identity(); }          // (s_binaryDumpSensorUseTrajectory is off)
+    void recordFrame() {}
     unsigned int getDepthWidth() const { return m_dw; }
     unsigned int getDepthHeight() const { return m_dh; }
     unsigned int getColorWidth() const { return m_cw; }
@@ -27,4 +31,5 @@ private:
     unsigned int m_dw, m_dh, m_cw, m_ch;
     mat4f m_depthIntrinsics, m_depthIntrinsicsInv, m_colorIntrinsics, m_extrinsics;
     std::vector<float> m_depth; std::vector<unsigned char> m_color;
+    bool m_receiving = true;
 };

@@ -795,6 +795,35 @@ class RefOnlineBundler:
         return t
 
 
+class RefFrameLoop:
+    """The reference's frame loop compiled as it is (oracle/ref/ref_loop.cpp: DepthSensing.cpp:723-762, :853-902, :966-1129) over a RefOnlineBundler's objects and a
+    RefScene(host_class=True): frame(depth, colour) = one OnD3D11FrameRender call with a new sensor frame, frame() = one call after the sequence has ended."""
+
+    def __init__(self, rob, rscene, cam, max_frame_fixes):
+        assert rscene._p == "ref_hscene_", "the compiled loop drives the reference's host class"
+        self.rob, self.rscene = rob, rscene
+        lib().ref_loop_bind(rob._h, rscene._h, C.byref(cam), C.c_uint32(max_frame_fixes))
+
+    def frame(self, depth=None, color=None):
+        if depth is None:
+            lib().ref_loop_end_of_sequence(self.rob._h)
+        else:
+            lib().ref_loop_set_frame(self.rob._h, _fp(_f32(depth)), _fp(np.ascontiguousarray(color, np.uint8)))
+            self.rob.num_frames += 1
+        return bool(lib().ref_loop_frame_render())
+
+    def ops(self, start=0):
+        """[(kind "in" | "de", stored frame index, T)] the loop asked of the volume, from entry `start` on"""
+        n = int(lib().ref_loop_num_ops())
+        out = []
+        for i in range(start, n):
+            kind, frame = C.c_int(), C.c_int()
+            T = np.zeros((4, 4), np.float32)
+            lib().ref_loop_op(C.c_uint32(i), C.byref(kind), _fp(T), C.byref(frame))
+            out.append(("in" if kind.value == 0 else "de", frame.value, T))
+        return out
+
+
 class _BorrowedTM(RefTrajectoryManager):
     def __del__(self):
         pass

@@ -1111,6 +1111,103 @@ def test_sba_align_local_dense_vs_reference_host_code(oracle):
     assert np.abs(r2["transforms"] - r["transforms"]).max() > 1e-5          # the dense term did something in the first run
 
 
+# ------------------------------------------------------------------------------------------------ the frame loop itself
+@pytest.mark.parametrize("scenario", ["three_chunks", pytest.param("tracking_loss", marks=pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="one more minute on the block emulator: BF_LONG_TESTS=1"))])
+def test_compiled_frame_loop_equals_the_restated_one(scenario):
+    """DepthSensing.cpp's own frame loop - integrate / deIntegrate (:723-762), reintegrate (:853-902) and OnD3D11FrameRender (:966-1129), cut out of the file and
+    compiled as they are (oracle/ref/ref_loop.cpp) - against the RESTATEMENT of those lines that test_online_bundler_vs_reference_host_code (below) drives the
+    reference's classes with, and that the oracle frame loop (tests/oracle_pipeline.py) and the product (host.hip: bf_pipeline_*) implement.  Two sets of the
+    reference's objects (CUDAImageManager, OnlineBundler with its TrajectoryManager, CUDASceneRepHashSDF), the same sensor frames, frame by frame plus the
+    iterations after the end of the sequence: the bundler's state machine, every trajectory, the operations asked of the volume (kind, stored frame, transform) in
+    order, and the volume itself - table, heap, every voxel byte - must be identical bit for bit (same code, same libm on both sides; only the ~40 lines of
+    glue differ, and those are what is being pinned)."""
+    from bundlefusion_amd.capi import default_app_state, default_bundling_state, intrinsics_matrix, camera_params
+    from tests.oracle_pipeline import scale_intrinsics, _minf
+    W, H, S = 320, 240, 3
+    NF, dark = (10, range(0)) if scenario == "three_chunks" else (16, range(4, 9))
+    gas = default_app_state(); gbs = default_bundling_state()
+    gas.s_integrationWidth, gas.s_integrationHeight = W, H
+    gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.05, 5000, 2000
+    gas.s_garbageCollectionEnabled = True
+    gbs.s_widthSIFT, gbs.s_heightSIFT, gbs.s_maxNumImages, gbs.s_submapSize = W, H, 8, S
+    frames = [synth.scene_room(3 * k, W, H) for k in range(NF)]
+    Kd = frames[0][3]
+    K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
+    frames = [((np.full_like(f[0], -np.inf) if k in dark else f[0]), f[1]) for k, f in enumerate(frames)]
+    Ki = scale_intrinsics(K, W, H, W, H)
+    cam = camera_params(W, H, float(Ki[0, 0]), float(Ki[1, 1]), float(Ki[0, 2]), float(Ki[1, 2]), gas.s_renderDepthMin, gas.s_renderDepthMax)
+    hp = ref_api.hash_params_from_global_app_state(gas)
+
+    # ---- side A: the restated loop over the reference's classes (the sequence of test_online_bundler_vs_reference_host_code, without the oracle)
+    ra = ref_api.RefOnlineBundler(gas, gbs, W, H, K)
+    sa = ref_api.RefScene(hp, host_class=True)
+    tma = ra.trajectory_manager()
+    ops_a, stored = [], []
+
+    def vol_a(kind, idx, T):
+        ops_a.append((kind, idx, np.array(T, np.float32)))
+        (sa.deintegrate if kind == "de" else sa.integrate)(T, stored[idx][0], stored[idx][1], cam)
+
+    def reintegrate_a():                         # DepthSensing.cpp:853-902
+        if tma.active() < gas.s_maxFrameFixes:
+            tma.generate()
+        for _ in range(gas.s_maxFrameFixes):
+            f, idx, T, _ = tma.top_de()
+            if f:
+                vol_a("de", idx, T); continue
+            f, idx, T, _ = tma.top_in()
+            if f:
+                vol_a("in", idx, T); tma.confirm(idx); continue
+            f, idx, old, new = tma.top_re()
+            if f:
+                vol_a("de", idx, old); vol_a("in", idx, new); tma.confirm(idx); continue
+            break
+        sa.garbage_collect()
+
+    # ---- side B: the compiled loop
+    rb = ref_api.RefOnlineBundler(gas, gbs, W, H, K)
+    sb = ref_api.RefScene(hp, host_class=True)
+    loop = ref_api.RefFrameLoop(rb, sb, cam, gas.s_maxFrameFixes)
+    n_b = 0
+    for i in range(NF + 5):
+        if i < NF:
+            d, c = frames[i]
+            ra.set_frame(d, c)                                   # CUDAImageManager::process
+            _, _, di, ci = ra.ingest_outputs()
+            stored.append((di.copy(), ci.copy()))                # what getIntegrateFrame(i) holds (side B reads it in place)
+            ra.process_input()
+            ok, T, idx, lost = ra.current_integration_frame()
+            reintegrate_a()
+            if ok:
+                vol_a("in", idx, T)
+                tma.add(0, T, i)
+            else:
+                tma.add(1, _minf(), i)
+            stop = loop.frame(d, c)
+        else:
+            ra.process_input()
+            reintegrate_a()
+            stop = loop.frame()
+        ra.process()
+        assert not stop, i
+        # the same state, the same trajectories, the same operations in the same order, the same volume
+        assert ra.state() == rb.state(), (i, ra.state(), rb.state())
+        n = ra.state()["num_complete"]
+        if n:
+            assert _same(ra.complete_trajectory(n), rb.complete_trajectory(n)), i
+        assert _same(ra.sift_trajectory(min(i + 1, NF)), rb.sift_trajectory(min(i + 1, NF))), i
+        new_b = loop.ops(n_b)
+        new_a = ops_a[n_b:]
+        assert [(k, f) for k, f, _ in new_a] == [(k, f) for k, f, _ in new_b], (i, [(k, f) for k, f, _ in new_a], [(k, f) for k, f, _ in new_b])
+        assert all(_same(Ta, Tb) for (_, _, Ta), (_, _, Tb) in zip(new_a, new_b)), i
+        n_b += len(new_b)
+        assert sa.heap_counter() == sb.heap_counter() and np.array_equal(sa.hash(), sb.hash()) and np.array_equal(sa.heap(), sb.heap()), i
+        assert np.array_equal(sa.voxels().view(np.uint8), sb.voxels().view(np.uint8)), i
+    kinds = {k for k, _, _ in ops_a}
+    assert kinds == {"in", "de"} and len(ops_a) > NF and ra.state()["past_end"] >= 4 and ra.state()["num_complete"] >= 2 * S, (kinds, len(ops_a), ra.state())
+    assert int(ref_api.lib().ref_loop_frames_rendered()) == NF + 5
+
+
 # ------------------------------------------------------------------------------------------------ the bundling half of the frame loop
 _LONG = pytest.mark.skipif(os.environ.get("BF_LONG_TESTS") != "1", reason="1-2 more minutes on the block emulator: BF_LONG_TESTS=1 (log of a run: profiles/r02_ref_pin_long.txt)")
 
