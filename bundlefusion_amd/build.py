@@ -18,6 +18,13 @@ HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",          # op-by-op IEEE arithmetic, bit-comparable with the oracle
     "-fvisibility=hidden", "-Wno-unused-value", "-Wno-unused-result",
+    # No packed-FP32 instructions (v_pk_add/mul/fma_f32): the compiler pads the gfx950 forwarding hazard behind such an instruction with s_nop ONLY when the
+    # instruction's first source has op_sel_hi set; where that source is a broadcast scalar (op_sel_hi:[0,1]) the very next instruction may read the result with no
+    # wait state - and on the device, with other kernels running, lanes 48-63 then now and then read the previous value (round 5: the batched voxel update's
+    # run-to-run differences sat exactly on the three such places of k_update_batch_apx, all in the first voxel pair's depth; every .hip file has some: tools/
+    # pk_hazard_scan.py, profiles/r05_determinism.md).  The two halves as two scalar instructions are the same IEEE operations bit for bit; the voxel update
+    # is 7 % longer in instructions and 12 registers smaller.  (The host pass prints "not a recognized feature for this target": expected.)
+    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
 ]
 
 

@@ -17,8 +17,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
 def test_fast_update_kernels_have_no_scalar_load_across_a_64_byte_line(tmp_path):
     out = tmp_path / "tsdf.s"
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-unused-result",
-           "--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "bundlefusion_amd", "csrc"),
+    from bundlefusion_amd.build import HIP_FLAGS
+    cmd = [HIPCC] + [f for f in HIP_FLAGS if f != "-shared"] + ["--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "bundlefusion_amd", "csrc"),
            os.path.join(ROOT, "bundlefusion_amd", "csrc", "tsdf.hip"), "-o", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -45,3 +45,14 @@ def test_fast_update_kernels_have_no_scalar_load_across_a_64_byte_line(tmp_path)
             assert seg and int(seg.group(1)) >= 64, (nm.group(1), seg and seg.group(1))
             seen += 1
     assert seen >= 8
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
+def test_no_packed_fp32_result_is_read_without_a_wait_state():
+    """tools/pk_hazard_scan.py over every csrc/*.hip with the library's build flags: no v_pk_add/mul/fma_f32 whose result the next instruction reads (with the
+    flags of bundlefusion_amd/build.py there is no packed FP32 instruction at all).  The other half of DESIGN.md 7.2: the compiler pads that forwarding hazard
+    only for some operand encodings, and the batched voxel update's run-to-run differences sat on the unpadded ones."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pk_hazard_scan.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "total 0" in r.stdout and r.stdout.count("packed FP32 instructions     0") >= 9, r.stdout
