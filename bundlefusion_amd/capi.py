@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbf_hip.so")
+LIB_PATH = os.environ.get("BF_LIB_PATH") or os.path.join(_HERE, "lib", "libbf_hip.so")      # BF_LIB_PATH: a variant build of the same library (tools/build_variant.py; diagnostics)
 
 
 class BFError(RuntimeError):

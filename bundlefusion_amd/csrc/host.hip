@@ -2025,7 +2025,7 @@ int volPost(bf_pipeline* p, int kind, uint32_t frame, const float* T0, const flo
     c.kind = kind; c.waitEv = waitEv;
     c.data.d_depthData = nullptr; c.data.d_colorData = nullptr;
     c.texels = nullptr;
-    if (kind != 3) {
+    if (kind < 3) {
         BF_TRY(bf_image_manager_get_integrate_frame_gpu(p->im, frame, &c.data.d_depthData, &c.data.d_colorData));   // resolved on the calling thread
         BF_TRY(bf_image_manager_get_integrate_frame_texels(p->im, frame, &c.texels));
     }
@@ -2082,7 +2082,9 @@ int plReintegrate(bf_pipeline* p) {                                             
         }
         break;
     }
-    if (p->gas.s_garbageCollectionEnabled) BF_TRY(volPost(p, 3, 0, nullptr, nullptr, -1));
+    // the frame boundary closes the volume thread's batch: the garbage collection does, or (collection disabled) a flush command - a batch is one frame's operators
+    // whatever the settings, and nothing stays pending across frames
+    BF_TRY(volPost(p, p->gas.s_garbageCollectionEnabled ? 3 : 4, 0, nullptr, nullptr, -1));
     return BF_OK;
 }
 
@@ -2271,6 +2273,17 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sBundle, hipStreamNonBlocking, greatest));
         // (measured and withdrawn, gpurun r03k: reserving R = 16 .. 96 CUs for the chain by masking the volume stream - the wait for the match result drops
         // 0.80 -> 0.69 ms while the voxel update slows 93.8 -> 126 us; frames/s 656 -> 655 / 648 / 623 / 565)
+        uint32_t reserve = 0;                // BF_VOLUME_CU_RESERVE=R: the volume stream may use all but R compute units (the matching chain then finds idle CUs beside a voxel update)
+        if (const char* e = getenv("BF_VOLUME_CU_RESERVE")) reserve = (uint32_t)std::max(atoi(e), 0);
+        if (reserve) {
+            hipDeviceProp_t prop; int devId = 0;
+            BF_HIP_TRY(hipGetDevice(&devId));
+            BF_HIP_TRY(hipGetDeviceProperties(&prop, devId));
+            const uint32_t ncu = (uint32_t)prop.multiProcessorCount, use = ncu > reserve ? ncu - reserve : 1u;
+            std::vector<uint32_t> mask((ncu + 31u) / 32u, 0u);
+            for (uint32_t i = 0; i < use; ++i) mask[i >> 5] |= 1u << (i & 31u);
+            BF_HIP_TRY(hipExtStreamCreateWithCUMask(&p->sVolume, (uint32_t)mask.size(), mask.data()));
+        } else
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sVolume, hipStreamNonBlocking, least));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sDetect, hipStreamNonBlocking, greatest));
         // The HIP runtime maps streams onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, four by default) by priority class and creation order, and streams

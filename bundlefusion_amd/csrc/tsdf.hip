@@ -1729,7 +1729,9 @@ struct bf_scene {
     // batched operators (bf_scene_run_batch, tsdf_batch.h)
     BatchDev bd{};
     bool batchReady = false;
-    uint2* btexel[NBMAX][BF_SCENE_BATCH_MAX] = {}; size_t btexelPixels = 0;      // the batch's frames as texel images, one set per list buffer
+    uint2* btexel[NBMAX][BF_SCENE_BATCH_MAX] = {}; size_t btexelPixels = 0;      // the batch's frames as texel images, one set per list buffer (the NB in use)
+    // diagnostic BF_DEBUG_VERIFY_BATCH=<file> (tsdf_batch.h k_verify_*): two shadow copies of the voxels, the mismatch log in pinned host memory
+    const char* verifyPath = nullptr; bf_voxel* vshadow[2] = {}; VerifyLog* vlog = nullptr; uint32_t vseq = 0;
     // optional HIP-event timing of the voxel-update kernel
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -2034,6 +2036,25 @@ int ensureBatch(bf_scene* s) {
     return BF_OK;
 }
 
+constexpr uint32_t VERIFY_CAP = 1u << 16;
+int verifyBuffers(bf_scene* s) {
+    if (s->vlog) return BF_OK;
+    for (int q = 0; q < 2; ++q) BF_HIP_TRY(hipMalloc((void**)&s->vshadow[q], (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel)));
+    BF_HIP_TRY(hipHostMalloc((void**)&s->vlog, sizeof(VerifyLog) + (size_t)VERIFY_CAP * sizeof(VerifyRec), hipHostMallocCoherent));
+    memset(s->vlog, 0, sizeof(VerifyLog));
+    s->vlog->cap = VERIFY_CAP;
+    return BF_OK;
+}
+void verifyDump(bf_scene* s) {          // (streams drained by the caller) appends {count, cap, batches, blocks} + the records to the file
+    if (!s->vlog) return;
+    if (FILE* f = fopen(s->verifyPath, "ab")) {
+        const uint32_t n = std::min(s->vlog->count, s->vlog->cap);
+        fwrite(s->vlog, 16, 1, f);
+        fwrite(s->vlog->rec, sizeof(VerifyRec), n, f);
+        fclose(f);
+    }
+}
+
 // A batch of operators in the serial order ops[0], ops[1], ...: one march, one binning, one placement + union list (preparation stream), one voxel update.
 int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
     BF_TRY_RC(ensureBatch(s));
@@ -2044,8 +2065,13 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
     const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
     if (fast && s->btexelPixels < npx) {
         BF_TRY_RC(syncAll(s));
+        s->btexelPixels = 0;                    // (a failed allocation below leaves the sets to be rebuilt by the next call)
         for (int q = 0; q < bf_scene::NBMAX; ++q)
-            for (uint32_t k = 0; k < BMAX; ++k) { if (s->btexel[q][k]) (void)hipFree(s->btexel[q][k]); s->btexel[q][k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->btexel[q][k], npx * sizeof(uint2))); }
+            for (uint32_t k = 0; k < BMAX; ++k) {
+                if (s->btexel[q][k]) (void)hipFree(s->btexel[q][k]);
+                s->btexel[q][k] = nullptr;
+                if (q < s->NB) BF_HIP_TRY(hipMalloc((void**)&s->btexel[q][k], npx * sizeof(uint2)));
+            }
         s->btexelPixels = npx;
     }
     // The march runs on the preparation stream like everything else of the preparation (on the main stream behind the previous batch's update it measured the same
@@ -2118,8 +2144,19 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
             if (ops[k].data.d_colorData) ua.liveMask |= 3u << (2u * k);      // CUDASceneRepHashSDF.cu:441-448: no colour data, no update
         }
         const ApxCam ac = makeApxCam(fl);
-        if (s->cvtRne) hipLaunchKernelGGL((k_update_batch_apx<true>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, ac, ua, acc);
-        else hipLaunchKernelGGL((k_update_batch_apx<false>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, ac, ua, acc);
+        auto update = [&](const Dev& dd, int accumulate) {
+            if (s->cvtRne) hipLaunchKernelGGL((k_update_batch_apx<true>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dd, ac, ua, accumulate);
+            else hipLaunchKernelGGL((k_update_batch_apx<false>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dd, ac, ua, accumulate);
+        };
+        if (s->verifyPath) {
+            BF_TRY_RC(verifyBuffers(s));
+            hipLaunchKernelGGL(k_verify_copy, dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, s->vshadow[0], s->vshadow[1]);
+        }
+        update(dv, acc);
+        if (s->verifyPath) {
+            for (int q = 0; q < 2; ++q) { Dev dq = dv; dq.vox = s->vshadow[q]; update(dq, 0); }
+            hipLaunchKernelGGL(k_verify_compare, dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dv, s->vshadow[0], s->vshadow[1], s->vlog, s->vseq++, n, s->gridUpdateCol * 4u);
+        }
     } else {
         BatchUpdColArgs ua;
         memset(&ua, 0, sizeof ua);
@@ -2206,6 +2243,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     s->gridCompact = std::min<uint32_t>(std::max<uint32_t>(div_up((uint32_t)N, TILE), 1u), 2048u);
     s->gridUpdateCol = s->gridUpdateColPlain = 8192;      // see k_update_col
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
+    if (const char* e = getenv("BF_DEBUG_VERIFY_BATCH")) s->verifyPath = e;
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
@@ -2322,6 +2360,10 @@ int bf_scene_destroy(bf_scene* s) {
     (void)syncAll(s);
     for (void* q : s->allocations) hipFree(q);
     for (uint2* t : s->texel) if (t) hipFree(t);
+    for (auto& set : s->btexel) for (uint2* t : set) if (t) hipFree(t);
+    verifyDump(s);
+    for (bf_voxel* v : s->vshadow) if (v) hipFree(v);
+    if (s->vlog) hipHostFree(s->vlog);
     if (s->d_allocSend) hipFree(s->d_allocSend);
     if (s->d_allocRecv) hipFree(s->d_allocRecv);
     if (s->d_allocSlots) hipFree(s->d_allocSlots);
@@ -2343,7 +2385,7 @@ int bf_scene_set_stream(bf_scene* s, void* hip_stream) {
 int bf_scene_set_overlap(bf_scene* s, int enable) {
     BF_REQUIRE(s, "null scene");
     BF_TRY_RC(syncAll(s));
-    s->overlap = enable != 0;
+    s->overlap = enable != 0 && !getenv("BF_DEBUG_NO_OVERLAP");      // (diagnostic: the preparation on the main stream, nothing of the volume beside its own update)
     for (bool& u : s->updRecorded) u = false;
     s->barrierPending = false;
     return BF_OK;

@@ -506,6 +506,23 @@ __global__ __launch_bounds__(256) void k_batch_place(Dev d, BatchDev bd, BatchCo
 struct alignas(64) BatchUpdOpApx { ApxPose in, de; const uint2* tex; };          // (ApxPose is 64-byte aligned itself)
 struct BatchUpdApxArgs { BatchUpdOpApx op[BMAX]; uint32_t nOps; uint32_t liveMask; };      // liveMask: membership bits of the operators that update voxels (an operator without colour data does not)
 
+#ifdef BF_VAR_VLOAD
+struct KargMirrorApx { Dev d; ApxCam c; BatchUpdApxArgs a; int accumulate; };
+BF_DEV BatchUpdOpApx loadOpVector(uint32_t k) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KargMirrorApx, a) + (uint64_t)k * sizeof(BatchUpdOpApx);
+    const volatile v4u* src = reinterpret_cast<const volatile v4u*>(ka);
+    union { BatchUpdOpApx o; uint32_t w[sizeof(BatchUpdOpApx) / 4]; } u;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(BatchUpdOpApx) / 16; ++i) {
+        const v4u v = src[i];
+        u.w[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x); u.w[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+        u.w[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z); u.w[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+    }
+    return u.o;
+}
+#endif
+
 template <bool RNE>
 __global__ __launch_bounds__(256) void k_update_batch_apx(Dev d, ApxCam c, BatchUpdApxArgs a, int accumulate) {
     const uint32_t n = (uint32_t)d.compactCount[0];
@@ -529,7 +546,11 @@ __global__ __launch_bounds__(256) void k_update_batch_apx(Dev d, ApxCam c, Batch
         for (uint32_t k = 0; k < a.nOps; ++k) {
             const uint32_t m = (mask >> (2u * k)) & 3u;                   // wave-uniform: bit 0 the block lies in the frustum of operator k's integration pose, bit 1 of its de-integration pose
             if (m == 0u) continue;
+#ifdef BF_VAR_VLOAD          // diagnostic variant: the operator's record through vector loads of the kernel-argument segment + readfirstlane (no scalar load at a run-time index)
+            const BatchUpdOpApx o = loadOpVector(k);
+#else
             const BatchUpdOpApx& o = a.op[k];
+#endif
             const __amdgpu_buffer_rsrc_t texRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(o.tex), 0, (int)(2u * c.bytes), 0x00020000);
             const ApxBlock cur = apxBlock<true, true>(d, c, o.in, o.de, e, m, lane);
 #pragma unroll
@@ -546,6 +567,54 @@ __global__ __launch_bounds__(256) void k_update_batch_apx(Dev d, ApxCam c, Batch
             uint32_t* vpA = base + (size_t)(2 * p) * 64u * 3u; uint32_t* vpB = vpA + 64u * 3u;
             if (__builtin_amdgcn_ballot_w64((dirty >> (2 * p)) & 1u) != 0ull) { vpA[0] = __float_as_uint(vS[p].x); vpA[1] = __float_as_uint(vW[p].x); vpA[2] = vCA[p]; }
             if (__builtin_amdgcn_ballot_w64((dirty >> (2 * p + 1)) & 1u) != 0ull) { vpB[0] = __float_as_uint(vS[p].y); vpB[1] = __float_as_uint(vW[p].y); vpB[2] = vCB[p]; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Diagnostic (BF_DEBUG_VERIFY_BATCH=<file>): every fast-contract batch update runs three times - on the volume and on two shadow copies of the union list's
+// blocks taken just before - and the three results are compared voxel by voxel.  The update is a pure function of (block, operators, texel images): any
+// difference is an execution error of one of the three launches, recorded with the two other values (the majority is the truth).  The frame loop keeps its
+// structure (the other streams keep running beside the three launches), so a 2000-frame stream is ~2000 trials of the real kernel under its real neighbours.
+// ---------------------------------------------------------------------------------------
+struct VerifyRec { uint32_t seq, blk, vox, which; int32_t ex, ey, ez; uint32_t mask; uint32_t val[3][3]; uint32_t nOps, hwWave, pad[5]; };      // 96 bytes
+static_assert(sizeof(VerifyRec) == 96, "record layout (tools/verify_stream.py)");
+struct VerifyLog { uint32_t count, cap, batches, blocks; VerifyRec rec[1]; };
+
+__global__ __launch_bounds__(256) void k_verify_copy(Dev d, bf_voxel* s0, bf_voxel* s1) {
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6), nWaves = gridDim.x * 4u;
+    for (uint32_t blk = wave; blk < n; blk += nWaves) {
+        const uint32_t ptr = (uint32_t)reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2].w;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(d.vox + ptr);
+        uint32_t* a = reinterpret_cast<uint32_t*>(s0 + ptr); uint32_t* b = reinterpret_cast<uint32_t*>(s1 + ptr);
+        for (uint32_t i = lane; i < VOX * 3u; i += 64u) { const uint32_t v = src[i]; a[i] = v; b[i] = v; }
+    }
+}
+__global__ __launch_bounds__(256) void k_verify_compare(Dev d, const bf_voxel* s0, const bf_voxel* s1, VerifyLog* log, uint32_t seq, uint32_t nOps, uint32_t nWavesUpd) {
+    const uint32_t n = (uint32_t)d.compactCount[0];
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6), nWaves = gridDim.x * 4u;
+    if (wave == 0 && lane == 0) { atomicAdd(&log->batches, 1u); atomicAdd(&log->blocks, n); }
+    for (uint32_t blk = wave; blk < n; blk += nWaves) {
+        const int4 e = reinterpret_cast<const int4*>(d.compact)[(size_t)blk * 2];
+        const uint32_t mask = reinterpret_cast<const uint32_t*>(d.compact)[(size_t)blk * 8 + 4];
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(d.vox + (uint32_t)e.w);
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(s0 + (uint32_t)e.w); const uint32_t* b = reinterpret_cast<const uint32_t*>(s1 + (uint32_t)e.w);
+        for (uint32_t v = lane; v < VOX; v += 64u) {
+            uint32_t x[3][3];
+            for (int q = 0; q < 3; ++q) { x[0][q] = r[v * 3 + q]; x[1][q] = a[v * 3 + q]; x[2][q] = b[v * 3 + q]; }
+            const bool d01 = x[0][0] != x[1][0] || x[0][1] != x[1][1] || x[0][2] != x[1][2];
+            const bool d02 = x[0][0] != x[2][0] || x[0][1] != x[2][1] || x[0][2] != x[2][2];
+            const bool d12 = x[1][0] != x[2][0] || x[1][1] != x[2][1] || x[1][2] != x[2][2];
+            if (d01 || d02 || d12) {
+                const uint32_t pos = atomicAdd(&log->count, 1u);
+                if (pos < log->cap) {
+                    VerifyRec& o = log->rec[pos];
+                    o.seq = seq; o.blk = blk; o.vox = v; o.which = (d01 ? 1u : 0u) | (d02 ? 2u : 0u) | (d12 ? 4u : 0u);
+                    o.ex = e.x; o.ey = e.y; o.ez = e.z; o.mask = mask; o.nOps = nOps; o.hwWave = blk % nWavesUpd;
+                    for (int c = 0; c < 3; ++c) for (int q = 0; q < 3; ++q) o.val[c][q] = x[c][q];
+                }
+            }
         }
     }
 }
