@@ -1349,12 +1349,40 @@ BF_DEV ApxCol apxCol(const ApxPose& p, float ix, float iy, float xw, float yw) {
 
 struct ApxSample { v2f pcz; uint32_t offA, offB; bool inA, inB; };
 
+#ifdef BF_VAR_SCALAR_PROJECT          // diagnostic variant (tools/build_variant.py): the projection as scalar instructions - the second voxel's operations depend (through an
+BF_DEV float afterF(float v, float dep) { asm volatile("" : "+v"(v) : "v"(dep)); return v; }      // empty asm) on the first voxel's results, so the compiler cannot pair them into v_pk_*_f32
+#endif
 BF_DEV ApxSample apxProject(const ApxCam& c, const ApxPose& p, const ApxCol& col, v2f iz, v2f pz, bool use) {
     ApxSample o;
+#ifdef BF_VAR_SCALAR_PROJECT          // bit 0 the depth, 1 the numerators, 2 the image coordinates (7: the whole projection)
+    v2f nx, ny, r, hx, hy;
+    if (BF_VAR_SCALAR_PROJECT & 1) { o.pcz.x = (col.zc + p.r8 * pz.x) + p.t2; o.pcz.y = (col.zc + p.r8 * afterF(pz.y, o.pcz.x)) + p.t2; }
+    else o.pcz = (sp2(col.zc) + sp2(p.r8) * pz) + sp2(p.t2);
+    if (BF_VAR_SCALAR_PROJECT & 2) {
+        nx.x = __builtin_fmaf(p.cx, iz.x, col.nx0); ny.x = __builtin_fmaf(p.cy, iz.x, col.ny0);
+        const float izy = afterF(iz.y, nx.x + ny.x);
+        nx.y = __builtin_fmaf(p.cx, izy, col.nx0); ny.y = __builtin_fmaf(p.cy, izy, col.ny0);
+    } else { nx = pkfma(sp2(p.cx), iz, sp2(col.nx0)); ny = pkfma(sp2(p.cy), iz, sp2(col.ny0)); }
+    r.x = __builtin_amdgcn_rcpf(o.pcz.x); r.y = __builtin_amdgcn_rcpf(o.pcz.y);
+    if (BF_VAR_SCALAR_PROJECT & 4) {
+        hx.x = __builtin_fmaf(nx.x, r.x, c.mxh); hy.x = __builtin_fmaf(ny.x, r.x, c.myh);
+        const float ry = afterF(r.y, hx.x + hy.x);
+        hx.y = __builtin_fmaf(nx.y, ry, c.mxh); hy.y = __builtin_fmaf(ny.y, ry, c.myh);
+    } else { hx = pkfma(nx, r, sp2(c.mxh)); hy = pkfma(ny, r, sp2(c.myh)); }
+#else
+#ifndef BF_VAR_PAD          // diagnostic variants: idle issue slots (s_nop 4, pinned by scheduling barriers) at one place of the projection - bit 0 in front of it, 1 depth -> reciprocal,
+#define BF_VAR_PAD 0        // 2 reciprocal -> image coordinates, 3 image coordinates -> conversion
+#endif
+#define BF_PAD_AT(bit) do { if (BF_VAR_PAD & (1 << (bit))) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 4"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    BF_PAD_AT(0);
     o.pcz = (sp2(col.zc) + sp2(p.r8) * pz) + sp2(p.t2);
     const v2f nx = pkfma(sp2(p.cx), iz, sp2(col.nx0)), ny = pkfma(sp2(p.cy), iz, sp2(col.ny0));
+    BF_PAD_AT(1);
     v2f r; r.x = __builtin_amdgcn_rcpf(o.pcz.x); r.y = __builtin_amdgcn_rcpf(o.pcz.y);
+    BF_PAD_AT(2);
     const v2f hx = pkfma(nx, r, sp2(c.mxh)), hy = pkfma(ny, r, sp2(c.myh));
+    BF_PAD_AT(3);
+#endif
     const uint32_t pxA = (uint32_t)f2iHw(hx.x), pyA = (uint32_t)f2iHw(hy.x), pxB = (uint32_t)f2iHw(hx.y), pyB = (uint32_t)f2iHw(hy.y);
     o.inA = use && pxA < c.W && pyA < c.H; o.inB = use && pxB < c.W && pyB < c.H;
     o.offA = o.inA ? (__umul24(pyA, c.W) + pxA) << 2 : 0xFFFFFFFFu;      // beyond the descriptor's range: the load returns 0

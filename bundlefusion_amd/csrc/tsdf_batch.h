@@ -554,7 +554,12 @@ __global__ __launch_bounds__(256) void k_update_batch_apx(Dev d, ApxCam c, Batch
             const __amdgpu_buffer_rsrc_t texRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(o.tex), 0, (int)(2u * c.bytes), 0x00020000);
             const ApxBlock cur = apxBlock<true, true>(d, c, o.in, o.de, e, m, lane);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int pp = 0; pp < 4; ++pp) {
+#ifdef BF_VAR_REVERSE_PAIRS          // diagnostic variant: the pair behind the operator's set-up is the block's LAST one (does the error follow the position in the instruction stream?)
+                const int p = 3 - pp;
+#else
+                const int p = pp;
+#endif
                 ApxPair pa;
                 apxSamples<true, true>(c, o.in, o.de, cur, 2 * p, texRes, pa);
                 bool stA, stB;

@@ -19,11 +19,21 @@ from bundlefusion_amd.capi import default_app_state, default_bundling_state, int
 
 def main():
     pat = sys.argv[1] if len(sys.argv) > 1 else "none"
-    W, H, n = 640, 480, 33
-    frames = synth.render_frames(range(n))
-    Kd = frames[0][3]
+    W, H, n = 640, 480, int(os.environ.get("FIRST_RUN_FRAMES", "33"))
+    cache = os.environ.get("FIRST_RUN_CACHE")          # rendered frames kept between processes (tools/determinism_processes.py)
+    cache = "%s_%d.npz" % (cache, n) if cache else None
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        depth, color = z["depth"], z["color"]
+    else:
+        fr = synth.render_frames(range(n))
+        depth = np.stack([f[0] for f in fr]); color = np.stack([f[1] for f in fr])
+        if cache:
+            np.savez(cache + ".tmp.npz", depth=depth, color=color)
+            os.replace(cache + ".tmp.npz", cache)
+    Kd = synth.intrinsics(W, H)
     K = intrinsics_matrix(Kd["fx"], Kd["fy"], Kd["mx"], Kd["my"])
-    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda()) for f in frames]
+    dev = [(torch.from_numpy(depth[i]).cuda(), torch.from_numpy(color[i]).cuda()) for i in range(n)]
     if pat != "none":
         v = int(pat, 16)
         fill = [torch.full((1 << 28,), v - (1 << 32) if v >= (1 << 31) else v, dtype=torch.int32, device="cuda") for _ in range(int(os.environ.get("POISON_GB", "24")))]      # 1 GiB each
@@ -33,7 +43,7 @@ def main():
     gas = default_app_state(); gbs = default_bundling_state()
     gas.s_integrationWidth, gas.s_integrationHeight = W, H
     gas.s_SDFVoxelSize, gas.s_hashNumBuckets, gas.s_hashNumSDFBlocks = 0.004, 1000000, 250000
-    gbs.s_maxNumImages = 8
+    gbs.s_maxNumImages = max(n // 10 + 5, 8)
     p = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
     for d, c in dev:
         assert p.process_frame(d, c)

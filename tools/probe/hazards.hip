@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); exit(2); } } while (0)
@@ -91,6 +92,103 @@ __global__ __launch_bounds__(256) void k_pk(const float* __restrict__ in, float 
     if (lane == 0) atomicAdd(&out->waves, 1u);
 }
 
+// ------------------------------------------------------------------------------------------------ window
+// The first voxel pair's projection of k_update_batch_apx as the packed-FP32 build has it (tools/probe/window_gen.h: the compiler's instructions and register
+// numbers), run in three paddings on the same inputs; outputs: the two texel offsets (v56, v53) and the two camera-space depths (v64, v65).
+#include "window_gen.h"
+struct WinOut { uint32_t bad[2][4][4]; uint32_t waves; uint32_t first[7]; };      // [RAW | PADPK vs PADALL][output][lane quarter]
+#define WIN_SETUP \
+    "v_mov_b32 v44, %4\n\tv_mov_b32 v45, %4\n\tv_mov_b32 v32, %5\n\tv_mov_b32 v33, %5\n\tv_mov_b32 v24, %6\n\tv_add_f32 v25, 1.0, %6\n\t" \
+    "v_mul_f32 v34, 0x3b83126f, %4\n\tv_mul_f32 v35, 0x3b83126f, %5\n\tv_mul_f32 v36, 0x3b83126f, v24\n\tv_mul_f32 v37, 0x3b83126f, v25\n\t" \
+    "s_mov_b32 s40, 0xbd23d70a\n\ts_mov_b32 s41, 0x3ca3d70a\n\ts_mov_b32 s42, 0x3f7fbe77\n\ts_mov_b32 s43, 0x3f000000\n\t" \
+    "s_mov_b32 s4, 0x40151eb8\n\ts_mov_b32 s5, 0x3c23d70a\n\ts_mov_b32 s6, 0x3dcccccd\n\ts_mov_b32 s7, 0x42693333\n\t" \
+    "s_mov_b32 s8, 0x3c23d70a\n\ts_mov_b32 s9, 0x40151eb8\n\ts_mov_b32 s10, 0x3d4ccccd\n\ts_mov_b32 s11, 0xc2e93333\n\t" \
+    "s_mov_b32 s56, 0x43a00000\n\ts_mov_b32 s57, 0x43a00000\n\ts_mov_b32 s24, 0x43700000\n\ts_mov_b32 s25, 0x43700000\n\t" \
+    "s_mov_b32 s31, 640\n\ts_mov_b32 s20, 480\n\ts_mov_b32 s21, 640\n\t" \
+    "v_mov_b32 v52, %7\n\tv_mov_b32 v53, %7\n\tv_mov_b32 v54, %7\n\tv_mov_b32 v55, %7\n\tv_mov_b32 v56, %7\n\tv_mov_b32 v57, %7\n\tv_mov_b32 v58, %7\n\tv_mov_b32 v59, %7\n\t" \
+    "v_mov_b32 v60, %7\n\tv_mov_b32 v61, %7\n\tv_mov_b32 v64, %7\n\tv_mov_b32 v65, %7\n\t" \
+    "s_mov_b32 s2, 3\n\ts_cmp_lg_u32 s2, 1\n\ts_nop 4\n\t"
+#define WIN_RUN(WINDOW, o0, o1, o2, o3) \
+    asm volatile(WIN_SETUP WINDOW "s_nop 4\n\tv_mov_b32 %0, v56\n\tv_mov_b32 %1, v53\n\tv_mov_b32 %2, v64\n\tv_mov_b32 %3, v65\n\ts_nop 1" \
+                 : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(ix), "v"(iy), "v"(iz), "v"(junk) \
+                 : "v24", "v25", "v32", "v33", "v34", "v35", "v36", "v37", "v44", "v45", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v64", "v65", \
+                   "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s20", "s21", "s24", "s25", "s31", "s40", "s41", "s42", "s43", "s56", "s57", "vcc", "scc")
+__global__ __launch_bounds__(256) void k_window(int iters, WinOut* out, uint32_t salt) {
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t bad[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    float junk = 1.0f + (float)lane;
+    for (int it = 0; it < iters; ++it) {
+        const float ix = (float)(8 * ((int)((wave * 7u + (uint32_t)it * 3u + salt) % 60u) - 30) + (int)(lane & 7u));
+        const float iy = (float)(8 * ((int)((wave * 5u + (uint32_t)it * 11u + salt) % 40u) - 20) + (int)(lane >> 3));
+        const float iz = (float)(8 * (50 + (it % 10)));
+        uint32_t r[4], k[4], a[4];
+        WIN_RUN(WINDOW_RAW, r[0], r[1], r[2], r[3]);
+        WIN_RUN(WINDOW_PADPK, k[0], k[1], k[2], k[3]);
+        WIN_RUN(WINDOW_PADALL, a[0], a[1], a[2], a[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (r[q] != a[q]) { bad[0][q]++; if (atomicAdd(&out->first[0], 1u) == 0u) { out->first[1] = (uint32_t)q; out->first[2] = lane; out->first[3] = r[q]; out->first[4] = a[q]; out->first[5] = (uint32_t)it; out->first[6] = wave; } }
+            if (k[q] != a[q]) bad[1][q]++;
+        }
+        junk = __uint_as_float((a[2] & 0x007FFFFFu) | 0x3F800000u) + (float)it;
+    }
+    for (int v = 0; v < 2; ++v) for (int q = 0; q < 4; ++q) if (bad[v][q]) atomicAdd(&out->bad[v][q][lane >> 4], bad[v][q]);
+    if (lane == 0) atomicAdd(&out->waves, 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ opsel
+// What the in-situ bisection (profiles/r06_determinism.md) left: v_pk_fma_f32 with broadcast modifiers (op_sel / op_sel_hi) on a scalar-register first source and
+// on the vector addend - the forms the compiler emits for the FIRST voxel pair of an operator slot, before it has materialised the broadcast pairs.  Each wave
+// alternates the four forms below (registers as in the kernel) with the voxel update's memory phase (eight 12-byte-per-lane loads, six stores, four 8-byte
+// gathers), so that co-resident waves issue vector-memory instructions beside the packed FMAs.  Every result half is checked against v_fma_f32.
+struct OsOut { uint32_t bad[4][2][4]; uint32_t waves; uint32_t first[6]; uint32_t pad; };      // [form][half][lane quarter]
+__global__ __launch_bounds__(256) void k_opsel(int iters, float* __restrict__ vox, const uint2* __restrict__ tex, uint32_t texN, OsOut* out, uint32_t salt, int memPhase) {
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    float* base = vox + (size_t)wave * 1536u + lane * 3u;
+    uint32_t bad[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    float carry = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+        const float iz0 = (float)(8 * (50 + ((it + (int)salt) % 10))), iz1 = iz0 + 1.0f;
+        const float n0 = 2.33f * (float)((int)(lane & 7u) - 3 + (int)(wave % 50u)) + 58.3f + carry * 0.0f, n1 = 2.33f * (float)((int)(lane >> 3) - 3 + (int)(wave % 37u)) - 116.6f;
+        const float cx = 0.1f + 0.001f * (float)(it & 7), cy = 0.05f + 0.001f * (float)(it & 3);
+        float r[4][2];
+        v2f sx; sx.x = cx; sx.y = 123.0f; v2f sy; sy.x = cy; sy.y = -77.0f;
+        asm volatile("v_mov_b32 v24, %8\n\tv_mov_b32 v25, %9\n\tv_mov_b32 v54, %10\n\tv_mov_b32 v55, %11\n\t"
+                     "v_readfirstlane_b32 s6, %12\n\ts_mov_b32 s7, 0x42f60000\n\tv_readfirstlane_b32 s10, %13\n\ts_mov_b32 s11, 0xc29a0000\n\ts_nop 4\n\t"
+                     "v_mov_b32 v62, s6\n\tv_mov_b32 v63, s6\n\tv_mov_b32 v66, v54\n\tv_mov_b32 v67, v54\n\t"
+                     "v_mov_b32 v58, -1.0\n\tv_mov_b32 v59, -1.0\n\tv_mov_b32 v60, -1.0\n\tv_mov_b32 v61, -1.0\n\tv_mov_b32 v68, -1.0\n\tv_mov_b32 v69, -1.0\n\tv_mov_b32 v70, -1.0\n\tv_mov_b32 v71, -1.0\n\t"
+                     "v_pk_fma_f32 v[58:59], s[6:7], v[24:25], v[54:55] op_sel_hi:[0,1,0]\n\t"
+                     "v_pk_fma_f32 v[60:61], s[10:11], v[24:25], v[54:55] op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[68:69], v[62:63], v[24:25], v[54:55] op_sel_hi:[0,1,0]\n\t"
+                     "v_pk_fma_f32 v[70:71], v[62:63], v[24:25], v[66:67]\n\t"
+                     "s_nop 4\n\t"
+                     "v_mov_b32 %0, v58\n\tv_mov_b32 %1, v59\n\tv_mov_b32 %2, v60\n\tv_mov_b32 %3, v61\n\tv_mov_b32 %4, v68\n\tv_mov_b32 %5, v69\n\tv_mov_b32 %6, v70\n\tv_mov_b32 %7, v71\n\ts_nop 1"
+                     : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1])
+                     : "v"(iz0), "v"(iz1), "v"(n0), "v"(n1), "v"(cx), "v"(cy)
+                     : "v24", "v25", "v54", "v55", "v58", "v59", "v60", "v61", "v62", "v63", "v66", "v67", "v68", "v69", "v70", "v71", "s6", "s7", "s10", "s11");
+        const float e[4][2] = {{__builtin_fmaf(cx, iz0, n0), __builtin_fmaf(cx, iz1, n0)}, {__builtin_fmaf(cy, iz0, n1), __builtin_fmaf(cy, iz1, n1)},
+                               {__builtin_fmaf(cx, iz0, n0), __builtin_fmaf(cx, iz1, n0)}, {__builtin_fmaf(cx, iz0, n0), __builtin_fmaf(cx, iz1, n0)}};
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (r[f][h] != e[f][h]) { bad[f][h]++; if (atomicAdd(&out->first[0], 1u) == 0u) { out->first[1] = (uint32_t)(f * 2 + h); out->first[2] = lane; out->first[3] = __float_as_uint(r[f][h]); out->first[4] = __float_as_uint(e[f][h]); out->first[5] = wave; } }
+        if (memPhase) {          // the voxel update's memory phase on this wave's own 6 KB
+            float v[8][3];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) { v[z][0] = base[z * 192 + 0]; v[z][1] = base[z * 192 + 1]; v[z][2] = base[z * 192 + 2]; }
+            uint2 t[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t[g] = tex[(wave * 977u + lane * 131u + (uint32_t)it * 7919u + (uint32_t)g * 40503u) % texN];
+#pragma unroll
+            for (int z = 0; z < 6; ++z) { base[z * 192 + 0] = v[z][0] + __uint_as_float(t[z & 3].x) * 0.0f; base[z * 192 + 1] = v[z][1] + 1.0f; base[z * 192 + 2] = v[z][2]; }
+            carry = v[7][0];
+        }
+    }
+    for (int f = 0; f < 4; ++f) for (int h = 0; h < 2; ++h) if (bad[f][h]) atomicAdd(&out->bad[f][h][lane >> 4], bad[f][h]);
+    if (lane == 0) atomicAdd(&out->waves, 1u);
+}
+
 // ------------------------------------------------------------------------------------------------ sload
 template <int WORDS> struct RecT { float f[WORDS]; };
 template <int WORDS> struct ArgsT { RecT<WORDS> op[12]; uint32_t salt; };
@@ -151,13 +249,52 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 8.0;
+    const bool onlyWindow = argc > 2 && std::string(argv[2]) == "window";
     Noise nz; nz.init();
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     std::vector<float> h(1 << 20); for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0f + (float)((i * 2654435761u) & 0xFFFF) * (1.0f / 4096.0f);
     float* din; CK(hipMalloc(&din, h.size() * 4)); CK(hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    void* dout; CK(hipMalloc(&dout, 256));
+    void* dout; CK(hipMalloc(&dout, 256));          // (every test's counters fit 256 bytes)
     printf("{");
     for (int noise = 0; noise < 2; ++noise) {
+        // ---- window
+        {
+            CK(hipMemset(dout, 0, 256));
+            const double t0 = now(); uint32_t salt = 0;
+            while (now() - t0 < secs) {
+                if (noise) nz.kick();
+                for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_window, dim3(8192), dim3(256), 0, st, 32, (WinOut*)dout, salt++);
+                CK(hipStreamSynchronize(st)); if (noise) nz.drain();
+            }
+            WinOut o; CK(hipMemcpy(&o, dout, sizeof o, hipMemcpyDeviceToHost));
+            printf("\"window_%s\": {\"waves\": %u, \"windows_per_wave\": 32, ", noise ? "noise" : "alone", o.waves);
+            static const char* on[4] = {"offsetA_v56", "offsetB_v53", "depthA_v64", "depthB_v65"};
+            for (int v = 0; v < 2; ++v) for (int q = 0; q < 4; ++q) printf("\"%s_%s_bad_by_lane_quarter\": [%u,%u,%u,%u], ", v ? "padpk" : "raw", on[q], o.bad[v][q][0], o.bad[v][q][1], o.bad[v][q][2], o.bad[v][q][3]);
+            printf("\"first_bad\": {\"count\": %u, \"output\": %u, \"lane\": %u, \"raw\": \"%08x\", \"padded\": \"%08x\", \"iteration\": %u, \"wave\": %u}}, ", o.first[0], o.first[1], o.first[2], o.first[3], o.first[4], o.first[5], o.first[6]);
+            fflush(stdout);
+        }
+        // ---- opsel
+        {
+            float* vox; uint2* tex; const uint32_t texN = 640 * 480 * 12;
+            CK(hipMalloc(&vox, (size_t)8192 * 4 * 1536 * 4)); CK(hipMemset(vox, 0, (size_t)8192 * 4 * 1536 * 4)); CK(hipMalloc(&tex, (size_t)texN * 8)); CK(hipMemset(tex, 0, (size_t)texN * 8));
+            for (int mem = 0; mem < 2; ++mem) {
+                void* d2; CK(hipMalloc(&d2, 512)); CK(hipMemset(d2, 0, 512));
+                const double t0 = now(); uint32_t salt = 0;
+                while (now() - t0 < secs) {
+                    if (noise) nz.kick();
+                    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_opsel, dim3(8192), dim3(256), 0, st, 64, vox, tex, texN, (OsOut*)d2, salt++, mem);
+                    CK(hipStreamSynchronize(st)); if (noise) nz.drain();
+                }
+                OsOut o; CK(hipMemcpy(&o, d2, sizeof o, hipMemcpyDeviceToHost)); CK(hipFree(d2));
+                printf("\"opsel_%s_%s\": {\"waves\": %u, \"sequences_per_wave\": 64, ", mem ? "with_memory_phase" : "arithmetic_only", noise ? "noise" : "alone", o.waves);
+                static const char* fn[4] = {"sgpr_src0_bcast_vgpr_src2_bcast_lo", "sgpr_src0_bcast_vgpr_src2_bcast_hi", "vgpr_src0_pair_src2_bcast_lo", "no_modifiers"};
+                for (int f = 0; f < 4; ++f) printf("\"%s\": {\"lo_bad_by_lane_quarter\": [%u,%u,%u,%u], \"hi_bad_by_lane_quarter\": [%u,%u,%u,%u]}, ", fn[f], o.bad[f][0][0], o.bad[f][0][1], o.bad[f][0][2], o.bad[f][0][3], o.bad[f][1][0], o.bad[f][1][1], o.bad[f][1][2], o.bad[f][1][3]);
+                printf("\"first_bad\": {\"count\": %u, \"form_half\": %u, \"lane\": %u, \"got\": \"%08x\", \"expected\": \"%08x\", \"wave\": %u}}, ", o.first[0], o.first[1], o.first[2], o.first[3], o.first[4], o.first[5]);
+                fflush(stdout);
+            }
+            CK(hipFree(vox)); CK(hipFree(tex));
+        }
+        if (onlyWindow) { if (noise) printf("\"only\": \"window\""); continue; }
         // ---- pk
         for (int pad = 0; pad < 2; ++pad) {
             CK(hipMemset(dout, 0, 256));
