@@ -35,7 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s HBM3E
-PMC_FILE = "r05_pmc_tsdf_update.json"
+PMC_FILE = "r06_pmc_tsdf_update.json"
+CLOCK_HZ = 2.4e9             # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs; a full-rate wave64 vector instruction issues in 2 cycles (SIMD-32)
+SIMDS = 1024
 
 
 def main():
@@ -60,18 +62,19 @@ def main():
                          "(-use_fast_math), 'exact' = IEEE op by op, bit-identical with the oracle")
     ap.add_argument("--both-contracts", action="store_true", default=True, help="(1 GPU) also measure the other contract, reported as other_contract")
     ap.add_argument("--one-contract", dest="both_contracts", action="store_false")
-    ap.add_argument("--solve-lag", type=int, default=int(os.environ.get("BF_BENCH_SOLVE_LAG", "0")),
-                    help="0: the reference's serial order (chunk solves inside the frame that closes the chunk).  L in 2..10 (at least the frame loop's depth): the chunk solves run on their own "
+    ap.add_argument("--solve-lag", type=int, default=int(os.environ.get("BF_BENCH_SOLVE_LAG", "-1")),
+                    help="-1: the library's default schedule (since round 6: L = 10).  L in 2..10 (at least the frame loop's depth): the chunk solves run on their own "
                          "thread and stream and are applied exactly L frames later (bf_pipeline_set_solve_lag) - the reference's optimiser thread "
-                         "(FriedLiver.cpp:112-143) with a defined hand-over; same solves, same count, nothing skipped")
+                         "(FriedLiver.cpp:112-143) with a defined hand-over; same solves, same count, nothing skipped.  0: the serial order of the reference's "
+                         "single-threaded branch (chunk solves inside the frame that closes the chunk), reported as `serial_order` beside the default")
     ap.add_argument("--volume-batching", choices=["on", "off"], default="on", help="on (library default): the frame loop issues a frame's TSDF operators - the integration of the previous "
                     "frame and this frame's up to s_maxFrameFixes re-integrations - as ONE bf_scene_run_batch (one march, one placement, one pass over the touched blocks); "
                     "off: one operator at a time (the rounds 1-4 path), for comparison.  Same volume either way (tests/test_tsdf_batch_gpu.py)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary block `sweep` (BASELINE configs[4] in small: the 1280x960 @2 mm re-integration sweep, the "
                     "workload north_star's >= 6x scaling target is quoted on; ~20 s, most of it rendering 24 frames on the host)")
-    ap.add_argument("--long-stream", type=int, default=2000, help="also run a stream of this many frames from frame 0 through a fresh pipeline and report it as `long_stream` "
-                    "(2000, the default: BASELINE configs[2], the stride-1 loop-closure stream, the one tests/golden/oracle_stream_2000.npz holds the oracle's results for; "
-                    "5000: configs[3], 2.5 loops + vertical sinusoid; 0: skip).  Rendering takes ~1 s of host time per 16 frames (2000 frames: ~2 minutes, untimed)")
+    ap.add_argument("--long-stream", type=int, default=5000, help="also run a stream of this many frames from frame 0 through a fresh pipeline and report it as `long_stream` "
+                    "(5000, the default: north_star's target stream - BASELINE configs[3] on one GPU, 2.5 loops + vertical sinusoid; 2000: configs[2], the stride-1 loop-closure "
+                    "stream, the one tests/golden/oracle_stream_2000.npz holds the oracle's results for; 0: skip).  Rendering takes ~1 s of host time per 16 frames (5000 frames: ~5 minutes, untimed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the stream the CPU baseline processes (three local chunks: the last ten frames "
                     "run with the re-integration queue saturated, like the timed window of the GPU leg)")
@@ -208,7 +211,7 @@ def main():
         pipe.scene().set_arith(arith)
         pipe.set_volume_batching(args.volume_batching == "on")
         solve_lag = args.solve_lag if solve_lag is None else solve_lag
-        if solve_lag and not chunked:
+        if solve_lag >= 0 and not chunked:
             pipe.set_solve_lag(solve_lag)
         if shard_volume and world > 1:
             pipe.set_volume_shard(rank, world)
@@ -255,7 +258,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        L = {"arith": arith, "c0": c0, "c1": pipe.counters(), "hp": pipe.host_profile(), "vp": pipe.volume_thread_profile()}
+        L = {"arith": arith, "c0": c0, "c1": pipe.counters(), "hp": pipe.host_profile(), "vp": pipe.volume_thread_profile(), "solve_lag": 0 if chunked else pipe.solve_lag()}
         L["occ_sum"], L["vis_plain"], L["vis_fused"], L["n_ops"] = sc.kernel_timing_blocks()
         L["n_images"] = sc.kernel_timing_images()
         L["n_launch"], L["kernel_ms"] = sc.kernel_timing_read()
@@ -297,6 +300,14 @@ def main():
         achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         achieved_op = bytes_per_operator_sum / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         traffic = pmc_traffic(args, L["arith"], L["vis_plain"], L["vis_fused"], n_launch)
+        # the batched fast update applies ~11 operators to a block per trip through HBM: ~900 vector instructions per block and operator slot against 12 KB of
+        # traffic - it is bound by vector-instruction issue, not by bytes.  Instruction roofline: wave-instructions issued (SQ_INSTS_VALU of the
+        # committed SQ pass, per visited block) x 2 issue cycles / (launch time x clock x SIMDs); transcendentals (v_rcp_f32, 32 of ~900 per slot) issue at a
+        # quarter of that rate, so this is a lower bound of the issue share.
+        valu_insts = pmc_valu(args, L["arith"], L["vis_fused"], n_launch) if batched else None
+        simd_cycles = avg_kernel_s * CLOCK_HZ * SIMDS
+        valu = None if not valu_insts else {"wave_instructions_per_launch": valu_insts, "issue_cycles_per_full_rate_instruction": 2, "simd_cycles_available_per_launch": simd_cycles,
+                                           "frac": 2.0 * valu_insts / simd_cycles if simd_cycles > 0 else None, "unit": "share of vector issue cycles (lower bound: quarter-rate instructions counted at full rate)"}
         if batched:
             kern = ("k_update_batch_apx (tsdf_batch.h): one wave per block of the batch's union list, voxels loaded once, the batch's operators applied in order from registers"
                     if L["arith"] == "fast" else "k_update_batch_col (tsdf_batch.h): the batch's operators one after the other per block, exact contract")
@@ -305,8 +316,10 @@ def main():
                    "k_update_col<2> (fused de-integrate + integrate) + k_update_col<0> (integrate)"
         return {
             "kernel": kern + " - TSDF voxel update, tsdf.hip",
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # `bound`: what limits the kernel.  achieved / peak / frac stay the HBM figures of the contract (algorithmic bytes over launch time against 8 TB/s); for
+            # the VALU-bound batched update they say how far the kernel is from the byte roofline it no longer touches, `valu` how close to the one it does.
+            "bound": "valu" if (batched and L["arith"] == "fast") else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
             "achieved_per_operator": achieved_op, "frac_per_operator": achieved_op / HBM_PEAK_GBS,
             "hbm_frac_measured": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_kernel_s > 0) else None,
             "launches": n_launch, "operators": n_ops, "frames_sampled": n_img, "avg_launch_us": 1e6 * avg_kernel_s,
@@ -325,11 +338,10 @@ def main():
     other = None
     if args.both_contracts and world == 1 and not args.pmc_out:
         other = run_leg("exact" if args.arith == "fast" else "fast")
-    lagged = None
-    if args.both_contracts and world == 1 and not args.pmc_out and not args.solve_lag and not chunked:
-        # the same window with the chunk solves on their own thread and stream, applied exactly 10 frames (one chunk) later: the schedule of the reference's optimiser
-        # thread made deterministic (tests/test_pipeline_gpu.py holds it to the oracle loop with the same lag).  Reported beside the serial order, never as `value`.
-        lagged = run_leg(args.arith, solve_lag=10)
+    serial = None
+    if args.both_contracts and world == 1 and not args.pmc_out and main_leg["solve_lag"] != 0 and not chunked:
+        # the same window in the serial order of the reference's single-threaded branch (the schedule of rounds 1-5's `value`), beside the default
+        serial = run_leg(args.arith, solve_lag=0)
     if args.pmc_out and rank == 0:
         json.dump({"config": pmc_config(args), "launches": main_leg["n_launch"],
                    "fused_launches": main_leg["n_launch"] if args.volume_batching == "on" else main_leg["n_ops"] - main_leg["n_launch"],      # launches over a union list
@@ -370,9 +382,10 @@ def main():
                                   "us_of_api_calls_per_operator": round(1e6 * main_leg["vp"]["busy_seconds"] / max(main_leg["vp"]["operators"], 1.0), 1)},
                 "frame_loop": "two frames behind the input: the matching chain of frame k+1 is enqueued before frame k's result is read back, detection runs one frame "
                               "further ahead (BF_PIPELINE_LOOKAHEAD=%s); chunk solves: %s" % (os.environ.get("BF_PIPELINE_LOOKAHEAD", "1"),
-                              ("own thread + stream, applied exactly %d frames after the chunk's last frame (lagged mode)" % args.solve_lag) if (args.solve_lag and not chunked)
+                              ("own thread + stream, applied exactly %d frames after the chunk's last frame (the reference's optimiser thread, FriedLiver.cpp:112-143, made "
+                               "deterministic; the library's default; parity: test_lagged_solve_mode_vs_oracle_loop_with_the_same_lag)" % main_leg["solve_lag"]) if main_leg["solve_lag"]
                               else "serial order (inside the frame that closes the chunk)"),
-                "solve_lag": args.solve_lag if not chunked else 0,
+                "solve_lag": main_leg["solve_lag"],
                 "parallelism": ("one stream: local chunks round-robin over %d ranks, %d RCCL all-gathers of key-frame packages in the timed region, global half "
                                 "replicated, volume sharded by hash-bucket range; the timed window holds the global half of its %d frames and, on every rank, "
                                 "the chunk-local half of ONE whole chunk of the next round (%d of them ran here) - the steady state when steps == 10 x ranks, "
@@ -392,11 +405,11 @@ def main():
             out["other_contract"] = {"arith": other["arith"], "value": args.steps / other["elapsed"], "unit": "frames/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
                                      "roofline": roofline_of(other), "timed_ops": {k: other["c1"][k] - other["c0"][k] for k in other["c1"]},
                                      "same_trajectory": other["ate"] == main_leg["ate"]}
-        if lagged is not None:
-            out["lagged_solve"] = {"solve_lag_frames": 10, "value": args.steps / lagged["elapsed"], "unit": "frames/s", "ms_per_step": 1e3 * lagged["elapsed"] / args.steps,
-                                   "timed_ops": {k: lagged["c1"][k] - lagged["c0"][k] for k in lagged["c1"]},
-                                   "note": "chunk solves on their own thread and stream, applied exactly one chunk (10 frames) later - the reference runs its optimiser in a second "
-                                           "thread; parity of this schedule: tests/test_pipeline_gpu.py::test_lagged_solve_mode_vs_oracle_loop_with_the_same_lag.  Not `value`."}
+        if serial is not None:
+            out["serial_order"] = {"solve_lag_frames": 0, "value": args.steps / serial["elapsed"], "unit": "frames/s", "ms_per_step": 1e3 * serial["elapsed"] / args.steps,
+                                   "timed_ops": {k: serial["c1"][k] - serial["c0"][k] for k in serial["c1"]}, "roofline": roofline_of(serial),
+                                   "note": "the same window with the chunk solves inside the frame that closes the chunk (BF_PIPELINE_SOLVE_LAG=0): the reference's single-threaded "
+                                           "branch, the schedule of every earlier round's `value`, and the one the oracle loop / the compiled reference loop are compared in"}
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], feed[:args.cpu_frames], params, K, W, H, args.arith)
     del frames, feed
@@ -510,7 +523,7 @@ def long_stream_block(args, K, W, H):
     gbs.s_maxNumImages = n // 10 + 8
     pipe = bf.capi.Pipeline(gas, gbs, sensor_desc(W, H, K))
     pipe.scene().set_arith(args.arith)
-    if args.solve_lag:
+    if args.solve_lag >= 0:
         pipe.set_solve_lag(args.solve_lag)
     poses, marks, dev = [], [], []
     for c0 in range(0, n, 500):                                       # render and upload in batches (host memory); the whole stream is resident in HBM before the clock starts (5000 frames = 12 GB)
@@ -572,10 +585,25 @@ def pmc_traffic(args, arith, vis_plain, vis_fused, n_launch):
     pmc = json.load(open(path)).get(arith)
     if not pmc or pmc["config"] != pmc_config(args):
         return None
-    from tools.pmc_to_json import update_kernel_sha
-    if pmc.get("update_kernel_sha256") != update_kernel_sha():          # counters of another version of the update kernels: stale, not reported
+    from tools.pmc_to_json import update_kernel_sha, build_flags_sha
+    if pmc.get("update_kernel_sha256") != update_kernel_sha() or pmc.get("build_flags_sha256") != build_flags_sha():          # counters of another version / another build of the update kernels: stale, not reported
         return None
     return (vis_fused * pmc["fused"]["hbm_bytes_per_visited_block"] + vis_plain * pmc["plain"]["hbm_bytes_per_visited_block"]) / n_launch
+
+
+def pmc_valu(args, arith, vis_fused, n_launch):
+    """Vector wave-instructions per voxel-update launch of THIS run, from the SQ pass of the same committed PMC file (SQ_INSTS_VALU per visited block x the blocks
+    visited here); None under the same conditions as pmc_traffic."""
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
+    if not os.path.exists(path) or n_launch == 0:
+        return None
+    pmc = json.load(open(path)).get(arith)
+    if not pmc or pmc["config"] != pmc_config(args) or "sq" not in pmc:
+        return None
+    from tools.pmc_to_json import update_kernel_sha, build_flags_sha
+    if pmc.get("update_kernel_sha256") != update_kernel_sha() or pmc.get("build_flags_sha256") != build_flags_sha():
+        return None
+    return vis_fused * pmc["sq"]["valu_wave_instructions_per_visited_block"] / n_launch
 
 
 def cpu_baseline(frames, feed, params, K, W, H, arith):

@@ -79,6 +79,12 @@ def build_probe(force=False):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("probe build failed:\n" + r.stdout.decode())
+    # tools/probe/bf_hazards: the per-mechanism hazard reproducers of round 6 (an executable; profiles/r06_determinism.md)
+    hsrc, hexe = os.path.join(ROOT, "tools", "probe", "hazards.hip"), os.path.join(ROOT, "tools", "probe", "bf_hazards")
+    if force or _stale(hexe, [hsrc, os.path.join(ROOT, "tools", "probe", "window_gen.h")]):
+        r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", hsrc, "-o", hexe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("hazard probe build failed:\n" + r.stdout.decode())
     return out
 
 

@@ -571,10 +571,6 @@ class Sift:
         except Exception:
             pass
 
-    def set_fused_octaves(self, enable=True):
-        """one launch per octave (default) or one per pyramid level group - the same pyramid bit for bit: bf_sift_set_fused_octaves"""
-        check(lib.bf_sift_set_fused_octaves(self._h, int(enable)))
-
     def run(self, intensity, depth, keys, descs, count):
         check(lib.bf_sift_run(self._h, C.c_void_p(intensity.data_ptr()), C.c_void_p(depth.data_ptr()), C.c_void_p(keys.data_ptr()),
                               C.c_void_p(descs.data_ptr()), C.c_void_p(count.data_ptr())))

@@ -9,7 +9,7 @@
 #include "../../include/bf_hip.h"
 
 // Diagnostic (tools/first_run_check.py): BF_DEBUG_POISON="<file>[:<line>]=<hex32>[,...]" fills every allocation made at that place (or "*": everywhere) with the
-// 32-bit pattern - a result that changes with the pattern was computed from memory nobody had written.  Without the variable: hipMalloc and one getenv per process.
+// 32-bit pattern - a result that changes with the pattern was computed from memory nobody had written.  Without the variable: hipMalloc and one getenv per process.  (BF_MALLOC below.)
 #include <cstdlib>
 #include <cstring>
 inline hipError_t bf_debug_malloc(void** p, size_t n, const char* file, int line) {
@@ -28,7 +28,8 @@ inline hipError_t bf_debug_malloc(void** p, size_t n, const char* file, int line
     (void)hipDeviceSynchronize();
     return e;
 }
-#define hipMalloc(p, n) bf_debug_malloc((void**)(p), (n), __FILE__, __LINE__)
+// every device allocation of the library goes through this name (an explicitly named wrapper: the HIP API name itself is not redefined)
+#define BF_MALLOC(p, n) bf_debug_malloc((void**)(p), (n), __FILE__, __LINE__)
 
 
 namespace bf {

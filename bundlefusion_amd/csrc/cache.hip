@@ -223,7 +223,7 @@ int bf_cache_create(uint32_t dw, uint32_t dh, uint32_t W, uint32_t H, uint32_t m
     const size_t n = (size_t)W * H;
     // one slab per array type: frame i at offset i*n  (288 GB of HBM: 1200 frames are 300 MB)
     float *depth, *campos, *inten, *derivs, *normals; uint8_t* nu;
-    auto A = [&](void** p, size_t bytes) { if (hipMalloc(p, bytes) != hipSuccess) return false; c->allocations.push_back(*p); return true; };
+    auto A = [&](void** p, size_t bytes) { if (BF_MALLOC(p, bytes) != hipSuccess) return false; c->allocations.push_back(*p); return true; };
     bool ok = A((void**)&depth, n * 4 * maxNumImages) && A((void**)&campos, n * 16 * maxNumImages) && A((void**)&inten, n * 4 * maxNumImages) &&
               A((void**)&derivs, n * 8 * maxNumImages) && A((void**)&nu, n * 4 * maxNumImages) && A((void**)&normals, n * 16 * maxNumImages) &&
               A((void**)&c->d_frames, sizeof(bf_cached_frame) * maxNumImages) && A((void**)&c->d_scratch, n * 4);

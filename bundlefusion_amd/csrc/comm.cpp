@@ -149,8 +149,8 @@ int bf_chunk_exchange(bf_comm* c, const void* h_mine, void* h_all, uint64_t pack
         if (c->d_send) (void)hipFree(c->d_send);
         if (c->d_recv) (void)hipFree(c->d_recv);
         c->d_send = c->d_recv = nullptr; c->stageBytes = 0;
-        BF_HIP_TRY(hipMalloc((void**)&c->d_send, package_bytes));
-        BF_HIP_TRY(hipMalloc((void**)&c->d_recv, package_bytes * c->world));
+        BF_HIP_TRY(BF_MALLOC((void**)&c->d_send, package_bytes));
+        BF_HIP_TRY(BF_MALLOC((void**)&c->d_recv, package_bytes * c->world));
         c->stageBytes = package_bytes;
     }
     BF_HIP_TRY(hipMemcpyAsync(c->d_send, h_mine, package_bytes, hipMemcpyHostToDevice, st));

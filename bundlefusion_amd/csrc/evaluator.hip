@@ -168,8 +168,8 @@ int evEnsure(bf_correspondence_evaluator* ev, uint32_t n) {
     if (ev->d_counts) hipFree(ev->d_counts);
     ev->d_T = nullptr; ev->d_counts = nullptr; ev->capacity = 0;
     const uint32_t cap = std::max<uint32_t>(64, 2 * n);
-    BF_HIP_TRY(hipMalloc((void**)&ev->d_T, sizeof(m44) * 2 * cap));
-    BF_HIP_TRY(hipMalloc((void**)&ev->d_counts, sizeof(uint32_t) * 4 * cap));
+    BF_HIP_TRY(BF_MALLOC((void**)&ev->d_T, sizeof(m44) * 2 * cap));
+    BF_HIP_TRY(BF_MALLOC((void**)&ev->d_counts, sizeof(uint32_t) * 4 * cap));
     ev->capacity = cap;
     return BF_OK;
 }

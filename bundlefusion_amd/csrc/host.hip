@@ -210,15 +210,15 @@ int bf_image_manager_create(uint32_t wInt, uint32_t hInt, uint32_t wSIFT, uint32
     im->depthExtrinsicsInv = inverse44(im->depthExtrinsics);
     const size_t nd = (size_t)sensor->depthWidth * sensor->depthHeight, nc = (size_t)sensor->colorWidth * sensor->colorHeight;
     for (uint32_t k = 0; k < (im->scratch ? 1u : bf_image_manager::NSETS); ++k) {
-        BF_HIP_TRY(hipMalloc((void**)&im->rawSet[k], nd * 4));
-        BF_HIP_TRY(hipMalloc((void**)&im->filtSet[k], nd * 4));
-        BF_HIP_TRY(hipMalloc((void**)&im->colSet[k], nc * 4));
+        BF_HIP_TRY(BF_MALLOC((void**)&im->rawSet[k], nd * 4));
+        BF_HIP_TRY(BF_MALLOC((void**)&im->filtSet[k], nd * 4));
+        BF_HIP_TRY(BF_MALLOC((void**)&im->colSet[k], nc * 4));
     }
     if (im->scratch) for (uint32_t k = 1; k < bf_image_manager::NSETS; ++k) { im->rawSet[k] = im->rawSet[0]; im->filtSet[k] = im->filtSet[0]; im->colSet[k] = im->colSet[0]; }
     im->d_depthInputRaw = im->rawSet[0]; im->d_depthInputFiltered = im->filtSet[0]; im->d_colorInput = im->colSet[0];
     if (!im->onGPU) {
-        BF_HIP_TRY(hipMalloc((void**)&im->d_stageDepth, im->nInt() * 4));
-        BF_HIP_TRY(hipMalloc((void**)&im->d_stageColor, im->nInt() * 4));
+        BF_HIP_TRY(BF_MALLOC((void**)&im->d_stageDepth, im->nInt() * 4));
+        BF_HIP_TRY(BF_MALLOC((void**)&im->d_stageColor, im->nInt() * 4));
     }
     *out = im;
     return BF_OK;
@@ -283,10 +283,10 @@ static int im_process(bf_image_manager* im, const float* depth, const uint8_t* c
         if (f / bf_image_manager::SLAB >= im->depthSlabs.size()) {
             float* pd = nullptr; uint8_t* pc = nullptr;
             const size_t slots = im->scratch ? 1 : bf_image_manager::SLAB;
-            BF_HIP_TRY(hipMalloc((void**)&pd, ni * 4 * slots));
-            BF_HIP_TRY(hipMalloc((void**)&pc, ni * 4 * slots));
+            BF_HIP_TRY(BF_MALLOC((void**)&pd, ni * 4 * slots));
+            BF_HIP_TRY(BF_MALLOC((void**)&pc, ni * 4 * slots));
             im->depthSlabs.push_back(pd); im->colorSlabs.push_back(pc);
-            if (im->storeTexels) { uint8_t* pt = nullptr; BF_HIP_TRY(hipMalloc((void**)&pt, ni * 8 * slots)); im->texelSlabs.push_back(pt); }
+            if (im->storeTexels) { uint8_t* pt = nullptr; BF_HIP_TRY(BF_MALLOC((void**)&pt, ni * 8 * slots)); im->texelSlabs.push_back(pt); }
         }
         frameDepth = im->depthSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni;
         frameColor = im->colorSlabs[f / bf_image_manager::SLAB] + (size_t)(f % bf_image_manager::SLAB) * ni * 4;
@@ -651,9 +651,9 @@ int bf_bundler_create(uint32_t maxNumImages, uint32_t maxNumKeysPerImage, const 
                                   gbs->s_colorDownSigma, gbs->s_depthDownSigmaD, gbs->s_depthDownSigmaR, &b->cache);
     if (!rc) rc = bf_siftmgr_create(maxNumImages, maxNumKeysPerImage, &b->mgr);
     if (rc) { bf_bundler_destroy(b); return rc; }
-    BF_HIP_TRY(hipMalloc((void**)&b->d_trajectory, sizeof(m44) * (maxNumImages + 1)));
-    BF_HIP_TRY(hipMalloc((void**)&b->d_xRot, sizeof(float) * 3 * maxNumImages));
-    BF_HIP_TRY(hipMalloc((void**)&b->d_xTrans, sizeof(float) * 3 * maxNumImages));
+    BF_HIP_TRY(BF_MALLOC((void**)&b->d_trajectory, sizeof(m44) * (maxNumImages + 1)));
+    BF_HIP_TRY(BF_MALLOC((void**)&b->d_xRot, sizeof(float) * 3 * maxNumImages));
+    BF_HIP_TRY(BF_MALLOC((void**)&b->d_xTrans, sizeof(float) * 3 * maxNumImages));
     k_fill_identity<<<div_up(maxNumImages + 1, 64), 64>>>(b->d_trajectory, maxNumImages + 1);
     BF_HIP_TRY(hipDeviceSynchronize());
     const uint32_t maxNumIts = std::max(gbs->s_numGlobalNonLinIterations, gbs->s_numLocalNonLinIterations);     // SBA.cpp:28-38
@@ -1415,15 +1415,15 @@ int bf_online_bundler_create(const bf_rgbd_sensor_desc* sensor, bf_image_manager
         BF_HIP_TRY(hipEventCreateWithFlags(&ob->evStageFree[k], hipEventDisableTiming));
     }
     const size_t nAll = (size_t)maxNumImages * S;
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_intensitySIFT, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_intensityFilterHelper, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_completeTrajectory, sizeof(m44) * nAll));
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_localTrajectories, sizeof(m44) * (size_t)maxNumImages * (S + 1)));
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_siftTrajectory, sizeof(m44) * nAll));
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_currIntegrateTransform, sizeof(m44) * nAll));
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_imageInvalidateList, sizeof(int) * nAll));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_intensitySIFT, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_intensityFilterHelper, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_completeTrajectory, sizeof(m44) * nAll));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_localTrajectories, sizeof(m44) * (size_t)maxNumImages * (S + 1)));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_siftTrajectory, sizeof(m44) * nAll));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_currIntegrateTransform, sizeof(m44) * nAll));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_imageInvalidateList, sizeof(int) * nAll));
     BF_HIP_TRY(hipHostMalloc((void**)&ob->h_pinT, bf_online_bundler::PEND * sizeof(m44)));
-    BF_HIP_TRY(hipMalloc((void**)&ob->d_completeShadow, sizeof(m44) * nAll));
+    BF_HIP_TRY(BF_MALLOC((void**)&ob->d_completeShadow, sizeof(m44) * nAll));
     BF_HIP_TRY(hipMemset(ob->d_completeShadow, 0, sizeof(m44) * nAll));
     BF_HIP_TRY(hipEventCreateWithFlags(&ob->evChunk, hipEventDisableTiming));
     BF_HIP_TRY(hipEventCreateWithFlags(&ob->evChunkCopy, hipEventDisableTiming));
@@ -1514,8 +1514,8 @@ int bf_online_bundler_set_second_detect_stream(bf_online_bundler* ob, void* s) {
     if (!ob->sift2) {
         const bf_bundler* b = ob->stage;
         BF_TRY(bf_sift_create(b->gbs.s_widthSIFT, b->gbs.s_heightSIFT, ob->depthW, ob->depthH, 150, b->gas.s_sensorDepthMin, b->gas.s_sensorDepthMax, b->gbs.s_minKeyScale, b->maxKeys, &ob->sift2));
-        BF_HIP_TRY(hipMalloc((void**)&ob->d_intensitySIFT2, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
-        BF_HIP_TRY(hipMalloc((void**)&ob->d_intensityFilterHelper2, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+        BF_HIP_TRY(BF_MALLOC((void**)&ob->d_intensitySIFT2, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
+        BF_HIP_TRY(BF_MALLOC((void**)&ob->d_intensityFilterHelper2, sizeof(float) * ob->widthSIFT * ob->heightSIFT));
     }
     return bf_sift_set_stream(ob->sift2, s);
 }
@@ -1923,6 +1923,7 @@ struct bf_pipeline {
     hipStream_t sSolve = nullptr;   // stream of the lagged solves (bf_pipeline_set_solve_lag)
     hipStream_t sIngest = nullptr;  // the ingest filters of frame n + 1 run beside the detection of frame n (several input sets in the image manager)
     hipStream_t sPair[2] = {nullptr, nullptr};      // pair stages of consecutive frames side by side (bf_online_bundler_set_pair_streams)
+    hipStream_t sPairStage[2] = {nullptr, nullptr}; // BF_PIPELINE_PAIR_STREAMS=1
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
@@ -2271,9 +2272,11 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         int least = 0, greatest = 0;
         BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sBundle, hipStreamNonBlocking, greatest));
-        // (measured and withdrawn, gpurun r03k: reserving R = 16 .. 96 CUs for the chain by masking the volume stream - the wait for the match result drops
-        // 0.80 -> 0.69 ms while the voxel update slows 93.8 -> 126 us; frames/s 656 -> 655 / 648 / 623 / 565)
-        uint32_t reserve = 0;                // BF_VOLUME_CU_RESERVE=R: the volume stream may use all but R compute units (the matching chain then finds idle CUs beside a voxel update)
+        // The volume stream may use all but `reserve` compute units (BF_VOLUME_CU_RESERVE, 0: the whole device at the lowest queue priority): the matching chain is
+        // ~20 dependent small launches, and behind a batched voxel update that fills every CU each of them waits for waves to retire.  With the frame's operators
+        // batched the volume queue is busy about half of the time, so the slower update costs nothing: 873 / 893 / 939 / 944 frames/s at R = 0 / 16 / 32 / 64, the
+        // wait for the match result 0.65 -> 0.49 ms (gpurun r06a, one box).  (Round 3, one launch chain per operator and the volume stream the bottleneck: no gain.)
+        uint32_t reserve = 32;
         if (const char* e = getenv("BF_VOLUME_CU_RESERVE")) reserve = (uint32_t)std::max(atoi(e), 0);
         if (reserve) {
             hipDeviceProp_t prop; int devId = 0;
@@ -2306,10 +2309,23 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // odd frames detect on a second queue (bf_online_bundler_set_second_detect_stream): the first of the two pair streams.  (The pair stages of consecutive frames
         // on those two streams - bf_online_bundler_set_pair_streams, round 4 - lost: 659 vs 697 frames/s, gpurun r04c; the mode is reachable through that call only.)
         BF_TRY(bf_online_bundler_set_second_detect_stream(p->ob, p->sPair[0])); p->sDetect2 = p->sPair[0];
+        if (const char* e = getenv("BF_PIPELINE_PAIR_STREAMS")) if (atoi(e) != 0) {      // experiment: the pair stages (match .. dense verify) of consecutive frames on two queues of their own
+            int least = 0, greatest = 0;
+            BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            for (auto& st : p->sPairStage) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+            BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPairStage[0], p->sPairStage[1]));
+        }
     }
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
-    if (const char* e = getenv("BF_PIPELINE_SOLVE_LAG")) BF_TRY(bf_pipeline_set_solve_lag(p, (uint32_t)atoi(e)));
+    {   // Default schedule (round 6): the reference's - its optimiser runs beside the frame loop on a second thread (FriedLiver.cpp:112-143) - made deterministic: the
+        // chunk solves on their own thread and stream, applied exactly `lag` frames behind the frame that closed the chunk.  bf_pipeline_set_solve_lag(p, 0) /
+        // BF_PIPELINE_SOLVE_LAG=0: the serial order of DepthSensing.cpp's single-threaded branch (what the oracle loop and the compiled reference loop run).
+        uint32_t lag = std::min<uint32_t>(10u, p->ob->submapSize);
+        if (const char* e = getenv("BF_PIPELINE_SOLVE_LAG")) lag = (uint32_t)std::max(atoi(e), 0);
+        if (lag && p->lookahead && lag < p->depth) lag = 0;
+        BF_TRY(bf_pipeline_set_solve_lag(p, lag));
+    }
     if (const char* e = getenv("BF_PIPELINE_TRACE")) p->tracePath = e;
     int dev = 0;
     BF_HIP_TRY(hipGetDevice(&dev));
@@ -2350,6 +2366,7 @@ int bf_pipeline_destroy(bf_pipeline* p) {
     if (p->sSolve) (void)hipStreamDestroy(p->sSolve);
     if (p->sIngest) (void)hipStreamDestroy(p->sIngest);
     for (auto st : p->sPair) if (st) (void)hipStreamDestroy(st);
+    for (auto st : p->sPairStage) if (st) (void)hipStreamDestroy(st);
     delete p;
     return BF_OK;
 }
@@ -2419,6 +2436,7 @@ int bf_pipeline_synchronize(bf_pipeline* p) {
     BF_HIP_TRY(hipStreamSynchronize(p->sIngest));
     BF_HIP_TRY(hipStreamSynchronize(p->sDetect));
     for (auto st : p->sPair) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
+    for (auto st : p->sPairStage) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
     BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
     if (p->sSolve) BF_HIP_TRY(hipStreamSynchronize(p->sSolve));
     BF_HIP_TRY(hipStreamSynchronize(p->sVolume));
@@ -2523,9 +2541,9 @@ int bf_chunk_worker_create(const bf_global_app_state* gas, const bf_global_bundl
     if (!rc) rc = bf_siftmgr_create(2, gbs->s_maxNumKeysPerImage, &w->fuseMgr);
     if (rc) { bf_chunk_worker_destroy(w); return rc; }
     const size_t nS = (size_t)gbs->s_widthSIFT * gbs->s_heightSIFT;
-    BF_HIP_TRY(hipMalloc((void**)&w->d_intensity, nS * 4));
-    BF_HIP_TRY(hipMalloc((void**)&w->d_intensityHelper, nS * 4));
-    BF_HIP_TRY(hipMalloc((void**)&w->d_rec, sizeof(bf_chunk_frame_record) * BF_CHUNK_MAX_FRAMES));
+    BF_HIP_TRY(BF_MALLOC((void**)&w->d_intensity, nS * 4));
+    BF_HIP_TRY(BF_MALLOC((void**)&w->d_intensityHelper, nS * 4));
+    BF_HIP_TRY(BF_MALLOC((void**)&w->d_rec, sizeof(bf_chunk_frame_record) * BF_CHUNK_MAX_FRAMES));
     float k4[4];
     BF_TRY(bf_cache_get_geometry(w->local->cache, &w->cacheW, &w->cacheH, k4));
     const uint64_t n = (uint64_t)w->cacheW * w->cacheH, mk = gbs->s_maxNumKeysPerImage;

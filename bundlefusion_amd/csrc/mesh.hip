@@ -327,11 +327,11 @@ int bf_marching_cubes_create(const bf_marching_cubes_params* p, bf_marching_cube
     bf_marching_cubes* m = new bf_marching_cubes;
     m->params = *p;
     McTables t; makeTables(t);
-    BF_HIP_TRY(hipMalloc((void**)&m->d_tables, sizeof t));
+    BF_HIP_TRY(BF_MALLOC((void**)&m->d_tables, sizeof t));
     BF_HIP_TRY(hipMemcpy(m->d_tables, &t, sizeof t, hipMemcpyHostToDevice));
-    BF_HIP_TRY(hipMalloc((void**)&m->d_triangles, sizeof(bf_mc_triangle) * (size_t)p->m_maxNumTriangles));
-    BF_HIP_TRY(hipMalloc((void**)&m->d_numBlocks, 4));
-    BF_HIP_TRY(hipMalloc((void**)&m->d_total, 4));
+    BF_HIP_TRY(BF_MALLOC((void**)&m->d_triangles, sizeof(bf_mc_triangle) * (size_t)p->m_maxNumTriangles));
+    BF_HIP_TRY(BF_MALLOC((void**)&m->d_numBlocks, 4));
+    BF_HIP_TRY(BF_MALLOC((void**)&m->d_total, 4));
     *out = m;
     return BF_OK;
 }
@@ -355,9 +355,9 @@ int bf_marching_cubes_extract(bf_marching_cubes* m, const bf_hash_data* hd, cons
     const uint32_t numTiles = div_up(numSlots, TILE);
     if (numSlots > m->capSlots) {
         (void)hipFree(m->d_tileCounts); (void)hipFree(m->d_slots); (void)hipFree(m->d_blockCounts);
-        BF_HIP_TRY(hipMalloc((void**)&m->d_tileCounts, 4 * (size_t)(numTiles + 1)));
-        BF_HIP_TRY(hipMalloc((void**)&m->d_slots, 4 * (size_t)numSlots));
-        BF_HIP_TRY(hipMalloc((void**)&m->d_blockCounts, 4 * (size_t)numSlots));
+        BF_HIP_TRY(BF_MALLOC((void**)&m->d_tileCounts, 4 * (size_t)(numTiles + 1)));
+        BF_HIP_TRY(BF_MALLOC((void**)&m->d_slots, 4 * (size_t)numSlots));
+        BF_HIP_TRY(BF_MALLOC((void**)&m->d_blockCounts, 4 * (size_t)numSlots));
         m->capSlots = numSlots;
     }
     McArgs a;

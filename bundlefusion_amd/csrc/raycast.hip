@@ -294,7 +294,7 @@ int bf_ray_cast_create(const bf_ray_cast_params* p, bf_ray_cast** out) {        
     const size_t n = (size_t)p->m_width * p->m_height;
     rc->capacity = (uint32_t)n;
     hipError_t e = hipSuccess;
-    auto A = [&](void** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(ptr, bytes); };
+    auto A = [&](void** ptr, size_t bytes) { if (e == hipSuccess) e = BF_MALLOC(ptr, bytes); };
     A((void**)&rc->d_depth, n * 4); A((void**)&rc->d_depth4, n * 16); A((void**)&rc->d_normals, n * 16); A((void**)&rc->d_colors, n * 16);
     A((void**)&rc->d_rayMin, n * 4); A((void**)&rc->d_rayMax, n * 4); A((void**)&rc->d_minKey, n * 4); A((void**)&rc->d_maxKey, n * 4);
     if (e != hipSuccess) { bf_ray_cast_destroy(rc); set_error("hipMalloc failed: %s", hipGetErrorString(e)); return BF_ERR_HIP; }

@@ -107,84 +107,6 @@ __global__ __launch_bounds__(256) void k_blur(BlurJobs jobs, Taps taps) {
     }
 }
 
-// One launch per OCTAVE (round 5; rounds 1-4 built the pyramid with 18 dependent launches of the kernel above, 190-330 us per frame of 8-18 us launches).
-// A workgroup owns an OT_W x OT_H tile of the octave and computes ALL six levels of it: level a is the blur of level a - 1, so the tile of level 5 needs level 4
-// on a halo of r5, level 3 on r5 + r4, ... - the region shrinks from level to level inside LDS (two buffers: the current level, and the H pass of the next).  Every
-// level's region is kept replicate-padded (the value stored for a position outside the image is the value at the clamped position), so the H and V passes read
-// their taps without clamping - exactly the clamp-to-edge fetches of FilterH / FilterV (ProgramCU.cu:159-264): same taps, same order, same bits as k_blur.
-// Level 0 is the blur of the input image (octave 0, filter 0) or the 2:1 down-sample of the previous octave's level 3 (DownsampleKernel :330-354).
-constexpr int OT_W = 40, OT_H = 32;
-struct OctaveJob {
-    const float* src; float* dst[NLEV];
-    int w, h, srcW, first, tilesX;
-    int halo[NLEV]; int haloIn;       // halo of level a's region around the tile; of the input region (octave 0)
-};
-
-typedef float f2v __attribute__((ext_vector_type(2)));
-
-// One level: H pass A -> B, V pass B -> A.  A lane owns TWO adjacent destination columns and keeps both running sums in one packed register pair (v_pk_mul_f32 +
-// v_pk_add_f32: every tap is `v += a * k` per output, in tap order, exactly FilterH / FilterV's sequence); waves stride over the rows, so there is no index division
-// anywhere.  The taps come through scalar loads (`k` is a kernel-argument pointer, the tap index is wave-uniform).
-BF_DEV void octaveBlurLevel(const float* A, float* B, float* Aout, const float* __restrict__ k, int fw, int x0, int y0, int w, int h, int Hs, int Hd) {
-    const int r = fw >> 1;
-    const int SW = OT_W + 2 * Hs, SH = OT_H + 2 * Hs, DW = OT_W + 2 * Hd, DH = OT_H + 2 * Hd;      // (all even)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int dx = 2 * lane;                         // this lane's column pair (DW <= 128)
-    if (dx < DW) {
-        const int xc0 = min(max(x0 - Hd + dx, 0), w - 1), xc1 = min(max(x0 - Hd + dx + 1, 0), w - 1);
-        const int o0 = (xc0 - x0) + Hs - r, o1 = (xc1 - x0) + Hs - r;
-        for (int row = wave; row < SH; row += nw) {          // H pass
-            const float* a = A + row * SW;
-            f2v v = {0.0f, 0.0f};
-            for (int i = 0; i < fw; ++i) { f2v s; s.x = a[o0 + i]; s.y = a[o1 + i]; const float ki = k[i]; f2v kk = {ki, ki}; v = v + s * kk; }
-            *reinterpret_cast<f2v*>(B + row * DW + dx) = v;
-        }
-    }
-    __syncthreads();
-    if (dx < DW) {
-        for (int dy = wave; dy < DH; dy += nw) {             // V pass
-            const int yc = min(max(y0 - Hd + dy, 0), h - 1);
-            const float* b = B + ((yc - y0) + Hs - r) * DW + dx;
-            f2v v = {0.0f, 0.0f};
-            for (int i = 0; i < fw; ++i) { const f2v s = *reinterpret_cast<const f2v*>(b + i * DW); const float ki = k[i]; f2v kk = {ki, ki}; v = v + s * kk; }
-            *reinterpret_cast<f2v*>(Aout + dy * DW + dx) = v;
-        }
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(512) void k_octave(OctaveJob job, const float* __restrict__ tapK, const int* __restrict__ tapW, int floatsA) {
-    extern __shared__ float oct_lds[];
-    float* A = oct_lds; float* B = oct_lds + floatsA;
-    const int x0 = ((int)blockIdx.x % job.tilesX) * OT_W, y0 = ((int)blockIdx.x / job.tilesX) * OT_H;
-    const int w = job.w, h = job.h;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int H = job.first ? job.haloIn : job.halo[0];
-    {   // the first region: replicate-padded input image, or the down-sampled previous octave
-        const int SW = OT_W + 2 * H, SH = OT_H + 2 * H;
-        for (int row = wave; row < SH; row += nw) {
-            const int yc = min(max(y0 - H + row, 0), h - 1);
-            for (int col = lane; col < SW; col += 64) {
-                const int xc = min(max(x0 - H + col, 0), w - 1);
-                A[row * SW + col] = job.first ? job.src[(size_t)yc * w + xc] : job.src[(size_t)(yc << 1) * job.srcW + min(xc << 1, job.srcW - 1)];
-            }
-        }
-        __syncthreads();
-    }
-    for (int a = 0; a < NLEV; ++a) {
-        if (a > 0 || job.first) {
-            const int Hd = job.halo[a];
-            octaveBlurLevel(A, B, A, tapK + a * MAX_FW, tapW[a], x0, y0, w, h, H, Hd);
-            H = Hd;
-        }
-        const int DW = OT_W + 2 * H;
-        float* dst = job.dst[a];
-        for (int ty = wave; ty < OT_H; ty += nw)
-            if (lane < OT_W && x0 + lane < w && y0 + ty < h) dst[(size_t)(y0 + ty) * w + x0 + lane] = A[(ty + H) * DW + lane + H];
-        // (no barrier: the next level's H pass only reads A)
-    }
-}
-
 // gradient magnitude / orientation of a gaussian level (ComputeDOG_Kernel :550-569); linear fetches
 // outside the image buffer read 0 like tex1Dfetch
 struct alignas(64) GradJob { const float* g; float* mag; float* ang; int w, h, blocks; };
@@ -580,9 +502,7 @@ struct bf_sift {
     Levels levels;
     GradJobs gradJobs; int gradBlocks = 0;
     DetectCfg detect; int detectBlocks = 0;
-    std::vector<BlurJobs> schedule;        // the level-by-level pyramid (k_blur), kept for bf_sift_set_fused_octaves(0)
-    OctaveJob octave[NUM_OCT]; int octaveBlocks[NUM_OCT]; int octFloatsA = 0, octFloatsB = 0; bool fusedOctaves = false;
-    float* d_tapK = nullptr; int* d_tapW = nullptr;        // the taps in device memory: k_octave reads them through scalar loads
+    std::vector<BlurJobs> schedule;        // the level-by-level pyramid (k_blur)
     float* gauss[NUM_OCT][NLEV];
     float* mag[NUM_OCT][3]; float* ang[NUM_OCT][3];
     SiftDev d{};
@@ -610,7 +530,7 @@ int bf_sift_create(uint32_t width, uint32_t height, uint32_t depthWidth, uint32_
     memset(&s->taps, 0, sizeof s->taps);
     makeTapsHost(initSigma, s->taps.fw[0], s->taps.k[0]);
     for (int i = 0; i < 5; ++i) makeTapsHost(dsigma0 * powf(sigmak, (float)i), s->taps.fw[i + 1], s->taps.k[i + 1]);
-    auto A = [&](void** p, size_t bytes) { if (hipMalloc(p, bytes) != hipSuccess) return false; s->allocations.push_back(*p); return true; };
+    auto A = [&](void** p, size_t bytes) { if (BF_MALLOC(p, bytes) != hipSuccess) return false; s->allocations.push_back(*p); return true; };
     bool ok = true;
     uint32_t candTotal = 0;
     for (int o = 0; o < NUM_OCT; ++o) {
@@ -682,38 +602,9 @@ int bf_sift_create(uint32_t width, uint32_t height, uint32_t depthWidth, uint32_
             }
         if (bj.n) s->schedule.push_back(bj);
     }
-    {   // the per-octave jobs of k_octave: halos from the filter widths
-        int r[NLEV];
-        for (int a = 0; a < NLEV; ++a) r[a] = s->taps.fw[a] >> 1;
-        int halo[NLEV];
-        halo[NLEV - 1] = 0;
-        for (int a = NLEV - 2; a >= 0; --a) halo[a] = halo[a + 1] + r[a + 1];
-        const int haloIn = halo[0] + r[0];
-        s->octFloatsA = (OT_W + 2 * haloIn) * (OT_H + 2 * haloIn);
-        s->octFloatsB = (OT_H + 2 * haloIn) * (OT_W + 2 * halo[0]);
-        for (int o = 0; o < NUM_OCT; ++o) {
-            OctaveJob& j = s->octave[o];
-            memset(&j, 0, sizeof j);
-            j.w = s->W >> o; j.h = s->H >> o; j.first = o == 0 ? 1 : 0;
-            j.src = o == 0 ? nullptr : s->gauss[o - 1][3]; j.srcW = o == 0 ? j.w : (s->W >> (o - 1));
-            for (int a = 0; a < NLEV; ++a) { j.dst[a] = s->gauss[o][a]; j.halo[a] = halo[a]; }
-            j.haloIn = haloIn;
-            j.tilesX = (j.w + OT_W - 1) / OT_W;
-            s->octaveBlocks[o] = j.tilesX * ((j.h + OT_H - 1) / OT_H);
-        }
-        const size_t bytes = (size_t)(s->octFloatsA + s->octFloatsB) * 4;
-        if (bytes > 160 * 1024 - 512) { set_error("bf_sift_create: octave tile does not fit the LDS"); bf_sift_destroy(s); return BF_ERR_INVALID_ARG; }
-        BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_octave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        if (!A((void**)&s->d_tapK, sizeof(float) * NLEV * MAX_FW) || !A((void**)&s->d_tapW, sizeof(int) * NLEV)) { set_error("bf_sift_create: hipMalloc failed"); bf_sift_destroy(s); return BF_ERR_HIP; }
-        BF_HIP_TRY(hipMemcpy(s->d_tapK, s->taps.k, sizeof(float) * NLEV * MAX_FW, hipMemcpyHostToDevice));
-        BF_HIP_TRY(hipMemcpy(s->d_tapW, s->taps.fw, sizeof(int) * NLEV, hipMemcpyHostToDevice));
-    }
     *out = s;
     return BF_OK;
 }
-
-// 1: one launch per octave (k_octave); 0 (default: 190 vs 366 us of pyramid per 640x480 frame, profiles/r05) : one launch per pyramid level (k_blur) - same pyramid bit for bit
-int bf_sift_set_fused_octaves(bf_sift* s, int enable) { BF_REQUIRE(s, "null sift"); s->fusedOctaves = enable != 0; return BF_OK; }
 
 int bf_sift_destroy(bf_sift* s) {
     if (!s) return BF_OK;
@@ -731,13 +622,6 @@ int bf_sift_set_stream(bf_sift* s, void* st) { BF_REQUIRE(s, "null sift"); s->st
 int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_depth, float* d_keyPoints, uint8_t* d_descs, int32_t* d_numKeys) {
     BF_REQUIRE(s && d_intensity && d_depth && d_keyPoints && d_descs && d_numKeys, "null argument");
     hipStream_t st = s->stream;
-    if (s->fusedOctaves) {
-        for (int o = 0; o < NUM_OCT; ++o) {
-            OctaveJob j = s->octave[o];
-            if (o == 0) j.src = d_intensity;
-            hipLaunchKernelGGL(k_octave, dim3(s->octaveBlocks[o]), dim3(512), (size_t)(s->octFloatsA + s->octFloatsB) * 4, st, j, s->d_tapK, s->d_tapW, s->octFloatsA);
-        }
-    } else
     for (size_t i = 0; i < s->schedule.size(); ++i) {
         BlurJobs bj = s->schedule[i];
         int blocks = 0;

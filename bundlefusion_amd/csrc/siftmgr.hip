@@ -90,6 +90,9 @@ BF_DEV int loadAgent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXE
 BF_DEV float loadAgentF(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchScratch sc) {
+#ifdef BF_VAR_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
@@ -481,6 +484,9 @@ struct FilterArgs {
 // LDS (the <= 128 raw matches' key positions and back-projected points are staged once), and the independent pieces of each
 // step (distance checks, residuals, sort ranks, the two covariance solves) are spread over lanes.
 __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
+#ifdef BF_VAR_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     const uint32_t tid = threadIdx.x;
@@ -637,6 +643,9 @@ BF_DEV float warpTree32(const float* v, int n) {
 struct AreaArgs { const Key* keys; uint32_t curFrame, startFrame; int* numFilt; const uint2* fidx; m44 Kinv; float areaThresh; };
 
 __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
+#ifdef BF_VAR_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     const int n = min(a.numFilt[prev], MAX_FILT);
@@ -833,6 +842,9 @@ BF_DEV bool denseVerifyPair(const VerifyArgs& a, const bf_cached_frame& fi, cons
 }
 
 __global__ __launch_bounds__(DV_THREADS) void k_filter_dense_verify(VerifyArgs a) {
+#ifdef BF_VAR_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     if (a.numFilt[prev] <= 0) return;
@@ -949,7 +961,7 @@ __global__ void k_reset_valid(int* valid, uint32_t n, int* globNum) {
 }
 
 template <class T>
-int dalloc(T*& p, size_t n) { BF_HIP_TRY(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return BF_OK; }
+int dalloc(T*& p, size_t n) { BF_HIP_TRY(BF_MALLOC((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return BF_OK; }
 
 m44 toM44(const float* p) { m44 m; memcpy(m.e, p, 64); return m; }
 
@@ -1564,10 +1576,10 @@ int bf_siftmgr_fuse_to_global(bf_siftmgr* local, bf_siftmgr* global, const float
         if (local->fuseScratch) BF_HIP_TRY(hipFree(local->fuseScratch));
         local->fuseScratch = nullptr; local->fuseScratchBytes = 0;
         const size_t cap = (size_t)local->maxImages * mk * 4 * 9 + (size_t)local->maxImages * mk * sizeof(Key) + (size_t)2 * local->maxResiduals * sizeof(FuseAdj) + 256;
-        BF_HIP_TRY(hipMalloc(&local->fuseScratch, cap));
+        BF_HIP_TRY(BF_MALLOC(&local->fuseScratch, cap));
         local->fuseScratchBytes = cap;
     }
-    if (!local->d_fuseError) { BF_HIP_TRY(hipMalloc((void**)&local->d_fuseError, sizeof(int))); BF_HIP_TRY(hipMemset(local->d_fuseError, 0, sizeof(int))); }
+    if (!local->d_fuseError) { BF_HIP_TRY(BF_MALLOC((void**)&local->d_fuseError, sizeof(int))); BF_HIP_TRY(hipMemset(local->d_fuseError, 0, sizeof(int))); }
     bf_sift_image_gpu img;
     { const int rc = bf_siftmgr_create_image(global, &img); if (rc != BF_OK) return rc; }
     FuseArgs a;

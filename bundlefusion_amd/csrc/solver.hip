@@ -1042,7 +1042,7 @@ namespace {
 template <class T>
 bool sAlloc(bf_solver* s, T** p, size_t n) {
     void* q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return false;
+    if (BF_MALLOC(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return false;
     s->allocations.push_back(q);
     *p = (T*)q;
     return true;
@@ -1283,8 +1283,8 @@ int bf_solver_debug_dense_system(bf_solver* s, float* hJtJ, float* hJtr, uint32_
     BF_REQUIRE(s && hJtJ && hJtr && numPairs && N == s->lastN, "bad argument");
     const size_t dim = 6 * (size_t)N;
     float *dJ = nullptr, *dr = nullptr;
-    BF_HIP_TRY(hipMalloc(&dJ, dim * dim * 4));
-    BF_HIP_TRY(hipMalloc(&dr, dim * 4));
+    BF_HIP_TRY(BF_MALLOC(&dJ, dim * dim * 4));
+    BF_HIP_TRY(BF_MALLOC(&dr, dim * 4));
     BF_HIP_TRY(hipMemsetAsync(dJ, 0, dim * dim * 4, s->stream));
     BF_HIP_TRY(hipMemsetAsync(dr, 0, dim * 4, s->stream));
     if (s->lastUsedDense) hipLaunchKernelGGL(k_expand_dense, dim3(1), dim3(64), 0, s->stream, s->d, dJ, dr);

@@ -1043,12 +1043,15 @@ BF_DEV void voxelApply(const FR& f, float sdf, uchar4 cc, float& vSdf, float& vW
 // ---------------------------------------------------------------------------------------
 // f2i as the one instruction it describes (v_cvt_i32_f32: toward zero, saturating, NaN -> 0).  The portable spelling in bf_device.h
 // costs three compares and three exec-mask branches per conversion in the voxel kernels' inner loop.
-// Spelled as HIP's own conversion (a plain v_cvt_i32_f32_e32 in the generated code), NOT as inline assembly: up to round 5 this was
-// `asm("v_cvt_i32_f32_e32 %0, %1")`, and with it the fast update gave run-to-run different voxels whenever other kernels shared the device - always lanes 48-63
-// (the last of a wave64 instruction's four passes) of a block's first voxel pair, one sample read at a neighbouring pixel or missed.  The compiler pads the VALU
-// forwarding hazards of gfx950 with s_nop where it can see the instructions (it does so in front of this very conversion when it follows a packed FMA); it
-// cannot see into an asm statement.  With the conversion visible: 8 of 8 runs of the frame loop bit-identical (profiles/r05_determinism.md).
-BF_DEV int f2iHw(float v) { return __float2int_rz(v); }
+// Spelled as a cast (one v_cvt_i32_f32_e32; HIP's __float2int_rz puts a redundant v_trunc_f32 in front of it), never as inline assembly: the compiler pads the
+// gfx950 VALU hazards only around instructions it can see.  (Round 5 blamed an asm spelling of this conversion for the batched update's run-to-run differences;
+// round 6 measured them in the running loop and found the packed-FP32 code of the projection responsible: profiles/r06_determinism.md.)
+BF_DEV int f2iHw(float v) { return (int)v; }
+// min / max of values that are never NaN as ONE v_med3_f32: fminf / fmaxf cost two instructions each under the IEEE mode (a v_max_f32 x, x, x to quiet a signalling
+// NaN in front of the v_min / v_max) - 72 of the batched update's ~990 vector instructions per operator slot
+// (finite outer bounds: with an infinity the compiler folds the median back into min / max)
+BF_DEV float minNoNan(float v, float hi) { return __builtin_amdgcn_fmed3f(v, -0x1p126f, hi); }
+BF_DEV float maxNoNan(float v, float lo) { return __builtin_amdgcn_fmed3f(v, lo, 0x1p126f); }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 BF_DEV v2f sp2(float a) { v2f r; r.x = a; r.y = a; return r; }
@@ -1335,7 +1338,7 @@ struct alignas(64) ApxPose {
 // roundf-then-truncate of the exact contract == nearest, ties away from zero: differs from RNE on exact .5 ties only (1 LSB, inside
 // the contract).  Both contracts clamp at 254 ((uint)254.5).
 template <bool RNE>
-BF_DEV uint32_t packByte(float v, uint32_t sel, uint32_t old) { return __builtin_amdgcn_cvt_pk_u8_f32(fminf(v, RNE ? 254.4f : 254.9f), sel, old); }
+BF_DEV uint32_t packByte(float v, uint32_t sel, uint32_t old) { return __builtin_amdgcn_cvt_pk_u8_f32(minNoNan(v, RNE ? 254.4f : 254.9f), sel, old); }      // (a NaN quotient - weight 1 de-integrated - is discarded by the caller)
 
 struct ApxCol { float nx0, ny0, zc; };       // per lane (column x, y) and pose: image-coordinate numerators at z = 0, R6 * xw + R7 * yw
 
@@ -1500,7 +1503,7 @@ BF_DEV void apxCompute(const ApxCam& c, const ApxPair& a, v2f& vS, v2f& vW, uint
             nA = packByte<RNE>(q.x, (uint32_t)k, nA); nB = packByte<RNE>(q.y, (uint32_t)k, nB);
         }
         const v2f s = pkfma(vS, vW, -sDe) * r;
-        float sA = s.x, sB = s.y, wA = fmaxf(0.0f, dd.x), wB = fmaxf(0.0f, dd.y);
+        float sA = s.x, sB = s.y, wA = maxNoNan(dd.x, 0.0f), wB = maxNoNan(dd.y, 0.0f);
         if (wA <= 0.001f) { sA = 0.0f; nA = 0u; wA = 0.0f; }
         if (wB <= 0.001f) { sB = 0.0f; nB = 0u; wB = 0.0f; }
         if (okDeA) { vS.x = sA; vW.x = wA; vCA = nA; }
@@ -1520,8 +1523,8 @@ BF_DEV void apxCompute(const ApxCam& c, const ApxPair& a, v2f& vS, v2f& vW, uint
             nA = packByte<RNE>(m.x, (uint32_t)k, nA); nB = packByte<RNE>(m.y, (uint32_t)k, nB);
         }
         const v2f s = pkfma(vS, vW, sIn) * r;
-        if (okInA) { vS.x = s.x; vW.x = fminf(c.weightMax, dd.x); vCA = nA; }
-        if (okInB) { vS.y = s.y; vW.y = fminf(c.weightMax, dd.y); vCB = nB; }
+        if (okInA) { vS.x = s.x; vW.x = minNoNan(dd.x, c.weightMax); vCA = nA; }
+        if (okInB) { vS.y = s.y; vW.y = minNoNan(dd.y, c.weightMax); vCB = nB; }
     }
 }
 
@@ -1774,8 +1777,8 @@ namespace {
 template <class T>
 int devAlloc(bf_scene* s, T** p, size_t count) {
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, count * sizeof(T));
-    if (e != hipSuccess) { set_error("hipMalloc(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e)); return BF_ERR_HIP; }
+    hipError_t e = BF_MALLOC(&q, count * sizeof(T));
+    if (e != hipSuccess) { set_error("BF_MALLOC(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e)); return BF_ERR_HIP; }
     s->allocations.push_back(q);
     *p = (T*)q;
     return BF_OK;
@@ -1842,7 +1845,7 @@ ApxPose makeApxPose(const Frame& f) {
 int probeCvt(bf_scene* s) {
     if (s->cvtRne >= 0) return BF_OK;
     uint32_t* d_out = nullptr;
-    BF_HIP_TRY(hipMalloc((void**)&d_out, 8 * sizeof(uint32_t)));
+    BF_HIP_TRY(BF_MALLOC((void**)&d_out, 8 * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_probe_cvt, dim3(1), dim3(64), 0, s->stream, d_out);
     uint32_t h[8];
     hipError_t e = hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, s->stream);
@@ -1974,7 +1977,7 @@ int runOperator(bf_scene* s, int kind, const Frame& f, const Frame& fo, const bf
     const size_t npx = (size_t)s->cam.m_imageWidth * s->cam.m_imageHeight;
     if (useTexel && !opTexels && s->texelPixels < npx) {
         BF_TRY_RC(syncAll(s));
-        for (int k = 0; k < bf_scene::NBMAX; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(hipMalloc((void**)&s->texel[k], npx * sizeof(uint2))); }
+        for (int k = 0; k < bf_scene::NBMAX; ++k) { if (s->texel[k]) (void)hipFree(s->texel[k]); s->texel[k] = nullptr; BF_HIP_TRY(BF_MALLOC((void**)&s->texel[k], npx * sizeof(uint2))); }
         s->texelPixels = npx;
     }
     // The preparation writes the operator's snapshot and list into buffer b (and, fast contract, the frame's texels into texel buffer b): not before the update
@@ -2067,7 +2070,7 @@ int ensureBatch(bf_scene* s) {
 constexpr uint32_t VERIFY_CAP = 1u << 16;
 int verifyBuffers(bf_scene* s) {
     if (s->vlog) return BF_OK;
-    for (int q = 0; q < 2; ++q) BF_HIP_TRY(hipMalloc((void**)&s->vshadow[q], (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel)));
+    for (int q = 0; q < 2; ++q) BF_HIP_TRY(BF_MALLOC((void**)&s->vshadow[q], (size_t)s->params.m_numSDFBlocks * VOX * sizeof(bf_voxel)));
     BF_HIP_TRY(hipHostMalloc((void**)&s->vlog, sizeof(VerifyLog) + (size_t)VERIFY_CAP * sizeof(VerifyRec), hipHostMallocCoherent));
     memset(s->vlog, 0, sizeof(VerifyLog));
     s->vlog->cap = VERIFY_CAP;
@@ -2098,7 +2101,7 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
             for (uint32_t k = 0; k < BMAX; ++k) {
                 if (s->btexel[q][k]) (void)hipFree(s->btexel[q][k]);
                 s->btexel[q][k] = nullptr;
-                if (q < s->NB) BF_HIP_TRY(hipMalloc((void**)&s->btexel[q][k], npx * sizeof(uint2)));
+                if (q < s->NB) BF_HIP_TRY(BF_MALLOC((void**)&s->btexel[q][k], npx * sizeof(uint2)));
             }
         s->btexelPixels = npx;
     }
@@ -2358,9 +2361,9 @@ int bf_scene_set_alloc_comm(bf_scene* s, bf_comm* comm, uint32_t capacity_keys) 
     uint32_t world = 1, rank = 0;
     BF_TRY_RC(bf_comm_world(comm, &world, &rank));
     const uint64_t rec = 8 + 8ull * capacity_keys;
-    BF_HIP_TRY(hipMalloc((void**)&s->d_allocSend, rec));
-    BF_HIP_TRY(hipMalloc((void**)&s->d_allocRecv, rec * world));
-    BF_HIP_TRY(hipMalloc((void**)&s->d_allocSlots, sizeof(uint32_t) * capacity_keys));
+    BF_HIP_TRY(BF_MALLOC((void**)&s->d_allocSend, rec));
+    BF_HIP_TRY(BF_MALLOC((void**)&s->d_allocRecv, rec * world));
+    BF_HIP_TRY(BF_MALLOC((void**)&s->d_allocSlots, sizeof(uint32_t) * capacity_keys));
     s->allocComm = comm; s->allocCap = capacity_keys;
     return BF_OK;
 }

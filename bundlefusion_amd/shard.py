@@ -67,6 +67,8 @@ class ChunkedRunner:
 
     def __init__(self, pipe, worker, feed, submap, rank=0, world=1, device=None, prefetch=True, comm=None):
         self.pipe, self.worker, self.feed, self.S = pipe, worker, feed, submap
+        if hasattr(pipe, "set_solve_lag"):
+            pipe.set_solve_lag(0)       # the replicated global half runs in the serial order on every rank (the pipeline's default is the lagged schedule)
         self.rank, self.world, self.device = rank, world, device
         self.comm = comm                # capi.Comm: the round's all-gather through the C ABI (bf_chunk_exchange: RCCL, or the host's callback) instead of torch.distributed
         self.next_frame = 0

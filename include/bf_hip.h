@@ -390,9 +390,6 @@ BF_API int bf_sift_create(uint32_t siftWidth, uint32_t siftHeight, uint32_t dept
                           uint32_t maxNumKeysPerImage, bf_sift** out);
 BF_API int bf_sift_destroy(bf_sift* s);
 BF_API int bf_sift_set_stream(bf_sift* s, void* hip_stream);
-/* 1 (default): the Gaussian pyramid is built with one launch per octave (all six levels of a tile in LDS); 0: one launch per level group (18 launches).  Same
- * pyramid bit for bit (SiftPyramid::BuildPyramid, SiftPyramid.cpp:82-145; FilterH / FilterV, ProgramCU.cu:159-264). */
-BF_API int bf_sift_set_fused_octaves(bf_sift* s, int enable);
 /* RunSIFT(d_intensity, d_depth) + GetKeyPointsAndDescriptorsCUDA(image, d_depth, max)  SiftGPU.cpp:72-101,267-272.
  * Asynchronous; *d_numKeys (device int) receives the feature count, or -1 for "too many keypoints".  */
 BF_API int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_depth, float* d_keyPoints, uint8_t* d_descs,

@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 # The bit-for-bit tests hold the product to the oracle, which is a host build's arithmetic: they run under `exact`, selected here for every scene
 # a test creates; the tests of the fast contract (tests/test_tsdf_fast_gpu.py and the fast legs of the pipeline tests) switch explicitly.
 os.environ.setdefault("BF_TSDF_ARITH", "exact")
+# Likewise the schedule: the pipeline's default runs the chunk solves on their own thread, applied ten frames later (the reference's optimiser thread, made
+# deterministic); the oracle loop and the compiled reference loop are the serial order, so the suite selects it.  The lagged schedule is tested against the oracle
+# loop under the same lag (tests/test_pipeline_gpu.py::test_lagged_solve_mode_vs_oracle_loop_with_the_same_lag) and measured by bench.py.
+os.environ.setdefault("BF_PIPELINE_SOLVE_LAG", "0")
 
 
 def pytest_configure(config):

@@ -32,27 +32,24 @@ def test_pyramid_bit_exact(gpu, oracle):
 
 
 @pytest.mark.parametrize("size", [(640, 480), (320, 240), (200, 136)])
-def test_pyramid_one_launch_per_octave_equals_one_per_level(gpu, oracle, size):
-    """k_octave (the default: all six levels of a tile in LDS, halos shrinking from level to level) against k_blur (one launch per level group) and the oracle: every
-    level of every octave bit for bit, incl. image sizes that are not a multiple of the 40 x 32 tile, and the features built on top."""
+def test_pyramid_at_other_image_sizes(gpu, oracle, size):
+    """Every level of every octave bit for bit against the oracle at image sizes other than 640 x 480 (incl. one that is no multiple of the blur kernel's tile), and a
+    second run of the same detector gives the same keys and descriptors.  (Round 5's one-launch-per-octave kernel measured slower - 366 vs 190 us - and was removed in round 6.)"""
     import torch
     W, H = size
     d, c, T, K = synth.scene_room(300, W, H)
     I = rgbx_to_intensity(c)
+    sift = gpu.capi.Sift(W, H, W, H)
     res = []
-    for fused in (True, False):
-        sift = gpu.capi.Sift(W, H, W, H)
-        sift.set_fused_octaves(fused)
+    for _ in range(2):
         keys = torch.zeros(1024, 4, device="cuda"); descs = torch.zeros(1024, 128, dtype=torch.uint8, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         sift.run(torch.from_numpy(I).cuda(), torch.from_numpy(d).cuda(), keys, descs, cnt)
         n = int(cnt.item())
-        res.append(([[sift.debug_level(o, a) for a in range(6)] for o in range(4)], n, keys.cpu().numpy()[:n], descs.cpu().numpy()[:n]))
+        res.append((n, keys.cpu().numpy()[:n], descs.cpu().numpy()[:n]))
     for o in range(4):
         for a in range(6):
-            assert np.array_equal(res[0][0][o][a].view(np.uint32), res[1][0][o][a].view(np.uint32)), (o, a)
-            if a in (0, 3, 5):
-                assert np.array_equal(res[0][0][o][a], oracle.sift_pyramid_level(I, o, a)), (o, a)
-    assert res[0][1] == res[1][1] > 10 and np.array_equal(res[0][2].view(np.uint32), res[1][2].view(np.uint32)) and np.array_equal(res[0][3], res[1][3])
+            assert np.array_equal(sift.debug_level(o, a), oracle.sift_pyramid_level(I, o, a)), (o, a)
+    assert res[0][0] == res[1][0] > 10 and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)) and np.array_equal(res[0][2], res[1][2])
 
 
 @pytest.mark.parametrize("k", [0, 200, 450, 777])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build a VARIANT of libbf_hip.so beside the product library, for A/B runs on one GPU box (select it with BF_LIB_PATH=<path>):
-    python tools/build_variant.py <name> [--packed] [--base <variant>] [-DMACRO ...]
-(--base: only tsdf.hip is compiled, the other objects are taken from that variant's build - for variants that differ in the volume kernels only)
+    python tools/build_variant.py <name> [--packed] [--base <variant> | --base product] [--only a.hip,b.hip] [-DMACRO ...]
+(--base: only the sources named by --only [default tsdf.hip] are compiled, the other objects are taken from that variant's build, or from the product's)
 writes bundlefusion_amd/lib/variants/libbf_hip_<name>.so.  --packed drops the library's `-packed-fp32-ops` feature switch (the compiler's default code)."""
 import os
 import subprocess
@@ -18,6 +18,9 @@ def main():
     base = None
     if "--base" in argv:
         i = argv.index("--base"); base = argv[i + 1]; del argv[i:i + 2]
+    only = ["tsdf.hip"]
+    if "--only" in argv:
+        i = argv.index("--only"); only = argv[i + 1].split(","); del argv[i:i + 2]
     extra = [a for a in argv if a != "--packed"]
     flags = [f for f in b.HIP_FLAGS if f != "-shared"]
     if "--packed" in sys.argv:
@@ -30,8 +33,8 @@ def main():
     procs, objs = [], []
     for src in srcs:
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
-        if base and os.path.basename(src) != "tsdf.hip":
-            objs.append(os.path.join(out_dir, "obj_" + base, os.path.basename(src) + ".o"))
+        if base and os.path.basename(src) not in only:
+            objs.append(os.path.join(b.LIB_DIR, "obj", os.path.basename(src) + ".o") if base == "product" else os.path.join(out_dir, "obj_" + base, os.path.basename(src) + ".o"))
             continue
         objs.append(obj)
         procs.append((src, subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + extra + ["-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -2,7 +2,7 @@
 """Turn the two PMC passes of `bench.py --pmc-out acc.json` (rocprofv3 --kernel-trace --pmc FETCH_SIZE, and --pmc WRITE_SIZE, each its
 own run) into profiles/rNN_pmc_tsdf_update.json: HBM bytes per visited SDF block for the plain and for the fused voxel-update kernel.
 
-    python tools/pmc_to_json.py <fetch_db> <write_db> <acc.json> <out.json> [out.md] [arith] [calibration.json]
+    python tools/pmc_to_json.py <fetch_db> <write_db> <acc.json> <out.json> [out.md] [arith] [calibration.json] [sq_db]
 
 The output file holds one entry per arithmetic contract of the voxel update ("fast" / "exact", bench.py --arith); a run adds or replaces its own.
 
@@ -24,6 +24,24 @@ def update_kernel_sha():
     a, b = src.index("// voxel update, column form: ONE WAVE per SDF block"), src.index("__global__ void k_probe_cvt")
     batch = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bundlefusion_amd", "csrc", "tsdf_batch.h")).read()
     return hashlib.sha256((src[a:b] + batch[batch.index("// the batch's voxel update, fast contract"):]).encode()).hexdigest()
+
+
+def build_flags_sha():
+    """sha256 of the library's compiler flags (bundlefusion_amd/build.py HIP_FLAGS): counters of a binary built with other flags (round 5: packed FP32 on / off)
+    are another kernel's counters even when the source is the same"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bundlefusion_amd.build import HIP_FLAGS
+    return hashlib.sha256(" ".join(HIP_FLAGS).encode()).hexdigest()
+
+
+def sq_totals(db):
+    """per counter: (launches, sum) over the union-list launches of the voxel update (an SQ pass: SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU ...)"""
+    c = sqlite3.connect(db)
+    out = {}
+    for name, counter, n, tot in c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+        if "k_update_batch" in name or "k_update_apx<2" in name or "k_update_col<2>" in name:
+            a = out.setdefault(counter, [0, 0.0]); a[0] += n; a[1] += tot
+    return out
 
 
 def totals(db, counter):
@@ -60,8 +78,16 @@ def main():
                   "hbm_bytes_per_launch": fb / max(n, 1) + wb / max(n2, 1), "visited_blocks": vis[k],
                   "hbm_bytes_per_visited_block": (fb + wb) / max(vis[k], 1)}
         lines.append("| voxel update, %s contract, `%s` | %d / %d | %.1f | %.1f | %.0f | %d |" % (arith, k, n, lau[k], fb / max(n, 1) / 1e6, wb / max(n2, 1) / 1e6, res[k]["hbm_bytes_per_visited_block"], 512 * 24 + 32))
+    sqdb = sys.argv[8] if len(sys.argv) > 8 and os.path.exists(sys.argv[8]) else None
+    if sqdb:          # the SQ pass of the same command: vector instructions issued and busy cycles of the union-list launches
+        sq = sq_totals(sqdb)
+        n = max(sq.get("SQ_INSTS_VALU", [0, 0.0])[0], 1)
+        res["sq"] = {"launches": n, "per_launch": {k: v[1] / max(v[0], 1) for k, v in sq.items()},
+                     "valu_wave_instructions_per_visited_block": sq.get("SQ_INSTS_VALU", [0, 0.0])[1] / max(vis["fused"], 1),
+                     "note": "SQ_INSTS_VALU counts wave-instructions; the cycle counters are in units of 4 cycles (MI355X_MICROARCH.md: SQ)"}
     allres = json.load(open(outp)) if os.path.exists(outp) else {}
     res["update_kernel_sha256"] = update_kernel_sha()
+    res["build_flags_sha256"] = build_flags_sha()
     allres[arith] = res
     json.dump(allres, open(outp, "w"), indent=1)
     text = "\n".join(lines)
