@@ -76,6 +76,8 @@ def main():
                     "(5000, the default: north_star's target stream - BASELINE configs[3] on one GPU, 2.5 loops + vertical sinusoid; 2000: configs[2], the stride-1 loop-closure "
                     "stream, the one tests/golden/oracle_stream_2000.npz holds the oracle's results for; 0: skip).  Rendering takes ~1 s of host time per 16 frames (5000 frames: ~5 minutes, untimed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-class-surface", action="store_true", help="skip the secondary block `class_surface` (the same window through the reference-named C++ classes of "
+                    "include/bundlefusion/bundlefusion.hpp, examples/class_surface_bench.cpp)")
     ap.add_argument("--cpu-frames", type=int, default=31, help="frames of the stream the CPU baseline processes (three local chunks: the last ten frames "
                     "run with the re-integration queue saturated, like the timed window of the GPU leg)")
     ap.add_argument("--launch-check", action="store_true", help="(CPU test of the launch path) rendezvous over gloo, print the world size, exit")
@@ -410,6 +412,11 @@ def main():
                                    "timed_ops": {k: serial["c1"][k] - serial["c0"][k] for k in serial["c1"]}, "roofline": roofline_of(serial),
                                    "note": "the same window with the chunk solves inside the frame that closes the chunk (BF_PIPELINE_SOLVE_LAG=0): the reference's single-threaded "
                                            "branch, the schedule of every earlier round's `value`, and the one the oracle loop / the compiled reference loop are compared in"}
+        if not args.no_class_surface and world == 1 and not args.pmc_out and not args.host:
+            try:
+                out["class_surface"] = class_surface_block(frames, pre, total, args, Kd, W, H, out["value"])
+            except Exception as e:      # noqa: BLE001 - reported in the line
+                out["class_surface"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames], feed[:args.cpu_frames], params, K, W, H, args.arith)
     del frames, feed
@@ -568,6 +575,36 @@ def long_stream_block(args, K, W, H):
             "last_over_first": round(last / first, 3), "frames_tracked": v_int, "ate_integrated_m": a_int, "ate_optimized_m": a_opt, "frames_with_optimized_pose": v_opt,
             "key_frames": (n - 1) // 10, "counters": {k: int(v) for k, v in c.items()}, "blocks_allocated": dbg["occupied"], "blocks_dropped": dbg["dropped"],
             "timing": "one continuous run over the whole stream, all frames resident in HBM before the clock starts (untimed: rendering, upload, clock warm-up); the pipeline is synchronised every 500 frames for the marks"}
+
+
+def class_surface_block(frames, pre, total, args, Kd, W, H, pipeline_fps):
+    """The same pre-roll + window through the drop-in CLASS surface: examples/class_surface_bench.cpp is DepthSensing.cpp's serial frame loop written against
+    include/bundlefusion/bundlefusion.hpp (CUDAImageManager / OnlineBundler / TrajectoryManager / CUDASceneRepHashSDF), one frame at a time, host frames in
+    (the class contract: RGBDSensor hands host buffers over), nothing in flight across frames.  Run twice: the calls as the reference issues them, and with the
+    wrapper's deferred batching (one bf_scene_run_batch per frame).  The executable is built by bundlefusion_amd.build (g++, no HIP headers)."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(ROOT, "bundlefusion_amd", "lib", "class_surface_bench")
+    if not os.path.exists(exe):
+        return {"error": "bundlefusion_amd/lib/class_surface_bench has not been built (python -m bundlefusion_amd.build)"}
+    res = {"loop": "examples/class_surface_bench.cpp: DepthSensing.cpp:966-1095 + :854-902 against the reference's class names; host frames per call (PCIe inclusive), one frame at a time",
+           "pipeline_value": pipeline_fps}
+    with tempfile.NamedTemporaryFile(prefix="bf_frames_", suffix=".bin", dir="/tmp", delete=True) as f:
+        for fr in frames[:total]:
+            d, c = fr[0], fr[1]
+            d = d.cpu().numpy() if hasattr(d, "cpu") else d
+            c = c.cpu().numpy() if hasattr(c, "cpu") else c
+            f.write(np.ascontiguousarray(d, np.float32).tobytes()); f.write(np.ascontiguousarray(c, np.uint8).tobytes())
+        f.flush()
+        for deferred in (0, 1):
+            r = subprocess.run([exe, f.name, str(W), str(H), str(total), str(pre), repr(args.voxel), str(args.buckets), str(args.blocks),
+                                repr(float(Kd["fx"])), repr(float(Kd["fy"])), repr(float(Kd["mx"])), repr(float(Kd["my"])), str(deferred)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            res["deferred_batching" if deferred else "as_the_reference_issues_them"] = json.loads(line[-1]) if line else {"error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+    best = res.get("deferred_batching", {}).get("value")
+    res["share_of_pipeline_value"] = (best / pipeline_fps) if (best and pipeline_fps) else None
+    return res
 
 
 def pmc_config(args):

@@ -88,6 +88,17 @@ def build_probe(force=False):
     return out
 
 
+def build_examples(force=False):
+    """bundlefusion_amd/lib/class_surface_bench: the reference's frame loop against include/bundlefusion/bundlefusion.hpp (plain g++, no HIP headers), run by bench.py"""
+    src = os.path.join(ROOT, "examples", "class_surface_bench.cpp")
+    exe = os.path.join(LIB_DIR, "class_surface_bench")
+    if force or _stale(exe, [src, os.path.join(ROOT, "include", "bundlefusion", "bundlefusion.hpp"), LIB_PATH]):
+        r = subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-L", LIB_DIR, "-lbf_hip", "-Wl,-rpath,$ORIGIN", "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("class_surface_bench build failed:\n" + r.stdout.decode())
+    return exe
+
+
 def build_oracle(force=False):
     """Compile the CPU oracle (oracle/*.cpp) into oracle/_build/liboracle.so via its Makefile."""
     args = ["make", "-s", "-C", ORACLE_DIR]
@@ -114,5 +125,6 @@ def build_ref():
 if __name__ == "__main__":
     print(build_lib(force="-f" in sys.argv, verbose=True))
     print(build_probe(force="-f" in sys.argv))
+    print(build_examples(force="-f" in sys.argv))
     print(build_oracle(force="-f" in sys.argv))
     print(build_ref())

@@ -1730,6 +1730,7 @@ struct bf_scene {
     bf_comm* allocComm = nullptr;
     uint32_t allocCap = 0;          // keys per rank and operator
     uint8_t *d_allocSend = nullptr, *d_allocRecv = nullptr; uint32_t* d_allocSlots = nullptr;
+    uint8_t *d_batchSend = nullptr, *d_batchRecv = nullptr;      // the same exchange for a whole batch: records {count, pad, {key, operator mask, pad}[allocCap]}
     int arith = BF_TSDF_ARITH_FAST; // bf_scene_set_arith / BF_TSDF_ARITH: fast (k_update_apx: the contract of the reference's own GPU build; default since round 4) or
                                     // exact (k_update_col: IEEE op by op, bit-comparable with a host build of the reference and with the oracle)
     int cvtRne = -1;                // what v_cvt_pk_u8_f32 does on this device: 1 nearest-even, 0 truncation, -1 not probed yet
@@ -2136,13 +2137,34 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
         m.texel = (fast && o.data.d_colorData && !o.d_texels) ? s->btexel[b][k] : nullptr;
         opsCount += o.kind == 2 ? 2u : 1u;
     }
+    const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
+    uint32_t world = 1, rank = 0;
+    if (s->allocComm) BF_TRY_RC(bf_comm_world(s->allocComm, &world, &rank));
+    uint2* texelOf[BMAX];
+    for (uint32_t k = 0; k < n; ++k) {
+        texelOf[k] = ma.op[k].texel;
+        if (s->allocComm && texelOf[k]) {          // the divided march covers a band of the image only: the operator's texel image is made by its own launch
+            hipLaunchKernelGGL(k_interleave, dim3(std::min<uint32_t>(div_up((uint32_t)npx, 256u), 2048u)), dim3(256), 0, ms, ops[k].data.d_depthData, reinterpret_cast<const uint32_t*>(ops[k].data.d_colorData), texelOf[k], (uint32_t)npx);
+            ma.op[k].texel = nullptr;
+        }
+    }
     const Frame fl = fin[n - 1];                // (the last pose set above is the last operator's: what a compactify / garbage collection behind the batch refers to)
     bc.cam = s->cam;
     bc.numBuckets = fl.numBuckets; bc.maxChain = fl.maxChain; bc.numSDFBlocks = fl.numSDFBlocks;
     bc.voxelSize = fl.voxelSize; bc.maxIntegrationDistance = fl.maxIntegrationDistance; bc.truncScale = fl.truncScale; bc.truncation = fl.truncation;
     bc.shardLo = fl.shardLo; bc.shardHi = fl.shardHi; bc.nOps = n;
-    const uint32_t tiles = div_up(s->cam.m_imageWidth, 8) * div_up(s->cam.m_imageHeight, 8);
-    hipLaunchKernelGGL(k_batch_march, dim3(div_up(tiles, 4), n), dim3(256), 0, ms, dv, s->bd, bc, ma);
+    bc.tile0 = (uint32_t)((uint64_t)tiles * rank / world); bc.tile1 = (uint32_t)((uint64_t)tiles * (rank + 1) / world);
+    if (bc.tile1 > bc.tile0) hipLaunchKernelGGL(k_batch_march, dim3(div_up(bc.tile1 - bc.tile0, 4), n), dim3(256), 0, ms, dv, s->bd, bc, ma);
+    if (s->allocComm) {          // one all-gather of the batch's {key, operator mask} lists (tsdf_batch.h)
+        const uint64_t brec = 8 + sizeof(BatchRec) * (uint64_t)s->allocCap;
+        hipLaunchKernelGGL(k_batch_pack, dim3(256), dim3(256), 0, ms, dv, s->bd, reinterpret_cast<uint32_t*>(s->d_batchSend), reinterpret_cast<BatchRec*>(s->d_batchSend + 8), s->allocCap);
+        hipLaunchKernelGGL(k_batch_pack_finish, dim3(1), dim3(1), 0, ms, s->bd);
+        BF_TRY_RC(bf_comm_all_gather(s->allocComm, s->d_batchSend, s->d_batchRecv, brec, ms));
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint8_t* base = s->d_batchRecv + brec * r;
+            hipLaunchKernelGGL(k_batch_ingest, dim3(256), dim3(256), 0, ms, dv, s->bd, reinterpret_cast<const uint32_t*>(base), reinterpret_cast<const BatchRec*>(base + 8), s->allocCap);
+        }
+    }
     // the table look-ups wait for whatever frees table entries (the last garbage collection); the march above does not
     if (s->overlap && s->barrierPending) { BF_HIP_TRY(hipStreamWaitEvent(ps, s->evBarrier, 0)); s->barrierPending = false; }
     hipLaunchKernelGGL(k_batch_bin, dim3(1024), dim3(256), 0, ps, dv, s->bd, bc);
@@ -2171,7 +2193,7 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
         ua.nOps = n;
         for (uint32_t k = 0; k < n; ++k) {
             ua.op[k].in = makeApxPose(fin[k]); ua.op[k].de = makeApxPose(fde[k]);
-            ua.op[k].tex = ops[k].d_texels ? reinterpret_cast<const uint2*>(ops[k].d_texels) : ma.op[k].texel;
+            ua.op[k].tex = ops[k].d_texels ? reinterpret_cast<const uint2*>(ops[k].d_texels) : texelOf[k];
             if (ops[k].data.d_colorData) ua.liveMask |= 3u << (2u * k);      // CUDASceneRepHashSDF.cu:441-448: no colour data, no update
         }
         const ApxCam ac = makeApxCam(fl);
@@ -2355,6 +2377,8 @@ int bf_scene_set_alloc_comm(bf_scene* s, bf_comm* comm, uint32_t capacity_keys) 
     if (s->d_allocSend) { (void)hipFree(s->d_allocSend); s->d_allocSend = nullptr; }
     if (s->d_allocRecv) { (void)hipFree(s->d_allocRecv); s->d_allocRecv = nullptr; }
     if (s->d_allocSlots) { (void)hipFree(s->d_allocSlots); s->d_allocSlots = nullptr; }
+    if (s->d_batchSend) { (void)hipFree(s->d_batchSend); s->d_batchSend = nullptr; }
+    if (s->d_batchRecv) { (void)hipFree(s->d_batchRecv); s->d_batchRecv = nullptr; }
     s->allocComm = nullptr; s->allocCap = 0;
     if (!comm) return BF_OK;
     BF_REQUIRE(capacity_keys >= 64, "capacity_keys too small");
@@ -2364,6 +2388,9 @@ int bf_scene_set_alloc_comm(bf_scene* s, bf_comm* comm, uint32_t capacity_keys) 
     BF_HIP_TRY(BF_MALLOC((void**)&s->d_allocSend, rec));
     BF_HIP_TRY(BF_MALLOC((void**)&s->d_allocRecv, rec * world));
     BF_HIP_TRY(BF_MALLOC((void**)&s->d_allocSlots, sizeof(uint32_t) * capacity_keys));
+    const uint64_t brec = 8 + sizeof(BatchRec) * (uint64_t)capacity_keys;
+    BF_HIP_TRY(BF_MALLOC((void**)&s->d_batchSend, brec));
+    BF_HIP_TRY(BF_MALLOC((void**)&s->d_batchRecv, brec * world));
     s->allocComm = comm; s->allocCap = capacity_keys;
     return BF_OK;
 }
@@ -2398,6 +2425,8 @@ int bf_scene_destroy(bf_scene* s) {
     if (s->d_allocSend) hipFree(s->d_allocSend);
     if (s->d_allocRecv) hipFree(s->d_allocRecv);
     if (s->d_allocSlots) hipFree(s->d_allocSlots);
+    if (s->d_batchSend) hipFree(s->d_batchSend);
+    if (s->d_batchRecv) hipFree(s->d_batchRecv);
     for (auto& e : s->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int b = 0; b < bf_scene::NBMAX; ++b) for (hipEvent_t e : {s->evPrep[b], s->evUpd[b]}) if (e) hipEventDestroy(e);
     for (hipEvent_t e : {s->evBarrier, s->evTmp}) if (e) hipEventDestroy(e);
@@ -2530,17 +2559,6 @@ int bf_scene_run_batch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n, co
         BF_REQUIRE(ops[k].data.d_depthData, "d_depthData is null");
     }
     s->cam = *cam; s->haveCam = true;
-    if (s->allocComm) {          // the divided march is a per-operator exchange: issue the operators one by one
-        for (uint32_t k = 0; k < n; ++k) {
-            const bf_scene_batch_op& o = ops[k];
-            if (o.wait_event) s->pendingEv = (hipEvent_t)o.wait_event;
-            if (o.d_texels) s->frameTexels = reinterpret_cast<const uint2*>(o.d_texels);
-            int rc = o.kind == 0 ? bf_scene_integrate(s, o.T0, &o.data, cam, nullptr) : o.kind == 1 ? bf_scene_deintegrate(s, o.T0, &o.data, cam, nullptr)
-                                                                                                     : bf_scene_reintegrate(s, o.T0, o.T1, &o.data, cam);
-            if (rc) return rc;
-        }
-        return BF_OK;
-    }
     return runBatch(s, ops, n);
 }
 

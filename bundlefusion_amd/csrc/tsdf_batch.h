@@ -31,6 +31,7 @@ struct BatchCommon {
     float voxelSize, maxIntegrationDistance, truncScale, truncation;
     uint32_t shardLo, shardHi;
     uint32_t nOps;
+    uint32_t tile0, tile1;          // the march's band of 8x8 pixel tiles (the whole image unless the march is divided over the ranks of a communicator)
 };
 // (kernel arguments read at a run-time index - an operator, a level, a job - are laid out so that no scalar load of them straddles a 64-byte line: see BatchUpdOpApx)
 struct alignas(64) BatchMarchOp { m44 T, Tinv; const float* depth; const uint32_t* color; uint2* texel; uint32_t marches; uint32_t pad; };
@@ -62,8 +63,46 @@ __global__ __launch_bounds__(256) void k_batch_march(Dev d, BatchDev bd, BatchCo
     BatchSink bs;
     bs.set = bd.set; bs.mask = bd.setMask; bs.opMask = bd.opMask; bs.list = bd.candList; bs.count = bd.candCount; bs.cap = bd.candCap; bs.flags = bd.flags; bs.op = op;
     TexelOut tx; tx.color = o.color; tx.texel = o.texel;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t tile = c.tile0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= c.tile1) return;          // wave-uniform
     marchTile<2>(d, f, o.depth, Collect{}, tx, bs, tile, o.marches != 0u, setAll[threadIdx.x >> 6], listAll[threadIdx.x >> 6]);
+}
+
+// ---------------------------------------------------------------------------------------
+// the march divided over the ranks of a communicator (bf_scene_set_alloc_comm): every rank marches its band of pixel tiles for ALL operators of the batch, packs the
+// distinct keys it met with their operator masks into a fixed-size record {count, {key, mask}[capacity]}, ONE all-gather per batch hands every rank every list, and
+// each rank claims all of them in its own key set (the union of the bands' sets with the masks OR-ed: exactly the set the undivided march builds); binning,
+// placement and the update follow unchanged.  (Round 5 fell back to one operator at a time here: one all-gather per operator.)
+// ---------------------------------------------------------------------------------------
+struct BatchRec { unsigned long long key; uint32_t mask, pad; };
+__global__ void k_batch_pack(Dev d, BatchDev bd, uint32_t* count, BatchRec* recs, uint32_t capacity) {
+    const uint32_t n = min(bd.candCount[0], bd.candCap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { count[0] = min(n, capacity); count[1] = 0u; if (n > capacity) atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW); }      // raised, never dropped silently
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = bd.candList[i];
+        if (i < capacity) { BatchRec r; r.key = bd.set[slot]; r.mask = bd.opMask[slot]; r.pad = 0u; recs[i] = r; }
+        bd.set[slot] = EMPTY64; bd.opMask[slot] = 0u;          // the set is refilled from the gathered lists (this rank's own among them)
+    }
+}
+__global__ void k_batch_pack_finish(BatchDev bd) { bd.candCount[0] = 0u; }
+__global__ void k_batch_ingest(Dev d, BatchDev bd, const uint32_t* count, const BatchRec* recs, uint32_t capacity) {
+    const uint32_t n = min(count[0], capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const BatchRec r = recs[i];
+        uint32_t slot = (uint32_t)((r.key * 0x9E3779B97F4A7C15ull) >> 40) & bd.setMask;
+        bool done = false;
+        for (uint32_t probe = 0; probe <= bd.setMask && !done; ++probe) {          // claimCandidate with a whole mask
+            const unsigned long long old = atomicCAS(&bd.set[slot], (unsigned long long)EMPTY64, r.key);
+            if (old == EMPTY64) {
+                const uint32_t pos = atomicAdd(bd.candCount, 1u);
+                if (pos < bd.candCap) bd.candList[pos] = slot;
+                else { atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_BIN_OVERFLOW); atomicOr(bd.flags, 2u); }
+            }
+            if (old == EMPTY64 || old == r.key) { atomicOr(&bd.opMask[slot], r.mask); done = true; }
+            slot = (slot + 1) & bd.setMask;
+        }
+        if (!done) atomicOr(&d.stats[ST_ERROR], (uint32_t)ERR_DEDUPE_FULL);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -640,7 +640,7 @@ struct DepthCameraData {
 class CUDASceneRepHashSDF {
 public:
     explicit CUDASceneRepHashSDF(const HashParams& params) { check(bf_scene_create(&params, &m_h)); }
-    ~CUDASceneRepHashSDF() { bf_scene_destroy(m_h); }
+    ~CUDASceneRepHashSDF() { try { flush(); } catch (...) {} bf_scene_destroy(m_h); }
     CUDASceneRepHashSDF(const CUDASceneRepHashSDF&) = delete;
     static HashParams parametersFromGlobalAppState(const GlobalAppState& gas) {          // CUDASceneRepHashSDF.h:39-59
         HashParams p;
@@ -656,29 +656,59 @@ public:
         return p;
     }
     void integrate(const mat4f& lastRigidTransform, const DepthCameraData& data, const DepthCameraParams& params, unsigned int* d_bitMask) {
-        check(bf_scene_integrate(m_h, lastRigidTransform.m, &data.d, &params, d_bitMask));
+        if (!m_deferred || d_bitMask) { flush(); check(bf_scene_integrate(m_h, lastRigidTransform.m, &data.d, &params, d_bitMask)); return; }
+        // deIntegrate(old) directly followed by integrate(new) of the same frame (DepthSensing.cpp:885-886) is one fused re-integration
+        if (!m_pending.empty() && m_pending.back().kind == 1 && m_pending.back().data.d_depthData == data.d.d_depthData && m_pending.back().data.d_colorData == data.d.d_colorData && m_lastWasDe) {
+            m_pending.back().kind = 2; std::memcpy(m_pending.back().T1, lastRigidTransform.m, 64); m_lastWasDe = false;
+        } else push(0, lastRigidTransform, data);
+        m_cam = params;
     }
     void deIntegrate(const mat4f& lastRigidTransform, const DepthCameraData& data, const DepthCameraParams& params, unsigned int* d_bitMask) {
-        check(bf_scene_deintegrate(m_h, lastRigidTransform.m, &data.d, &params, d_bitMask));
+        if (!m_deferred || d_bitMask) { flush(); check(bf_scene_deintegrate(m_h, lastRigidTransform.m, &data.d, &params, d_bitMask)); return; }
+        push(1, lastRigidTransform, data); m_lastWasDe = true;
+        m_cam = params;
     }
-    void garbageCollect() { check(bf_scene_garbage_collect(m_h)); }
-    void reset() { check(bf_scene_reset(m_h)); }
+    void garbageCollect() { flush(); check(bf_scene_garbage_collect(m_h)); }
+    void reset() { m_pending.clear(); check(bf_scene_reset(m_h)); }
     void setLastRigidTransformAndCompactify(const mat4f& lastRigidTransform, const DepthCameraParams& params) {
-        check(bf_scene_set_last_rigid_transform_and_compactify(m_h, lastRigidTransform.m, &params));
+        flush(); check(bf_scene_set_last_rigid_transform_and_compactify(m_h, lastRigidTransform.m, &params));
     }
-    void setLastRigidTransform(const mat4f& lastRigidTransform) { check(bf_scene_set_last_rigid_transform(m_h, lastRigidTransform.m)); }
+    void setLastRigidTransform(const mat4f& lastRigidTransform) { flush(); check(bf_scene_set_last_rigid_transform(m_h, lastRigidTransform.m)); }
     const mat4f getLastRigidTransform() { const HashParams p = getHashParams(); mat4f m; std::memcpy(m.m, p.m_rigidTransform, 64); return m; }
     void debugHash() {                                             // :179-314: the invariants the reference prints, from the device-side check
+        flush();
         uint32_t v[6]; check(bf_scene_debug_hash(m_h, v));
         std::printf("number of occupied entries: %u\nfree heap: %u\nduplicate keys: %u\nallocated and free: %u\nleaked blocks: %u\ndropped: %u\n", v[0], v[1], v[2], v[3], v[4], v[5]);
     }
-    HashDataStruct getHashData() { HashDataStruct d; check(bf_scene_get_hash_data(m_h, &d)); return d; }
-    HashParams getHashParams() { HashParams p; check(bf_scene_get_hash_params(m_h, &p)); return p; }
-    unsigned int getHeapFreeCount() { uint32_t n; check(bf_scene_get_heap_free_count(m_h, &n)); return n; }
-    unsigned int getNumIntegratedFrames() { uint32_t n; check(bf_scene_get_num_integrated_frames(m_h, &n)); return n; }
+    HashDataStruct getHashData() { flush(); HashDataStruct d; check(bf_scene_get_hash_data(m_h, &d)); return d; }
+    HashParams getHashParams() { flush(); HashParams p; check(bf_scene_get_hash_params(m_h, &p)); return p; }
+    unsigned int getHeapFreeCount() { flush(); uint32_t n; check(bf_scene_get_heap_free_count(m_h, &n)); return n; }
+    unsigned int getNumIntegratedFrames() { flush(); uint32_t n; check(bf_scene_get_num_integrated_frames(m_h, &n)); return n; }
     bf_scene* handle() const { return m_h; }
+
+    // MI355X addition (off by default: the calls above then execute one by one, like the reference's): integrate / deIntegrate calls are COLLECTED and issued as one
+    // bf_scene_run_batch - one ray march, one placement, one pass over the touched blocks for up to BF_SCENE_BATCH_MAX operators - when garbageCollect() or any
+    // accessor is called: a frame's reintegrate() pass (DepthSensing.cpp:854-902) becomes one batch, as in bf_pipeline.  Same volume bit for bit (the batch is the
+    // operators in call order).  Requires the DepthCameraData pointers to stay valid until that flush: true for frames of a CUDAImageManager constructed with
+    // storeFramesOnGPU = true (every frame resident), not for the reference's single staging buffer.
+    void setDeferredBatching(bool enable) { flush(); m_deferred = enable; }
+    void flush() {
+        if (m_pending.empty()) return;
+        std::vector<bf_scene_batch_op> ops; ops.swap(m_pending);
+        m_lastWasDe = false;
+        check(bf_scene_run_batch(m_h, ops.data(), (uint32_t)ops.size(), &m_cam));
+    }
 private:
+    void push(int kind, const mat4f& T, const DepthCameraData& data) {
+        if (m_pending.size() == BF_SCENE_BATCH_MAX) flush();
+        bf_scene_batch_op o; std::memset(&o, 0, sizeof o);
+        o.kind = kind; std::memcpy(o.T0, T.m, 64); std::memcpy(o.T1, T.m, 64); o.data = data.d;
+        m_pending.push_back(o); m_lastWasDe = false;
+    }
     bf_scene* m_h = nullptr;
+    bool m_deferred = false, m_lastWasDe = false;
+    std::vector<bf_scene_batch_op> m_pending;
+    DepthCameraParams m_cam;
 };
 
 // ---- consumers of the volume: CUDAMarchingCubesHashSDF (DepthSensing/CUDAMarchingCubesHashSDF.h:8-82) and CUDARayCastSDF (CUDARayCastSDF.h:14-101)

@@ -287,7 +287,8 @@ def test_config2_stream_2000_vs_oracle_fixture(gpu):
     assert len(marks) == len(om) == 4
     for m, o in zip(marks, om):
         assert m[0] == o[0] and m[3] == o[3] and m[4] == o[4], "solves at frame %d: product %s oracle %s" % (m[0], m[3:], list(o[3:5]))
-        assert abs(m[1] - o[1]) <= 0.01 * o[1] and abs(m[2] - o[2]) <= 0.01 * o[2], "TSDF operations at frame %d: product %s oracle %s" % (m[0], m[1:3], list(o[1:3]))
+        # (the schedule depends on the poses through the re-integration ranking's thresholds; measured: identical at every mark, rounds 5 and 6)
+        assert abs(m[1] - o[1]) <= 0.001 * o[1] and abs(m[2] - o[2]) <= 0.001 * o[2], "TSDF operations at frame %d: product %s oracle %s" % (m[0], m[1:3], list(o[1:3]))
     gt, ot = gp.integrated_trajectory(), fx["integrated"]
     gopt = gp.optimized_trajectory()[:NF]
     assert len(gt) == NF and np.isfinite(gt[:, 0, 0]).all() and np.isfinite(ot[:, 0, 0]).all(), "frames lost"
@@ -308,7 +309,8 @@ def test_config2_stream_2000_vs_oracle_fixture(gpu):
           % (marks[-1][3:], marks[-1][1:3], list(om[-1][1:3]), dev_int_t, dev_int_r, dev_opt_t, dev_opt_r, 1e3 * ate(gt), 1e3 * ate(ot), 1e3 * ate(gopt, vo), 1e3 * ate(oopt, vo),
              dbg["occupied"], dbg["dropped"]))
     assert abs(ate(gt) - ate(ot)) < 1e-3 and abs(ate(gopt, vo) - ate(oopt, vo)) < 1e-3          # north_star: ATE within 1 mm
-    assert dev_int_t < 1e-2 and dev_opt_t < 1e-2 and dev_int_r < 5e-3 and dev_opt_r < 5e-3
+    # twice the measured deviations (1.88e-3 m / 1.42e-3 integrated, 3.1e-4 m / 2.8e-4 optimised: profiles/r05_test_reports.txt)
+    assert dev_int_t < 4e-3 and dev_opt_t < 7e-4 and dev_int_r < 3e-3 and dev_opt_r < 6e-4
     assert dbg["duplicate_keys"] == 0 and dbg["leaked"] == 0 and dbg["dropped"] == 0
 
 
