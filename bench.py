@@ -555,7 +555,10 @@ def long_stream_block(args, K, W, H):
             pipe.synchronize(); torch.cuda.synchronize()
             now = time.perf_counter()
             first_k = (k // 500) * 500
-            marks.append({"frames": "%d-%d" % (first_k, k), "fps": round((k + 1 - first_k) / (now - tm), 1)})
+            hp = pipe.host_profile(reset=True); vp = pipe.volume_thread_profile(reset=True)
+            marks.append({"frames": "%d-%d" % (first_k, k), "fps": round((k + 1 - first_k) / (now - tm), 1),
+                          "host_thread_ms_per_frame": {kk: round(1e3 * v / max(hp["frames"], 1.0), 3) for kk, v in hp.items() if kk != "frames"},      # where the calling thread's time goes as the global problem grows
+                          "volume_thread_busy_share": round(vp["busy_seconds"] / max(now - tm, 1e-9), 3)})
             tm = now
     t_run = time.perf_counter() - t0
     done = n

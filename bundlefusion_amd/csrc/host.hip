@@ -1923,7 +1923,6 @@ struct bf_pipeline {
     hipStream_t sSolve = nullptr;   // stream of the lagged solves (bf_pipeline_set_solve_lag)
     hipStream_t sIngest = nullptr;  // the ingest filters of frame n + 1 run beside the detection of frame n (several input sets in the image manager)
     hipStream_t sPair[2] = {nullptr, nullptr};      // pair stages of consecutive frames side by side (bf_online_bundler_set_pair_streams)
-    hipStream_t sPairStage[2] = {nullptr, nullptr}; // BF_PIPELINE_PAIR_STREAMS=1
     static const int NEV = 8;
     hipEvent_t evIngest[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring, indexed by frame
     // The volume stream is fed by its own host thread: the main thread decides WHAT to integrate (TrajectoryManager lists, poses)
@@ -2309,12 +2308,6 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // odd frames detect on a second queue (bf_online_bundler_set_second_detect_stream): the first of the two pair streams.  (The pair stages of consecutive frames
         // on those two streams - bf_online_bundler_set_pair_streams, round 4 - lost: 659 vs 697 frames/s, gpurun r04c; the mode is reachable through that call only.)
         BF_TRY(bf_online_bundler_set_second_detect_stream(p->ob, p->sPair[0])); p->sDetect2 = p->sPair[0];
-        if (const char* e = getenv("BF_PIPELINE_PAIR_STREAMS")) if (atoi(e) != 0) {      // experiment: the pair stages (match .. dense verify) of consecutive frames on two queues of their own
-            int least = 0, greatest = 0;
-            BF_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            for (auto& st : p->sPairStage) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
-            BF_TRY(bf_online_bundler_set_pair_streams(p->ob, p->sPairStage[0], p->sPairStage[1]));
-        }
     }
     BF_TRY(bf_scene_set_stream(p->scene, p->sVolume));
     BF_TRY(bf_scene_set_overlap(p->scene, 1));        // frames are ordered against the volume by evIngest / host synchronisation
@@ -2366,7 +2359,6 @@ int bf_pipeline_destroy(bf_pipeline* p) {
     if (p->sSolve) (void)hipStreamDestroy(p->sSolve);
     if (p->sIngest) (void)hipStreamDestroy(p->sIngest);
     for (auto st : p->sPair) if (st) (void)hipStreamDestroy(st);
-    for (auto st : p->sPairStage) if (st) (void)hipStreamDestroy(st);
     delete p;
     return BF_OK;
 }
@@ -2436,7 +2428,6 @@ int bf_pipeline_synchronize(bf_pipeline* p) {
     BF_HIP_TRY(hipStreamSynchronize(p->sIngest));
     BF_HIP_TRY(hipStreamSynchronize(p->sDetect));
     for (auto st : p->sPair) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
-    for (auto st : p->sPairStage) if (st) BF_HIP_TRY(hipStreamSynchronize(st));
     BF_HIP_TRY(hipStreamSynchronize(p->sBundle));
     if (p->sSolve) BF_HIP_TRY(hipStreamSynchronize(p->sSolve));
     BF_HIP_TRY(hipStreamSynchronize(p->sVolume));

@@ -90,9 +90,6 @@ BF_DEV int loadAgent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXE
 BF_DEV float loadAgentF(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchScratch sc) {
-#ifdef BF_VAR_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
@@ -484,9 +481,6 @@ struct FilterArgs {
 // LDS (the <= 128 raw matches' key positions and back-projected points are staged once), and the independent pieces of each
 // step (distance checks, residuals, sort ranks, the two covariance solves) are spread over lanes.
 __global__ __launch_bounds__(64) void k_filter_kabsch(FilterArgs a) {
-#ifdef BF_VAR_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     const uint32_t tid = threadIdx.x;
@@ -643,9 +637,6 @@ BF_DEV float warpTree32(const float* v, int n) {
 struct AreaArgs { const Key* keys; uint32_t curFrame, startFrame; int* numFilt; const uint2* fidx; m44 Kinv; float areaThresh; };
 
 __global__ __launch_bounds__(64) void k_filter_surface_area(AreaArgs a) {
-#ifdef BF_VAR_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     const int n = min(a.numFilt[prev], MAX_FILT);
@@ -842,9 +833,6 @@ BF_DEV bool denseVerifyPair(const VerifyArgs& a, const bf_cached_frame& fi, cons
 }
 
 __global__ __launch_bounds__(DV_THREADS) void k_filter_dense_verify(VerifyArgs a) {
-#ifdef BF_VAR_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const uint32_t prev = blockIdx.x + a.startFrame;
     if (prev == a.curFrame) return;
     if (a.numFilt[prev] <= 0) return;

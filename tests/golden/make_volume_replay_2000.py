@@ -4,7 +4,7 @@ configs[2] stream (S2 room, stride 1, 640x480 @4 mm) - digests of the whole volu
 Why a replay: the product's own 2000-frame run differs from the oracle's in its poses by ~2 mm (the solver tolerance, tests/test_pipeline_baseline_gpu.py), so its
 volume cannot be compared byte for byte with an oracle volume built from the oracle's poses.  Here BOTH sides execute the SAME operator list - which frame, which
 pose(s), in which order, with a garbage collection per frame - so the volume operators are held to the oracle bit for bit AT LENGTH (the short suites stop at a
-few dozen operators): 2000 integrations, 5955 re-integrations (de-integrate at the old pose + integrate at the new one), 2000 garbage collections, the loop
+few dozen operators): 2000 integrations, 5835 re-integrations (de-integrate at the old pose + integrate at the new one), 2000 garbage collections, the loop
 closing at frame 1800 on top of voxels integrated 1800 frames earlier.
 
 The schedule (deterministic, from the oracle's own trajectories in tests/golden/oracle_stream_2000.npz; `schedule()` below is shared with the GPU test):
@@ -13,7 +13,7 @@ The schedule (deterministic, from the oracle's own trajectories in tests/golden/
             garbageCollect (:897); integrate(k) at integrated[k] (:1051-1061).
 The frames are the rendered depth / colour images themselves (no ingest filter: the volume operators take any depth image).
 
-    python tests/golden/make_volume_replay_2000.py [out.npz] [frames] [threads]          (~60-90 minutes on 8 cores, ~25 GB of host memory)
+    python tests/golden/make_volume_replay_2000.py [out.npz] [frames] [threads]          (40 minutes with 6 threads, ~25 GB of host memory)
 """
 import hashlib
 import os

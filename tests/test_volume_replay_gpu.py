@@ -1,4 +1,4 @@
-"""GPU parity test (-m gpu) of the volume operators AT LENGTH: the 2000-frame operator schedule of tests/golden/make_volume_replay_2000.py (2000 integrations, ~6000
+"""GPU parity test (-m gpu) of the volume operators AT LENGTH: the 2000-frame operator schedule of tests/golden/make_volume_replay_2000.py (2000 integrations, 5835
 re-integrations, a garbage collection per frame, on the BASELINE configs[2] stream at 640x480 @4 mm) through bf_scene_run_batch under the exact contract, the whole
 volume - block set, every voxel byte, free counter - against the ORACLE's digests at frames 500 / 1000 / 1500 / 2000 (CUDASceneRepHashSDF.h:65-155,
 DepthSensing.cpp:854-902).  The product's own 2000-frame loop is compared with the oracle loop in tests/test_pipeline_baseline_gpu.py (trajectories, schedule);

@@ -40,7 +40,7 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
     bench_env)      # the driver's window under environment variants: ENVS="A=1;B=2 C=3" runs once per ';'-separated assignment list
       IFS=';' read -ra VARIANTS <<< "${ENVS:-}"
       for V in "${VARIANTS[@]}"; do
-        TAG=$(echo "$V" | tr ' =' '__')
+        TAG=$(echo "$V" | tr ' =/' '___' | tail -c 80)
         (cd "$ROOT" && env $V timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 $BENCH_ARGS > "$OUT/bench_env_$TAG.json" 2> "$OUT/bench_env_$TAG.err"; python -c "
 import json; j=json.load(open('$OUT/bench_env_$TAG.json')); print('$V', round(j['value'],1), 'fps', j['config']['host_thread_ms_per_frame'])"; tail -1 "$OUT/bench_env_$TAG.err")
       done ;;
@@ -82,7 +82,7 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
     racehunt)    # how often does a fresh process produce another trajectory?  RH_ENVS="X=0;BF_PIPELINE_LOOKAHEAD=0" x RH_N processes each
       IFS=';' read -ra RV <<< "${RH_ENVS:-X=0}"
       for V in "${RV[@]}"; do
-        TAG=$(echo "$V" | tr ' =' '__')
+        TAG=$(echo "$V" | tr ' =/' '___' | tail -c 80)
         rm -f "$OUT/race_$TAG.txt"
         for i in $(seq 1 ${RH_N:-8}); do
           (cd "$ROOT" && env $V timeout 120 python tools/first_run_check.py ${RH_PATTERN:-12345678} 2>&1 | grep -v amdgpu.ids | tail -1 >> "$OUT/race_$TAG.txt")
@@ -92,7 +92,7 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
     det_bisect)  # the fast batched configuration only, under environment variants (ENVS="A=1;B=2"): which overlap a run-to-run difference needs
       IFS=";" read -ra VARIANTS <<< "${DET_ENVS:-X=0}"
       for V in "${VARIANTS[@]}"; do
-        TAG=$(echo "$V" | tr ' =' '__')
+        TAG=$(echo "$V" | tr ' =/' '___' | tail -c 80)
         (cd "$ROOT" && env $V timeout 200 python tools/determinism_check.py ${DET_RUNS:-3} fast-batched 2>&1 | grep -v amdgpu.ids > "$OUT/det_$TAG.txt"; echo "== $V"; grep -E "^  block|differing|stale-read" "$OUT/det_$TAG.txt" | cut -c1-300 | head -14; tail -1 "$OUT/det_$TAG.txt")
       done ;;
     hiptrace)   # host side: HIP API calls per thread (totals) and a merged API + kernel window (no counters: --pmc must not be combined with the hip trace)
