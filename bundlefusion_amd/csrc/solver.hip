@@ -72,10 +72,21 @@ struct Dev {
 BF_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 BF_DEV bool validCorr(const bf_entry_j& c) { return c.imgIdx_i != 0xFFFFFFFFu; }
 
+__global__ void k_solve_begin(Dev d) {          // flags and the grid barrier's words cleared (one launch instead of two memsets)
+    for (uint32_t k = threadIdx.x; k < (uint32_t)FL_COUNT; k += blockDim.x) d.flags[k] = 0;
+    for (uint32_t k = threadIdx.x; k < 32u; k += blockDim.x) d.gridBar[k] = 0;
+}
+
 // ------------------------------------------------------------------ poses -> matrices (:1114-1121)
-__global__ void k_poses(Dev d) {
-    if (d.flags[FL_DONE]) return;
+// ... and the iteration's structure counters cleared in the same launch (four hipMemsetAsync per Gauss-Newton iteration until round 6: the chunk's solve job is
+// ~120 dependent launches, and what it costs is launches, not kernel time - profiles/r06_loop_schedule.md)
+__global__ void k_poses(Dev d, uint32_t numKeys, int useDense) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t k = i; k < numKeys; k += gridDim.x * blockDim.x) {
+        d.keyCount[k] = 0u; d.cursor[k] = 0u;
+        if (useDense) { d.denseRaw[k] = 0u; d.keyPair[k] = 0u; }
+    }
+    if (d.flags[FL_DONE]) return;
     if (i >= d.N) return;
     const m44 M = poseToMatrix(ld3(d.xRot + 3 * i), ld3(d.xTrans + 3 * i));
     d.T[i] = M;
@@ -1129,8 +1140,7 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
     c.usePairwise = usePairwise;
     hipStream_t st = s->stream;
     const size_t M = (size_t)N * N;
-    BF_HIP_TRY(hipMemsetAsync(d.flags, 0, FL_COUNT * sizeof(int), st));
-    BF_HIP_TRY(hipMemsetAsync(d.gridBar, 0, 32 * sizeof(int), st));
+    hipLaunchKernelGGL(k_solve_begin, dim3(1), dim3(64), 0, st, d);
     const bool record = s->cfg.recordConvergence != 0;
     if (record) hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, st, d, wS[0], 0u, 0);
     bool anyDense = false;
@@ -1138,12 +1148,8 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
         c.wSparse = wS[it]; c.wDepth = wDD[it]; c.wColor = wDC[it];
         const int useDense = (d_cache != nullptr) && (c.wDepth > 0.0f || c.wColor > 0.0f);
         anyDense |= useDense != 0;
-        hipLaunchKernelGGL(k_poses, dim3(div_up(N, 64)), dim3(64), 0, st, d);
-        BF_HIP_TRY(hipMemsetAsync(d.keyCount, 0, M * 4, st));
-        BF_HIP_TRY(hipMemsetAsync(d.cursor, 0, M * 4, st));
+        hipLaunchKernelGGL(k_poses, dim3(std::max<uint32_t>(div_up(N, 256), std::min<uint32_t>(div_up((uint32_t)M, 256), 128u))), dim3(256), 0, st, d, (uint32_t)M, useDense);
         if (useDense) {
-            BF_HIP_TRY(hipMemsetAsync(d.denseRaw, 0, M * 4, st));
-            BF_HIP_TRY(hipMemsetAsync(d.keyPair, 0, M * 4, st));
             const dim3 grid = usePairwise ? dim3(N, N) : dim3(N - 1, 1);
             hipLaunchKernelGGL(k_dense_overlap, grid, dim3(512), 0, st, d, c);
         }
