@@ -10,7 +10,7 @@ executed: the fixture holds the trajectories, the validity of every frame, the k
 tests/test_pipeline_baseline_gpu.py::test_config2_stream_2000_vs_oracle_fixture holds the product to it (same frames valid, same key frames, same operation
 schedule per 500 frames, |delta ATE| < 1 mm, per-pose bound).
 
-    python tests/golden/make_oracle_stream_2000.py [out.npz] [frames]          (~40-60 minutes on 8 cores)
+    python tests/golden/make_oracle_stream_2000.py [out.npz] [frames] [bob]          (~40-60 minutes on 8 cores; `... oracle_stream_5000.npz 5000 0.3` writes the 5000-frame fixture)
 """
 import os
 import sys
@@ -34,7 +34,7 @@ def params(nf=NF):
     return gas, gbs
 
 
-def run(nf=NF, verbose=True):
+def run(nf=NF, verbose=True, bob=0.0):
     from bundlefusion_amd import synth
     from bundlefusion_amd.capi import intrinsics_matrix
     from tests.oracle_pipeline import OraclePipeline
@@ -46,7 +46,7 @@ def run(nf=NF, verbose=True):
     poses, marks = [], []
     t0 = time.time()
     for c0 in range(0, nf, 100):
-        part = synth.render_frames(range(c0, min(c0 + 100, nf)), W, H)
+        part = synth.render_frames(range(c0, min(c0 + 100, nf)), W, H, bob=bob)
         for d, c, T, _ in part:
             op.process_frame(d, c)
             op.frames[-1] = None                                      # the filtered frame is only needed by the (logged) volume operators
@@ -68,6 +68,8 @@ def run(nf=NF, verbose=True):
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "oracle_stream_2000.npz")
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else NF
-    r = run(nf)
+    bob = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0          # 0.3: BASELINE configs[3] (5000 frames: 2.5 loops + vertical sinusoid) -> oracle_stream_5000.npz
+    r = run(nf, bob=bob)
+    r["bob"] = np.float64(bob)
     np.savez_compressed(out, **r)
     print({k: (v if np.ndim(v) == 0 else np.shape(v)) for k, v in r.items()}, "->", out)
