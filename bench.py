@@ -304,12 +304,17 @@ def main():
         traffic = pmc_traffic(args, L["arith"], L["vis_plain"], L["vis_fused"], n_launch)
         # the batched fast update applies ~11 operators to a block per trip through HBM: ~900 vector instructions per block and operator slot against 12 KB of
         # traffic - it is bound by vector-instruction issue, not by bytes.  Instruction roofline: wave-instructions issued (SQ_INSTS_VALU of the
-        # committed SQ pass, per visited block) x 2 issue cycles / (launch time x clock x SIMDs); transcendentals (v_rcp_f32, 32 of ~900 per slot) issue at a
-        # quarter of that rate, so this is a lower bound of the issue share.
-        valu_insts = pmc_valu(args, L["arith"], L["vis_fused"], n_launch) if batched else None
-        simd_cycles = avg_kernel_s * CLOCK_HZ * SIMDS
-        valu = None if not valu_insts else {"wave_instructions_per_launch": valu_insts, "issue_cycles_per_full_rate_instruction": 2, "simd_cycles_available_per_launch": simd_cycles,
-                                           "frac": 2.0 * valu_insts / simd_cycles if simd_cycles > 0 else None, "unit": "share of vector issue cycles (lower bound: quarter-rate instructions counted at full rate)"}
+        # committed SQ pass, per visited block) and the cycles they were active (SQ_ACTIVE_INST_VALU: 4.2 cycles per instruction measured on this kernel - the guide's
+        # 2-cycle full-rate figure is reported beside it as the lower bound) over launch time x clock x SIMDs.
+        vi = pmc_valu(args, L["arith"], L["vis_fused"], n_launch) if batched else None
+        reserve = int(os.environ.get("BF_VOLUME_CU_RESERVE", "32"))          # the volume stream's launches run on all but `reserve` compute units (bf_pipeline_create)
+        simds = SIMDS - 4 * max(0, min(reserve, 255))
+        simd_cycles = avg_kernel_s * CLOCK_HZ * simds
+        valu = None if not vi else {"wave_instructions_per_launch": vi[0], "active_cycles_per_launch": vi[1], "cycles_per_instruction_measured": vi[1] / vi[0] if vi[0] else None,
+                                    "simds": simds, "simd_cycles_available_per_launch": simd_cycles,
+                                    "frac": vi[1] / simd_cycles if simd_cycles > 0 else None,                    # measured: SQ_ACTIVE_INST_VALU (x 4 cycles) per visited block x blocks visited here
+                                    "frac_at_2_cycles_per_instruction": 2.0 * vi[0] / simd_cycles if simd_cycles > 0 else None,      # the guide's full-rate issue cost: a lower bound
+                                    "unit": "share of the vector-issue cycles of the SIMDs the launch may use"}
         if batched:
             kern = ("k_update_batch_apx (tsdf_batch.h): one wave per block of the batch's union list, voxels loaded once, the batch's operators applied in order from registers"
                     if L["arith"] == "fast" else "k_update_batch_col (tsdf_batch.h): the batch's operators one after the other per block, exact contract")
@@ -643,7 +648,7 @@ def pmc_valu(args, arith, vis_fused, n_launch):
     from tools.pmc_to_json import update_kernel_sha, build_flags_sha
     if pmc.get("update_kernel_sha256") != update_kernel_sha() or pmc.get("build_flags_sha256") != build_flags_sha():
         return None
-    return vis_fused * pmc["sq"]["valu_wave_instructions_per_visited_block"] / n_launch
+    return (vis_fused * pmc["sq"]["valu_wave_instructions_per_visited_block"] / n_launch, vis_fused * pmc["sq"].get("valu_active_cycles_per_visited_block", 0.0) / n_launch)
 
 
 def cpu_baseline(frames, feed, params, K, W, H, arith):

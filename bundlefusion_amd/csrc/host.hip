@@ -2291,8 +2291,9 @@ int bf_pipeline_create(const bf_global_app_state* gas, const bf_global_bundling_
         // The HIP runtime maps streams onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, four by default) by priority class and creation order, and streams
         // that share a queue serialise.  Which streams exist - even idle ones - therefore decides the frame rate: measured on one box (gpurun r04i - r04k) 710
         // frames/s with exactly this set in exactly this order (allocation [the scene's], bundling, volume, detection, solve, ingest, pair x 2), 440 - 660 with
-        // any other set tried (a second preparation stream, no solve / pair streams, the ingest on the bundling stream, 2 - 16 queues requested).  The solve
-        // and pair streams are used by the lagged-solve / side-by-side pair modes only; they are created regardless, as placeholders in that order.
+        // any other set tried (a second preparation stream, no solve / pair streams, the ingest on the bundling stream, 2 - 16 queues requested).  Round 6, with the
+        // volume on a masked stream and the lagged schedule: eight creation orders of the five streams below gave 937 - 1037 frames/s, this one 985 - 1005 (gpurun r06m / r06n:
+        // within the spread; whichever streams share a queue, the waits move and their sum stays - profiles/r06_loop_schedule.md).
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sSolve, hipStreamNonBlocking, greatest));
         BF_HIP_TRY(hipStreamCreateWithPriority(&p->sIngest, hipStreamNonBlocking, greatest));
         for (auto& st : p->sPair) BF_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));

@@ -65,7 +65,7 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
         done
         rm -rf /tmp/r_pmc_SQ          # third pass: the vector instructions the update issues and its busy cycles (the kernel is VALU-bound: VERDICT round 5)
         (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d /tmp/r_pmc_SQ -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_SQ.json > /dev/null 2>&1)
-        python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A "${PMC_CAL:-$ROOT/profiles/r05_pmc_calibration.json}" "$(db /tmp/r_pmc_SQ)"
+        python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A "${PMC_CAL:-$ROOT/profiles/r06_pmc_calibration.json}" "$(db /tmp/r_pmc_SQ)"
       done ;;
     pltrace)    # the frame loop's own per-frame trace (BF_PIPELINE_TRACE): host enqueue / wait times and the GPU times of detection end, chain begin / end, untraced otherwise
       rm -f "$OUT/pltrace.txt"

@@ -84,6 +84,7 @@ def main():
         n = max(sq.get("SQ_INSTS_VALU", [0, 0.0])[0], 1)
         res["sq"] = {"launches": n, "per_launch": {k: v[1] / max(v[0], 1) for k, v in sq.items()},
                      "valu_wave_instructions_per_visited_block": sq.get("SQ_INSTS_VALU", [0, 0.0])[1] / max(vis["fused"], 1),
+                     "valu_active_cycles_per_visited_block": 4.0 * sq.get("SQ_ACTIVE_INST_VALU", [0, 0.0])[1] / max(vis["fused"], 1),      # (the counter is in units of 4 cycles)
                      "note": "SQ_INSTS_VALU counts wave-instructions; the cycle counters are in units of 4 cycles (MI355X_MICROARCH.md: SQ)"}
     allres = json.load(open(outp)) if os.path.exists(outp) else {}
     res["update_kernel_sha256"] = update_kernel_sha()
