@@ -285,7 +285,7 @@ BF_API int bf_online_bundler_process_frame(bf_online_bundler* ob, uint32_t frame
  * valid complete transform, the TrajectoryManager's optimised poses, the tracking-lost flag - becomes visible exactly when frame
  * b + L enters processInput (_begin) / its re-integration scheduling (_apply_lagged_solve, which a host loop calls before it consults
  * the TrajectoryManager for that frame), and at the first iteration past the end of the sequence at the latest.  Results are a function
- * of (input, L): reproducible, and comparable with the oracle loop under the same L.  L = 0 (default): the serial order. */
+ * of (input, L): reproducible, and comparable with the oracle loop under the same L.  L = 0 (the online bundler's default; bf_pipeline_create chooses 10): the serial order. */
 /* Pair stages side by side: with two streams of the caller's, the staged detection of frame k is committed and its per-pair kernels (match, Kabsch filter,
  * surface-area filter, dense verification - each pair depends on its two images only) run on stream k & 1, into the sift manager's result set k & 1
  * (bf_siftmgr_set_pair_stage), while frame k - 1's are still running on the other stream; the bundling stream carries the short commit stage (which
@@ -341,8 +341,9 @@ BF_API int bf_pipeline_set_volume_shard(bf_pipeline* p, uint32_t rank, uint32_t 
  * (enable = 0), which stays available for comparison. */
 BF_API int bf_pipeline_set_volume_batching(bf_pipeline* p, int enable);
 /* Lagged solve for the whole loop (bf_online_bundler_set_solve_lag on a stream of the pipeline's): the chunk solves leave the frame
- * loop's critical path and are applied `lag` frames after the frame that closed the chunk.  0 = serial order (default; also
- * BF_PIPELINE_SOLVE_LAG in the environment).  Only between frames. */
+ * loop's critical path and are applied `lag` frames after the frame that closed the chunk.  bf_pipeline_create sets lag = min(10, s_submapSize)
+ * (the reference's optimiser thread, FriedLiver.cpp:112-143, with a defined hand-over; round 6); 0 = the serial order of the reference's single-threaded
+ * branch (also BF_PIPELINE_SOLVE_LAG=0 in the environment).  Only between frames. */
 /* measurement aid: seconds the volume thread spent issuing TSDF operators (HIP API calls) and the number of operators, since the last reset */
 BF_API int bf_pipeline_get_volume_thread_profile(bf_pipeline* p, double* busySeconds, double* commands, int reset);
 BF_API int bf_pipeline_set_solve_lag(bf_pipeline* p, uint32_t lag);

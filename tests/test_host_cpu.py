@@ -394,38 +394,45 @@ def test_committed_bench_line_follows_the_contract():
     assert line["unit"] == "frames/s" and line["scaling"] in ("weak", "strong") and "workload" in line["config"] and "model" not in line["config"]
     assert abs(line["value"] - line["n_gpus"] * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
     r = line["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is None or r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
 
 
-def test_round5_bench_line_and_pmc_file_are_consistent():
-    """profiles/r05_bench_driver.json (the driver's invocation on the MI355X box) against the contract and against the PMC file its `traffic` comes from: the
-    counters were collected on the update kernels' CURRENT source (bench.py reports no traffic otherwise), with the calibrated factor on record."""
+def test_round6_bench_line_and_pmc_file_are_consistent():
+    """profiles/r06_bench_driver.json (the driver's invocation on the MI355X box) against the contract and against the PMC file its `traffic` and `valu` figures come
+    from: the counters were collected on the update kernels' CURRENT source AND build flags (bench.py reports neither otherwise), with the calibrated factor on record."""
     import json
     import sys
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_driver.json")).read().strip().split("\n")[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_driver.json")).read().strip().split("\n")[-1])
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(line[key], typ), key
     assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["vs_baseline"] is None
     assert abs(line["value"] - 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    assert line["config"]["solve_lag"] == 10                    # the library's default schedule (the reference's optimiser thread, deterministic)
     r = line["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
+    assert r["bound"] == "valu" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
     assert 0.0 < r["frac"] < 1.0 and r["frac_per_operator"] > r["frac"] and 0.0 < r["frac_beyond_l3"] < 1.0
     assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
-    assert line["lagged_solve"]["solve_lag_frames"] == 10 and line["lagged_solve"]["value"] > 0
+    v = r["valu"]
+    assert v is not None and 0.2 < v["frac_at_2_cycles_per_instruction"] < v["frac"] < 1.0 and 3.0 < v["cycles_per_instruction_measured"] < 6.0
+    assert line["serial_order"]["solve_lag_frames"] == 0 and 0 < line["serial_order"]["value"] < 1.2 * line["value"]
+    cs = line["class_surface"]
+    assert cs["deferred_batching"]["value"] > cs["as_the_reference_issues_them"]["value"] > 0 and cs["deferred_batching"]["integrate"] == cs["as_the_reference_issues_them"]["integrate"]
     ls = line["long_stream"]
-    assert ls["frames"] == 2000 and ls["frames_tracked"] == 2000 and ls["ate_optimized_m"] < 0.01
+    assert ls["frames"] == 5000 and ls["frames_tracked"] == 5000 and ls["ate_optimized_m"] < 0.02 and len(ls["per_500_frames"]) == 10
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"]
     sys.path.insert(0, ROOT)
-    from tools.pmc_to_json import update_kernel_sha
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_tsdf_update.json")))["fast"]
-    assert pmc["update_kernel_sha256"] == update_kernel_sha(), "the committed PMC traffic was collected on another version of the voxel-update kernels"
+    from tools.pmc_to_json import update_kernel_sha, build_flags_sha
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_tsdf_update.json")))["fast"]
+    assert pmc["update_kernel_sha256"] == update_kernel_sha(), "the committed PMC figures were collected on another version of the voxel-update kernels"
+    assert pmc["build_flags_sha256"] == build_flags_sha(), "the committed PMC figures were collected on a build with other compiler flags"
     assert abs(pmc["fetch_factor_applied"] - pmc["calibration"]["k_probe_slices"]["fetch_factor"]) < 1e-12 and 2.0 < pmc["fetch_factor_applied"] < 3.0
     assert pmc["fused"]["launches"] > 200 and 12320 < pmc["fused"]["hbm_bytes_per_visited_block"] < 60000
+    assert pmc["sq"]["launches"] > 200 and 2000 < pmc["sq"]["valu_wave_instructions_per_visited_block"] < 20000
 
 
 def test_bench_launches_its_own_ranks_and_refuses_a_mismatched_world():

@@ -325,7 +325,7 @@ def test_stream_5000_vs_oracle_fixture(gpu):
     the product's frame loop exactly as bench.py's `long_stream` block runs it, against the ORACLE frame loop's results for the same stream
     (tests/golden/oracle_stream_5000.npz, written by `tests/golden/make_oracle_stream_2000.py ... 5000 0.3`): every frame tracked on both sides, 499 key frames, the same
     solves and (within 0.1 %) the same scheduled TSDF operations at every 500 frames, |ATE(product) - ATE(oracle)| < 1 mm, every pose within the printed bound."""
-    _stream_vs_oracle_fixture(gpu, "oracle_stream_5000.npz", 5000, "the 5000-frame stream", (1e-2, 5e-3, 5e-3, 5e-3))
+    _stream_vs_oracle_fixture(gpu, "oracle_stream_5000.npz", 5000, "the 5000-frame stream", (1.2e-2, 2.4e-3, 7.5e-3, 1.2e-3))          # twice the measured deviations (5.76e-3 m / 3.62e-3 integrated, 1.16e-3 m / 5.8e-4 optimised: profiles/r06_streams_at_length.txt)
 
 
 def test_replay_1280x960_2mm_reintegration_sweep(gpu, oracle):
