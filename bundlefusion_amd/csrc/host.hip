@@ -1668,10 +1668,28 @@ int obApplyTmSide(bf_online_bundler* ob, uint32_t frame, bool force) {
     return BF_OK;
 }
 
+// diagnostic BF_DEBUG_SOLVE_PROFILE=1: wall time of the chunk job's three stages (each closed by a stream synchronisation), printed when the process ends
+struct SolveProfile {
+    double t[3] = {0, 0, 0}; uint64_t n = 0; bool on = getenv("BF_DEBUG_SOLVE_PROFILE") != nullptr;
+    ~SolveProfile() { if (on && n) fprintf(stderr, "solve job: %llu chunks, local solve %.3f ms, fuse + global matching %.3f ms, global solve %.3f ms per chunk\n", (unsigned long long)n, 1e3 * t[0] / n, 1e3 * t[1] / n, 1e3 * t[2] / n); }
+};
+SolveProfile g_solveProfile;
+
 int obSolves(bf_online_bundler* ob, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {
-    BF_TRY(obOptimizeLocal(ob, nlLocal, linLocal));
-    BF_TRY(obProcessGlobal(ob));
-    return obOptimizeGlobal(ob, nlGlobal, linGlobal);
+    if (!g_solveProfile.on) {
+        BF_TRY(obOptimizeLocal(ob, nlLocal, linLocal));
+        BF_TRY(obProcessGlobal(ob));
+        return obOptimizeGlobal(ob, nlGlobal, linGlobal);
+    }
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    BF_TRY(obOptimizeLocal(ob, nlLocal, linLocal)); (void)hipStreamSynchronize(ob->sSolve);
+    double t1 = now(); g_solveProfile.t[0] += t1 - t0;
+    BF_TRY(obProcessGlobal(ob)); (void)hipStreamSynchronize(ob->sSolve);
+    double t2 = now(); g_solveProfile.t[1] += t2 - t1;
+    const int rc = obOptimizeGlobal(ob, nlGlobal, linGlobal); (void)hipStreamSynchronize(ob->sSolve);
+    g_solveProfile.t[2] += now() - t2; g_solveProfile.n++;
+    return rc;
 }
 
 int obStartJob(bf_online_bundler* ob, uint32_t frame, uint32_t nlLocal, uint32_t linLocal, uint32_t nlGlobal, uint32_t linGlobal) {

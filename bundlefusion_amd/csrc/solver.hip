@@ -1143,22 +1143,29 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
     hipLaunchKernelGGL(k_solve_begin, dim3(1), dim3(64), 0, st, d);
     const bool record = s->cfg.recordConvergence != 0;
     if (record) hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, st, d, wS[0], 0u, 0);
-    bool anyDense = false;
+    bool anyDense = false, prevDense = false;
     for (uint32_t it = 0; it < nNonLin; ++it) {
         c.wSparse = wS[it]; c.wDepth = wDD[it]; c.wColor = wDC[it];
         const int useDense = (d_cache != nullptr) && (c.wDepth > 0.0f || c.wColor > 0.0f);
         anyDense |= useDense != 0;
-        hipLaunchKernelGGL(k_poses, dim3(std::max<uint32_t>(div_up(N, 256), std::min<uint32_t>(div_up((uint32_t)M, 256), 128u))), dim3(256), 0, st, d, (uint32_t)M, useDense);
+        // The block structure (directed key counts, CSR offsets, the keys' correspondence lists) depends on the correspondences and, through the dense pairs, on the
+        // poses.  Without a dense term it is the same in every Gauss-Newton iteration: built in the first, kept afterwards (five launches per iteration fewer in the
+        // global solves: the chunk's solve job costs launches, not kernel time - profiles/r06_loop_schedule.md).
+        const bool reuse = it > 0 && !useDense && !prevDense;
+        prevDense = useDense != 0;
+        hipLaunchKernelGGL(k_poses, dim3(std::max<uint32_t>(div_up(N, 256), std::min<uint32_t>(div_up((uint32_t)M, 256), 128u))), dim3(256), 0, st, d, reuse ? 0u : (uint32_t)M, useDense);
         if (useDense) {
             const dim3 grid = usePairwise ? dim3(N, N) : dim3(N - 1, 1);
             hipLaunchKernelGGL(k_dense_overlap, grid, dim3(512), 0, st, d, c);
         }
-        if (numCorr) hipLaunchKernelGGL(k_key_count, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
-        if (it == 0) hipLaunchKernelGGL(k_row_entries, dim3(div_up(N, 64)), dim3(64), 0, st, d);     // table as of solve start (rebuildJT)
-        hipLaunchKernelGGL(k_scan_rows, dim3(N), dim3(64), 0, st, d, useDense);
-        hipLaunchKernelGGL(k_scan_base, dim3(1), dim3(1024), 0, st, d);
-        hipLaunchKernelGGL(k_scan_fill, dim3(N), dim3(64), 0, st, d, useDense);
-        if (numCorr) hipLaunchKernelGGL(k_fill, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
+        if (!reuse) {
+            if (numCorr) hipLaunchKernelGGL(k_key_count, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
+            if (it == 0) hipLaunchKernelGGL(k_row_entries, dim3(div_up(N, 64)), dim3(64), 0, st, d);     // table as of solve start (rebuildJT)
+            hipLaunchKernelGGL(k_scan_rows, dim3(N), dim3(64), 0, st, d, useDense);
+            hipLaunchKernelGGL(k_scan_base, dim3(1), dim3(1024), 0, st, d);
+            hipLaunchKernelGGL(k_scan_fill, dim3(N), dim3(64), 0, st, d, useDense);
+            if (numCorr) hipLaunchKernelGGL(k_fill, dim3(div_up(numCorr, 256)), dim3(256), 0, st, d);
+        }
         if (useDense) {
             const uint32_t g = std::min<uint32_t>(std::max<uint32_t>(N * (N - 1) / 2, 1u), 1024u);
             hipLaunchKernelGGL(k_dense_weight, dim3(g), dim3(256), 0, st, d, c);
