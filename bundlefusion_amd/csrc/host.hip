@@ -1532,6 +1532,10 @@ int bf_online_bundler_detect_ahead_after(bf_online_bundler* ob, void* ingest_eve
     BF_TRY(bf_image_manager_get_curr_frame_number(ob->im, &frame));
     const int slot = (int)(frame % bf_online_bundler::STAGE);
     BF_REQUIRE(ob->stagedFrame[slot] < 0, "staging slot still holds an uncommitted frame");
+    // The second detection stream is ordered behind the frame's ingest by the ingest event only (and the cache frame then runs on the ingest stream): without an
+    // event - bf_online_bundler_detect_ahead(), or an image manager that shares the detection stream - odd frames would detect beside their own ingest.
+    BF_REQUIRE(ob->detectStream2 == nullptr || (ingest_event != nullptr && ob->im->stream != ob->detectStream2 && ob->im->stream != ob->detectStream),
+               "a second detect stream needs the ingest on a stream of its own and its event (bf_online_bundler_detect_ahead_after)");
     const bool odd = ob->detectStream2 != nullptr && (frame & 1u) != 0u;
     hipStream_t sd = odd ? ob->detectStream2 : ob->detectStream;
     bf_sift* sift = odd ? ob->sift2 : ob->stage->sift;
