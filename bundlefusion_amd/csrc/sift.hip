@@ -65,7 +65,11 @@ enum { CNT_RAW = 0, CNT_FEAT = 1, CNT_LEVEL0 = 2, CNT_LEVEL1 = 16, CNT_ERR = 30,
 // ---------------------------------------------------------------- pyramid
 // fused separable blur: tile 32x32 outputs, (32+2r)x(32+2r) inputs, H pass into LDS then V pass.
 // taps are applied in index order 0..fw-1 like FilterH/FilterV (ProgramCU.cu:159-264), clamp-to-edge.
-__global__ __launch_bounds__(256) void k_blur(BlurJobs jobs, Taps taps) {
+#ifndef BF_VAR_BLUR_THREADS
+#define BF_VAR_BLUR_THREADS 1024
+#endif
+constexpr int BLUR_THREADS = BF_VAR_BLUR_THREADS;     // 16 waves per tile: the three phases are latency chains (11 / 7 / 4 trips of a 256-thread group), the device is otherwise idle
+__global__ __launch_bounds__(BLUR_THREADS) void k_blur(BlurJobs jobs, Taps taps) {
     __shared__ float tileIn[(TILE_H + MAX_FW - 1) * (TILE_W + MAX_FW - 1)];
     __shared__ float tileH[(TILE_H + MAX_FW - 1) * TILE_W];
     int b = blockIdx.x, ji = 0;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void k_blur(BlurJobs jobs, Taps taps) {
     const int tilesX = (job.w + TILE_W - 1) / TILE_W;
     const int x0 = (b % tilesX) * TILE_W, y0 = (b / tilesX) * TILE_H;
     if (job.mode == 1) {          // DownsampleKernel :330-354
-        for (int t = threadIdx.x; t < TILE_W * TILE_H; t += blockDim.x) {
+        for (int t = threadIdx.x; t < TILE_W * TILE_H; t += BLUR_THREADS) {
             const int x = x0 + t % TILE_W, y = y0 + t / TILE_W;
             if (x < job.w && y < job.h) job.dst[(size_t)y * job.w + x] = job.src[(size_t)(y << 1) * job.srcW + min(x << 1, job.srcW - 1)];
         }
@@ -82,14 +86,18 @@ __global__ __launch_bounds__(256) void k_blur(BlurJobs jobs, Taps taps) {
     }
     const int fw = taps.fw[job.filter], half = fw >> 1;
     const float* k = taps.k[job.filter];
-    const int inW = TILE_W + fw - 1, inH = TILE_H + fw - 1;
-    for (int t = threadIdx.x; t < inW * inH; t += blockDim.x) {
-        const int ix = t % inW, iy = t / inW;
-        const int sx = min(max(x0 - half + ix, 0), job.w - 1), sy = min(max(y0 - half + iy, 0), job.h - 1);
-        tileIn[t] = job.src[(size_t)sy * job.w + sx];
+    const int inW = TILE_W + fw - 1, inH = TILE_H + fw - 1;     // <= 64
+    {   // one wave per input row (inW <= 64 columns): no division by a run-time width
+        const int ix = threadIdx.x & 63;
+        const int sx = min(max(x0 - half + ix, 0), job.w - 1);
+        if (ix < inW)
+            for (int iy = threadIdx.x >> 6; iy < inH; iy += BLUR_THREADS / 64) {
+                const int sy = min(max(y0 - half + iy, 0), job.h - 1);
+                tileIn[iy * inW + ix] = job.src[(size_t)sy * job.w + sx];
+            }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < TILE_W * inH; t += blockDim.x) {
+    for (int t = threadIdx.x; t < TILE_W * inH; t += BLUR_THREADS) {
         const int ox = t % TILE_W, iy = t / TILE_W;
         // tileIn column ox+i holds the clamped source column (x0+ox) - half + i
         float v = 0.0f;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void k_blur(BlurJobs jobs, Taps taps) {
         tileH[t] = v;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < TILE_W * TILE_H; t += blockDim.x) {
+    for (int t = threadIdx.x; t < TILE_W * TILE_H; t += BLUR_THREADS) {
         const int ox = t % TILE_W, oy = t / TILE_W;
         const int gx = x0 + ox, gy = y0 + oy;
         if (gx >= job.w || gy >= job.h) continue;
@@ -111,8 +119,8 @@ __global__ __launch_bounds__(256) void k_blur(BlurJobs jobs, Taps taps) {
 // outside the image buffer read 0 like tex1Dfetch
 struct alignas(64) GradJob { const float* g; float* mag; float* ang; int w, h, blocks; };
 struct GradJobs { GradJob j[NKL]; };
-__global__ __launch_bounds__(256) void k_grad(GradJobs jobs) {
-    int b = blockIdx.x, ji = 0;
+__device__ __forceinline__ void gradBlock(const GradJobs& jobs, int b) {
+    int ji = 0;
     while (ji < NKL - 1 && b >= jobs.j[ji].blocks) { b -= jobs.j[ji].blocks; ++ji; }
     const GradJob job = jobs.j[ji];
     const long n = (long)job.w * job.h;
@@ -129,7 +137,10 @@ __global__ __launch_bounds__(256) void k_grad(GradJobs jobs) {
 // ---------------------------------------------------------------- keypoint detection (ComputeKEY_Kernel :616-750)
 struct DetectCfg { int W, H, depthW, depthH; float depthMin, depthMax, dogThreshold, edgeT; int blocks[NKL]; };
 
-__global__ __launch_bounds__(256) void k_detect(Levels lv, DetectCfg c, SiftDev d, const float* __restrict__ depth) {
+// (the gradient blocks ride in the same launch: they read the finished pyramid like the detection does and are independent of it - one dispatch fewer on the
+// detection's queue)
+__global__ __launch_bounds__(256) void k_detect(Levels lv, DetectCfg c, SiftDev d, const float* __restrict__ depth, GradJobs grad, int detectBlocks) {
+    if ((int)blockIdx.x >= detectBlocks) { gradBlock(grad, (int)blockIdx.x - detectBlocks); return; }
     int b = blockIdx.x, li = 0;
     while (li < NKL - 1 && b >= c.blocks[li]) { b -= c.blocks[li]; ++li; }
     const LevelInfo L = lv.l[li];
@@ -626,10 +637,9 @@ int bf_sift_run(bf_sift* s, const float* d_intensity, const float* d_depth, floa
         BlurJobs bj = s->schedule[i];
         int blocks = 0;
         for (int k = 0; k < bj.n; ++k) { if (bj.j[k].src == nullptr) bj.j[k].src = d_intensity; blocks += bj.j[k].blocks; }
-        hipLaunchKernelGGL(k_blur, dim3(blocks), dim3(256), 0, st, bj, s->taps);
+        hipLaunchKernelGGL(k_blur, dim3(blocks), dim3(BLUR_THREADS), 0, st, bj, s->taps);
     }
-    hipLaunchKernelGGL(k_grad, dim3(s->gradBlocks), dim3(256), 0, st, s->gradJobs);
-    hipLaunchKernelGGL(k_detect, dim3(s->detectBlocks), dim3(256), 0, st, s->levels, s->detect, s->d, d_depth);
+    hipLaunchKernelGGL(k_detect, dim3(s->detectBlocks + s->gradBlocks), dim3(256), 0, st, s->levels, s->detect, s->d, d_depth, s->gradJobs, s->detectBlocks);
     hipLaunchKernelGGL(k_keys_finalize, dim3(NKL), dim3(1024), 0, st, s->levels, s->d, s->featureCountThreshold);
     hipLaunchKernelGGL(k_orientation, dim3(2048), dim3(64), 0, st, s->levels, s->d);
     hipLaunchKernelGGL(k_reshape, dim3(1), dim3(1024), 0, st, s->levels, s->d, s->minKeyScale, s->featureCountThreshold, s->maxFeatures);

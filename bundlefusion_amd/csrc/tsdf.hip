@@ -1763,6 +1763,7 @@ struct bf_scene {
     bool batchReady = false;
     uint2* btexel[NBMAX][BF_SCENE_BATCH_MAX] = {}; size_t btexelPixels = 0;      // the batch's frames as texel images, one set per list buffer (the NB in use)
     // diagnostic BF_DEBUG_VERIFY_BATCH=<file> (tsdf_batch.h k_verify_*): two shadow copies of the voxels, the mismatch log in pinned host memory
+    uint32_t updateLds = 0;       // (diagnostic, BF_DEBUG_UPDATE_LDS: unused dynamic LDS per workgroup of the batched fast update = a cap on its workgroups per CU)
     const char* verifyPath = nullptr; bf_voxel* vshadow[2] = {}; VerifyLog* vlog = nullptr; uint32_t vseq = 0;
     // optional HIP-event timing of the voxel-update kernel
     bool timing = false;
@@ -2198,8 +2199,8 @@ int runBatch(bf_scene* s, const bf_scene_batch_op* ops, uint32_t n) {
         }
         const ApxCam ac = makeApxCam(fl);
         auto update = [&](const Dev& dd, int accumulate) {
-            if (s->cvtRne) hipLaunchKernelGGL((k_update_batch_apx<true>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dd, ac, ua, accumulate);
-            else hipLaunchKernelGGL((k_update_batch_apx<false>), dim3(s->gridUpdateCol), dim3(256), 0, s->stream, dd, ac, ua, accumulate);
+            if (s->cvtRne) hipLaunchKernelGGL((k_update_batch_apx<true>), dim3(s->gridUpdateCol), dim3(256), s->updateLds, s->stream, dd, ac, ua, accumulate);
+            else hipLaunchKernelGGL((k_update_batch_apx<false>), dim3(s->gridUpdateCol), dim3(256), s->updateLds, s->stream, dd, ac, ua, accumulate);
         };
         if (s->verifyPath) {
             BF_TRY_RC(verifyBuffers(s));
@@ -2297,6 +2298,7 @@ int bf_scene_create(const bf_hash_params* p, bf_scene** out) {
     s->gridUpdateCol = s->gridUpdateColPlain = 8192;      // see k_update_col
     if (const char* e = getenv("BF_TSDF_EXACT_DIV")) s->forceExactDiv = atoi(e) != 0;
     if (const char* e = getenv("BF_DEBUG_VERIFY_BATCH")) s->verifyPath = e;
+    if (const char* e = getenv("BF_DEBUG_UPDATE_LDS")) s->updateLds = (uint32_t)atoi(e);
     *out = s;
     int rcReset = bf_scene_reset(s);
     if (rcReset != BF_OK) return rcReset;
