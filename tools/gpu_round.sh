@@ -42,7 +42,7 @@ import json; j=json.load(open('$OUT/bench_long_$N.json'))['long_stream']; print(
       for V in "${VARIANTS[@]}"; do
         TAG=$(echo "$V" | tr ' =/' '___' | tail -c 80)
         (cd "$ROOT" && env $V timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-contract --no-sweep --long-stream 0 $BENCH_ARGS > "$OUT/bench_env_$TAG.json" 2> "$OUT/bench_env_$TAG.err"; python -c "
-import json; j=json.load(open('$OUT/bench_env_$TAG.json')); print('$V', round(j['value'],1), 'fps', j['config']['host_thread_ms_per_frame'])"; tail -1 "$OUT/bench_env_$TAG.err")
+import json; j=json.load(open('$OUT/bench_env_$TAG.json')); print('$V', round(j['value'],1), 'fps', 'update', round(j['roofline']['avg_launch_us'],1), 'us', j['config']['host_thread_ms_per_frame'])"; tail -1 "$OUT/bench_env_$TAG.err")
       done ;;
     bench_ab)       # the driver's window with the frame's TSDF operators batched (default) and one at a time: same code, same box
       for B in on off; do
