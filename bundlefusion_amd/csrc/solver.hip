@@ -765,7 +765,7 @@ __global__ __launch_bounds__(1024) void k_pcg(Dev d, uint32_t nLin, uint32_t gnI
 // no second exchange is needed.  The result does not depend on G (row arithmetic is per row, reductions are per 256 threads).
 // Exchanged data and the barrier counter use relaxed agent-scope atomics (sc1 accesses: coherent across the 8 XCD L2s) and an
 // explicit s_waitcnt instead of fences, so no L2 write-back / invalidate disturbs the voxel kernels running beside it.
-constexpr uint32_t COOP_THREADS = 256, COOP_MAX_GROUPS = 64, COOP_ROWS_PER_GROUP = 8, COOP_SPIN_LIMIT = 1u << 22;
+constexpr uint32_t COOP_THREADS = 256, COOP_THREADS_SMALL = 1024, COOP_MAX_GROUPS = 64, COOP_ROWS_PER_GROUP = 8, COOP_SPIN_LIMIT = 1u << 22;
 
 BF_DEV void coopPublish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 BF_DEV float coopRead(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -787,17 +787,21 @@ BF_DEV bool gridBarrier(uint32_t* counter, uint32_t target, int* shFail) {
     return *shFail == 0;
 }
 
+// THREADS: 256; 1024 for ONE workgroup over a small problem (6 N <= 256: every vector element has a thread of its own under both widths and the wave
+// partials beyond the first four are zeros, so the sums - and every bit of the result - are those of the 256-thread form): the row products, one wave per row,
+// take N / 16 instead of N / 4 trips - the single-workgroup solves of a chunk (11 frames) and of the first ~40 key frames are latency chains of 100 - 150 iterations.
 // vecGlobal: the workgroup's private copies of the five vectors and of the row offsets live in global memory (d.coopVec, one region per
 // workgroup, L2-resident) instead of LDS - the form for problems whose vectors do not fit (31 N floats: N > ~1300 key frames; round 2 fell
 // back to ONE workgroup there, 79 us per iteration at N = 2000).  Same arithmetic, same order.
-__global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t gnIter, int lastGN, uint32_t ldsFloats, uint32_t vecGlobal) {
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t gnIter, int lastGN, uint32_t ldsFloats, uint32_t vecGlobal) {
     if (d.flags[FL_DONE]) return;
     extern __shared__ __align__(16) float coopLds[];
     float* const dynLds = coopLds;
     __shared__ float sh[16];
     __shared__ int shFail;
     const uint32_t N = d.N, n6 = 6 * N, G = gridDim.x;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = COOP_THREADS >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = THREADS >> 6;
     const uint32_t vecFloats = (5 * n6 + (N + 1) + 3) & ~3u;
     float* const vec = vecGlobal ? d.coopVec + (size_t)blockIdx.x * vecFloats : dynLds;
     float* const P = vec;
@@ -813,9 +817,9 @@ __global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t
     float* const DG = dynLds + ldsBase;                                        // diagonal blocks of the own rows
     float* const OL = dynLds + ((ldsBase + rpg * 36 + 3) & ~3u);               // off-diagonal blocks (16-byte aligned), then one column index per slot
     if (threadIdx.x == 0) shFail = 0;
-    for (uint32_t t = threadIdx.x; t < n6; t += COOP_THREADS) M[t] = d.prec[t];
-    for (uint32_t t = threadIdx.x; t <= N; t += COOP_THREADS) RS[t] = d.rowStart[t];
-    for (uint32_t t = threadIdx.x; t < (r1 - r0) * 36; t += COOP_THREADS) DG[t] = d.diagA[(size_t)r0 * 36 + t];
+    for (uint32_t t = threadIdx.x; t < n6; t += THREADS) M[t] = d.prec[t];
+    for (uint32_t t = threadIdx.x; t <= N; t += THREADS) RS[t] = d.rowStart[t];
+    for (uint32_t t = threadIdx.x; t < (r1 - r0) * 36; t += THREADS) DG[t] = d.diagA[(size_t)r0 * 36 + t];
     __syncthreads();
     const uint32_t sBase = RS[r0], sEnd = RS[r1];
     const uint32_t ldsSlots = min(sEnd - sBase, (ldsFloats - (uint32_t)(OL - dynLds)) / 37u);
@@ -823,12 +827,12 @@ __global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t
     {
         const float4* src = reinterpret_cast<const float4*>(d.slotO + (size_t)sBase * 36);
         float4* dst = reinterpret_cast<float4*>(OL);
-        for (uint32_t t = threadIdx.x; t < ldsSlots * 9; t += COOP_THREADS) dst[t] = src[t];
-        for (uint32_t t = threadIdx.x; t < ldsSlots; t += COOP_THREADS) CL[t] = d.slotCol[sBase + t];
+        for (uint32_t t = threadIdx.x; t < ldsSlots * 9; t += THREADS) dst[t] = src[t];
+        for (uint32_t t = threadIdx.x; t < ldsSlots; t += THREADS) CL[t] = d.slotCol[sBase + t];
     }
     // Initialization (SolverBundling.cu:755-794): r = -J^T F, p = M^-1 r, delta = 0
     float part = 0.0f;
-    for (uint32_t t = threadIdx.x; t < n6; t += COOP_THREADS) {
+    for (uint32_t t = threadIdx.x; t < n6; t += THREADS) {
         const bool var = t >= 6;
         const float rr = var ? d.rhs[t] : 0.0f;
         const float pp = var ? M[t] * rr : 0.0f;
@@ -879,15 +883,15 @@ __global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t
         part = 0.0f;
         if (G > 1) {
             if (!gridBarrier(counter, G * it, &shFail)) { if (threadIdx.x == 0) d.flags[FL_BARRIER_FAIL] = 1; return; }
-            for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) { const float ap = coopRead(out + t); AP[t] = ap; part += P[t] * ap; }
+            for (uint32_t t = 6 + threadIdx.x; t < n6; t += THREADS) { const float ap = coopRead(out + t); AP[t] = ap; part += P[t] * ap; }
         } else {
             __syncthreads();
-            for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) part += P[t] * AP[t];
+            for (uint32_t t = 6 + threadIdx.x; t < n6; t += THREADS) part += P[t] * AP[t];
         }
         const float pAp = blockSum(part, sh);                                      // PCGStep_Kernel1b
         const float alpha = pAp > FLOAT_EPSILON ? rzOld / pAp : 0.0f;             // PCGStep_Kernel2 :948-983
         part = 0.0f;
-        for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) {           // each thread re-reads its own AP[t]: no barrier needed
+        for (uint32_t t = 6 + threadIdx.x; t < n6; t += THREADS) {           // each thread re-reads its own AP[t]: no barrier needed
             X[t] = X[t] + alpha * P[t];
             const float rr = R[t] - alpha * AP[t];
             R[t] = rr;
@@ -897,14 +901,14 @@ __global__ __launch_bounds__(256) void k_pcg_coop(Dev d, uint32_t nLin, uint32_t
         if (fabsf(pAp) < 5e-7f) last = true;                                      // :1088-1093
         const float beta = rzOld > FLOAT_EPSILON ? rzNew / rzOld : 0.0f;          // PCGStep_Kernel3 :985-1022
         rzOld = rzNew;
-        for (uint32_t t = 6 + threadIdx.x; t < n6; t += COOP_THREADS) P[t] = M[t] * R[t] + beta * P[t];
+        for (uint32_t t = 6 + threadIdx.x; t < n6; t += THREADS) P[t] = M[t] * R[t] + beta * P[t];
         if (last) break;
     }
     if (blockIdx.x != 0) return;
     __syncthreads();
     // Lie update (computeLieUpdate, LieDerivUtil.h:301-307) + GN convergence (EvalGNConvergence :694-749)
     float mx = 0.0f;
-    for (uint32_t i = 1 + threadIdx.x; i < N; i += COOP_THREADS) {
+    for (uint32_t i = 1 + threadIdx.x; i < N; i += THREADS) {
         const f3 dT = ld3(X + 6 * i), dW = ld3(X + 6 * i + 3);
         f3 nw, nt;
         lieUpdate(dW, dT, ld3(d.xRot + 3 * i), ld3(d.xTrans + 3 * i), nw, nt);
@@ -1040,6 +1044,7 @@ struct bf_solver {
     std::vector<void*> allocations;
     std::vector<float> convergence;
     float hMaxRes = 0.0f; int hMaxIdx = 0; int hBarrierFail = 0;
+    bool pcgWide = true;                 // (BF_VAR_PCG_WIDE=0: the 256-thread kernel for every problem, for the A/B)
     int pcgGroups = -1;                  // BF_PCG_GROUPS: -1 automatic, 0 single-workgroup kernel, n forced group count
     uint32_t maxCoopGroups = COOP_MAX_GROUPS;
     bool forceVecGlobal = false;
@@ -1069,7 +1074,9 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
     s->cfg = *cfg;
     s->maxImages = maxNumberOfImages; s->maxResiduals = maxNumResiduals;
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
-    BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
+    BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop<COOP_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
+    BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop<COOP_THREADS_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
+    if (const char* e = getenv("BF_VAR_PCG_WIDE")) s->pcgWide = atoi(e) != 0;
     if (const char* e = getenv("BF_PCG_GROUPS")) s->pcgGroups = atoi(e);        // 0: single-workgroup kernel, n > 0: force n groups
     if (const char* e = getenv("BF_PCG_VEC_GLOBAL")) s->forceVecGlobal = atoi(e) != 0;      // tests: the large-N form (vectors in global memory) on a small problem
     {   // every group of the cooperative PCG must be resident at once (each may take a whole CU's LDS): never ask for more than
@@ -1183,7 +1190,12 @@ int bf_solver_solve(bf_solver* s, bf_entry_j* d_corr, uint32_t numCorr, const in
             const size_t ldsFloats = std::min<size_t>(PCG_LDS_MAX / 4, baseFloats + (size_t)rpg * std::min<uint32_t>(N - 1, 96u) * 37);
             const bool vecFits = !vecGlobal || (size_t)G * (((size_t)31 * N + 1 + 3) & ~(size_t)3) <= s->coopVecFloats;
             if (s->pcgGroups != 0 && nNonLin <= 32 && vecFits && baseFloats + 37 * 8 <= PCG_LDS_MAX / 4)
-                hipLaunchKernelGGL(k_pcg_coop, dim3(G), dim3(COOP_THREADS), ldsFloats * 4, st, d, nLin, it, (int)(it == nNonLin - 1), (uint32_t)ldsFloats, vecGlobal);
+            {
+                if (s->pcgWide && G == 1 && 6 * N <= COOP_THREADS)
+                    hipLaunchKernelGGL(k_pcg_coop<COOP_THREADS_SMALL>, dim3(G), dim3(COOP_THREADS_SMALL), ldsFloats * 4, st, d, nLin, it, (int)(it == nNonLin - 1), (uint32_t)ldsFloats, vecGlobal);
+                else
+                    hipLaunchKernelGGL(k_pcg_coop<COOP_THREADS>, dim3(G), dim3(COOP_THREADS), ldsFloats * 4, st, d, nLin, it, (int)(it == nNonLin - 1), (uint32_t)ldsFloats, vecGlobal);
+            }
             else if ((size_t)N * 124 + 4 <= PCG_LDS_MAX)                              // 5 vectors of 6N floats + N+1 row offsets
                 hipLaunchKernelGGL(k_pcg<true>, dim3(1), dim3(1024), (size_t)N * 124 + 4, st, d, nLin, it, (int)(it == nNonLin - 1));
             else hipLaunchKernelGGL(k_pcg<false>, dim3(1), dim3(1024), 0, st, d, nLin, it, (int)(it == nNonLin - 1));

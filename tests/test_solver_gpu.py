@@ -146,6 +146,26 @@ def test_pcg_result_independent_of_workgroup_count(gpu, oracle, monkeypatch):
     assert dt < 2e-2 and dR < 2e-2
 
 
+@pytest.mark.parametrize("n", [2, 3, 11, 22, 42, 43])
+def test_wide_single_workgroup_pcg_gives_the_bits_of_the_narrow_one(gpu, oracle, monkeypatch, n):
+    """Problems of up to 42 frames (6 N <= 256: a chunk's 11, the first 42 key frames) run the cooperative kernel as ONE workgroup of 1024 threads instead of 256 -
+    one wave per block row in N / 16 instead of N / 4 trips.  Every vector element has a thread of its own under both widths, so the result must not change by a bit
+    (N = 43 takes the 256-thread kernel either way: the switch itself is covered)."""
+    corr, T_gt, T_init = bs.sparse_problem(n_images=n, pair_prob=min(1.0, 8.0 / n), seed=20 + n)
+    rot0, tr0 = oracle.matrices_to_poses(T_init)
+    valid = np.ones(n, np.int32)
+    out = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("BF_VAR_PCG_WIDE", wide)
+        solver = gpu.capi.Solver(max(n, 2), len(corr), default_solver_config(record_convergence=True))
+        grot, gtr = _dev(rot0.copy()), _dev(tr0.copy())
+        solver.solve(_dev(corr.view(np.uint8)), len(corr), _dev(valid), n, 3, 150, None, [1.0] * 3, [0.0] * 3, [0.0] * 3, grot, gtr, find_max_residual=True)
+        out[wide] = (grot.cpu().numpy(), gtr.cpu().numpy(), solver.iteration_counts(), np.array(solver.convergence()), solver.max_residual())
+    monkeypatch.delenv("BF_VAR_PCG_WIDE", raising=False)
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    assert out["1"][2] == out["0"][2] and np.array_equal(out["1"][3], out["0"][3]) and out["1"][4] == out["0"][4]
+
+
 @pytest.mark.parametrize("n", [500, 2000])
 def test_global_solve_at_scale_vs_oracle(gpu, oracle, monkeypatch, n):
     """The global solve at the sizes of the long streams (N <= 500 key frames at 5000 frames, <= 2000 at 20000; SolverBundling.cu:1137-1220 is
