@@ -1044,7 +1044,7 @@ struct bf_solver {
     std::vector<void*> allocations;
     std::vector<float> convergence;
     float hMaxRes = 0.0f; int hMaxIdx = 0; int hBarrierFail = 0;
-    bool pcgWide = true;                 // (BF_VAR_PCG_WIDE=0: the 256-thread kernel for every problem, for the A/B)
+    bool pcgWide = true;                 // (BF_PCG_WIDE=0: the 256-thread kernel for every problem, for the A/B)
     int pcgGroups = -1;                  // BF_PCG_GROUPS: -1 automatic, 0 single-workgroup kernel, n forced group count
     uint32_t maxCoopGroups = COOP_MAX_GROUPS;
     bool forceVecGlobal = false;
@@ -1076,7 +1076,7 @@ int bf_solver_create(uint32_t maxNumberOfImages, uint32_t maxNumResiduals, const
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop<COOP_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
     BF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_coop<COOP_THREADS_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCG_LDS_MAX));
-    if (const char* e = getenv("BF_VAR_PCG_WIDE")) s->pcgWide = atoi(e) != 0;
+    if (const char* e = getenv("BF_PCG_WIDE")) s->pcgWide = atoi(e) != 0;
     if (const char* e = getenv("BF_PCG_GROUPS")) s->pcgGroups = atoi(e);        // 0: single-workgroup kernel, n > 0: force n groups
     if (const char* e = getenv("BF_PCG_VEC_GLOBAL")) s->forceVecGlobal = atoi(e) != 0;      // tests: the large-N form (vectors in global memory) on a small problem
     {   // every group of the cooperative PCG must be resident at once (each may take a whole CU's LDS): never ask for more than

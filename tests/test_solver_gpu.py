@@ -156,12 +156,12 @@ def test_wide_single_workgroup_pcg_gives_the_bits_of_the_narrow_one(gpu, oracle,
     valid = np.ones(n, np.int32)
     out = {}
     for wide in ("1", "0"):
-        monkeypatch.setenv("BF_VAR_PCG_WIDE", wide)
+        monkeypatch.setenv("BF_PCG_WIDE", wide)
         solver = gpu.capi.Solver(max(n, 2), len(corr), default_solver_config(record_convergence=True))
         grot, gtr = _dev(rot0.copy()), _dev(tr0.copy())
         solver.solve(_dev(corr.view(np.uint8)), len(corr), _dev(valid), n, 3, 150, None, [1.0] * 3, [0.0] * 3, [0.0] * 3, grot, gtr, find_max_residual=True)
         out[wide] = (grot.cpu().numpy(), gtr.cpu().numpy(), solver.iteration_counts(), np.array(solver.convergence()), solver.max_residual())
-    monkeypatch.delenv("BF_VAR_PCG_WIDE", raising=False)
+    monkeypatch.delenv("BF_PCG_WIDE", raising=False)
     assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
     assert out["1"][2] == out["0"][2] and np.array_equal(out["1"][3], out["0"][3]) and out["1"][4] == out["0"][4]
 
