@@ -1748,7 +1748,7 @@ struct bf_scene {
     // prep stream had to wait for the update two operators back, and the two cross-stream event hops of ~40 us each sat inside the
     // steady-state cycle: period = hop + (prep + update) / 2, profiles/r02_pipeline_timeline.txt: 44 us idle between consecutive updates.)
     static constexpr int NBMAX = 8;
-    int NB = 4;                     // list buffers in use (BF_SCENE_LIST_BUFFERS, 2 .. NBMAX)
+    int NB = 4;                     // list buffers in use (2 .. NBMAX)
     bf_hash_entry* cbuf[NBMAX] = {}; uint32_t* csrc[NBMAX] = {}; int32_t* ccnt[NBMAX] = {};
     int cur = 0;                    // buffer that holds the latest list (== d.compact / d.compactSrc / d.compactCount)
     hipEvent_t evPrep[NBMAX] = {}, evUpd[NBMAX] = {}, evBarrier = nullptr, evTmp = nullptr;
