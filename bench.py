@@ -315,6 +315,15 @@ def main():
                                     "frac": vi[1] / simd_cycles if simd_cycles > 0 else None,                    # measured: SQ_ACTIVE_INST_VALU (x 4 cycles) per visited block x blocks visited here
                                     "frac_at_2_cycles_per_instruction": 2.0 * vi[0] / simd_cycles if simd_cycles > 0 else None,      # the guide's full-rate issue cost: a lower bound
                                     "unit": "share of the vector-issue cycles of the SIMDs the launch may use"}
+        # ... and the other unit the kernel keeps busy: every CU's vector-memory return path (16 divergent 8-byte texel gathers per block and operator slot, ~19 L1
+        # accesses each).  From the TD / TCP passes of the same PMC file: busy cycles per visited block x the blocks visited here, over launch time x clock x CUs.
+        mp = pmc_mem(args, L["arith"], L["vis_fused"], n_launch) if batched else None
+        cus = simds // 4
+        mem_pipe = None if not mp else {"td_busy_cycles_per_launch": mp["td_busy_cycles_per_launch"], "compute_units": cus,
+                                        "td_busy_frac": mp["td_busy_cycles_per_launch"] / (avg_kernel_s * CLOCK_HZ * cus) if avg_kernel_s > 0 else None,
+                                        "td_busy_frac_in_the_pmc_run": mp["td_busy_share_of_cu_cycles"], "td_stalled_on_l1_frac_in_the_pmc_run": mp["td_stalled_on_l1_share_of_cu_cycles"],
+                                        "l1_accesses_per_vmem_instruction": mp["l1_accesses_per_vmem_instruction"],
+                                        "unit": "share of the cycles of the CUs the launch may use during which the texture-data unit (vector-memory return path) is busy"}
         if batched:
             kern = ("k_update_batch_apx (tsdf_batch.h): one wave per block of the batch's union list, voxels loaded once, the batch's operators applied in order from registers"
                     if L["arith"] == "fast" else "k_update_batch_col (tsdf_batch.h): the batch's operators one after the other per block, exact contract")
@@ -326,7 +335,7 @@ def main():
             # `bound`: what limits the kernel.  achieved / peak / frac stay the HBM figures of the contract (algorithmic bytes over launch time against 8 TB/s); for
             # the VALU-bound batched update they say how far the kernel is from the byte roofline it no longer touches, `valu` how close to the one it does.
             "bound": "valu" if (batched and L["arith"] == "fast") else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu, "mem_pipe": mem_pipe,
             "achieved_per_operator": achieved_op, "frac_per_operator": achieved_op / HBM_PEAK_GBS,
             "hbm_frac_measured": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_kernel_s > 0) else None,
             "launches": n_launch, "operators": n_ops, "frames_sampled": n_img, "avg_launch_us": 1e6 * avg_kernel_s,
@@ -649,6 +658,22 @@ def pmc_valu(args, arith, vis_fused, n_launch):
     if pmc.get("update_kernel_sha256") != update_kernel_sha() or pmc.get("build_flags_sha256") != build_flags_sha():
         return None
     return (vis_fused * pmc["sq"]["valu_wave_instructions_per_visited_block"] / n_launch, vis_fused * pmc["sq"].get("valu_active_cycles_per_visited_block", 0.0) / n_launch)
+
+
+def pmc_mem(args, arith, vis_fused, n_launch):
+    """The vector-memory return path of the batched update, from the TD / TCP / VMEM passes of the same committed PMC file; None under the same conditions as pmc_traffic."""
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
+    if not os.path.exists(path) or n_launch == 0:
+        return None
+    pmc = json.load(open(path)).get(arith)
+    if not pmc or pmc["config"] != pmc_config(args) or "mem_pipe" not in pmc:
+        return None
+    from tools.pmc_to_json import update_kernel_sha, build_flags_sha
+    if pmc.get("update_kernel_sha256") != update_kernel_sha() or pmc.get("build_flags_sha256") != build_flags_sha():
+        return None
+    m = dict(pmc["mem_pipe"])
+    m["td_busy_cycles_per_launch"] = vis_fused * m["td_busy_cycles_per_visited_block"] / n_launch
+    return m
 
 
 def cpu_baseline(frames, feed, params, K, W, H, arith):

@@ -65,7 +65,12 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
         done
         rm -rf /tmp/r_pmc_SQ          # third pass: the vector instructions the update issues and its busy cycles (the kernel is VALU-bound: VERDICT round 5)
         (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d /tmp/r_pmc_SQ -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_SQ.json > /dev/null 2>&1)
-        python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A "${PMC_CAL:-$ROOT/profiles/r06_pmc_calibration.json}" "$(db /tmp/r_pmc_SQ)"
+        rm -rf /tmp/r_pmc_TD /tmp/r_pmc_VM     # fourth and fifth pass: the vector-memory return path (texture-data unit busy / stalled on the L1, L1 accesses) and the memory instruction counts
+        if [ "$A" = fast ]; then
+        (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc TD_TD_BUSY_sum TD_TC_STALL_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE -d /tmp/r_pmc_TD -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_TD.json > /dev/null 2>&1)
+        (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM -d /tmp/r_pmc_VM -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --steps 20 --warmup 5 --one-contract --arith $A $BENCH_ARGS --pmc-out /tmp/acc_VM.json > /dev/null 2>&1)
+        fi
+        python "$ROOT/tools/pmc_to_json.py" "$(db /tmp/r_pmc_FETCH_SIZE)" "$(db /tmp/r_pmc_WRITE_SIZE)" /tmp/acc_FETCH_SIZE.json "$OUT/pmc_tsdf_update.json" "$OUT/pmc_tsdf_update.md" $A "${PMC_CAL:-$ROOT/profiles/r06_pmc_calibration.json}" "$(db /tmp/r_pmc_SQ)" "$(db /tmp/r_pmc_TD)" "$(db /tmp/r_pmc_VM)"
       done ;;
     pltrace)    # the frame loop's own per-frame trace (BF_PIPELINE_TRACE): host enqueue / wait times and the GPU times of detection end, chain begin / end, untraced otherwise
       rm -f "$OUT/pltrace.txt"
@@ -130,6 +135,15 @@ import json; j=json.load(open('$OUT/bench_batching_$B.json')); r=j['roofline']; 
         i=$((i+1)); rm -rf /tmp/r_sw
         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_sw -o run -- python "$ROOT/tools/tsdf_sweep.py" $SWEEP_ARGS > /dev/null 2>&1)
         python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_sw)" "${PMC_FILTER:-update}" | grep '^|' > "$OUT/sweep_pmc_pass$i.txt"; tail -3 "$OUT/sweep_pmc_pass$i.txt" | cut -c1-200
+      done ;;
+    bench_pmc_extra)   # the batched update's memory-pipeline counters in the bench configuration (own passes, --kernel-trace only): texture-data busy / stalls, L1 accesses, VMEM instruction counts, L2 hits
+      i=0
+      for C in "TD_TD_BUSY_sum TD_TC_STALL_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE" \
+               "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_WAVE_CYCLES" \
+               "SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_CYCLES TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+        i=$((i+1)); rm -rf /tmp/r_bx
+        (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/r_bx -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-sweep --long-stream 0 --no-class-surface --steps 20 --warmup 5 --one-contract $BENCH_ARGS > /dev/null 2>&1)
+        python "$ROOT/tools/rocpd_pmc.py" "$(db /tmp/r_bx)" "k_update_batch" | grep '^|' > "$OUT/bench_pmc_extra_pass$i.txt"; cat "$OUT/bench_pmc_extra_pass$i.txt" | cut -c1-220
       done ;;
     clocks)
       (rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|Temp" | head -12 | tee -a "$OUT/clocks.txt") ;;

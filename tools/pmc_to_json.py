@@ -86,6 +86,24 @@ def main():
                      "valu_wave_instructions_per_visited_block": sq.get("SQ_INSTS_VALU", [0, 0.0])[1] / max(vis["fused"], 1),
                      "valu_active_cycles_per_visited_block": 4.0 * sq.get("SQ_ACTIVE_INST_VALU", [0, 0.0])[1] / max(vis["fused"], 1),      # (the counter is in units of 4 cycles)
                      "note": "SQ_INSTS_VALU counts wave-instructions; the cycle counters are in units of 4 cycles (MI355X_MICROARCH.md: SQ)"}
+    mem, memtot = {}, {}
+    for a in sys.argv[9:11]:          # the memory-pipeline passes (TD_* / TCP_* / GRBM_GUI_ACTIVE, SQ_INSTS_VMEM_* ...) of the same command, when given
+        if os.path.exists(a):
+            for k, v in sq_totals(a).items():
+                mem[k] = v[1] / max(v[0], 1); memtot[k] = v[1]
+    if mem:
+        cus = 256 - max(0, min(int(os.environ.get("BF_VOLUME_CU_RESERVE", "32")), 255))      # the volume stream's CU mask (bf_pipeline_create)
+        dev_cycles = mem.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                                    # summed over the 8 XCDs
+        vmem = mem.get("SQ_INSTS_VMEM_RD", 0.0) + mem.get("SQ_INSTS_VMEM_WR", 0.0)
+        share = (lambda name: mem.get(name, 0.0) / (dev_cycles * cus) if dev_cycles > 0 else None)
+        res["mem_pipe"] = {"per_launch": mem, "compute_units": cus, "device_cycles_per_launch": dev_cycles,
+                           "td_busy_share_of_cu_cycles": share("TD_TD_BUSY_sum"), "td_stalled_on_l1_share_of_cu_cycles": share("TD_TC_STALL_sum"),
+                           "l1_accesses_per_cu_cycle": share("TCP_TOTAL_CACHE_ACCESSES_sum"),
+                           "l1_accesses_per_vmem_instruction": mem.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / vmem if vmem > 0 else None,
+                           "td_busy_cycles_per_visited_block": memtot.get("TD_TD_BUSY_sum", 0.0) / max(vis["fused"], 1),
+                           "vmem_wave_instructions_per_visited_block": (memtot.get("SQ_INSTS_VMEM_RD", 0.0) + memtot.get("SQ_INSTS_VMEM_WR", 0.0)) / max(vis["fused"], 1),
+                           "note": "TD_*: the texture-data (vector-memory return) unit of every CU, cycles summed over the CUs; the shares are over the CUs the masked volume stream may use "
+                                   "and the device cycles of the same pass (GRBM_GUI_ACTIVE / 8 XCDs)"}
     allres = json.load(open(outp)) if os.path.exists(outp) else {}
     res["update_kernel_sha256"] = update_kernel_sha()
     res["build_flags_sha256"] = build_flags_sha()
