@@ -314,6 +314,9 @@ def main():
                                     "simds": simds, "simd_cycles_available_per_launch": simd_cycles,
                                     "frac": vi[1] / simd_cycles if simd_cycles > 0 else None,                    # measured: SQ_ACTIVE_INST_VALU (x 4 cycles) per visited block x blocks visited here
                                     "frac_at_2_cycles_per_instruction": 2.0 * vi[0] / simd_cycles if simd_cycles > 0 else None,      # the guide's full-rate issue cost: a lower bound
+                                    # the same share inside the PMC run itself (all its launches, its own device cycles: GRBM_GUI_ACTIVE / 8 XCDs of the TD pass) - free of the
+                                    # per-visited-block scaling above, which spreads the run's instructions evenly over blocks although the window's blocks carry more operators
+                                    "frac_in_the_pmc_run": vi[2],
                                     "unit": "share of the vector-issue cycles of the SIMDs the launch may use"}
         # ... and the other unit the kernel keeps busy: every CU's vector-memory return path (16 divergent 8-byte texel gathers per block and operator slot, ~19 L1
         # accesses each).  From the TD / TCP passes of the same PMC file: busy cycles per visited block x the blocks visited here, over launch time x clock x CUs.
@@ -657,7 +660,11 @@ def pmc_valu(args, arith, vis_fused, n_launch):
     from tools.pmc_to_json import update_kernel_sha, build_flags_sha
     if pmc.get("update_kernel_sha256") != update_kernel_sha() or pmc.get("build_flags_sha256") != build_flags_sha():
         return None
-    return (vis_fused * pmc["sq"]["valu_wave_instructions_per_visited_block"] / n_launch, vis_fused * pmc["sq"].get("valu_active_cycles_per_visited_block", 0.0) / n_launch)
+    mp = pmc.get("mem_pipe")
+    in_run = None
+    if mp and mp.get("device_cycles_per_launch"):
+        in_run = 4.0 * pmc["sq"]["per_launch"]["SQ_ACTIVE_INST_VALU"] / (mp["device_cycles_per_launch"] * 4.0 * mp["compute_units"])
+    return (vis_fused * pmc["sq"]["valu_wave_instructions_per_visited_block"] / n_launch, vis_fused * pmc["sq"].get("valu_active_cycles_per_visited_block", 0.0) / n_launch, in_run)
 
 
 def pmc_mem(args, arith, vis_fused, n_launch):

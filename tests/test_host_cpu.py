@@ -433,6 +433,13 @@ def test_round6_bench_line_and_pmc_file_are_consistent():
     assert abs(pmc["fetch_factor_applied"] - pmc["calibration"]["k_probe_slices"]["fetch_factor"]) < 1e-12 and 2.0 < pmc["fetch_factor_applied"] < 3.0
     assert pmc["fused"]["launches"] > 200 and 12320 < pmc["fused"]["hbm_bytes_per_visited_block"] < 60000
     assert pmc["sq"]["launches"] > 200 and 2000 < pmc["sq"]["valu_wave_instructions_per_visited_block"] < 20000
+    # the vector-memory return path (TD / TCP / VMEM passes of the same file) and its figure in the bench line
+    mp = pmc["mem_pipe"]
+    assert mp["compute_units"] == 224 and 0.3 < mp["td_busy_share_of_cu_cycles"] <= 1.0 and mp["td_stalled_on_l1_share_of_cu_cycles"] < mp["td_busy_share_of_cu_cycles"]
+    assert 4.0 < mp["l1_accesses_per_vmem_instruction"] < 64.0 and 50 < mp["vmem_wave_instructions_per_visited_block"] < 500
+    m = r["mem_pipe"]
+    assert m is not None and 0.2 < m["td_busy_frac"] <= 1.0 and abs(m["td_busy_frac_in_the_pmc_run"] - mp["td_busy_share_of_cu_cycles"]) < 1e-9
+    assert 0.3 < v["frac_in_the_pmc_run"] <= 1.05 and v["frac_in_the_pmc_run"] > v["frac_at_2_cycles_per_instruction"]
 
 
 def test_bench_launches_its_own_ranks_and_refuses_a_mismatched_world():
