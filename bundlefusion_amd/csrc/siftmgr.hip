@@ -379,23 +379,7 @@ BF_DEV m44 kabschFromMoments(const float* V, f3 p0, f3 q0, f3& evs) {
     return ret;
 }
 
-BF_DEV m44 kabsch(const f3* src, const f3* tgt, unsigned n, f3& evs) {       // cuda_kabsch.h:73-211
-    f3 p0 = mk3(0, 0, 0), q0 = mk3(0, 0, 0);
-    for (unsigned i = 0; i < n; ++i) { p0 = p0 + src[i]; q0 = q0 + tgt[i]; }
-    p0 = p0 / (float)n; q0 = q0 / (float)n;
-    float V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (unsigned i = 0; i < n; ++i) {
-        const f3 p = src[i] - p0, q = tgt[i] - q0;
-        const float pv[3] = {p.x, p.y, p.z}, qv[3] = {q.x, q.y, q.z};
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) V[r * 3 + c] += pv[r] * qv[c];
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) V[i] /= (float)n;
-    return kabschFromMoments(V, p0, q0, evs);
-}
+// (kabsch(), cuda_kabsch.h:73-110 - centroids, cross-covariance - is spread over the lanes of computeReprojection below; what follows the sums is kabschFromMoments above)
 
 BF_DEV f3 covarianceEig(const f3* pts, unsigned n) {
     f3 p0 = mk3(0, 0, 0);
@@ -426,7 +410,7 @@ template <class T> BF_DEV void swp(T& a, T& b) { const T t = a; a = b; b = t; }
 //   lanes 0 and 1   covariance eigenvalues of the (sorted) source / target points
 // (Measured and withdrawn in round 4, gpurun r04a: the accumulation loops of the fit and of the two covariance solves spread one sum per lane, bit-identical -
 // 244 vs 259 us per launch, no change at the frame level: the time is in the dependent SVD / eigenvalue chains, not in the sums.)
-struct ReprojShared { m44 T; float ev[3]; float cond[2]; };
+struct ReprojShared { m44 T; float ev[3]; float cond[2]; float mom[15]; };      // mom: the fit's centroids (6) and cross-covariance (9), one lane each
 
 // The verdict of ComputeReprojection (:404-418): condition numbers of the fit and of the two point sets, on the state the last computeReprojection left behind.
 // Round 5: evaluated only where the greedy filter READS it (the end of the walk, and the two places of the removal loop) - the reference computes the two
@@ -441,9 +425,33 @@ __device__ __noinline__ bool reprojectionValid(uint32_t lane, const f3* src, con
 }
 
 __device__ __noinline__ void computeReprojection(uint32_t lane, f3* src, f3* tgt, unsigned n, float* res, Sel* sel, ReprojShared* sh) {
+    // kabsch() with its fifteen accumulation loops on fifteen lanes: every sum is the same sequential chain over i = 0 .. n - 1 (the operations of the loops in
+    // kabsch(), cuda_kabsch.h:73-110, component by component), only no longer one after the other on lane 0 - a quarter of a fit's instructions at n = 14.
+    // (Round 4 measured this form at 244 vs 259 us per launch when the two covariance eigen-solves still ran after every fit; they no longer do.)
+    {
+        const float* sf = reinterpret_cast<const float*>(src); const float* tf = reinterpret_cast<const float*>(tgt);
+        if (lane < 6) {
+            const float* b = (lane < 3 ? sf : tf) + (lane % 3u);
+            float acc = 0.0f;
+            for (unsigned i = 0; i < n; ++i) acc = acc + b[3 * i];
+            sh->mom[lane] = acc / (float)n;
+        }
+        __syncthreads();
+        if (lane < 9) {
+            const unsigned r = lane / 3u, c = lane % 3u;
+            const float p0 = sh->mom[r], q0 = sh->mom[3 + c];
+            float acc = 0.0f;
+            for (unsigned i = 0; i < n; ++i) { const float pr = sf[3 * i + r] - p0, qc = tf[3 * i + c] - q0; acc += pr * qc; }
+            sh->mom[6 + lane] = acc / (float)n;
+        }
+        __syncthreads();
+    }
     if (lane == 0) {
         f3 ev;
-        sh->T = kabsch(src, tgt, n, ev);
+        float V[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) V[i] = sh->mom[6 + i];
+        sh->T = kabschFromMoments(V, mk3(sh->mom[0], sh->mom[1], sh->mom[2]), mk3(sh->mom[3], sh->mom[4], sh->mom[5]), ev);
         sh->ev[0] = ev.x; sh->ev[1] = ev.y; sh->ev[2] = ev.z;
     }
     __syncthreads();
