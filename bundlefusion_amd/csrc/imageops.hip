@@ -29,75 +29,45 @@ Taps makeTaps(float sigma, int r) {
     return t;
 }
 
-// The two window filters of the ingest over a 64 x 16 output tile per workgroup (threads 64 x 4, four rows each) with the tile and its halo staged in LDS once -
-// round 6; before, every output pixel walked its (2s+1)^2 window through the L1 with four bounds tests per tap (33 / 48 us per 640x480 image).  Out-of-image
-// positions hold a value the tap test rejects by itself (erosion: NaN - equal to nothing, |d - old| > t false; depth filter: -inf, the reference's own "invalid"),
-// so the counted / summed taps and their order are the reference's.
-constexpr int WF_W = 64, WF_H = 16, WF_MAXR = MAX_R;
-constexpr int WF_TILE = (WF_W + 2 * WF_MAXR) * (WF_H + 2 * WF_MAXR);
-BF_DEV void stageTile(float* tile, const float* __restrict__ in, int x0, int y0, int r, int w, int h, float outside) {
-    const int tw = WF_W + 2 * r, th = WF_H + 2 * r, tid = (int)(threadIdx.y * 64 + threadIdx.x);
-    for (int ty = tid >> 6; ty < th; ty += 4) {
-        const int gy = y0 - r + ty;
-        for (int tx = tid & 63; tx < tw; tx += 64) {
-            const int gx = x0 - r + tx;
-            tile[ty * tw + tx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? in[(size_t)gy * w + gx] : outside;
-        }
-    }
-    __syncthreads();
-}
-
 // csrc / cdst1 / cdst2 (optional): a pixel-wise copy of a 4-byte-per-pixel image of the same size riding along (the ingest's colour copies: one launch less per copy)
 __global__ __launch_bounds__(256) void k_erode(float* __restrict__ out, const float* __restrict__ in, int s, int w, int h, float dThresh, float fracReq,
                                                const uint32_t* __restrict__ csrc, uint32_t* __restrict__ cdst1, uint32_t* __restrict__ cdst2) {
-    __shared__ float tile[WF_TILE];
-    const int x0 = (int)blockIdx.x * WF_W, y0 = (int)blockIdx.y * WF_H, tw = WF_W + 2 * s;
-    stageTile(tile, in, x0, y0, s, w, h, __builtin_nanf(""));
-    const unsigned sum = (2 * s + 1) * (2 * s + 1);
-    const int lx = (int)threadIdx.x, x = x0 + lx;
-    if (x >= w) return;
-    for (int ly = (int)threadIdx.y; ly < WF_H; ly += 4) {
-        const int y = y0 + ly;
-        if (y >= h) break;
-        if (csrc) { const uint32_t c = csrc[y * w + x]; if (cdst1) cdst1[y * w + x] = c; if (cdst2) cdst2[y * w + x] = c; }
-        unsigned count = 0;
-        const float old = tile[(ly + s) * tw + lx + s];
-        for (int i = 0; i <= 2 * s; ++i)
-            for (int j = 0; j <= 2 * s; ++j) {
-                const float d = tile[(ly + i) * tw + lx + j];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    if (csrc) { const uint32_t c = csrc[y * w + x]; if (cdst1) cdst1[y * w + x] = c; if (cdst2) cdst2[y * w + x] = c; }
+    unsigned count = 0;
+    const float old = in[y * w + x];
+    for (int i = -s; i <= s; ++i)
+        for (int j = -s; j <= s; ++j)
+            if (x + j >= 0 && x + j < w && y + i >= 0 && y + i < h) {
+                const float d = in[(y + i) * w + (x + j)];
                 if (d == BF_MINF || d == 0.0f || fabsf(d - old) > dThresh) count++;
             }
-        out[y * w + x] = ((float)count / (float)sum >= fracReq) ? BF_MINF : old;
-    }
+    const unsigned sum = (2 * s + 1) * (2 * s + 1);
+    out[y * w + x] = ((float)count / (float)sum >= fracReq) ? BF_MINF : old;
 }
 
 // out2 (optional): a second copy of the result (the ingest's stored frame)
 __global__ __launch_bounds__(256) void k_gauss_depth(float* __restrict__ out, const float* __restrict__ in, Taps t, float sigmaR, int w, int h, float* __restrict__ out2) {
-    __shared__ float tile[WF_TILE];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
     const int r = t.r, n = 2 * r + 1;
-    const int x0 = (int)blockIdx.x * WF_W, y0 = (int)blockIdx.y * WF_H, tw = WF_W + 2 * r;
-    stageTile(tile, in, x0, y0, r, w, h, BF_MINF);
-    const int lx = (int)threadIdx.x, x = x0 + lx;
-    if (x >= w) return;
-    for (int ly = (int)threadIdx.y; ly < WF_H; ly += 4) {
-        const int y = y0 + ly;
-        if (y >= h) break;
-        float sum = 0.0f, sumW = 0.0f, res = BF_MINF;
-        const float c = tile[(ly + r) * tw + lx + r];
-        if (c != BF_MINF)
-            for (int m = 0; m < n; ++m)            // (m, k): the reference's order - columns outside, rows inside
-                for (int k = 0; k < n; ++k) {
-                    const float d = tile[(ly + k) * tw + lx + m];
+    float sum = 0.0f, sumW = 0.0f, res = BF_MINF;
+    const float c = in[y * w + x];
+    if (c != BF_MINF)
+        for (int m = x - r; m <= x + r; ++m)
+            for (int k = y - r; k <= y + r; ++k)
+                if (m >= 0 && k >= 0 && m < w && k < h) {
+                    const float d = in[k * w + m];
                     if (d != BF_MINF && fabsf(c - d) < sigmaR) {
-                        const float wt = t.w[m * n + k];
+                        const float wt = t.w[(m - x + r) * n + (k - y + r)];
                         sumW += wt;
                         sum += wt * d;
                     }
                 }
-        if (sumW > 0.0f) res = sum / sumW;
-        out[y * w + x] = res;
-        if (out2) out2[y * w + x] = res;
-    }
+    if (sumW > 0.0f) res = sum / sumW;
+    out[y * w + x] = res;
+    if (out2) out2[y * w + x] = res;
 }
 
 __global__ __launch_bounds__(256) void k_gauss_intensity(float* __restrict__ out, const float* __restrict__ in, Taps t, int w, int h) {
@@ -142,7 +112,6 @@ __global__ __launch_bounds__(256) void k_resample_intensity(float* __restrict__ 
 }
 
 inline dim3 grid2(uint32_t w, uint32_t h) { return dim3(div_up(w, 64), div_up(h, 4)); }
-inline dim3 gridWF(uint32_t w, uint32_t h) { return dim3(div_up(w, (uint32_t)WF_W), div_up(h, (uint32_t)WF_H)); }
 
 }  // namespace
 
@@ -150,8 +119,8 @@ extern "C" {
 
 int bf_image_erode_depth_map(float* d_output, const float* d_input, int structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq,
                              void* stream) {
-    BF_REQUIRE(d_output && d_input && d_output != d_input && structureSize >= 0 && structureSize <= WF_MAXR && width && height, "bad argument (structure size 0 .. 8)");
-    k_erode<<<gridWF(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq, nullptr, nullptr, nullptr);
+    BF_REQUIRE(d_output && d_input && d_output != d_input && structureSize >= 0 && width && height, "bad argument");
+    k_erode<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq, nullptr, nullptr, nullptr);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -160,8 +129,8 @@ int bf_image_erode_depth_map(float* d_output, const float* d_input, int structur
 // CUDAImageManager::process does with three launches (CUDAImageManager.cpp:39-60, :66-86) when the frame already lives in device memory.
 int bf_image_erode_depth_map_and_copy(float* d_output, const float* d_input, int structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq,
                                       const void* d_copySrc, void* d_copyDst1, void* d_copyDst2, void* stream) {
-    BF_REQUIRE(d_output && d_input && d_output != d_input && structureSize >= 0 && structureSize <= WF_MAXR && width && height && d_copySrc && d_copyDst1, "bad argument (structure size 0 .. 8)");
-    k_erode<<<gridWF(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq,
+    BF_REQUIRE(d_output && d_input && d_output != d_input && structureSize >= 0 && width && height && d_copySrc && d_copyDst1, "bad argument");
+    k_erode<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq,
                                                                            (const uint32_t*)d_copySrc, (uint32_t*)d_copyDst1, (uint32_t*)d_copyDst2);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -171,7 +140,7 @@ int bf_image_gauss_filter_depth_map(float* d_output, const float* d_input, float
     BF_REQUIRE(d_output && d_input && d_output != d_input && width && height, "bad argument");
     const int r = (int)ceil(2.0 * sigmaD);
     BF_REQUIRE(r >= 0 && r <= MAX_R, "sigmaD too large (kernel radius > 8)");
-    k_gauss_depth<<<gridWF(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, makeTaps(sigmaD, r), sigmaR, (int)width, (int)height, nullptr);
+    k_gauss_depth<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, makeTaps(sigmaD, r), sigmaR, (int)width, (int)height, nullptr);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -181,7 +150,7 @@ int bf_image_gauss_filter_depth_map2(float* d_output, float* d_output2, const fl
     BF_REQUIRE(d_output && d_output2 && d_input && d_output != d_input && d_output2 != d_input && width && height, "bad argument");
     const int r = (int)ceil(2.0 * sigmaD);
     BF_REQUIRE(r >= 0 && r <= MAX_R, "sigmaD too large (kernel radius > 8)");
-    k_gauss_depth<<<gridWF(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, makeTaps(sigmaD, r), sigmaR, (int)width, (int)height, d_output2);
+    k_gauss_depth<<<grid2(width, height), dim3(64, 4), 0, (hipStream_t)stream>>>(d_output, d_input, makeTaps(sigmaD, r), sigmaR, (int)width, (int)height, d_output2);
     BF_HIP_TRY(hipGetLastError());
     return BF_OK;
 }

@@ -539,7 +539,7 @@ BF_API int bf_siftmgr_fuse_error(bf_siftmgr* local, int* err);
 /* Frame-ingest image operators:  CUDAImageUtil.h / CUDAImageUtil.cu          */
 /* (device pointers, asynchronous on hip_stream)                              */
 /* ------------------------------------------------------------------------- */
-/* erodeDepthMap(d_output, d_input, structureSize, w, h, dThresh, fracReq)     CUDAImageUtil.cu:701-757   (structureSize 0 .. 8: the window is staged in LDS; the reference uses 3) */
+/* erodeDepthMap(d_output, d_input, structureSize, w, h, dThresh, fracReq)     CUDAImageUtil.cu:701-757 */
 BF_API int bf_image_erode_depth_map(float* d_output, const float* d_input, int structureSize, uint32_t width, uint32_t height,
                                     float dThresh, float fracReq, void* hip_stream);
 /* gaussFilterDepthMap(d_output, d_input, sigmaD, sigmaR, w, h)                :759-809 */
